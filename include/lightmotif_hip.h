@@ -1,0 +1,260 @@
+/*
+ * lightmotif_hip.h -- C ABI of the MI355X (gfx950) scoring back-end.
+ *
+ * This is the drop-in boundary for ONE hot path of althonos/lightmotif:
+ *
+ *     pssm.score(&striped)  ->  StripedScores  ->  argmax / max / threshold
+ *
+ * The reference has no FFI; its boundary is the trait surface
+ * `Score` / `Maximum` / `Threshold` (+ `Stripe`, `Encode`) of
+ * lightmotif/src/pli/mod.rs:34-222, implemented per back-end marker and fanned
+ * out by `enum Dispatch` (lightmotif/src/pli/dispatch.rs:33-41).  A new
+ * `Dispatch::Hip` arm (dispatch.rs:90-106, 160-177) -- or an out-of-crate type
+ * implementing the public traits -- forwards raw pointers and dimensions to
+ * the functions below (INTEGRATION.md has the Rust shim).  Every entry point
+ * names the reference function it stands in for.
+ *
+ * Conventions
+ *  - plain C types only; no C++ exceptions cross the boundary;
+ *  - every function returns an `lm_hip_status`; `lm_hip_last_error()` gives the
+ *    thread-local message of the last failure.  The reference's trait methods
+ *    return ()/Option and *panic* on misuse (avx2.rs:832-837, 354-358); the shim
+ *    turns a non-zero status into `panic!`.  Degenerate inputs are NOT errors:
+ *    L < M or an empty row range gives zero rows (pli/mod.rs:85-88), empty
+ *    scores give found = 0 (pli/mod.rs:136-138);
+ *  - memory layout is the reference's: striped sequence
+ *    (rows+wrap) x stride bytes, PSSM M x stride f32 (stride 8 for DNA, 24 for
+ *    protein), scores rows x stride f32, all row-major, `stride` in ELEMENTS
+ *    (DenseMatrix::stride, dense.rs:126-128);
+ *  - `*_dptr` functions take DEVICE pointers and enqueue on the context's
+ *    stream; results that come back to the host (argmax, threshold, counts)
+ *    synchronise that stream before returning.  Host-pointer functions are
+ *    fully synchronous (the GPU analogue of the `_mm_sfence` at avx2.rs:198);
+ *  - all entry points are thread-safe; a context serialises its own calls.
+ */
+#ifndef LIGHTMOTIF_HIP_H
+#define LIGHTMOTIF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LM_HIP_ABI_VERSION 1
+
+typedef enum lm_hip_status {
+    LM_HIP_OK = 0,
+    LM_HIP_ERR_BAD_ARGS = 1,    /* null pointer, stride < cols, rows out of range ... */
+    LM_HIP_ERR_WRAP = 2,        /* "not enough wrapping rows for motif of length M" (avx2.rs:832-837) */
+    LM_HIP_ERR_HIP = 3,         /* a HIP runtime call failed */
+    LM_HIP_ERR_OOM = 4,         /* host or device allocation failed */
+    LM_HIP_ERR_NO_DEVICE = 5,   /* no gfx950 device: maps to UnsupportedBackend (err.rs:34) */
+    LM_HIP_ERR_INVALID_SYMBOL = 6, /* Encode: InvalidSymbol (err.rs:10) */
+    LM_HIP_ERR_CAPACITY = 7     /* caller-provided output buffer too small */
+} lm_hip_status;
+
+/* (row, col) of a cell of a striped matrix -- dense.rs:28-39 MatrixCoordinates. */
+typedef struct lm_hip_coords {
+    size_t row;
+    size_t col;
+} lm_hip_coords;
+
+/* One above-threshold position of the fused scan (scan.rs:52-75 `Hit`). */
+typedef struct lm_hip_hit {
+    size_t position; /* col * rows + row, scores.rs:155-157 */
+    float score;
+} lm_hip_hit;
+
+typedef struct lm_hip_ctx lm_hip_ctx;       /* device + stream + scratch */
+typedef struct lm_hip_pssm lm_hip_pssm;     /* ScoringMatrix data resident on the device */
+typedef struct lm_hip_seq lm_hip_seq;       /* StripedSequence resident on the device */
+typedef struct lm_hip_scores lm_hip_scores; /* StripedScores<f32> resident on the device */
+
+/* ---- library ------------------------------------------------------------ */
+
+int lm_hip_abi_version(void);
+const char *lm_hip_last_error(void);
+/* Pipeline::avx2()/neon() -> Result<_, UnsupportedBackend> (pli/mod.rs:401-407):
+ * number of usable devices; 0 devices is reported through *count, not an error. */
+int lm_hip_device_count(int *count);
+/* Frees buffers this library returned to the caller (threshold / hit lists). */
+void lm_hip_free(void *p);
+
+/* DenseMatrix::stride (dense.rs:126-128) for x86-64 hosts: elements per row. */
+size_t lm_hip_stride(size_t cols, size_t elem_size);
+
+/* ---- context ------------------------------------------------------------ */
+
+/* `Pipeline::dispatch()` is re-created per call in the reference
+ * (pwm/mod.rs:646, scores.rs:182); the GPU state it would need lives here. */
+int lm_hip_ctx_create(int device, lm_hip_ctx **out);
+/* Borrow an existing hipStream_t (e.g. PyTorch's current stream) instead of
+ * creating one.  The stream must outlive the context. */
+int lm_hip_ctx_create_on_stream(int device, void *hip_stream, lm_hip_ctx **out);
+int lm_hip_ctx_destroy(lm_hip_ctx *ctx);
+int lm_hip_ctx_sync(lm_hip_ctx *ctx);
+/* hipStream_t the context enqueues on (for hipEvent timing by the caller). */
+int lm_hip_ctx_stream(lm_hip_ctx *ctx, void **hip_stream);
+/* Tuning knob: output rows each wavefront half sweeps in the C=32 score
+ * kernels (0 = library default). */
+int lm_hip_ctx_set_rows_per_stream(lm_hip_ctx *ctx, size_t rows);
+/* Name of the kernel the last score call on this context launched
+ * (for profiling tools); valid until the next call. */
+const char *lm_hip_ctx_last_kernel(lm_hip_ctx *ctx);
+
+/* ---- PSSM ---------------------------------------------------------------- */
+
+/* ScoringMatrix<A>.matrix() (pwm/mod.rs:561-564): `pssm` = pssm[0].as_ptr(),
+ * m = rows(), stride = stride() (8 for Dna, 24 for Protein), k = A::K::USIZE.
+ * Columns >= k of a row are never read (A4: they may be uninitialised). */
+int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stride,
+                       size_t k, lm_hip_pssm **out);
+int lm_hip_pssm_destroy(lm_hip_pssm *pssm);
+size_t lm_hip_pssm_len(const lm_hip_pssm *pssm);
+
+/* ---- Score (device pointers) ---------------------------------------------- */
+
+/*
+ * Score::score_rows_into (pli/mod.rs:72-106) / Avx2::score_f32_rows_into
+ * (avx2.rs:889-904).
+ *   d_seq            seq.matrix()[0].as_ptr(), on the device
+ *   seq_rows_total   seq.matrix().rows()   (includes the wrap rows)
+ *   seq_stride       seq.matrix().stride()
+ *   cols             C (32 through pssm.score() on x86-64, dispatch.rs:45)
+ *   wrap, length     seq.wrap(), seq.len()
+ *   [row_begin,row_end)  the `rows` range
+ *   d_out            scores.matrix_mut()[0].as_mut_ptr(), on the device, with
+ *                    room for (row_end-row_begin) rows of out_stride floats
+ * On return *out_rows / *max_index hold the arguments the reference passes to
+ * scores.resize (pli/mod.rs:86,91): (0,0) in the degenerate case, else
+ * (row_end-row_begin, L+1-M).  Asynchronous on the context's stream.
+ * Errors: LM_HIP_ERR_WRAP if wrap < M-1; BAD_ARGS if row_end > rows.
+ */
+int lm_hip_score_f32_dptr(lm_hip_ctx *ctx, const lm_hip_pssm *pssm,
+                          const uint8_t *d_seq, size_t seq_rows_total, size_t seq_stride,
+                          size_t cols, size_t wrap, size_t length,
+                          size_t row_begin, size_t row_end,
+                          float *d_out, size_t out_stride,
+                          size_t *out_rows, size_t *max_index);
+
+/* ---- Maximum / Threshold (device pointers) -------------------------------- */
+
+/* Maximum::argmax, Generic semantics (pli/mod.rs:135-155): the maximal cell
+ * that is LAST in (row, col) order; NaN never wins; if scores[0][0] is NaN the
+ * answer is (0,0).  *found = 0 when rows == 0.  `value` (optional) receives
+ * Maximum::max (pli/mod.rs:158-160).  Synchronises. */
+int lm_hip_argmax_f32_dptr(lm_hip_ctx *ctx, const float *d_scores, size_t rows,
+                           size_t stride, size_t cols, int *found,
+                           lm_hip_coords *best, float *value);
+
+/* Threshold::threshold (pli/mod.rs:210-221): every (row, col) with x >= t, in
+ * row-major order (the reference's push order).  *coords is malloc'ed by the
+ * library (NULL when *n == 0); release with lm_hip_free.  Synchronises. */
+int lm_hip_threshold_f32_dptr(lm_hip_ctx *ctx, const float *d_scores, size_t rows,
+                              size_t stride, size_t cols, float t,
+                              lm_hip_coords **coords, size_t *n);
+
+/* ---- fused score + reduce (no score matrix is written) -------------------- */
+
+/* Equivalent to score_rows_into followed by argmax on the result
+ * (lightmotif-bench/dna.rs:104-107 times exactly that pair).  `best` is in the
+ * coordinates of the scored block (row relative to row_begin).  *found = 0 in
+ * the degenerate case. */
+int lm_hip_score_argmax_f32_dptr(lm_hip_ctx *ctx, const lm_hip_pssm *pssm,
+                                 const uint8_t *d_seq, size_t seq_rows_total,
+                                 size_t seq_stride, size_t cols, size_t wrap, size_t length,
+                                 size_t row_begin, size_t row_end,
+                                 int *found, lm_hip_coords *best, float *value);
+
+/* Equivalent to score_rows_into followed by threshold(t): (row, col) list in
+ * row-major order, rows relative to row_begin. */
+int lm_hip_score_threshold_f32_dptr(lm_hip_ctx *ctx, const lm_hip_pssm *pssm,
+                                    const uint8_t *d_seq, size_t seq_rows_total,
+                                    size_t seq_stride, size_t cols, size_t wrap, size_t length,
+                                    size_t row_begin, size_t row_end, float t,
+                                    lm_hip_coords **coords, float **values, size_t *n);
+
+/* ---- Encode / Stripe (device pointers) ------------------------------------ */
+
+/* Encode::encode_into (pli/mod.rs:56-66): ASCII -> symbol index.  alphabet is
+ * 'D' (abc.rs:91-135) or 'P' (abc.rs:193-256).  lossy != 0 maps unknown bytes
+ * to the default symbol (seq.rs:122-129) and never fails; otherwise the first
+ * invalid byte's index is stored in *bad_index and LM_HIP_ERR_INVALID_SYMBOL
+ * returned.  Synchronises. */
+int lm_hip_encode_dptr(lm_hip_ctx *ctx, char alphabet, const uint8_t *d_ascii, size_t len,
+                       int lossy, uint8_t *d_dst, size_t *bad_index);
+
+/* Stripe::stripe_into (pli/mod.rs:178-200) + configure_wrap(wrap)
+ * (seq.rs:369-381): writes ceil(len/cols)+wrap rows of `stride` bytes.
+ * Padding bytes past `cols` in each row are zeroed (dense.rs:144-147). */
+int lm_hip_stripe_dptr(lm_hip_ctx *ctx, const uint8_t *d_encoded, size_t len, size_t cols,
+                       uint8_t default_symbol, size_t wrap, uint8_t *d_data, size_t stride);
+
+/* StripedSequence::configure_wrap (seq.rs:369-381) on a resident matrix that
+ * has room for rows + new_wrap rows. */
+int lm_hip_configure_wrap_dptr(lm_hip_ctx *ctx, uint8_t *d_data, size_t rows, size_t stride,
+                               size_t cols, size_t new_wrap, uint8_t default_symbol);
+
+/* ---- resident handles ------------------------------------------------------ */
+
+/* Upload an existing StripedSequence (seq.rs:288-294): data = matrix()[0].as_ptr(),
+ * rows_total = matrix().rows() (incl. wrap), k = alphabet size (default symbol = k-1). */
+int lm_hip_seq_upload(lm_hip_ctx *ctx, const uint8_t *data, size_t rows_total, size_t stride,
+                      size_t cols, size_t wrap, size_t length, size_t k, lm_hip_seq **out);
+/* EncodedSequence::to_striped (seq.rs:168-175) on the device: uploads `len`
+ * symbol bytes and stripes them there. */
+int lm_hip_seq_from_encoded(lm_hip_ctx *ctx, const uint8_t *encoded, size_t len, size_t cols,
+                            size_t k, lm_hip_seq **out);
+/* Same, from ASCII text: encode (strict or lossy) + stripe on the device. */
+int lm_hip_seq_from_ascii(lm_hip_ctx *ctx, char alphabet, const uint8_t *ascii, size_t len,
+                          size_t cols, int lossy, lm_hip_seq **out, size_t *bad_index);
+/* StripedSequence::configure_wrap (seq.rs:369-381); `m` = wrap rows wanted. */
+int lm_hip_seq_configure_wrap(lm_hip_ctx *ctx, lm_hip_seq *seq, size_t m);
+/* len(), wrap(), matrix().rows() - wrap(), stride, cols, device pointer. */
+int lm_hip_seq_info(const lm_hip_seq *seq, size_t *length, size_t *wrap, size_t *rows,
+                    size_t *stride, size_t *cols, const uint8_t **d_data);
+/* Copies (rows+wrap) x stride bytes back. */
+int lm_hip_seq_download(lm_hip_ctx *ctx, const lm_hip_seq *seq, uint8_t *dst);
+int lm_hip_seq_destroy(lm_hip_seq *seq);
+
+/* StripedScores::empty() (scores.rs:118-121). */
+int lm_hip_scores_create(lm_hip_ctx *ctx, size_t cols, lm_hip_scores **out);
+int lm_hip_scores_info(const lm_hip_scores *scores, size_t *rows, size_t *stride, size_t *cols,
+                       size_t *max_index, const float **d_data);
+/* Copies rows x stride floats back. */
+int lm_hip_scores_download(lm_hip_ctx *ctx, const lm_hip_scores *scores, float *dst);
+int lm_hip_scores_destroy(lm_hip_scores *scores);
+
+/* Score::score_rows_into on handles; resizes `scores` like scores.resize. */
+int lm_hip_score_rows_into(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *seq,
+                           size_t row_begin, size_t row_end, lm_hip_scores *scores);
+/* Score::score_into (pli/mod.rs:109-117): rows = matrix.rows() - wrap. */
+int lm_hip_score_into(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *seq,
+                      lm_hip_scores *scores);
+/* Maximum::argmax / max, Threshold::threshold on a resident StripedScores. */
+int lm_hip_argmax(lm_hip_ctx *ctx, const lm_hip_scores *scores, int *found,
+                  lm_hip_coords *best, float *value);
+int lm_hip_threshold(lm_hip_ctx *ctx, const lm_hip_scores *scores, float t,
+                     lm_hip_coords **coords, size_t *n);
+
+/* ---- host-pointer convenience forms (synchronous, PCIe both ways) ---------- */
+
+/* Exactly what a Rust shim can obtain from &StripedSequence / &DenseMatrix /
+ * &mut StripedScores; uses a lazily created per-process default context on
+ * device 0 (or $LM_HIP_DEVICE). */
+int lm_hip_score_f32(const uint8_t *seq, size_t seq_rows_total, size_t seq_stride, size_t cols,
+                     size_t wrap, size_t length,
+                     const float *pssm, size_t m, size_t pssm_stride, size_t k,
+                     size_t row_begin, size_t row_end,
+                     float *out, size_t out_stride, size_t *out_rows, size_t *max_index);
+int lm_hip_argmax_f32(const float *scores, size_t rows, size_t stride, size_t cols,
+                      int *found, lm_hip_coords *best, float *value);
+int lm_hip_threshold_f32(const float *scores, size_t rows, size_t stride, size_t cols, float t,
+                         lm_hip_coords **coords, size_t *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIGHTMOTIF_HIP_H */

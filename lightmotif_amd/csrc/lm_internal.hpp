@@ -1,0 +1,132 @@
+// lm_internal.hpp -- shared declarations of the gfx950 back-end (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "lightmotif_hip.h"
+
+namespace lm {
+
+// ---- error plumbing ---------------------------------------------------------
+
+int fail(int status, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define LM_HIP_TRY(expr)                                                               \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess)                                                          \
+            return ::lm::fail(_e == hipErrorOutOfMemory ? LM_HIP_ERR_OOM : LM_HIP_ERR_HIP, \
+                              "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),   \
+                              __FILE__, __LINE__);                                     \
+    } while (0)
+
+#define LM_TRY(expr)                 \
+    do {                             \
+        int _s = (expr);             \
+        if (_s != LM_HIP_OK)         \
+            return _s;               \
+    } while (0)
+
+// ---- device scratch ---------------------------------------------------------
+
+struct Scratch {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t n);  // grows (never shrinks); contents are not preserved
+    void release();
+};
+
+// Record written by the reductions (device) and read back through pinned memory.
+struct ArgmaxRecord {
+    float value;
+    int found;
+    long long index;  // flat index row * cols + col, -1 = none
+};
+
+}  // namespace lm
+
+// ---- opaque handle definitions ------------------------------------------------
+
+struct lm_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    std::mutex mu;
+    lm::Scratch scratch;        // block partials, chunk counts, hit lists
+    lm::Scratch scratch2;
+    void *pinned = nullptr;     // 4 KiB of host-pinned memory for small read-backs
+    size_t rows_per_stream = 0; // 0 = default
+    int num_cus = 256;
+    const char *last_kernel = "";
+};
+
+struct lm_hip_pssm {
+    int device = 0;
+    size_t m = 0, k = 0;
+    std::vector<float> host;  // m x k, dense (row-major, stride k)
+    // Transposed, padded copy for the C=32 kernels: table[s * ts + j] = pssm[j][s],
+    // ts = floats per symbol row (multiple of 4, ts/4 odd), zero padded.
+    float *d_table = nullptr;
+    size_t ts = 0;
+    // Row-major dense copy for the generic kernel: d_dense[j * k + s].
+    float *d_dense = nullptr;
+};
+
+struct lm_hip_seq {
+    int device = 0;
+    uint8_t *d_data = nullptr;
+    size_t capacity_rows = 0;  // allocated rows
+    size_t rows = 0;           // non-wrap rows = ceil(length / cols)
+    size_t wrap = 0;
+    size_t stride = 0, cols = 0, length = 0, k = 0;
+};
+
+struct lm_hip_scores {
+    int device = 0;
+    float *d_data = nullptr;
+    size_t capacity_rows = 0;
+    size_t rows = 0, stride = 0, cols = 0, max_index = 0;
+};
+
+namespace lm {
+
+// ---- kernel launchers (score.hip, reduce.hip, layout.hip) ----------------------
+
+enum class ScoreMode { Store, Argmax, Threshold };
+
+struct ScoreArgs {
+    const lm_hip_pssm *pssm;
+    const uint8_t *d_seq;     // row 0 of the striped matrix
+    size_t seq_stride, cols;
+    size_t row_begin, row_end;
+    // Store
+    float *d_out; size_t out_stride;
+};
+
+// Materialising score kernels.
+int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a);
+// Fused score+argmax: leaves one ArgmaxRecord at ctx->scratch (device) -> out.
+int launch_score_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *out);
+// Fused score+threshold: hits as (flat index, value) sorted by flat index.
+int launch_score_threshold(lm_hip_ctx *ctx, const ScoreArgs &a, float t,
+                           std::vector<unsigned long long> *flat, std::vector<float> *values);
+
+int launch_argmax(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride,
+                  size_t cols, ArgmaxRecord *out);
+int launch_threshold(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride,
+                     size_t cols, float t, lm_hip_coords **coords, size_t *n);
+
+int launch_encode(lm_hip_ctx *ctx, char alphabet, const uint8_t *d_ascii, size_t len, int lossy,
+                  uint8_t *d_dst, size_t *bad_index);
+int launch_stripe(lm_hip_ctx *ctx, const uint8_t *d_encoded, size_t len, size_t cols,
+                  uint8_t default_symbol, size_t wrap, uint8_t *d_data, size_t stride);
+int launch_wrap(lm_hip_ctx *ctx, uint8_t *d_data, size_t rows, size_t stride, size_t cols,
+                size_t new_wrap, uint8_t default_symbol);
+
+}  // namespace lm

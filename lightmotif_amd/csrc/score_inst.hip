@@ -1,0 +1,32 @@
+// score_inst.hip -- instantiates score_c32<M, MODE> for M in [LM_M_LO, LM_M_HI].
+// Compiled several times with different -DLM_M_LO/-DLM_M_HI/-DLM_INST_ID so the
+// fully unrolled kernels build in parallel (see build.py).
+#include "score_kernels.hpp"
+
+#ifndef LM_M_LO
+#error "LM_M_LO / LM_M_HI / LM_INST_ID must be defined"
+#endif
+
+namespace lm {
+
+#define LM_CAT2(a, b) a##b
+#define LM_CAT(a, b) LM_CAT2(a, b)
+
+template <int M>
+struct RegisterRange {
+    static void run(ScoreC32Launcher (*tab)[3])
+    {
+        tab[M][MODE_STORE] = &score_c32_launch<M, MODE_STORE>;
+        tab[M][MODE_ARGMAX] = &score_c32_launch<M, MODE_ARGMAX>;
+        tab[M][MODE_THRESHOLD] = &score_c32_launch<M, MODE_THRESHOLD>;
+        if constexpr (M < LM_M_HI)
+            RegisterRange<M + 1>::run(tab);
+    }
+};
+
+void LM_CAT(register_score_c32_, LM_INST_ID)(ScoreC32Launcher (*tab)[3])
+{
+    RegisterRange<LM_M_LO>::run(tab);
+}
+
+}  // namespace lm

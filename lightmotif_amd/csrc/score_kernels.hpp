@@ -1,0 +1,378 @@
+// score_kernels.hpp -- device code of the PSSM scoring kernels (gfx950 only).
+//
+// What is computed (reference: lightmotif/src/pli/mod.rs:96-105, the Generic
+// body every SIMD back-end must agree with):
+//
+//     out[r][c] = (((0.0f + P[0][s(r,c)]) + P[1][s(r+1,c)]) + ... ) + P[M-1][s(r+M-1,c)]
+//
+// with s(r,c) the symbol byte at row r, column c of the striped sequence.  The
+// sum is M *sequential* IEEE f32 adds in motif order -- no re-association, no
+// FMA, no pre-summed k-mer tables -- so results are bit-identical to Generic.
+//
+// C = 32 kernel (`score_c32`): "input-stationary rotating accumulators".
+//   * one lane owns ONE column of the striped matrix and sweeps a run of T
+//     consecutive rows ("stream"); a wavefront = 32 columns x 2 streams, so every
+//     load is a contiguous 32-byte row and every store a contiguous 128-byte row;
+//   * the PSSM is staged in LDS *transposed*: tab[s][j] = P[j][s], one padded
+//     row of TS floats per symbol.  For the symbol s read at sequence row r the
+//     lane fetches the whole column P[0..M-1][s] with ceil(M/4) ds_read_b128
+//     (row stride TS = 4*odd floats: the <=16 distinct rows a 16-lane b128 group
+//     can touch fall in distinct 4-bank slots, equal rows broadcast -> no bank
+//     conflicts for K <= 16);
+//   * P[j][s] belongs to output row r-j, so the lane keeps M accumulators in
+//     registers, one per in-flight output row; the slot of output row o is
+//     (o - o0) mod M, made a compile-time register index by unrolling M steps.
+//     Each accumulator therefore receives P[0],P[1],... in order as r advances:
+//     exactly the reference's add order;
+//   * at step t the slot started at t-M+1 completes and is emitted (stored /
+//     compared), and is restarted by the next step.
+//   Every symbol byte is read from memory once per stream and every weight comes
+//   from LDS; HBM traffic is the algorithmic 1 B in + 4 B out per position.
+//
+// Generic kernel (`score_generic`): one thread per cell, any C / stride / M / K.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "lm_internal.hpp"
+
+namespace lm {
+
+constexpr int kBlock = 256;          // threads per workgroup (4 wavefronts)
+constexpr int kStreamsPerBlock = 8;  // 2 per wavefront
+constexpr int kMaxFastM = 32;        // largest motif the unrolled kernel is built for
+
+// Floats per symbol row of the transposed LDS table used by score_c32<M>:
+// 4 * (smallest odd number >= ceil(M/4)).
+constexpr int table_stride(int m) { return 4 * (((m + 3) / 4) | 1); }
+
+enum : int { MODE_STORE = 0, MODE_ARGMAX = 1, MODE_THRESHOLD = 2 };
+
+struct FusedOut {
+    // MODE_ARGMAX: one record per block
+    ArgmaxRecord *block_best;
+    // MODE_THRESHOLD
+    float threshold;
+    unsigned long long *hit_count;  // device counter
+    unsigned long long *hit_flat;   // capacity entries
+    float *hit_value;
+    unsigned long long hit_capacity;
+};
+
+// Ordering used by every argmax reduction: larger value wins; equal values ->
+// larger flat index (= later in the reference's row-major scan, pli/mod.rs:144-151
+// with `>=`); NaN is never a candidate; index -1 = "no candidate yet".
+__device__ __forceinline__ void best_merge(float &v, long long &i, float ov, long long oi)
+{
+    if (oi >= 0 && (i < 0 || ov > v || (ov == v && oi > i))) {
+        v = ov;
+        i = oi;
+    }
+}
+
+__device__ __forceinline__ void best_wave_reduce(float &v, long long &i)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(v, off);
+        const long long oi = __shfl_xor(i, off);
+        best_merge(v, i, ov, oi);
+    }
+}
+
+// Block-level reduce of (v, i); result valid in thread 0.  `sm` has room for
+// kBlock/64 entries of each type.
+__device__ __forceinline__ void best_block_reduce(float &v, long long &i, float *sm_v,
+                                                  long long *sm_i)
+{
+    best_wave_reduce(v, i);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        sm_v[wave] = v;
+        sm_i[wave] = i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w)
+            best_merge(v, i, sm_v[w], sm_i[w]);
+    }
+}
+
+// Tuning parameters of score_c32 (fixed per build; tools/kbench sweeps them):
+//   PF  global prefetch distance in steps: the symbol byte of step k+PF is
+//       requested while step k is processed (0 = load at use);
+//   LP  1 = the LDS reads of step k+1 are issued before the adds of step k.
+#ifndef LM_SCORE_PF
+#define LM_SCORE_PF 6
+#endif
+#ifndef LM_SCORE_LP
+#define LM_SCORE_LP 0
+#endif
+
+template <int M>
+__device__ __forceinline__ void lds_fetch_column(float (&w)[4 * ((M + 3) / 4)],
+                                                 const char *__restrict__ tab, const unsigned s)
+{
+    constexpr int NV = (M + 3) / 4;
+    constexpr unsigned TSB = table_stride(M) * 4;  // bytes per symbol row, multiple of 16
+    const char *row =
+        static_cast<const char *>(__builtin_assume_aligned(tab + __umul24(s, TSB), 16));
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(row + 16 * q);
+        w[4 * q + 0] = v.x;
+        w[4 * q + 1] = v.y;
+        w[4 * q + 2] = v.z;
+        w[4 * q + 3] = v.w;
+    }
+}
+
+enum : int { PHASE_FIRST = 0, PHASE_MAIN = 1, PHASE_LAST = 2 };
+
+// One group of M consecutive steps of one lane.  `sp` -> symbol byte of the
+// group's first step; `orow` = output row (relative to row_begin) completed by
+// the group's first step (in the FIRST group only step M-1 completes a row).
+// `sym` is a ring of symbol bytes indexed by step mod M (only ~PF are live),
+// `wc` carries the prefetched LDS column across steps when LP = 1.
+template <int M, int MODE, int PF, int LP, int PHASE>
+__device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
+                                            float (&wc)[4 * ((M + 3) / 4)],
+                                            const uint8_t *__restrict__ sp,
+                                            const char *__restrict__ tab,
+                                            float *__restrict__ op, const long long orow,
+                                            const int col, float &best_v, long long &best_row,
+                                            const FusedOut &fo)
+{
+    constexpr int NW = 4 * ((M + 3) / 4);
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        // (1) request the symbol byte PF steps ahead (stays inside the stream's
+        //     T+M-1 input rows: the LAST group does not look past its end)
+        if (PF > 0) {
+            if (PHASE != PHASE_LAST || k + PF < M)
+                sym[(k + PF) % M] = sp[(k + PF) * 32];
+        } else {
+            sym[k] = sp[k * 32];
+        }
+        // (2) the PSSM column of this step's symbol
+        float w[NW];
+        if (LP) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i)
+                w[i] = wc[i];
+            if (PHASE != PHASE_LAST || k + 1 < M)
+                lds_fetch_column<M>(wc, tab, sym[(k + 1) % M]);
+        } else {
+            lds_fetch_column<M>(w, tab, sym[k]);
+        }
+        // (3) P[j][s] goes to the output row started j steps ago: slot (k - j) mod M.
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            const int slot = (k - j + M) % M;
+            if (j == 0)
+                acc[slot] = 0.0f + w[0];  // T::default() + P[0][s]   (pli/mod.rs:98,101)
+            else
+                acc[slot] = acc[slot] + w[j];
+        }
+        // (4) the slot started at step k-(M-1) is complete.
+        if (PHASE != PHASE_FIRST || k == M - 1) {
+            const float score = acc[(k + 1) % M];
+            if (MODE == MODE_STORE) {
+                __builtin_nontemporal_store(score, op + k * 32);
+            } else if (MODE == MODE_ARGMAX) {
+                if (score >= best_v) {  // same `>=` as pli/mod.rs:146, NaN never passes
+                    best_v = score;
+                    best_row = orow + k;
+                }
+            } else {
+                if (score >= fo.threshold) {  // pli/mod.rs:215
+                    const unsigned long long slot_i = atomicAdd(fo.hit_count, 1ull);
+                    if (slot_i < fo.hit_capacity) {
+                        fo.hit_flat[slot_i] = (unsigned long long)(orow + k) * 32ull + col;
+                        fo.hit_value[slot_i] = score;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// C = 32, seq stride 32 B, out stride 32 floats.  Grid: ceil(nstreams / 8) blocks.
+// Every stream sweeps exactly T = q*M + 1 output rows, q >= 1, i.e. T + M - 1 =
+// (q+1)*M steps = one FIRST group, q-1 MAIN groups and one LAST group.  The last
+// stream is shifted back so that it ends at row_end; idle half-waves re-do the
+// last stream (identical values -> benign duplicates).
+template <int M, int MODE, int PF = LM_SCORE_PF, int LP = LM_SCORE_LP>
+__global__ __launch_bounds__(kBlock) void score_c32(
+    const uint8_t *__restrict__ seq, const float *__restrict__ table, const int K,
+    const unsigned long long row_begin, const unsigned long long row_end,
+    const unsigned long long T, const unsigned long long nstreams, float *__restrict__ out,
+    const FusedOut fo)
+{
+    static_assert(PF < M || M == 1, "prefetch distance must be shorter than the motif");
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    {
+        float4 *dst = reinterpret_cast<float4 *>(lds_raw);
+        const float4 *src = reinterpret_cast<const float4 *>(table);
+        const int n4 = K * table_stride(M) / 4;
+        for (int i = threadIdx.x; i < n4; i += kBlock)
+            dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 31;
+    unsigned long long stream =
+        ((unsigned long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    if (stream >= nstreams)
+        stream = nstreams - 1;
+    unsigned long long o0 = row_begin + stream * T;
+    if (o0 + T > row_end)
+        o0 = row_end - T;
+
+    const uint8_t *sp = seq + o0 * 32 + col;
+    // output row completed by step t is o0 + t - (M-1); `op` tracks step 0 of the group
+    long long orow = (long long)(o0 - row_begin) - (M - 1);
+    float *op = (MODE == MODE_STORE) ? out + orow * 32 + col : nullptr;
+
+    constexpr int NW = 4 * ((M + 3) / 4);
+    constexpr int PFE = (M == 1) ? 0 : PF;
+    float acc[M];
+    unsigned sym[M];
+    float wc[NW];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        acc[j] = 0.0f;
+        sym[j] = 0;
+    }
+#pragma unroll
+    for (int j = 0; j < PFE; ++j)
+        sym[j] = sp[j * 32];
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+        wc[i] = 0.0f;
+    constexpr int LPE = (PFE >= 1) ? LP : 0;
+    if (LPE)
+        lds_fetch_column<M>(wc, lds_raw, sym[0]);
+    float best_v = -INFINITY;
+    long long best_row = -1;
+
+    const unsigned long long ngroups = (T + M - 1) / M;  // exact: T = q*M + 1, >= 2
+
+    score_group<M, MODE, PFE, LPE, PHASE_FIRST>(acc, sym, wc, sp, lds_raw, op, orow, col, best_v,
+                                                best_row, fo);
+    for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
+        sp += M * 32;
+        orow += M;
+        if (MODE == MODE_STORE)
+            op += M * 32;
+        score_group<M, MODE, PFE, LPE, PHASE_MAIN>(acc, sym, wc, sp, lds_raw, op, orow, col,
+                                                   best_v, best_row, fo);
+    }
+    sp += M * 32;
+    orow += M;
+    if (MODE == MODE_STORE)
+        op += M * 32;
+    score_group<M, MODE, PFE, LPE, PHASE_LAST>(acc, sym, wc, sp, lds_raw, op, orow, col, best_v,
+                                               best_row, fo);
+
+    if (MODE == MODE_ARGMAX) {
+        // the table is dead: reuse the dynamic LDS (>= 64 B) as reduction scratch
+        __syncthreads();
+        long long *sm_i = reinterpret_cast<long long *>(lds_raw);
+        float *sm_v = reinterpret_cast<float *>(lds_raw + 32);
+        long long idx = best_row >= 0 ? best_row * 32 + col : -1;
+        best_block_reduce(best_v, idx, sm_v, sm_i);
+        if (threadIdx.x == 0) {
+            fo.block_best[blockIdx.x].value = best_v;
+            fo.block_best[blockIdx.x].index = idx;
+            fo.block_best[blockIdx.x].found = idx >= 0;
+        }
+    }
+}
+
+// Any column count / stride / motif length / alphabet: one thread per cell.
+// `pssm` is the dense M x K matrix; it is staged in LDS when `use_lds`.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void score_generic(
+    const uint8_t *__restrict__ seq, const unsigned long long seq_stride, const int cols,
+    const float *__restrict__ pssm, const int M, const int K, const int use_lds,
+    const unsigned long long row_begin, const unsigned long long row_end, float *__restrict__ out,
+    const unsigned long long out_stride, const FusedOut fo)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const float *tab = pssm;
+    if (use_lds) {
+        float *dst = reinterpret_cast<float *>(lds_raw);
+        for (int i = threadIdx.x; i < M * K; i += kBlock)
+            dst[i] = pssm[i];
+        __syncthreads();
+        tab = dst;
+    }
+    const unsigned long long ncells = (row_end - row_begin) * (unsigned long long)cols;
+    float best_v = -INFINITY;
+    long long best_i = -1;
+    for (unsigned long long cell = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+         cell < ncells; cell += (unsigned long long)gridDim.x * kBlock) {
+        const unsigned long long r = cell / cols;
+        const int c = (int)(cell - r * cols);
+        const uint8_t *sp = seq + (row_begin + r) * seq_stride + c;
+        float score = 0.0f;                       // pli/mod.rs:98
+        for (int j = 0; j < M; ++j)               // pli/mod.rs:99-102
+            score = score + tab[j * K + sp[j * seq_stride]];
+        if (MODE == MODE_STORE) {
+            out[r * out_stride + c] = score;      // pli/mod.rs:103
+        } else if (MODE == MODE_ARGMAX) {
+            if (score >= best_v) {
+                best_v = score;
+                best_i = (long long)cell;
+            }
+        } else {
+            if (score >= fo.threshold) {
+                const unsigned long long slot_i = atomicAdd(fo.hit_count, 1ull);
+                if (slot_i < fo.hit_capacity) {
+                    fo.hit_flat[slot_i] = cell;
+                    fo.hit_value[slot_i] = score;
+                }
+            }
+        }
+    }
+    if (MODE == MODE_ARGMAX) {
+        __syncthreads();
+        long long *sm_i = reinterpret_cast<long long *>(lds_raw);
+        float *sm_v = reinterpret_cast<float *>(lds_raw + 32);
+        best_block_reduce(best_v, best_i, sm_v, sm_i);
+        if (threadIdx.x == 0) {
+            fo.block_best[blockIdx.x].value = best_v;
+            fo.block_best[blockIdx.x].index = best_i;
+            fo.block_best[blockIdx.x].found = best_i >= 0;
+        }
+    }
+}
+
+// Host-side launch shim, one per (M, MODE), defined in score_inst_*.hip.
+using ScoreC32Launcher = hipError_t (*)(dim3 grid, size_t lds_bytes, hipStream_t stream,
+                                        const uint8_t *seq, const float *table, int K,
+                                        unsigned long long row_begin, unsigned long long row_end,
+                                        unsigned long long T, unsigned long long nstreams,
+                                        float *out, FusedOut fo);
+
+template <int M, int MODE>
+hipError_t score_c32_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, const uint8_t *seq,
+                            const float *table, int K, unsigned long long row_begin,
+                            unsigned long long row_end, unsigned long long T,
+                            unsigned long long nstreams, float *out, FusedOut fo)
+{
+    hipLaunchKernelGGL((score_c32<M, MODE>), grid, dim3(kBlock), lds_bytes, stream, seq, table, K,
+                       row_begin, row_end, T, nstreams, out, fo);
+    return hipGetLastError();
+}
+
+// Filled by the score_inst_*.hip translation units; [M][MODE], nullptr if absent.
+ScoreC32Launcher score_c32_lookup(int M, int mode);
+const char *score_c32_name(int M, int mode);
+
+}  // namespace lm

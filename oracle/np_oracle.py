@@ -1,0 +1,121 @@
+"""numpy-float32 restatement of the reference's Generic pipeline.
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).  Written independently
+of ``lm_oracle.c`` so the two can cross-check each other; every function cites
+the reference lines it follows (crate ``lightmotif/``).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+DNA = "ACTGN"                    # abc.rs:106-108
+PROTEIN = "ACDEFGHIKLMNPQRSTVWYX"  # abc.rs:193-256
+
+
+def stride(cols: int, elem_size: int) -> int:
+    """dense.rs:43-48,126-128 (x86-64: rows aligned to 32 bytes)."""
+    return -(-cols * elem_size // 32) * 32 // elem_size
+
+
+def encode(text: str, alphabet: str = DNA) -> np.ndarray:
+    """pli/mod.rs:56-66 with Symbol::from_ascii (abc.rs:166-171)."""
+    lut = {c: i for i, c in enumerate(alphabet)}
+    try:
+        return np.array([lut[c] for c in text], dtype=np.uint8)
+    except KeyError as e:  # err.rs InvalidSymbol
+        raise ValueError(f"invalid symbol {e.args[0]!r}") from None
+
+
+def stripe(encoded: np.ndarray, cols: int, default: int) -> np.ndarray:
+    """pli/mod.rs:178-200: position i -> data[i % rows][i / rows]."""
+    n = len(encoded)
+    rows = -(-n // cols)
+    data = np.zeros((rows, stride(cols, 1)), dtype=np.uint8)
+    if rows == 0:
+        return data
+    i = np.arange(rows * cols)
+    vals = np.full(rows * cols, default, dtype=np.uint8)
+    vals[:n] = encoded
+    data[i % rows, i // rows] = vals
+    return data
+
+
+def configure_wrap(data: np.ndarray, rows: int, cols: int, wrap: int, m: int, default: int):
+    """seq.rs:369-381.  Returns (data, wrap)."""
+    if m <= wrap:
+        return data, wrap
+    out = np.zeros((rows + m, data.shape[1]), dtype=np.uint8)
+    out[:rows + wrap] = data[:rows + wrap]
+    for i in range(m):
+        out[rows + i, :cols - 1] = out[i, 1:cols]
+        out[rows + i, cols - 1] = default
+    return out, m
+
+
+def pssm_from_sites(sites: list[np.ndarray], k: int, pseudocount: float = 0.1) -> np.ndarray:
+    """pwm/mod.rs:209-237, 240-258, 415-430 with the uniform background of
+    abc.rs:473-487; all arithmetic in float32 like the reference."""
+    m = len(sites[0])
+    f32 = np.float32
+    out = np.zeros((m, stride(k, 4)), dtype=f32)
+    bg = np.array([f32(1) / f32(k - 1)] * (k - 1) + [f32(0)], dtype=f32)
+    for i in range(m):
+        row = np.zeros(k, dtype=f32)
+        for j in range(k):
+            cnt = sum(int(s[i] == j) for s in sites)
+            row[j] = f32(cnt) + (f32(pseudocount) if j != k - 1 else f32(0))
+        tot = f32(0)
+        for j in range(k):
+            tot = f32(tot + row[j])
+        row = (row / tot).astype(f32)
+        with np.errstate(divide="ignore"):
+            for j in range(k):
+                out[i, j] = -np.inf if bg[j] == 0 else np.log2(f32(row[j] / bg[j]), dtype=f32)
+    return out
+
+
+def score_rows(data: np.ndarray, cols: int, length: int, pssm: np.ndarray,
+               row_begin: int, row_end: int):
+    """pli/mod.rs:72-106.  Returns (scores (rows, stride(cols,4)) f32, max_index)."""
+    m = pssm.shape[0]
+    if length < m or row_begin >= row_end:
+        return np.zeros((0, stride(cols, 4)), dtype=np.float32), 0
+    n = row_end - row_begin
+    out = np.zeros((n, stride(cols, 4)), dtype=np.float32)
+    acc = np.zeros((n, cols), dtype=np.float32)          # :98 T::default()
+    with np.errstate(invalid="ignore"):
+        for j in range(m):                                   # :99, sequential in j
+            sym = data[row_begin + j:row_end + j, :cols]     # :100
+            acc = (acc + pssm[j][sym]).astype(np.float32)    # :101 one f32 add per row
+    out[:, :cols] = acc
+    return out, max(length + 1 - m, 0)
+
+
+def argmax(scores: np.ndarray, cols: int):
+    """pli/mod.rs:135-155: last maximal cell in (row, col) order; NaN never wins."""
+    if scores.shape[0] == 0:
+        return None
+    best = scores[0, 0]
+    br = bc = 0
+    flat = scores[:, :cols]
+    if np.isnan(best):
+        return (0, 0)
+    with np.errstate(invalid="ignore"):
+        mx = np.nanmax(flat)
+        cand = np.argwhere(flat >= mx)
+    br, bc = cand[-1]
+    return (int(br), int(bc))
+
+
+def threshold(scores: np.ndarray, cols: int, t: float) -> np.ndarray:
+    """pli/mod.rs:210-221: row-major (row, col) list of cells with x >= t."""
+    with np.errstate(invalid="ignore"):
+        return np.argwhere(scores[:, :cols] >= np.float32(t))
+
+
+def unstripe(scores: np.ndarray, cols: int, max_index: int) -> np.ndarray:
+    """scores.rs:270-288."""
+    rows = scores.shape[0]
+    end = min(max_index, rows * cols)
+    i = np.arange(end)
+    return scores[i % rows, i // rows] if rows else np.zeros(0, np.float32)

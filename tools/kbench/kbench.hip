@@ -1,0 +1,333 @@
+// kbench -- standalone sweep of score_c32 variants on one GPU (development tool).
+// Build: see tools/kbench/build.sh.  Not part of the product library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "score_kernels.hpp"
+
+#define CK(x)                                                                          \
+    do {                                                                               \
+        hipError_t e_ = (x);                                                           \
+        if (e_ != hipSuccess) {                                                        \
+            fprintf(stderr, "%s: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(2);                                                                   \
+        }                                                                              \
+    } while (0)
+
+#ifndef KB_M
+#define KB_M 20
+#endif
+
+using namespace lm;
+
+__device__ __forceinline__ unsigned long long splitmix(unsigned long long x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// rows x 32 random symbols in [0, nsym), then wrap rows (seq.rs:373-378)
+__global__ void fill_seq(uint8_t *d, unsigned long long rows, unsigned long long wrap, int nsym,
+                         int defsym)
+{
+    const unsigned long long n = (rows + wrap) * 32;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        unsigned long long r = i / 32, c = i % 32;
+        if (r >= rows) {  // wrap row: data[rows+k][c] = data[k][c+1]
+            r -= rows;
+            c += 1;
+        }
+        d[i] = (c >= 32) ? defsym : (uint8_t)(splitmix(r * 32 + c) % nsym);
+    }
+}
+
+__global__ void compare_bits(const unsigned *a, const unsigned *b, unsigned long long n,
+                             unsigned long long *bad)
+{
+    unsigned long long local = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x)
+        local += a[i] != b[i];
+    if (local)
+        atomicAdd(bad, local);
+}
+
+// stream copy with the score kernel's traffic mix: read n bytes, write 4n bytes
+__global__ void mix_copy(const uint4 *in, float4 *out, unsigned long long n16)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint4 v = in[i];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 o;
+            o.x = (float)(w[q] & 0xff);
+            o.y = (float)((w[q] >> 8) & 0xff);
+            o.z = (float)((w[q] >> 16) & 0xff);
+            o.w = (float)(w[q] >> 24);
+            __builtin_nontemporal_store(o.x, &out[i * 4 + q].x);
+            __builtin_nontemporal_store(o.y, &out[i * 4 + q].y);
+            __builtin_nontemporal_store(o.z, &out[i * 4 + q].z);
+            __builtin_nontemporal_store(o.w, &out[i * 4 + q].w);
+        }
+    }
+}
+
+__global__ void fill_f4(float4 *out, unsigned long long n16, float v)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
+         i += (unsigned long long)gridDim.x * blockDim.x)
+        out[i] = make_float4(v, v, v, v);
+}
+
+// VALU throughput probes: NI dependent-free adds per lane
+template <int PK>
+__global__ void valu_probe(float *out, int iters)
+{
+    float a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        a[i] = threadIdx.x * 0.001f + i;
+    const float inc = out[0];
+    for (int it = 0; it < iters; ++it) {
+        if (PK) {
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                typedef float v2 __attribute__((ext_vector_type(2)));
+                v2 x = {a[i], a[i + 1]};
+                v2 y = {inc, inc};
+                asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(x) : "v"(y));
+                a[i] = x.x;
+                a[i + 1] = x.y;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(inc));
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        s += a[i];
+    if (s == 12345.678f)
+        out[1] = s;
+}
+
+struct Variant {
+    const char *name;
+    ScoreC32Launcher fn;
+};
+
+template <int PF, int LP>
+hipError_t launch_v(dim3 grid, size_t lds_bytes, hipStream_t stream, const uint8_t *seq,
+                    const float *table, int K, unsigned long long row_begin,
+                    unsigned long long row_end, unsigned long long T,
+                    unsigned long long nstreams, float *out, FusedOut fo)
+{
+    hipLaunchKernelGGL((score_c32<KB_M, MODE_STORE, PF, LP>), grid, dim3(kBlock), lds_bytes, stream,
+                       seq, table, K, row_begin, row_end, T, nstreams, out, fo);
+    return hipGetLastError();
+}
+
+template <int PF, int LP>
+hipError_t launch_am(dim3 grid, size_t lds_bytes, hipStream_t stream, const uint8_t *seq,
+                     const float *table, int K, unsigned long long row_begin,
+                     unsigned long long row_end, unsigned long long T,
+                     unsigned long long nstreams, float *out, FusedOut fo)
+{
+    hipLaunchKernelGGL((score_c32<KB_M, MODE_ARGMAX, PF, LP>), grid, dim3(kBlock), lds_bytes,
+                       stream, seq, table, K, row_begin, row_end, T, nstreams, out, fo);
+    return hipGetLastError();
+}
+
+static double median(std::vector<float> v)
+{
+    std::sort(v.begin(), v.end());
+    return v[v.size() / 2];
+}
+
+int main(int argc, char **argv)
+{
+    const unsigned long long L = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1000000000ull;
+    const int K = argc > 2 ? atoi(argv[2]) : 5;
+    const int reps = argc > 3 ? atoi(argv[3]) : 15;
+    const char *tag = argc > 4 ? argv[4] : "";
+    constexpr int M = KB_M;
+    const unsigned long long rows = (L + 31) / 32, wrap = M - 1;
+
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    printf("# device %s CUs=%d clock=%d MHz  L=%llu rows=%llu M=%d K=%d %s\n", prop.name,
+           prop.multiProcessorCount, prop.clockRate / 1000, L, rows, M, K, tag);
+
+    uint8_t *d_seq;
+    float *d_ref, *d_out, *d_table, *d_dense;
+    unsigned long long *d_bad;
+    CK(hipMalloc(&d_seq, (rows + wrap) * 32 + 4096));
+    CK(hipMalloc(&d_ref, rows * 32 * 4));
+    CK(hipMalloc(&d_out, rows * 32 * 4));
+    CK(hipMalloc(&d_bad, 8));
+    hipLaunchKernelGGL(fill_seq, dim3(4096), dim3(256), 0, 0, d_seq, rows, wrap, K - 1, K - 1);
+
+    // random log-odds-like PSSM with -inf in the last column
+    std::vector<float> pssm(M * K), table(K * table_stride(M), 0.0f);
+    srand(12345);
+    for (int j = 0; j < M; ++j)
+        for (int s = 0; s < K; ++s)
+            pssm[j * K + s] = (s == K - 1) ? -INFINITY : (float)(rand() % 100000) / 7919.0f - 6.0f;
+    for (int s = 0; s < K; ++s)
+        for (int j = 0; j < M; ++j)
+            table[s * table_stride(M) + j] = pssm[j * K + s];
+    CK(hipMalloc(&d_table, table.size() * 4));
+    CK(hipMalloc(&d_dense, pssm.size() * 4));
+    CK(hipMemcpy(d_table, table.data(), table.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_dense, pssm.data(), pssm.size() * 4, hipMemcpyHostToDevice));
+
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    FusedOut fo{};
+
+    // reference: generic kernel
+    {
+        const size_t lds = std::max<size_t>(M * K * 4, 64);
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((score_generic<MODE_STORE>), dim3(8192), dim3(kBlock), lds, 0, d_seq,
+                           32ull, 32, d_dense, M, K, 1, 0ull, rows, d_ref, 32ull, fo);
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("generic            ms=%8.3f  Gpos/s=%8.1f\n", ms, rows * 32 / ms * 1e-6);
+    }
+
+    // HBM calibration with the same traffic mix
+    {
+        std::vector<float> t;
+        for (int r = 0; r < reps; ++r) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(mix_copy, dim3(8192), dim3(256), 0, 0, (const uint4 *)d_seq,
+                               (float4 *)d_out, rows * 2);
+            CK(hipEventRecord(e1));
+            CK(hipDeviceSynchronize());
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            t.push_back(ms);
+        }
+        const double ms = median(t);
+        printf("mix_copy(1R+4W)    ms=%8.3f  GB/s=%8.1f\n", ms, rows * 32 * 5 / ms * 1e-6);
+        t.clear();
+        for (int r = 0; r < reps; ++r) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(fill_f4, dim3(8192), dim3(256), 0, 0, (float4 *)d_out, rows * 8,
+                               1.0f);
+            CK(hipEventRecord(e1));
+            CK(hipDeviceSynchronize());
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            t.push_back(ms);
+        }
+        printf("fill(4W)           ms=%8.3f  GB/s=%8.1f\n", median(t), rows * 32 * 4 / median(t) * 1e-6);
+    }
+
+    // VALU probes
+    for (int pk = 0; pk < 2; ++pk) {
+        const int iters = 4096;
+        float *d_tmp = d_out;
+        CK(hipMemset(d_tmp, 0, 64));
+        CK(hipEventRecord(e0));
+        if (pk)
+            hipLaunchKernelGGL(valu_probe<1>, dim3(256 * 8), dim3(256), 0, 0, d_tmp, iters);
+        else
+            hipLaunchKernelGGL(valu_probe<0>, dim3(256 * 8), dim3(256), 0, 0, d_tmp, iters);
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double adds = 256.0 * 8 * 256 * iters * 16;
+        printf("valu_probe pk=%d     ms=%8.3f  Tadd/s=%8.2f\n", pk, ms, adds / ms * 1e-9);
+    }
+
+    std::vector<Variant> vars = {
+        {"pf0_lp0", launch_v<0, 0>},  {"pf2_lp0", launch_v<2, 0>},  {"pf4_lp0", launch_v<4, 0>},
+        {"pf6_lp0", launch_v<6, 0>},  {"pf8_lp0", launch_v<8, 0>},  {"pf12_lp0", launch_v<12, 0>},
+        {"pf4_lp1", launch_v<4, 1>},  {"pf6_lp1", launch_v<6, 1>},  {"pf8_lp1", launch_v<8, 1>},
+        {"pf12_lp1", launch_v<12, 1>},
+    };
+    const int qs[] = {3, 6, 12, 25, 50, 100, 200};
+    const size_t lds = std::max<size_t>((size_t)K * table_stride(M) * 4, 64);
+    for (auto &v : vars) {
+        for (int q : qs) {
+            const unsigned long long T = (unsigned long long)q * M + 1;
+            if (T > rows)
+                continue;
+            const unsigned long long ns = (rows + T - 1) / T;
+            const dim3 grid((unsigned)((ns + kStreamsPerBlock - 1) / kStreamsPerBlock));
+            CK(hipMemset(d_out, 0xff, rows * 32 * 4));
+            CK(v.fn(grid, lds, 0, d_seq, d_table, K, 0, rows, T, ns, d_out, fo));
+            CK(hipMemset(d_bad, 0, 8));
+            hipLaunchKernelGGL(compare_bits, dim3(4096), dim3(256), 0, 0, (const unsigned *)d_ref,
+                               (const unsigned *)d_out, rows * 32, d_bad);
+            unsigned long long bad = 0;
+            CK(hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost));
+            std::vector<float> t;
+            for (int r = 0; r < reps; ++r) {
+                CK(hipEventRecord(e0));
+                CK(v.fn(grid, lds, 0, d_seq, d_table, K, 0, rows, T, ns, d_out, fo));
+                CK(hipEventRecord(e1));
+                CK(hipDeviceSynchronize());
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                t.push_back(ms);
+            }
+            std::sort(t.begin(), t.end());
+            const double ms = t[t.size() / 2];
+            printf("%-10s T=%5llu grid=%6u  ms=%8.3f (min %7.3f)  Gpos/s=%8.1f  GB/s=%8.1f  mismatches=%llu\n",
+                   v.name, T, grid.x, ms, t[0], rows * 32 / ms * 1e-6, rows * 32 * 5 / ms * 1e-6,
+                   bad);
+            fflush(stdout);
+        }
+    }
+
+    // fused argmax variants (no store): LDS/VALU-bound
+    {
+        ArgmaxRecord *d_rec;
+        CK(hipMalloc(&d_rec, sizeof(ArgmaxRecord) * 1000000));
+        fo.block_best = d_rec;
+        Variant avars[] = {{"am_pf6_lp0", launch_am<6, 0>}, {"am_pf6_lp1", launch_am<6, 1>}};
+        for (auto &v : avars)
+            for (int q : {12, 50, 200}) {
+                const unsigned long long T = (unsigned long long)q * M + 1;
+                if (T > rows)
+                    continue;
+                const unsigned long long ns = (rows + T - 1) / T;
+                const dim3 grid((unsigned)((ns + kStreamsPerBlock - 1) / kStreamsPerBlock));
+                std::vector<float> t;
+                for (int r = 0; r < reps; ++r) {
+                    CK(hipEventRecord(e0));
+                    CK(v.fn(grid, lds, 0, d_seq, d_table, K, 0, rows, T, ns, nullptr, fo));
+                    CK(hipEventRecord(e1));
+                    CK(hipDeviceSynchronize());
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    t.push_back(ms);
+                }
+                std::sort(t.begin(), t.end());
+                printf("%-10s T=%5llu grid=%6u  ms=%8.3f (min %7.3f)  Gpos/s=%8.1f\n", v.name, T,
+                       grid.x, t[t.size() / 2], t[0], rows * 32 / t[t.size() / 2] * 1e-6);
+            }
+    }
+    return 0;
+}
