@@ -1,0 +1,82 @@
+"""Builds ``liblightmotif_hip.so`` (HIP kernels + C ABI) for gfx950 with hipcc.
+
+Cross-compiles without a GPU.  Run as ``python -m lightmotif_amd.build`` or
+through ``__graft_entry__.build()``.  The library is written next to the
+sources (``lightmotif_amd/csrc/``) so it ships with the tree.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+ROOT = PKG.parent
+OBJ = CSRC / "_obj"
+LIB = CSRC / "liblightmotif_hip.so"
+
+ARCH = "gfx950"
+# -fno-slp-vectorize: packed v_pk_add_f32 measured slower than scalar v_add_f32 on
+# MI355X for this kernel (profiles/r01_kbench_*.txt).  -ffp-contract=off and no
+# fast-math: the score is M sequential IEEE adds (pli/mod.rs:98-102).
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fno-slp-vectorize", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+         f"-I{ROOT / 'include'}", f"-I{CSRC}"]
+# score_inst.hip is compiled 8 times: motif lengths 4*i+1 .. 4*i+4
+INST = [(i, 4 * i + 1, 4 * i + 4) for i in range(8)]
+UNITS = ["score.hip", "reduce.hip", "layout.hip", "api.hip"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP back-end cannot be built")
+    return exe
+
+
+def _newer(target: Path, deps: list[Path]) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def _run(cmd: list[str]) -> None:
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: " + " ".join(cmd) + "\n" + r.stdout)
+    if r.stdout.strip() and os.environ.get("LM_BUILD_VERBOSE"):
+        print(r.stdout)
+
+
+def build(force: bool = False, jobs: int | None = None) -> Path:
+    hipcc = _hipcc()
+    OBJ.mkdir(exist_ok=True)
+    headers = list(CSRC.glob("*.hpp")) + [ROOT / "include" / "lightmotif_hip.h", Path(__file__)]
+    cmds, objs = [], []
+    for unit in UNITS:
+        obj = OBJ / (unit + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [CSRC / unit] + headers):
+            cmds.append([hipcc, *FLAGS, "-c", str(CSRC / unit), "-o", str(obj)])
+    for inst, lo, hi in INST:
+        obj = OBJ / f"score_inst_{inst}.o"
+        objs.append(obj)
+        if force or _newer(obj, [CSRC / "score_inst.hip"] + headers):
+            cmds.append([hipcc, *FLAGS, f"-DLM_M_LO={lo}", f"-DLM_M_HI={hi}", f"-DLM_INST_ID={inst}",
+                         "-c", str(CSRC / "score_inst.hip"), "-o", str(obj)])
+    if cmds:
+        with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
+            list(ex.map(_run, cmds))
+    if cmds or force or not LIB.exists():
+        _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB),
+              *map(str, objs)])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,900 @@
+// api.hip -- the extern "C" surface declared in include/lightmotif_hip.h.
+//
+// Pre-checks and result shapes follow the reference wrappers:
+//   Avx2::score_f32_rows_into_permute (lightmotif/src/pli/platform/avx2.rs:817-851):
+//     wrap check (:832-837), degenerate check (:839-842), scores.resize (:844)
+//   Score::score_into (pli/mod.rs:109-117), StripedScores::{argmax,threshold}
+//     (scores.rs:181-213).
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "score_kernels.hpp"
+
+namespace lm {
+
+static thread_local char g_err[512] = "";
+
+int fail(int status, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return status;
+}
+
+int Scratch::reserve(size_t n)
+{
+    if (n <= bytes)
+        return LM_HIP_OK;
+    if (ptr) {
+        LM_HIP_TRY(hipFree(ptr));
+        ptr = nullptr;
+        bytes = 0;
+    }
+    const size_t want = (n + (1u << 20) - 1) & ~((size_t)(1u << 20) - 1);
+    LM_HIP_TRY(hipMalloc(&ptr, want));
+    bytes = want;
+    return LM_HIP_OK;
+}
+
+void Scratch::release()
+{
+    if (ptr)
+        (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess)
+            prev = -1;
+        if (prev != dev)
+            ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+
+static int check_score_args(const lm_hip_pssm *pssm, size_t seq_rows_total, size_t seq_stride,
+                            size_t cols, size_t wrap, size_t row_begin, size_t row_end)
+{
+    if (!pssm)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score: null pssm");
+    if (cols == 0 || seq_stride < cols)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score: stride %zu < columns %zu", seq_stride, cols);
+    if (wrap > seq_rows_total)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score: wrap %zu > matrix rows %zu", wrap, seq_rows_total);
+    // avx2.rs:832-837
+    if (pssm->m > 0 && wrap < pssm->m - 1)
+        return fail(LM_HIP_ERR_WRAP, "not enough wrapping rows for motif of length %zu", pssm->m);
+    if (row_begin < row_end && row_end > seq_rows_total - wrap)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score: row range %zu..%zu exceeds the %zu sequence rows",
+                    row_begin, row_end, seq_rows_total - wrap);
+    return LM_HIP_OK;
+}
+
+static int default_ctx(lm_hip_ctx **out)
+{
+    static std::mutex mu;
+    static lm_hip_ctx *ctx = nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ctx) {
+        int dev = 0;
+        if (const char *e = getenv("LM_HIP_DEVICE"))
+            dev = atoi(e);
+        LM_TRY(lm_hip_ctx_create(dev, &ctx));
+    }
+    *out = ctx;
+    return LM_HIP_OK;
+}
+
+}  // namespace lm
+
+using namespace lm;
+
+extern "C" {
+
+// ---- library ----------------------------------------------------------------------------
+
+int lm_hip_abi_version(void) { return LM_HIP_ABI_VERSION; }
+
+const char *lm_hip_last_error(void) { return g_err; }
+
+int lm_hip_device_count(int *count)
+{
+    if (!count)
+        return fail(LM_HIP_ERR_BAD_ARGS, "device_count: null output");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        n = 0;
+    int usable = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0)
+            ++usable;
+    }
+    *count = usable;
+    return LM_HIP_OK;
+}
+
+void lm_hip_free(void *p) { free(p); }
+
+size_t lm_hip_stride(size_t cols, size_t elem_size)
+{
+    // dense.rs:43-48 (Row is repr(align(32)) on x86-64) + dense.rs:126-128
+    if (elem_size == 0)
+        return 0;
+    const size_t bytes = (cols * elem_size + 31) / 32 * 32;
+    return bytes / elem_size;
+}
+
+// ---- context ----------------------------------------------------------------------------
+
+static int ctx_create(int device, void *stream, bool borrow, lm_hip_ctx **out)
+{
+    if (!out)
+        return fail(LM_HIP_ERR_BAD_ARGS, "ctx_create: null output");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+        return fail(LM_HIP_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= n)
+        return fail(LM_HIP_ERR_NO_DEVICE, "device %d out of range (%d devices)", device, n);
+    hipDeviceProp_t prop;
+    LM_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(LM_HIP_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
+                    device, prop.gcnArchName);
+    DeviceGuard guard(device);
+    if (!guard.ok)
+        return fail(LM_HIP_ERR_HIP, "hipSetDevice(%d) failed", device);
+    lm_hip_ctx *ctx = new (std::nothrow) lm_hip_ctx();
+    if (!ctx)
+        return fail(LM_HIP_ERR_OOM, "out of host memory");
+    ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount;
+    if (borrow) {
+        ctx->stream = static_cast<hipStream_t>(stream);
+        ctx->owns_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            return fail(LM_HIP_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+        }
+        ctx->owns_stream = true;
+    }
+    hipError_t e = hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        if (ctx->owns_stream)
+            (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return fail(LM_HIP_ERR_OOM, "hipHostMalloc failed: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return LM_HIP_OK;
+}
+
+int lm_hip_ctx_create(int device, lm_hip_ctx **out) { return ctx_create(device, nullptr, false, out); }
+
+int lm_hip_ctx_create_on_stream(int device, void *hip_stream, lm_hip_ctx **out)
+{
+    return ctx_create(device, hip_stream, true, out);
+}
+
+int lm_hip_ctx_destroy(lm_hip_ctx *ctx)
+{
+    if (!ctx)
+        return LM_HIP_OK;
+    DeviceGuard guard(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->scratch.release();
+    ctx->scratch2.release();
+    if (ctx->pinned)
+        (void)hipHostFree(ctx->pinned);
+    if (ctx->owns_stream)
+        (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return LM_HIP_OK;
+}
+
+int lm_hip_ctx_sync(lm_hip_ctx *ctx)
+{
+    if (!ctx)
+        return fail(LM_HIP_ERR_BAD_ARGS, "null context");
+    DeviceGuard guard(ctx->device);
+    LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return LM_HIP_OK;
+}
+
+int lm_hip_ctx_stream(lm_hip_ctx *ctx, void **hip_stream)
+{
+    if (!ctx || !hip_stream)
+        return fail(LM_HIP_ERR_BAD_ARGS, "null argument");
+    *hip_stream = ctx->stream;
+    return LM_HIP_OK;
+}
+
+int lm_hip_ctx_set_rows_per_stream(lm_hip_ctx *ctx, size_t rows)
+{
+    if (!ctx)
+        return fail(LM_HIP_ERR_BAD_ARGS, "null context");
+    ctx->rows_per_stream = rows;
+    return LM_HIP_OK;
+}
+
+const char *lm_hip_ctx_last_kernel(lm_hip_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
+
+// ---- PSSM ---------------------------------------------------------------------------------
+
+int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stride, size_t k,
+                       lm_hip_pssm **out)
+{
+    if (!ctx || !out || (!pssm && m))
+        return fail(LM_HIP_ERR_BAD_ARGS, "pssm_create: null argument");
+    *out = nullptr;
+    if (k == 0 || k > 256 || stride < k)
+        return fail(LM_HIP_ERR_BAD_ARGS, "pssm_create: bad alphabet size %zu / stride %zu", k, stride);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    lm_hip_pssm *p = new (std::nothrow) lm_hip_pssm();
+    if (!p)
+        return fail(LM_HIP_ERR_OOM, "out of host memory");
+    p->device = ctx->device;
+    p->m = m;
+    p->k = k;
+    p->host.resize(m * k);
+    for (size_t j = 0; j < m; ++j)
+        for (size_t s = 0; s < k; ++s)
+            p->host[j * k + s] = pssm[j * stride + s];
+    auto cleanup = [&](int st) {
+        lm_hip_pssm_destroy(p);
+        return st;
+    };
+    if (m) {
+        hipError_t e = hipMalloc(&p->d_dense, m * k * sizeof(float));
+        if (e != hipSuccess)
+            return cleanup(fail(LM_HIP_ERR_OOM, "hipMalloc(pssm) failed: %s", hipGetErrorString(e)));
+        e = hipMemcpyAsync(p->d_dense, p->host.data(), m * k * sizeof(float), hipMemcpyHostToDevice,
+                           ctx->stream);
+        if (e != hipSuccess)
+            return cleanup(fail(LM_HIP_ERR_HIP, "pssm upload failed: %s", hipGetErrorString(e)));
+        if (m <= (size_t)kMaxFastM) {
+            // transposed, padded table of score_c32<M>: table[s * ts + j] = pssm[j][s]
+            p->ts = (size_t)table_stride((int)m);
+            std::vector<float> table(k * p->ts, 0.0f);
+            for (size_t s = 0; s < k; ++s)
+                for (size_t j = 0; j < m; ++j)
+                    table[s * p->ts + j] = p->host[j * k + s];
+            e = hipMalloc(&p->d_table, table.size() * sizeof(float));
+            if (e != hipSuccess)
+                return cleanup(fail(LM_HIP_ERR_OOM, "hipMalloc(table) failed: %s", hipGetErrorString(e)));
+            e = hipMemcpyAsync(p->d_table, table.data(), table.size() * sizeof(float),
+                               hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(ctx->stream);  // `table` dies with this scope
+            if (e != hipSuccess)
+                return cleanup(fail(LM_HIP_ERR_HIP, "table upload failed: %s", hipGetErrorString(e)));
+        }
+        e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess)
+            return cleanup(fail(LM_HIP_ERR_HIP, "pssm upload failed: %s", hipGetErrorString(e)));
+    }
+    *out = p;
+    return LM_HIP_OK;
+}
+
+int lm_hip_pssm_destroy(lm_hip_pssm *p)
+{
+    if (!p)
+        return LM_HIP_OK;
+    DeviceGuard guard(p->device);
+    if (p->d_dense)
+        (void)hipFree(p->d_dense);
+    if (p->d_table)
+        (void)hipFree(p->d_table);
+    delete p;
+    return LM_HIP_OK;
+}
+
+size_t lm_hip_pssm_len(const lm_hip_pssm *p) { return p ? p->m : 0; }
+
+// ---- Score (device pointers) -----------------------------------------------------------------
+
+int lm_hip_score_f32_dptr(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const uint8_t *d_seq,
+                          size_t seq_rows_total, size_t seq_stride, size_t cols, size_t wrap,
+                          size_t length, size_t row_begin, size_t row_end, float *d_out,
+                          size_t out_stride, size_t *out_rows, size_t *max_index)
+{
+    if (!ctx)
+        return fail(LM_HIP_ERR_BAD_ARGS, "null context");
+    LM_TRY(check_score_args(pssm, seq_rows_total, seq_stride, cols, wrap, row_begin, row_end));
+    // pli/mod.rs:85-88
+    if (length < pssm->m || row_begin >= row_end) {
+        if (out_rows) *out_rows = 0;
+        if (max_index) *max_index = 0;
+        return LM_HIP_OK;
+    }
+    if (!d_seq || !d_out || out_stride < cols)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score: null buffer or out stride %zu < columns %zu",
+                    out_stride, cols);
+    if (out_rows) *out_rows = row_end - row_begin;       // pli/mod.rs:91
+    if (max_index) *max_index = length + 1 - pssm->m;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    ScoreArgs a{pssm, d_seq, seq_stride, cols, row_begin, row_end, d_out, out_stride};
+    return launch_score_store(ctx, a);
+}
+
+static void record_to_coords(const ArgmaxRecord &rec, size_t cols, int *found, lm_hip_coords *best,
+                             float *value)
+{
+    if (found)
+        *found = rec.found;
+    if (rec.found) {
+        if (best) {
+            best->row = (size_t)(rec.index / (long long)cols);
+            best->col = (size_t)(rec.index % (long long)cols);
+        }
+        if (value)
+            *value = rec.value;
+    }
+}
+
+int lm_hip_argmax_f32_dptr(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride,
+                           size_t cols, int *found, lm_hip_coords *best, float *value)
+{
+    if (!ctx || !found)
+        return fail(LM_HIP_ERR_BAD_ARGS, "argmax: null argument");
+    *found = 0;
+    if (rows == 0)  // pli/mod.rs:136-138
+        return LM_HIP_OK;
+    if (!d_scores || cols == 0 || stride < cols)
+        return fail(LM_HIP_ERR_BAD_ARGS, "argmax: bad matrix (stride %zu, columns %zu)", stride, cols);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    ArgmaxRecord rec{};
+    LM_TRY(launch_argmax(ctx, d_scores, rows, stride, cols, &rec));
+    record_to_coords(rec, cols, found, best, value);
+    return LM_HIP_OK;
+}
+
+int lm_hip_threshold_f32_dptr(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride,
+                              size_t cols, float t, lm_hip_coords **coords, size_t *n)
+{
+    if (!ctx || !coords || !n)
+        return fail(LM_HIP_ERR_BAD_ARGS, "threshold: null argument");
+    *coords = nullptr;
+    *n = 0;
+    if (rows == 0)
+        return LM_HIP_OK;
+    if (!d_scores || cols == 0 || stride < cols)
+        return fail(LM_HIP_ERR_BAD_ARGS, "threshold: bad matrix (stride %zu, columns %zu)", stride, cols);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    return launch_threshold(ctx, d_scores, rows, stride, cols, t, coords, n);
+}
+
+// ---- fused ---------------------------------------------------------------------------------------
+
+int lm_hip_score_argmax_f32_dptr(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const uint8_t *d_seq,
+                                 size_t seq_rows_total, size_t seq_stride, size_t cols, size_t wrap,
+                                 size_t length, size_t row_begin, size_t row_end, int *found,
+                                 lm_hip_coords *best, float *value)
+{
+    if (!ctx || !found)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score_argmax: null argument");
+    *found = 0;
+    LM_TRY(check_score_args(pssm, seq_rows_total, seq_stride, cols, wrap, row_begin, row_end));
+    if (length < pssm->m || row_begin >= row_end)
+        return LM_HIP_OK;  // empty scores -> None
+    if (!d_seq)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score_argmax: null sequence");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    ScoreArgs a{pssm, d_seq, seq_stride, cols, row_begin, row_end, nullptr, 0};
+    ArgmaxRecord rec{};
+    LM_TRY(launch_score_argmax(ctx, a, &rec));
+    record_to_coords(rec, cols, found, best, value);
+    return LM_HIP_OK;
+}
+
+int lm_hip_score_threshold_f32_dptr(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const uint8_t *d_seq,
+                                    size_t seq_rows_total, size_t seq_stride, size_t cols,
+                                    size_t wrap, size_t length, size_t row_begin, size_t row_end,
+                                    float t, lm_hip_coords **coords, float **values, size_t *n)
+{
+    if (!ctx || !coords || !n)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score_threshold: null argument");
+    *coords = nullptr;
+    if (values)
+        *values = nullptr;
+    *n = 0;
+    LM_TRY(check_score_args(pssm, seq_rows_total, seq_stride, cols, wrap, row_begin, row_end));
+    if (length < pssm->m || row_begin >= row_end)
+        return LM_HIP_OK;
+    if (!d_seq)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score_threshold: null sequence");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    ScoreArgs a{pssm, d_seq, seq_stride, cols, row_begin, row_end, nullptr, 0};
+    std::vector<unsigned long long> flat;
+    std::vector<float> vals;
+    LM_TRY(launch_score_threshold(ctx, a, t, &flat, &vals));
+    if (flat.empty())
+        return LM_HIP_OK;
+    lm_hip_coords *c = static_cast<lm_hip_coords *>(malloc(flat.size() * sizeof(lm_hip_coords)));
+    float *v = values ? static_cast<float *>(malloc(flat.size() * sizeof(float))) : nullptr;
+    if (!c || (values && !v)) {
+        free(c);
+        free(v);
+        return fail(LM_HIP_ERR_OOM, "score_threshold: cannot allocate %zu hits", flat.size());
+    }
+    for (size_t i = 0; i < flat.size(); ++i) {
+        c[i].row = (size_t)(flat[i] / cols);
+        c[i].col = (size_t)(flat[i] % cols);
+        if (v)
+            v[i] = vals[i];
+    }
+    *coords = c;
+    if (values)
+        *values = v;
+    *n = flat.size();
+    return LM_HIP_OK;
+}
+
+// ---- Encode / Stripe (device pointers) ---------------------------------------------------------------
+
+int lm_hip_encode_dptr(lm_hip_ctx *ctx, char alphabet, const uint8_t *d_ascii, size_t len, int lossy,
+                       uint8_t *d_dst, size_t *bad_index)
+{
+    if (!ctx || (len && (!d_ascii || !d_dst)))
+        return fail(LM_HIP_ERR_BAD_ARGS, "encode: null argument");
+    if (alphabet != 'D' && alphabet != 'P')
+        return fail(LM_HIP_ERR_BAD_ARGS, "encode: alphabet must be 'D' or 'P'");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    return launch_encode(ctx, alphabet, d_ascii, len, lossy, d_dst, bad_index);
+}
+
+int lm_hip_stripe_dptr(lm_hip_ctx *ctx, const uint8_t *d_encoded, size_t len, size_t cols,
+                       uint8_t default_symbol, size_t wrap, uint8_t *d_data, size_t stride)
+{
+    if (!ctx || cols == 0 || stride < cols || (len && (!d_encoded || !d_data)))
+        return fail(LM_HIP_ERR_BAD_ARGS, "stripe: bad argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    return launch_stripe(ctx, d_encoded, len, cols, default_symbol, wrap, d_data, stride);
+}
+
+int lm_hip_configure_wrap_dptr(lm_hip_ctx *ctx, uint8_t *d_data, size_t rows, size_t stride,
+                               size_t cols, size_t new_wrap, uint8_t default_symbol)
+{
+    if (!ctx || cols == 0 || stride < cols || (new_wrap && !d_data))
+        return fail(LM_HIP_ERR_BAD_ARGS, "configure_wrap: bad argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    return launch_wrap(ctx, d_data, rows, stride, cols, new_wrap, default_symbol);
+}
+
+// ---- resident handles ---------------------------------------------------------------------------------
+
+static int seq_alloc(lm_hip_ctx *ctx, size_t rows, size_t stride, size_t cols, size_t length,
+                     size_t k, lm_hip_seq **out)
+{
+    lm_hip_seq *s = new (std::nothrow) lm_hip_seq();
+    if (!s)
+        return fail(LM_HIP_ERR_OOM, "out of host memory");
+    s->device = ctx->device;
+    s->rows = rows;
+    s->stride = stride;
+    s->cols = cols;
+    s->length = length;
+    s->k = k;
+    s->capacity_rows = rows + 32;  // seq.rs:285 DEFAULT_EXTRA_ROWS
+    hipError_t e = hipMalloc(&s->d_data, s->capacity_rows * stride);
+    if (e != hipSuccess) {
+        delete s;
+        return fail(LM_HIP_ERR_OOM, "hipMalloc(sequence) failed: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return LM_HIP_OK;
+}
+
+int lm_hip_seq_upload(lm_hip_ctx *ctx, const uint8_t *data, size_t rows_total, size_t stride,
+                      size_t cols, size_t wrap, size_t length, size_t k, lm_hip_seq **out)
+{
+    if (!ctx || !out || (rows_total && !data))
+        return fail(LM_HIP_ERR_BAD_ARGS, "seq_upload: null argument");
+    *out = nullptr;
+    if (cols == 0 || stride < cols || wrap > rows_total || k == 0 || k > 256)
+        return fail(LM_HIP_ERR_BAD_ARGS, "seq_upload: bad geometry");
+    if ((rows_total - wrap) * cols < length)  // seq.rs:303-304 InvalidData
+        return fail(LM_HIP_ERR_BAD_ARGS, "seq_upload: matrix stores fewer than %zu symbols", length);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    lm_hip_seq *s = nullptr;
+    LM_TRY(seq_alloc(ctx, rows_total - wrap, stride, cols, length, k, &s));
+    if (s->capacity_rows < rows_total) {
+        lm_hip_seq_destroy(s);
+        return fail(LM_HIP_ERR_BAD_ARGS, "seq_upload: wrap too large");
+    }
+    s->wrap = wrap;
+    if (rows_total) {
+        hipError_t e = hipMemcpyAsync(s->d_data, data, rows_total * stride, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            lm_hip_seq_destroy(s);
+            return fail(LM_HIP_ERR_HIP, "sequence upload failed: %s", hipGetErrorString(e));
+        }
+    }
+    *out = s;
+    return LM_HIP_OK;
+}
+
+static int seq_from_device_encoded(lm_hip_ctx *ctx, const uint8_t *d_enc, size_t len, size_t cols,
+                                   size_t k, lm_hip_seq **out)
+{
+    const size_t rows = (len + cols - 1) / cols;
+    const size_t stride = lm_hip_stride(cols, 1);
+    lm_hip_seq *s = nullptr;
+    LM_TRY(seq_alloc(ctx, rows, stride, cols, len, k, &s));
+    int st = launch_stripe(ctx, d_enc, len, cols, (uint8_t)(k - 1), 0, s->d_data, stride);
+    if (st == LM_HIP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
+        st = fail(LM_HIP_ERR_HIP, "stripe failed");
+    if (st != LM_HIP_OK) {
+        lm_hip_seq_destroy(s);
+        return st;
+    }
+    *out = s;
+    return LM_HIP_OK;
+}
+
+int lm_hip_seq_from_encoded(lm_hip_ctx *ctx, const uint8_t *encoded, size_t len, size_t cols,
+                            size_t k, lm_hip_seq **out)
+{
+    if (!ctx || !out || (len && !encoded) || cols == 0 || k == 0 || k > 256)
+        return fail(LM_HIP_ERR_BAD_ARGS, "seq_from_encoded: bad argument");
+    *out = nullptr;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    LM_TRY(ctx->scratch2.reserve(len + 16));
+    uint8_t *d_enc = static_cast<uint8_t *>(ctx->scratch2.ptr);
+    if (len)
+        LM_HIP_TRY(hipMemcpyAsync(d_enc, encoded, len, hipMemcpyHostToDevice, ctx->stream));
+    return seq_from_device_encoded(ctx, d_enc, len, cols, k, out);
+}
+
+int lm_hip_seq_from_ascii(lm_hip_ctx *ctx, char alphabet, const uint8_t *ascii, size_t len,
+                          size_t cols, int lossy, lm_hip_seq **out, size_t *bad_index)
+{
+    if (!ctx || !out || (len && !ascii) || cols == 0)
+        return fail(LM_HIP_ERR_BAD_ARGS, "seq_from_ascii: bad argument");
+    if (alphabet != 'D' && alphabet != 'P')
+        return fail(LM_HIP_ERR_BAD_ARGS, "seq_from_ascii: alphabet must be 'D' or 'P'");
+    *out = nullptr;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    LM_TRY(ctx->scratch2.reserve(2 * len + 32));
+    uint8_t *d_ascii = static_cast<uint8_t *>(ctx->scratch2.ptr);
+    uint8_t *d_enc = d_ascii + (len + 15) / 16 * 16;
+    if (len)
+        LM_HIP_TRY(hipMemcpyAsync(d_ascii, ascii, len, hipMemcpyHostToDevice, ctx->stream));
+    LM_TRY(launch_encode(ctx, alphabet, d_ascii, len, lossy, d_enc, bad_index));
+    return seq_from_device_encoded(ctx, d_enc, len, cols, alphabet == 'P' ? 21 : 5, out);
+}
+
+int lm_hip_seq_configure_wrap(lm_hip_ctx *ctx, lm_hip_seq *seq, size_t m)
+{
+    if (!ctx || !seq)
+        return fail(LM_HIP_ERR_BAD_ARGS, "configure_wrap: null argument");
+    if (m <= seq->wrap)  // seq.rs:370
+        return LM_HIP_OK;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    if (seq->rows + m > seq->capacity_rows) {
+        const size_t cap = seq->rows + m + 32;
+        uint8_t *nd = nullptr;
+        LM_HIP_TRY(hipMalloc(&nd, cap * seq->stride));
+        hipError_t e = hipMemcpyAsync(nd, seq->d_data, seq->rows * seq->stride, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(nd);
+            return fail(LM_HIP_ERR_HIP, "sequence regrow failed: %s", hipGetErrorString(e));
+        }
+        (void)hipFree(seq->d_data);
+        seq->d_data = nd;
+        seq->capacity_rows = cap;
+    }
+    LM_TRY(launch_wrap(ctx, seq->d_data, seq->rows, seq->stride, seq->cols, m, (uint8_t)(seq->k - 1)));
+    seq->wrap = m;
+    return LM_HIP_OK;
+}
+
+int lm_hip_seq_info(const lm_hip_seq *seq, size_t *length, size_t *wrap, size_t *rows,
+                    size_t *stride, size_t *cols, const uint8_t **d_data)
+{
+    if (!seq)
+        return fail(LM_HIP_ERR_BAD_ARGS, "seq_info: null sequence");
+    if (length) *length = seq->length;
+    if (wrap) *wrap = seq->wrap;
+    if (rows) *rows = seq->rows;
+    if (stride) *stride = seq->stride;
+    if (cols) *cols = seq->cols;
+    if (d_data) *d_data = seq->d_data;
+    return LM_HIP_OK;
+}
+
+int lm_hip_seq_download(lm_hip_ctx *ctx, const lm_hip_seq *seq, uint8_t *dst)
+{
+    if (!ctx || !seq || !dst)
+        return fail(LM_HIP_ERR_BAD_ARGS, "seq_download: null argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    const size_t bytes = (seq->rows + seq->wrap) * seq->stride;
+    if (bytes) {
+        LM_HIP_TRY(hipMemcpyAsync(dst, seq->d_data, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return LM_HIP_OK;
+}
+
+int lm_hip_seq_destroy(lm_hip_seq *seq)
+{
+    if (!seq)
+        return LM_HIP_OK;
+    DeviceGuard guard(seq->device);
+    if (seq->d_data)
+        (void)hipFree(seq->d_data);
+    delete seq;
+    return LM_HIP_OK;
+}
+
+int lm_hip_scores_create(lm_hip_ctx *ctx, size_t cols, lm_hip_scores **out)
+{
+    if (!ctx || !out || cols == 0)
+        return fail(LM_HIP_ERR_BAD_ARGS, "scores_create: bad argument");
+    lm_hip_scores *s = new (std::nothrow) lm_hip_scores();
+    if (!s)
+        return fail(LM_HIP_ERR_OOM, "out of host memory");
+    s->device = ctx->device;
+    s->cols = cols;
+    s->stride = lm_hip_stride(cols, sizeof(float));
+    *out = s;
+    return LM_HIP_OK;
+}
+
+int lm_hip_scores_info(const lm_hip_scores *s, size_t *rows, size_t *stride, size_t *cols,
+                       size_t *max_index, const float **d_data)
+{
+    if (!s)
+        return fail(LM_HIP_ERR_BAD_ARGS, "scores_info: null scores");
+    if (rows) *rows = s->rows;
+    if (stride) *stride = s->stride;
+    if (cols) *cols = s->cols;
+    if (max_index) *max_index = s->max_index;
+    if (d_data) *d_data = s->d_data;
+    return LM_HIP_OK;
+}
+
+int lm_hip_scores_download(lm_hip_ctx *ctx, const lm_hip_scores *s, float *dst)
+{
+    if (!ctx || !s || (s->rows && !dst))
+        return fail(LM_HIP_ERR_BAD_ARGS, "scores_download: null argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    if (s->rows) {
+        LM_HIP_TRY(hipMemcpyAsync(dst, s->d_data, s->rows * s->stride * sizeof(float),
+                                  hipMemcpyDeviceToHost, ctx->stream));
+        LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return LM_HIP_OK;
+}
+
+int lm_hip_scores_destroy(lm_hip_scores *s)
+{
+    if (!s)
+        return LM_HIP_OK;
+    DeviceGuard guard(s->device);
+    if (s->d_data)
+        (void)hipFree(s->d_data);
+    delete s;
+    return LM_HIP_OK;
+}
+
+// scores.resize(rows, max_index) (scores.rs:148-152): grows the allocation when needed.
+static int scores_resize(lm_hip_ctx *ctx, lm_hip_scores *s, size_t rows, size_t max_index)
+{
+    if (rows > s->capacity_rows) {
+        LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (s->d_data)
+            LM_HIP_TRY(hipFree(s->d_data));
+        s->d_data = nullptr;
+        s->capacity_rows = 0;
+        LM_HIP_TRY(hipMalloc(&s->d_data, rows * s->stride * sizeof(float)));
+        s->capacity_rows = rows;
+    }
+    s->rows = rows;
+    s->max_index = max_index;
+    return LM_HIP_OK;
+}
+
+int lm_hip_score_rows_into(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *seq,
+                           size_t row_begin, size_t row_end, lm_hip_scores *scores)
+{
+    if (!ctx || !pssm || !seq || !scores)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score_rows_into: null argument");
+    if (scores->cols != seq->cols)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score_rows_into: scores have %zu columns, sequence %zu",
+                    scores->cols, seq->cols);
+    LM_TRY(check_score_args(pssm, seq->rows + seq->wrap, seq->stride, seq->cols, seq->wrap,
+                            row_begin, row_end));
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    if (seq->length < pssm->m || row_begin >= row_end)  // pli/mod.rs:85-88
+        return scores_resize(ctx, scores, 0, 0);
+    LM_TRY(scores_resize(ctx, scores, row_end - row_begin, seq->length + 1 - pssm->m));
+    ScoreArgs a{pssm, seq->d_data, seq->stride, seq->cols, row_begin, row_end, scores->d_data,
+                scores->stride};
+    return launch_score_store(ctx, a);
+}
+
+int lm_hip_score_into(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *seq,
+                      lm_hip_scores *scores)
+{
+    if (!seq)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score_into: null sequence");
+    return lm_hip_score_rows_into(ctx, pssm, seq, 0, seq->rows, scores);  // pli/mod.rs:115-116
+}
+
+int lm_hip_argmax(lm_hip_ctx *ctx, const lm_hip_scores *s, int *found, lm_hip_coords *best,
+                  float *value)
+{
+    if (!s)
+        return fail(LM_HIP_ERR_BAD_ARGS, "argmax: null scores");
+    return lm_hip_argmax_f32_dptr(ctx, s->d_data, s->rows, s->stride, s->cols, found, best, value);
+}
+
+int lm_hip_threshold(lm_hip_ctx *ctx, const lm_hip_scores *s, float t, lm_hip_coords **coords,
+                     size_t *n)
+{
+    if (!s)
+        return fail(LM_HIP_ERR_BAD_ARGS, "threshold: null scores");
+    return lm_hip_threshold_f32_dptr(ctx, s->d_data, s->rows, s->stride, s->cols, t, coords, n);
+}
+
+// ---- host-pointer convenience forms ----------------------------------------------------------------------
+
+int lm_hip_score_f32(const uint8_t *seq, size_t seq_rows_total, size_t seq_stride, size_t cols,
+                     size_t wrap, size_t length, const float *pssm, size_t m, size_t pssm_stride,
+                     size_t k, size_t row_begin, size_t row_end, float *out, size_t out_stride,
+                     size_t *out_rows, size_t *max_index)
+{
+    lm_hip_ctx *ctx = nullptr;
+    LM_TRY(default_ctx(&ctx));
+    lm_hip_pssm *p = nullptr;
+    LM_TRY(lm_hip_pssm_create(ctx, pssm, m, pssm_stride, k, &p));
+    int st = check_score_args(p, seq_rows_total, seq_stride, cols, wrap, row_begin, row_end);
+    size_t orow = 0, mi = 0;
+    if (st == LM_HIP_OK && !(length < m || row_begin >= row_end)) {
+        if (!seq || !out || out_stride < cols) {
+            st = fail(LM_HIP_ERR_BAD_ARGS, "score: null buffer or bad output stride");
+        } else {
+            // ship only the rows the range needs: [row_begin, row_end + m - 1)
+            const size_t nrows_in = (row_end - row_begin) + (m ? m - 1 : 0);
+            const size_t nrows_out = row_end - row_begin;
+            std::lock_guard<std::mutex> lock(ctx->mu);
+            DeviceGuard guard(ctx->device);
+            uint8_t *d_seq = nullptr;
+            float *d_out = nullptr;
+            hipError_t e = hipMalloc(&d_seq, nrows_in * seq_stride + 64);
+            if (e == hipSuccess)
+                e = hipMalloc(&d_out, nrows_out * out_stride * sizeof(float));
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(d_seq, seq + row_begin * seq_stride, nrows_in * seq_stride,
+                                   hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) {
+                st = fail(e == hipErrorOutOfMemory ? LM_HIP_ERR_OOM : LM_HIP_ERR_HIP,
+                          "score: staging failed: %s", hipGetErrorString(e));
+            } else {
+                ScoreArgs a{p, d_seq, seq_stride, cols, 0, nrows_out, d_out, out_stride};
+                st = launch_score_store(ctx, a);
+                if (st == LM_HIP_OK) {
+                    e = hipMemcpyAsync(out, d_out, nrows_out * out_stride * sizeof(float),
+                                       hipMemcpyDeviceToHost, ctx->stream);
+                    if (e == hipSuccess)
+                        e = hipStreamSynchronize(ctx->stream);
+                    if (e != hipSuccess)
+                        st = fail(LM_HIP_ERR_HIP, "score: read-back failed: %s", hipGetErrorString(e));
+                }
+            }
+            if (d_seq) (void)hipFree(d_seq);
+            if (d_out) (void)hipFree(d_out);
+            orow = nrows_out;
+            mi = length + 1 - m;
+        }
+    }
+    lm_hip_pssm_destroy(p);
+    if (st == LM_HIP_OK) {
+        if (out_rows) *out_rows = orow;
+        if (max_index) *max_index = mi;
+    }
+    return st;
+}
+
+static int stage_scores(lm_hip_ctx *ctx, const float *scores, size_t rows, size_t stride,
+                        float **d_scores)
+{
+    LM_HIP_TRY(hipMalloc(d_scores, rows * stride * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(*d_scores, scores, rows * stride * sizeof(float),
+                                  hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(*d_scores);
+        return fail(LM_HIP_ERR_HIP, "score upload failed: %s", hipGetErrorString(e));
+    }
+    return LM_HIP_OK;
+}
+
+int lm_hip_argmax_f32(const float *scores, size_t rows, size_t stride, size_t cols, int *found,
+                      lm_hip_coords *best, float *value)
+{
+    if (!found)
+        return fail(LM_HIP_ERR_BAD_ARGS, "argmax: null argument");
+    *found = 0;
+    if (rows == 0)
+        return LM_HIP_OK;
+    if (!scores || cols == 0 || stride < cols)
+        return fail(LM_HIP_ERR_BAD_ARGS, "argmax: bad matrix");
+    lm_hip_ctx *ctx = nullptr;
+    LM_TRY(default_ctx(&ctx));
+    float *d = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        DeviceGuard guard(ctx->device);
+        LM_TRY(stage_scores(ctx, scores, rows, stride, &d));
+    }
+    const int st = lm_hip_argmax_f32_dptr(ctx, d, rows, stride, cols, found, best, value);
+    DeviceGuard guard(ctx->device);
+    (void)hipFree(d);
+    return st;
+}
+
+int lm_hip_threshold_f32(const float *scores, size_t rows, size_t stride, size_t cols, float t,
+                         lm_hip_coords **coords, size_t *n)
+{
+    if (!coords || !n)
+        return fail(LM_HIP_ERR_BAD_ARGS, "threshold: null argument");
+    *coords = nullptr;
+    *n = 0;
+    if (rows == 0)
+        return LM_HIP_OK;
+    if (!scores || cols == 0 || stride < cols)
+        return fail(LM_HIP_ERR_BAD_ARGS, "threshold: bad matrix");
+    lm_hip_ctx *ctx = nullptr;
+    LM_TRY(default_ctx(&ctx));
+    float *d = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        DeviceGuard guard(ctx->device);
+        LM_TRY(stage_scores(ctx, scores, rows, stride, &d));
+    }
+    const int st = lm_hip_threshold_f32_dptr(ctx, d, rows, stride, cols, t, coords, n);
+    DeviceGuard guard(ctx->device);
+    (void)hipFree(d);
+    return st;
+}
+
+}  // extern "C"

@@ -1,0 +1,348 @@
+// reduce.hip -- argmax / max / threshold over a materialised StripedScores matrix.
+//
+// Semantics follow the reference's *Generic* bodies, which differ from its AVX2
+// and SSE2 ones on ties:
+//   argmax    lightmotif/src/pli/mod.rs:135-155  `x >= best` in a row-major scan
+//             => the maximal cell that is LAST in (row, col) order; NaN never wins;
+//             scores[0][0] == NaN => (0, 0)
+//   max       pli/mod.rs:158-160                 value at argmax
+//   threshold pli/mod.rs:210-221                 every cell with x >= t, pushed in
+//             row-major order (NaN never selected)
+// All of them scan the whole rows x cols matrix, padded tail included (scores.rs:181-213
+// do not clip to max_index).
+//
+// These are pure streaming reads (4 B per cell): the roofline is HBM.
+#include <algorithm>
+
+#include "score_kernels.hpp"
+
+namespace lm {
+
+int finalize_argmax_materialised(lm_hip_ctx *ctx, const ArgmaxRecord *d_blocks, unsigned nblocks,
+                                 const float *d_scores, ArgmaxRecord *d_out);
+
+// ---- argmax ---------------------------------------------------------------------------
+
+// Contiguous case (stride == cols): the matrix is one flat array of `ncells`
+// floats whose index IS the row-major rank.  16-byte loads, grid-stride.
+__global__ __launch_bounds__(kBlock) void argmax_flat(const float *__restrict__ s,
+                                                      const unsigned long long ncells,
+                                                      ArgmaxRecord *__restrict__ blocks)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    float v = -INFINITY;
+    long long bi = -1;
+    const unsigned long long n4 = ncells / 4;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 *s4 = reinterpret_cast<const f32x4 *>(s);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < n4;
+         i += (unsigned long long)gridDim.x * kBlock) {
+        const f32x4 x = __builtin_nontemporal_load(&s4[i]);
+        const long long base = (long long)(i * 4);
+        // ascending index order inside the thread, so `>=` keeps the later cell
+        if (x.x >= v) { v = x.x; bi = base; }
+        if (x.y >= v) { v = x.y; bi = base + 1; }
+        if (x.z >= v) { v = x.z; bi = base + 2; }
+        if (x.w >= v) { v = x.w; bi = base + 3; }
+    }
+    // tail (ncells % 4) handled by the last thread of the grid
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) {
+        for (unsigned long long i = n4 * 4; i < ncells; ++i) {
+            const float x = s[i];
+            float tv = x;
+            long long ti = (long long)i;
+            if (x == x)
+                best_merge(v, bi, tv, ti);
+        }
+    }
+    long long *sm_i = reinterpret_cast<long long *>(lds_raw);
+    float *sm_v = reinterpret_cast<float *>(lds_raw + 32);
+    best_block_reduce(v, bi, sm_v, sm_i);
+    if (threadIdx.x == 0) {
+        blocks[blockIdx.x].value = v;
+        blocks[blockIdx.x].index = bi;
+        blocks[blockIdx.x].found = bi >= 0;
+    }
+}
+
+// Padded rows (stride > cols): index = row * cols + col.
+__global__ __launch_bounds__(kBlock) void argmax_strided(const float *__restrict__ s,
+                                                         const unsigned long long rows,
+                                                         const unsigned long long stride,
+                                                         const unsigned cols,
+                                                         ArgmaxRecord *__restrict__ blocks)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    float v = -INFINITY;
+    long long bi = -1;
+    const unsigned long long ncells = rows * cols;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < ncells;
+         i += (unsigned long long)gridDim.x * kBlock) {
+        const unsigned long long r = i / cols;
+        const float x = s[r * stride + (i - r * cols)];
+        if (x >= v) {
+            v = x;
+            bi = (long long)i;
+        }
+    }
+    long long *sm_i = reinterpret_cast<long long *>(lds_raw);
+    float *sm_v = reinterpret_cast<float *>(lds_raw + 32);
+    best_block_reduce(v, bi, sm_v, sm_i);
+    if (threadIdx.x == 0) {
+        blocks[blockIdx.x].value = v;
+        blocks[blockIdx.x].index = bi;
+        blocks[blockIdx.x].found = bi >= 0;
+    }
+}
+
+int launch_argmax(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride, size_t cols,
+                  ArgmaxRecord *out)
+{
+    const unsigned long long ncells = (unsigned long long)rows * cols;
+    const unsigned grid = (unsigned)std::max<unsigned long long>(
+        std::min<unsigned long long>((ncells / 4 + kBlock - 1) / kBlock,
+                                     (unsigned long long)ctx->num_cus * 16), 1);
+    LM_TRY(ctx->scratch.reserve(sizeof(ArgmaxRecord) * ((size_t)grid + 1)));
+    ArgmaxRecord *recs = static_cast<ArgmaxRecord *>(ctx->scratch.ptr);
+    const bool flat = stride == cols && (reinterpret_cast<uintptr_t>(d_scores) % 16 == 0);
+    if (flat)
+        hipLaunchKernelGGL(argmax_flat, dim3(grid), dim3(kBlock), 64, ctx->stream, d_scores, ncells,
+                           recs + 1);
+    else
+        hipLaunchKernelGGL(argmax_strided, dim3(grid), dim3(kBlock), 64, ctx->stream, d_scores,
+                           (unsigned long long)rows, (unsigned long long)stride, (unsigned)cols,
+                           recs + 1);
+    LM_HIP_TRY(hipGetLastError());
+    LM_TRY(finalize_argmax_materialised(ctx, recs + 1, grid, d_scores, recs));
+    LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, recs, sizeof(ArgmaxRecord), hipMemcpyDeviceToHost,
+                              ctx->stream));
+    LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out = *static_cast<const ArgmaxRecord *>(ctx->pinned);
+    return LM_HIP_OK;
+}
+
+// ---- threshold: count -> scan -> ordered fill -------------------------------------------
+
+constexpr int kChunk = 4096;               // cells per workgroup
+constexpr int kPerThread = kChunk / kBlock; // 16 consecutive cells per thread
+
+__device__ __forceinline__ float cell_at(const float *__restrict__ s, unsigned long long e,
+                                         unsigned long long stride, unsigned cols, bool flat)
+{
+    if (flat)
+        return s[e];
+    const unsigned long long r = e / cols;
+    return s[r * stride + (e - r * cols)];
+}
+
+// Loads the thread's 16 consecutive cells (row-major rank e0..e0+15) as a hit mask.
+__device__ __forceinline__ unsigned hit_mask(const float *__restrict__ s, unsigned long long e0,
+                                             unsigned long long ncells, unsigned long long stride,
+                                             unsigned cols, bool flat, float t)
+{
+    unsigned mask = 0;
+    if (flat && e0 + kPerThread <= ncells) {
+        const float4 *p = reinterpret_cast<const float4 *>(s + e0);
+#pragma unroll
+        for (int q = 0; q < kPerThread / 4; ++q) {
+            const float4 x = p[q];
+            mask |= (unsigned)(x.x >= t) << (4 * q + 0);
+            mask |= (unsigned)(x.y >= t) << (4 * q + 1);
+            mask |= (unsigned)(x.z >= t) << (4 * q + 2);
+            mask |= (unsigned)(x.w >= t) << (4 * q + 3);
+        }
+    } else {
+#pragma unroll 4
+        for (int q = 0; q < kPerThread; ++q)
+            if (e0 + q < ncells)
+                mask |= (unsigned)(cell_at(s, e0 + q, stride, cols, flat) >= t) << q;
+    }
+    return mask;
+}
+
+__global__ __launch_bounds__(kBlock) void threshold_count(const float *__restrict__ s,
+                                                          const unsigned long long ncells,
+                                                          const unsigned long long stride,
+                                                          const unsigned cols, const int flat,
+                                                          const float t,
+                                                          unsigned *__restrict__ counts)
+{
+    __shared__ unsigned sm[kBlock / 64];
+    const unsigned long long e0 = (unsigned long long)blockIdx.x * kChunk + threadIdx.x * kPerThread;
+    unsigned c = __popc(hit_mask(s, e0, ncells, stride, cols, flat, t));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0)
+        sm[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        counts[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// Exclusive scan of `counts` in tiles of 1024: level 1 writes per-chunk offsets
+// relative to the tile and the tile totals; level 2 scans the totals.
+constexpr int kScanTile = 1024;
+
+__device__ __forceinline__ unsigned long long block_exclusive_scan_1024(unsigned long long x,
+                                                                        unsigned long long *total)
+{
+    __shared__ unsigned long long wsum[kScanTile / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long incl = x;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long y = __shfl_up(incl, off);
+        if (lane >= off)
+            incl += y;
+    }
+    if (lane == 63)
+        wsum[wave] = incl;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+    for (int w = 0; w < kScanTile / 64; ++w) {
+        if (w < wave)
+            base += wsum[w];
+        tot += wsum[w];
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - x;
+}
+
+__global__ __launch_bounds__(kScanTile) void scan_level1(const unsigned *__restrict__ counts,
+                                                         const unsigned long long n,
+                                                         unsigned long long *__restrict__ offsets,
+                                                         unsigned long long *__restrict__ tile_totals)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * kScanTile + threadIdx.x;
+    const unsigned long long x = i < n ? counts[i] : 0;
+    unsigned long long total;
+    const unsigned long long ex = block_exclusive_scan_1024(x, &total);
+    if (i < n)
+        offsets[i] = ex;
+    if (threadIdx.x == 0)
+        tile_totals[blockIdx.x] = total;
+}
+
+// Single block: exclusive scan of the tile totals (in place) + grand total.
+__global__ __launch_bounds__(kScanTile) void scan_level2(unsigned long long *__restrict__ tile_totals,
+                                                         const unsigned long long ntiles,
+                                                         unsigned long long *__restrict__ grand_total)
+{
+    unsigned long long carry = 0;
+    for (unsigned long long base = 0; base < ntiles; base += kScanTile) {
+        const unsigned long long i = base + threadIdx.x;
+        const unsigned long long x = i < ntiles ? tile_totals[i] : 0;
+        unsigned long long total;
+        const unsigned long long ex = block_exclusive_scan_1024(x, &total);
+        if (i < ntiles)
+            tile_totals[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0)
+        *grand_total = carry;
+}
+
+__global__ __launch_bounds__(kBlock) void threshold_fill(
+    const float *__restrict__ s, const unsigned long long ncells, const unsigned long long stride,
+    const unsigned cols, const int flat, const float t, const unsigned *__restrict__ counts,
+    const unsigned long long *__restrict__ offsets, const unsigned long long *__restrict__ tile_offsets,
+    lm_hip_coords *__restrict__ out)
+{
+    if (counts[blockIdx.x] == 0)
+        return;
+    __shared__ unsigned sm[kBlock / 64];
+    const unsigned long long e0 = (unsigned long long)blockIdx.x * kChunk + threadIdx.x * kPerThread;
+    unsigned mask = hit_mask(s, e0, ncells, stride, cols, flat, t);
+    const unsigned c = __popc(mask);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned y = __shfl_up(incl, off);
+        if (lane >= off)
+            incl += y;
+    }
+    if (lane == 63)
+        sm[wave] = incl;
+    __syncthreads();
+    unsigned base = 0;
+    for (int w = 0; w < wave; ++w)
+        base += sm[w];
+    unsigned long long pos =
+        tile_offsets[blockIdx.x / kScanTile] + offsets[blockIdx.x] + base + incl - c;
+    while (mask) {
+        const int q = __ffs(mask) - 1;
+        mask &= mask - 1;
+        const unsigned long long e = e0 + q;
+        const unsigned long long r = e / cols;
+        out[pos].row = r;
+        out[pos].col = e - r * cols;
+        ++pos;
+    }
+}
+
+int launch_threshold(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride,
+                     size_t cols, float t, lm_hip_coords **coords, size_t *n)
+{
+    *coords = nullptr;
+    *n = 0;
+    const unsigned long long ncells = (unsigned long long)rows * cols;
+    if (ncells == 0)
+        return LM_HIP_OK;
+    const unsigned long long nchunks = (ncells + kChunk - 1) / kChunk;
+    const unsigned long long ntiles = (nchunks + kScanTile - 1) / kScanTile;
+    const int flat = stride == cols && (reinterpret_cast<uintptr_t>(d_scores) % 16 == 0);
+    // scratch: counts u32[nchunks] | offsets u64[nchunks] | tile totals u64[ntiles] | total u64
+    const size_t off_counts = 0;
+    const size_t off_offsets = (nchunks * 4 + 15) / 16 * 16;
+    const size_t off_tiles = off_offsets + nchunks * 8;
+    const size_t off_total = off_tiles + ntiles * 8;
+    LM_TRY(ctx->scratch.reserve(off_total + 16));
+    char *base = static_cast<char *>(ctx->scratch.ptr);
+    unsigned *counts = reinterpret_cast<unsigned *>(base + off_counts);
+    unsigned long long *offsets = reinterpret_cast<unsigned long long *>(base + off_offsets);
+    unsigned long long *tiles = reinterpret_cast<unsigned long long *>(base + off_tiles);
+    unsigned long long *total = reinterpret_cast<unsigned long long *>(base + off_total);
+
+    hipLaunchKernelGGL(threshold_count, dim3((unsigned)nchunks), dim3(kBlock), 0, ctx->stream,
+                       d_scores, ncells, (unsigned long long)stride, (unsigned)cols, flat, t, counts);
+    hipLaunchKernelGGL(scan_level1, dim3((unsigned)ntiles), dim3(kScanTile), 0, ctx->stream, counts,
+                       nchunks, offsets, tiles);
+    hipLaunchKernelGGL(scan_level2, dim3(1), dim3(kScanTile), 0, ctx->stream, tiles, ntiles, total);
+    LM_HIP_TRY(hipGetLastError());
+    LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const unsigned long long count = *static_cast<unsigned long long *>(ctx->pinned);
+    if (count == 0)
+        return LM_HIP_OK;
+
+    lm_hip_coords *host = static_cast<lm_hip_coords *>(malloc(count * sizeof(lm_hip_coords)));
+    if (!host)
+        return fail(LM_HIP_ERR_OOM, "threshold: cannot allocate %llu hits on the host", count);
+    int st = ctx->scratch2.reserve(count * sizeof(lm_hip_coords));
+    if (st != LM_HIP_OK) {
+        free(host);
+        return st;
+    }
+    lm_hip_coords *d_out = static_cast<lm_hip_coords *>(ctx->scratch2.ptr);
+    hipLaunchKernelGGL(threshold_fill, dim3((unsigned)nchunks), dim3(kBlock), 0, ctx->stream,
+                       d_scores, ncells, (unsigned long long)stride, (unsigned)cols, flat, t, counts,
+                       offsets, tiles, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(host, d_out, count * sizeof(lm_hip_coords), hipMemcpyDeviceToHost,
+                           ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        free(host);
+        return fail(LM_HIP_ERR_HIP, "threshold fill failed: %s", hipGetErrorString(e));
+    }
+    *coords = host;
+    *n = (size_t)count;
+    return LM_HIP_OK;
+}
+
+}  // namespace lm

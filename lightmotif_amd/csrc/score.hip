@@ -1,0 +1,287 @@
+// score.hip -- launch logic of the scoring kernels (kernel bodies: score_kernels.hpp).
+#include <algorithm>
+#include <mutex>
+#include <numeric>
+
+#include "score_kernels.hpp"
+
+namespace lm {
+
+// ---- registry of the unrolled C=32 kernels ---------------------------------------
+
+void register_score_c32_0(ScoreC32Launcher (*tab)[3]);
+void register_score_c32_1(ScoreC32Launcher (*tab)[3]);
+void register_score_c32_2(ScoreC32Launcher (*tab)[3]);
+void register_score_c32_3(ScoreC32Launcher (*tab)[3]);
+void register_score_c32_4(ScoreC32Launcher (*tab)[3]);
+void register_score_c32_5(ScoreC32Launcher (*tab)[3]);
+void register_score_c32_6(ScoreC32Launcher (*tab)[3]);
+void register_score_c32_7(ScoreC32Launcher (*tab)[3]);
+
+static ScoreC32Launcher g_c32[kMaxFastM + 1][3];
+static char g_c32_names[kMaxFastM + 1][3][32];
+static std::once_flag g_c32_once;
+
+static void init_registry()
+{
+    register_score_c32_0(g_c32);
+    register_score_c32_1(g_c32);
+    register_score_c32_2(g_c32);
+    register_score_c32_3(g_c32);
+    register_score_c32_4(g_c32);
+    register_score_c32_5(g_c32);
+    register_score_c32_6(g_c32);
+    register_score_c32_7(g_c32);
+    for (int m = 0; m <= kMaxFastM; ++m)
+        for (int mode = 0; mode < 3; ++mode)
+            snprintf(g_c32_names[m][mode], sizeof g_c32_names[m][mode], "score_c32<%d,%d>", m, mode);
+}
+
+ScoreC32Launcher score_c32_lookup(int M, int mode)
+{
+    std::call_once(g_c32_once, init_registry);
+    if (M < 1 || M > kMaxFastM || mode < 0 || mode > 2)
+        return nullptr;
+    return g_c32[M][mode];
+}
+
+const char *score_c32_name(int M, int mode)
+{
+    std::call_once(g_c32_once, init_registry);
+    return g_c32_names[M][mode];
+}
+
+// ---- stream geometry ---------------------------------------------------------------
+
+struct C32Plan {
+    bool ok = false;
+    unsigned long long T = 0, nstreams = 0;
+    dim3 grid;
+    size_t lds = 0;
+};
+
+// Rows per stream T = q*M + 1.  The default aims at ~8 resident wavefronts per
+// SIMD worth of streams with enough rows each to amortise the M-1 fill steps.
+static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store)
+{
+    C32Plan p;
+    const size_t M = a.pssm->m, K = a.pssm->k;
+    const unsigned long long n = a.row_end - a.row_begin;
+    if (a.cols != 32 || a.seq_stride != 32 || (store && a.out_stride != 32))
+        return p;
+    if (M < 1 || M > (size_t)kMaxFastM || n < M + 1)
+        return p;
+    const size_t lds = std::max<size_t>(K * table_stride((int)M) * sizeof(float), 64);
+    if (lds > 60 * 1024)
+        return p;
+    unsigned long long target = ctx->rows_per_stream ? ctx->rows_per_stream : 512;
+    // keep at least ~4 streams per SIMD lane-half in flight on small inputs
+    const unsigned long long want_streams = (unsigned long long)ctx->num_cus * 64;
+    if (n / target < want_streams)
+        target = std::max<unsigned long long>(n / want_streams, 1);
+    unsigned long long q = std::max<unsigned long long>((target + M / 2) / M, 1);
+    if (q * M + 1 > n)
+        q = (n - 1) / M;
+    if (q < 1)
+        return p;
+    p.T = q * M + 1;
+    p.nstreams = (n + p.T - 1) / p.T;
+    p.grid = dim3((unsigned)((p.nstreams + kStreamsPerBlock - 1) / kStreamsPerBlock));
+    p.lds = lds;
+    p.ok = true;
+    return p;
+}
+
+static dim3 generic_grid(const lm_hip_ctx *ctx, unsigned long long ncells)
+{
+    unsigned long long blocks = (ncells + kBlock - 1) / kBlock;
+    const unsigned long long cap = (unsigned long long)ctx->num_cus * 32;
+    return dim3((unsigned)std::max<unsigned long long>(std::min(blocks, cap), 1));
+}
+
+static size_t generic_lds(const lm_hip_pssm *p, int *use_lds)
+{
+    const size_t bytes = p->m * p->k * sizeof(float);
+    *use_lds = bytes <= 48 * 1024 && bytes > 0;
+    return std::max<size_t>(*use_lds ? bytes : 0, 64);
+}
+
+template <int MODE>
+static int launch_generic(lm_hip_ctx *ctx, const ScoreArgs &a, const FusedOut &fo, dim3 grid)
+{
+    int use_lds = 0;
+    const size_t lds = generic_lds(a.pssm, &use_lds);
+    hipLaunchKernelGGL((score_generic<MODE>), grid, dim3(kBlock), lds, ctx->stream, a.d_seq,
+                       (unsigned long long)a.seq_stride, (int)a.cols, a.pssm->d_dense,
+                       (int)a.pssm->m, (int)a.pssm->k, use_lds,
+                       (unsigned long long)a.row_begin, (unsigned long long)a.row_end, a.d_out,
+                       (unsigned long long)a.out_stride, fo);
+    LM_HIP_TRY(hipGetLastError());
+    return LM_HIP_OK;
+}
+
+// ---- Store --------------------------------------------------------------------------
+
+int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
+{
+    FusedOut fo{};
+    const C32Plan p = plan_c32(ctx, a, true);
+    if (p.ok) {
+        ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_STORE);
+        ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_STORE);
+        LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
+                      a.row_begin, a.row_end, p.T, p.nstreams, a.d_out, fo));
+        return LM_HIP_OK;
+    }
+    ctx->last_kernel = "score_generic<0>";
+    const unsigned long long ncells = (unsigned long long)(a.row_end - a.row_begin) * a.cols;
+    return launch_generic<MODE_STORE>(ctx, a, fo, generic_grid(ctx, ncells));
+}
+
+// ---- fused argmax ---------------------------------------------------------------------
+
+// Final reduction of per-block records; also applies the reference's "scores[0]
+// is NaN -> (0,0)" rule (pli/mod.rs:142,146: nothing ever compares >= NaN).  In
+// the fused path scores[0][0] does not exist in memory, so it is recomputed here.
+__global__ __launch_bounds__(kBlock) void argmax_finalize(
+    const ArgmaxRecord *__restrict__ blocks, const unsigned nblocks,
+    const float *__restrict__ scores00,  // non-null: materialised scores
+    const uint8_t *__restrict__ seq00, const unsigned long long seq_stride,
+    const float *__restrict__ pssm, const int M, const int K, ArgmaxRecord *__restrict__ out)
+{
+    __shared__ float sm_v[kBlock / 64];
+    __shared__ long long sm_i[kBlock / 64];
+    float v = -INFINITY;
+    long long i = -1;
+    for (unsigned b = threadIdx.x; b < nblocks; b += kBlock)
+        if (blocks[b].found)
+            best_merge(v, i, blocks[b].value, blocks[b].index);
+    best_block_reduce(v, i, sm_v, sm_i);
+    if (threadIdx.x == 0) {
+        float first;
+        if (scores00) {
+            first = scores00[0];
+        } else {
+            first = 0.0f;
+            for (int j = 0; j < M; ++j)
+                first = first + pssm[j * K + seq00[j * seq_stride]];
+        }
+        if (first != first) {  // NaN
+            v = first;
+            i = 0;
+        }
+        out->value = v;
+        out->index = i;
+        out->found = i >= 0;
+    }
+}
+
+static int read_record(lm_hip_ctx *ctx, const ArgmaxRecord *d_rec, ArgmaxRecord *out)
+{
+    LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, d_rec, sizeof(ArgmaxRecord), hipMemcpyDeviceToHost,
+                              ctx->stream));
+    LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out = *static_cast<const ArgmaxRecord *>(ctx->pinned);
+    return LM_HIP_OK;
+}
+
+int launch_score_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *out)
+{
+    FusedOut fo{};
+    const C32Plan p = plan_c32(ctx, a, false);
+    const unsigned long long ncells = (unsigned long long)(a.row_end - a.row_begin) * a.cols;
+    const dim3 grid = p.ok ? p.grid : generic_grid(ctx, ncells);
+    LM_TRY(ctx->scratch.reserve(sizeof(ArgmaxRecord) * ((size_t)grid.x + 1)));
+    ArgmaxRecord *recs = static_cast<ArgmaxRecord *>(ctx->scratch.ptr);
+    fo.block_best = recs + 1;
+    if (p.ok) {
+        ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_ARGMAX);
+        ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_ARGMAX);
+        LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
+                      a.row_begin, a.row_end, p.T, p.nstreams, nullptr, fo));
+    } else {
+        ctx->last_kernel = "score_generic<1>";
+        LM_TRY(launch_generic<MODE_ARGMAX>(ctx, a, fo, grid));
+    }
+    hipLaunchKernelGGL(argmax_finalize, dim3(1), dim3(kBlock), 0, ctx->stream, recs + 1, grid.x,
+                       (const float *)nullptr, a.d_seq + a.row_begin * a.seq_stride,
+                       (unsigned long long)a.seq_stride, a.pssm->d_dense, (int)a.pssm->m,
+                       (int)a.pssm->k, recs);
+    LM_HIP_TRY(hipGetLastError());
+    return read_record(ctx, recs, out);
+}
+
+// ---- fused threshold --------------------------------------------------------------------
+
+int launch_score_threshold(lm_hip_ctx *ctx, const ScoreArgs &a, float t,
+                           std::vector<unsigned long long> *flat, std::vector<float> *values)
+{
+    const C32Plan p = plan_c32(ctx, a, false);
+    const unsigned long long ncells = (unsigned long long)(a.row_end - a.row_begin) * a.cols;
+    unsigned long long cap = std::min<unsigned long long>(std::max<unsigned long long>(ncells / 64, 1 << 16), ncells + 64);
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        // layout: [count u64][pad to 16][flat u64 x cap][value f32 x cap]
+        const size_t bytes = 16 + cap * 8 + cap * 4;
+        LM_TRY(ctx->scratch.reserve(bytes));
+        char *base = static_cast<char *>(ctx->scratch.ptr);
+        FusedOut fo{};
+        fo.threshold = t;
+        fo.hit_count = reinterpret_cast<unsigned long long *>(base);
+        fo.hit_flat = reinterpret_cast<unsigned long long *>(base + 16);
+        fo.hit_value = reinterpret_cast<float *>(base + 16 + cap * 8);
+        fo.hit_capacity = cap;
+        LM_HIP_TRY(hipMemsetAsync(base, 0, 16, ctx->stream));
+        if (p.ok) {
+            ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_THRESHOLD);
+            ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_THRESHOLD);
+            LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
+                          a.row_begin, a.row_end, p.T, p.nstreams, nullptr, fo));
+        } else {
+            ctx->last_kernel = "score_generic<2>";
+            LM_TRY(launch_generic<MODE_THRESHOLD>(ctx, a, fo, generic_grid(ctx, ncells)));
+        }
+        LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, base, 8, hipMemcpyDeviceToHost, ctx->stream));
+        LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        const unsigned long long count = *static_cast<unsigned long long *>(ctx->pinned);
+        if (count > cap) {  // the shifted last stream may report a few cells twice
+            cap = count + 64;
+            continue;
+        }
+        std::vector<unsigned long long> f(count);
+        std::vector<float> v(count);
+        if (count) {
+            LM_HIP_TRY(hipMemcpyAsync(f.data(), fo.hit_flat, count * 8, hipMemcpyDeviceToHost, ctx->stream));
+            LM_HIP_TRY(hipMemcpyAsync(v.data(), fo.hit_value, count * 4, hipMemcpyDeviceToHost, ctx->stream));
+            LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        // Row-major order (pli/mod.rs:212-218) = ascending flat index; duplicates
+        // written by the shifted last stream carry identical values.
+        std::vector<size_t> order(count);
+        std::iota(order.begin(), order.end(), (size_t)0);
+        std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return f[x] < f[y]; });
+        flat->clear();
+        values->clear();
+        flat->reserve(count);
+        values->reserve(count);
+        for (size_t idx : order) {
+            if (!flat->empty() && flat->back() == f[idx])
+                continue;
+            flat->push_back(f[idx]);
+            values->push_back(v[idx]);
+        }
+        return LM_HIP_OK;
+    }
+    return fail(LM_HIP_ERR_HIP, "fused threshold: hit list kept overflowing");
+}
+
+int finalize_argmax_materialised(lm_hip_ctx *ctx, const ArgmaxRecord *d_blocks, unsigned nblocks,
+                                 const float *d_scores, ArgmaxRecord *d_out)
+{
+    hipLaunchKernelGGL(argmax_finalize, dim3(1), dim3(kBlock), 0, ctx->stream, d_blocks, nblocks,
+                       d_scores, (const uint8_t *)nullptr, 0ull, (const float *)nullptr, 0, 0,
+                       d_out);
+    LM_HIP_TRY(hipGetLastError());
+    return LM_HIP_OK;
+}
+
+}  // namespace lm

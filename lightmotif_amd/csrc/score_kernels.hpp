@@ -106,7 +106,7 @@ __device__ __forceinline__ void best_block_reduce(float &v, long long &i, float 
 //       requested while step k is processed (0 = load at use);
 //   LP  1 = the LDS reads of step k+1 are issued before the adds of step k.
 #ifndef LM_SCORE_PF
-#define LM_SCORE_PF 6
+#define LM_SCORE_PF 12
 #endif
 #ifndef LM_SCORE_LP
 #define LM_SCORE_LP 0
@@ -212,7 +212,6 @@ __global__ __launch_bounds__(kBlock) void score_c32(
     const unsigned long long T, const unsigned long long nstreams, float *__restrict__ out,
     const FusedOut fo)
 {
-    static_assert(PF < M || M == 1, "prefetch distance must be shorter than the motif");
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     {
         float4 *dst = reinterpret_cast<float4 *>(lds_raw);
@@ -239,7 +238,7 @@ __global__ __launch_bounds__(kBlock) void score_c32(
     float *op = (MODE == MODE_STORE) ? out + orow * 32 + col : nullptr;
 
     constexpr int NW = 4 * ((M + 3) / 4);
-    constexpr int PFE = (M == 1) ? 0 : PF;
+    constexpr int PFE = PF < M ? PF : M - 1;  // look-ahead stays inside one group
     float acc[M];
     unsigned sym[M];
     float wc[NW];

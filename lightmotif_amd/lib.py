@@ -1,0 +1,748 @@
+"""Host-side mirror of lightmotif's scoring interface on top of the HIP C ABI.
+
+Two layers, both thin:
+
+* :class:`Pipeline` -- the reference's trait surface (``Encode`` / ``Stripe`` /
+  ``Score`` / ``Maximum`` / ``Threshold``, lightmotif/src/pli/mod.rs:34-222) for the
+  ``Hip`` back-end: same method names, argument meaning and error behaviour
+  (misuse raises where the reference panics; degenerate input gives empty results).
+* ``EncodedSequence`` / ``StripedSequence`` / ``CountMatrix`` / ``WeightMatrix`` /
+  ``ScoringMatrix`` / ``StripedScores`` / ``create`` / ``stripe`` / ``scan`` -- the
+  user-facing objects of the reference's Python module
+  (lightmotif-py/lightmotif/lib.rs, lib.pyi) so its tests read the same here.
+
+All sequence and score data live in device memory; every scoring operation runs
+in the hand-written gfx950 kernels.  Nothing here falls back to the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import Coords, InvalidSymbol, LightmotifHipError, UnsupportedBackend, check
+
+__all__ = [
+    "Pipeline", "EncodedSequence", "StripedSequence", "CountMatrix", "WeightMatrix",
+    "ScoringMatrix", "StripedScores", "Scanner", "Hit", "Motif", "create", "stripe", "scan",
+    "UnsupportedBackend", "InvalidSymbol", "LightmotifHipError", "DEFAULT_COLUMNS",
+]
+
+DNA_SYMBOLS = "ACTGN"                     # abc.rs:106-108
+PROTEIN_SYMBOLS = "ACDEFGHIKLMNPQRSTVWYX"  # abc.rs:193-256
+DEFAULT_COLUMNS = 32                      # dispatch.rs:45 / dense.rs:17 on x86-64
+
+
+def _symbols(protein: bool) -> str:
+    return PROTEIN_SYMBOLS if protein else DNA_SYMBOLS
+
+
+def _k(protein: bool) -> int:
+    return len(_symbols(protein))
+
+
+def stride(cols: int, elem_size: int) -> int:
+    """DenseMatrix::stride (dense.rs:126-128)."""
+    return int(_ffi.lib().lm_hip_stride(cols, elem_size))
+
+
+# --- Pipeline -----------------------------------------------------------------
+
+
+class Pipeline:
+    """``Pipeline<A, Hip>``: owns a device context (stream + scratch)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        L = _ffi.lib()
+        h = C.c_void_p()
+        if stream is None:
+            check(L.lm_hip_ctx_create(device, C.byref(h)))
+        else:
+            check(L.lm_hip_ctx_create_on_stream(device, C.c_void_p(stream), C.byref(h)))
+        self._L = L
+        self._h = h
+        self.device = device
+
+    # Pipeline::avx2()/neon() return Result<_, UnsupportedBackend> (pli/mod.rs:401-407)
+    @classmethod
+    def hip(cls, device: int = 0, stream: Optional[int] = None) -> "Pipeline":
+        return cls(device, stream)
+
+    @staticmethod
+    def device_count() -> int:
+        n = C.c_int(0)
+        check(_ffi.lib().lm_hip_device_count(C.byref(n)))
+        return n.value
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._L.lm_hip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self) -> None:
+        check(self._L.lm_hip_ctx_sync(self._h))
+
+    @property
+    def stream(self) -> int:
+        s = C.c_void_p()
+        check(self._L.lm_hip_ctx_stream(self._h, C.byref(s)))
+        return s.value or 0
+
+    def set_rows_per_stream(self, rows: int) -> None:
+        check(self._L.lm_hip_ctx_set_rows_per_stream(self._h, rows))
+
+    @property
+    def last_kernel(self) -> str:
+        return self._L.lm_hip_ctx_last_kernel(self._h).decode()
+
+    # -- Encode / Stripe (pli/mod.rs:34-67, 164-201) ---------------------------
+
+    def encode(self, sequence: Union[str, bytes], protein: bool = False) -> "EncodedSequence":
+        return EncodedSequence(sequence, protein=protein)
+
+    def stripe(self, encoded: "EncodedSequence", columns: int = DEFAULT_COLUMNS) -> "StripedSequence":
+        h = C.c_void_p()
+        data = np.ascontiguousarray(encoded.data, dtype=np.uint8)
+        check(self._L.lm_hip_seq_from_encoded(self._h, data.ctypes.data, data.size, columns,
+                                              _k(encoded.protein), C.byref(h)))
+        return StripedSequence(self, h, encoded.protein)
+
+    def stripe_ascii(self, sequence: Union[str, bytes], protein: bool = False, lossy: bool = False,
+                     columns: int = DEFAULT_COLUMNS) -> "StripedSequence":
+        """encode (+ encode_lossy) and stripe entirely on the device."""
+        raw = sequence.encode("ascii", "replace") if isinstance(sequence, str) else bytes(sequence)
+        buf = np.frombuffer(raw, dtype=np.uint8)
+        h = C.c_void_p()
+        bad = C.c_size_t(0)
+        st = self._L.lm_hip_seq_from_ascii(self._h, b"P" if protein else b"D", buf.ctypes.data,
+                                           buf.size, columns, int(lossy), C.byref(h), C.byref(bad))
+        if st == _ffi.ERR_INVALID_SYMBOL:
+            raise InvalidSymbol(f"Invalid symbol in sequence: {chr(raw[bad.value])!r}")
+        check(st)
+        return StripedSequence(self, h, protein)
+
+    def upload(self, data: np.ndarray, length: int, wrap: int, columns: int,
+               protein: bool = False) -> "StripedSequence":
+        """Adopt an already striped host matrix ((rows+wrap) x stride u8)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        h = C.c_void_p()
+        check(self._L.lm_hip_seq_upload(self._h, data.ctypes.data, data.shape[0], data.shape[1],
+                                        columns, wrap, length, _k(protein), C.byref(h)))
+        return StripedSequence(self, h, protein)
+
+    # -- Score (pli/mod.rs:69-130) ----------------------------------------------
+
+    def score_rows_into(self, pssm: "ScoringMatrix", seq: "StripedSequence", rows: range,
+                        scores: "StripedScores") -> None:
+        check(self._L.lm_hip_score_rows_into(self._h, pssm._device(self), seq._h,
+                                             rows.start, max(rows.stop, rows.start), scores._h))
+
+    def score_into(self, pssm: "ScoringMatrix", seq: "StripedSequence",
+                   scores: "StripedScores") -> None:
+        check(self._L.lm_hip_score_into(self._h, pssm._device(self), seq._h, scores._h))
+
+    def score(self, pssm: "ScoringMatrix", seq: "StripedSequence") -> "StripedScores":
+        scores = StripedScores.empty(self, seq.columns)
+        self.score_into(pssm, seq, scores)
+        return scores
+
+    # -- Maximum / Threshold (pli/mod.rs:132-161, 203-222) ------------------------
+
+    def argmax(self, scores: "StripedScores") -> Optional[Tuple[int, int]]:
+        found, best, _ = self._argmax(scores)
+        return (best.row, best.col) if found else None
+
+    def max(self, scores: "StripedScores") -> Optional[float]:
+        found, _, value = self._argmax(scores)
+        return value if found else None
+
+    def _argmax(self, scores: "StripedScores"):
+        found, best, value = C.c_int(0), Coords(), C.c_float(0)
+        check(self._L.lm_hip_argmax(self._h, scores._h, C.byref(found), C.byref(best), C.byref(value)))
+        return bool(found.value), best, float(value.value)
+
+    def threshold(self, scores: "StripedScores", threshold: float) -> List[Tuple[int, int]]:
+        ptr, n = C.POINTER(Coords)(), C.c_size_t(0)
+        check(self._L.lm_hip_threshold(self._h, scores._h, threshold, C.byref(ptr), C.byref(n)))
+        return self._take_coords(ptr, n.value)
+
+    def _take_coords(self, ptr, n: int) -> List[Tuple[int, int]]:
+        try:
+            if n == 0:
+                return []
+            arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_size_t)), shape=(n, 2))
+            return [(int(r), int(c)) for r, c in arr]
+        finally:
+            if ptr:
+                self._L.lm_hip_free(ptr)
+
+    # -- fused forms ----------------------------------------------------------------
+
+    def score_argmax(self, pssm: "ScoringMatrix", seq: "StripedSequence",
+                     rows: Optional[range] = None):
+        """score_rows_into + argmax without writing the scores: ((row, col), value) or None."""
+        rows = range(0, seq.rows) if rows is None else rows
+        found, best, value = C.c_int(0), Coords(), C.c_float(0)
+        check(self._L.lm_hip_score_argmax_f32_dptr(
+            self._h, pssm._device(self), seq.data_ptr, seq.rows + seq.wrap, seq.stride, seq.columns,
+            seq.wrap, len(seq), rows.start, max(rows.stop, rows.start), C.byref(found),
+            C.byref(best), C.byref(value)))
+        return ((best.row, best.col), float(value.value)) if found.value else None
+
+    def score_threshold(self, pssm: "ScoringMatrix", seq: "StripedSequence", threshold: float,
+                        rows: Optional[range] = None):
+        """score_rows_into + threshold without writing the scores: ([(row, col)], [value])."""
+        rows = range(0, seq.rows) if rows is None else rows
+        ptr, vals, n = C.POINTER(Coords)(), C.POINTER(C.c_float)(), C.c_size_t(0)
+        check(self._L.lm_hip_score_threshold_f32_dptr(
+            self._h, pssm._device(self), seq.data_ptr, seq.rows + seq.wrap, seq.stride, seq.columns,
+            seq.wrap, len(seq), rows.start, max(rows.stop, rows.start), threshold,
+            C.byref(ptr), C.byref(vals), C.byref(n)))
+        try:
+            values = [float(vals[i]) for i in range(n.value)]
+        finally:
+            if vals:
+                self._L.lm_hip_free(vals)
+        return self._take_coords(ptr, n.value), values
+
+    # -- raw device-pointer forms (used with torch tensors by bench.py / tests) -------
+
+    def score_dptr(self, pssm: "ScoringMatrix", seq_ptr: int, seq_rows_total: int, seq_stride: int,
+                   columns: int, wrap: int, length: int, row_begin: int, row_end: int,
+                   out_ptr: int, out_stride: int) -> Tuple[int, int]:
+        orow, mi = C.c_size_t(0), C.c_size_t(0)
+        check(self._L.lm_hip_score_f32_dptr(self._h, pssm._device(self), C.c_void_p(seq_ptr),
+                                            seq_rows_total, seq_stride, columns, wrap, length,
+                                            row_begin, row_end, C.c_void_p(out_ptr), out_stride,
+                                            C.byref(orow), C.byref(mi)))
+        return orow.value, mi.value
+
+    def argmax_dptr(self, scores_ptr: int, rows: int, stride_: int, columns: int):
+        found, best, value = C.c_int(0), Coords(), C.c_float(0)
+        check(self._L.lm_hip_argmax_f32_dptr(self._h, C.c_void_p(scores_ptr), rows, stride_, columns,
+                                             C.byref(found), C.byref(best), C.byref(value)))
+        return ((best.row, best.col), float(value.value)) if found.value else None
+
+    def threshold_dptr(self, scores_ptr: int, rows: int, stride_: int, columns: int,
+                       threshold: float) -> List[Tuple[int, int]]:
+        ptr, n = C.POINTER(Coords)(), C.c_size_t(0)
+        check(self._L.lm_hip_threshold_f32_dptr(self._h, C.c_void_p(scores_ptr), rows, stride_,
+                                                columns, threshold, C.byref(ptr), C.byref(n)))
+        return self._take_coords(ptr, n.value)
+
+    def score_argmax_dptr(self, pssm: "ScoringMatrix", seq_ptr: int, seq_rows_total: int,
+                          seq_stride: int, columns: int, wrap: int, length: int, row_begin: int,
+                          row_end: int):
+        found, best, value = C.c_int(0), Coords(), C.c_float(0)
+        check(self._L.lm_hip_score_argmax_f32_dptr(
+            self._h, pssm._device(self), C.c_void_p(seq_ptr), seq_rows_total, seq_stride, columns,
+            wrap, length, row_begin, row_end, C.byref(found), C.byref(best), C.byref(value)))
+        return ((best.row, best.col), float(value.value)) if found.value else None
+
+    def stripe_dptr(self, encoded_ptr: int, length: int, columns: int, default_symbol: int,
+                    wrap: int, data_ptr: int, stride_: int) -> None:
+        check(self._L.lm_hip_stripe_dptr(self._h, C.c_void_p(encoded_ptr), length, columns,
+                                         default_symbol, wrap, C.c_void_p(data_ptr), stride_))
+
+    def configure_wrap_dptr(self, data_ptr: int, rows: int, stride_: int, columns: int,
+                            new_wrap: int, default_symbol: int) -> None:
+        check(self._L.lm_hip_configure_wrap_dptr(self._h, C.c_void_p(data_ptr), rows, stride_,
+                                                 columns, new_wrap, default_symbol))
+
+    def encode_dptr(self, ascii_ptr: int, length: int, dst_ptr: int, protein: bool = False,
+                    lossy: bool = False) -> None:
+        bad = C.c_size_t(0)
+        st = self._L.lm_hip_encode_dptr(self._h, b"P" if protein else b"D", C.c_void_p(ascii_ptr),
+                                        length, int(lossy), C.c_void_p(dst_ptr), C.byref(bad))
+        if st == _ffi.ERR_INVALID_SYMBOL:
+            raise InvalidSymbol(f"Invalid symbol in sequence at position {bad.value}")
+        check(st)
+
+
+_default: Optional[Pipeline] = None
+
+
+def default_pipeline() -> Pipeline:
+    """The analogue of ``Pipeline::dispatch()`` (pli/mod.rs:269-308): the reference
+    re-creates a zero-sized pipeline per call (pwm/mod.rs:646, scores.rs:182); the
+    GPU context it needs is cached here instead."""
+    global _default
+    if _default is None:
+        _default = Pipeline.hip()
+    return _default
+
+
+# --- sequences ----------------------------------------------------------------------
+
+
+class EncodedSequence:
+    """seq.rs:83-98: a vector of symbol indices (host side; 1 byte per symbol)."""
+
+    def __init__(self, sequence: Union[str, bytes, np.ndarray], *, protein: bool = False,
+                 lossy: bool = False):
+        self.protein = protein
+        if isinstance(sequence, np.ndarray):
+            self.data = np.ascontiguousarray(sequence, dtype=np.uint8)
+            return
+        raw = sequence.encode("utf-8") if isinstance(sequence, str) else bytes(sequence)
+        lut = np.full(256, 255, dtype=np.uint8)
+        for i, ch in enumerate(_symbols(protein)):
+            lut[ord(ch)] = i
+        data = lut[np.frombuffer(raw, dtype=np.uint8)]
+        bad = np.flatnonzero(data == 255)
+        if bad.size:
+            if not lossy:  # pli/mod.rs:63 -> Err(InvalidSymbol)
+                raise InvalidSymbol(f"Invalid symbol in sequence: {chr(raw[int(bad[0])])!r}")
+            data[bad] = _k(protein) - 1  # seq.rs:126 unwrap_or_default
+        self.data = data
+
+    @classmethod
+    def encode_lossy(cls, sequence: Union[str, bytes], *, protein: bool = False) -> "EncodedSequence":
+        return cls(sequence, protein=protein, lossy=True)
+
+    def __len__(self) -> int:
+        return int(self.data.size)
+
+    def __str__(self) -> str:
+        sym = _symbols(self.protein)
+        return "".join(sym[i] for i in self.data)
+
+    def copy(self) -> "EncodedSequence":
+        return EncodedSequence(self.data.copy(), protein=self.protein)
+
+    def stripe(self, columns: int = DEFAULT_COLUMNS) -> "StripedSequence":
+        return default_pipeline().stripe(self, columns)
+
+
+class StripedSequence:
+    """seq.rs:288-294 ``{length, wrap, data}``, resident on the device."""
+
+    def __init__(self, pli: Pipeline, handle: C.c_void_p, protein: bool):
+        self._pli, self._h, self.protein = pli, handle, protein
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._pli._L.lm_hip_seq_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _info(self):
+        v = [C.c_size_t(0) for _ in range(5)]
+        p = C.c_void_p()
+        check(self._pli._L.lm_hip_seq_info(self._h, *[C.byref(x) for x in v], C.byref(p)))
+        return [x.value for x in v] + [p.value or 0]
+
+    def __len__(self) -> int:
+        return self._info()[0]
+
+    @property
+    def wrap(self) -> int:
+        return self._info()[1]
+
+    @property
+    def rows(self) -> int:
+        """matrix().rows() - wrap()"""
+        return self._info()[2]
+
+    @property
+    def stride(self) -> int:
+        return self._info()[3]
+
+    @property
+    def columns(self) -> int:
+        return self._info()[4]
+
+    @property
+    def data_ptr(self) -> int:
+        return self._info()[5]
+
+    def configure(self, motif: "ScoringMatrix") -> None:
+        """seq.rs:362-366"""
+        if len(motif) > 0:
+            self.configure_wrap(len(motif) - 1)
+
+    def configure_wrap(self, m: int) -> None:
+        """seq.rs:369-381"""
+        check(self._pli._L.lm_hip_seq_configure_wrap(self._pli._h, self._h, m))
+
+    def matrix(self) -> np.ndarray:
+        """Host copy of the (rows + wrap) x stride byte matrix."""
+        _, wrap, rows, st, _, _ = self._info()
+        out = np.empty((rows + wrap, st), dtype=np.uint8)
+        check(self._pli._L.lm_hip_seq_download(self._pli._h, self._h, out.ctypes.data))
+        return out
+
+
+# --- matrices ------------------------------------------------------------------------
+
+
+def _dict_to_rows(values: Dict[str, Iterable[float]], protein: bool, dtype) -> np.ndarray:
+    sym = _symbols(protein)
+    k = len(sym)
+    length = None
+    for key, col in values.items():
+        if key not in sym:
+            raise ValueError(f"Invalid symbol: {key!r}")
+        col = list(col)
+        if length is None:
+            length = len(col)
+        elif length != len(col):
+            raise ValueError("Invalid number of rows")
+    out = np.zeros((length or 0, k), dtype=dtype)
+    for key, col in values.items():
+        out[:, sym.index(key)] = np.asarray(list(col), dtype=dtype)
+    return out
+
+
+class CountMatrix:
+    """pwm/mod.rs:178-258 (counts are M x K u32)."""
+
+    def __init__(self, values: Union[Dict[str, Iterable[int]], np.ndarray], *, protein: bool = False):
+        self.protein = protein
+        self.data = (_dict_to_rows(values, protein, np.uint32) if isinstance(values, dict)
+                     else np.ascontiguousarray(values, dtype=np.uint32))
+
+    @classmethod
+    def from_sequences(cls, sequences: Sequence[EncodedSequence], protein: bool = False) -> "CountMatrix":
+        """pwm/mod.rs:209-237"""
+        seqs = list(sequences)
+        m = len(seqs[0]) if seqs else 0
+        data = np.zeros((m, _k(protein)), dtype=np.uint32)
+        for s in seqs:
+            if len(s) != m:
+                raise ValueError("Inconsistent sequence length")
+            np.add.at(data, (np.arange(m), s.data), 1)
+        return cls(data, protein=protein)
+
+    def __len__(self) -> int:
+        return self.data.shape[0]
+
+    def __getitem__(self, i: int) -> List[int]:
+        return [int(x) for x in self.data[i]]
+
+    def __eq__(self, other) -> bool:
+        return isinstance(other, CountMatrix) and np.array_equal(self.data, other.data)
+
+    def normalize(self, pseudocount: Union[None, float, Dict[str, float]] = None) -> "WeightMatrix":
+        """lib.rs:501-526: ``to_freq(pseudo).to_weight(None)`` in f32."""
+        k = self.data.shape[1]
+        f32 = np.float32
+        if pseudocount is None:
+            pseudo = np.zeros(k, dtype=f32)
+        elif isinstance(pseudocount, dict):
+            pseudo = _dict_to_rows({a: [b] for a, b in pseudocount.items()}, self.protein, f32)[0]
+        else:  # abc.rs:558-573: every symbol but the default one
+            pseudo = np.full(k, f32(pseudocount), dtype=f32)
+            pseudo[k - 1] = 0
+        bg = uniform_background(k)
+        out = np.zeros((len(self), k), dtype=f32)
+        for i in range(len(self)):
+            row = (self.data[i].astype(f32) + pseudo).astype(f32)  # pwm/mod.rs:249-251
+            total = f32(0)
+            for x in row:                                            # :252 sequential f32 sum
+                total = f32(total + x)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                row = (row / total).astype(f32)                      # :253-255
+                out[i] = np.where(bg == 0, f32(0), row / np.where(bg == 0, f32(1), bg))  # :384-390
+        return WeightMatrix(out, bg, protein=self.protein)
+
+
+def uniform_background(k: int) -> np.ndarray:
+    """abc.rs:473-487: 1/(K-1) everywhere, 0 for the default symbol."""
+    bg = np.full(k, np.float32(1) / np.float32(k - 1), dtype=np.float32)
+    bg[k - 1] = 0
+    return bg
+
+
+class WeightMatrix:
+    """pwm/mod.rs:450-456: odds ratios."""
+
+    def __init__(self, data: np.ndarray, background: np.ndarray, *, protein: bool = False):
+        self.data = np.ascontiguousarray(data, dtype=np.float32)
+        self.background = np.asarray(background, dtype=np.float32)
+        self.protein = protein
+
+    def __len__(self) -> int:
+        return self.data.shape[0]
+
+    def __getitem__(self, i: int) -> List[float]:
+        return [float(x) for x in self.data[i]]
+
+    def log_odds(self, background: Optional[Dict[str, float]] = None, base: float = 2.0) -> "ScoringMatrix":
+        """lib.rs WeightMatrix.log_odds -> rescale + to_scoring_with_base (pwm/mod.rs:505-526)."""
+        data, bg = self.data, self.background
+        if background is not None:
+            nb = _dict_to_rows({a: [b] for a, b in background.items()}, self.protein, np.float32)[0]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                data = (data * (bg / nb)).astype(np.float32)  # pwm/mod.rs:477-481
+            bg = nb
+        with np.errstate(divide="ignore"):
+            if base == 2.0:
+                out = np.log2(data, dtype=np.float32)
+            elif base == 10.0:
+                out = np.log10(data, dtype=np.float32)
+            else:
+                out = (np.log(data, dtype=np.float32) / np.log(np.float32(base))).astype(np.float32)
+        return ScoringMatrix(out, bg, protein=self.protein)
+
+
+class ScoringMatrix:
+    """pwm/mod.rs:561-564 ``{background, data: DenseMatrix<f32, K>}``.
+
+    ``data`` is kept in the reference's padded layout (M x stride(K) f32: stride 8
+    for DNA, 24 for protein) so the pointer handed to the C ABI is what a Rust
+    caller would hand over."""
+
+    def __init__(self, values: Union[Dict[str, Iterable[float]], np.ndarray],
+                 background: Union[None, Dict[str, float], np.ndarray] = None, *,
+                 protein: bool = False):
+        self.protein = protein
+        k = _k(protein)
+        dense = (_dict_to_rows(values, protein, np.float32) if isinstance(values, dict)
+                 else np.asarray(values, dtype=np.float32))
+        if dense.ndim != 2 or dense.shape[1] < k:
+            raise ValueError("scoring matrix must be M x K")
+        st = stride(k, 4)
+        self.data = np.zeros((dense.shape[0], st), dtype=np.float32)  # dense.rs:144-147
+        self.data[:, :k] = dense[:, :k]
+        if isinstance(background, dict):
+            background = _dict_to_rows({a: [b] for a, b in background.items()}, protein, np.float32)[0]
+        self.background = uniform_background(k) if background is None else np.asarray(background, np.float32)
+        self._dev: Dict[int, C.c_void_p] = {}
+        self._plis: Dict[int, Pipeline] = {}
+
+    @property
+    def k(self) -> int:
+        return _k(self.protein)
+
+    def __len__(self) -> int:
+        return self.data.shape[0]
+
+    def __eq__(self, other) -> bool:
+        return (isinstance(other, ScoringMatrix) and self.protein == other.protein
+                and np.array_equal(self.data, other.data, equal_nan=True))
+
+    def _device(self, pli: Pipeline) -> C.c_void_p:
+        key = id(pli)
+        if key not in self._dev:
+            h = C.c_void_p()
+            check(pli._L.lm_hip_pssm_create(pli._h, self.data.ctypes.data, self.data.shape[0],
+                                            self.data.shape[1], self.k, C.byref(h)))
+            self._dev[key] = h
+            self._plis[key] = pli
+        return self._dev[key]
+
+    def __del__(self):
+        try:
+            for key, h in self._dev.items():
+                self._plis[key]._L.lm_hip_pssm_destroy(h)
+        except Exception:
+            pass
+
+    def calculate(self, sequence: StripedSequence) -> "StripedScores":
+        """lib.rs:855-874: ``configure(pssm)`` then full-range ``pli.score``."""
+        if sequence.protein != self.protein:
+            raise ValueError("alphabet mismatch")
+        sequence.configure(self)
+        return sequence._pli.score(self, sequence)
+
+    def score(self, sequence: StripedSequence) -> "StripedScores":
+        """pwm/mod.rs:640-648 (the caller configures the wrap rows, like in Rust)."""
+        return sequence._pli.score(self, sequence)
+
+    def reverse_complement(self) -> "ScoringMatrix":
+        """pwm/mod.rs:566-577 (DNA: A<->T, C<->G, N->N)."""
+        if self.protein:
+            raise ValueError("cannot complement a protein matrix")
+        comp = [2, 3, 0, 1, 4]
+        return ScoringMatrix(self.data[::-1, :5][:, comp], self.background, protein=False)
+
+
+# --- scores -----------------------------------------------------------------------------
+
+
+class StripedScores:
+    """scores.rs:102-107 ``{data, max_index}``, resident on the device."""
+
+    def __init__(self, pli: Pipeline, handle: C.c_void_p):
+        self._pli, self._h = pli, handle
+
+    @classmethod
+    def empty(cls, pli: Optional[Pipeline] = None, columns: int = DEFAULT_COLUMNS) -> "StripedScores":
+        pli = pli or default_pipeline()
+        h = C.c_void_p()
+        check(pli._L.lm_hip_scores_create(pli._h, columns, C.byref(h)))
+        return cls(pli, h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._pli._L.lm_hip_scores_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _info(self):
+        v = [C.c_size_t(0) for _ in range(4)]
+        p = C.c_void_p()
+        check(self._pli._L.lm_hip_scores_info(self._h, *[C.byref(x) for x in v], C.byref(p)))
+        return [x.value for x in v] + [p.value or 0]
+
+    @property
+    def rows(self) -> int:
+        return self._info()[0]
+
+    @property
+    def stride(self) -> int:
+        return self._info()[1]
+
+    @property
+    def columns(self) -> int:
+        return self._info()[2]
+
+    @property
+    def max_index(self) -> int:
+        return self._info()[3]
+
+    @property
+    def data_ptr(self) -> int:
+        return self._info()[4]
+
+    def is_empty(self) -> bool:
+        return self.rows == 0
+
+    def matrix(self) -> np.ndarray:
+        """Host copy of the rows x stride f32 matrix."""
+        rows, st = self.rows, self.stride
+        out = np.empty((rows, st), dtype=np.float32)
+        check(self._pli._L.lm_hip_scores_download(self._pli._h, self._h, out.ctypes.data))
+        return out
+
+    def offset(self, row: int, col: int) -> int:
+        """scores.rs:155-157"""
+        return col * self.rows + row
+
+    def __len__(self) -> int:
+        """scores.rs:274-279: min(max_index, rows * C)"""
+        rows, _, cols, mi, _ = self._info()
+        return min(mi, rows * cols)
+
+    def unstripe(self) -> np.ndarray:
+        """scores.rs:167-170"""
+        m = self.matrix()
+        n, rows = len(self), self.rows
+        i = np.arange(n)
+        return m[i % rows, i // rows] if rows else np.zeros(0, np.float32)
+
+    def __iter__(self) -> Iterator[float]:
+        return iter(float(x) for x in self.unstripe())
+
+    def __getitem__(self, index: int) -> float:
+        """scores.rs:246-254 (lib.rs:1038-1050 raises IndexError past the end)."""
+        n = len(self)
+        if index < 0:
+            index += n
+        if not 0 <= index < n:
+            raise IndexError(index)
+        rows = self.rows
+        return float(self.matrix()[index % rows, index // rows])
+
+    def argmax(self) -> Optional[int]:
+        """scores.rs:190-192"""
+        mc = self._pli.argmax(self)
+        return None if mc is None else self.offset(*mc)
+
+    def max(self) -> Optional[float]:
+        """scores.rs:181-183"""
+        return self._pli.max(self)
+
+    def threshold(self, threshold: float) -> List[int]:
+        """scores.rs:207-213 (unsorted: row-major order of the striped matrix)."""
+        rows = self.rows
+        return [c * rows + r for r, c in self._pli.threshold(self, threshold)]
+
+
+# --- Scanner (scan.rs:96-250 semantics on the fused kernel) ----------------------------------
+
+
+class Hit:
+    """scan.rs:52-75"""
+
+    __slots__ = ("position", "score")
+
+    def __init__(self, position: int, score: float):
+        self.position, self.score = position, score
+
+    def __repr__(self) -> str:
+        return f"Hit(position={self.position}, score={self.score})"
+
+
+class Scanner:
+    """All positions with ``score >= threshold`` and ``position + M <= L``
+    (scan.rs:185-190), found by the fused score+threshold kernel -- the u8
+    prefilter of scan.rs:169-178 is a CPU-cache trick the GPU path does not need
+    because the f32 scores never leave registers."""
+
+    def __init__(self, pssm: ScoringMatrix, sequence: StripedSequence, threshold: float = 0.0,
+                 block_size: int = 256):
+        if pssm.protein or sequence.protein:
+            raise ValueError("scanner only supports DNA")  # lib.rs scan()
+        self.block_size = block_size
+        if sequence.wrap < len(pssm) - 1:  # scan.rs:127-131 panics
+            raise ValueError(f"not enough wrapping rows for motif of length {len(pssm)}")
+        coords, values = sequence._pli.score_threshold(pssm, sequence, threshold)
+        rows, length, m = sequence.rows, len(sequence), len(pssm)
+        hits = [Hit(c * rows + r, v) for (r, c), v in zip(coords, values)
+                if c * rows + r + m <= length]
+        hits.sort(key=lambda h: h.position, reverse=True)
+        self._hits = hits
+
+    def __iter__(self) -> "Scanner":
+        return self
+
+    def __next__(self) -> Hit:
+        if not self._hits:
+            raise StopIteration
+        return self._hits.pop()
+
+
+# --- module-level helpers (lib.rs:1335-1451) ---------------------------------------------------
+
+
+class Motif:
+    def __init__(self, counts: Optional[CountMatrix], pwm: WeightMatrix, pssm: ScoringMatrix,
+                 name: Optional[str] = None):
+        self.counts, self.pwm, self.pssm, self.name = counts, pwm, pssm, name
+
+    @property
+    def protein(self) -> bool:
+        return self.pssm.protein
+
+
+def create(sequences: Iterable[str], *, protein: bool = False, name: Optional[str] = None) -> Motif:
+    """lib.rs:1352-1386: counts -> to_freq(0.0).to_weight(None) -> to_scoring()."""
+    encoded = [EncodedSequence(s, protein=protein) for s in sequences]
+    counts = CountMatrix.from_sequences(encoded, protein=protein)
+    pwm = counts.normalize(0.0)
+    return Motif(counts, pwm, pwm.log_odds(), name)
+
+
+def stripe(sequence: str, *, protein: bool = False) -> StripedSequence:
+    """lib.rs:1402-1409"""
+    return EncodedSequence(sequence, protein=protein).stripe()
+
+
+def scan(pssm: ScoringMatrix, sequence: StripedSequence, *, threshold: float = 0.0,
+         block_size: int = 256) -> Scanner:
+    """lib.rs:1437-1451"""
+    return Scanner(pssm, sequence, threshold, block_size)

@@ -1,0 +1,73 @@
+"""Encode / Stripe / configure_wrap on the device vs the oracle."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import lightmotif_amd as lm
+from oracle import c_oracle as co
+
+pytestmark = pytest.mark.gpu
+GOLD = json.loads((Path(__file__).parent / "golden" / "reference_vectors.json").read_text())
+DNA = "ACTGN"
+
+
+def test_g4_literals(pli):
+    g = GOLD["G4_stripe"]
+    enc = lm.EncodedSequence(g["sequence"])
+    s4 = pli.stripe(enc, 4)
+    assert ["".join(DNA[x] for x in row[:4]) for row in s4.matrix()] == g["c4_rows"]
+    s2 = pli.stripe(enc, 2)
+    assert ["".join(DNA[x] for x in row[:2]) for row in s2.matrix()] == g["c2_rows"]
+    s4.configure_wrap(2)
+    assert ["".join(DNA[x] for x in row[:4]) for row in s4.matrix()] == g["c4_wrap2_rows"]
+    assert s4.wrap == 2 and s4.rows == 2 and len(s4) == 5
+
+
+@pytest.mark.parametrize("length", [0, 1, 31, 32, 33, 64, 1000, 8191, 8192, 8193, 100_001])
+@pytest.mark.parametrize("cols", [32, 16, 1])
+def test_stripe_matches_oracle(pli, length, cols):
+    """tests/stripe.rs:17-45 property + exact padding bytes."""
+    rng = np.random.default_rng(length * 7 + cols)
+    enc = rng.integers(0, 5, length, dtype=np.uint8)
+    want = co.stripe(enc, cols, 5)
+    got = pli.stripe(lm.EncodedSequence(enc), cols)
+    assert got.rows == want.rows and len(got) == length and got.stride == want.stride
+    m = got.matrix()
+    assert np.array_equal(m, want.data)
+    for i in range(0, length, max(1, length // 50)):
+        assert m[i % got.rows, i // got.rows] == enc[i]
+
+
+@pytest.mark.parametrize("wraps", [(3,), (14, 19), (5, 2, 40), (100,)])
+def test_configure_wrap_matches_oracle_including_wrap_longer_than_rows(pli, wraps):
+    rng = np.random.default_rng(1)
+    for length in (64, 97, 3000):                        # 64 bp -> 2 rows: wrap >> rows
+        enc = rng.integers(0, 5, length, dtype=np.uint8)
+        want = co.stripe(enc, 32, 5)
+        got = pli.stripe(lm.EncodedSequence(enc), 32)
+        for w in wraps:
+            co.configure_wrap(want, w)
+            got.configure_wrap(w)
+            assert got.wrap == want.wrap
+            assert np.array_equal(got.matrix(), want.data)
+
+
+def test_encode_on_device(pli):
+    g = GOLD["G9_encode"]
+    s = pli.stripe_ascii(g["sequence"])
+    assert np.array_equal(s.matrix(), co.stripe(co.encode(g["sequence"]), 32).data)
+    with pytest.raises(lm.InvalidSymbol, match=r"'\.'"):
+        pli.stripe_ascii(g["unknowns"])                   # tests/encode.rs:22-26
+    lossy = pli.stripe_ascii(g["unknowns"], lossy=True)
+    assert np.array_equal(lossy.matrix(), co.stripe(co.encode(g["unknowns"], lossy=True), 32).data)
+    rng = np.random.default_rng(2)
+    text = bytes(rng.choice(list(b"ACDEFGHIKLMNPQRSTVWYX"), 10_007).tolist())
+    p = pli.stripe_ascii(text, protein=True)
+    assert np.array_equal(p.matrix(), co.stripe(co.encode(text, "P"), 32, 21).data)
+    bad = bytearray(text)
+    bad[5000] = ord("B")
+    bad[7000] = ord("Z")
+    with pytest.raises(lm.InvalidSymbol, match="'B'"):    # first invalid symbol wins
+        pli.stripe_ascii(bytes(bad), protein=True)

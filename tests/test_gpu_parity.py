@@ -1,0 +1,327 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle.
+
+Bar (BASELINE.json north_star): argmax / threshold indices bit-exact vs the
+reference Generic pipeline, scores within 1 ulp f32.  The kernels keep the
+reference's add order, so scores are compared BIT-EXACTLY (0 ulp) here."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import lightmotif_amd as lm
+from oracle import c_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+GOLD = json.loads((Path(__file__).parent / "golden" / "reference_vectors.json").read_text())
+CASES = np.load(Path(__file__).parent / "golden" / "generated_cases.npz")
+CASE_NAMES = sorted({k.split("/")[0] for k in CASES.files})
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def random_pssm(rng, m, k, kind="normal"):
+    p = np.zeros((m, co.stride(k, 4)), np.float32)
+    if kind == "ties":
+        p[:, :k] = rng.integers(-2, 3, (m, k))
+    else:
+        p[:, :k] = rng.normal(0, 2, (m, k))
+    p[:, k - 1] = -np.inf
+    return p
+
+
+def check_against_oracle(pli, enc, pssm_np, cols, k, rows=None, extra_wrap=0, thresholds=()):
+    """Runs score / argmax / max / threshold / fused forms on the GPU and on the oracle."""
+    protein = k == 21
+    m = pssm_np.shape[0]
+    s = co.stripe(enc, cols, k)
+    co.configure_wrap(s, max(m - 1, 0) + extra_wrap)
+    a, b = (0, s.rows) if rows is None else rows
+    want, want_mi = co.score_rows(s, pssm_np, a, b)
+
+    seq = pli.stripe(lm.EncodedSequence(enc, protein=protein), cols)
+    seq.configure_wrap(max(m - 1, 0) + extra_wrap)
+    assert np.array_equal(seq.matrix(), s.data), "striped matrix differs"
+    pssm = lm.ScoringMatrix(pssm_np, protein=protein)
+    scores = lm.StripedScores.empty(pli, cols)
+    pli.score_rows_into(pssm, seq, range(a, b), scores)
+    got = scores.matrix()
+    assert got.shape == want.shape
+    assert scores.max_index == want_mi
+    assert np.array_equal(bits(got[:, :cols]), bits(want[:, :cols])), \
+        f"scores differ ({pli.last_kernel})"
+    # Maximum
+    assert pli.argmax(scores) == co.argmax(want, cols)
+    wmax = co.max_(want, cols)
+    gmax = pli.max(scores)
+    assert (gmax is None) == (wmax is None)
+    if wmax is not None:
+        assert bits(np.float32(gmax)) == bits(wmax)
+    # fused argmax
+    fused = pli.score_argmax(pssm, seq, range(a, b))
+    if want.shape[0] == 0:
+        assert fused is None
+    else:
+        assert fused[0] == co.argmax(want, cols)
+        assert bits(np.float32(fused[1])) == bits(wmax)
+    # Threshold (row-major order is part of the contract here)
+    for t in thresholds:
+        wrc = [tuple(map(int, rc)) for rc in co.threshold(want, cols, float(t))]
+        assert pli.threshold(scores, float(t)) == wrc, f"threshold({t})"
+        frc, fval = pli.score_threshold(pssm, seq, float(t), range(a, b))
+        assert frc == wrc, f"fused threshold({t})"
+        assert np.array_equal(bits(fval), bits([want[r, c] for r, c in wrc]))
+    return scores, want
+
+
+# ---- the reference's own known answers -------------------------------------------------
+
+
+def golden_objects(pli, cols=32):
+    g = GOLD["G1_scores"]
+    motif = lm.create(g["patterns"])
+    pssm = motif.counts.normalize(g["pseudocount"]).log_odds()
+    seq = pli.stripe(lm.EncodedSequence(g["sequence"]), cols)
+    return g, pssm, seq
+
+
+@pytest.mark.parametrize("cols", [32, 1, 16])
+def test_g1_scores_like_tests_dna_rs(pli, cols):
+    g, pssm, seq = golden_objects(pli, cols)
+    seq.configure(pssm)
+    result = pli.score(pssm, seq)
+    scores = result.unstripe()
+    assert len(scores) == len(g["expected"])                            # tests/dna.rs:81
+    assert np.abs(scores - np.float32(g["expected"])).max() < 1e-5       # tests/dna.rs:83-90
+    # test_score_rows (tests/dna.rs:40-63): exact equality
+    sc = lm.StripedScores.empty(pli, cols)
+    pli.score_rows_into(pssm, seq, range(0, 2), sc)
+    m = sc.matrix()
+    assert m.shape[0] == 2 and m[0, 0] == np.float32(g["exact"]["0"])
+    if seq.rows > 1:
+        assert m[1, 0] == np.float32(g["exact"]["1"])
+        pli.score_rows_into(pssm, seq, range(1, 2), sc)
+        m = sc.matrix()
+        assert m.shape[0] == 1 and m[0, 0] == np.float32(g["exact"]["1"])
+
+
+@pytest.mark.parametrize("cols", [32, 1, 16])
+def test_g2_g3_argmax_threshold_like_tests_dna_rs(pli, cols):
+    _, pssm, seq = golden_objects(pli, cols)
+    seq.configure(pssm)
+    result = pli.score(pssm, seq)
+    mc = pli.argmax(result)
+    assert result.offset(*mc) == GOLD["G2_argmax"]["offset"]             # tests/dna.rs:138
+    for case in GOLD["G3_threshold"]["cases"]:
+        idx = sorted(result.offset(r, c) for r, c in pli.threshold(result, case["t"]))
+        assert idx == case["sorted_offsets"]                             # tests/dna.rs:158-172
+
+
+def test_readme_example(pli):
+    """README.md:77-90 through the user-facing objects (default 32 columns)."""
+    g = GOLD["G1_scores"]
+    pssm = lm.create(g["patterns"]).counts.normalize(0.1).log_odds()
+    striped = lm.stripe(g["sequence"])
+    scores = pssm.calculate(striped)                                     # lib.rs:855-874
+    assert len(scores) == 50
+    assert scores[0] == np.float32(-23.07094)
+    assert scores.argmax() == 18
+    assert scores.threshold(10.0) == []
+    assert scores.threshold(-10.0) == [18, 32, 27]                       # SURVEY A3 [probe], C = 32
+    assert abs(scores.max() - (-5.50167)) < 1e-5
+    for x, y in zip(scores, g["expected"]):                              # test_pipeline.py:72-73
+        assert round(x - y, 5) == 0
+
+
+def test_g5_scanner_like_test_scanner_py(pli):
+    g = GOLD["G1_scores"]
+    pssm = lm.create(g["patterns"]).counts.normalize(0.1).log_odds()
+    seq = lm.stripe(g["sequence"])
+    seq.configure(pssm)
+    assert len(list(lm.scan(pssm, seq))) == 0                            # test_scanner.py:71-72
+    hits = list(lm.scan(pssm, seq, threshold=-10.0))
+    assert len(hits) == 3
+    hits.sort(key=lambda h: h.position)
+    for h, w in zip(hits, GOLD["G5_scanner"]["threshold_m10"]):
+        assert h.position == w["position"] and abs(h.score - w["score"]) < 1e-5
+
+
+def test_g7_empty_row_range_does_not_fail(pli):
+    g = GOLD["G7_empty_range"]
+    seq = pli.stripe(lm.EncodedSequence(g["sequence"]), g["columns"])
+    pssm = lm.create(g["patterns"]).counts.normalize(g["pseudocount"]).log_odds()
+    seq.configure(pssm)
+    sc = lm.StripedScores.empty(pli, g["columns"])
+    pli.score_rows_into(pssm, seq, range(1, 1), sc)                      # pli/mod.rs:603-623
+    assert sc.rows == 0 and sc.is_empty() and sc.max_index == 0
+    assert pli.argmax(sc) is None and pli.max(sc) is None and pli.threshold(sc, 0.0) == []
+
+
+# ---- committed fixtures + seeded random cases vs the oracle ---------------------------------
+
+
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_generated_fixtures(pli, name):
+    c = {k.split("/", 1)[1]: CASES[k] for k in CASES.files if k.startswith(name + "/")}
+    cols, k = int(c["cols"]), int(c["k"])
+    m = c["pssm"].shape[0]
+    extra = int(c["wrap"]) - max(m - 1, 0)
+    scores, _ = check_against_oracle(pli, c["encoded"], c["pssm"], cols, k,
+                                     rows=tuple(map(int, c["row_range"])), extra_wrap=extra,
+                                     thresholds=list(c["thresholds"]))
+    assert np.array_equal(bits(scores.matrix()), bits(c["scores"]))      # the committed bits
+    am = pli.argmax(scores)
+    assert (am if am else (-1, -1)) == tuple(c["argmax"])
+    for i, t in enumerate(c["thresholds"]):
+        got = np.array(pli.threshold(scores, float(t)), dtype=np.int64).reshape(-1, 2)
+        assert np.array_equal(got, c[f"threshold_{i}"])
+
+
+@pytest.mark.parametrize("m", list(range(1, 35)) + [40, 64])
+def test_every_motif_length_dna(pli, m):
+    """Unrolled kernels exist for M = 1..32; longer motifs take the generic kernel."""
+    rng = np.random.default_rng(1000 + m)
+    length = int(rng.integers(32 * (m + 2), 9000))
+    enc = rng.integers(0, 5, length, dtype=np.uint8)   # includes N -> -inf scores
+    p = random_pssm(rng, m, 5)
+    check_against_oracle(pli, enc, p, 32, 5, thresholds=[0.0, -np.inf])
+    if m <= 32:
+        assert pli.last_kernel.startswith("score_c32") or length // 32 < m + 1
+
+
+@pytest.mark.parametrize("length", [0, 1, 14, 15, 16, 31, 32, 33, 63, 64, 65, 479, 480, 481, 2047, 4099])
+def test_ragged_lengths(pli, length):
+    rng = np.random.default_rng(length)
+    enc = rng.integers(0, 4, length, dtype=np.uint8)
+    check_against_oracle(pli, enc, random_pssm(rng, 15, 5), 32, 5, thresholds=[1.0])
+
+
+@pytest.mark.parametrize("rows", [(0, 1), (3, 4), (0, 16), (5, 37), (100, 301), (299, 300), (7, 7), (9, 2)])
+def test_row_ranges(pli, rows):
+    rng = np.random.default_rng(42)
+    enc = rng.integers(0, 4, 9601, dtype=np.uint8)       # 301 rows
+    check_against_oracle(pli, enc, random_pssm(rng, 20, 5), 32, 5, rows=rows, thresholds=[2.0])
+
+
+@pytest.mark.parametrize("rps", [21, 61, 500, 100000])
+def test_rows_per_stream_knob_does_not_change_results(pli, rps):
+    rng = np.random.default_rng(5)
+    enc = rng.integers(0, 4, 200_003, dtype=np.uint8)
+    pli.set_rows_per_stream(rps)
+    try:
+        check_against_oracle(pli, enc, random_pssm(rng, 20, 5), 32, 5, thresholds=[8.0])
+    finally:
+        pli.set_rows_per_stream(0)
+
+
+@pytest.mark.parametrize("cols", [1, 2, 4, 16, 32, 33])
+def test_other_column_counts(pli, cols):
+    rng = np.random.default_rng(cols)
+    enc = rng.integers(0, 5, 777, dtype=np.uint8)
+    check_against_oracle(pli, enc, random_pssm(rng, 9, 5, "ties"), cols, 5, thresholds=[0.0, 3.0])
+
+
+@pytest.mark.parametrize("m", [1, 5, 12, 20, 33])
+def test_protein(pli, m):
+    rng = np.random.default_rng(m)
+    enc = rng.integers(0, 21, 20_011, dtype=np.uint8)
+    check_against_oracle(pli, enc, random_pssm(rng, m, 21), 32, 21, thresholds=[4.0])
+
+
+def test_million_positions_bitwise(pli):
+    rng = np.random.default_rng(99)
+    enc = rng.integers(0, 4, 1_000_003, dtype=np.uint8)
+    p = random_pssm(rng, 20, 5)
+    scores, want = check_against_oracle(pli, enc, p, 32, 5, thresholds=[12.0])
+    assert scores.rows == 31251
+
+
+def test_ties_take_the_last_cell_in_row_major_order(pli):
+    """pli/mod.rs:146 `>=`: differs from the AVX2 and SSE2 rules."""
+    enc = np.zeros(32 * 50, np.uint8)                     # all 'A' -> every score equal
+    p = np.zeros((4, 8), np.float32)
+    p[:, 0] = 1.5
+    p[:, 4] = -np.inf
+    scores, want = check_against_oracle(pli, enc, p, 32, 5, thresholds=[6.0, 6.5])
+    # 50 rows x 32 cols; the last 3 positions (tail of column 31) touch the N wrap -> -inf
+    assert pli.argmax(scores) == co.argmax(want, 32) == (49, 30)
+
+
+def test_nan_and_all_neg_inf(pli):
+    rng = np.random.default_rng(3)
+    enc = rng.integers(0, 4, 3200, dtype=np.uint8)
+    p = random_pssm(rng, 6, 5)
+    p[2, 1] = np.nan
+    check_against_oracle(pli, enc, p, 32, 5, thresholds=[0.0])
+    # scores[0][0] NaN -> argmax (0, 0) (pli/mod.rs:142-146)
+    enc2 = enc.copy()
+    enc2[2] = 1
+    scores, want = check_against_oracle(pli, enc2, p, 32, 5)
+    assert np.isnan(want[0, 0]) and pli.argmax(scores) == (0, 0)
+    # every score -inf: answer is the very last cell, even past max_index
+    p2 = np.full((6, 8), -np.inf, np.float32)
+    scores, want = check_against_oracle(pli, enc, p2, 32, 5, thresholds=[-np.inf])
+    assert pli.argmax(scores) == (99, 31)
+
+
+def test_finite_default_column_exposes_padded_tail(pli):
+    """A5: Threshold/Maximum ignore max_index; reproduce, do not fix."""
+    rng = np.random.default_rng(8)
+    enc = rng.integers(0, 4, 1000, dtype=np.uint8)        # 32 rows, 24 padded cells
+    p = random_pssm(rng, 5, 5)
+    p[:, 4] = 50.0                                        # N scores high
+    scores, want = check_against_oracle(pli, enc, p, 32, 5, thresholds=[100.0])
+    r, c = pli.argmax(scores)
+    assert scores.offset(r, c) >= len(scores)             # offset beyond len(scores)
+
+
+def test_not_enough_wrap_rows_is_an_error(pli):
+    seq = pli.stripe(lm.EncodedSequence("ACGT" * 100), 32)
+    pssm = lm.ScoringMatrix(np.zeros((10, 8), np.float32))
+    with pytest.raises(lm.LightmotifHipError, match="not enough wrapping rows for motif of length 10"):
+        pli.score(pssm, seq)                              # avx2.rs:832-837 panics
+    seq.configure_wrap(8)
+    with pytest.raises(lm.LightmotifHipError, match="not enough wrapping rows"):
+        pli.score(pssm, seq)
+    seq.configure_wrap(9)
+    assert pli.score(pssm, seq).rows == seq.rows
+    sc = lm.StripedScores.empty(pli, 32)
+    with pytest.raises(lm.LightmotifHipError):
+        pli.score_rows_into(pssm, seq, range(0, seq.rows + 1), sc)
+
+
+def test_host_pointer_entry_points(pli):
+    """The forms a Rust shim would call with pointers into its own Vecs."""
+    import ctypes as C
+    from lightmotif_amd import _ffi
+    L = _ffi.lib()
+    rng = np.random.default_rng(17)
+    enc = rng.integers(0, 4, 50_000, dtype=np.uint8)
+    p = random_pssm(rng, 20, 5)
+    s = co.stripe(enc, 32, 5)
+    co.configure_wrap(s, 19)
+    want, mi = co.score_rows(s, p, 10, 900)
+    out = np.zeros((890, 32), np.float32)
+    orow, omi = C.c_size_t(0), C.c_size_t(0)
+    st = L.lm_hip_score_f32(s.data.ctypes.data, s.data.shape[0], 32, 32, s.wrap, s.length,
+                            p.ctypes.data, 20, 8, 5, 10, 900, out.ctypes.data, 32,
+                            C.byref(orow), C.byref(omi))
+    assert st == 0, L.lm_hip_last_error()
+    assert (orow.value, omi.value) == (890, mi)
+    assert np.array_equal(bits(out), bits(want))
+    found, best, val = C.c_int(0), _ffi.Coords(), C.c_float(0)
+    assert L.lm_hip_argmax_f32(out.ctypes.data, 890, 32, 32, C.byref(found), C.byref(best), C.byref(val)) == 0
+    assert found.value == 1 and (best.row, best.col) == co.argmax(want, 32)
+    ptr, n = C.POINTER(_ffi.Coords)(), C.c_size_t(0)
+    assert L.lm_hip_threshold_f32(out.ctypes.data, 890, 32, 32, 9.0, C.byref(ptr), C.byref(n)) == 0
+    got = [(ptr[i].row, ptr[i].col) for i in range(n.value)]
+    L.lm_hip_free(ptr)
+    assert got == [tuple(map(int, rc)) for rc in co.threshold(want, 32, 9.0)]
+    # degenerate: L < M is not an error (pli/mod.rs:85-88)
+    st = L.lm_hip_score_f32(s.data.ctypes.data, s.data.shape[0], 32, 32, s.wrap, 5,
+                            p.ctypes.data, 20, 8, 5, 0, 10, out.ctypes.data, 32,
+                            C.byref(orow), C.byref(omi))
+    assert st == 0 and (orow.value, omi.value) == (0, 0)

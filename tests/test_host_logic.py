@@ -1,0 +1,65 @@
+"""Host-side logic of lightmotif_amd.lib that needs no device: encoding, count ->
+weight -> scoring matrix construction (pwm/mod.rs:209-258, 376-431, 505-526), layout."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import lightmotif_amd as lm
+from lightmotif_amd import lib
+from oracle import c_oracle as co
+
+GOLD = json.loads((Path(__file__).parent / "golden" / "reference_vectors.json").read_text())
+
+
+def test_encode_matches_reference_alphabets():
+    g = GOLD["G9_encode"]
+    e = lm.EncodedSequence(g["sequence"])
+    assert str(e) == g["sequence"] and len(e) == 64
+    assert np.array_equal(e.data, co.encode(g["sequence"]))
+    with pytest.raises(lm.InvalidSymbol, match=r"'\.'"):
+        lm.EncodedSequence(g["unknowns"])
+    lossy = lm.EncodedSequence.encode_lossy(g["unknowns"])
+    assert np.array_equal(lossy.data, co.encode(g["unknowns"], lossy=True))
+    p = lm.EncodedSequence("ACDEFGHIKLMNPQRSTVWYX", protein=True)
+    assert list(p.data) == list(range(21))
+    with pytest.raises(lm.InvalidSymbol):
+        lm.EncodedSequence("PILFFRLK")  # lib.rs module doc example: protein text as DNA
+
+
+def test_create_normalize_log_odds_equals_oracle_pssm():
+    g = GOLD["G1_scores"]
+    motif = lm.create(g["patterns"])
+    assert motif.counts[0] == [0, 0, 0, 2, 0] and len(motif.counts) == 15
+    pssm = motif.counts.normalize(g["pseudocount"]).log_odds()
+    want = co.pssm_from_sites([co.encode(p) for p in g["patterns"]], pseudocount=g["pseudocount"])
+    assert pssm.data.shape == want.shape == (15, 8)          # DenseMatrix<f32, U5> stride 8
+    assert np.array_equal(pssm.data.view(np.uint32), want.view(np.uint32))
+    assert np.all(np.isneginf(pssm.data[:, 4]))              # pwm/mod.rs:422-423
+    # pseudocount 0 -> -inf for unseen symbols (tests/scan.rs:47-60 uses it)
+    z = motif.pssm
+    assert np.isneginf(z.data[0, 0]) and z.data[0, 3] == np.float32(2.0)
+
+
+def test_protein_pssm_and_layout():
+    sites = ["PILFFRLK", "KDMLKEYL", "PFRLTHKL"]
+    motif = lm.create(sites, protein=True)
+    pssm = motif.counts.normalize(0.1).log_odds()
+    want = co.pssm_from_sites([co.encode(s, "P") for s in sites], k=21, pseudocount=0.1)
+    assert pssm.data.shape == (8, 24)
+    assert np.array_equal(pssm.data.view(np.uint32), want.view(np.uint32))
+
+
+def test_scoring_matrix_from_dict_and_reverse_complement():
+    sm = lm.ScoringMatrix({"A": [1, 2], "C": [3, 4], "T": [5, 6], "G": [7, 8]})
+    assert sm.data.shape == (2, 8) and sm.data[0, 4] == 0.0   # lib.rs:729-745 missing -> 0.0
+    rc = sm.reverse_complement()
+    assert list(rc.data[0, :4]) == [6, 8, 2, 4]               # row 1 with A<->T, C<->G
+    with pytest.raises(ValueError):
+        lm.ScoringMatrix({"A": [1, 2], "C": [3]})
+
+
+def test_stride_helper():
+    for c in GOLD["G6_stride"]["cases"]:
+        assert lib.stride(c["cols"], c["elem"]) == c["stride"]

@@ -1,0 +1,186 @@
+"""The CPU oracle against every literal vector the reference's own tests hold for
+the scoring path (tests/golden/reference_vectors.json), the independent numpy
+restatement, the committed generated fixtures and the AVX2 baseline port."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import np_oracle as no
+
+GOLD = json.loads((Path(__file__).parent / "golden" / "reference_vectors.json").read_text())
+CASES = np.load(Path(__file__).parent / "golden" / "generated_cases.npz")
+CASE_NAMES = sorted({k.split("/")[0] for k in CASES.files})
+DNA = "ACTGN"
+
+
+def golden_setup(cols):
+    g = GOLD["G1_scores"]
+    s = co.stripe(co.encode(g["sequence"]), cols)
+    pssm = co.pssm_from_sites([co.encode(p) for p in g["patterns"]], pseudocount=g["pseudocount"])
+    co.configure_wrap(s, pssm.shape[0] - 1)
+    return g, s, pssm
+
+
+@pytest.mark.parametrize("cols", [32, 1, 16])
+def test_g1_scores(cols):
+    g, s, pssm = golden_setup(cols)
+    scores, mi = co.score_rows(s, pssm)
+    u = co.unstripe(scores, cols, mi)
+    assert len(u) == g["unstripe_len"]                               # tests/dna.rs:81
+    assert np.abs(u - np.float32(g["expected"])).max() < g["tolerance"]  # tests/dna.rs:83-90
+    for i, v in g["exact"].items():                                  # tests/dna.rs:57-58
+        assert u[int(i)] == np.float32(v)
+    # score_rows_into(0..2) and (1..2): tests/dna.rs:55-62
+    sc, _ = co.score_rows(s, pssm, 0, 2)
+    assert sc.shape[0] == 2 and sc[0, 0] == np.float32(g["exact"]["0"])
+    if s.rows > 1:
+        assert sc[1, 0] == np.float32(g["exact"]["1"])
+        sc, _ = co.score_rows(s, pssm, 1, 2)
+        assert sc.shape[0] == 1 and sc[0, 0] == np.float32(g["exact"]["1"])
+    # score_position: tests/dna.rs:175-199
+    for i in range(50):
+        assert abs(co.score_position(s, pssm, i) - g["expected"][i]) < 1e-5
+
+
+@pytest.mark.parametrize("cols", [32, 1, 16])
+def test_g2_g3_argmax_threshold(cols):
+    _, s, pssm = golden_setup(cols)
+    scores, _ = co.score_rows(s, pssm)
+    am = co.argmax(scores, cols)
+    assert co.offset(scores.shape[0], *am) == GOLD["G2_argmax"]["offset"]
+    assert co.max_(scores, cols) == scores[am]
+    for case in GOLD["G3_threshold"]["cases"]:
+        rc = co.threshold(scores, cols, case["t"])
+        offs = sorted(co.offset(scores.shape[0], int(r), int(c)) for r, c in rc)
+        assert offs == case["sorted_offsets"]
+
+
+def test_g4_stripe_literals():
+    g = GOLD["G4_stripe"]
+    enc = co.encode(g["sequence"])
+    s4 = co.stripe(enc, 4)
+    assert ["".join(DNA[x] for x in row[:4]) for row in s4.data] == g["c4_rows"]
+    s2 = co.stripe(enc, 2)
+    assert ["".join(DNA[x] for x in row[:2]) for row in s2.data] == g["c2_rows"]
+    co.configure_wrap(s4, 2)
+    assert ["".join(DNA[x] for x in row[:4]) for row in s4.data] == g["c4_wrap2_rows"]
+
+
+def test_g5_scanner_hits_by_brute_force():
+    """scan.rs:185-190: hits = positions with score >= t and pos + M <= L."""
+    _, s, pssm = golden_setup(32)
+    scores, mi = co.score_rows(s, pssm)
+    u = co.unstripe(scores, 32, mi)
+    assert (u >= 0.0).sum() == GOLD["G5_scanner"]["threshold_0_hits"]
+    hits = [(i, float(u[i])) for i in np.flatnonzero(u >= -10.0)]
+    want = GOLD["G5_scanner"]["threshold_m10"]
+    assert [h[0] for h in hits] == [w["position"] for w in want]
+    for h, w in zip(hits, want):
+        assert abs(h[1] - w["score"]) < 1e-5
+
+
+def test_g6_stride_table():
+    for c in GOLD["G6_stride"]["cases"]:
+        assert co.stride(c["cols"], c["elem"]) == c["stride"]
+        assert no.stride(c["cols"], c["elem"]) == c["stride"]
+    assert co.stride(5, 4) == 8 and co.stride(21, 4) == 24
+
+
+def test_g7_empty_row_range():
+    g = GOLD["G7_empty_range"]
+    s = co.stripe(co.encode(g["sequence"]), g["columns"])
+    pssm = co.pssm_from_sites([co.encode(p) for p in g["patterns"]], pseudocount=g["pseudocount"])
+    co.configure_wrap(s, pssm.shape[0] - 1)
+    sc, mi = co.score_rows(s, pssm, *g["rows"])
+    assert sc.shape[0] == g["expected_rows"] and mi == 0
+
+
+def test_g9_encode():
+    g = GOLD["G9_encode"]
+    assert "".join(DNA[x] for x in co.encode(g["sequence"])) == g["sequence"]
+    with pytest.raises(ValueError, match=r"'\.'"):
+        co.encode(g["unknowns"])
+    lossy = co.encode(g["unknowns"], lossy=True)
+    assert "".join(DNA[x] for x in lossy) == g["unknowns"].replace(".", "N")
+
+
+def test_short_sequence_is_empty():
+    s = co.stripe(co.encode("ACGT"), 32)
+    pssm = co.pssm_from_sites([co.encode("ACGTAC")])
+    co.configure_wrap(s, 5)
+    sc, mi = co.score_rows(s, pssm)
+    assert sc.shape[0] == 0 and mi == 0
+    assert co.argmax(sc, 32) is None
+
+
+def test_argmax_rules_ties_nan():
+    """pli/mod.rs:135-155: last maximal cell in (row, col) order; NaN never wins."""
+    sc = np.zeros((3, 32), np.float32)
+    assert co.argmax(sc, 32) == (2, 31) == no.argmax(sc, 32)
+    sc[1, 5] = np.nan
+    assert co.argmax(sc, 32) == (2, 31)
+    sc[0, 0] = np.nan           # scores[0] is NaN: nothing ever compares >= NaN
+    assert co.argmax(sc, 32) == (0, 0) == no.argmax(sc, 32)
+    sc[:] = -np.inf
+    assert co.argmax(sc, 32) == (2, 31)
+    sc[1, 7] = 3.0
+    sc[1, 9] = 3.0
+    sc[0, 30] = 3.0
+    assert co.argmax(sc, 32) == (1, 9)
+
+
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_generated_fixtures_match_both_restatements(name):
+    c = {k.split("/", 1)[1]: CASES[k] for k in CASES.files if k.startswith(name + "/")}
+    cols, k = int(c["cols"]), int(c["k"])
+    enc, pssm = c["encoded"], c["pssm"]
+    m = pssm.shape[0]
+    s = co.stripe(enc, cols, k)
+    co.configure_wrap(s, int(c["wrap"]))
+    assert np.array_equal(s.data, c["striped"])
+    a, b = map(int, c["row_range"])
+    sc, mi = co.score_rows(s, pssm, a, b)
+    assert mi == int(c["max_index"])
+    assert np.array_equal(sc.view(np.uint32), c["scores"].view(np.uint32))
+    sc2, _ = no.score_rows(c["striped"], cols, len(enc), pssm, a, b)
+    assert np.array_equal(sc2.view(np.uint32), c["scores"].view(np.uint32))
+    am = co.argmax(sc, cols)
+    assert (am if am else (-1, -1)) == tuple(c["argmax"])
+    for i, t in enumerate(c["thresholds"]):
+        assert np.array_equal(co.threshold(sc, cols, float(t)).astype(np.int64), c[f"threshold_{i}"])
+    assert m == pssm.shape[0]
+
+
+def test_avx2_port_matches_generic_scores_bitwise():
+    """avx2.rs:104-199 vs pli/mod.rs:96-105: identical f32 add order."""
+    rng = np.random.default_rng(7)
+    for k, m in ((5, 20), (5, 7), (21, 12)):
+        enc = rng.integers(0, k, size=70001, dtype=np.uint8)
+        s = co.stripe(enc, 32, k)
+        pssm = np.zeros((m, co.stride(k, 4)), np.float32)
+        pssm[:, :k] = rng.normal(0, 3, (m, k))
+        pssm[:, k - 1] = -np.inf
+        al = co.aligned_empty(pssm.shape, np.float32)
+        al[:] = pssm
+        with pytest.raises(RuntimeError, match="not enough wrapping rows"):  # avx2.rs:832-837
+            co.avx2_score_rows(s, al)
+        co.configure_wrap(s, m - 1)
+        want, _ = co.score_rows(s, al)
+        for threads in (1, 3):
+            got = co.avx2_score_rows(s, al, threads=threads)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        got = co.avx2_score_rows(s, al, row_begin=5, row_end=90)
+        assert np.array_equal(got.view(np.uint32), want[5:90].view(np.uint32))
+
+
+def test_avx2_argmax_agrees_when_maximum_is_unique():
+    """avx2.rs:351-426 has a different tie rule but must agree with
+    Generic whenever the maximum is unique (tests/argmax.rs:41-52)."""
+    rng = np.random.default_rng(11)
+    sc = co.aligned_empty((500, 32), np.float32)
+    sc[:] = rng.normal(0, 1, sc.shape)
+    sc[123, 17] = 99.0
+    assert co.avx2_argmax(sc, 500 * 32) == co.argmax(sc, 32) == (123, 17)
