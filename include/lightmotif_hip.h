@@ -149,6 +149,15 @@ int lm_hip_argmax_f32_dptr(lm_hip_ctx *ctx, const float *d_scores, size_t rows,
                            size_t stride, size_t cols, int *found,
                            lm_hip_coords *best, float *value);
 
+/* Same for one SHARD of a row-partitioned score matrix (multi-GPU):
+ * with first_cell_rule = 0 the "scores[0][0] is NaN -> (0,0)" rule is not applied,
+ * because the shard's first cell is not the matrix's first cell; the caller
+ * applies it once, on the shard that holds row 0.  first_cell_rule = 1 is
+ * lm_hip_argmax_f32_dptr. */
+int lm_hip_argmax_shard_f32_dptr(lm_hip_ctx *ctx, const float *d_scores, size_t rows,
+                                 size_t stride, size_t cols, int first_cell_rule, int *found,
+                                 lm_hip_coords *best, float *value);
+
 /* Threshold::threshold (pli/mod.rs:210-221): every (row, col) with x >= t, in
  * row-major order (the reference's push order).  *coords is malloc'ed by the
  * library (NULL when *n == 0); release with lm_hip_free.  Synchronises. */
@@ -167,6 +176,13 @@ int lm_hip_score_argmax_f32_dptr(lm_hip_ctx *ctx, const lm_hip_pssm *pssm,
                                  size_t seq_stride, size_t cols, size_t wrap, size_t length,
                                  size_t row_begin, size_t row_end,
                                  int *found, lm_hip_coords *best, float *value);
+
+/* Shard form of the fused argmax (see lm_hip_argmax_shard_f32_dptr). */
+int lm_hip_score_argmax_shard_f32_dptr(lm_hip_ctx *ctx, const lm_hip_pssm *pssm,
+                                       const uint8_t *d_seq, size_t seq_rows_total,
+                                       size_t seq_stride, size_t cols, size_t wrap, size_t length,
+                                       size_t row_begin, size_t row_end, int first_cell_rule,
+                                       int *found, lm_hip_coords *best, float *value);
 
 /* Equivalent to score_rows_into followed by threshold(t): (row, col) list in
  * row-major order, rows relative to row_begin. */

@@ -60,9 +60,12 @@ SIGNATURES = {
     "lm_hip_score_f32_dptr": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz, _vp, _sz,
                                        _szp, _szp]),
     "lm_hip_argmax_f32_dptr": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _ip, _cp, _fp]),
+    "lm_hip_argmax_shard_f32_dptr": (C.c_int, [_vp, _vp, _sz, _sz, _sz, C.c_int, _ip, _cp, _fp]),
     "lm_hip_threshold_f32_dptr": (C.c_int, [_vp, _vp, _sz, _sz, _sz, C.c_float, C.POINTER(_cp), _szp]),
     "lm_hip_score_argmax_f32_dptr": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz,
                                               _ip, _cp, _fp]),
+    "lm_hip_score_argmax_shard_f32_dptr": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz,
+                                                    _sz, C.c_int, _ip, _cp, _fp]),
     "lm_hip_score_threshold_f32_dptr": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz,
                                                  C.c_float, C.POINTER(_cp), C.POINTER(_fp), _szp]),
     "lm_hip_encode_dptr": (C.c_int, [_vp, C.c_char, _vp, _sz, C.c_int, _vp, _szp]),

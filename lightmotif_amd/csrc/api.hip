@@ -355,6 +355,13 @@ static void record_to_coords(const ArgmaxRecord &rec, size_t cols, int *found, l
 int lm_hip_argmax_f32_dptr(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride,
                            size_t cols, int *found, lm_hip_coords *best, float *value)
 {
+    return lm_hip_argmax_shard_f32_dptr(ctx, d_scores, rows, stride, cols, 1, found, best, value);
+}
+
+int lm_hip_argmax_shard_f32_dptr(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride,
+                                 size_t cols, int first_cell_rule, int *found, lm_hip_coords *best,
+                                 float *value)
+{
     if (!ctx || !found)
         return fail(LM_HIP_ERR_BAD_ARGS, "argmax: null argument");
     *found = 0;
@@ -365,7 +372,7 @@ int lm_hip_argmax_f32_dptr(lm_hip_ctx *ctx, const float *d_scores, size_t rows, 
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard guard(ctx->device);
     ArgmaxRecord rec{};
-    LM_TRY(launch_argmax(ctx, d_scores, rows, stride, cols, &rec));
+    LM_TRY(launch_argmax(ctx, d_scores, rows, stride, cols, first_cell_rule, &rec));
     record_to_coords(rec, cols, found, best, value);
     return LM_HIP_OK;
 }
@@ -393,6 +400,17 @@ int lm_hip_score_argmax_f32_dptr(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const
                                  size_t length, size_t row_begin, size_t row_end, int *found,
                                  lm_hip_coords *best, float *value)
 {
+    return lm_hip_score_argmax_shard_f32_dptr(ctx, pssm, d_seq, seq_rows_total, seq_stride, cols,
+                                              wrap, length, row_begin, row_end, 1, found, best,
+                                              value);
+}
+
+int lm_hip_score_argmax_shard_f32_dptr(lm_hip_ctx *ctx, const lm_hip_pssm *pssm,
+                                       const uint8_t *d_seq, size_t seq_rows_total,
+                                       size_t seq_stride, size_t cols, size_t wrap, size_t length,
+                                       size_t row_begin, size_t row_end, int first_cell_rule,
+                                       int *found, lm_hip_coords *best, float *value)
+{
     if (!ctx || !found)
         return fail(LM_HIP_ERR_BAD_ARGS, "score_argmax: null argument");
     *found = 0;
@@ -405,7 +423,7 @@ int lm_hip_score_argmax_f32_dptr(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const
     DeviceGuard guard(ctx->device);
     ScoreArgs a{pssm, d_seq, seq_stride, cols, row_begin, row_end, nullptr, 0};
     ArgmaxRecord rec{};
-    LM_TRY(launch_score_argmax(ctx, a, &rec));
+    LM_TRY(launch_score_argmax(ctx, a, first_cell_rule, &rec));
     record_to_coords(rec, cols, found, best, value);
     return LM_HIP_OK;
 }

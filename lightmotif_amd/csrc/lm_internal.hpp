@@ -112,13 +112,13 @@ struct ScoreArgs {
 // Materialising score kernels.
 int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a);
 // Fused score+argmax: leaves one ArgmaxRecord at ctx->scratch (device) -> out.
-int launch_score_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *out);
+int launch_score_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, int first_cell_rule, ArgmaxRecord *out);
 // Fused score+threshold: hits as (flat index, value) sorted by flat index.
 int launch_score_threshold(lm_hip_ctx *ctx, const ScoreArgs &a, float t,
                            std::vector<unsigned long long> *flat, std::vector<float> *values);
 
 int launch_argmax(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride,
-                  size_t cols, ArgmaxRecord *out);
+                  size_t cols, int first_cell_rule, ArgmaxRecord *out);
 int launch_threshold(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride,
                      size_t cols, float t, lm_hip_coords **coords, size_t *n);
 

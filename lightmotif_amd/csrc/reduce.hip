@@ -19,7 +19,7 @@
 namespace lm {
 
 int finalize_argmax_materialised(lm_hip_ctx *ctx, const ArgmaxRecord *d_blocks, unsigned nblocks,
-                                 const float *d_scores, ArgmaxRecord *d_out);
+                                 const float *d_scores, int first_cell_rule, ArgmaxRecord *d_out);
 
 // ---- argmax ---------------------------------------------------------------------------
 
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void argmax_strided(const float *__restrict
 }
 
 int launch_argmax(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride, size_t cols,
-                  ArgmaxRecord *out)
+                  int first_cell_rule, ArgmaxRecord *out)
 {
     const unsigned long long ncells = (unsigned long long)rows * cols;
     const unsigned grid = (unsigned)std::max<unsigned long long>(
@@ -113,7 +113,7 @@ int launch_argmax(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t st
                            (unsigned long long)rows, (unsigned long long)stride, (unsigned)cols,
                            recs + 1);
     LM_HIP_TRY(hipGetLastError());
-    LM_TRY(finalize_argmax_materialised(ctx, recs + 1, grid, d_scores, recs));
+    LM_TRY(finalize_argmax_materialised(ctx, recs + 1, grid, d_scores, first_cell_rule, recs));
     LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, recs, sizeof(ArgmaxRecord), hipMemcpyDeviceToHost,
                               ctx->stream));
     LM_HIP_TRY(hipStreamSynchronize(ctx->stream));

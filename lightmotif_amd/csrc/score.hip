@@ -60,8 +60,11 @@ struct C32Plan {
     size_t lds = 0;
 };
 
-// Rows per stream T = q*M + 1.  The default aims at ~8 resident wavefronts per
-// SIMD worth of streams with enough rows each to amortise the M-1 fill steps.
+// Rows per stream T = q*M + 1.  Short streams win: the rows being written by all
+// resident wavefronts then form a compact window that moves through memory in
+// order, which HBM (and the TLB) reward more than the M-1 fill steps per stream
+// cost -- the kernel is HBM-bound, not LDS-bound (profiles/r01_kbench2_nt.txt:
+// T=61 0.947 ms, T=501 0.995 ms, T=4001 1.12 ms at M=20 on 1 Gbp).
 static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store)
 {
     C32Plan p;
@@ -74,7 +77,9 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store)
     const size_t lds = std::max<size_t>(K * table_stride((int)M) * sizeof(float), 64);
     if (lds > 60 * 1024)
         return p;
-    unsigned long long target = ctx->rows_per_stream ? ctx->rows_per_stream : 512;
+    // The fused kernels write nothing, so they are LDS/VALU-bound and prefer long
+    // streams (fewer fill steps): T=1001 0.69 ms vs T=61 0.79 ms on the same input.
+    unsigned long long target = ctx->rows_per_stream ? ctx->rows_per_stream : (store ? 64 : 1024);
     // keep at least ~4 streams per SIMD lane-half in flight on small inputs
     const unsigned long long want_streams = (unsigned long long)ctx->num_cus * 64;
     if (n / target < want_streams)
@@ -147,7 +152,8 @@ __global__ __launch_bounds__(kBlock) void argmax_finalize(
     const ArgmaxRecord *__restrict__ blocks, const unsigned nblocks,
     const float *__restrict__ scores00,  // non-null: materialised scores
     const uint8_t *__restrict__ seq00, const unsigned long long seq_stride,
-    const float *__restrict__ pssm, const int M, const int K, ArgmaxRecord *__restrict__ out)
+    const float *__restrict__ pssm, const int M, const int K, const int first_cell_rule,
+    ArgmaxRecord *__restrict__ out)
 {
     __shared__ float sm_v[kBlock / 64];
     __shared__ long long sm_i[kBlock / 64];
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void argmax_finalize(
         if (blocks[b].found)
             best_merge(v, i, blocks[b].value, blocks[b].index);
     best_block_reduce(v, i, sm_v, sm_i);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && first_cell_rule) {
         float first;
         if (scores00) {
             first = scores00[0];
@@ -170,6 +176,8 @@ __global__ __launch_bounds__(kBlock) void argmax_finalize(
             v = first;
             i = 0;
         }
+    }
+    if (threadIdx.x == 0) {
         out->value = v;
         out->index = i;
         out->found = i >= 0;
@@ -185,7 +193,8 @@ static int read_record(lm_hip_ctx *ctx, const ArgmaxRecord *d_rec, ArgmaxRecord 
     return LM_HIP_OK;
 }
 
-int launch_score_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *out)
+int launch_score_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, int first_cell_rule,
+                        ArgmaxRecord *out)
 {
     FusedOut fo{};
     const C32Plan p = plan_c32(ctx, a, false);
@@ -206,7 +215,7 @@ int launch_score_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *out)
     hipLaunchKernelGGL(argmax_finalize, dim3(1), dim3(kBlock), 0, ctx->stream, recs + 1, grid.x,
                        (const float *)nullptr, a.d_seq + a.row_begin * a.seq_stride,
                        (unsigned long long)a.seq_stride, a.pssm->d_dense, (int)a.pssm->m,
-                       (int)a.pssm->k, recs);
+                       (int)a.pssm->k, first_cell_rule, recs);
     LM_HIP_TRY(hipGetLastError());
     return read_record(ctx, recs, out);
 }
@@ -275,11 +284,11 @@ int launch_score_threshold(lm_hip_ctx *ctx, const ScoreArgs &a, float t,
 }
 
 int finalize_argmax_materialised(lm_hip_ctx *ctx, const ArgmaxRecord *d_blocks, unsigned nblocks,
-                                 const float *d_scores, ArgmaxRecord *d_out)
+                                 const float *d_scores, int first_cell_rule, ArgmaxRecord *d_out)
 {
     hipLaunchKernelGGL(argmax_finalize, dim3(1), dim3(kBlock), 0, ctx->stream, d_blocks, nblocks,
                        d_scores, (const uint8_t *)nullptr, 0ull, (const float *)nullptr, 0, 0,
-                       d_out);
+                       first_cell_rule, d_out);
     LM_HIP_TRY(hipGetLastError());
     return LM_HIP_OK;
 }

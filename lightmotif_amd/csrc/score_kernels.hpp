@@ -111,6 +111,10 @@ __device__ __forceinline__ void best_block_reduce(float &v, long long &i, float 
 #ifndef LM_SCORE_LP
 #define LM_SCORE_LP 0
 #endif
+// 1 = score rows are written with non-temporal (streaming) stores
+#ifndef LM_SCORE_NT_STORE
+#define LM_SCORE_NT_STORE 1
+#endif
 
 template <int M>
 __device__ __forceinline__ void lds_fetch_column(float (&w)[4 * ((M + 3) / 4)],
@@ -181,7 +185,10 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
         if (PHASE != PHASE_FIRST || k == M - 1) {
             const float score = acc[(k + 1) % M];
             if (MODE == MODE_STORE) {
-                __builtin_nontemporal_store(score, op + k * 32);
+                if (LM_SCORE_NT_STORE)
+                    __builtin_nontemporal_store(score, op + k * 32);
+                else
+                    op[k * 32] = score;
             } else if (MODE == MODE_ARGMAX) {
                 if (score >= best_v) {  // same `>=` as pli/mod.rs:146, NaN never passes
                     best_v = score;

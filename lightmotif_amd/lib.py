@@ -225,26 +225,56 @@ class Pipeline:
                                             C.byref(orow), C.byref(mi)))
         return orow.value, mi.value
 
-    def argmax_dptr(self, scores_ptr: int, rows: int, stride_: int, columns: int):
+    def argmax_dptr(self, scores_ptr: int, rows: int, stride_: int, columns: int,
+                    first_cell_rule: bool = True):
         found, best, value = C.c_int(0), Coords(), C.c_float(0)
-        check(self._L.lm_hip_argmax_f32_dptr(self._h, C.c_void_p(scores_ptr), rows, stride_, columns,
-                                             C.byref(found), C.byref(best), C.byref(value)))
+        check(self._L.lm_hip_argmax_shard_f32_dptr(self._h, C.c_void_p(scores_ptr), rows, stride_,
+                                                   columns, int(first_cell_rule), C.byref(found),
+                                                   C.byref(best), C.byref(value)))
         return ((best.row, best.col), float(value.value)) if found.value else None
 
+    def _take_coords_array(self, ptr, n: int) -> np.ndarray:
+        try:
+            if n == 0:
+                return np.zeros((0, 2), dtype=np.int64)
+            arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_size_t)), shape=(n, 2))
+            return arr.astype(np.int64)
+        finally:
+            if ptr:
+                self._L.lm_hip_free(ptr)
+
     def threshold_dptr(self, scores_ptr: int, rows: int, stride_: int, columns: int,
-                       threshold: float) -> List[Tuple[int, int]]:
+                       threshold: float) -> np.ndarray:
+        """(n, 2) int64 array of (row, col) in the reference's row-major order."""
         ptr, n = C.POINTER(Coords)(), C.c_size_t(0)
         check(self._L.lm_hip_threshold_f32_dptr(self._h, C.c_void_p(scores_ptr), rows, stride_,
                                                 columns, threshold, C.byref(ptr), C.byref(n)))
-        return self._take_coords(ptr, n.value)
+        return self._take_coords_array(ptr, n.value)
+
+    def score_threshold_dptr(self, pssm: "ScoringMatrix", seq_ptr: int, seq_rows_total: int,
+                             seq_stride: int, columns: int, wrap: int, length: int,
+                             row_begin: int, row_end: int, threshold: float):
+        """Fused form: ((n, 2) int64 coords, (n,) f32 values), rows relative to row_begin."""
+        ptr, vals, n = C.POINTER(Coords)(), C.POINTER(C.c_float)(), C.c_size_t(0)
+        check(self._L.lm_hip_score_threshold_f32_dptr(
+            self._h, pssm._device(self), C.c_void_p(seq_ptr), seq_rows_total, seq_stride, columns,
+            wrap, length, row_begin, row_end, threshold, C.byref(ptr), C.byref(vals), C.byref(n)))
+        try:
+            values = (np.ctypeslib.as_array(vals, shape=(n.value,)).copy() if n.value
+                      else np.zeros(0, np.float32))
+        finally:
+            if vals:
+                self._L.lm_hip_free(vals)
+        return self._take_coords_array(ptr, n.value), values
 
     def score_argmax_dptr(self, pssm: "ScoringMatrix", seq_ptr: int, seq_rows_total: int,
                           seq_stride: int, columns: int, wrap: int, length: int, row_begin: int,
-                          row_end: int):
+                          row_end: int, first_cell_rule: bool = True):
         found, best, value = C.c_int(0), Coords(), C.c_float(0)
-        check(self._L.lm_hip_score_argmax_f32_dptr(
+        check(self._L.lm_hip_score_argmax_shard_f32_dptr(
             self._h, pssm._device(self), C.c_void_p(seq_ptr), seq_rows_total, seq_stride, columns,
-            wrap, length, row_begin, row_end, C.byref(found), C.byref(best), C.byref(value)))
+            wrap, length, row_begin, row_end, int(first_cell_rule), C.byref(found), C.byref(best),
+            C.byref(value)))
         return ((best.row, best.col), float(value.value)) if found.value else None
 
     def stripe_dptr(self, encoded_ptr: int, length: int, columns: int, default_symbol: int,

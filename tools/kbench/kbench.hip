@@ -76,12 +76,56 @@ __global__ void mix_copy(const uint4 *in, float4 *out, unsigned long long n16)
             o.y = (float)((w[q] >> 8) & 0xff);
             o.z = (float)((w[q] >> 16) & 0xff);
             o.w = (float)(w[q] >> 24);
-            __builtin_nontemporal_store(o.x, &out[i * 4 + q].x);
-            __builtin_nontemporal_store(o.y, &out[i * 4 + q].y);
-            __builtin_nontemporal_store(o.z, &out[i * 4 + q].z);
-            __builtin_nontemporal_store(o.w, &out[i * 4 + q].w);
+            out[i * 4 + q] = o;
         }
     }
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ void mix_copy_nt(const uint4 *in, f32x4 *out, unsigned long long n16)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint4 v = in[i];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 o = {(float)(w[q] & 0xff), (float)((w[q] >> 8) & 0xff),
+                       (float)((w[q] >> 16) & 0xff), (float)(w[q] >> 24)};
+            __builtin_nontemporal_store(o, &out[i * 4 + q]);
+        }
+    }
+}
+
+// each thread converts ONE input dword -> one float4 (fully coalesced 16 B/lane stores)
+__global__ void mix_copy_dw(const unsigned *in, f32x4 *out, unsigned long long n4, int nt)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned w = in[i];
+        f32x4 o = {(float)(w & 0xff), (float)((w >> 8) & 0xff), (float)((w >> 16) & 0xff),
+                   (float)(w >> 24)};
+        if (nt)
+            __builtin_nontemporal_store(o, &out[i]);
+        else
+            out[i] = o;
+    }
+}
+
+__global__ void fill_nt(f32x4 *out, unsigned long long n16, float v)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        f32x4 o = {v, v, v, v};
+        __builtin_nontemporal_store(o, &out[i]);
+    }
+}
+
+__global__ void copy_f4(const float4 *in, float4 *out, unsigned long long n16)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
+         i += (unsigned long long)gridDim.x * blockDim.x)
+        out[i] = in[i];
 }
 
 __global__ void fill_f4(float4 *out, unsigned long long n16, float v)
@@ -240,6 +284,31 @@ int main(int argc, char **argv)
             t.push_back(ms);
         }
         printf("fill(4W)           ms=%8.3f  GB/s=%8.1f\n", median(t), rows * 32 * 4 / median(t) * 1e-6);
+        auto timeit = [&](const char *name, double bytes, auto &&launch) {
+            std::vector<float> tt;
+            for (int r = 0; r < reps; ++r) {
+                CK(hipEventRecord(e0));
+                launch();
+                CK(hipEventRecord(e1));
+                CK(hipDeviceSynchronize());
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                tt.push_back(ms);
+            }
+            printf("%-18s ms=%8.3f  GB/s=%8.1f\n", name, median(tt), bytes / median(tt) * 1e-6);
+        };
+        for (int g : {2048, 8192, 32768}) {
+            char nm[64];
+            snprintf(nm, sizeof nm, "fill_nt g=%d", g);
+            timeit(nm, rows * 32.0 * 4, [&] { hipLaunchKernelGGL(fill_nt, dim3(g), dim3(256), 0, 0, (f32x4 *)d_out, rows * 8, 1.0f); });
+            snprintf(nm, sizeof nm, "mix_nt(1R+4W) g=%d", g);
+            timeit(nm, rows * 32.0 * 5, [&] { hipLaunchKernelGGL(mix_copy_nt, dim3(g), dim3(256), 0, 0, (const uint4 *)d_seq, (f32x4 *)d_out, rows * 2); });
+            snprintf(nm, sizeof nm, "mix_dw_nt g=%d", g);
+            timeit(nm, rows * 32.0 * 5, [&] { hipLaunchKernelGGL(mix_copy_dw, dim3(g), dim3(256), 0, 0, (const unsigned *)d_seq, (f32x4 *)d_out, rows * 8, 1); });
+            snprintf(nm, sizeof nm, "mix_dw_plain g=%d", g);
+            timeit(nm, rows * 32.0 * 5, [&] { hipLaunchKernelGGL(mix_copy_dw, dim3(g), dim3(256), 0, 0, (const unsigned *)d_seq, (f32x4 *)d_out, rows * 8, 0); });
+        }
+        timeit("copy_f4(2R+2W GB)", rows * 32.0 * 4, [&] { hipLaunchKernelGGL(copy_f4, dim3(8192), dim3(256), 0, 0, (const float4 *)d_ref, (float4 *)d_out, rows * 4); });
     }
 
     // VALU probes
@@ -261,12 +330,10 @@ int main(int argc, char **argv)
     }
 
     std::vector<Variant> vars = {
-        {"pf0_lp0", launch_v<0, 0>},  {"pf2_lp0", launch_v<2, 0>},  {"pf4_lp0", launch_v<4, 0>},
-        {"pf6_lp0", launch_v<6, 0>},  {"pf8_lp0", launch_v<8, 0>},  {"pf12_lp0", launch_v<12, 0>},
-        {"pf4_lp1", launch_v<4, 1>},  {"pf6_lp1", launch_v<6, 1>},  {"pf8_lp1", launch_v<8, 1>},
-        {"pf12_lp1", launch_v<12, 1>},
+        {"pf8_lp0", launch_v<8, 0>},   {"pf12_lp0", launch_v<12, 0>}, {"pf16_lp0", launch_v<16, 0>},
+        {"pf19_lp0", launch_v<19, 0>}, {"pf12_lp1", launch_v<12, 1>}, {"pf16_lp1", launch_v<16, 1>},
     };
-    const int qs[] = {3, 6, 12, 25, 50, 100, 200};
+    const int qs[] = {1, 2, 3, 4, 5, 6, 8, 12, 25};
     const size_t lds = std::max<size_t>((size_t)K * table_stride(M) * 4, 64);
     for (auto &v : vars) {
         for (int q : qs) {
