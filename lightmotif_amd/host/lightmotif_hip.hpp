@@ -1,0 +1,461 @@
+// lightmotif_hip.hpp -- header-only C++ host mirror of lightmotif's scoring interface
+// for the MI355X back-end, written over the C ABI of include/lightmotif_hip.h.
+//
+// The reference's host language is Rust; this image has no Rust toolchain, so the
+// host side above the C ABI is C++ (the reference is compiled code).  Names, argument
+// meaning and error behaviour follow the reference so tests/cpp/test_dna.cpp reads
+// like lightmotif/tests/dna.rs:
+//
+//   Pipeline<A>::hip()                      pli/mod.rs:401-407 (Result -> throws UnsupportedBackend)
+//   pli.encode / pli.stripe                 pli/mod.rs:34-67, 164-201
+//   pli.score_rows_into / score_into / score pli/mod.rs:69-130
+//   pli.argmax / max / threshold            pli/mod.rs:132-161, 203-222
+//   StripedSequence::configure{,_wrap}      seq.rs:362-381
+//   StripedScores::{offset,len,at,unstripe,argmax,max,threshold}  scores.rs:148-213, 246-288
+//   CountMatrix -> FrequencyMatrix -> WeightMatrix -> ScoringMatrix  pwm/mod.rs:209-258, 376-431, 505-526
+//
+// Sequence and score data are device-resident; every scoring operation runs in the
+// HIP kernels.  Misuse that panics in the reference throws std::runtime_error here.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "lightmotif_hip.h"
+
+namespace lightmotif {
+
+struct UnsupportedBackend : std::runtime_error {  // err.rs:34
+    using std::runtime_error::runtime_error;
+};
+struct InvalidSymbol : std::invalid_argument {  // err.rs:10
+    char symbol;
+    explicit InvalidSymbol(char c) : std::invalid_argument(std::string("invalid symbol: ") + c), symbol(c) {}
+};
+struct InvalidData : std::invalid_argument {  // err.rs:22
+    InvalidData() : std::invalid_argument("invalid data") {}
+};
+
+inline void check(int status)
+{
+    if (status == LM_HIP_OK)
+        return;
+    const std::string msg = lm_hip_last_error();
+    if (status == LM_HIP_ERR_NO_DEVICE)
+        throw UnsupportedBackend(msg);
+    throw std::runtime_error(msg);  // the reference panics
+}
+
+// ---- alphabets (abc.rs:91-135, 193-256) ---------------------------------------------------
+
+struct Dna {
+    static constexpr size_t K = 5;
+    static constexpr char code = 'D';
+    static const char *symbols() { return "ACTGN"; }
+};
+struct Protein {
+    static constexpr size_t K = 21;
+    static constexpr char code = 'P';
+    static const char *symbols() { return "ACDEFGHIKLMNPQRSTVWYX"; }
+};
+
+struct MatrixCoordinates {  // dense.rs:28-39
+    size_t row = 0, col = 0;
+    bool operator==(const MatrixCoordinates &o) const { return row == o.row && col == o.col; }
+};
+
+// ---- host-side dense matrix with the reference's padded rows (dense.rs:43-55) -----------------
+
+template <class T>
+class DenseMatrix {
+public:
+    DenseMatrix(size_t rows, size_t cols)
+        : rows_(rows), cols_(cols), stride_(lm_hip_stride(cols, sizeof(T))), data_(rows * stride_, T()) {}
+    size_t rows() const { return rows_; }
+    size_t columns() const { return cols_; }
+    size_t stride() const { return stride_; }  // dense.rs:126-128
+    T *operator[](size_t r) { return data_.data() + r * stride_; }
+    const T *operator[](size_t r) const { return data_.data() + r * stride_; }
+    T &operator()(size_t r, size_t c) { return data_[r * stride_ + c]; }
+    const T &operator()(size_t r, size_t c) const { return data_[r * stride_ + c]; }
+    T *ptr() { return data_.data(); }
+    const T *ptr() const { return data_.data(); }
+
+private:
+    size_t rows_, cols_, stride_;
+    std::vector<T> data_;
+};
+
+// ---- sequences --------------------------------------------------------------------------------
+
+template <class A>
+class EncodedSequence {  // seq.rs:83-98
+public:
+    explicit EncodedSequence(std::vector<uint8_t> d) : data(std::move(d)) {}
+    // EncodedSequence::encode (seq.rs:110-113) -> Err(InvalidSymbol)
+    static EncodedSequence encode(const std::string &text) { return from(text, false); }
+    // seq.rs:122-129
+    static EncodedSequence encode_lossy(const std::string &text) { return from(text, true); }
+    size_t len() const { return data.size(); }
+    std::vector<uint8_t> data;
+
+private:
+    static EncodedSequence from(const std::string &text, bool lossy)
+    {
+        int8_t lut[256];
+        std::memset(lut, -1, sizeof lut);
+        for (size_t i = 0; i < A::K; ++i)
+            lut[(uint8_t)A::symbols()[i]] = (int8_t)i;
+        std::vector<uint8_t> out(text.size());
+        for (size_t i = 0; i < text.size(); ++i) {
+            int8_t s = lut[(uint8_t)text[i]];
+            if (s < 0) {
+                if (!lossy)
+                    throw InvalidSymbol(text[i]);
+                s = (int8_t)(A::K - 1);
+            }
+            out[i] = (uint8_t)s;
+        }
+        return EncodedSequence(std::move(out));
+    }
+};
+
+template <class A>
+class Pipeline;
+template <class A>
+class ScoringMatrix;
+
+struct CtxHandle {
+    lm_hip_ctx *ctx = nullptr;
+    explicit CtxHandle(int device) { check(lm_hip_ctx_create(device, &ctx)); }
+    ~CtxHandle() { lm_hip_ctx_destroy(ctx); }
+    CtxHandle(const CtxHandle &) = delete;
+    CtxHandle &operator=(const CtxHandle &) = delete;
+};
+
+template <class A>
+class StripedSequence {  // seq.rs:288-294, device-resident
+public:
+    StripedSequence(std::shared_ptr<CtxHandle> c, lm_hip_seq *h) : ctx_(std::move(c)), h_(h) {}
+    ~StripedSequence() { lm_hip_seq_destroy(h_); }
+    StripedSequence(StripedSequence &&o) noexcept : ctx_(std::move(o.ctx_)), h_(o.h_) { o.h_ = nullptr; }
+    StripedSequence(const StripedSequence &) = delete;
+
+    size_t len() const { return info().length; }
+    size_t wrap() const { return info().wrap; }
+    size_t columns() const { return info().cols; }
+    // Reconfigure for a motif (seq.rs:362-366)
+    void configure(const ScoringMatrix<A> &motif)
+    {
+        if (motif.len() > 0)
+            configure_wrap(motif.len() - 1);
+    }
+    // seq.rs:369-381
+    void configure_wrap(size_t m) { check(lm_hip_seq_configure_wrap(ctx_->ctx, h_, m)); }
+    // Host copy of the (rows + wrap) x stride matrix.
+    DenseMatrix<uint8_t> matrix() const
+    {
+        const Info i = info();
+        DenseMatrix<uint8_t> m(i.rows + i.wrap, i.cols);
+        check(lm_hip_seq_download(ctx_->ctx, h_, m.ptr()));
+        return m;
+    }
+    lm_hip_seq *handle() const { return h_; }
+
+private:
+    struct Info { size_t length, wrap, rows, stride, cols; };
+    Info info() const
+    {
+        Info i{};
+        check(lm_hip_seq_info(h_, &i.length, &i.wrap, &i.rows, &i.stride, &i.cols, nullptr));
+        return i;
+    }
+    std::shared_ptr<CtxHandle> ctx_;
+    lm_hip_seq *h_;
+};
+
+// ---- matrices (pwm/mod.rs) ---------------------------------------------------------------------
+
+template <class A>
+inline std::vector<float> uniform_background()  // abc.rs:473-487
+{
+    std::vector<float> bg(A::K, 1.0f / (float)(A::K - 1));
+    bg[A::K - 1] = 0.0f;
+    return bg;
+}
+
+template <class A>
+class ScoringMatrix {  // pwm/mod.rs:561-564
+public:
+    ScoringMatrix(std::vector<float> bg, DenseMatrix<float> d) : background(std::move(bg)), data(std::move(d)) {}
+    ~ScoringMatrix()
+    {
+        if (dev_)
+            lm_hip_pssm_destroy(dev_);
+    }
+    ScoringMatrix(ScoringMatrix &&o) noexcept
+        : background(std::move(o.background)), data(std::move(o.data)), dev_(o.dev_), dev_ctx_(o.dev_ctx_)
+    {
+        o.dev_ = nullptr;
+    }
+    ScoringMatrix(const ScoringMatrix &o) : background(o.background), data(o.data) {}
+    size_t len() const { return data.rows(); }
+    const DenseMatrix<float> &matrix() const { return data; }
+    lm_hip_pssm *device(lm_hip_ctx *ctx) const
+    {
+        if (!dev_ || dev_ctx_ != ctx) {
+            if (dev_)
+                lm_hip_pssm_destroy(dev_);
+            check(lm_hip_pssm_create(ctx, data.ptr(), data.rows(), data.stride(), A::K, &dev_));
+            dev_ctx_ = ctx;
+        }
+        return dev_;
+    }
+    std::vector<float> background;
+    DenseMatrix<float> data;
+
+private:
+    mutable lm_hip_pssm *dev_ = nullptr;
+    mutable lm_hip_ctx *dev_ctx_ = nullptr;
+};
+
+template <class A>
+class WeightMatrix {  // pwm/mod.rs:450-456
+public:
+    WeightMatrix(std::vector<float> bg, DenseMatrix<float> d) : background(std::move(bg)), data(std::move(d)) {}
+    // pwm/mod.rs:505-526 (base 2)
+    ScoringMatrix<A> to_scoring() const
+    {
+        DenseMatrix<float> out = data;
+        for (size_t i = 0; i < out.rows(); ++i)
+            for (size_t j = 0; j < A::K; ++j)
+                out(i, j) = std::log2(out(i, j));
+        return ScoringMatrix<A>(background, std::move(out));
+    }
+    std::vector<float> background;
+    DenseMatrix<float> data;
+};
+
+template <class A>
+class FrequencyMatrix {  // pwm/mod.rs:340-431
+public:
+    explicit FrequencyMatrix(DenseMatrix<float> d) : data(std::move(d)) {}
+    // pwm/mod.rs:376-392; None background = uniform
+    WeightMatrix<A> to_weight() const
+    {
+        const std::vector<float> bg = uniform_background<A>();
+        DenseMatrix<float> w(data.rows(), A::K);
+        for (size_t i = 0; i < data.rows(); ++i)
+            for (size_t j = 0; j < A::K; ++j)
+                w(i, j) = bg[j] == 0.0f ? 0.0f : data(i, j) / bg[j];
+        return WeightMatrix<A>(bg, std::move(w));
+    }
+    // pwm/mod.rs:415-430
+    ScoringMatrix<A> to_scoring() const
+    {
+        const std::vector<float> bg = uniform_background<A>();
+        DenseMatrix<float> s(data.rows(), A::K);
+        for (size_t i = 0; i < data.rows(); ++i)
+            for (size_t j = 0; j < A::K; ++j)
+                s(i, j) = bg[j] == 0.0f ? -std::numeric_limits<float>::infinity()
+                                        : std::log2(data(i, j) / bg[j]);
+        return ScoringMatrix<A>(bg, std::move(s));
+    }
+    DenseMatrix<float> data;
+};
+
+template <class A>
+class CountMatrix {  // pwm/mod.rs:178-258
+public:
+    explicit CountMatrix(DenseMatrix<uint32_t> d) : data(std::move(d)) {}
+    // pwm/mod.rs:209-237
+    static CountMatrix from_sequences(const std::vector<EncodedSequence<A>> &seqs)
+    {
+        const size_t m = seqs.empty() ? 0 : seqs[0].len();
+        DenseMatrix<uint32_t> d(m, A::K);
+        for (const auto &s : seqs) {
+            if (s.len() != m)
+                throw InvalidData();
+            for (size_t i = 0; i < m; ++i)
+                d(i, s.data[i]) += 1;
+        }
+        return CountMatrix(std::move(d));
+    }
+    // pwm/mod.rs:240-258 with a scalar pseudocount (abc.rs:558-573)
+    FrequencyMatrix<A> to_freq(float pseudo) const
+    {
+        DenseMatrix<float> p(data.rows(), A::K);
+        for (size_t i = 0; i < data.rows(); ++i) {
+            float sum = 0.0f;
+            for (size_t j = 0; j < A::K; ++j) {
+                p(i, j) = (float)data(i, j) + (j != A::K - 1 ? pseudo : 0.0f);
+                sum = sum + p(i, j);
+            }
+            for (size_t j = 0; j < A::K; ++j)
+                p(i, j) = p(i, j) / sum;
+        }
+        return FrequencyMatrix<A>(std::move(p));
+    }
+    DenseMatrix<uint32_t> data;
+};
+
+// ---- scores ---------------------------------------------------------------------------------------
+
+class StripedScores {  // scores.rs:102-107, device-resident
+public:
+    StripedScores(std::shared_ptr<CtxHandle> c, lm_hip_scores *h) : ctx_(std::move(c)), h_(h) {}
+    ~StripedScores() { lm_hip_scores_destroy(h_); }
+    StripedScores(StripedScores &&o) noexcept : ctx_(std::move(o.ctx_)), h_(o.h_) { o.h_ = nullptr; }
+    StripedScores(const StripedScores &) = delete;
+
+    size_t max_index() const { return info().max_index; }        // scores.rs:124-127
+    bool is_empty() const { return info().rows == 0; }           // scores.rs:130-133
+    size_t rows() const { return info().rows; }
+    DenseMatrix<float> matrix() const                            // host copy of rows x stride
+    {
+        const Info i = info();
+        DenseMatrix<float> m(i.rows, i.cols);
+        check(lm_hip_scores_download(ctx_->ctx, h_, m.ptr()));
+        return m;
+    }
+    size_t offset(MatrixCoordinates mc) const { return mc.col * info().rows + mc.row; }  // scores.rs:155-157
+    size_t len() const                                           // scores.rs:274-279
+    {
+        const Info i = info();
+        return std::min(i.max_index, i.rows * i.cols);
+    }
+    std::vector<float> unstripe() const                          // scores.rs:167-170
+    {
+        const DenseMatrix<float> m = matrix();
+        const size_t n = len(), r = m.rows();
+        std::vector<float> out(n);
+        for (size_t i = 0; i < n; ++i)
+            out[i] = m(i % r, i / r);
+        return out;
+    }
+    // scores.rs:181-213 (the wrappers map coordinates through offset())
+    std::optional<size_t> argmax() const
+    {
+        int found = 0;
+        lm_hip_coords best{};
+        check(lm_hip_argmax(ctx_->ctx, h_, &found, &best, nullptr));
+        if (!found)
+            return std::nullopt;
+        return offset({best.row, best.col});
+    }
+    std::optional<float> max() const
+    {
+        int found = 0;
+        float v = 0;
+        check(lm_hip_argmax(ctx_->ctx, h_, &found, nullptr, &v));
+        return found ? std::optional<float>(v) : std::nullopt;
+    }
+    std::vector<size_t> threshold(float t) const
+    {
+        lm_hip_coords *c = nullptr;
+        size_t n = 0;
+        check(lm_hip_threshold(ctx_->ctx, h_, t, &c, &n));
+        std::vector<size_t> out(n);
+        const size_t r = info().rows;
+        for (size_t i = 0; i < n; ++i)
+            out[i] = c[i].col * r + c[i].row;
+        lm_hip_free(c);
+        return out;
+    }
+    lm_hip_scores *handle() const { return h_; }
+
+private:
+    struct Info { size_t rows, stride, cols, max_index; };
+    Info info() const
+    {
+        Info i{};
+        check(lm_hip_scores_info(h_, &i.rows, &i.stride, &i.cols, &i.max_index, nullptr));
+        return i;
+    }
+    std::shared_ptr<CtxHandle> ctx_;
+    lm_hip_scores *h_;
+};
+
+// ---- Pipeline<A, Hip> --------------------------------------------------------------------------------
+
+template <class A>
+class Pipeline {
+public:
+    // Pipeline::avx2() -> Result<Self, UnsupportedBackend> (pli/mod.rs:401-407)
+    static Pipeline hip(int device = 0) { return Pipeline(std::make_shared<CtxHandle>(device)); }
+
+    // Encode (pli/mod.rs:47-50)
+    EncodedSequence<A> encode(const std::string &text) const { return EncodedSequence<A>::encode(text); }
+
+    // Stripe::stripe (pli/mod.rs:166-175), on the device
+    StripedSequence<A> stripe(const EncodedSequence<A> &seq, size_t columns = 32) const
+    {
+        lm_hip_seq *h = nullptr;
+        check(lm_hip_seq_from_encoded(ctx_->ctx, seq.data.data(), seq.len(), columns, A::K, &h));
+        return StripedSequence<A>(ctx_, h);
+    }
+
+    StripedScores empty_scores(size_t columns = 32) const  // StripedScores::empty() (scores.rs:118-121)
+    {
+        lm_hip_scores *h = nullptr;
+        check(lm_hip_scores_create(ctx_->ctx, columns, &h));
+        return StripedScores(ctx_, h);
+    }
+
+    // Score::score_rows_into (pli/mod.rs:72-106); rows = [begin, end)
+    void score_rows_into(const ScoringMatrix<A> &pssm, const StripedSequence<A> &seq, size_t begin,
+                         size_t end, StripedScores &scores) const
+    {
+        check(lm_hip_score_rows_into(ctx_->ctx, pssm.device(ctx_->ctx), seq.handle(), begin, end,
+                                     scores.handle()));
+    }
+    // Score::score_into (pli/mod.rs:109-117)
+    void score_into(const ScoringMatrix<A> &pssm, const StripedSequence<A> &seq, StripedScores &scores) const
+    {
+        check(lm_hip_score_into(ctx_->ctx, pssm.device(ctx_->ctx), seq.handle(), scores.handle()));
+    }
+    // Score::score (pli/mod.rs:120-129)
+    StripedScores score(const ScoringMatrix<A> &pssm, const StripedSequence<A> &seq) const
+    {
+        StripedScores s = empty_scores(seq.columns());
+        score_into(pssm, seq, s);
+        return s;
+    }
+    // Maximum::argmax / max (pli/mod.rs:135-160)
+    std::optional<MatrixCoordinates> argmax(const StripedScores &scores) const
+    {
+        int found = 0;
+        lm_hip_coords best{};
+        check(lm_hip_argmax(ctx_->ctx, scores.handle(), &found, &best, nullptr));
+        if (!found)
+            return std::nullopt;
+        return MatrixCoordinates{best.row, best.col};
+    }
+    std::optional<float> max(const StripedScores &scores) const { return scores.max(); }
+    // Threshold::threshold (pli/mod.rs:210-221)
+    std::vector<MatrixCoordinates> threshold(const StripedScores &scores, float t) const
+    {
+        lm_hip_coords *c = nullptr;
+        size_t n = 0;
+        check(lm_hip_threshold(ctx_->ctx, scores.handle(), t, &c, &n));
+        std::vector<MatrixCoordinates> out(n);
+        for (size_t i = 0; i < n; ++i)
+            out[i] = {c[i].row, c[i].col};
+        lm_hip_free(c);
+        return out;
+    }
+
+private:
+    explicit Pipeline(std::shared_ptr<CtxHandle> c) : ctx_(std::move(c)) {}
+    std::shared_ptr<CtxHandle> ctx_;
+};
+
+}  // namespace lightmotif

@@ -1,0 +1,215 @@
+// C++ counterpart of the reference's integration tests for the scoring path, written
+// against the host mirror (lightmotif_amd/host/lightmotif_hip.hpp) so it reads like
+//   lightmotif/tests/dna.rs     (score_rows, score, argmax, threshold)
+//   lightmotif/tests/stripe.rs  (stripe property)
+//   lightmotif/tests/encode.rs  (encode / unknown symbol)
+//   lightmotif/src/pli/mod.rs:603-623 (empty row range)
+// The expected values are the literals those tests hold (tests/golden/reference_vectors.json).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "lightmotif_hip.hpp"
+
+using namespace lightmotif;
+
+static int failures = 0;
+#define CHECK(cond)                                                             \
+    do {                                                                        \
+        if (!(cond)) {                                                          \
+            std::fprintf(stderr, "FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+            ++failures;                                                         \
+        }                                                                       \
+    } while (0)
+
+static const char *SEQUENCE = "ATGTCCCAACAACGATACCCCGAGCCCATCGCCGTCATCGGCTCGGCATGCAGATTCCCAGGCG";
+static const std::vector<std::string> PATTERNS = {"GTTGACCTTATCAAC", "GTTGATCCAGTCAAC"};
+
+// scores computed with Bio.motifs (tests/dna.rs:22-38)
+static const float EXPECTED[50] = {
+    -23.07094f,  -18.678621f, -15.219191f, -17.745737f, -18.678621f, -23.07094f,  -17.745737f,
+    -19.611507f, -27.463257f, -29.989803f, -14.286304f, -26.53037f,  -15.219191f, -10.826873f,
+    -10.826873f, -22.138054f, -38.774437f, -30.922688f, -5.50167f,   -24.003826f, -18.678621f,
+    -15.219191f, -35.315006f, -17.745737f, -10.826873f, -30.922688f, -23.07094f,  -6.4345555f,
+    -31.855574f, -23.07094f,  -15.219191f, -31.855574f, -8.961102f,  -26.53037f,  -27.463257f,
+    -14.286304f, -15.219191f, -26.53037f,  -23.07094f,  -18.678621f, -14.286304f, -18.678621f,
+    -26.53037f,  -16.152077f, -17.745737f, -18.678621f, -17.745737f, -14.286304f, -30.922688f,
+    -18.678621f};
+
+static ScoringMatrix<Dna> golden_pssm()
+{
+    std::vector<EncodedSequence<Dna>> sites;
+    for (const auto &p : PATTERNS)
+        sites.push_back(EncodedSequence<Dna>::encode(p));
+    const auto cm = CountMatrix<Dna>::from_sequences(sites);
+    const auto pbm = cm.to_freq(0.1f);
+    const auto pwm = pbm.to_weight();
+    return pwm.to_scoring();
+}
+
+// tests/dna.rs:40-63
+static void test_score_rows(const Pipeline<Dna> &pli, size_t columns)
+{
+    const auto encoded = EncodedSequence<Dna>::encode(SEQUENCE);
+    auto striped = pli.stripe(encoded, columns);
+    const auto pssm = golden_pssm();
+    striped.configure(pssm);
+    auto scores = pli.empty_scores(columns);
+
+    const size_t rows = (64 + columns - 1) / columns;
+    pli.score_rows_into(pssm, striped, 0, std::min<size_t>(2, rows), scores);
+    CHECK(scores.matrix().rows() == std::min<size_t>(2, rows));
+    CHECK(scores.matrix()(0, 0) == EXPECTED[0]);
+    if (rows > 1) {
+        CHECK(scores.matrix()(1, 0) == EXPECTED[1]);
+        pli.score_rows_into(pssm, striped, 1, 2, scores);
+        CHECK(scores.matrix().rows() == 1);
+        CHECK(scores.matrix()(0, 0) == EXPECTED[1]);
+    }
+}
+
+// tests/dna.rs:65-91
+static void test_score(const Pipeline<Dna> &pli, size_t columns)
+{
+    auto striped = pli.stripe(EncodedSequence<Dna>::encode(SEQUENCE), columns);
+    const auto pssm = golden_pssm();
+    striped.configure(pssm);
+    const auto result = pli.score(pssm, striped);
+    const auto scores = result.unstripe();
+    CHECK(scores.size() == 50);
+    for (size_t i = 0; i < scores.size() && i < 50; ++i)
+        CHECK(std::fabs(scores[i] - EXPECTED[i]) < 1e-5f);
+}
+
+// tests/dna.rs:123-139
+static void test_argmax(const Pipeline<Dna> &pli, size_t columns)
+{
+    auto striped = pli.stripe(EncodedSequence<Dna>::encode(SEQUENCE), columns);
+    const auto pssm = golden_pssm();
+    striped.configure(pssm);
+    const auto result = pli.score(pssm, striped);
+    const auto mc = pli.argmax(result);
+    CHECK(mc.has_value() && result.offset(*mc) == 18);
+    CHECK(result.argmax() == std::optional<size_t>(18));            // README.md:85-86
+    CHECK(std::fabs(*result.max() - (-5.50167f)) < 1e-5f);
+}
+
+// tests/dna.rs:141-173
+static void test_threshold(const Pipeline<Dna> &pli, size_t columns)
+{
+    auto striped = pli.stripe(EncodedSequence<Dna>::encode(SEQUENCE), columns);
+    const auto pssm = golden_pssm();
+    striped.configure(pssm);
+    const auto result = pli.score(pssm, striped);
+
+    std::vector<size_t> indices;
+    for (const auto &c : pli.threshold(result, -10.0f))
+        indices.push_back(result.offset(c));
+    std::sort(indices.begin(), indices.end());
+    CHECK((indices == std::vector<size_t>{18, 27, 32}));
+
+    indices.clear();
+    for (const auto &c : pli.threshold(result, -15.0f))
+        indices.push_back(result.offset(c));
+    std::sort(indices.begin(), indices.end());
+    CHECK((indices == std::vector<size_t>{10, 13, 14, 18, 24, 27, 32, 35, 40, 47}));
+    CHECK(result.threshold(10.0f).empty());                          // README.md:89-90
+}
+
+// tests/stripe.rs:17-45
+static void test_stripe(const Pipeline<Dna> &pli, const std::string &sequence, size_t columns)
+{
+    const auto encoded = EncodedSequence<Dna>::encode(sequence);
+    const auto striped = pli.stripe(encoded, columns);
+    const auto matrix = striped.matrix();
+    if (matrix.rows() > 0) CHECK(matrix(0, 0) == 0 /* A */);
+    if (matrix.rows() > 1) CHECK(matrix(1, 0) == 2 /* T */);
+    if (matrix.rows() > 2) CHECK(matrix(2, 0) == 3 /* G */);
+    if (matrix.rows() > 3) CHECK(matrix(3, 0) == 2 /* T */);
+    for (size_t i = 0; i < encoded.len(); ++i)
+        CHECK(matrix(i % matrix.rows(), i / matrix.rows()) == encoded.data[i]);
+    for (size_t i = sequence.size(); i < matrix.rows() * matrix.columns(); ++i)
+        CHECK(matrix(i % matrix.rows(), i / matrix.rows()) == 4 /* Nucleotide::default() */);
+}
+
+// seq.rs:509-540
+static void test_stripe_literals(const Pipeline<Dna> &pli)
+{
+    auto striped = pli.stripe(EncodedSequence<Dna>::encode("ATGCA"), 4);
+    auto m = striped.matrix();
+    const uint8_t A = 0, C = 1, T = 2, G = 3, N = 4;
+    CHECK(m.rows() == 2);
+    CHECK(m(0, 0) == A && m(0, 1) == G && m(0, 2) == A && m(0, 3) == N);
+    CHECK(m(1, 0) == T && m(1, 1) == C && m(1, 2) == N && m(1, 3) == N);
+    striped.configure_wrap(2);
+    m = striped.matrix();
+    CHECK(m.rows() == 4);
+    CHECK(m(2, 0) == G && m(2, 1) == A && m(2, 2) == N && m(2, 3) == N);
+    CHECK(m(3, 0) == C && m(3, 1) == N && m(3, 2) == N && m(3, 3) == N);
+}
+
+// tests/encode.rs:10-26
+static void test_encode(const Pipeline<Dna> &pli)
+{
+    const auto encoded = pli.encode(SEQUENCE);
+    CHECK(encoded.len() == 64 && encoded.data[0] == 0 && encoded.data[1] == 2 && encoded.data[2] == 3);
+    bool threw = false;
+    try {
+        pli.encode("ATGTCCCAACAACGATACCNN..................NNNNNNNNATGCAGATTCCCAGGCG");
+    } catch (const InvalidSymbol &e) {
+        threw = e.symbol == '.';
+    }
+    CHECK(threw);
+}
+
+// pli/mod.rs:603-623 + avx2.rs:832-837
+static void test_edge_cases(const Pipeline<Dna> &pli)
+{
+    auto striped = pli.stripe(EncodedSequence<Dna>::encode("ATGCA"), 4);
+    std::vector<EncodedSequence<Dna>> sites = {EncodedSequence<Dna>::encode("ATTA"),
+                                               EncodedSequence<Dna>::encode("ATTC")};
+    const auto pssm = CountMatrix<Dna>::from_sequences(sites).to_freq(0.1f).to_weight().to_scoring();
+    striped.configure(pssm);
+    auto scores = pli.empty_scores(4);
+    pli.score_rows_into(pssm, striped, 1, 1, scores);   // must not fail
+    CHECK(scores.is_empty() && scores.max_index() == 0);
+    CHECK(!pli.argmax(scores).has_value() && pli.threshold(scores, 0.0f).empty());
+
+    auto bare = pli.stripe(EncodedSequence<Dna>::encode(SEQUENCE));
+    bool threw = false;
+    try {
+        pli.score(golden_pssm(), bare);                 // no wrap rows configured
+    } catch (const std::runtime_error &e) {
+        threw = std::string(e.what()).find("not enough wrapping rows for motif of length 15") != std::string::npos;
+    }
+    CHECK(threw);
+}
+
+int main()
+{
+    Pipeline<Dna> pli = Pipeline<Dna>::hip();
+    for (size_t columns : {32u, 1u, 16u}) {   // mod generic: U32, U1 (+ sse2's U16), tests/dna.rs:201-233
+        test_score_rows(pli, columns);
+        test_score(pli, columns);
+        test_argmax(pli, columns);
+        test_threshold(pli, columns);
+    }
+    std::string s1;
+    for (int i = 0; i < 16; ++i) s1 += SEQUENCE;
+    s1 += "TTATTAT";                              // tests/stripe.rs S1
+    for (size_t columns : {32u, 16u}) {
+        test_stripe(pli, s1, columns);
+        test_stripe(pli, SEQUENCE, columns);
+    }
+    test_stripe_literals(pli);
+    test_encode(pli);
+    test_edge_cases(pli);
+    if (failures) {
+        std::fprintf(stderr, "%d check(s) failed\n", failures);
+        return 1;
+    }
+    std::puts("test_dna: all checks passed");
+    return 0;
+}

@@ -1,0 +1,34 @@
+"""The C++ host mirror (lightmotif_amd/host/lightmotif_hip.hpp) and its test program
+tests/cpp/test_dna.cpp, the counterpart of lightmotif/tests/{dna,stripe,encode}.rs."""
+import os
+import subprocess
+from pathlib import Path
+
+import pytest
+
+CPP = Path(__file__).resolve().parent / "cpp"
+
+
+def build():
+    subprocess.run(["make", "-C", str(CPP)], check=True, capture_output=True)
+    return CPP / "test_dna"
+
+
+def test_cpp_mirror_compiles_and_links_against_the_c_abi():
+    exe = build()
+    assert exe.exists()
+    out = subprocess.run(["ldd", str(exe)], capture_output=True, text=True).stdout
+    assert "liblightmotif_hip.so" in out and "not found" not in out.split("liblightmotif_hip.so")[1].split("\n")[0]
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_cpp_mirror_without_device_raises_unsupported_backend():
+    r = subprocess.run([str(build())], capture_output=True, text=True)
+    assert r.returncode != 0 and "UnsupportedBackend" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_reference_style_tests_pass_on_gpu():
+    r = subprocess.run([str(build())], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "all checks passed" in r.stdout

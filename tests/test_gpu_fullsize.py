@@ -1,0 +1,120 @@
+"""BASELINE.json's full size (1 Gbp x len-20) through size-independent properties:
+window samples against the oracle, row-range consistency, exact scaling by powers of
+two, argmax / threshold against an independent torch formulation, fused == materialised.
+Also the protein configuration (K = 21, M = 12, 200 Mres)."""
+import numpy as np
+import pytest
+import torch
+
+import lightmotif_amd as lm
+from oracle import c_oracle as co
+
+pytestmark = pytest.mark.gpu
+COLS = 32
+
+
+def make_workload(pli, length, m, k, seed):
+    dev = torch.device("cuda", 0)
+    rows = -(-length // COLS)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    seq = torch.empty((rows + m - 1, COLS), dtype=torch.uint8, device=dev)
+    seq[:rows] = torch.randint(0, k - 1, (rows, COLS), dtype=torch.uint8, device=dev, generator=gen)
+    if length < rows * COLS:  # padded tail = default symbol (pli/mod.rs:194-196)
+        idx = torch.arange(length, rows * COLS, device=dev)
+        seq[idx % rows, idx // rows] = k - 1
+    pli.configure_wrap_dptr(seq.data_ptr(), rows, COLS, COLS, m - 1, k - 1)
+    rng = np.random.default_rng(seed)
+    sym = lm.lib.PROTEIN_SYMBOLS if k == 21 else lm.lib.DNA_SYMBOLS
+    sites = ["".join(sym[i] for i in rng.integers(0, k - 1, m)) for _ in range(10)]
+    pssm = lm.create(sites, protein=k == 21).counts.normalize(0.1).log_odds()
+    return seq, rows, pssm
+
+
+def score_all(pli, pssm, seq, rows, m, length, out=None, a=0, b=None):
+    b = rows if b is None else b
+    if out is None:
+        out = torch.empty((b - a, COLS), dtype=torch.float32, device=seq.device)
+    got = pli.score_dptr(pssm, seq.data_ptr(), rows + m - 1, COLS, COLS, m - 1, length, a, b,
+                         out.data_ptr(), COLS)
+    assert got == (b - a, length + 1 - m)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.fixture(scope="module")
+def gpu_pli():
+    torch.cuda.set_device(0)
+    return lm.Pipeline.hip(0, stream=torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("length,m,k", [(1_000_000_000, 20, 5), (999_999_937, 15, 5), (200_000_000, 12, 21)],
+                         ids=["dna_1Gbp_m20", "dna_ragged_m15", "protein_200M_m12"])
+def test_full_size_properties(gpu_pli, length, m, k):
+    pli = gpu_pli
+    seq, rows, pssm = make_workload(pli, length, m, k, seed=1234 + m)
+    scores = score_all(pli, pssm, seq, rows, m, length)
+    assert pli.last_kernel == f"score_c32<{m},0>"
+
+    # (1) windows against the oracle, bit for bit (start, middle, the wrap-touching end)
+    for a in (0, rows // 2 - 777, rows - 4096):
+        b = min(a + 4096, rows)
+        host = seq[a:b + m - 1].cpu().numpy()
+        win = co.Striped(host, length, m - 1, COLS, k)
+        want, _ = co.score_rows(win, pssm.data, 0, b - a)
+        got = scores[a:b].cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"window at row {a}"
+    host_wrap = seq[rows:].cpu().numpy()
+    host_head = seq[:m - 1].cpu().numpy()
+    assert np.array_equal(host_wrap[:, :COLS - 1], host_head[:, 1:COLS]) and (host_wrap[:, COLS - 1] == k - 1).all()
+
+    # (2) score_rows_into over sub-ranges == the same rows of the full result (pli/mod.rs:72-78)
+    for a, b in ((0, 1), (5, 6 + m), (rows // 3, rows // 3 + 100_003), (rows - 2 * m - 1, rows)):
+        part = score_all(pli, pssm, seq, rows, m, length, a=a, b=b)
+        assert torch.equal(part.view(torch.int32), scores[a:b].view(torch.int32)), (a, b)
+
+    # (3) scaling the PSSM by a power of two scales every score exactly (adds commute with 2^k)
+    scaled = lm.ScoringMatrix(pssm.data * np.float32(4.0), protein=pssm.protein)
+    s4 = score_all(pli, scaled, seq, rows, m, length)
+    assert torch.equal(s4, scores * 4.0)
+    del s4
+
+    # (4) argmax: Generic rule = last maximal cell in row-major order; fused == materialised
+    flat = scores.view(-1)
+    vmax = flat.max()
+    last = int(torch.nonzero(flat == vmax)[-1])
+    want_am = ((last // COLS, last % COLS), float(vmax))
+    assert pli.argmax_dptr(scores.data_ptr(), rows, COLS, COLS) == want_am
+    assert pli.score_argmax_dptr(pssm, seq.data_ptr(), rows + m - 1, COLS, COLS, m - 1, length, 0, rows) == want_am
+
+    # (5) threshold at a ~1e-5 tail: row-major (row, col) list == torch.nonzero order
+    t = float(torch.quantile(flat[:8_000_000][torch.isfinite(flat[:8_000_000])], 1 - 1e-5))
+    want_hits = torch.nonzero(scores >= t).cpu().numpy()
+    got_hits = pli.threshold_dptr(scores.data_ptr(), rows, COLS, COLS, t)
+    assert got_hits.shape[0] > 100 and np.array_equal(got_hits, want_hits)
+    f_hits, f_vals = pli.score_threshold_dptr(pssm, seq.data_ptr(), rows + m - 1, COLS, COLS, m - 1,
+                                              length, 0, rows, t)
+    assert np.array_equal(f_hits, want_hits)
+    assert np.array_equal(f_vals, scores[want_hits[:, 0], want_hits[:, 1]].cpu().numpy())
+
+    # (6) the padded tail really scores -inf (N/X column is -inf, pwm/mod.rs:422-423)
+    n_pad = rows * COLS - (length + 1 - m)
+    tail = torch.arange(length + 1 - m, rows * COLS, device=scores.device)
+    assert n_pad == tail.numel()
+    assert torch.isneginf(scores[tail % rows, tail // rows]).all()
+
+
+def test_device_stripe_of_100M_positions_round_trips(gpu_pli):
+    """Stripe on the device at scale: position i must land at [i % R][i / R]."""
+    pli = gpu_pli
+    dev = torch.device("cuda", 0)
+    length = 100_000_037
+    enc = torch.randint(0, 4, (length,), dtype=torch.uint8, device=dev)
+    rows = -(-length // COLS)
+    data = torch.empty((rows + 19, COLS), dtype=torch.uint8, device=dev)
+    pli.stripe_dptr(enc.data_ptr(), length, COLS, 4, 19, data.data_ptr(), COLS)
+    torch.cuda.synchronize()
+    want = torch.full((rows * COLS,), 4, dtype=torch.uint8, device=dev)
+    want[:length] = enc
+    assert torch.equal(data[:rows], want.view(COLS, rows).t())
+    assert torch.equal(data[rows:, :COLS - 1], data[:19, 1:]) and (data[rows:, COLS - 1] == 4).all()
