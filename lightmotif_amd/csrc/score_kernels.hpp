@@ -101,6 +101,17 @@ __device__ __forceinline__ void best_block_reduce(float &v, long long &i, float 
     }
 }
 
+// Appends one above-threshold cell to the (unordered) device hit list.
+__device__ __forceinline__ void record_hit(const FusedOut &fo, unsigned long long flat,
+                                           float score)
+{
+    const unsigned long long slot_i = atomicAdd(fo.hit_count, 1ull);
+    if (slot_i < fo.hit_capacity) {
+        fo.hit_flat[slot_i] = flat;
+        fo.hit_value[slot_i] = score;
+    }
+}
+
 // Tuning parameters of score_c32 (fixed per build; tools/kbench sweeps them):
 //   PF  global prefetch distance in steps: the symbol byte of step k+PF is
 //       requested while step k is processed (0 = load at use);
@@ -110,6 +121,12 @@ __device__ __forceinline__ void best_block_reduce(float &v, long long &i, float 
 #endif
 #ifndef LM_SCORE_LP
 #define LM_SCORE_LP 0
+#endif
+// Minimum wavefronts per SIMD the register allocator must leave room for (2nd
+// __launch_bounds__ argument).  Without it the fused-threshold variant is allocated
+// 228 VGPRs (2 waves/SIMD) although ~75 suffice.
+#ifndef LM_SCORE_MIN_WAVES
+#define LM_SCORE_MIN_WAVES(M) ((M) <= 20 ? 6 : 4)
 #endif
 // 1 = score rows are written with non-temporal (streaming) stores
 #ifndef LM_SCORE_NT_STORE
@@ -195,15 +212,40 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
                     best_row = orow + k;
                 }
             } else {
-                if (score >= fo.threshold) {  // pli/mod.rs:215
-                    const unsigned long long slot_i = atomicAdd(fo.hit_count, 1ull);
-                    if (slot_i < fo.hit_capacity) {
-                        fo.hit_flat[slot_i] = (unsigned long long)(orow + k) * 32ull + col;
-                        fo.hit_value[slot_i] = score;
-                    }
-                }
+                // Hits are rare (a p = 1e-5 tail).  The hot loop only tracks the
+                // lane's "saw a hit" flag (v_cmp + v_cndmask); a group with a
+                // flagged lane is re-scored out of line by rescan_rows.  Recording
+                // hits inline at every unrolled step cost 230 VGPRs and a third of
+                // the throughput.
+                if (score >= fo.threshold)  // pli/mod.rs:215
+                    best_row = 1;
             }
         }
+    }
+}
+
+// Slow path of the fused threshold: re-scores output rows [r0, r1) of this lane's
+// column with the same add order and appends the cells with score >= t.  The M
+// symbol loads of a row are independent and issued together; rows run in a loop.
+template <int M>
+__device__ __forceinline__ void rescan_rows(const uint8_t *__restrict__ seq_col,
+                                            const float *__restrict__ tabf, const long long r0,
+                                            const long long r1, const int col, const FusedOut &fo)
+{
+    constexpr int TS = table_stride(M);
+#pragma unroll 1
+    for (long long r = r0; r < r1; ++r) {
+        const uint8_t *p = seq_col + r * 32;
+        unsigned s[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+            s[j] = p[j * 32];
+        float sc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+            sc = sc + tabf[s[j] * TS + j];
+        if (sc >= fo.threshold)
+            record_hit(fo, (unsigned long long)r * 32ull + col, sc);
     }
 }
 
@@ -213,7 +255,7 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
 // stream is shifted back so that it ends at row_end; idle half-waves re-do the
 // last stream (identical values -> benign duplicates).
 template <int M, int MODE, int PF = LM_SCORE_PF, int LP = LM_SCORE_LP>
-__global__ __launch_bounds__(kBlock) void score_c32(
+__global__ __launch_bounds__(kBlock, LM_SCORE_MIN_WAVES(M)) void score_c32(
     const uint8_t *__restrict__ seq, const float *__restrict__ table, const int K,
     const unsigned long long row_begin, const unsigned long long row_end,
     const unsigned long long T, const unsigned long long nstreams, float *__restrict__ out,
@@ -264,12 +306,31 @@ __global__ __launch_bounds__(kBlock) void score_c32(
     if (LPE)
         lds_fetch_column<M>(wc, lds_raw, sym[0]);
     float best_v = -INFINITY;
-    long long best_row = -1;
+    long long best_row = (MODE == MODE_THRESHOLD) ? 0 : -1;  // threshold mode: "group saw a hit" flag
 
     const unsigned long long ngroups = (T + M - 1) / M;  // exact: T = q*M + 1, >= 2
 
+    // Fused threshold: the hot loop must stay branch-free (any `if` inside the
+    // unrolled groups wrecks the schedule: 230 VGPRs / spills), so a lane only
+    // remembers WHICH groups saw a score >= t -- one bit per G groups -- and
+    // re-scores those rows after its stream.  Hits are rare (p ~ 1e-5).
+    unsigned long long hit_groups = 0;
+    const unsigned long long G = (ngroups + 63) / 64;  // groups per bit
+    unsigned long long gbit = 1, gleft = G;
+    auto note_group = [&]() {
+        if (MODE == MODE_THRESHOLD) {
+            hit_groups |= best_row ? gbit : 0ull;
+            best_row = 0;
+            if (--gleft == 0) {
+                gleft = G;
+                gbit <<= 1;
+            }
+        }
+    };
+
     score_group<M, MODE, PFE, LPE, PHASE_FIRST>(acc, sym, wc, sp, lds_raw, op, orow, col, best_v,
                                                 best_row, fo);
+    note_group();
     for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
         sp += M * 32;
         orow += M;
@@ -277,6 +338,7 @@ __global__ __launch_bounds__(kBlock) void score_c32(
             op += M * 32;
         score_group<M, MODE, PFE, LPE, PHASE_MAIN>(acc, sym, wc, sp, lds_raw, op, orow, col,
                                                    best_v, best_row, fo);
+        note_group();
     }
     sp += M * 32;
     orow += M;
@@ -284,6 +346,26 @@ __global__ __launch_bounds__(kBlock) void score_c32(
         op += M * 32;
     score_group<M, MODE, PFE, LPE, PHASE_LAST>(acc, sym, wc, sp, lds_raw, op, orow, col, best_v,
                                                best_row, fo);
+    note_group();
+
+    if (MODE == MODE_THRESHOLD) {
+        const uint8_t *seq_col = seq + row_begin * 32 + col;
+        const float *tabf = reinterpret_cast<const float *>(lds_raw);
+        const long long first_row = (long long)(o0 - row_begin);  // = orow0 + M - 1
+        const long long orow0 = first_row - (M - 1);
+        while (hit_groups) {
+            const int bit = __ffsll((long long)hit_groups) - 1;
+            hit_groups &= hit_groups - 1;
+            const unsigned long long g0 = (unsigned long long)bit * G;
+            unsigned long long g1 = g0 + G;
+            if (g1 > ngroups)
+                g1 = ngroups;
+            long long r0 = orow0 + (long long)(g0 * M);
+            if (r0 < first_row)
+                r0 = first_row;  // group 0 completes only the stream's first row
+            rescan_rows<M>(seq_col, tabf, r0, orow0 + (long long)(g1 * M), col, fo);
+        }
+    }
 
     if (MODE == MODE_ARGMAX) {
         // the table is dead: reuse the dynamic LDS (>= 64 B) as reduction scratch
@@ -337,13 +419,8 @@ __global__ __launch_bounds__(kBlock) void score_generic(
                 best_i = (long long)cell;
             }
         } else {
-            if (score >= fo.threshold) {
-                const unsigned long long slot_i = atomicAdd(fo.hit_count, 1ull);
-                if (slot_i < fo.hit_capacity) {
-                    fo.hit_flat[slot_i] = cell;
-                    fo.hit_value[slot_i] = score;
-                }
-            }
+            if (score >= fo.threshold)
+                record_hit(fo, cell, score);
         }
     }
     if (MODE == MODE_ARGMAX) {
