@@ -192,6 +192,24 @@ int lm_hip_score_threshold_f32_dptr(lm_hip_ctx *ctx, const lm_hip_pssm *pssm,
                                     size_t row_begin, size_t row_end, float t,
                                     lm_hip_coords **coords, float **values, size_t *n);
 
+/* ---- many motifs x one resident sequence ---------------------------------- */
+
+/* lightmotif-cli sends every motif against every sequence (main.rs:554-561), one
+ * Scanner per (motif, sequence) job.  These run `n` motifs over one resident
+ * sequence as back-to-back fused kernels with a single synchronisation; no score
+ * matrix is written.  The sequence must have wrap >= max(M) - 1 (the CLI does
+ * configure_wrap(max_m), main.rs:540-546).  Per motif the results equal
+ * score_into + argmax / threshold on the full row range.
+ *   found/best/value : arrays of n
+ *   counts           : array of n; *coords / *values hold sum(counts) entries,
+ *                      motif after motif, each motif's hits in row-major order;
+ *                      release both with lm_hip_free (NULL when there are no hits). */
+int lm_hip_scan_argmax_batch(lm_hip_ctx *ctx, const lm_hip_pssm *const *pssms, size_t n,
+                             const lm_hip_seq *seq, int *found, lm_hip_coords *best, float *value);
+int lm_hip_scan_threshold_batch(lm_hip_ctx *ctx, const lm_hip_pssm *const *pssms,
+                                const float *thresholds, size_t n, const lm_hip_seq *seq,
+                                size_t *counts, lm_hip_coords **coords, float **values);
+
 /* ---- Encode / Stripe (device pointers) ------------------------------------ */
 
 /* Encode::encode_into (pli/mod.rs:56-66): ASCII -> symbol index.  alphabet is

@@ -68,6 +68,9 @@ SIGNATURES = {
                                                     _sz, C.c_int, _ip, _cp, _fp]),
     "lm_hip_score_threshold_f32_dptr": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz,
                                                  C.c_float, C.POINTER(_cp), C.POINTER(_fp), _szp]),
+    "lm_hip_scan_argmax_batch": (C.c_int, [_vp, C.POINTER(_vp), _sz, _vp, _ip, _cp, _fp]),
+    "lm_hip_scan_threshold_batch": (C.c_int, [_vp, C.POINTER(_vp), _fp, _sz, _vp, _szp,
+                                              C.POINTER(_cp), C.POINTER(_fp)]),
     "lm_hip_encode_dptr": (C.c_int, [_vp, C.c_char, _vp, _sz, C.c_int, _vp, _szp]),
     "lm_hip_stripe_dptr": (C.c_int, [_vp, _vp, _sz, _sz, C.c_uint8, _sz, _vp, _sz]),
     "lm_hip_configure_wrap_dptr": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _sz, C.c_uint8]),

@@ -472,6 +472,117 @@ int lm_hip_score_threshold_f32_dptr(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, co
     return LM_HIP_OK;
 }
 
+// ---- many motifs x one resident sequence -----------------------------------------------------------------
+
+static int batch_jobs(const lm_hip_pssm *const *pssms, size_t n, const lm_hip_seq *seq,
+                      std::vector<ScoreArgs> *jobs, std::vector<char> *degenerate)
+{
+    if (!pssms || !seq)
+        return fail(LM_HIP_ERR_BAD_ARGS, "scan batch: null argument");
+    jobs->clear();
+    degenerate->assign(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+        LM_TRY(check_score_args(pssms[i], seq->rows + seq->wrap, seq->stride, seq->cols, seq->wrap,
+                                0, seq->rows));
+        if (seq->length < pssms[i]->m || seq->rows == 0)
+            (*degenerate)[i] = 1;  // pli/mod.rs:85-88: empty scores
+        jobs->push_back(ScoreArgs{pssms[i], seq->d_data, seq->stride, seq->cols, 0, seq->rows,
+                                  nullptr, 0});
+    }
+    return LM_HIP_OK;
+}
+
+int lm_hip_scan_argmax_batch(lm_hip_ctx *ctx, const lm_hip_pssm *const *pssms, size_t n,
+                             const lm_hip_seq *seq, int *found, lm_hip_coords *best, float *value)
+{
+    if (!ctx || (n && !found))
+        return fail(LM_HIP_ERR_BAD_ARGS, "scan_argmax_batch: null argument");
+    std::vector<ScoreArgs> jobs;
+    std::vector<char> degenerate;
+    LM_TRY(batch_jobs(pssms, n, seq, &jobs, &degenerate));
+    std::vector<ScoreArgs> live;
+    std::vector<size_t> live_idx;
+    for (size_t i = 0; i < n; ++i) {
+        found[i] = 0;
+        if (!degenerate[i]) {
+            live.push_back(jobs[i]);
+            live_idx.push_back(i);
+        }
+    }
+    if (live.empty())
+        return LM_HIP_OK;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    std::vector<ArgmaxRecord> recs(live.size());
+    LM_TRY(launch_score_argmax_batch(ctx, live.data(), live.size(), 1, recs.data()));
+    for (size_t k = 0; k < live.size(); ++k) {
+        const size_t i = live_idx[k];
+        record_to_coords(recs[k], seq->cols, &found[i], best ? &best[i] : nullptr,
+                         value ? &value[i] : nullptr);
+    }
+    return LM_HIP_OK;
+}
+
+int lm_hip_scan_threshold_batch(lm_hip_ctx *ctx, const lm_hip_pssm *const *pssms,
+                                const float *thresholds, size_t n, const lm_hip_seq *seq,
+                                size_t *counts, lm_hip_coords **coords, float **values)
+{
+    if (!ctx || !coords || (n && (!counts || !thresholds)))
+        return fail(LM_HIP_ERR_BAD_ARGS, "scan_threshold_batch: null argument");
+    *coords = nullptr;
+    if (values)
+        *values = nullptr;
+    std::vector<ScoreArgs> jobs;
+    std::vector<char> degenerate;
+    LM_TRY(batch_jobs(pssms, n, seq, &jobs, &degenerate));
+    std::vector<ScoreArgs> live;
+    std::vector<float> live_t;
+    std::vector<size_t> live_idx;
+    for (size_t i = 0; i < n; ++i) {
+        counts[i] = 0;
+        if (!degenerate[i]) {
+            live.push_back(jobs[i]);
+            live_t.push_back(thresholds[i]);
+            live_idx.push_back(i);
+        }
+    }
+    if (live.empty())
+        return LM_HIP_OK;
+    std::vector<std::vector<unsigned long long>> flat;
+    std::vector<std::vector<float>> vals;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        DeviceGuard guard(ctx->device);
+        LM_TRY(launch_score_threshold_batch(ctx, live.data(), live_t.data(), live.size(), &flat, &vals));
+    }
+    size_t total = 0;
+    for (size_t k = 0; k < live.size(); ++k) {
+        counts[live_idx[k]] = flat[k].size();
+        total += flat[k].size();
+    }
+    if (total == 0)
+        return LM_HIP_OK;
+    lm_hip_coords *c = static_cast<lm_hip_coords *>(malloc(total * sizeof(lm_hip_coords)));
+    float *v = values ? static_cast<float *>(malloc(total * sizeof(float))) : nullptr;
+    if (!c || (values && !v)) {
+        free(c);
+        free(v);
+        return fail(LM_HIP_ERR_OOM, "scan_threshold_batch: cannot allocate %zu hits", total);
+    }
+    size_t pos = 0;
+    for (size_t k = 0; k < live.size(); ++k)
+        for (size_t h = 0; h < flat[k].size(); ++h, ++pos) {
+            c[pos].row = (size_t)(flat[k][h] / seq->cols);
+            c[pos].col = (size_t)(flat[k][h] % seq->cols);
+            if (v)
+                v[pos] = vals[k][h];
+        }
+    *coords = c;
+    if (values)
+        *values = v;
+    return LM_HIP_OK;
+}
+
 // ---- Encode / Stripe (device pointers) ---------------------------------------------------------------
 
 int lm_hip_encode_dptr(lm_hip_ctx *ctx, char alphabet, const uint8_t *d_ascii, size_t len, int lossy,

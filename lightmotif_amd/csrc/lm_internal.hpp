@@ -117,6 +117,13 @@ int launch_score_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, int first_cell_rule
 int launch_score_threshold(lm_hip_ctx *ctx, const ScoreArgs &a, float t,
                            std::vector<unsigned long long> *flat, std::vector<float> *values);
 
+// Batched forms: n independent jobs, one stream synchronisation.
+int launch_score_argmax_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
+                              int first_cell_rule, ArgmaxRecord *out);
+int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const float *ts, size_t n,
+                                 std::vector<std::vector<unsigned long long>> *flat,
+                                 std::vector<std::vector<float>> *values);
+
 int launch_argmax(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride,
                   size_t cols, int first_cell_rule, ArgmaxRecord *out);
 int launch_threshold(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride,

@@ -184,25 +184,15 @@ __global__ __launch_bounds__(kBlock) void argmax_finalize(
     }
 }
 
-static int read_record(lm_hip_ctx *ctx, const ArgmaxRecord *d_rec, ArgmaxRecord *out)
-{
-    LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, d_rec, sizeof(ArgmaxRecord), hipMemcpyDeviceToHost,
-                              ctx->stream));
-    LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    *out = *static_cast<const ArgmaxRecord *>(ctx->pinned);
-    return LM_HIP_OK;
-}
-
-int launch_score_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, int first_cell_rule,
-                        ArgmaxRecord *out)
+// Enqueues the fused argmax of one job: block records -> `blocks`, result -> `d_result`.
+static int enqueue_score_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, int first_cell_rule,
+                                ArgmaxRecord *blocks, ArgmaxRecord *d_result)
 {
     FusedOut fo{};
     const C32Plan p = plan_c32(ctx, a, false);
     const unsigned long long ncells = (unsigned long long)(a.row_end - a.row_begin) * a.cols;
     const dim3 grid = p.ok ? p.grid : generic_grid(ctx, ncells);
-    LM_TRY(ctx->scratch.reserve(sizeof(ArgmaxRecord) * ((size_t)grid.x + 1)));
-    ArgmaxRecord *recs = static_cast<ArgmaxRecord *>(ctx->scratch.ptr);
-    fo.block_best = recs + 1;
+    fo.block_best = blocks;
     if (p.ok) {
         ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_ARGMAX);
         ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_ARGMAX);
@@ -212,75 +202,140 @@ int launch_score_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, int first_cell_rule
         ctx->last_kernel = "score_generic<1>";
         LM_TRY(launch_generic<MODE_ARGMAX>(ctx, a, fo, grid));
     }
-    hipLaunchKernelGGL(argmax_finalize, dim3(1), dim3(kBlock), 0, ctx->stream, recs + 1, grid.x,
+    hipLaunchKernelGGL(argmax_finalize, dim3(1), dim3(kBlock), 0, ctx->stream, blocks, grid.x,
                        (const float *)nullptr, a.d_seq + a.row_begin * a.seq_stride,
                        (unsigned long long)a.seq_stride, a.pssm->d_dense, (int)a.pssm->m,
-                       (int)a.pssm->k, first_cell_rule, recs);
+                       (int)a.pssm->k, first_cell_rule, d_result);
     LM_HIP_TRY(hipGetLastError());
-    return read_record(ctx, recs, out);
+    return LM_HIP_OK;
+}
+
+static unsigned argmax_grid(const lm_hip_ctx *ctx, const ScoreArgs &a)
+{
+    const C32Plan p = plan_c32(ctx, a, false);
+    const unsigned long long ncells = (unsigned long long)(a.row_end - a.row_begin) * a.cols;
+    return p.ok ? p.grid.x : generic_grid(ctx, ncells).x;
+}
+
+// Fused score+argmax of `n` independent jobs (one motif each) enqueued back to back on
+// the context's stream with ONE synchronisation at the end.  Kernels of one stream run in
+// order, so all jobs share one block-record region.
+int launch_score_argmax_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
+                              int first_cell_rule, ArgmaxRecord *out)
+{
+    if (n == 0)
+        return LM_HIP_OK;
+    unsigned max_grid = 1;
+    for (size_t i = 0; i < n; ++i)
+        max_grid = std::max(max_grid, argmax_grid(ctx, jobs[i]));
+    LM_TRY(ctx->scratch.reserve(sizeof(ArgmaxRecord) * (n + (size_t)max_grid)));
+    ArgmaxRecord *results = static_cast<ArgmaxRecord *>(ctx->scratch.ptr);
+    ArgmaxRecord *blocks = results + n;
+    for (size_t i = 0; i < n; ++i)
+        LM_TRY(enqueue_score_argmax(ctx, jobs[i], first_cell_rule, blocks, results + i));
+    LM_HIP_TRY(hipMemcpyAsync(out, results, sizeof(ArgmaxRecord) * n, hipMemcpyDeviceToHost,
+                              ctx->stream));
+    LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return LM_HIP_OK;
+}
+
+int launch_score_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, int first_cell_rule,
+                        ArgmaxRecord *out)
+{
+    return launch_score_argmax_batch(ctx, &a, 1, first_cell_rule, out);
 }
 
 // ---- fused threshold --------------------------------------------------------------------
 
-int launch_score_threshold(lm_hip_ctx *ctx, const ScoreArgs &a, float t,
-                           std::vector<unsigned long long> *flat, std::vector<float> *values)
+// Fused score+threshold of `n` jobs with ONE synchronisation: every job appends
+// (job id, flat index, score) to a shared device list; the host sorts each job's
+// hits by flat index = the reference's row-major push order (pli/mod.rs:212-218)
+// and drops the duplicates the shifted last stream may have produced.
+int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const float *ts, size_t n,
+                                 std::vector<std::vector<unsigned long long>> *flat,
+                                 std::vector<std::vector<float>> *values)
 {
-    const C32Plan p = plan_c32(ctx, a, false);
-    const unsigned long long ncells = (unsigned long long)(a.row_end - a.row_begin) * a.cols;
-    unsigned long long cap = std::min<unsigned long long>(std::max<unsigned long long>(ncells / 64, 1 << 16), ncells + 64);
+    flat->assign(n, {});
+    values->assign(n, {});
+    if (n == 0)
+        return LM_HIP_OK;
+    unsigned long long max_cells = 0;
+    for (size_t i = 0; i < n; ++i)
+        max_cells = std::max<unsigned long long>(
+            max_cells, (unsigned long long)(jobs[i].row_end - jobs[i].row_begin) * jobs[i].cols);
+    unsigned long long cap = std::min<unsigned long long>(
+        std::max<unsigned long long>(max_cells / 64, 1 << 16), max_cells * n + 64);
     for (int attempt = 0; attempt < 3; ++attempt) {
-        // layout: [count u64][pad to 16][flat u64 x cap][value f32 x cap]
-        const size_t bytes = 16 + cap * 8 + cap * 4;
+        // layout: [count u64][pad to 16][flat u64 x cap][value f32 x cap][job u32 x cap]
+        const size_t bytes = 16 + cap * 8 + cap * 4 + cap * 4;
         LM_TRY(ctx->scratch.reserve(bytes));
         char *base = static_cast<char *>(ctx->scratch.ptr);
         FusedOut fo{};
-        fo.threshold = t;
         fo.hit_count = reinterpret_cast<unsigned long long *>(base);
         fo.hit_flat = reinterpret_cast<unsigned long long *>(base + 16);
         fo.hit_value = reinterpret_cast<float *>(base + 16 + cap * 8);
+        fo.hit_job = reinterpret_cast<unsigned *>(base + 16 + cap * 12);
         fo.hit_capacity = cap;
         LM_HIP_TRY(hipMemsetAsync(base, 0, 16, ctx->stream));
-        if (p.ok) {
-            ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_THRESHOLD);
-            ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_THRESHOLD);
-            LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
-                          a.row_begin, a.row_end, p.T, p.nstreams, nullptr, fo));
-        } else {
-            ctx->last_kernel = "score_generic<2>";
-            LM_TRY(launch_generic<MODE_THRESHOLD>(ctx, a, fo, generic_grid(ctx, ncells)));
+        for (size_t i = 0; i < n; ++i) {
+            const ScoreArgs &a = jobs[i];
+            const C32Plan p = plan_c32(ctx, a, false);
+            fo.threshold = ts[i];
+            fo.job_id = (unsigned)i;
+            if (p.ok) {
+                ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_THRESHOLD);
+                ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_THRESHOLD);
+                LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, a.pssm->d_table,
+                              (int)a.pssm->k, a.row_begin, a.row_end, p.T, p.nstreams, nullptr, fo));
+            } else {
+                ctx->last_kernel = "score_generic<2>";
+                const unsigned long long ncells =
+                    (unsigned long long)(a.row_end - a.row_begin) * a.cols;
+                LM_TRY(launch_generic<MODE_THRESHOLD>(ctx, a, fo, generic_grid(ctx, ncells)));
+            }
         }
         LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, base, 8, hipMemcpyDeviceToHost, ctx->stream));
         LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
         const unsigned long long count = *static_cast<unsigned long long *>(ctx->pinned);
-        if (count > cap) {  // the shifted last stream may report a few cells twice
-            cap = count + 64;
+        if (count > cap) {
+            cap = count + count / 8 + 64;
             continue;
         }
         std::vector<unsigned long long> f(count);
         std::vector<float> v(count);
+        std::vector<unsigned> job(count);
         if (count) {
             LM_HIP_TRY(hipMemcpyAsync(f.data(), fo.hit_flat, count * 8, hipMemcpyDeviceToHost, ctx->stream));
             LM_HIP_TRY(hipMemcpyAsync(v.data(), fo.hit_value, count * 4, hipMemcpyDeviceToHost, ctx->stream));
+            LM_HIP_TRY(hipMemcpyAsync(job.data(), fo.hit_job, count * 4, hipMemcpyDeviceToHost, ctx->stream));
             LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
         }
-        // Row-major order (pli/mod.rs:212-218) = ascending flat index; duplicates
-        // written by the shifted last stream carry identical values.
         std::vector<size_t> order(count);
         std::iota(order.begin(), order.end(), (size_t)0);
-        std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return f[x] < f[y]; });
-        flat->clear();
-        values->clear();
-        flat->reserve(count);
-        values->reserve(count);
+        std::sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+            return job[x] != job[y] ? job[x] < job[y] : f[x] < f[y];
+        });
         for (size_t idx : order) {
-            if (!flat->empty() && flat->back() == f[idx])
+            std::vector<unsigned long long> &fl = (*flat)[job[idx]];
+            if (!fl.empty() && fl.back() == f[idx])
                 continue;
-            flat->push_back(f[idx]);
-            values->push_back(v[idx]);
+            fl.push_back(f[idx]);
+            (*values)[job[idx]].push_back(v[idx]);
         }
         return LM_HIP_OK;
     }
     return fail(LM_HIP_ERR_HIP, "fused threshold: hit list kept overflowing");
+}
+
+int launch_score_threshold(lm_hip_ctx *ctx, const ScoreArgs &a, float t,
+                           std::vector<unsigned long long> *flat, std::vector<float> *values)
+{
+    std::vector<std::vector<unsigned long long>> f;
+    std::vector<std::vector<float>> v;
+    LM_TRY(launch_score_threshold_batch(ctx, &a, &t, 1, &f, &v));
+    *flat = std::move(f[0]);
+    *values = std::move(v[0]);
+    return LM_HIP_OK;
 }
 
 int finalize_argmax_materialised(lm_hip_ctx *ctx, const ArgmaxRecord *d_blocks, unsigned nblocks,

@@ -59,6 +59,8 @@ struct FusedOut {
     unsigned long long *hit_count;  // device counter
     unsigned long long *hit_flat;   // capacity entries
     float *hit_value;
+    unsigned *hit_job;              // batch scans: which job (motif) the hit belongs to
+    unsigned job_id;
     unsigned long long hit_capacity;
 };
 
@@ -109,6 +111,7 @@ __device__ __forceinline__ void record_hit(const FusedOut &fo, unsigned long lon
     if (slot_i < fo.hit_capacity) {
         fo.hit_flat[slot_i] = flat;
         fo.hit_value[slot_i] = score;
+        fo.hit_job[slot_i] = fo.job_id;
     }
 }
 

@@ -213,6 +213,42 @@ class Pipeline:
                 self._L.lm_hip_free(vals)
         return self._take_coords(ptr, n.value), values
 
+    # -- many motifs x one resident sequence (the CLI's job fan-out, main.rs:554-561) ----
+
+    def scan_argmax_batch(self, pssms: Sequence["ScoringMatrix"], seq: "StripedSequence"):
+        """Per motif: ``((row, col), value)`` of the best cell, or ``None`` (L < M)."""
+        n = len(pssms)
+        handles = (C.c_void_p * n)(*[p._device(self) for p in pssms])
+        found = (C.c_int * n)()
+        best = (Coords * n)()
+        value = (C.c_float * n)()
+        check(self._L.lm_hip_scan_argmax_batch(self._h, handles, n, seq._h, found, best, value))
+        return [((best[i].row, best[i].col), float(value[i])) if found[i] else None for i in range(n)]
+
+    def scan_threshold_batch(self, pssms: Sequence["ScoringMatrix"], thresholds: Sequence[float],
+                             seq: "StripedSequence"):
+        """Per motif: ``(coords (n_i, 2) int64 in row-major order, values (n_i,) f32)``."""
+        n = len(pssms)
+        handles = (C.c_void_p * n)(*[p._device(self) for p in pssms])
+        ts = (C.c_float * n)(*[float(t) for t in thresholds])
+        counts = (C.c_size_t * n)()
+        ptr, vals = C.POINTER(Coords)(), C.POINTER(C.c_float)()
+        check(self._L.lm_hip_scan_threshold_batch(self._h, handles, ts, n, seq._h, counts,
+                                                  C.byref(ptr), C.byref(vals)))
+        total = sum(counts)
+        try:
+            values = (np.ctypeslib.as_array(vals, shape=(total,)).copy() if total
+                      else np.zeros(0, np.float32))
+        finally:
+            if vals:
+                self._L.lm_hip_free(vals)
+        coords = self._take_coords_array(ptr, total)
+        out, pos = [], 0
+        for i in range(n):
+            out.append((coords[pos:pos + counts[i]], values[pos:pos + counts[i]]))
+            pos += counts[i]
+        return out
+
     # -- raw device-pointer forms (used with torch tensors by bench.py / tests) -------
 
     def score_dptr(self, pssm: "ScoringMatrix", seq_ptr: int, seq_rows_total: int, seq_stride: int,

@@ -325,3 +325,41 @@ def test_host_pointer_entry_points(pli):
                             p.ctypes.data, 20, 8, 5, 0, 10, out.ctypes.data, 32,
                             C.byref(orow), C.byref(omi))
     assert st == 0 and (orow.value, omi.value) == (0, 0)
+
+
+# ---- many motifs x one resident sequence (BASELINE.json configs[2]) ----------------------------
+
+
+def test_batch_scan_matches_per_motif_oracle(pli):
+    rng = np.random.default_rng(2024)
+    length = 300_017
+    enc = rng.integers(0, 4, length, dtype=np.uint8)
+    enc[rng.random(length) < 0.002] = 4                        # a few N -> -inf scores
+    lengths = [4, 5, 6, 8, 8, 11, 15, 20, 24, 29, 33, 40]      # JASPAR spans 4..33; 40 -> generic kernel
+    pssms_np = [random_pssm(rng, m, 5, "ties" if i % 3 == 0 else "normal") for i, m in enumerate(lengths)]
+    seq = pli.stripe(lm.EncodedSequence(enc), 32)
+    seq.configure_wrap(max(lengths) - 1)                        # main.rs:540-546 configure_wrap(max_m)
+    pssms = [lm.ScoringMatrix(p) for p in pssms_np]
+    ref = co.stripe(enc, 32, 5)
+    co.configure_wrap(ref, max(lengths) - 1)
+    wants = [co.score_rows(ref, p)[0] for p in pssms_np]
+    ts = [float(np.sort(w[:, :32][np.isfinite(w[:, :32])])[-200:][0]) for w in wants]
+
+    got_am = pli.scan_argmax_batch(pssms, seq)
+    got_th = pli.scan_threshold_batch(pssms, ts, seq)
+    for i, w in enumerate(wants):
+        assert got_am[i][0] == co.argmax(w, 32), lengths[i]
+        assert bits(np.float32(got_am[i][1])) == bits(co.max_(w, 32))
+        wrc = co.threshold(w, 32, ts[i]).astype(np.int64)
+        assert np.array_equal(got_th[i][0], wrc), lengths[i]
+        assert np.array_equal(bits(got_th[i][1]), bits(w[wrc[:, 0], wrc[:, 1]]))
+    # a motif longer than the sequence is a degenerate job, not an error (pli/mod.rs:85-88)
+    short = pli.stripe(lm.EncodedSequence(enc[:10]), 32)
+    short.configure_wrap(39)
+    res = pli.scan_argmax_batch(pssms, short)
+    assert [r is None for r in res] == [m > 10 for m in lengths]
+    # not enough wrap rows for the longest motif -> the reference panics
+    bare = pli.stripe(lm.EncodedSequence(enc), 32)
+    bare.configure_wrap(10)
+    with pytest.raises(lm.LightmotifHipError, match="not enough wrapping rows"):
+        pli.scan_argmax_batch(pssms, bare)
