@@ -101,6 +101,8 @@ def main() -> None:
     ap.add_argument("--cpu-sample", type=int, default=256_000_000, help="positions in the CPU sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rows-per-stream", type=int, default=0)
+    ap.add_argument("--ab", action="store_true",
+                    help="development: interleaved A/B of the store kernel's tuning knobs, then exit")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,6 +156,23 @@ def main() -> None:
         step()
     barrier()
     kernel_name = pli.last_kernel
+
+    if args.ab:  # same process, same buffers, configurations interleaved round by round
+        cfgs = [(x, t) for x in (0, 1) for t in (61, 121, 241)]
+        times = {c: [] for c in cfgs}
+        for _ in range(args.steps):
+            for x, t in cfgs:
+                pli.set_xcd_remap(bool(x))
+                pli.set_rows_per_stream(t)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                step()
+                b.record(stream)
+                torch.cuda.synchronize()
+                times[(x, t)].append(a.elapsed_time(b))
+        for (x, t), v in times.items():
+            print(f"xcd_remap={x} rows_per_stream={t}: median {np.median(v):.4f} ms  min {min(v):.4f} ms")
+        return
 
     # --- timed region: exactly K steps ---------------------------------------------------
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

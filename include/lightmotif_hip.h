@@ -100,6 +100,10 @@ int lm_hip_ctx_stream(lm_hip_ctx *ctx, void **hip_stream);
 /* Tuning knob: output rows each wavefront half sweeps in the C=32 score
  * kernels (0 = library default). */
 int lm_hip_ctx_set_rows_per_stream(lm_hip_ctx *ctx, size_t rows);
+/* Tuning knob of the materialising C=32 kernel: 1 = workgroups are remapped so that
+ * each XCD (private L2) sweeps one contiguous eighth of the rows; 0 (default) = plain
+ * dispatch order, one compact window.  Speed only, results are identical. */
+int lm_hip_ctx_set_xcd_remap(lm_hip_ctx *ctx, int enabled);
 /* Name of the kernel the last score call on this context launched
  * (for profiling tools); valid until the next call. */
 const char *lm_hip_ctx_last_kernel(lm_hip_ctx *ctx);

@@ -234,6 +234,14 @@ int lm_hip_ctx_set_rows_per_stream(lm_hip_ctx *ctx, size_t rows)
     return LM_HIP_OK;
 }
 
+int lm_hip_ctx_set_xcd_remap(lm_hip_ctx *ctx, int enabled)
+{
+    if (!ctx)
+        return fail(LM_HIP_ERR_BAD_ARGS, "null context");
+    ctx->xcd_remap = enabled != 0;
+    return LM_HIP_OK;
+}
+
 const char *lm_hip_ctx_last_kernel(lm_hip_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
 
 // ---- PSSM ---------------------------------------------------------------------------------

@@ -62,6 +62,7 @@ struct lm_hip_ctx {
     lm::Scratch scratch2;
     void *pinned = nullptr;     // 4 KiB of host-pinned memory for small read-backs
     size_t rows_per_stream = 0; // 0 = default
+    bool xcd_remap = false;      // A/B knob of the store kernel (lm_hip_ctx_set_xcd_remap)
     int num_cus = 256;
     const char *last_kernel = "";
 };

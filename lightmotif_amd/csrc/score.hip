@@ -9,16 +9,16 @@ namespace lm {
 
 // ---- registry of the unrolled C=32 kernels ---------------------------------------
 
-void register_score_c32_0(ScoreC32Launcher (*tab)[3]);
-void register_score_c32_1(ScoreC32Launcher (*tab)[3]);
-void register_score_c32_2(ScoreC32Launcher (*tab)[3]);
-void register_score_c32_3(ScoreC32Launcher (*tab)[3]);
-void register_score_c32_4(ScoreC32Launcher (*tab)[3]);
-void register_score_c32_5(ScoreC32Launcher (*tab)[3]);
-void register_score_c32_6(ScoreC32Launcher (*tab)[3]);
-void register_score_c32_7(ScoreC32Launcher (*tab)[3]);
+void register_score_c32_0(ScoreC32Launcher (*tab)[kRegistrySlots]);
+void register_score_c32_1(ScoreC32Launcher (*tab)[kRegistrySlots]);
+void register_score_c32_2(ScoreC32Launcher (*tab)[kRegistrySlots]);
+void register_score_c32_3(ScoreC32Launcher (*tab)[kRegistrySlots]);
+void register_score_c32_4(ScoreC32Launcher (*tab)[kRegistrySlots]);
+void register_score_c32_5(ScoreC32Launcher (*tab)[kRegistrySlots]);
+void register_score_c32_6(ScoreC32Launcher (*tab)[kRegistrySlots]);
+void register_score_c32_7(ScoreC32Launcher (*tab)[kRegistrySlots]);
 
-static ScoreC32Launcher g_c32[kMaxFastM + 1][3];
+static ScoreC32Launcher g_c32[kMaxFastM + 1][kRegistrySlots];
 static char g_c32_names[kMaxFastM + 1][3][32];
 static std::once_flag g_c32_once;
 
@@ -37,11 +37,13 @@ static void init_registry()
             snprintf(g_c32_names[m][mode], sizeof g_c32_names[m][mode], "score_c32<%d,%d>", m, mode);
 }
 
-ScoreC32Launcher score_c32_lookup(int M, int mode)
+ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap)
 {
     std::call_once(g_c32_once, init_registry);
     if (M < 1 || M > kMaxFastM || mode < 0 || mode > 2)
         return nullptr;
+    if (mode == MODE_STORE && xcd_remap)
+        return g_c32[M][3];
     return g_c32[M][mode];
 }
 
@@ -65,6 +67,12 @@ struct C32Plan {
 // order, which HBM (and the TLB) reward more than the M-1 fill steps per stream
 // cost -- the kernel is HBM-bound, not LDS-bound (profiles/r01_kbench2_nt.txt:
 // T=61 0.947 ms, T=501 0.995 ms, T=4001 1.12 ms at M=20 on 1 Gbp).
+// The XCD-aware block remap (lm_hip_ctx_set_xcd_remap) is OFF by default: it wins
+// 3 % when the buffers are fresh, separately hipMalloc'ed regions (kbench5_ab.txt:
+// 0.908 vs 0.941 ms) but loses 3 % inside one large arena or under PyTorch's
+// allocator (kbench6_place.txt, `bench.py --ab`: 1.00 vs 0.97 ms on the same box) --
+// eight distant windows instead of one compact one; the compact window is the
+// robust choice.
 static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store)
 {
     C32Plan p;
@@ -132,7 +140,7 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
     FusedOut fo{};
     const C32Plan p = plan_c32(ctx, a, true);
     if (p.ok) {
-        ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_STORE);
+        ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_STORE, ctx->xcd_remap);
         ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_STORE);
         LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
                       a.row_begin, a.row_end, p.T, p.nstreams, a.d_out, fo));

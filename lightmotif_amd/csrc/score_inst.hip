@@ -14,17 +14,18 @@ namespace lm {
 
 template <int M>
 struct RegisterRange {
-    static void run(ScoreC32Launcher (*tab)[3])
+    static void run(ScoreC32Launcher (*tab)[kRegistrySlots])
     {
         tab[M][MODE_STORE] = &score_c32_launch<M, MODE_STORE>;
         tab[M][MODE_ARGMAX] = &score_c32_launch<M, MODE_ARGMAX>;
         tab[M][MODE_THRESHOLD] = &score_c32_launch<M, MODE_THRESHOLD>;
+        tab[M][3] = &score_c32_launch<M, MODE_STORE, 1>;
         if constexpr (M < LM_M_HI)
             RegisterRange<M + 1>::run(tab);
     }
 };
 
-void LM_CAT(register_score_c32_, LM_INST_ID)(ScoreC32Launcher (*tab)[3])
+void LM_CAT(register_score_c32_, LM_INST_ID)(ScoreC32Launcher (*tab)[kRegistrySlots])
 {
     RegisterRange<LM_M_LO>::run(tab);
 }

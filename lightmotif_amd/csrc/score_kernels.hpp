@@ -41,8 +41,11 @@
 
 namespace lm {
 
-constexpr int kBlock = 256;          // threads per workgroup (4 wavefronts)
-constexpr int kStreamsPerBlock = 8;  // 2 per wavefront
+#ifndef LM_BLOCK
+#define LM_BLOCK 256
+#endif
+constexpr int kBlock = LM_BLOCK;                 // threads per workgroup (4 wavefronts)
+constexpr int kStreamsPerBlock = kBlock / 32;    // 2 per wavefront
 constexpr int kMaxFastM = 32;        // largest motif the unrolled kernel is built for
 
 // Floats per symbol row of the transposed LDS table used by score_c32<M>:
@@ -87,6 +90,7 @@ __device__ __forceinline__ void best_wave_reduce(float &v, long long &i)
 
 // Block-level reduce of (v, i); result valid in thread 0.  `sm` has room for
 // kBlock/64 entries of each type.
+template <int BLK = kBlock>
 __device__ __forceinline__ void best_block_reduce(float &v, long long &i, float *sm_v,
                                                   long long *sm_i)
 {
@@ -98,7 +102,7 @@ __device__ __forceinline__ void best_block_reduce(float &v, long long &i, float 
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < kBlock / 64; ++w)
+        for (int w = 1; w < BLK / 64; ++w)
             best_merge(v, i, sm_v[w], sm_i[w]);
     }
 }
@@ -257,8 +261,12 @@ __device__ __forceinline__ void rescan_rows(const uint8_t *__restrict__ seq_col,
 // (q+1)*M steps = one FIRST group, q-1 MAIN groups and one LAST group.  The last
 // stream is shifted back so that it ends at row_end; idle half-waves re-do the
 // last stream (identical values -> benign duplicates).
-template <int M, int MODE, int PF = LM_SCORE_PF, int LP = LM_SCORE_LP>
-__global__ __launch_bounds__(kBlock, LM_SCORE_MIN_WAVES(M)) void score_c32(
+#ifndef LM_SCORE_XCD_REMAP
+#define LM_SCORE_XCD_REMAP 0
+#endif
+template <int M, int MODE, int PF = LM_SCORE_PF, int LP = LM_SCORE_LP, int BLK = LM_BLOCK,
+          int XCD = LM_SCORE_XCD_REMAP, int MINW = LM_SCORE_MIN_WAVES(M)>
+__global__ __launch_bounds__(BLK, MINW) void score_c32(
     const uint8_t *__restrict__ seq, const float *__restrict__ table, const int K,
     const unsigned long long row_begin, const unsigned long long row_end,
     const unsigned long long T, const unsigned long long nstreams, float *__restrict__ out,
@@ -269,15 +277,22 @@ __global__ __launch_bounds__(kBlock, LM_SCORE_MIN_WAVES(M)) void score_c32(
         float4 *dst = reinterpret_cast<float4 *>(lds_raw);
         const float4 *src = reinterpret_cast<const float4 *>(table);
         const int n4 = K * table_stride(M) / 4;
-        for (int i = threadIdx.x; i < n4; i += kBlock)
+        for (int i = threadIdx.x; i < n4; i += BLK)
             dst[i] = src[i];
     }
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int col = lane & 31;
-    unsigned long long stream =
-        ((unsigned long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    unsigned long long bid = blockIdx.x;
+    if (XCD) {
+        // Workgroup b runs on XCD b % 8 (observed dispatch order; speed only, never
+        // correctness): give each XCD one contiguous eighth of the rows.  Bijective for
+        // any grid size.
+        const unsigned long long nb = gridDim.x, xcd = bid % 8, q = nb / 8, r = nb % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    unsigned long long stream = (bid * (BLK / 64) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
     if (stream >= nstreams)
         stream = nstreams - 1;
     unsigned long long o0 = row_begin + stream * T;
@@ -376,7 +391,7 @@ __global__ __launch_bounds__(kBlock, LM_SCORE_MIN_WAVES(M)) void score_c32(
         long long *sm_i = reinterpret_cast<long long *>(lds_raw);
         float *sm_v = reinterpret_cast<float *>(lds_raw + 32);
         long long idx = best_row >= 0 ? best_row * 32 + col : -1;
-        best_block_reduce(best_v, idx, sm_v, sm_i);
+        best_block_reduce<BLK>(best_v, idx, sm_v, sm_i);
         if (threadIdx.x == 0) {
             fo.block_best[blockIdx.x].value = best_v;
             fo.block_best[blockIdx.x].index = idx;
@@ -446,19 +461,22 @@ using ScoreC32Launcher = hipError_t (*)(dim3 grid, size_t lds_bytes, hipStream_t
                                         unsigned long long T, unsigned long long nstreams,
                                         float *out, FusedOut fo);
 
-template <int M, int MODE>
+template <int M, int MODE, int XCD = LM_SCORE_XCD_REMAP>
 hipError_t score_c32_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, const uint8_t *seq,
                             const float *table, int K, unsigned long long row_begin,
                             unsigned long long row_end, unsigned long long T,
                             unsigned long long nstreams, float *out, FusedOut fo)
 {
-    hipLaunchKernelGGL((score_c32<M, MODE>), grid, dim3(kBlock), lds_bytes, stream, seq, table, K,
-                       row_begin, row_end, T, nstreams, out, fo);
+    hipLaunchKernelGGL((score_c32<M, MODE, LM_SCORE_PF, LM_SCORE_LP, LM_BLOCK, XCD>), grid,
+                       dim3(kBlock), lds_bytes, stream, seq, table, K, row_begin, row_end, T,
+                       nstreams, out, fo);
     return hipGetLastError();
 }
 
 // Filled by the score_inst_*.hip translation units; [M][MODE], nullptr if absent.
-ScoreC32Launcher score_c32_lookup(int M, int mode);
+// Slot 3 of a registry row = the store kernel WITH the XCD remap (A/B knob).
+constexpr int kRegistrySlots = 4;
+ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap = false);
 const char *score_c32_name(int M, int mode);
 
 }  // namespace lm

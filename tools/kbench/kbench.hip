@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <cstring>
 #include <vector>
 
 #include "score_kernels.hpp"
@@ -196,6 +197,24 @@ hipError_t launch_am(dim3 grid, size_t lds_bytes, hipStream_t stream, const uint
     return hipGetLastError();
 }
 
+template <int PF, int BLK, int XCD, int MINW>
+hipError_t launch_cfg(dim3 grid, size_t lds_bytes, hipStream_t stream, const uint8_t *seq,
+                      const float *table, int K, unsigned long long row_begin,
+                      unsigned long long row_end, unsigned long long T,
+                      unsigned long long nstreams, float *out, FusedOut fo)
+{
+    hipLaunchKernelGGL((score_c32<KB_M, MODE_STORE, PF, 0, BLK, XCD, MINW>), grid, dim3(BLK),
+                       lds_bytes, stream, seq, table, K, row_begin, row_end, T, nstreams, out, fo);
+    return hipGetLastError();
+}
+
+struct Config {
+    std::string name;
+    ScoreC32Launcher fn;
+    int blk;
+    int q;
+};
+
 static double median(std::vector<float> v)
 {
     std::sort(v.begin(), v.end());
@@ -208,6 +227,7 @@ int main(int argc, char **argv)
     const int K = argc > 2 ? atoi(argv[2]) : 5;
     const int reps = argc > 3 ? atoi(argv[3]) : 15;
     const char *tag = argc > 4 ? argv[4] : "";
+    const bool quick = argc > 5 && !strcmp(argv[5], "quick");
     constexpr int M = KB_M;
     const unsigned long long rows = (L + 31) / 32, wrap = M - 1;
 
@@ -258,7 +278,7 @@ int main(int argc, char **argv)
     }
 
     // HBM calibration with the same traffic mix
-    {
+    if (!quick) {
         std::vector<float> t;
         for (int r = 0; r < reps; ++r) {
             CK(hipEventRecord(e0));
@@ -312,7 +332,7 @@ int main(int argc, char **argv)
     }
 
     // VALU probes
-    for (int pk = 0; pk < 2; ++pk) {
+    for (int pk = 0; pk < 2 && !quick; ++pk) {
         const int iters = 4096;
         float *d_tmp = d_out;
         CK(hipMemset(d_tmp, 0, 64));
@@ -329,11 +349,122 @@ int main(int argc, char **argv)
         printf("valu_probe pk=%d     ms=%8.3f  Tadd/s=%8.2f\n", pk, ms, adds / ms * 1e-9);
     }
 
+    if (argc > 5 && !strcmp(argv[5], "place")) {
+        // does the relative placement of the input and output buffers matter?
+        char *arena;
+        const size_t GB = 1ull << 30;
+        CK(hipMalloc(&arena, 11 * GB));
+        const size_t seq_bytes = (rows + wrap) * 32;
+        const size_t lds2 = std::max<size_t>((size_t)K * table_stride(M) * 4, 64);
+        struct P { const char *name; size_t seq_off, out_off; };
+        const size_t adj = (seq_bytes + (2u << 20) - 1) / (2u << 20) * (2u << 20);  // next 2 MiB
+        std::vector<P> places = {
+            {"out=seq+adj(2MiB aligned)", 0, adj},      {"out=seq+adj+4K", 0, adj + 4096},
+            {"out=seq+adj+64K", 0, adj + 65536},        {"out=seq+adj+1M", 0, adj + (1u << 20)},
+            {"out=seq+1GiB", 0, GB},                    {"out=seq+5GiB", 0, 5 * GB},
+            {"out=seq+5GiB+adjrem", 0, 5 * GB + adj - GB + 0}, {"out first, seq after (+4GiB)", 4 * GB + (2u << 20), 0},
+            {"seq+128B, out=seq+adj", 128, adj + (2u << 20)},
+        };
+        struct KC { const char *name; ScoreC32Launcher fn; int q; };
+        std::vector<KC> kcs = {{"x0_T61", launch_cfg<12, 256, 0, 6>, 3}, {"x0_T121", launch_cfg<12, 256, 0, 6>, 6},
+                               {"x1_T61", launch_cfg<12, 256, 1, 6>, 3}, {"x1_T121", launch_cfg<12, 256, 1, 6>, 6}};
+        std::vector<std::vector<float>> times(places.size() * kcs.size());
+        for (size_t pi = 0; pi < places.size(); ++pi)
+            CK(hipMemcpy(arena + places[pi].seq_off, d_seq, seq_bytes, hipMemcpyDeviceToDevice));
+        for (int r = 0; r < reps; ++r)
+            for (size_t pi = 0; pi < places.size(); ++pi) {
+                // (re)copy the sequence: placements overlap each other's buffers
+                CK(hipMemcpy(arena + places[pi].seq_off, d_seq, seq_bytes, hipMemcpyDeviceToDevice));
+                for (size_t ki = 0; ki < kcs.size(); ++ki) {
+                    const unsigned long long T = (unsigned long long)kcs[ki].q * M + 1;
+                    const unsigned long long ns = (rows + T - 1) / T;
+                    const dim3 grid((unsigned)((ns + 7) / 8));
+                    CK(hipEventRecord(e0));
+                    CK(kcs[ki].fn(grid, lds2, 0, (const uint8_t *)(arena + places[pi].seq_off), d_table, K, 0,
+                                  rows, T, ns, (float *)(arena + places[pi].out_off), fo));
+                    CK(hipEventRecord(e1));
+                    CK(hipDeviceSynchronize());
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    times[pi * kcs.size() + ki].push_back(ms);
+                }
+            }
+        for (size_t pi = 0; pi < places.size(); ++pi) {
+            printf("%-34s", places[pi].name);
+            for (size_t ki = 0; ki < kcs.size(); ++ki) {
+                auto &t = times[pi * kcs.size() + ki];
+                std::sort(t.begin(), t.end());
+                printf("  %s %.4f", kcs[ki].name, t[t.size() / 2]);
+            }
+            printf("\n");
+        }
+        return 0;
+    }
+
+    if (argc > 5 && !strcmp(argv[5], "ab")) {
+        // interleaved A/B: every config once per round, R rounds, report median and min
+        std::vector<Config> cfgs;
+        const int qlist[] = {4, 6, 12, 20};
+#define ADD(PF, BLK, XCD, MINW)                                                             \
+    for (int q : qlist)                                                                      \
+        cfgs.push_back({"pf" #PF "_b" #BLK "_x" #XCD "_w" #MINW, launch_cfg<PF, BLK, XCD, MINW>, BLK, q});
+        ADD(12, 256, 0, 6) ADD(12, 256, 1, 6) ADD(12, 256, 1, 4)
+        ADD(12, 128, 0, 6) ADD(12, 128, 1, 6) ADD(12, 128, 1, 4)
+        ADD(12, 64, 0, 6) ADD(12, 64, 1, 6) ADD(12, 64, 1, 4) ADD(12, 64, 0, 4)
+        ADD(16, 64, 1, 4) ADD(16, 128, 1, 4) ADD(16, 256, 1, 4)
+#undef ADD
+        const size_t lds2 = std::max<size_t>((size_t)K * table_stride(M) * 4, 64);
+        std::vector<std::vector<float>> times(cfgs.size());
+        std::vector<unsigned long long> bads(cfgs.size(), 0);
+        const int rounds = reps;
+        for (int r = -1; r < rounds; ++r) {
+            for (size_t c = 0; c < cfgs.size(); ++c) {
+                const unsigned long long T = (unsigned long long)cfgs[c].q * M + 1;
+                const unsigned long long ns = (rows + T - 1) / T;
+                const unsigned spb = cfgs[c].blk / 32;
+                const dim3 grid((unsigned)((ns + spb - 1) / spb));
+                if (r < 0) {  // correctness pass
+                    CK(hipMemset(d_out, 0xff, rows * 32 * 4));
+                    CK(cfgs[c].fn(grid, lds2, 0, d_seq, d_table, K, 0, rows, T, ns, d_out, fo));
+                    CK(hipMemset(d_bad, 0, 8));
+                    hipLaunchKernelGGL(compare_bits, dim3(4096), dim3(256), 0, 0,
+                                       (const unsigned *)d_ref, (const unsigned *)d_out, rows * 32, d_bad);
+                    CK(hipMemcpy(&bads[c], d_bad, 8, hipMemcpyDeviceToHost));
+                    continue;
+                }
+                CK(hipEventRecord(e0));
+                CK(cfgs[c].fn(grid, lds2, 0, d_seq, d_table, K, 0, rows, T, ns, d_out, fo));
+                CK(hipEventRecord(e1));
+                CK(hipDeviceSynchronize());
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                times[c].push_back(ms);
+            }
+        }
+        for (size_t c = 0; c < cfgs.size(); ++c) {
+            std::sort(times[c].begin(), times[c].end());
+            const double med = times[c][times[c].size() / 2];
+            printf("%-20s T=%4d  med=%7.4f min=%7.4f  GB/s=%7.1f  mismatches=%llu\n",
+                   cfgs[c].name.c_str(), cfgs[c].q * M + 1, med, times[c][0],
+                   rows * 32 * 5 / med * 1e-6, bads[c]);
+        }
+        return 0;
+    }
+
     std::vector<Variant> vars = {
         {"pf8_lp0", launch_v<8, 0>},   {"pf12_lp0", launch_v<12, 0>}, {"pf16_lp0", launch_v<16, 0>},
         {"pf19_lp0", launch_v<19, 0>}, {"pf12_lp1", launch_v<12, 1>}, {"pf16_lp1", launch_v<16, 1>},
     };
-    const int qs[] = {1, 2, 3, 4, 5, 6, 8, 12, 25};
+    if (quick)
+        vars = {{"pf12_lp0", launch_v<12, 0>}, {"pf16_lp0", launch_v<16, 0>}, {"pf8_lp0", launch_v<8, 0>}};
+    std::vector<int> qs = {1, 2, 3, 4, 5, 6, 8, 12, 25};
+    if (quick)
+        qs = {2, 3, 4, 6, 12, 50};
+    if (argc > 6) {
+        qs.clear();
+        for (char *tok = strtok(argv[6], ","); tok; tok = strtok(nullptr, ","))
+            qs.push_back(atoi(tok));
+    }
     const size_t lds = std::max<size_t>((size_t)K * table_stride(M) * 4, 64);
     for (auto &v : vars) {
         for (int q : qs) {
@@ -369,7 +500,7 @@ int main(int argc, char **argv)
     }
 
     // fused argmax variants (no store): LDS/VALU-bound
-    {
+    if (!quick) {
         ArgmaxRecord *d_rec;
         CK(hipMalloc(&d_rec, sizeof(ArgmaxRecord) * 1000000));
         fo.block_best = d_rec;
