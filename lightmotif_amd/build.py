@@ -26,8 +26,8 @@ ARCH = "gfx950"
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-slp-vectorize", "-fno-fast-math", "-Wall", "-Wno-unused-function",
          f"-I{ROOT / 'include'}", f"-I{CSRC}"]
-# score_inst.hip is compiled 8 times: motif lengths 4*i+1 .. 4*i+4
-INST = [(i, 4 * i + 1, 4 * i + 4) for i in range(8)]
+# score_inst.hip is compiled 9 times: motif lengths 4*i+1 .. 4*i+4 (M = 1 .. 36)
+INST = [(i, 4 * i + 1, 4 * i + 4) for i in range(9)]
 UNITS = ["score.hip", "reduce.hip", "layout.hip", "api.hip"]
 
 

@@ -35,16 +35,48 @@ __global__ __launch_bounds__(kBlock) void encode_kernel(const uint8_t *__restric
     }
     const uint8_t def = protein ? 20 : 4;
     unsigned long long bad = ~0ull;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < len;
+    // 16 bytes per lane per iteration (coalesced 16-B loads/stores); the byte -> symbol
+    // map is a 256-entry LDS table (all 64 lanes hit <= 21 distinct bytes: broadcasts).
+    const bool aligned = ((reinterpret_cast<uintptr_t>(ascii) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    const unsigned long long n16 = aligned ? len / 16 : 0;
+    const uint4 *src16 = reinterpret_cast<const uint4 *>(ascii);
+    uint4 *dst16 = reinterpret_cast<uint4 *>(dst);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < n16;
          i += (unsigned long long)gridDim.x * kBlock) {
-        uint8_t s = lut[ascii[i]];
-        if (s == 0xff) {
-            if (lossy)
-                s = def;                 // seq.rs:126 unwrap_or_default
-            else if (i < bad)
-                bad = i;                 // pli/mod.rs:63 `?` -> Err(InvalidSymbol)
+        const uint4 v = src16[i];
+        const unsigned in[4] = {v.x, v.y, v.z, v.w};
+        unsigned out[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            unsigned o = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned sym = lut[(in[w] >> (8 * q)) & 0xff];
+                if (sym == 0xff) {
+                    if (lossy) {
+                        sym = def;           // seq.rs:126 unwrap_or_default
+                    } else {
+                        const unsigned long long at = i * 16 + w * 4 + q;
+                        if (at < bad)
+                            bad = at;        // pli/mod.rs:63 `?` -> Err(InvalidSymbol)
+                    }
+                }
+                o |= sym << (8 * q);
+            }
+            out[w] = o;
         }
-        dst[i] = s;
+        dst16[i] = make_uint4(out[0], out[1], out[2], out[3]);
+    }
+    for (unsigned long long i = n16 * 16 + (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+         i < len; i += (unsigned long long)gridDim.x * kBlock) {
+        uint8_t sym = lut[ascii[i]];
+        if (sym == 0xff) {
+            if (lossy)
+                sym = def;
+            else if (i < bad)
+                bad = i;
+        }
+        dst[i] = sym;
     }
     if (bad != ~0ull)
         atomicMin(first_bad, bad);
@@ -58,7 +90,7 @@ int launch_encode(lm_hip_ctx *ctx, char alphabet, const uint8_t *d_ascii, size_t
     LM_HIP_TRY(hipMemsetAsync(d_bad, 0xff, 8, ctx->stream));
     if (len) {
         const unsigned grid = (unsigned)std::min<unsigned long long>(
-            (len + kBlock - 1) / kBlock, (unsigned long long)ctx->num_cus * 32);
+            (len / 16 + kBlock) / kBlock, (unsigned long long)ctx->num_cus * 64);
         hipLaunchKernelGGL(encode_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_ascii,
                            (unsigned long long)len, alphabet == 'P' ? 1 : 0, lossy, d_dst, d_bad);
         LM_HIP_TRY(hipGetLastError());
@@ -110,6 +142,59 @@ __global__ __launch_bounds__(kBlock) void stripe_kernel(const uint8_t *__restric
     }
 }
 
+// Fast path (stride % 4 == 0, 4-byte aligned output): a workgroup transposes 1024
+// striped rows.  Phase 1: for every column c the 1024 bytes enc[c*rows + r0 ..] are
+// contiguous -> one (unaligned) dword load per lane = 4 consecutive rows, scattered
+// into an LDS tile [row][pitch].  Phase 2: the tile is read back as dwords (4 columns
+// of one row) and written with fully coalesced dword stores.
+constexpr int kFastTileRows = 4 * kBlock;
+
+__global__ __launch_bounds__(kBlock) void stripe_kernel_fast(const uint8_t *__restrict__ enc,
+                                                             const unsigned long long len,
+                                                             const unsigned long long rows,
+                                                             const unsigned cols, const uint8_t def,
+                                                             uint8_t *__restrict__ data,
+                                                             const unsigned stride)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t tile[];  // [kFastTileRows][stride + 4]
+    const unsigned pitch = stride + 4;
+    const unsigned long long r0 = (unsigned long long)blockIdx.x * kFastTileRows;
+    const unsigned long long r = r0 + 4ull * threadIdx.x;
+    for (unsigned c = 0; c < cols; ++c) {
+        const unsigned long long i = (unsigned long long)c * rows + r;  // pli/mod.rs:192
+        unsigned v;
+        if (r + 3 < rows && i + 3 < len) {
+            __builtin_memcpy(&v, enc + i, 4);  // unaligned dword load
+        } else {
+            v = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned b = (r + q < rows) ? (i + q < len ? enc[i + q] : def) : 0;  // :195
+                v |= b << (8 * q);
+            }
+        }
+        uint8_t *t = tile + (4u * threadIdx.x) * pitch + c;
+        t[0] = (uint8_t)v;
+        t[pitch] = (uint8_t)(v >> 8);
+        t[2 * pitch] = (uint8_t)(v >> 16);
+        t[3 * pitch] = (uint8_t)(v >> 24);
+    }
+    // alignment padding past `cols` is zero (dense.rs:144-147)
+    for (unsigned c = cols; c < stride; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            tile[(4u * threadIdx.x + q) * pitch + c] = 0;
+    __syncthreads();
+    const unsigned long long nrows = rows - r0 < kFastTileRows ? rows - r0 : kFastTileRows;
+    const unsigned dw_per_row = stride / 4;
+    const unsigned long long ndw = nrows * dw_per_row;
+    unsigned *dst = reinterpret_cast<unsigned *>(data + r0 * stride);
+    for (unsigned long long d = threadIdx.x; d < ndw; d += kBlock) {
+        const unsigned rr = (unsigned)(d / dw_per_row), cc = (unsigned)(d - (unsigned long long)rr * dw_per_row);
+        dst[d] = *reinterpret_cast<const unsigned *>(tile + rr * pitch + 4 * cc);
+    }
+}
+
 // Wrap rows in closed form.  seq.rs:373-378 runs
 //     for i in 0..m { data[rows+i][j] = data[i][j+1] (j < C-1); data[rows+i][C-1] = default }
 // sequentially in place, so for i >= rows the source row is itself a wrap row
@@ -158,7 +243,15 @@ int launch_stripe(lm_hip_ctx *ctx, const uint8_t *d_encoded, size_t len, size_t 
                   uint8_t default_symbol, size_t wrap, uint8_t *d_data, size_t stride)
 {
     const unsigned long long rows = (len + cols - 1) / cols;  // pli/mod.rs:182
-    if (rows) {
+    const size_t fast_lds = (size_t)kFastTileRows * (stride + 4);
+    if (rows && stride % 4 == 0 && fast_lds <= 60 * 1024 &&
+        reinterpret_cast<uintptr_t>(d_data) % 4 == 0) {
+        const unsigned grid = (unsigned)((rows + kFastTileRows - 1) / kFastTileRows);
+        hipLaunchKernelGGL(stripe_kernel_fast, dim3(grid), dim3(kBlock), fast_lds, ctx->stream,
+                           d_encoded, (unsigned long long)len, rows, (unsigned)cols, default_symbol,
+                           d_data, (unsigned)stride);
+        LM_HIP_TRY(hipGetLastError());
+    } else if (rows) {
         const unsigned grid = (unsigned)((rows + kTileRows - 1) / kTileRows);
         const size_t lds = (size_t)kTileRows * (stride + 1);
         if (lds > 60 * 1024)

@@ -64,6 +64,7 @@ struct lm_hip_ctx {
     size_t rows_per_stream = 0; // 0 = default
     bool xcd_remap = false;      // A/B knob of the store kernel (lm_hip_ctx_set_xcd_remap)
     int num_cus = 256;
+    unsigned long long last_hit_count = 0;  // sizes the next fused-threshold hit list
     const char *last_kernel = "";
 };
 

@@ -17,6 +17,7 @@ void register_score_c32_4(ScoreC32Launcher (*tab)[kRegistrySlots]);
 void register_score_c32_5(ScoreC32Launcher (*tab)[kRegistrySlots]);
 void register_score_c32_6(ScoreC32Launcher (*tab)[kRegistrySlots]);
 void register_score_c32_7(ScoreC32Launcher (*tab)[kRegistrySlots]);
+void register_score_c32_8(ScoreC32Launcher (*tab)[kRegistrySlots]);
 
 static ScoreC32Launcher g_c32[kMaxFastM + 1][kRegistrySlots];
 static char g_c32_names[kMaxFastM + 1][3][32];
@@ -32,6 +33,7 @@ static void init_registry()
     register_score_c32_5(g_c32);
     register_score_c32_6(g_c32);
     register_score_c32_7(g_c32);
+    register_score_c32_8(g_c32);
     for (int m = 0; m <= kMaxFastM; ++m)
         for (int mode = 0; mode < 3; ++mode)
             snprintf(g_c32_names[m][mode], sizeof g_c32_names[m][mode], "score_c32<%d,%d>", m, mode);
@@ -193,29 +195,45 @@ __global__ __launch_bounds__(kBlock) void argmax_finalize(
 }
 
 // Enqueues the fused argmax of one job: block records -> `blocks`, result -> `d_result`.
-static int enqueue_score_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, int first_cell_rule,
-                                ArgmaxRecord *blocks, ArgmaxRecord *d_result)
+// One entry per job of a batch: where its block records are and how to recompute its
+// scores[0][0] (first-cell rule).
+struct FinalizeJob {
+    const ArgmaxRecord *blocks;
+    unsigned nblocks;
+    int M, K;
+    const uint8_t *seq00;
+    unsigned long long seq_stride;
+    const float *pssm;
+};
+
+// grid = number of jobs: block j reduces the block records of job j.
+__global__ __launch_bounds__(kBlock) void argmax_finalize_batch(const FinalizeJob *__restrict__ jobs,
+                                                                const int first_cell_rule,
+                                                                ArgmaxRecord *__restrict__ out)
 {
-    FusedOut fo{};
-    const C32Plan p = plan_c32(ctx, a, false);
-    const unsigned long long ncells = (unsigned long long)(a.row_end - a.row_begin) * a.cols;
-    const dim3 grid = p.ok ? p.grid : generic_grid(ctx, ncells);
-    fo.block_best = blocks;
-    if (p.ok) {
-        ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_ARGMAX);
-        ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_ARGMAX);
-        LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
-                      a.row_begin, a.row_end, p.T, p.nstreams, nullptr, fo));
-    } else {
-        ctx->last_kernel = "score_generic<1>";
-        LM_TRY(launch_generic<MODE_ARGMAX>(ctx, a, fo, grid));
+    __shared__ float sm_v[kBlock / 64];
+    __shared__ long long sm_i[kBlock / 64];
+    const FinalizeJob job = jobs[blockIdx.x];
+    float v = -INFINITY;
+    long long i = -1;
+    for (unsigned b = threadIdx.x; b < job.nblocks; b += kBlock)
+        if (job.blocks[b].found)
+            best_merge(v, i, job.blocks[b].value, job.blocks[b].index);
+    best_block_reduce(v, i, sm_v, sm_i);
+    if (threadIdx.x == 0) {
+        if (first_cell_rule) {
+            float first = 0.0f;
+            for (int j = 0; j < job.M; ++j)
+                first = first + job.pssm[j * job.K + job.seq00[j * job.seq_stride]];
+            if (first != first) {  // NaN (pli/mod.rs:142-146)
+                v = first;
+                i = 0;
+            }
+        }
+        out[blockIdx.x].value = v;
+        out[blockIdx.x].index = i;
+        out[blockIdx.x].found = i >= 0;
     }
-    hipLaunchKernelGGL(argmax_finalize, dim3(1), dim3(kBlock), 0, ctx->stream, blocks, grid.x,
-                       (const float *)nullptr, a.d_seq + a.row_begin * a.seq_stride,
-                       (unsigned long long)a.seq_stride, a.pssm->d_dense, (int)a.pssm->m,
-                       (int)a.pssm->k, first_cell_rule, d_result);
-    LM_HIP_TRY(hipGetLastError());
-    return LM_HIP_OK;
 }
 
 static unsigned argmax_grid(const lm_hip_ctx *ctx, const ScoreArgs &a)
@@ -225,25 +243,56 @@ static unsigned argmax_grid(const lm_hip_ctx *ctx, const ScoreArgs &a)
     return p.ok ? p.grid.x : generic_grid(ctx, ncells).x;
 }
 
-// Fused score+argmax of `n` independent jobs (one motif each) enqueued back to back on
-// the context's stream with ONE synchronisation at the end.  Kernels of one stream run in
-// order, so all jobs share one block-record region.
+// Fused score+argmax of `n` independent jobs (one motif each): the n scoring kernels
+// are enqueued back to back, each leaving per-workgroup records in its own region,
+// then ONE finalize launch reduces every job and ONE synchronisation returns.
 int launch_score_argmax_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
                               int first_cell_rule, ArgmaxRecord *out)
 {
     if (n == 0)
         return LM_HIP_OK;
-    unsigned max_grid = 1;
-    for (size_t i = 0; i < n; ++i)
-        max_grid = std::max(max_grid, argmax_grid(ctx, jobs[i]));
-    LM_TRY(ctx->scratch.reserve(sizeof(ArgmaxRecord) * (n + (size_t)max_grid)));
-    ArgmaxRecord *results = static_cast<ArgmaxRecord *>(ctx->scratch.ptr);
-    ArgmaxRecord *blocks = results + n;
-    for (size_t i = 0; i < n; ++i)
-        LM_TRY(enqueue_score_argmax(ctx, jobs[i], first_cell_rule, blocks, results + i));
+    std::vector<unsigned> grids(n);
+    size_t total_blocks = 0;
+    for (size_t i = 0; i < n; ++i) {
+        grids[i] = argmax_grid(ctx, jobs[i]);
+        total_blocks += grids[i];
+    }
+    const size_t off_blocks = sizeof(ArgmaxRecord) * n;
+    const size_t off_jobs = off_blocks + sizeof(ArgmaxRecord) * total_blocks;
+    LM_TRY(ctx->scratch.reserve(off_jobs + sizeof(FinalizeJob) * n));
+    char *base = static_cast<char *>(ctx->scratch.ptr);
+    ArgmaxRecord *results = reinterpret_cast<ArgmaxRecord *>(base);
+    ArgmaxRecord *blocks = reinterpret_cast<ArgmaxRecord *>(base + off_blocks);
+    FinalizeJob *d_jobs = reinterpret_cast<FinalizeJob *>(base + off_jobs);
+    std::vector<FinalizeJob> fj(n);
+    size_t pos = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const ScoreArgs &a = jobs[i];
+        const C32Plan p = plan_c32(ctx, a, false);
+        FusedOut fo{};
+        fo.block_best = blocks + pos;
+        if (p.ok) {
+            ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_ARGMAX);
+            ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_ARGMAX);
+            LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
+                          a.row_begin, a.row_end, p.T, p.nstreams, nullptr, fo));
+        } else {
+            ctx->last_kernel = "score_generic<1>";
+            LM_TRY(launch_generic<MODE_ARGMAX>(ctx, a, fo, dim3(grids[i])));
+        }
+        fj[i] = FinalizeJob{blocks + pos, grids[i], (int)a.pssm->m, (int)a.pssm->k,
+                            a.d_seq + a.row_begin * a.seq_stride,
+                            (unsigned long long)a.seq_stride, a.pssm->d_dense};
+        pos += grids[i];
+    }
+    LM_HIP_TRY(hipMemcpyAsync(d_jobs, fj.data(), sizeof(FinalizeJob) * n, hipMemcpyHostToDevice,
+                              ctx->stream));
+    hipLaunchKernelGGL(argmax_finalize_batch, dim3((unsigned)n), dim3(kBlock), 0, ctx->stream,
+                       d_jobs, first_cell_rule, results);
+    LM_HIP_TRY(hipGetLastError());
     LM_HIP_TRY(hipMemcpyAsync(out, results, sizeof(ArgmaxRecord) * n, hipMemcpyDeviceToHost,
                               ctx->stream));
-    LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    LM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // also keeps `fj` alive long enough
     return LM_HIP_OK;
 }
 
@@ -271,8 +320,17 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
     for (size_t i = 0; i < n; ++i)
         max_cells = std::max<unsigned long long>(
             max_cells, (unsigned long long)(jobs[i].row_end - jobs[i].row_begin) * jobs[i].cols);
-    unsigned long long cap = std::min<unsigned long long>(
-        std::max<unsigned long long>(max_cells / 64, 1 << 16), max_cells * n + 64);
+    // Hit-list capacity: room for a 1.2e-4 hit rate over the whole batch (the CLI's
+    // default p-value is 1e-5, main.rs:487), at least what the previous call on this
+    // context needed, never more than every cell.  An overflow re-runs the batch once
+    // with the exact count.
+    unsigned long long total_cells = 0;
+    for (size_t i = 0; i < n; ++i)
+        total_cells += (unsigned long long)(jobs[i].row_end - jobs[i].row_begin) * jobs[i].cols;
+    unsigned long long cap = std::max<unsigned long long>(total_cells / 8192, 1 << 16);
+    cap = std::max(cap, ctx->last_hit_count + ctx->last_hit_count / 2);
+    cap = std::min(cap, total_cells + 64);
+    (void)max_cells;
     for (int attempt = 0; attempt < 3; ++attempt) {
         // layout: [count u64][pad to 16][flat u64 x cap][value f32 x cap][job u32 x cap]
         const size_t bytes = 16 + cap * 8 + cap * 4 + cap * 4;
@@ -305,6 +363,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
         LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, base, 8, hipMemcpyDeviceToHost, ctx->stream));
         LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
         const unsigned long long count = *static_cast<unsigned long long *>(ctx->pinned);
+        ctx->last_hit_count = count;
         if (count > cap) {
             cap = count + count / 8 + 64;
             continue;
@@ -318,17 +377,19 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
             LM_HIP_TRY(hipMemcpyAsync(job.data(), fo.hit_job, count * 4, hipMemcpyDeviceToHost, ctx->stream));
             LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
         }
-        std::vector<size_t> order(count);
-        std::iota(order.begin(), order.end(), (size_t)0);
-        std::sort(order.begin(), order.end(), [&](size_t x, size_t y) {
-            return job[x] != job[y] ? job[x] < job[y] : f[x] < f[y];
-        });
-        for (size_t idx : order) {
-            std::vector<unsigned long long> &fl = (*flat)[job[idx]];
-            if (!fl.empty() && fl.back() == f[idx])
-                continue;
-            fl.push_back(f[idx]);
-            (*values)[job[idx]].push_back(v[idx]);
+        // (job, flat) packed in one 64-bit key: flat < rows * cols < 2^40 for anything
+        // that fits in 288 GB, jobs < 2^24
+        struct Hit { unsigned long long key; float value; };
+        std::vector<Hit> hits(count);
+        for (size_t h = 0; h < count; ++h)
+            hits[h] = Hit{((unsigned long long)job[h] << 40) | f[h], v[h]};
+        std::sort(hits.begin(), hits.end(), [](const Hit &x, const Hit &y) { return x.key < y.key; });
+        for (size_t h = 0; h < count; ++h) {
+            if (h && hits[h].key == hits[h - 1].key)
+                continue;  // duplicate from the shifted last stream
+            const size_t j = (size_t)(hits[h].key >> 40);
+            (*flat)[j].push_back(hits[h].key & ((1ull << 40) - 1));
+            (*values)[j].push_back(hits[h].value);
         }
         return LM_HIP_OK;
     }

@@ -46,7 +46,7 @@ namespace lm {
 #endif
 constexpr int kBlock = LM_BLOCK;                 // threads per workgroup (4 wavefronts)
 constexpr int kStreamsPerBlock = kBlock / 32;    // 2 per wavefront
-constexpr int kMaxFastM = 32;        // largest motif the unrolled kernel is built for
+constexpr int kMaxFastM = 36;        // largest motif the unrolled kernel is built for
 
 // Floats per symbol row of the transposed LDS table used by score_c32<M>:
 // 4 * (smallest odd number >= ceil(M/4)).

@@ -182,13 +182,13 @@ def test_generated_fixtures(pli, name):
 
 @pytest.mark.parametrize("m", list(range(1, 35)) + [40, 64])
 def test_every_motif_length_dna(pli, m):
-    """Unrolled kernels exist for M = 1..32; longer motifs take the generic kernel."""
+    """Unrolled kernels exist for M = 1..36; longer motifs take the generic kernel."""
     rng = np.random.default_rng(1000 + m)
     length = int(rng.integers(32 * (m + 2), 9000))
     enc = rng.integers(0, 5, length, dtype=np.uint8)   # includes N -> -inf scores
     p = random_pssm(rng, m, 5)
     check_against_oracle(pli, enc, p, 32, 5, thresholds=[0.0, -np.inf])
-    if m <= 32:
+    if m <= 36:
         assert pli.last_kernel.startswith("score_c32") or length // 32 < m + 1
 
 

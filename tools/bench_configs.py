@@ -141,9 +141,29 @@ def config5(pli):
             "GBps": round(5 * rows * COLS / t / 1e9, 1), "hbm_frac": round(5 * rows * COLS / t / 8e12, 4)}
 
 
+def config_layout(pli):
+    """encode + stripe + configure_wrap on the device (byte work, HBM-bound:
+    1 B read + 1 B written per symbol for each of encode and stripe)."""
+    dev = torch.device("cuda", 0)
+    length = 1_000_000_000
+    rows = -(-length // COLS)
+    ascii_ = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[
+        torch.randint(0, 4, (length,), device=dev, dtype=torch.int64)]
+    enc = torch.empty(length, dtype=torch.uint8, device=dev)
+    data = torch.empty((rows + 19, COLS), dtype=torch.uint8, device=dev)
+    t_enc = timeit(lambda: pli.encode_dptr(ascii_.data_ptr(), length, enc.data_ptr()), 5)
+    t_str = timeit(lambda: pli.stripe_dptr(enc.data_ptr(), length, COLS, 4, 19, data.data_ptr(), COLS), 5)
+    want = enc.view(COLS, rows).t()
+    assert torch.equal(data[:rows], want)
+    return {"config": "layout: encode + stripe(+wrap 19) of 1 Gbp on the device",
+            "encode_ms": round(t_enc * 1e3, 3), "encode_GBps": round(2 * length / t_enc / 1e9, 1),
+            "stripe_ms": round(t_str * 1e3, 3), "stripe_GBps": round(2 * length / t_str / 1e9, 1),
+            "note": "algorithmic traffic 2 B per symbol each; HBM-bound byte kernels"}
+
+
 if __name__ == "__main__":
     torch.cuda.set_device(0)
     pli = lm.Pipeline.hip(0, stream=torch.cuda.current_stream().cuda_stream)
-    which = sys.argv[1:] or ["c1", "c5", "c3"]
+    which = sys.argv[1:] or ["c1", "c5", "layout", "c3"]
     for name in which:
-        print(json.dumps({"c1": config1, "c3": config3, "c5": config5}[name](pli)), flush=True)
+        print(json.dumps({"c1": config1, "c3": config3, "c5": config5, "layout": config_layout}[name](pli)), flush=True)
