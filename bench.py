@@ -101,6 +101,9 @@ def main() -> None:
     ap.add_argument("--cpu-sample", type=int, default=256_000_000, help="positions in the CPU sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rows-per-stream", type=int, default=0)
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="development: 'gloo' + --single-device exercises the N>1 control flow on a 1-GPU box")
+    ap.add_argument("--single-device", action="store_true", help="development: every rank uses cuda:0")
     ap.add_argument("--ab", action="store_true",
                     help="development: interleaved A/B of the store kernel's tuning knobs, then exit")
     args = ap.parse_args()
@@ -111,11 +114,17 @@ def main() -> None:
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes "
                          f"(WORLD_SIZE={world})")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where collectives run
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     m = args.motif_len
     rows = -(-args.length // COLS)            # striped rows owned by this rank
@@ -186,7 +195,7 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
@@ -209,7 +218,7 @@ def main() -> None:
     fam_ms, fam = timed(lambda: pli.score_argmax_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS,
                                                       m - 1, total_length, 0, rows, first_cell_rule=rank == 0))
     assert am == fam, (am, fam)
-    mg_ms, best = timed(lambda: D.merge_argmax(am, row0, device=dev))
+    mg_ms, best = timed(lambda: D.merge_argmax(am, row0, device=coll_dev))
     # threshold ~ the p = 1e-5 tail the CLI defaults to (main.rs:487): estimated from a sample
     sample = scores[: min(rows, 1 << 20)].flatten()
     thr_t = float(torch.quantile(sample[torch.isfinite(sample)][:8_000_000].float(), 1 - 1e-5))
@@ -217,7 +226,7 @@ def main() -> None:
     fth_ms, fhits = timed(lambda: pli.score_threshold_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS,
                                                           m - 1, total_length, 0, rows, thr_t), reps=2)
     assert np.array_equal(hits, fhits[0]), "fused threshold differs from materialised threshold"
-    all_hits = D.merge_threshold(hits, row0, device=dev)
+    all_hits = D.merge_threshold(hits, row0, device=coll_dev)
 
     if rank != 0:
         if world > 1:
@@ -232,7 +241,12 @@ def main() -> None:
     pmc = ROOT / "profiles" / "pmc_traffic.json"
     if pmc.exists():
         try:
-            traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+            j = json.loads(pmc.read_text())
+            # PMC counters come from separate rocprofv3 passes over this workload
+            # (profiles/README.md); only quoted for the launch shape they were taken on
+            if (j.get("algorithmic_bytes_per_launch") == BYTES_PER_POS * rows * COLS and m == 20
+                    and not args.rows_per_stream):
+                traffic = j.get("hbm_bytes_per_launch")
         except (OSError, ValueError):
             traffic = None
     out = {

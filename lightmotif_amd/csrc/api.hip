@@ -203,6 +203,12 @@ int lm_hip_ctx_destroy(lm_hip_ctx *ctx)
     ctx->scratch2.release();
     if (ctx->pinned)
         (void)hipHostFree(ctx->pinned);
+    if (ctx->aux_stream) {
+        (void)hipStreamSynchronize(ctx->aux_stream);
+        (void)hipStreamDestroy(ctx->aux_stream);
+        (void)hipEventDestroy(ctx->fork_event);
+        (void)hipEventDestroy(ctx->join_event);
+    }
     if (ctx->owns_stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;

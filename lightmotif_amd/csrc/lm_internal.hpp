@@ -57,6 +57,8 @@ struct lm_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
+    hipStream_t aux_stream = nullptr;  // second lane for independent jobs of a batch
+    hipEvent_t fork_event = nullptr, join_event = nullptr;
     std::mutex mu;
     lm::Scratch scratch;        // block partials, chunk counts, hit lists
     lm::Scratch scratch2;

@@ -91,9 +91,13 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store)
     // streams (fewer fill steps): T=1001 0.69 ms vs T=61 0.79 ms on the same input.
     unsigned long long target = ctx->rows_per_stream ? ctx->rows_per_stream : (store ? 64 : 1024);
     // keep at least ~4 streams per SIMD lane-half in flight on small inputs
-    const unsigned long long want_streams = (unsigned long long)ctx->num_cus * 64;
+    // Enough workgroups for several rounds of the chip's resident capacity (6 x 256 CUs
+    // of 8-stream workgroups), so the last partial round costs little; the fused
+    // kernels run back to back per motif, where that tail is paid every launch.
+    const unsigned long long want_streams = (unsigned long long)ctx->num_cus * (store ? 64 : 128);
     if (n / target < want_streams)
         target = std::max<unsigned long long>(n / want_streams, 1);
+    target = std::min<unsigned long long>(target, 1ull << 30);  // step indices are 32-bit
     unsigned long long q = std::max<unsigned long long>((target + M / 2) / M, 1);
     if (q * M + 1 > n)
         q = (n - 1) / M;
@@ -122,11 +126,14 @@ static size_t generic_lds(const lm_hip_pssm *p, int *use_lds)
 }
 
 template <int MODE>
-static int launch_generic(lm_hip_ctx *ctx, const ScoreArgs &a, const FusedOut &fo, dim3 grid)
+static int launch_generic(lm_hip_ctx *ctx, const ScoreArgs &a, const FusedOut &fo, dim3 grid,
+                          hipStream_t stream = nullptr)
 {
+    if (!stream)
+        stream = ctx->stream;
     int use_lds = 0;
     const size_t lds = generic_lds(a.pssm, &use_lds);
-    hipLaunchKernelGGL((score_generic<MODE>), grid, dim3(kBlock), lds, ctx->stream, a.d_seq,
+    hipLaunchKernelGGL((score_generic<MODE>), grid, dim3(kBlock), lds, stream, a.d_seq,
                        (unsigned long long)a.seq_stride, (int)a.cols, a.pssm->d_dense,
                        (int)a.pssm->m, (int)a.pssm->k, use_lds,
                        (unsigned long long)a.row_begin, (unsigned long long)a.row_end, a.d_out,
@@ -195,6 +202,29 @@ __global__ __launch_bounds__(kBlock) void argmax_finalize(
 }
 
 // Enqueues the fused argmax of one job: block records -> `blocks`, result -> `d_result`.
+// Independent jobs of a batch alternate between the context's stream and an auxiliary
+// one, so the tail of one motif's kernel (the last, partially filled round of
+// workgroups) overlaps the head of the next.  fork: aux waits for everything already
+// enqueued on the main stream; join: the main stream waits for aux.
+static int batch_fork(lm_hip_ctx *ctx)
+{
+    if (!ctx->aux_stream) {
+        LM_HIP_TRY(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+        LM_HIP_TRY(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
+        LM_HIP_TRY(hipEventCreateWithFlags(&ctx->join_event, hipEventDisableTiming));
+    }
+    LM_HIP_TRY(hipEventRecord(ctx->fork_event, ctx->stream));
+    LM_HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->fork_event, 0));
+    return LM_HIP_OK;
+}
+
+static int batch_join(lm_hip_ctx *ctx)
+{
+    LM_HIP_TRY(hipEventRecord(ctx->join_event, ctx->aux_stream));
+    LM_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->join_event, 0));
+    return LM_HIP_OK;
+}
+
 // One entry per job of a batch: where its block records are and how to recompute its
 // scores[0][0] (first-cell rule).
 struct FinalizeJob {
@@ -266,25 +296,31 @@ int launch_score_argmax_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
     FinalizeJob *d_jobs = reinterpret_cast<FinalizeJob *>(base + off_jobs);
     std::vector<FinalizeJob> fj(n);
     size_t pos = 0;
+    const bool two_streams = n > 1;
+    if (two_streams)
+        LM_TRY(batch_fork(ctx));
     for (size_t i = 0; i < n; ++i) {
         const ScoreArgs &a = jobs[i];
         const C32Plan p = plan_c32(ctx, a, false);
+        hipStream_t st = (two_streams && (i & 1)) ? ctx->aux_stream : ctx->stream;
         FusedOut fo{};
         fo.block_best = blocks + pos;
         if (p.ok) {
             ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_ARGMAX);
             ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_ARGMAX);
-            LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
+            LM_HIP_TRY(fn(p.grid, p.lds, st, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
                           a.row_begin, a.row_end, p.T, p.nstreams, nullptr, fo));
         } else {
             ctx->last_kernel = "score_generic<1>";
-            LM_TRY(launch_generic<MODE_ARGMAX>(ctx, a, fo, dim3(grids[i])));
+            LM_TRY(launch_generic<MODE_ARGMAX>(ctx, a, fo, dim3(grids[i]), st));
         }
         fj[i] = FinalizeJob{blocks + pos, grids[i], (int)a.pssm->m, (int)a.pssm->k,
                             a.d_seq + a.row_begin * a.seq_stride,
                             (unsigned long long)a.seq_stride, a.pssm->d_dense};
         pos += grids[i];
     }
+    if (two_streams)
+        LM_TRY(batch_join(ctx));
     LM_HIP_TRY(hipMemcpyAsync(d_jobs, fj.data(), sizeof(FinalizeJob) * n, hipMemcpyHostToDevice,
                               ctx->stream));
     hipLaunchKernelGGL(argmax_finalize_batch, dim3((unsigned)n), dim3(kBlock), 0, ctx->stream,
@@ -343,23 +379,29 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
         fo.hit_job = reinterpret_cast<unsigned *>(base + 16 + cap * 12);
         fo.hit_capacity = cap;
         LM_HIP_TRY(hipMemsetAsync(base, 0, 16, ctx->stream));
+        const bool two_streams = n > 1;
+        if (two_streams)
+            LM_TRY(batch_fork(ctx));
         for (size_t i = 0; i < n; ++i) {
             const ScoreArgs &a = jobs[i];
             const C32Plan p = plan_c32(ctx, a, false);
+            hipStream_t st = (two_streams && (i & 1)) ? ctx->aux_stream : ctx->stream;
             fo.threshold = ts[i];
             fo.job_id = (unsigned)i;
             if (p.ok) {
                 ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_THRESHOLD);
                 ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_THRESHOLD);
-                LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, a.pssm->d_table,
+                LM_HIP_TRY(fn(p.grid, p.lds, st, a.d_seq, a.pssm->d_table,
                               (int)a.pssm->k, a.row_begin, a.row_end, p.T, p.nstreams, nullptr, fo));
             } else {
                 ctx->last_kernel = "score_generic<2>";
                 const unsigned long long ncells =
                     (unsigned long long)(a.row_end - a.row_begin) * a.cols;
-                LM_TRY(launch_generic<MODE_THRESHOLD>(ctx, a, fo, generic_grid(ctx, ncells)));
+                LM_TRY(launch_generic<MODE_THRESHOLD>(ctx, a, fo, generic_grid(ctx, ncells), st));
             }
         }
+        if (two_streams)
+            LM_TRY(batch_join(ctx));
         LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, base, 8, hipMemcpyDeviceToHost, ctx->stream));
         LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
         const unsigned long long count = *static_cast<unsigned long long *>(ctx->pinned);

@@ -161,7 +161,8 @@ __device__ __forceinline__ void lds_fetch_column(float (&w)[4 * ((M + 3) / 4)],
 enum : int { PHASE_FIRST = 0, PHASE_MAIN = 1, PHASE_LAST = 2 };
 
 // One group of M consecutive steps of one lane.  `sp` -> symbol byte of the
-// group's first step; `orow` = output row (relative to row_begin) completed by
+// group's first step; `tbase` = index of that step within the stream (wave-uniform;
+// the output row completed by step t is o0 + t - (M-1)); `orow` = output row completed by
 // the group's first step (in the FIRST group only step M-1 completes a row).
 // `sym` is a ring of symbol bytes indexed by step mod M (only ~PF are live),
 // `wc` carries the prefetched LDS column across steps when LP = 1.
@@ -170,8 +171,8 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
                                             float (&wc)[4 * ((M + 3) / 4)],
                                             const uint8_t *__restrict__ sp,
                                             const char *__restrict__ tab,
-                                            float *__restrict__ op, const long long orow,
-                                            const int col, float &best_v, long long &best_row,
+                                            float *__restrict__ op, const unsigned tbase,
+                                            const int col, float &best_v, unsigned &best_t,
                                             const FusedOut &fo)
 {
     constexpr int NW = 4 * ((M + 3) / 4);
@@ -216,7 +217,7 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
             } else if (MODE == MODE_ARGMAX) {
                 if (score >= best_v) {  // same `>=` as pli/mod.rs:146, NaN never passes
                     best_v = score;
-                    best_row = orow + k;
+                    best_t = tbase + k;  // scalar + constant: no per-lane arithmetic
                 }
             } else {
                 // Hits are rare (a p = 1e-5 tail).  The hot loop only tracks the
@@ -225,7 +226,7 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
                 // hits inline at every unrolled step cost 230 VGPRs and a third of
                 // the throughput.
                 if (score >= fo.threshold)  // pli/mod.rs:215
-                    best_row = 1;
+                    best_t = 1;
             }
         }
     }
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
 
     const uint8_t *sp = seq + o0 * 32 + col;
     // output row completed by step t is o0 + t - (M-1); `op` tracks step 0 of the group
-    long long orow = (long long)(o0 - row_begin) - (M - 1);
+    const long long orow = (long long)(o0 - row_begin) - (M - 1);
     float *op = (MODE == MODE_STORE) ? out + orow * 32 + col : nullptr;
 
     constexpr int NW = 4 * ((M + 3) / 4);
@@ -324,7 +325,10 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
     if (LPE)
         lds_fetch_column<M>(wc, lds_raw, sym[0]);
     float best_v = -INFINITY;
-    long long best_row = (MODE == MODE_THRESHOLD) ? 0 : -1;  // threshold mode: "group saw a hit" flag
+    // argmax mode: step index of the lane's best score (0xffffffff = none);
+    // threshold mode: "this group saw a hit" flag
+    unsigned best_t = (MODE == MODE_THRESHOLD) ? 0u : 0xffffffffu;
+    unsigned tbase = 0;
 
     const unsigned long long ngroups = (T + M - 1) / M;  // exact: T = q*M + 1, >= 2
 
@@ -337,8 +341,8 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
     unsigned long long gbit = 1, gleft = G;
     auto note_group = [&]() {
         if (MODE == MODE_THRESHOLD) {
-            hit_groups |= best_row ? gbit : 0ull;
-            best_row = 0;
+            hit_groups |= best_t ? gbit : 0ull;
+            best_t = 0;
             if (--gleft == 0) {
                 gleft = G;
                 gbit <<= 1;
@@ -346,24 +350,24 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         }
     };
 
-    score_group<M, MODE, PFE, LPE, PHASE_FIRST>(acc, sym, wc, sp, lds_raw, op, orow, col, best_v,
-                                                best_row, fo);
+    score_group<M, MODE, PFE, LPE, PHASE_FIRST>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
+                                                best_t, fo);
     note_group();
     for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
         sp += M * 32;
-        orow += M;
+        tbase += M;
         if (MODE == MODE_STORE)
             op += M * 32;
-        score_group<M, MODE, PFE, LPE, PHASE_MAIN>(acc, sym, wc, sp, lds_raw, op, orow, col,
-                                                   best_v, best_row, fo);
+        score_group<M, MODE, PFE, LPE, PHASE_MAIN>(acc, sym, wc, sp, lds_raw, op, tbase, col,
+                                                   best_v, best_t, fo);
         note_group();
     }
     sp += M * 32;
-    orow += M;
+    tbase += M;
     if (MODE == MODE_STORE)
         op += M * 32;
-    score_group<M, MODE, PFE, LPE, PHASE_LAST>(acc, sym, wc, sp, lds_raw, op, orow, col, best_v,
-                                               best_row, fo);
+    score_group<M, MODE, PFE, LPE, PHASE_LAST>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
+                                               best_t, fo);
     note_group();
 
     if (MODE == MODE_THRESHOLD) {
@@ -390,7 +394,10 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         __syncthreads();
         long long *sm_i = reinterpret_cast<long long *>(lds_raw);
         float *sm_v = reinterpret_cast<float *>(lds_raw + 32);
-        long long idx = best_row >= 0 ? best_row * 32 + col : -1;
+        // step t completes output row o0 + t - (M-1)
+        long long idx = best_t != 0xffffffffu
+                            ? ((long long)(o0 - row_begin) + (long long)best_t - (M - 1)) * 32 + col
+                            : -1;
         best_block_reduce<BLK>(best_v, idx, sm_v, sm_i);
         if (threadIdx.x == 0) {
             fo.block_best[blockIdx.x].value = best_v;

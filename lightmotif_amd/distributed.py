@@ -151,6 +151,8 @@ def exchange_halo(shard: torch.Tensor, halo_rows: int, columns: int, default_sym
     if halo_rows == 0:
         return shard
     head = shard[:halo_rows].contiguous()
+    if world > 1 and head.is_cuda and dist.get_backend(group) == "gloo":
+        head = head.cpu()  # gloo has no device-to-device send/recv: stage through the host
     if world == 1:
         recv = head
     else:
@@ -164,5 +166,5 @@ def exchange_halo(shard: torch.Tensor, halo_rows: int, columns: int, default_sym
         wrapped[:, :columns - 1] = recv[:, 1:columns]
         wrapped[:, columns - 1] = default_symbol
         recv = wrapped
-    shard[rows:] = recv
+    shard[rows:] = recv.to(shard.device)
     return shard

@@ -118,3 +118,42 @@ def test_device_stripe_of_100M_positions_round_trips(gpu_pli):
     want[:length] = enc
     assert torch.equal(data[:rows], want.view(COLS, rows).t())
     assert torch.equal(data[rows:, :COLS - 1], data[:19, 1:]) and (data[rows:, COLS - 1] == 4).all()
+
+
+def test_more_positions_than_u32_max(gpu_pli):
+    """4.4 Gbp on one GPU: flat indices and offsets exceed 2^32.  The reference's AVX2
+    argmax refuses such inputs (avx2.rs:354-358); Generic (usize) handles them, so must we."""
+    pli = gpu_pli
+    dev = torch.device("cuda", 0)
+    free, _ = torch.cuda.mem_get_info()
+    length, m, k = 4_400_000_000, 20, 5
+    rows = -(-length // COLS)
+    if free < 30 * (1 << 30):
+        pytest.skip("needs ~26 GB of free HBM")
+    assert rows * COLS > 2 ** 32
+    seq, rows, pssm = make_workload(pli, length, m, k, seed=77)
+    # plant the consensus of the motif at the very end of the sequence (last column, last valid rows)
+    best_syms = torch.from_numpy(np.argmax(pssm.data[:, :4], axis=1).astype(np.uint8)).to(dev)
+    pos0 = length - m - 5                       # position -> (pos % rows, pos // rows)
+    idx = torch.arange(pos0, pos0 + m, device=dev)
+    seq[idx % rows, idx // rows] = best_syms
+    scores = score_all(pli, pssm, seq, rows, m, length)
+    want_cell = (pos0 % rows, pos0 // rows)
+    assert want_cell[0] * COLS + want_cell[1] > 2 ** 32
+    max_score = float(np.float32(sum(np.float32(pssm.data[j, int(best_syms[j])]) for j in range(m))))
+    got = pli.argmax_dptr(scores.data_ptr(), rows, COLS, COLS)
+    fused = pli.score_argmax_dptr(pssm, seq.data_ptr(), rows + m - 1, COLS, COLS, m - 1, length, 0, rows)
+    assert got[0] == want_cell == fused[0]
+    assert abs(got[1] - max_score) < 1e-3 and got[1] == fused[1]
+    # window at the end against the oracle
+    a = rows - 2048
+    host = seq[a:rows + m - 1].cpu().numpy()
+    win = co.Striped(host, length, m - 1, COLS, k)
+    want, _ = co.score_rows(win, pssm.data, 0, rows - a)
+    assert np.array_equal(scores[a:].cpu().numpy().view(np.uint32), want.view(np.uint32))
+    # threshold just below the planted maximum: the hit list must contain the planted cell
+    hits = pli.threshold_dptr(scores.data_ptr(), rows, COLS, COLS, got[1] - 1e-3)
+    assert [want_cell[0], want_cell[1]] in hits.tolist()
+    f_hits, _ = pli.score_threshold_dptr(pssm, seq.data_ptr(), rows + m - 1, COLS, COLS, m - 1, length,
+                                         0, rows, got[1] - 1e-3)
+    assert np.array_equal(f_hits, hits)
