@@ -214,6 +214,16 @@ int lm_hip_scan_threshold_batch(lm_hip_ctx *ctx, const lm_hip_pssm *const *pssms
                                 const float *thresholds, size_t n, const lm_hip_seq *seq,
                                 size_t *counts, lm_hip_coords **coords, float **values);
 
+/* Scanner (scan.rs:96-250), collected: every position with score >= threshold and
+ * position + M <= L (scan.rs:185-190), as (position, f32 score) sorted by position
+ * (the reference yields them in block-LIFO order and callers sort, scan.rs:291).
+ * Runs the fused score+threshold kernel on exact f32 scores; the reference's u8
+ * DiscreteMatrix prefilter (scan.rs:169-178) is a CPU-cache device with the same
+ * result.  Errors with LM_HIP_ERR_WRAP if wrap < M-1 (scan.rs:127-131 panics).
+ * *hits is malloc'ed (NULL when *n == 0); release with lm_hip_free. */
+int lm_hip_scan_f32(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *seq,
+                    float threshold, lm_hip_hit **hits, size_t *n);
+
 /* ---- Encode / Stripe (device pointers) ------------------------------------ */
 
 /* Encode::encode_into (pli/mod.rs:56-66): ASCII -> symbol index.  alphabet is

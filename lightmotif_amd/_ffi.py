@@ -18,6 +18,10 @@ class Coords(C.Structure):
     _fields_ = [("row", C.c_size_t), ("col", C.c_size_t)]
 
 
+class Hit(C.Structure):
+    _fields_ = [("position", C.c_size_t), ("score", C.c_float)]
+
+
 class LightmotifHipError(RuntimeError):
     def __init__(self, status: int, message: str):
         super().__init__(f"lightmotif_hip error {status}: {message}")
@@ -72,6 +76,7 @@ SIGNATURES = {
     "lm_hip_scan_argmax_batch": (C.c_int, [_vp, C.POINTER(_vp), _sz, _vp, _ip, _cp, _fp]),
     "lm_hip_scan_threshold_batch": (C.c_int, [_vp, C.POINTER(_vp), _fp, _sz, _vp, _szp,
                                               C.POINTER(_cp), C.POINTER(_fp)]),
+    "lm_hip_scan_f32": (C.c_int, [_vp, _vp, _vp, C.c_float, C.POINTER(C.POINTER(Hit)), _szp]),
     "lm_hip_encode_dptr": (C.c_int, [_vp, C.c_char, _vp, _sz, C.c_int, _vp, _szp]),
     "lm_hip_stripe_dptr": (C.c_int, [_vp, _vp, _sz, _sz, C.c_uint8, _sz, _vp, _sz]),
     "lm_hip_configure_wrap_dptr": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _sz, C.c_uint8]),

@@ -5,6 +5,7 @@
 //     wrap check (:832-837), degenerate check (:839-842), scores.resize (:844)
 //   Score::score_into (pli/mod.rs:109-117), StripedScores::{argmax,threshold}
 //     (scores.rs:181-213).
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -286,7 +287,13 @@ int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stri
             return cleanup(fail(LM_HIP_ERR_HIP, "pssm upload failed: %s", hipGetErrorString(e)));
         if (m <= (size_t)kMaxFastM) {
             // transposed, padded table of score_c32<M>: table[s * ts + j] = pssm[j][s]
-            p->ts = (size_t)table_stride((int)m);
+            // Protein (K = 21 > 16 slots) has 2-way LDS conflicts with 16-byte reads.  The
+            // conflict-free 8-byte-read layout (`wide`, -DLM_SCORE_BUILD_WIDE) measured
+            // SLOWER on MI355X: hipcc fuses the ds_read_b64 pairs into half-rate
+            // ds_read2_b64 (protein M=12 x 200 Mres: 0.254 ms vs 0.197 ms materialised,
+            // 0.280 vs 0.183 ms fused argmax), so it stays off.
+            p->wide = false;
+            p->ts = (size_t)table_stride((int)m, p->wide);
             std::vector<float> table(k * p->ts, 0.0f);
             for (size_t s = 0; s < k; ++s)
                 for (size_t j = 0; j < m; ++j)
@@ -594,6 +601,46 @@ int lm_hip_scan_threshold_batch(lm_hip_ctx *ctx, const lm_hip_pssm *const *pssms
     *coords = c;
     if (values)
         *values = v;
+    return LM_HIP_OK;
+}
+
+int lm_hip_scan_f32(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *seq,
+                    float threshold, lm_hip_hit **hits, size_t *n)
+{
+    if (!ctx || !pssm || !seq || !hits || !n)
+        return fail(LM_HIP_ERR_BAD_ARGS, "scan: null argument");
+    *hits = nullptr;
+    *n = 0;
+    LM_TRY(check_score_args(pssm, seq->rows + seq->wrap, seq->stride, seq->cols, seq->wrap, 0,
+                            seq->rows));
+    if (seq->length < pssm->m || seq->rows == 0)
+        return LM_HIP_OK;
+    std::vector<unsigned long long> flat;
+    std::vector<float> vals;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        DeviceGuard guard(ctx->device);
+        ScoreArgs a{pssm, seq->d_data, seq->stride, seq->cols, 0, seq->rows, nullptr, 0};
+        LM_TRY(launch_score_threshold(ctx, a, threshold, &flat, &vals));
+    }
+    std::vector<lm_hip_hit> out;
+    out.reserve(flat.size());
+    for (size_t i = 0; i < flat.size(); ++i) {
+        const size_t row = (size_t)(flat[i] / seq->cols), col = (size_t)(flat[i] % seq->cols);
+        const size_t pos = col * seq->rows + row;        // scan.rs:185 / scores.rs:155-157
+        if (pos + pssm->m <= seq->length)                // scan.rs:186
+            out.push_back(lm_hip_hit{pos, vals[i]});
+    }
+    if (out.empty())
+        return LM_HIP_OK;
+    std::sort(out.begin(), out.end(),
+              [](const lm_hip_hit &x, const lm_hip_hit &y) { return x.position < y.position; });
+    lm_hip_hit *h = static_cast<lm_hip_hit *>(malloc(out.size() * sizeof(lm_hip_hit)));
+    if (!h)
+        return fail(LM_HIP_ERR_OOM, "scan: cannot allocate %zu hits", out.size());
+    memcpy(h, out.data(), out.size() * sizeof(lm_hip_hit));
+    *hits = h;
+    *n = out.size();
     return LM_HIP_OK;
 }
 

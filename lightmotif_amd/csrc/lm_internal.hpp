@@ -78,6 +78,7 @@ struct lm_hip_pssm {
     // ts = floats per symbol row (multiple of 4, ts/4 odd), zero padded.
     float *d_table = nullptr;
     size_t ts = 0;
+    bool wide = false;  // K > 16: 8-byte LDS reads, row stride 2*odd (score_kernels.hpp)
     // Row-major dense copy for the generic kernel: d_dense[j * k + s].
     float *d_dense = nullptr;
 };

@@ -39,11 +39,13 @@ static void init_registry()
             snprintf(g_c32_names[m][mode], sizeof g_c32_names[m][mode], "score_c32<%d,%d>", m, mode);
 }
 
-ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap)
+ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap, bool wide)
 {
     std::call_once(g_c32_once, init_registry);
     if (M < 1 || M > kMaxFastM || mode < 0 || mode > 2)
         return nullptr;
+    if (wide)
+        return g_c32[M][4 + mode];
     if (mode == MODE_STORE && xcd_remap)
         return g_c32[M][3];
     return g_c32[M][mode];
@@ -84,7 +86,7 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store)
         return p;
     if (M < 1 || M > (size_t)kMaxFastM || n < M + 1)
         return p;
-    const size_t lds = std::max<size_t>(K * table_stride((int)M) * sizeof(float), 64);
+    const size_t lds = std::max<size_t>(K * table_stride((int)M, a.pssm->wide) * sizeof(float), 64);
     if (lds > 60 * 1024)
         return p;
     // The fused kernels write nothing, so they are LDS/VALU-bound and prefer long
@@ -149,7 +151,7 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
     FusedOut fo{};
     const C32Plan p = plan_c32(ctx, a, true);
     if (p.ok) {
-        ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_STORE, ctx->xcd_remap);
+        ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_STORE, ctx->xcd_remap, a.pssm->wide);
         ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_STORE);
         LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
                       a.row_begin, a.row_end, p.T, p.nstreams, a.d_out, fo));
@@ -306,7 +308,7 @@ int launch_score_argmax_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
         FusedOut fo{};
         fo.block_best = blocks + pos;
         if (p.ok) {
-            ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_ARGMAX);
+            ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_ARGMAX, false, a.pssm->wide);
             ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_ARGMAX);
             LM_HIP_TRY(fn(p.grid, p.lds, st, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
                           a.row_begin, a.row_end, p.T, p.nstreams, nullptr, fo));
@@ -389,7 +391,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
             fo.threshold = ts[i];
             fo.job_id = (unsigned)i;
             if (p.ok) {
-                ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_THRESHOLD);
+                ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_THRESHOLD, false, a.pssm->wide);
                 ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_THRESHOLD);
                 LM_HIP_TRY(fn(p.grid, p.lds, st, a.d_seq, a.pssm->d_table,
                               (int)a.pssm->k, a.row_begin, a.row_end, p.T, p.nstreams, nullptr, fo));

@@ -20,6 +20,12 @@ struct RegisterRange {
         tab[M][MODE_ARGMAX] = &score_c32_launch<M, MODE_ARGMAX>;
         tab[M][MODE_THRESHOLD] = &score_c32_launch<M, MODE_THRESHOLD>;
         tab[M][3] = &score_c32_launch<M, MODE_STORE, 1>;
+#if defined(LM_SCORE_BUILD_WIDE)
+        // 8-byte-read variant for K > 16; not built by default, see api.hip (pssm_create)
+        tab[M][4 + MODE_STORE] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1>;
+        tab[M][4 + MODE_ARGMAX] = &score_c32_launch<M, MODE_ARGMAX, LM_SCORE_XCD_REMAP, 1>;
+        tab[M][4 + MODE_THRESHOLD] = &score_c32_launch<M, MODE_THRESHOLD, LM_SCORE_XCD_REMAP, 1>;
+#endif
         if constexpr (M < LM_M_HI)
             RegisterRange<M + 1>::run(tab);
     }

@@ -50,7 +50,13 @@ constexpr int kMaxFastM = 36;        // largest motif the unrolled kernel is bui
 
 // Floats per symbol row of the transposed LDS table used by score_c32<M>:
 // 4 * (smallest odd number >= ceil(M/4)).
-constexpr int table_stride(int m) { return 4 * (((m + 3) / 4) | 1); }
+// Alphabets with more than 16 symbols (protein, K = 21) cannot be conflict-free with
+// 16-byte reads (16 slots per 16-lane group), so they use 8-byte reads (32 slots per
+// 32-lane group) and a row stride of 2 * odd floats (`wide`).
+constexpr int table_stride(int m, bool wide = false)
+{
+    return wide ? 2 * (((m + 1) / 2) | 1) : 4 * (((m + 3) / 4) | 1);
+}
 
 enum : int { MODE_STORE = 0, MODE_ARGMAX = 1, MODE_THRESHOLD = 2 };
 
@@ -140,21 +146,35 @@ __device__ __forceinline__ void record_hit(const FusedOut &fo, unsigned long lon
 #define LM_SCORE_NT_STORE 1
 #endif
 
-template <int M>
+template <int M, int WIDE>
 __device__ __forceinline__ void lds_fetch_column(float (&w)[4 * ((M + 3) / 4)],
                                                  const char *__restrict__ tab, const unsigned s)
 {
-    constexpr int NV = (M + 3) / 4;
-    constexpr unsigned TSB = table_stride(M) * 4;  // bytes per symbol row, multiple of 16
-    const char *row =
-        static_cast<const char *>(__builtin_assume_aligned(tab + __umul24(s, TSB), 16));
+    constexpr unsigned TSB = table_stride(M, WIDE) * 4;  // bytes per symbol row
+    if (WIDE) {
+        // ds_read_b64: bank = (addr/4) mod 64, 32 two-dword slots per 32-lane group;
+        // rows at s * (2*odd) dwords -> up to 32 symbols in distinct slots
+        constexpr int NV = (M + 1) / 2;
+        const char *row =
+            static_cast<const char *>(__builtin_assume_aligned(tab + __umul24(s, TSB), 8));
 #pragma unroll
-    for (int q = 0; q < NV; ++q) {
-        const float4 v = *reinterpret_cast<const float4 *>(row + 16 * q);
-        w[4 * q + 0] = v.x;
-        w[4 * q + 1] = v.y;
-        w[4 * q + 2] = v.z;
-        w[4 * q + 3] = v.w;
+        for (int q = 0; q < NV; ++q) {
+            const float2 v = *reinterpret_cast<const float2 *>(row + 8 * q);
+            w[2 * q + 0] = v.x;
+            w[2 * q + 1] = v.y;
+        }
+    } else {
+        constexpr int NV = (M + 3) / 4;
+        const char *row =
+            static_cast<const char *>(__builtin_assume_aligned(tab + __umul24(s, TSB), 16));
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(row + 16 * q);
+            w[4 * q + 0] = v.x;
+            w[4 * q + 1] = v.y;
+            w[4 * q + 2] = v.z;
+            w[4 * q + 3] = v.w;
+        }
     }
 }
 
@@ -166,7 +186,7 @@ enum : int { PHASE_FIRST = 0, PHASE_MAIN = 1, PHASE_LAST = 2 };
 // the group's first step (in the FIRST group only step M-1 completes a row).
 // `sym` is a ring of symbol bytes indexed by step mod M (only ~PF are live),
 // `wc` carries the prefetched LDS column across steps when LP = 1.
-template <int M, int MODE, int PF, int LP, int PHASE>
+template <int M, int MODE, int PF, int LP, int PHASE, int WIDE>
 __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
                                             float (&wc)[4 * ((M + 3) / 4)],
                                             const uint8_t *__restrict__ sp,
@@ -193,9 +213,9 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
             for (int i = 0; i < NW; ++i)
                 w[i] = wc[i];
             if (PHASE != PHASE_LAST || k + 1 < M)
-                lds_fetch_column<M>(wc, tab, sym[(k + 1) % M]);
+                lds_fetch_column<M, WIDE>(wc, tab, sym[(k + 1) % M]);
         } else {
-            lds_fetch_column<M>(w, tab, sym[k]);
+            lds_fetch_column<M, WIDE>(w, tab, sym[k]);
         }
         // (3) P[j][s] goes to the output row started j steps ago: slot (k - j) mod M.
 #pragma unroll
@@ -235,12 +255,12 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
 // Slow path of the fused threshold: re-scores output rows [r0, r1) of this lane's
 // column with the same add order and appends the cells with score >= t.  The M
 // symbol loads of a row are independent and issued together; rows run in a loop.
-template <int M>
+template <int M, int WIDE>
 __device__ __forceinline__ void rescan_rows(const uint8_t *__restrict__ seq_col,
                                             const float *__restrict__ tabf, const long long r0,
                                             const long long r1, const int col, const FusedOut &fo)
 {
-    constexpr int TS = table_stride(M);
+    constexpr int TS = table_stride(M, WIDE);
 #pragma unroll 1
     for (long long r = r0; r < r1; ++r) {
         const uint8_t *p = seq_col + r * 32;
@@ -266,7 +286,7 @@ __device__ __forceinline__ void rescan_rows(const uint8_t *__restrict__ seq_col,
 #define LM_SCORE_XCD_REMAP 0
 #endif
 template <int M, int MODE, int PF = LM_SCORE_PF, int LP = LM_SCORE_LP, int BLK = LM_BLOCK,
-          int XCD = LM_SCORE_XCD_REMAP, int MINW = LM_SCORE_MIN_WAVES(M)>
+          int XCD = LM_SCORE_XCD_REMAP, int MINW = LM_SCORE_MIN_WAVES(M), int WIDE = 0>
 __global__ __launch_bounds__(BLK, MINW) void score_c32(
     const uint8_t *__restrict__ seq, const float *__restrict__ table, const int K,
     const unsigned long long row_begin, const unsigned long long row_end,
@@ -274,7 +294,12 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
     const FusedOut fo)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    {
+    if (WIDE) {
+        float *dst = reinterpret_cast<float *>(lds_raw);
+        const int nf = K * table_stride(M, true);
+        for (int i = threadIdx.x; i < nf; i += BLK)
+            dst[i] = table[i];
+    } else {
         float4 *dst = reinterpret_cast<float4 *>(lds_raw);
         const float4 *src = reinterpret_cast<const float4 *>(table);
         const int n4 = K * table_stride(M) / 4;
@@ -323,7 +348,7 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         wc[i] = 0.0f;
     constexpr int LPE = (PFE >= 1) ? LP : 0;
     if (LPE)
-        lds_fetch_column<M>(wc, lds_raw, sym[0]);
+        lds_fetch_column<M, WIDE>(wc, lds_raw, sym[0]);
     float best_v = -INFINITY;
     // argmax mode: step index of the lane's best score (0xffffffff = none);
     // threshold mode: "this group saw a hit" flag
@@ -350,7 +375,7 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         }
     };
 
-    score_group<M, MODE, PFE, LPE, PHASE_FIRST>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
+    score_group<M, MODE, PFE, LPE, PHASE_FIRST, WIDE>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
                                                 best_t, fo);
     note_group();
     for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
@@ -358,7 +383,7 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         tbase += M;
         if (MODE == MODE_STORE)
             op += M * 32;
-        score_group<M, MODE, PFE, LPE, PHASE_MAIN>(acc, sym, wc, sp, lds_raw, op, tbase, col,
+        score_group<M, MODE, PFE, LPE, PHASE_MAIN, WIDE>(acc, sym, wc, sp, lds_raw, op, tbase, col,
                                                    best_v, best_t, fo);
         note_group();
     }
@@ -366,7 +391,7 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
     tbase += M;
     if (MODE == MODE_STORE)
         op += M * 32;
-    score_group<M, MODE, PFE, LPE, PHASE_LAST>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
+    score_group<M, MODE, PFE, LPE, PHASE_LAST, WIDE>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
                                                best_t, fo);
     note_group();
 
@@ -385,7 +410,7 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
             long long r0 = orow0 + (long long)(g0 * M);
             if (r0 < first_row)
                 r0 = first_row;  // group 0 completes only the stream's first row
-            rescan_rows<M>(seq_col, tabf, r0, orow0 + (long long)(g1 * M), col, fo);
+            rescan_rows<M, WIDE>(seq_col, tabf, r0, orow0 + (long long)(g1 * M), col, fo);
         }
     }
 
@@ -468,22 +493,24 @@ using ScoreC32Launcher = hipError_t (*)(dim3 grid, size_t lds_bytes, hipStream_t
                                         unsigned long long T, unsigned long long nstreams,
                                         float *out, FusedOut fo);
 
-template <int M, int MODE, int XCD = LM_SCORE_XCD_REMAP>
+template <int M, int MODE, int XCD = LM_SCORE_XCD_REMAP, int WIDE = 0>
 hipError_t score_c32_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, const uint8_t *seq,
                             const float *table, int K, unsigned long long row_begin,
                             unsigned long long row_end, unsigned long long T,
                             unsigned long long nstreams, float *out, FusedOut fo)
 {
-    hipLaunchKernelGGL((score_c32<M, MODE, LM_SCORE_PF, LM_SCORE_LP, LM_BLOCK, XCD>), grid,
+    hipLaunchKernelGGL((score_c32<M, MODE, LM_SCORE_PF, LM_SCORE_LP, LM_BLOCK, XCD,
+                                  LM_SCORE_MIN_WAVES(M), WIDE>), grid,
                        dim3(kBlock), lds_bytes, stream, seq, table, K, row_begin, row_end, T,
                        nstreams, out, fo);
     return hipGetLastError();
 }
 
 // Filled by the score_inst_*.hip translation units; [M][MODE], nullptr if absent.
-// Slot 3 of a registry row = the store kernel WITH the XCD remap (A/B knob).
-constexpr int kRegistrySlots = 4;
-ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap = false);
+// Registry row: [0..2] = modes, [3] = store kernel WITH the XCD remap (A/B knob),
+// [4..6] = modes for wide alphabets (K > 16).
+constexpr int kRegistrySlots = 8;
+ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap = false, bool wide = false);
 const char *score_c32_name(int M, int mode);
 
 }  // namespace lm

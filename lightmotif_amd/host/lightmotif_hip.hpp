@@ -453,6 +453,23 @@ public:
         return out;
     }
 
+    // Scanner::new(pssm, seq).threshold(t).collect() sorted by position (scan.rs:96-250)
+    struct Hit {
+        size_t position;
+        float score;
+    };
+    std::vector<Hit> scan(const ScoringMatrix<A> &pssm, const StripedSequence<A> &seq, float threshold) const
+    {
+        lm_hip_hit *h = nullptr;
+        size_t n = 0;
+        check(lm_hip_scan_f32(ctx_->ctx, pssm.device(ctx_->ctx), seq.handle(), threshold, &h, &n));
+        std::vector<Hit> out(n);
+        for (size_t i = 0; i < n; ++i)
+            out[i] = Hit{h[i].position, h[i].score};
+        lm_hip_free(h);
+        return out;
+    }
+
 private:
     explicit Pipeline(std::shared_ptr<CtxHandle> c) : ctx_(std::move(c)) {}
     std::shared_ptr<CtxHandle> ctx_;

@@ -769,11 +769,16 @@ class Scanner:
         self.block_size = block_size
         if sequence.wrap < len(pssm) - 1:  # scan.rs:127-131 panics
             raise ValueError(f"not enough wrapping rows for motif of length {len(pssm)}")
-        coords, values = sequence._pli.score_threshold(pssm, sequence, threshold)
-        rows, length, m = sequence.rows, len(sequence), len(pssm)
-        hits = [Hit(c * rows + r, v) for (r, c), v in zip(coords, values)
-                if c * rows + r + m <= length]
-        hits.sort(key=lambda h: h.position, reverse=True)
+        pli = sequence._pli
+        ptr, n = C.POINTER(_ffi.Hit)(), C.c_size_t(0)
+        check(pli._L.lm_hip_scan_f32(pli._h, pssm._device(pli), sequence._h, threshold,
+                                     C.byref(ptr), C.byref(n)))
+        try:
+            hits = [Hit(int(ptr[i].position), float(ptr[i].score)) for i in range(n.value)]
+        finally:
+            if ptr:
+                pli._L.lm_hip_free(ptr)
+        hits.reverse()  # popped from the end: ascending positions come out first
         self._hits = hits
 
     def __iter__(self) -> "Scanner":

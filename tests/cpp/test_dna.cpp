@@ -118,6 +118,22 @@ static void test_threshold(const Pipeline<Dna> &pli, size_t columns)
     CHECK(result.threshold(10.0f).empty());                          // README.md:89-90
 }
 
+// scan.rs:279-353 / lightmotif-py test_scanner.py:64-80
+static void test_scanner(const Pipeline<Dna> &pli)
+{
+    auto striped = pli.stripe(EncodedSequence<Dna>::encode(SEQUENCE));
+    const auto pssm = golden_pssm();
+    striped.configure(pssm);
+    CHECK(pli.scan(pssm, striped, 0.0f).empty());
+    const auto hits = pli.scan(pssm, striped, -10.0f);
+    CHECK(hits.size() == 3);
+    if (hits.size() == 3) {
+        CHECK(hits[0].position == 18 && std::fabs(hits[0].score - (-5.50167f)) < 1e-5f);
+        CHECK(hits[1].position == 27 && std::fabs(hits[1].score - (-6.4345555f)) < 1e-5f);
+        CHECK(hits[2].position == 32 && std::fabs(hits[2].score - (-8.961102f)) < 1e-5f);
+    }
+}
+
 // tests/stripe.rs:17-45
 static void test_stripe(const Pipeline<Dna> &pli, const std::string &sequence, size_t columns)
 {
@@ -204,6 +220,7 @@ int main()
         test_stripe(pli, SEQUENCE, columns);
     }
     test_stripe_literals(pli);
+    test_scanner(pli);
     test_encode(pli);
     test_edge_cases(pli);
     if (failures) {
