@@ -629,6 +629,27 @@ class ScoringMatrix:
         """pwm/mod.rs:640-648 (the caller configures the wrap rows, like in Rust)."""
         return sequence._pli.score(self, sequence)
 
+    @property
+    def score_distribution(self):
+        """pwm/mod.rs:698-705 ``to_score_distribution`` (MEME-style, pwm/dist.rs)."""
+        from .dist import ScoreDistribution
+        if getattr(self, "_dist", None) is None:
+            self._dist = ScoreDistribution(self)
+        return self._dist
+
+    def pvalue(self, score: float, method: str = "meme") -> float:
+        """lib.pyi ``ScoringMatrix.pvalue``; only the MEME method is on this path
+        (TFM-PVALUE is a separate GPL crate, out of scope)."""
+        if method != "meme":
+            raise ValueError(f"unsupported method: {method!r}")
+        return self.score_distribution.pvalue(score)
+
+    def score_for_pvalue(self, pvalue: float, method: str = "meme") -> float:
+        """lib.pyi ``ScoringMatrix.score`` (renamed here: ``score`` is the scoring call)."""
+        if method != "meme":
+            raise ValueError(f"unsupported method: {method!r}")
+        return self.score_distribution.score(pvalue)
+
     def reverse_complement(self) -> "ScoringMatrix":
         """pwm/mod.rs:566-577 (DNA: A<->T, C<->G, N->N)."""
         if self.protein:

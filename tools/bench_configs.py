@@ -96,20 +96,10 @@ def config3(pli):
     for p in pssms:  # device tables
         p._device(pli)
     t_am = timeit(lambda: pli.scan_argmax_batch(pssms, seq), 3)
-    # per-motif threshold at the p ~ 1e-5 tail the CLI defaults to (main.rs:487), estimated
-    # from the scores of the first 8.4 M positions; motifs too short to reach 1e-5 get 0 hits
-    srows = 262_144
-    tmp = torch.empty((srows, COLS), dtype=torch.float32, device=enc_seq.device)
-    ts = []
-    for p in pssms:
-        m = len(p)
-        pli.score_dptr(p, enc_seq.data_ptr(), enc_seq.shape[0], COLS, COLS, max(lengths) - 1, length,
-                       0, srows, tmp.data_ptr(), COLS)
-        flat = tmp.view(-1)[:8_000_000]
-        t = float(torch.quantile(flat[torch.isfinite(flat)], 1 - 1e-5))
-        if float((flat >= t).float().mean()) > 5e-5:  # a tie plateau: step above it
-            t = float(np.nextafter(np.float32(t), np.float32(np.inf)))
-        ts.append(t)
+    # per-motif score threshold for p = 1e-5, the CLI default (lightmotif-cli main.rs:487-498),
+    # from the MEME-style score distribution (lightmotif_amd/dist.py <- pwm/dist.rs); motifs too
+    # short to reach 1e-5 get a threshold above their maximum, i.e. no hits
+    ts = [p.score_for_pvalue(1e-5) for p in pssms]
     res = pli.scan_threshold_batch(pssms, ts, seq)
     t_th = timeit(lambda: pli.scan_threshold_batch(pssms, ts, seq), 3)
     cells = len(pssms) * rows * COLS
