@@ -104,6 +104,12 @@ int lm_hip_ctx_set_rows_per_stream(lm_hip_ctx *ctx, size_t rows);
  * each XCD (private L2) sweeps one contiguous eighth of the rows; 0 (default) = plain
  * dispatch order, one compact window.  Speed only, results are identical. */
 int lm_hip_ctx_set_xcd_remap(lm_hip_ctx *ctx, int enabled);
+/* Tuning knob of the fused score+threshold scans (lm_hip_score_threshold_f32_dptr,
+ * lm_hip_scan_f32, lm_hip_scan_threshold_batch): 1 (default) = candidates are found
+ * with a packed 16-bit over-estimating discretisation of the PSSM (the GPU form of the
+ * reference Scanner's DiscreteMatrix prefilter, scan.rs:169-198) and re-scored exactly;
+ * 0 = every position is scored in f32.  The hit lists are identical either way. */
+int lm_hip_ctx_set_prefilter(lm_hip_ctx *ctx, int enabled);
 /* Name of the kernel the last score call on this context launched
  * (for profiling tools); valid until the next call. */
 const char *lm_hip_ctx_last_kernel(lm_hip_ctx *ctx);

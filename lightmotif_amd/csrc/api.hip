@@ -6,13 +6,14 @@
 //   Score::score_into (pli/mod.rs:109-117), StripedScores::{argmax,threshold}
 //     (scores.rs:181-213).
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 
-#include "score_kernels.hpp"
+#include "score_prefilter.hpp"
 
 namespace lm {
 
@@ -83,6 +84,73 @@ static int check_score_args(const lm_hip_pssm *pssm, size_t seq_rows_total, size
         return fail(LM_HIP_ERR_BAD_ARGS, "score: row range %zu..%zu exceeds the %zu sequence rows",
                     row_begin, row_end, seq_rows_total - wrap);
     return LM_HIP_OK;
+}
+
+// Builds the LDS image of score_c32_prefilter<M>: [exact f32 table | u16 layout EVEN |
+// u16 layout ODD] and the affine map discrete ~ (score - offset) / factor.  Follows the
+// idea of DiscreteMatrix (pwm/mod.rs:665-696: per-row offsets, one global factor,
+// weights rounded UP) on 16 bits.  Returns false when no sound prefilter exists.
+static bool build_prefilter(lm_hip_pssm &p, const std::vector<float> &table, std::vector<unsigned> *image)
+{
+    const int m = (int)p.m, k = (int)p.k;
+    if (m < 1 || p.wide)
+        return false;
+    const int mp = prefilter_mp(m), shift = mp - m, dsd = prefilter_stride_dw(m);
+    std::vector<double> off(m), top(m);
+    double offset = 0, range = 0, abs_sum = 0;
+    for (int j = 0; j < m; ++j) {
+        double lo = INFINITY, hi = -INFINITY, amax = 0;
+        for (int s = 0; s < k; ++s) {
+            const float x = p.host[(size_t)j * k + s];
+            if (x != x || x == INFINITY)
+                return false;             // NaN / +inf: score semantics the bound cannot cover
+            if (x == -INFINITY)
+                continue;                 // stands for the row minimum (over-estimate)
+            lo = std::min(lo, (double)x);
+            hi = std::max(hi, (double)x);
+            amax = std::max(amax, std::fabs((double)x));
+        }
+        if (lo == INFINITY)
+            return false;                 // a row of -inf only: every score is -inf
+        off[j] = lo;
+        top[j] = hi;
+        offset += lo;
+        range += hi - lo;
+        abs_sum += amax;
+    }
+    if (!(range > 0))
+        return false;
+    const double factor = range / 65000.0;
+    // discrete weights d'[0..mp): leading zero row when m is odd
+    std::vector<unsigned> d((size_t)mp * k, 0);
+    for (int j = 0; j < m; ++j)
+        for (int s = 0; s < k; ++s) {
+            const float x = p.host[(size_t)j * k + s];
+            const double v = (x == -INFINITY) ? 0.0 : ((double)x - off[j]) / factor;
+            unsigned q = (unsigned)std::ceil(v);
+            if ((double)q < v + 1e-9)     // guard the ceil against representation error
+                q += 1;
+            d[(size_t)(j + shift) * k + s] = q;
+        }
+    image->assign((size_t)prefilter_image_dw(m, k), 0u);
+    static_assert(sizeof(float) == sizeof(unsigned), "f32 table is stored in dwords");
+    memcpy(image->data(), table.data(), table.size() * sizeof(float));
+    unsigned *even = image->data() + (size_t)k * table_stride(m);
+    unsigned *odd = even + (size_t)k * dsd;
+    for (int s = 0; s < k; ++s)
+        for (int w = 0; w < mp / 2; ++w) {
+            const unsigned e_lo = d[(size_t)(2 * w) * k + s];
+            const unsigned e_hi = d[(size_t)((2 * w - 1 + mp) % mp) * k + s];
+            const unsigned o_lo = d[(size_t)(2 * w + 1) * k + s];
+            const unsigned o_hi = d[(size_t)(2 * w) * k + s];
+            even[(size_t)s * dsd + w] = e_lo | (e_hi << 16);
+            odd[(size_t)s * dsd + w] = o_lo | (o_hi << 16);
+        }
+    p.pre_offset = offset;
+    p.pre_factor = factor;
+    // |f32 sum - real sum| <= (M-1) * 2^-24 * sum |terms|  (each add rounds to nearest)
+    p.pre_emax = (double)m * std::ldexp(1.0, -24) * abs_sum * 1.5;
+    return true;
 }
 
 static int default_ctx(lm_hip_ctx **out)
@@ -176,7 +244,7 @@ static int ctx_create(int device, void *stream, bool borrow, lm_hip_ctx **out)
         }
         ctx->owns_stream = true;
     }
-    hipError_t e = hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(&ctx->pinned, kPinnedBytes, hipHostMallocDefault);
     if (e != hipSuccess) {
         if (ctx->owns_stream)
             (void)hipStreamDestroy(ctx->stream);
@@ -249,6 +317,14 @@ int lm_hip_ctx_set_xcd_remap(lm_hip_ctx *ctx, int enabled)
     return LM_HIP_OK;
 }
 
+int lm_hip_ctx_set_prefilter(lm_hip_ctx *ctx, int enabled)
+{
+    if (!ctx)
+        return fail(LM_HIP_ERR_BAD_ARGS, "null context");
+    ctx->use_prefilter = enabled != 0;
+    return LM_HIP_OK;
+}
+
 const char *lm_hip_ctx_last_kernel(lm_hip_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
 
 // ---- PSSM ---------------------------------------------------------------------------------
@@ -307,6 +383,21 @@ int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stri
                 e = hipStreamSynchronize(ctx->stream);  // `table` dies with this scope
             if (e != hipSuccess)
                 return cleanup(fail(LM_HIP_ERR_HIP, "table upload failed: %s", hipGetErrorString(e)));
+            // discrete prefilter image (score_prefilter.hpp); absent when the matrix has
+            // NaN / +inf entries or no spread -- the exact f32 fused kernel is used then
+            std::vector<unsigned> image;
+            if (build_prefilter(*p, table, &image)) {
+                e = hipMalloc(&p->d_image, image.size() * sizeof(unsigned));
+                if (e != hipSuccess)
+                    return cleanup(fail(LM_HIP_ERR_OOM, "hipMalloc(prefilter) failed: %s", hipGetErrorString(e)));
+                e = hipMemcpyAsync(p->d_image, image.data(), image.size() * sizeof(unsigned),
+                                   hipMemcpyHostToDevice, ctx->stream);
+                if (e == hipSuccess)
+                    e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess)
+                    return cleanup(fail(LM_HIP_ERR_HIP, "prefilter upload failed: %s", hipGetErrorString(e)));
+                p->has_prefilter = true;
+            }
         }
         e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess)
@@ -325,6 +416,8 @@ int lm_hip_pssm_destroy(lm_hip_pssm *p)
         (void)hipFree(p->d_dense);
     if (p->d_table)
         (void)hipFree(p->d_table);
+    if (p->d_image)
+        (void)hipFree(p->d_image);
     delete p;
     return LM_HIP_OK;
 }

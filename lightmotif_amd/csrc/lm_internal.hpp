@@ -49,6 +49,8 @@ struct ArgmaxRecord {
     long long index;  // flat index row * cols + col, -1 = none
 };
 
+constexpr size_t kPinnedBytes = 4u << 20;  // pinned staging buffer per context
+
 }  // namespace lm
 
 // ---- opaque handle definitions ------------------------------------------------
@@ -62,8 +64,9 @@ struct lm_hip_ctx {
     std::mutex mu;
     lm::Scratch scratch;        // block partials, chunk counts, hit lists
     lm::Scratch scratch2;
-    void *pinned = nullptr;     // 4 KiB of host-pinned memory for small read-backs
+    void *pinned = nullptr;     // kPinnedBytes of host-pinned memory for read-backs
     size_t rows_per_stream = 0; // 0 = default
+    bool use_prefilter = true;  // fused threshold: packed 16-bit discrete prefilter (A/B knob)
     bool xcd_remap = false;      // A/B knob of the store kernel (lm_hip_ctx_set_xcd_remap)
     int num_cus = 256;
     unsigned long long last_hit_count = 0;  // sizes the next fused-threshold hit list
@@ -81,6 +84,12 @@ struct lm_hip_pssm {
     bool wide = false;  // K > 16: 8-byte LDS reads, row stride 2*odd (score_kernels.hpp)
     // Row-major dense copy for the generic kernel: d_dense[j * k + s].
     float *d_dense = nullptr;
+    // Discrete prefilter of the fused threshold scan (score_prefilter.hpp): LDS image
+    // (exact f32 table | u16 layout EVEN | u16 layout ODD) and the affine map
+    // discrete = (score - pre_offset) / pre_factor, pre_emax = f32 rounding-error bound.
+    unsigned *d_image = nullptr;
+    bool has_prefilter = false;
+    double pre_offset = 0, pre_factor = 0, pre_emax = 0;
 };
 
 struct lm_hip_seq {

@@ -1,39 +1,44 @@
 // score.hip -- launch logic of the scoring kernels (kernel bodies: score_kernels.hpp).
 #include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
 #include <mutex>
+#include <thread>
 #include <numeric>
 
-#include "score_kernels.hpp"
+#include "score_prefilter.hpp"
 
 namespace lm {
 
 // ---- registry of the unrolled C=32 kernels ---------------------------------------
 
-void register_score_c32_0(ScoreC32Launcher (*tab)[kRegistrySlots]);
-void register_score_c32_1(ScoreC32Launcher (*tab)[kRegistrySlots]);
-void register_score_c32_2(ScoreC32Launcher (*tab)[kRegistrySlots]);
-void register_score_c32_3(ScoreC32Launcher (*tab)[kRegistrySlots]);
-void register_score_c32_4(ScoreC32Launcher (*tab)[kRegistrySlots]);
-void register_score_c32_5(ScoreC32Launcher (*tab)[kRegistrySlots]);
-void register_score_c32_6(ScoreC32Launcher (*tab)[kRegistrySlots]);
-void register_score_c32_7(ScoreC32Launcher (*tab)[kRegistrySlots]);
-void register_score_c32_8(ScoreC32Launcher (*tab)[kRegistrySlots]);
+void register_score_c32_0(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre);
+void register_score_c32_1(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre);
+void register_score_c32_2(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre);
+void register_score_c32_3(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre);
+void register_score_c32_4(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre);
+void register_score_c32_5(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre);
+void register_score_c32_6(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre);
+void register_score_c32_7(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre);
+void register_score_c32_8(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre);
 
 static ScoreC32Launcher g_c32[kMaxFastM + 1][kRegistrySlots];
+static PrefilterLauncher g_pre[kMaxFastM + 1];
 static char g_c32_names[kMaxFastM + 1][3][32];
 static std::once_flag g_c32_once;
 
 static void init_registry()
 {
-    register_score_c32_0(g_c32);
-    register_score_c32_1(g_c32);
-    register_score_c32_2(g_c32);
-    register_score_c32_3(g_c32);
-    register_score_c32_4(g_c32);
-    register_score_c32_5(g_c32);
-    register_score_c32_6(g_c32);
-    register_score_c32_7(g_c32);
-    register_score_c32_8(g_c32);
+    register_score_c32_0(g_c32, g_pre);
+    register_score_c32_1(g_c32, g_pre);
+    register_score_c32_2(g_c32, g_pre);
+    register_score_c32_3(g_c32, g_pre);
+    register_score_c32_4(g_c32, g_pre);
+    register_score_c32_5(g_c32, g_pre);
+    register_score_c32_6(g_c32, g_pre);
+    register_score_c32_7(g_c32, g_pre);
+    register_score_c32_8(g_c32, g_pre);
     for (int m = 0; m <= kMaxFastM; ++m)
         for (int mode = 0; mode < 3; ++mode)
             snprintf(g_c32_names[m][mode], sizeof g_c32_names[m][mode], "score_c32<%d,%d>", m, mode);
@@ -49,6 +54,12 @@ ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap, bool wide)
     if (mode == MODE_STORE && xcd_remap)
         return g_c32[M][3];
     return g_c32[M][mode];
+}
+
+PrefilterLauncher score_c32_prefilter_lookup(int M)
+{
+    std::call_once(g_c32_once, init_registry);
+    return (M >= 1 && M <= kMaxFastM) ? g_pre[M] : nullptr;
 }
 
 const char *score_c32_name(int M, int mode)
@@ -77,16 +88,20 @@ struct C32Plan {
 // allocator (kbench6_place.txt, `bench.py --ab`: 1.00 vs 0.97 ms on the same box) --
 // eight distant windows instead of one compact one; the compact window is the
 // robust choice.
-static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store)
+static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store, bool prefilter = false)
 {
     C32Plan p;
-    const size_t M = a.pssm->m, K = a.pssm->k;
+    const size_t K = a.pssm->k;
+    // the prefilter kernel rotates over the motif padded to an even length
+    const size_t M = prefilter ? (size_t)prefilter_mp((int)a.pssm->m) : a.pssm->m;
     const unsigned long long n = a.row_end - a.row_begin;
     if (a.cols != 32 || a.seq_stride != 32 || (store && a.out_stride != 32))
         return p;
-    if (M < 1 || M > (size_t)kMaxFastM || n < M + 1)
+    if (a.pssm->m < 1 || a.pssm->m > (size_t)kMaxFastM || n < M + 1)
         return p;
-    const size_t lds = std::max<size_t>(K * table_stride((int)M, a.pssm->wide) * sizeof(float), 64);
+    const size_t lds = prefilter
+        ? (size_t)prefilter_image_dw((int)a.pssm->m, (int)K) * 4
+        : std::max<size_t>(K * table_stride((int)M, a.pssm->wide) * sizeof(float), 64);
     if (lds > 60 * 1024)
         return p;
     // The fused kernels write nothing, so they are LDS/VALU-bound and prefer long
@@ -370,15 +385,13 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
     cap = std::min(cap, total_cells + 64);
     (void)max_cells;
     for (int attempt = 0; attempt < 3; ++attempt) {
-        // layout: [count u64][pad to 16][flat u64 x cap][value f32 x cap][job u32 x cap]
-        const size_t bytes = 16 + cap * 8 + cap * 4 + cap * 4;
+        // layout: [count u64][pad to 16][HitRecord x cap]
+        const size_t bytes = 16 + cap * sizeof(HitRecord);
         LM_TRY(ctx->scratch.reserve(bytes));
         char *base = static_cast<char *>(ctx->scratch.ptr);
         FusedOut fo{};
         fo.hit_count = reinterpret_cast<unsigned long long *>(base);
-        fo.hit_flat = reinterpret_cast<unsigned long long *>(base + 16);
-        fo.hit_value = reinterpret_cast<float *>(base + 16 + cap * 8);
-        fo.hit_job = reinterpret_cast<unsigned *>(base + 16 + cap * 12);
+        fo.hits = reinterpret_cast<HitRecord *>(base + 16);
         fo.hit_capacity = cap;
         LM_HIP_TRY(hipMemsetAsync(base, 0, 16, ctx->stream));
         const bool two_streams = n > 1;
@@ -386,10 +399,25 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
             LM_TRY(batch_fork(ctx));
         for (size_t i = 0; i < n; ++i) {
             const ScoreArgs &a = jobs[i];
-            const C32Plan p = plan_c32(ctx, a, false);
             hipStream_t st = (two_streams && (i & 1)) ? ctx->aux_stream : ctx->stream;
             fo.threshold = ts[i];
-            fo.job_id = (unsigned)i;
+            fo.job_key = (unsigned long long)i << 40;
+            // discrete prefilter (score_prefilter.hpp) when a sound one exists and the
+            // threshold maps into its 16-bit range; exact f32 kernel otherwise
+            if (a.pssm->has_prefilter && ctx->use_prefilter && std::isfinite(ts[i])) {
+                const C32Plan pp = plan_c32(ctx, a, false, true);
+                const double scaled = std::floor(((double)ts[i] - a.pssm->pre_offset) / a.pssm->pre_factor) -
+                                      std::ceil(a.pssm->pre_emax / a.pssm->pre_factor) - 1.0;
+                if (pp.ok && scaled >= 1.0) {
+                    const unsigned td = scaled > 65535.0 ? 65535u : (unsigned)scaled;
+                    PrefilterLauncher fn = score_c32_prefilter_lookup((int)a.pssm->m);
+                    ctx->last_kernel = "score_c32_prefilter";
+                    LM_HIP_TRY(fn(pp.grid, pp.lds, st, a.d_seq, a.pssm->d_image, (int)a.pssm->k,
+                                  a.row_begin, a.row_end, pp.T, pp.nstreams, td, fo));
+                    continue;
+                }
+            }
+            const C32Plan p = plan_c32(ctx, a, false);
             if (p.ok) {
                 ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_THRESHOLD, false, a.pssm->wide);
                 ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_THRESHOLD);
@@ -412,28 +440,58 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
             cap = count + count / 8 + 64;
             continue;
         }
-        std::vector<unsigned long long> f(count);
-        std::vector<float> v(count);
-        std::vector<unsigned> job(count);
+        // one contiguous read-back, through pinned memory when it fits
+        std::vector<HitRecord> hits(count);
         if (count) {
-            LM_HIP_TRY(hipMemcpyAsync(f.data(), fo.hit_flat, count * 8, hipMemcpyDeviceToHost, ctx->stream));
-            LM_HIP_TRY(hipMemcpyAsync(v.data(), fo.hit_value, count * 4, hipMemcpyDeviceToHost, ctx->stream));
-            LM_HIP_TRY(hipMemcpyAsync(job.data(), fo.hit_job, count * 4, hipMemcpyDeviceToHost, ctx->stream));
+            const size_t nbytes = count * sizeof(HitRecord);
+            void *stage = nbytes <= kPinnedBytes ? ctx->pinned : static_cast<void *>(hits.data());
+            LM_HIP_TRY(hipMemcpyAsync(stage, fo.hits, nbytes, hipMemcpyDeviceToHost, ctx->stream));
             LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (stage == ctx->pinned)
+                memcpy(hits.data(), ctx->pinned, nbytes);
         }
-        // (job, flat) packed in one 64-bit key: flat < rows * cols < 2^40 for anything
-        // that fits in 288 GB, jobs < 2^24
-        struct Hit { unsigned long long key; float value; };
-        std::vector<Hit> hits(count);
+        // ascending key = job, then row-major order (pli/mod.rs:212-218): counting sort
+        // by job, then each job's hits are sorted independently (in parallel for big lists)
+        std::vector<size_t> start(n + 1, 0);
         for (size_t h = 0; h < count; ++h)
-            hits[h] = Hit{((unsigned long long)job[h] << 40) | f[h], v[h]};
-        std::sort(hits.begin(), hits.end(), [](const Hit &x, const Hit &y) { return x.key < y.key; });
-        for (size_t h = 0; h < count; ++h) {
-            if (h && hits[h].key == hits[h - 1].key)
-                continue;  // duplicate from the shifted last stream
-            const size_t j = (size_t)(hits[h].key >> 40);
-            (*flat)[j].push_back(hits[h].key & ((1ull << 40) - 1));
-            (*values)[j].push_back(hits[h].value);
+            ++start[(size_t)(hits[h].key >> 40) + 1];
+        for (size_t j = 0; j < n; ++j)
+            start[j + 1] += start[j];
+        std::vector<HitRecord> sorted(count);
+        {
+            std::vector<size_t> fill(start.begin(), start.end() - 1);
+            for (size_t h = 0; h < count; ++h)
+                sorted[fill[(size_t)(hits[h].key >> 40)]++] = hits[h];
+        }
+        auto finish_job = [&](size_t j) {
+            HitRecord *lo = sorted.data() + start[j], *hi = sorted.data() + start[j + 1];
+            std::sort(lo, hi, [](const HitRecord &x, const HitRecord &y) { return x.key < y.key; });
+            std::vector<unsigned long long> &fl = (*flat)[j];
+            std::vector<float> &vl = (*values)[j];
+            fl.reserve(hi - lo);
+            vl.reserve(hi - lo);
+            for (HitRecord *r = lo; r != hi; ++r) {
+                if (r != lo && r->key == (r - 1)->key)
+                    continue;  // duplicate from the shifted last stream
+                fl.push_back(r->key & ((1ull << 40) - 1));
+                vl.push_back(r->value);
+            }
+        };
+        const unsigned nthreads =
+            count > (1u << 18) ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1u;
+        if (nthreads <= 1) {
+            for (size_t j = 0; j < n; ++j)
+                finish_job(j);
+        } else {
+            std::atomic<size_t> next{0};
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nthreads; ++t)
+                pool.emplace_back([&] {
+                    for (size_t j = next.fetch_add(1); j < n; j = next.fetch_add(1))
+                        finish_job(j);
+                });
+            for (auto &th : pool)
+                th.join();
         }
         return LM_HIP_OK;
     }

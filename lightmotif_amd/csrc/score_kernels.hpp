@@ -60,16 +60,22 @@ constexpr int table_stride(int m, bool wide = false)
 
 enum : int { MODE_STORE = 0, MODE_ARGMAX = 1, MODE_THRESHOLD = 2 };
 
+// One above-threshold cell: key = (job << 40) | flat index (row * cols + col).  Flat
+// indices stay below 2^40 for anything that fits in 288 GB of HBM.
+struct __attribute__((aligned(16))) HitRecord {
+    unsigned long long key;
+    float value;
+    unsigned pad;
+};
+
 struct FusedOut {
     // MODE_ARGMAX: one record per block
     ArgmaxRecord *block_best;
     // MODE_THRESHOLD
     float threshold;
     unsigned long long *hit_count;  // device counter
-    unsigned long long *hit_flat;   // capacity entries
-    float *hit_value;
-    unsigned *hit_job;              // batch scans: which job (motif) the hit belongs to
-    unsigned job_id;
+    HitRecord *hits;                // hit_capacity entries
+    unsigned long long job_key;     // batch scans: (job index << 40), OR-ed into the key
     unsigned long long hit_capacity;
 };
 
@@ -119,9 +125,11 @@ __device__ __forceinline__ void record_hit(const FusedOut &fo, unsigned long lon
 {
     const unsigned long long slot_i = atomicAdd(fo.hit_count, 1ull);
     if (slot_i < fo.hit_capacity) {
-        fo.hit_flat[slot_i] = flat;
-        fo.hit_value[slot_i] = score;
-        fo.hit_job[slot_i] = fo.job_id;
+        HitRecord r;
+        r.key = fo.job_key | flat;
+        r.value = score;
+        r.pad = 0;
+        fo.hits[slot_i] = r;  // one 16-byte store
     }
 }
 

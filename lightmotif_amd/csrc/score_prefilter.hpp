@@ -1,0 +1,226 @@
+// score_prefilter.hpp -- fused score+threshold with a packed 16-bit discrete prefilter.
+//
+// The reference's Scanner (lightmotif/src/scan.rs:169-198) does not score in f32
+// first: it scores a *discretised*, over-estimating matrix (DiscreteMatrix,
+// pwm/mod.rs:665-696: weights rounded UP, threshold rounded DOWN), keeps the
+// positions whose discrete score reaches the discrete threshold, and re-scores only
+// those exactly (`score_position`, scan.rs:187-190).  The hit set is therefore exactly
+// `{i : f32 score(i) >= t}`, whatever the discretisation.  This kernel is the MI355X
+// form of that idea:
+//
+//   * weights are u16 (the reference uses u8 for AVX2's byte shuffles; 16 bits keep
+//     the false-positive rate negligible and cannot overflow: sum <= 65000 + M);
+//   * two accumulators share one VGPR and are advanced by ONE v_pk_add_u16, and a
+//     symbol's whole column is M*2 bytes of LDS instead of M*4 -> half the LDS
+//     traffic and half the adds of the f32 kernel, which is LDS-bound;
+//   * candidates are re-scored with the exact f32 table by the same out-of-line
+//     `rescan_rows` the f32 fused kernel uses, so results are bit-identical to it.
+//
+// Soundness (no false negatives): with P' = P where finite and the row minimum where
+// P = -inf, off_j = min_s P'[j][s], O = sum off_j, factor = (sum_j max_s P'[j][s] - O)
+// / 65000, d[j][s] = ceil((P'[j][s] - off_j) / factor), an f32 score S >= t implies
+// sum d >= floor((t - O) / factor) - ceil(E / factor) where E bounds the rounding error
+// of the M sequential f32 adds (host side, api.hip: build_prefilter).
+//
+// Rotating accumulators as in score_c32, with the motif padded to an EVEN length MP by
+// a leading all-zero row (SHIFT = MP - M): slot pair i = outputs (2i, 2i+1) mod MP.
+// At step k the pair needs the weights (d[j], d[j-1]) with j = (k - 2i) mod MP, which
+// sit in one dword of one of two pre-arranged LDS layouts chosen by the parity of k:
+//   layout EVEN (k even): dword m = (lo d[2m],   hi d[2m-1 mod MP])
+//   layout ODD  (k odd) : dword m = (lo d[2m+1], hi d[2m])
+#pragma once
+
+#include "score_kernels.hpp"
+
+namespace lm {
+
+constexpr int prefilter_mp(int m) { return (m + 1) / 2 * 2; }
+// dwords per symbol row of one discrete layout: 4 * odd >= MP / 2 (conflict-free b128)
+constexpr int prefilter_stride_dw(int m) { return 4 * (((prefilter_mp(m) / 2 + 3) / 4) | 1); }
+// total dwords of the LDS image: exact f32 table | layout EVEN | layout ODD
+constexpr int prefilter_image_dw(int m, int k)
+{
+    return k * table_stride(m) + 2 * k * prefilter_stride_dw(m);
+}
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pk_add_u16(unsigned a, unsigned b)
+{
+    const u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(unsigned, (u16x2)(x + y));
+}
+
+template <int M, int PF, int PHASE>
+__device__ __forceinline__ void prefilter_group(unsigned (&acc2)[prefilter_mp(M) / 2],
+                                                unsigned (&sym)[prefilter_mp(M)],
+                                                const uint8_t *__restrict__ sp,
+                                                const char *__restrict__ tab_even,
+                                                const char *__restrict__ tab_odd,
+                                                const unsigned td, unsigned &flag)
+{
+    constexpr int MP = prefilter_mp(M);
+    constexpr int NP = MP / 2;
+    constexpr int NV = (NP + 3) / 4;
+    constexpr unsigned DSB = prefilter_stride_dw(M) * 4;
+#pragma unroll
+    for (int k = 0; k < MP; ++k) {
+        if (PF > 0) {
+            if (PHASE != PHASE_LAST || k + PF < MP)
+                sym[(k + PF) % MP] = sp[(k + PF) * 32];
+        } else {
+            sym[k] = sp[k * 32];
+        }
+        const char *row = static_cast<const char *>(__builtin_assume_aligned(
+            ((k & 1) ? tab_odd : tab_even) + __umul24(sym[k], DSB), 16));
+        unsigned w2[NV * 4];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(row + 16 * q);
+            w2[4 * q + 0] = v.x;
+            w2[4 * q + 1] = v.y;
+            w2[4 * q + 2] = v.z;
+            w2[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int j_lo = (k - 2 * i + 2 * MP) % MP;  // weight row of slot 2i at this step
+            acc2[i] = pk_add_u16(acc2[i], w2[j_lo / 2]);
+        }
+        // slot (k+1) mod MP received its last weight: compare, then clear it for the
+        // output that starts in it at the next step
+        const int sc = (k + 1) % MP;
+        const unsigned v = (sc & 1) ? (acc2[sc / 2] >> 16) : (acc2[sc / 2] & 0xffffu);
+        if (PHASE != PHASE_FIRST || k == MP - 1) {
+            if (v >= td)
+                flag = 1;
+        }
+        acc2[sc / 2] &= (sc & 1) ? 0x0000ffffu : 0xffff0000u;
+    }
+}
+
+// Same geometry as score_c32<M, MODE_THRESHOLD> with M replaced by MP: every stream
+// sweeps T = q*MP + 1 outputs in (q+1) groups of MP steps.  `image` = the LDS image
+// described above; `td` = discrete threshold.
+template <int M, int PF = LM_SCORE_PF>
+__global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter(
+    const uint8_t *__restrict__ seq, const unsigned *__restrict__ image, const int K,
+    const unsigned long long row_begin, const unsigned long long row_end,
+    const unsigned long long T, const unsigned long long nstreams, const unsigned td,
+    const FusedOut fo)
+{
+    constexpr int MP = prefilter_mp(M);
+    constexpr int SHIFT = MP - M;
+    constexpr int NP = MP / 2;
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    {
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
+        const uint4 *src = reinterpret_cast<const uint4 *>(image);
+        const int n4 = prefilter_image_dw(M, K) / 4;
+        for (int i = threadIdx.x; i < n4; i += kBlock)
+            dst[i] = src[i];
+    }
+    __syncthreads();
+    const float *tabf = reinterpret_cast<const float *>(lds_raw);
+    const char *tab_even = lds_raw + (size_t)K * table_stride(M) * 4;
+    const char *tab_odd = tab_even + (size_t)K * prefilter_stride_dw(M) * 4;
+
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 31;
+    unsigned long long stream =
+        ((unsigned long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    if (stream >= nstreams)
+        stream = nstreams - 1;
+    unsigned long long o0 = row_begin + stream * T;
+    if (o0 + T > row_end)
+        o0 = row_end - T;
+
+    // padded output o' = o - SHIFT covers input rows o' .. o'+MP-1; its first row carries
+    // the all-zero weight row, so when o0 == 0 that (non-existent) row is never loaded
+    const uint8_t *sp = seq + (long long)(o0 - SHIFT) * 32 + col;
+    constexpr int PFE = PF < MP ? PF : MP - 1;
+    unsigned acc2[NP];
+    unsigned sym[MP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+        acc2[i] = 0;
+#pragma unroll
+    for (int j = 0; j < MP; ++j)
+        sym[j] = 0;
+    static_assert(PFE >= 1, "the prefilter kernel needs a look-ahead of at least one step");
+#pragma unroll
+    for (int j = 0; j < PFE; ++j) {
+        if (j == 0 && SHIFT) {
+            if (o0 > 0)  // row -1 does not exist; its weight row is all zero anyway
+                sym[0] = sp[0];
+        } else {
+            sym[j] = sp[j * 32];
+        }
+    }
+
+    const unsigned long long ngroups = (T + MP - 1) / MP;  // exact: T = q*MP + 1, >= 2
+    unsigned long long hit_groups = 0;
+    const unsigned long long G = (ngroups + 63) / 64;  // groups per bit
+    unsigned long long gbit = 1, gleft = G;
+    unsigned flag = 0;
+    auto note_group = [&]() {
+        hit_groups |= flag ? gbit : 0ull;
+        flag = 0;
+        if (--gleft == 0) {
+            gleft = G;
+            gbit <<= 1;
+        }
+    };
+
+    prefilter_group<M, PFE, PHASE_FIRST>(acc2, sym, sp, tab_even, tab_odd, td, flag);
+    note_group();
+    for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
+        sp += MP * 32;
+        prefilter_group<M, PFE, PHASE_MAIN>(acc2, sym, sp, tab_even, tab_odd, td, flag);
+        note_group();
+    }
+    sp += MP * 32;
+    prefilter_group<M, PFE, PHASE_LAST>(acc2, sym, sp, tab_even, tab_odd, td, flag);
+    note_group();
+
+    // exact re-scoring of the flagged groups (outputs are counted from the stream's
+    // first TRUE output row; group 0 completes output 0, group g >= 1 outputs
+    // (g-1)*MP+1 .. g*MP)
+    const uint8_t *seq_col = seq + row_begin * 32 + col;
+    const long long first_row = (long long)(o0 - row_begin);
+    while (hit_groups) {
+        const int bit = __ffsll((long long)hit_groups) - 1;
+        hit_groups &= hit_groups - 1;
+        const unsigned long long g0 = (unsigned long long)bit * G;
+        unsigned long long g1 = g0 + G;
+        if (g1 > ngroups)
+            g1 = ngroups;
+        const long long i0 = g0 == 0 ? 0 : (long long)((g0 - 1) * MP + 1);
+        long long i1 = (long long)((g1 - 1) * MP + 1);
+        if (i1 > (long long)T)
+            i1 = (long long)T;
+        rescan_rows<M, 0>(seq_col, tabf, first_row + i0, first_row + i1, col, fo);
+    }
+}
+
+using PrefilterLauncher = hipError_t (*)(dim3 grid, size_t lds_bytes, hipStream_t stream,
+                                         const uint8_t *seq, const unsigned *image, int K,
+                                         unsigned long long row_begin, unsigned long long row_end,
+                                         unsigned long long T, unsigned long long nstreams,
+                                         unsigned td, FusedOut fo);
+
+template <int M>
+hipError_t score_c32_prefilter_launch(dim3 grid, size_t lds_bytes, hipStream_t stream,
+                                      const uint8_t *seq, const unsigned *image, int K,
+                                      unsigned long long row_begin, unsigned long long row_end,
+                                      unsigned long long T, unsigned long long nstreams,
+                                      unsigned td, FusedOut fo)
+{
+    hipLaunchKernelGGL((score_c32_prefilter<M>), grid, dim3(kBlock), lds_bytes, stream, seq, image,
+                       K, row_begin, row_end, T, nstreams, td, fo);
+    return hipGetLastError();
+}
+
+PrefilterLauncher score_c32_prefilter_lookup(int M);
+
+}  // namespace lm

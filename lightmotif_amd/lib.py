@@ -99,6 +99,9 @@ class Pipeline:
     def set_rows_per_stream(self, rows: int) -> None:
         check(self._L.lm_hip_ctx_set_rows_per_stream(self._h, rows))
 
+    def set_prefilter(self, enabled: bool) -> None:
+        check(self._L.lm_hip_ctx_set_prefilter(self._h, int(enabled)))
+
     def set_xcd_remap(self, enabled: bool) -> None:
         check(self._L.lm_hip_ctx_set_xcd_remap(self._h, int(enabled)))
 

@@ -363,3 +363,65 @@ def test_batch_scan_matches_per_motif_oracle(pli):
     bare.configure_wrap(10)
     with pytest.raises(lm.LightmotifHipError, match="not enough wrapping rows"):
         pli.scan_argmax_batch(pssms, bare)
+
+
+# ---- discrete prefilter of the fused threshold scan (score_prefilter.hpp) -----------------------
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 7, 8, 15, 20, 21, 33, 36])
+@pytest.mark.parametrize("kind", ["normal", "ties"])
+def test_prefilter_and_exact_fused_threshold_agree(pli, m, kind):
+    """The packed 16-bit prefilter may only over-select; after exact re-scoring the hit
+    list must equal the f32 kernel's and the oracle's, for even and odd motif lengths."""
+    rng = np.random.default_rng(7000 + m)
+    length = 250_003
+    enc = rng.integers(0, 4, length, dtype=np.uint8)
+    enc[rng.random(length) < 0.01] = 4                       # N -> -inf weights in the window
+    p = random_pssm(rng, m, 5, kind)
+    ref = co.stripe(enc, 32, 5)
+    co.configure_wrap(ref, max(m - 1, 0))
+    want, _ = co.score_rows(ref, p)
+    finite = np.sort(want[:, :32][np.isfinite(want[:, :32])])
+    seq = pli.stripe(lm.EncodedSequence(enc), 32)
+    seq.configure_wrap(max(m - 1, 0))
+    pssm = lm.ScoringMatrix(p)
+    # thresholds: deep tail, an exact score value (>= must include ties), mid-range, below everything
+    for t in (float(finite[-50]), float(finite[-1]), float(finite[len(finite) // 2]), float(finite[0]) - 1.0,
+              float(finite[-1]) + 1.0):
+        wrc = [tuple(map(int, rc)) for rc in co.threshold(want, 32, t)]
+        got = {}
+        for on in (True, False):
+            pli.set_prefilter(on)
+            try:
+                rc, val = pli.score_threshold(pssm, seq, t)
+            finally:
+                pli.set_prefilter(True)
+            got[on] = (rc, val, pli.last_kernel)
+            assert rc == wrc, (m, kind, t, on, pli.last_kernel)
+            assert np.array_equal(bits(val), bits([want[r, c] for r, c in wrc]))
+        assert got[False][2].startswith("score_c32<")
+    # with a meaningful threshold the prefilter kernel is the one that runs
+    pli.score_threshold(pssm, seq, float(finite[-50]))
+    if m >= 2:
+        assert pli.last_kernel == "score_c32_prefilter"
+
+
+def test_prefilter_is_skipped_when_it_cannot_be_sound(pli):
+    rng = np.random.default_rng(99)
+    enc = rng.integers(0, 4, 100_000, dtype=np.uint8)
+    seq = pli.stripe(lm.EncodedSequence(enc), 32)
+    seq.configure_wrap(9)
+    ref = co.stripe(enc, 32, 5)
+    co.configure_wrap(ref, 9)
+    for poison in (np.nan, np.inf):
+        p = random_pssm(rng, 10, 5)
+        p[3, 2] = poison                                      # NaN / +inf weights: no discrete bound
+        want, _ = co.score_rows(ref, p)
+        rc, _ = pli.score_threshold(lm.ScoringMatrix(p), seq, 5.0)
+        assert pli.last_kernel.startswith("score_c32<10,2>")
+        assert rc == [tuple(map(int, x)) for x in co.threshold(want, 32, 5.0)]
+    p = random_pssm(rng, 10, 5)
+    want, _ = co.score_rows(ref, p)
+    rc, _ = pli.score_threshold(lm.ScoringMatrix(p), seq, float("-inf"))   # selects everything non-NaN
+    assert pli.last_kernel.startswith("score_c32<10,2>")
+    assert len(rc) == want.shape[0] * 32
