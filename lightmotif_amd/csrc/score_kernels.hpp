@@ -172,17 +172,24 @@ __device__ __forceinline__ void lds_fetch_column(float (&w)[4 * ((M + 3) / 4)],
             w[2 * q + 1] = v.y;
         }
     } else {
-        constexpr int NV = (M + 3) / 4;
+        // M floats: whole 16-byte reads, then an 8- and/or 4-byte read for the rest
         const char *row =
             static_cast<const char *>(__builtin_assume_aligned(tab + __umul24(s, TSB), 16));
 #pragma unroll
-        for (int q = 0; q < NV; ++q) {
+        for (int q = 0; q < M / 4; ++q) {
             const float4 v = *reinterpret_cast<const float4 *>(row + 16 * q);
             w[4 * q + 0] = v.x;
             w[4 * q + 1] = v.y;
             w[4 * q + 2] = v.z;
             w[4 * q + 3] = v.w;
         }
+        if (M % 4 >= 2) {
+            const float2 v = *reinterpret_cast<const float2 *>(row + 16 * (M / 4));
+            w[4 * (M / 4) + 0] = v.x;
+            w[4 * (M / 4) + 1] = v.y;
+        }
+        if (M % 2 == 1)
+            w[M - 1] = *reinterpret_cast<const float *>(row + 4 * (M - 1));
     }
 }
 

@@ -73,15 +73,23 @@ __device__ __forceinline__ void prefilter_group(unsigned (&acc2)[prefilter_mp(M)
         }
         const char *row = static_cast<const char *>(__builtin_assume_aligned(
             ((k & 1) ? tab_odd : tab_even) + __umul24(sym[k], DSB), 16));
+        // NP dwords: whole 16-byte reads, then an 8- and/or 4-byte read for the rest
         unsigned w2[NV * 4];
 #pragma unroll
-        for (int q = 0; q < NV; ++q) {
+        for (int q = 0; q < NP / 4; ++q) {
             const uint4 v = *reinterpret_cast<const uint4 *>(row + 16 * q);
             w2[4 * q + 0] = v.x;
             w2[4 * q + 1] = v.y;
             w2[4 * q + 2] = v.z;
             w2[4 * q + 3] = v.w;
         }
+        if (NP % 4 >= 2) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(row + 16 * (NP / 4));
+            w2[4 * (NP / 4) + 0] = v.x;
+            w2[4 * (NP / 4) + 1] = v.y;
+        }
+        if (NP % 2 == 1)
+            w2[NP - 1] = *reinterpret_cast<const unsigned *>(row + 4 * (NP - 1));
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int j_lo = (k - 2 * i + 2 * MP) % MP;  // weight row of slot 2i at this step
