@@ -561,28 +561,14 @@ int lm_hip_score_threshold_f32_dptr(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, co
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard guard(ctx->device);
     ScoreArgs a{pssm, d_seq, seq_stride, cols, row_begin, row_end, nullptr, 0};
-    std::vector<unsigned long long> flat;
-    std::vector<float> vals;
-    LM_TRY(launch_score_threshold(ctx, a, t, &flat, &vals));
-    if (flat.empty())
-        return LM_HIP_OK;
-    lm_hip_coords *c = static_cast<lm_hip_coords *>(malloc(flat.size() * sizeof(lm_hip_coords)));
-    float *v = values ? static_cast<float *>(malloc(flat.size() * sizeof(float))) : nullptr;
-    if (!c || (values && !v)) {
-        free(c);
-        free(v);
-        return fail(LM_HIP_ERR_OOM, "score_threshold: cannot allocate %zu hits", flat.size());
-    }
-    for (size_t i = 0; i < flat.size(); ++i) {
-        c[i].row = (size_t)(flat[i] / cols);
-        c[i].col = (size_t)(flat[i] % cols);
-        if (v)
-            v[i] = vals[i];
-    }
-    *coords = c;
+    HitOutput ho;
+    LM_TRY(launch_score_threshold_batch(ctx, &a, &t, 1, HitKeys::RowMajor, &ho));
+    *coords = ho.coords;
     if (values)
-        *values = v;
-    *n = flat.size();
+        *values = ho.values;
+    else
+        free(ho.values);
+    *n = ho.total;
     return LM_HIP_OK;
 }
 
@@ -662,38 +648,21 @@ int lm_hip_scan_threshold_batch(lm_hip_ctx *ctx, const lm_hip_pssm *const *pssms
     }
     if (live.empty())
         return LM_HIP_OK;
-    std::vector<std::vector<unsigned long long>> flat;
-    std::vector<std::vector<float>> vals;
+    HitOutput ho;
     {
         std::lock_guard<std::mutex> lock(ctx->mu);
         DeviceGuard guard(ctx->device);
-        LM_TRY(launch_score_threshold_batch(ctx, live.data(), live_t.data(), live.size(), &flat, &vals));
+        LM_TRY(launch_score_threshold_batch(ctx, live.data(), live_t.data(), live.size(),
+                                            HitKeys::RowMajor, &ho));
     }
-    size_t total = 0;
-    for (size_t k = 0; k < live.size(); ++k) {
-        counts[live_idx[k]] = flat[k].size();
-        total += flat[k].size();
-    }
-    if (total == 0)
-        return LM_HIP_OK;
-    lm_hip_coords *c = static_cast<lm_hip_coords *>(malloc(total * sizeof(lm_hip_coords)));
-    float *v = values ? static_cast<float *>(malloc(total * sizeof(float))) : nullptr;
-    if (!c || (values && !v)) {
-        free(c);
-        free(v);
-        return fail(LM_HIP_ERR_OOM, "scan_threshold_batch: cannot allocate %zu hits", total);
-    }
-    size_t pos = 0;
+    // live jobs are in caller order, so the concatenated list already is the output
     for (size_t k = 0; k < live.size(); ++k)
-        for (size_t h = 0; h < flat[k].size(); ++h, ++pos) {
-            c[pos].row = (size_t)(flat[k][h] / seq->cols);
-            c[pos].col = (size_t)(flat[k][h] % seq->cols);
-            if (v)
-                v[pos] = vals[k][h];
-        }
-    *coords = c;
+        counts[live_idx[k]] = ho.job_start[k + 1] - ho.job_start[k];
+    *coords = ho.coords;
     if (values)
-        *values = v;
+        *values = ho.values;
+    else
+        free(ho.values);
     return LM_HIP_OK;
 }
 
@@ -708,32 +677,26 @@ int lm_hip_scan_f32(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *
                             seq->rows));
     if (seq->length < pssm->m || seq->rows == 0)
         return LM_HIP_OK;
-    std::vector<unsigned long long> flat;
-    std::vector<float> vals;
+    HitOutput ho;
     {
         std::lock_guard<std::mutex> lock(ctx->mu);
         DeviceGuard guard(ctx->device);
         ScoreArgs a{pssm, seq->d_data, seq->stride, seq->cols, 0, seq->rows, nullptr, 0};
-        LM_TRY(launch_score_threshold(ctx, a, threshold, &flat, &vals));
+        // keys are sequence positions col * rows + row (scan.rs:185, scores.rs:155-157),
+        // so the list comes back in ascending position
+        LM_TRY(launch_score_threshold_batch(ctx, &a, &threshold, 1, HitKeys::Position, &ho));
     }
-    std::vector<lm_hip_hit> out;
-    out.reserve(flat.size());
-    for (size_t i = 0; i < flat.size(); ++i) {
-        const size_t row = (size_t)(flat[i] / seq->cols), col = (size_t)(flat[i] % seq->cols);
-        const size_t pos = col * seq->rows + row;        // scan.rs:185 / scores.rs:155-157
-        if (pos + pssm->m <= seq->length)                // scan.rs:186
-            out.push_back(lm_hip_hit{pos, vals[i]});
-    }
-    if (out.empty())
+    // scan.rs:186: only positions where the whole motif fits; the others are cells of
+    // the padded tail, i.e. the largest positions = the end of the list
+    size_t keep = ho.total;
+    while (keep && ho.hits[keep - 1].position + pssm->m > seq->length)
+        --keep;
+    if (keep == 0) {
+        ho.release();
         return LM_HIP_OK;
-    std::sort(out.begin(), out.end(),
-              [](const lm_hip_hit &x, const lm_hip_hit &y) { return x.position < y.position; });
-    lm_hip_hit *h = static_cast<lm_hip_hit *>(malloc(out.size() * sizeof(lm_hip_hit)));
-    if (!h)
-        return fail(LM_HIP_ERR_OOM, "scan: cannot allocate %zu hits", out.size());
-    memcpy(h, out.data(), out.size() * sizeof(lm_hip_hit));
-    *hits = h;
-    *n = out.size();
+    }
+    *hits = ho.hits;
+    *n = keep;
     return LM_HIP_OK;
 }
 
@@ -1009,6 +972,10 @@ static int scores_resize(lm_hip_ctx *ctx, lm_hip_scores *s, size_t rows, size_t 
         s->capacity_rows = 0;
         LM_HIP_TRY(hipMalloc(&s->d_data, rows * s->stride * sizeof(float)));
         s->capacity_rows = rows;
+        // alignment padding past `cols` is never written by the kernels and reads as
+        // zero in the reference (DenseMatrix rows are default-initialised, dense.rs:144-147)
+        if (s->stride != s->cols)
+            LM_HIP_TRY(hipMemsetAsync(s->d_data, 0, rows * s->stride * sizeof(float), ctx->stream));
     }
     s->rows = rows;
     s->max_index = max_index;
@@ -1096,8 +1063,14 @@ int lm_hip_score_f32(const uint8_t *seq, size_t seq_rows_total, size_t seq_strid
                 ScoreArgs a{p, d_seq, seq_stride, cols, 0, nrows_out, d_out, out_stride};
                 st = launch_score_store(ctx, a);
                 if (st == LM_HIP_OK) {
-                    e = hipMemcpyAsync(out, d_out, nrows_out * out_stride * sizeof(float),
-                                       hipMemcpyDeviceToHost, ctx->stream);
+                    // only the `cols` scored cells of each row: the caller's alignment
+                    // padding is left as it was, like pli/mod.rs:103 does
+                    e = out_stride == cols
+                            ? hipMemcpyAsync(out, d_out, nrows_out * out_stride * sizeof(float),
+                                             hipMemcpyDeviceToHost, ctx->stream)
+                            : hipMemcpy2DAsync(out, out_stride * sizeof(float), d_out,
+                                               out_stride * sizeof(float), cols * sizeof(float),
+                                               nrows_out, hipMemcpyDeviceToHost, ctx->stream);
                     if (e == hipSuccess)
                         e = hipStreamSynchronize(ctx->stream);
                     if (e != hipSuccess)

@@ -1,0 +1,243 @@
+// hits.hip -- puts the hit list of the fused threshold kernels in key order ON THE DEVICE.
+//
+// The fused kernels append (key, score) records with atomics, i.e. in no particular
+// order, while the reference's Threshold pushes cells in row-major order
+// (pli/mod.rs:212-218) and its Scanner yields positions in sequence order.  Keys are
+// unique (every cell is reported once) and live in a bounded universe --
+// key = (job << 40) | low, low < cells of the job -- so ordering is a bucket sort:
+//
+//   1. hits_bucket_count    bucket = job * nb + (low >> shift); histogram with atomics
+//   2. exclusive scan of the histogram (launch_scan_u32, reduce.hip)
+//   3. hits_bucket_scatter  records grouped by bucket (any order inside a bucket)
+//   4. hits_rank_emit       rank of a record inside its bucket = number of smaller
+//                           keys there; the final slot is bucket start + rank, written
+//                           directly in the caller's output format
+//
+// `shift` is chosen from the hit density so that a bucket holds ~8 records on
+// average; a bucket never holds more records than it has cells (2^shift), which bounds
+// step 4 at 8 x (cells of the batch) comparisons whatever the distribution of hits.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "score_kernels.hpp"
+
+namespace lm {
+
+namespace {
+
+constexpr unsigned long long kLowMask = (1ull << 40) - 1;
+
+__device__ __forceinline__ unsigned long long bucket_of(unsigned long long key, int shift,
+                                                        unsigned long long nb)
+{
+    return (key >> 40) * nb + ((key & kLowMask) >> shift);
+}
+
+__device__ __forceinline__ unsigned long long bucket_start(
+    unsigned long long b, unsigned long long nbuckets, unsigned long long count,
+    const unsigned long long *__restrict__ offsets, const unsigned long long *__restrict__ tiles)
+{
+    return b < nbuckets ? tiles[b / kScanTile] + offsets[b] : count;
+}
+
+__global__ __launch_bounds__(kBlock) void hits_bucket_count(const HitRecord *__restrict__ hits,
+                                                            const unsigned long long count,
+                                                            const int shift,
+                                                            const unsigned long long nb,
+                                                            unsigned *__restrict__ counts)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < count;
+         i += (unsigned long long)gridDim.x * kBlock)
+        atomicAdd(&counts[bucket_of(hits[i].key, shift, nb)], 1u);
+}
+
+__global__ __launch_bounds__(kBlock) void hits_bucket_scatter(
+    const HitRecord *__restrict__ hits, const unsigned long long count, const int shift,
+    const unsigned long long nb, const unsigned long long *__restrict__ offsets,
+    const unsigned long long *__restrict__ tiles, unsigned *__restrict__ counts,
+    HitRecord *__restrict__ grouped)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < count;
+         i += (unsigned long long)gridDim.x * kBlock) {
+        const HitRecord r = hits[i];
+        const unsigned long long b = bucket_of(r.key, shift, nb);
+        const unsigned left = atomicSub(&counts[b], 1u);  // counts down to 0
+        grouped[tiles[b / kScanTile] + offsets[b] + left - 1] = r;
+    }
+}
+
+// EMIT 0: lm_hip_coords {low / cols, low % cols} + score (Threshold, pli/mod.rs:215)
+// EMIT 1: lm_hip_hit {low, score} (Scanner: low is the sequence position)
+template <int EMIT>
+__global__ __launch_bounds__(kBlock) void hits_rank_emit(
+    const HitRecord *__restrict__ grouped, const unsigned long long count, const int shift,
+    const unsigned long long nb, const unsigned long long nbuckets,
+    const unsigned long long *__restrict__ offsets, const unsigned long long *__restrict__ tiles,
+    const unsigned long long cols, lm_hip_coords *__restrict__ coords, float *__restrict__ values,
+    lm_hip_hit *__restrict__ out_hits)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < count;
+         i += (unsigned long long)gridDim.x * kBlock) {
+        const HitRecord r = grouped[i];
+        const unsigned long long b = bucket_of(r.key, shift, nb);
+        const unsigned long long lo = bucket_start(b, nbuckets, count, offsets, tiles);
+        const unsigned long long hi = bucket_start(b + 1, nbuckets, count, offsets, tiles);
+        unsigned long long rank = 0;
+        for (unsigned long long k = lo; k < hi; ++k) {
+            const unsigned long long other = grouped[k].key;
+            rank += (other < r.key) || (other == r.key && k < i);
+        }
+        const unsigned long long pos = lo + rank;
+        const unsigned long long low = r.key & kLowMask;
+        if (EMIT == 0) {
+            lm_hip_coords c;
+            c.row = low / cols;
+            c.col = low - c.row * cols;
+            coords[pos] = c;
+            values[pos] = r.value;
+        } else {
+            lm_hip_hit h;
+            h.position = low;
+            h.score = r.value;
+            out_hits[pos] = h;
+        }
+    }
+}
+
+__global__ void hits_job_starts(const unsigned long long njobs, const unsigned long long nb,
+                                const unsigned long long nbuckets, const unsigned long long count,
+                                const unsigned long long *__restrict__ offsets,
+                                const unsigned long long *__restrict__ tiles,
+                                unsigned long long *__restrict__ starts)
+{
+    const unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j <= njobs)
+        starts[j] = bucket_start(j * nb, nbuckets, count, offsets, tiles);
+}
+
+size_t align16(size_t x) { return (x + 15) / 16 * 16; }
+
+}  // namespace
+
+void HitOutput::release()
+{
+    free(coords);
+    free(values);
+    free(hits);
+    coords = nullptr;
+    values = nullptr;
+    hits = nullptr;
+    total = 0;
+}
+
+// `d_hits`: `count` records (in ctx->scratch) of `njobs` jobs whose keys' low parts are
+// all below `max_low`.  On success `out` owns malloc'ed host arrays in key order and
+// job_start[j] .. job_start[j + 1] delimit job j.  Uses ctx->scratch2; synchronises.
+int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, unsigned long long count, size_t njobs,
+               unsigned long long max_low, int emit, size_t cols, HitOutput *out)
+{
+    out->job_start.assign(njobs + 1, 0);
+    out->total = 0;
+    if (count == 0)
+        return LM_HIP_OK;
+    if (max_low == 0)
+        max_low = 1;
+    if (max_low > kLowMask + 1)
+        return fail(LM_HIP_ERR_CAPACITY, "fused threshold: %llu cells per job exceed the 2^40 key space",
+                    max_low);
+    // ~8 records per bucket on average; at most 2^26 buckets
+    int shift = 5;
+    {
+        const long double universe = (long double)max_low * (long double)njobs;
+        while (shift < 40 && ((long double)(1ull << shift) * (long double)count < 8.0L * universe))
+            ++shift;
+        while (shift < 40 && (((max_low - 1) >> shift) + 1) * njobs > (1ull << 26))
+            ++shift;
+    }
+    const unsigned long long nb = ((max_low - 1) >> shift) + 1;
+    const unsigned long long nbuckets = nb * njobs;
+    const unsigned long long ntiles = (nbuckets + kScanTile - 1) / kScanTile;
+
+    const size_t rec_bytes = emit == 0 ? sizeof(lm_hip_coords) : sizeof(lm_hip_hit);
+    const size_t off_grouped = 0;
+    const size_t off_counts = off_grouped + align16(count * sizeof(HitRecord));
+    const size_t off_offsets = off_counts + align16(nbuckets * 4);
+    const size_t off_tiles = off_offsets + align16(nbuckets * 8);
+    const size_t off_total = off_tiles + align16(ntiles * 8);
+    const size_t off_starts = off_total + 16;
+    const size_t off_out = off_starts + align16((njobs + 1) * 8);
+    const size_t off_values = off_out + align16(count * rec_bytes);
+    const size_t bytes = off_values + align16(count * sizeof(float));
+    LM_TRY(ctx->scratch2.reserve(bytes));
+    char *base = static_cast<char *>(ctx->scratch2.ptr);
+    HitRecord *grouped = reinterpret_cast<HitRecord *>(base + off_grouped);
+    unsigned *counts = reinterpret_cast<unsigned *>(base + off_counts);
+    unsigned long long *offsets = reinterpret_cast<unsigned long long *>(base + off_offsets);
+    unsigned long long *tiles = reinterpret_cast<unsigned long long *>(base + off_tiles);
+    unsigned long long *total = reinterpret_cast<unsigned long long *>(base + off_total);
+    unsigned long long *starts = reinterpret_cast<unsigned long long *>(base + off_starts);
+    void *d_out = base + off_out;
+    float *d_values = reinterpret_cast<float *>(base + off_values);
+
+    hipStream_t st = ctx->stream;
+    const unsigned grid = (unsigned)std::min<unsigned long long>((count + kBlock - 1) / kBlock,
+                                                                 (unsigned long long)ctx->num_cus * 32);
+    LM_HIP_TRY(hipMemsetAsync(counts, 0, nbuckets * 4, st));
+    hipLaunchKernelGGL(hits_bucket_count, dim3(grid), dim3(kBlock), 0, st, d_hits, count, shift, nb,
+                       counts);
+    LM_TRY(launch_scan_u32(ctx, counts, nbuckets, offsets, tiles, total));
+    hipLaunchKernelGGL(hits_bucket_scatter, dim3(grid), dim3(kBlock), 0, st, d_hits, count, shift, nb,
+                       offsets, tiles, counts, grouped);
+    if (emit == 0)
+        hipLaunchKernelGGL(hits_rank_emit<0>, dim3(grid), dim3(kBlock), 0, st, grouped, count, shift,
+                           nb, nbuckets, offsets, tiles, (unsigned long long)cols,
+                           static_cast<lm_hip_coords *>(d_out), d_values,
+                           static_cast<lm_hip_hit *>(nullptr));
+    else
+        hipLaunchKernelGGL(hits_rank_emit<1>, dim3(grid), dim3(kBlock), 0, st, grouped, count, shift,
+                           nb, nbuckets, offsets, tiles, (unsigned long long)cols,
+                           static_cast<lm_hip_coords *>(nullptr), static_cast<float *>(nullptr),
+                           static_cast<lm_hip_hit *>(d_out));
+    hipLaunchKernelGGL(hits_job_starts, dim3((unsigned)((njobs + 1 + 255) / 256)), dim3(256), 0, st,
+                       (unsigned long long)njobs, nb, nbuckets, count, offsets, tiles, starts);
+    LM_HIP_TRY(hipGetLastError());
+
+    void *host = malloc(count * rec_bytes);
+    float *host_values = emit == 0 ? static_cast<float *>(malloc(count * sizeof(float))) : nullptr;
+    if (!host || (emit == 0 && !host_values)) {
+        free(host);
+        free(host_values);
+        return fail(LM_HIP_ERR_OOM, "fused threshold: cannot allocate %llu hits on the host", count);
+    }
+    // job offsets: through pinned memory when they fit, else straight into the vector
+    const size_t starts_bytes = (njobs + 1) * 8;
+    void *starts_dst = starts_bytes <= kPinnedBytes ? ctx->pinned
+                                                    : static_cast<void *>(out->job_start.data());
+    static_assert(sizeof(size_t) == 8, "job offsets are read back as 64-bit values");
+    hipError_t e = hipMemcpyAsync(starts_dst, starts, starts_bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(host, d_out, count * rec_bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && host_values)
+        e = hipMemcpyAsync(host_values, d_values, count * sizeof(float), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        free(host);
+        free(host_values);
+        return fail(LM_HIP_ERR_HIP, "fused threshold: ordering the hit list failed: %s",
+                    hipGetErrorString(e));
+    }
+    if (starts_dst == ctx->pinned)
+        memcpy(out->job_start.data(), ctx->pinned, starts_bytes);
+    out->total = (size_t)count;
+    if (emit == 0) {
+        out->coords = static_cast<lm_hip_coords *>(host);
+        out->values = host_values;
+    } else {
+        out->hits = static_cast<lm_hip_hit *>(host);
+    }
+    return LM_HIP_OK;
+}
+
+}  // namespace lm

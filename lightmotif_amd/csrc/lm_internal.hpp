@@ -127,16 +127,42 @@ struct ScoreArgs {
 int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a);
 // Fused score+argmax: leaves one ArgmaxRecord at ctx->scratch (device) -> out.
 int launch_score_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, int first_cell_rule, ArgmaxRecord *out);
-// Fused score+threshold: hits as (flat index, value) sorted by flat index.
-int launch_score_threshold(lm_hip_ctx *ctx, const ScoreArgs &a, float t,
-                           std::vector<unsigned long long> *flat, std::vector<float> *values);
+// Result of a fused score+threshold batch: malloc'ed host arrays in key order (the
+// caller takes them over or calls release()); job j owns [job_start[j], job_start[j+1]).
+struct HitOutput {
+    size_t total = 0;
+    std::vector<size_t> job_start;
+    lm_hip_coords *coords = nullptr;  // HitKeys::RowMajor: (row, col) + values
+    float *values = nullptr;
+    lm_hip_hit *hits = nullptr;       // HitKeys::Position: (sequence position, score)
+    void release();
+};
 
-// Batched forms: n independent jobs, one stream synchronisation.
+// Order of the hits of one job: the reference's row-major push order
+// (pli/mod.rs:212-218), or ascending sequence position col * rows + row
+// (scores.rs:155-157) for Scanner-style output.
+enum class HitKeys { RowMajor, Position };
+
+// Fused score+threshold of n independent jobs (row indices relative to each job's
+// row_begin).  HitKeys::Position requires row_begin == 0 on every job.
+int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const float *ts, size_t n,
+                                 HitKeys keys, HitOutput *out);
+
+// Batched fused score+argmax: n independent jobs, one stream synchronisation.
 int launch_score_argmax_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
                               int first_cell_rule, ArgmaxRecord *out);
-int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const float *ts, size_t n,
-                                 std::vector<std::vector<unsigned long long>> *flat,
-                                 std::vector<std::vector<float>> *values);
+
+// hits.hip: device-side ordering of the fused kernels' hit list
+struct HitRecord;
+int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, unsigned long long count, size_t njobs,
+               unsigned long long max_low, int emit, size_t cols, HitOutput *out);
+
+// reduce.hip: exclusive scan of n u32 counts (async on ctx->stream); the offset of
+// element i is tiles[i / kScanTile] + offsets[i], *total the grand total.
+constexpr int kScanTile = 1024;
+int launch_scan_u32(lm_hip_ctx *ctx, const unsigned *counts, unsigned long long n,
+                    unsigned long long *offsets, unsigned long long *tiles,
+                    unsigned long long *total);
 
 int launch_argmax(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride,
                   size_t cols, int first_cell_rule, ArgmaxRecord *out);

@@ -182,7 +182,6 @@ __global__ __launch_bounds__(kBlock) void threshold_count(const float *__restric
 
 // Exclusive scan of `counts` in tiles of 1024: level 1 writes per-chunk offsets
 // relative to the tile and the tile totals; level 2 scans the totals.
-constexpr int kScanTile = 1024;
 
 __device__ __forceinline__ unsigned long long block_exclusive_scan_1024(unsigned long long x,
                                                                         unsigned long long *total)
@@ -297,6 +296,18 @@ __global__ __launch_bounds__(kBlock) void threshold_fill(
     }
 }
 
+int launch_scan_u32(lm_hip_ctx *ctx, const unsigned *counts, unsigned long long n,
+                    unsigned long long *offsets, unsigned long long *tiles,
+                    unsigned long long *total)
+{
+    const unsigned long long ntiles = (n + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(scan_level1, dim3((unsigned)ntiles), dim3(kScanTile), 0, ctx->stream, counts, n,
+                       offsets, tiles);
+    hipLaunchKernelGGL(scan_level2, dim3(1), dim3(kScanTile), 0, ctx->stream, tiles, ntiles, total);
+    LM_HIP_TRY(hipGetLastError());
+    return LM_HIP_OK;
+}
+
 int launch_threshold(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride,
                      size_t cols, float t, lm_hip_coords **coords, size_t *n)
 {
@@ -322,10 +333,7 @@ int launch_threshold(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t
 
     hipLaunchKernelGGL(threshold_count, dim3((unsigned)nchunks), dim3(kBlock), 0, ctx->stream,
                        d_scores, ncells, (unsigned long long)stride, (unsigned)cols, flat, t, counts);
-    hipLaunchKernelGGL(scan_level1, dim3((unsigned)ntiles), dim3(kScanTile), 0, ctx->stream, counts,
-                       nchunks, offsets, tiles);
-    hipLaunchKernelGGL(scan_level2, dim3(1), dim3(kScanTile), 0, ctx->stream, tiles, ntiles, total);
-    LM_HIP_TRY(hipGetLastError());
+    LM_TRY(launch_scan_u32(ctx, counts, nchunks, offsets, tiles, total));
     LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, total, 8, hipMemcpyDeviceToHost, ctx->stream));
     LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     const unsigned long long count = *static_cast<unsigned long long *>(ctx->pinned);

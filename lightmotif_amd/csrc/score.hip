@@ -357,33 +357,37 @@ int launch_score_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, int first_cell_rule
 
 // ---- fused threshold --------------------------------------------------------------------
 
-// Fused score+threshold of `n` jobs with ONE synchronisation: every job appends
-// (job id, flat index, score) to a shared device list; the host sorts each job's
-// hits by flat index = the reference's row-major push order (pli/mod.rs:212-218)
-// and drops the duplicates the shifted last stream may have produced.
+// Fused score+threshold of `n` jobs: every job appends (key, score) records to one
+// shared device list, key = (job << 40) | row-major cell index or sequence position;
+// hits.hip then orders the list on the device (the reference's row-major push order,
+// pli/mod.rs:212-218, or ascending position) and the result is copied straight into
+// the arrays handed to the caller.  Two synchronisations: the hit count, the result.
 int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const float *ts, size_t n,
-                                 std::vector<std::vector<unsigned long long>> *flat,
-                                 std::vector<std::vector<float>> *values)
+                                 HitKeys keys, HitOutput *out)
 {
-    flat->assign(n, {});
-    values->assign(n, {});
+    out->job_start.assign(n + 1, 0);
+    out->total = 0;
     if (n == 0)
         return LM_HIP_OK;
-    unsigned long long max_cells = 0;
-    for (size_t i = 0; i < n; ++i)
-        max_cells = std::max<unsigned long long>(
-            max_cells, (unsigned long long)(jobs[i].row_end - jobs[i].row_begin) * jobs[i].cols);
+    if (n > (1u << 23))
+        return fail(LM_HIP_ERR_CAPACITY, "fused threshold: at most 2^23 jobs per batch");
+    unsigned long long max_low = 0, total_cells = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned long long rows = jobs[i].row_end - jobs[i].row_begin;
+        if (keys == HitKeys::Position && jobs[i].row_begin != 0)
+            return fail(LM_HIP_ERR_BAD_ARGS, "fused threshold: position keys need row_begin == 0");
+        if (jobs[i].cols != jobs[0].cols)
+            return fail(LM_HIP_ERR_BAD_ARGS, "fused threshold: the jobs of a batch must share `cols`");
+        max_low = std::max(max_low, rows * jobs[i].cols);
+        total_cells += rows * jobs[i].cols;
+    }
     // Hit-list capacity: room for a 1.2e-4 hit rate over the whole batch (the CLI's
     // default p-value is 1e-5, main.rs:487), at least what the previous call on this
     // context needed, never more than every cell.  An overflow re-runs the batch once
     // with the exact count.
-    unsigned long long total_cells = 0;
-    for (size_t i = 0; i < n; ++i)
-        total_cells += (unsigned long long)(jobs[i].row_end - jobs[i].row_begin) * jobs[i].cols;
     unsigned long long cap = std::max<unsigned long long>(total_cells / 8192, 1 << 16);
     cap = std::max(cap, ctx->last_hit_count + ctx->last_hit_count / 2);
     cap = std::min(cap, total_cells + 64);
-    (void)max_cells;
     for (int attempt = 0; attempt < 3; ++attempt) {
         // layout: [count u64][pad to 16][HitRecord x cap]
         const size_t bytes = 16 + cap * sizeof(HitRecord);
@@ -402,6 +406,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
             hipStream_t st = (two_streams && (i & 1)) ? ctx->aux_stream : ctx->stream;
             fo.threshold = ts[i];
             fo.job_key = (unsigned long long)i << 40;
+            fo.key_rows = keys == HitKeys::Position ? (unsigned long long)(a.row_end - a.row_begin) : 0;
             // discrete prefilter (score_prefilter.hpp) when a sound one exists and the
             // threshold maps into its 16-bit range; exact f32 kernel otherwise
             if (a.pssm->has_prefilter && ctx->use_prefilter && std::isfinite(ts[i])) {
@@ -440,73 +445,10 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
             cap = count + count / 8 + 64;
             continue;
         }
-        // one contiguous read-back, through pinned memory when it fits
-        std::vector<HitRecord> hits(count);
-        if (count) {
-            const size_t nbytes = count * sizeof(HitRecord);
-            void *stage = nbytes <= kPinnedBytes ? ctx->pinned : static_cast<void *>(hits.data());
-            LM_HIP_TRY(hipMemcpyAsync(stage, fo.hits, nbytes, hipMemcpyDeviceToHost, ctx->stream));
-            LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-            if (stage == ctx->pinned)
-                memcpy(hits.data(), ctx->pinned, nbytes);
-        }
-        // ascending key = job, then row-major order (pli/mod.rs:212-218): counting sort
-        // by job, then each job's hits are sorted independently (in parallel for big lists)
-        std::vector<size_t> start(n + 1, 0);
-        for (size_t h = 0; h < count; ++h)
-            ++start[(size_t)(hits[h].key >> 40) + 1];
-        for (size_t j = 0; j < n; ++j)
-            start[j + 1] += start[j];
-        std::vector<HitRecord> sorted(count);
-        {
-            std::vector<size_t> fill(start.begin(), start.end() - 1);
-            for (size_t h = 0; h < count; ++h)
-                sorted[fill[(size_t)(hits[h].key >> 40)]++] = hits[h];
-        }
-        auto finish_job = [&](size_t j) {
-            HitRecord *lo = sorted.data() + start[j], *hi = sorted.data() + start[j + 1];
-            std::sort(lo, hi, [](const HitRecord &x, const HitRecord &y) { return x.key < y.key; });
-            std::vector<unsigned long long> &fl = (*flat)[j];
-            std::vector<float> &vl = (*values)[j];
-            fl.reserve(hi - lo);
-            vl.reserve(hi - lo);
-            for (HitRecord *r = lo; r != hi; ++r) {
-                if (r != lo && r->key == (r - 1)->key)
-                    continue;  // duplicate from the shifted last stream
-                fl.push_back(r->key & ((1ull << 40) - 1));
-                vl.push_back(r->value);
-            }
-        };
-        const unsigned nthreads =
-            count > (1u << 18) ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1u;
-        if (nthreads <= 1) {
-            for (size_t j = 0; j < n; ++j)
-                finish_job(j);
-        } else {
-            std::atomic<size_t> next{0};
-            std::vector<std::thread> pool;
-            for (unsigned t = 0; t < nthreads; ++t)
-                pool.emplace_back([&] {
-                    for (size_t j = next.fetch_add(1); j < n; j = next.fetch_add(1))
-                        finish_job(j);
-                });
-            for (auto &th : pool)
-                th.join();
-        }
-        return LM_HIP_OK;
+        return order_hits(ctx, fo.hits, count, n, max_low, keys == HitKeys::Position ? 1 : 0,
+                          jobs[0].cols, out);
     }
     return fail(LM_HIP_ERR_HIP, "fused threshold: hit list kept overflowing");
-}
-
-int launch_score_threshold(lm_hip_ctx *ctx, const ScoreArgs &a, float t,
-                           std::vector<unsigned long long> *flat, std::vector<float> *values)
-{
-    std::vector<std::vector<unsigned long long>> f;
-    std::vector<std::vector<float>> v;
-    LM_TRY(launch_score_threshold_batch(ctx, &a, &t, 1, &f, &v));
-    *flat = std::move(f[0]);
-    *values = std::move(v[0]);
-    return LM_HIP_OK;
 }
 
 int finalize_argmax_materialised(lm_hip_ctx *ctx, const ArgmaxRecord *d_blocks, unsigned nblocks,

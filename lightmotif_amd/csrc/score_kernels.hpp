@@ -77,6 +77,7 @@ struct FusedOut {
     HitRecord *hits;                // hit_capacity entries
     unsigned long long job_key;     // batch scans: (job index << 40), OR-ed into the key
     unsigned long long hit_capacity;
+    unsigned long long key_rows;    // 0: key = row * cols + col; else key = col * key_rows + row
 };
 
 // Ordering used by every argmax reduction: larger value wins; equal values ->
@@ -119,14 +120,24 @@ __device__ __forceinline__ void best_block_reduce(float &v, long long &i, float 
     }
 }
 
-// Appends one above-threshold cell to the (unordered) device hit list.
-__device__ __forceinline__ void record_hit(const FusedOut &fo, unsigned long long flat,
-                                           float score)
+// Appends one above-threshold cell (row, col) to the (unordered) device hit list.
+// key = row-major flat index row * cols + col, or -- for Scanner-style output
+// (fo.key_rows != 0) -- the sequence position col * key_rows + row (scores.rs:155-157).
+// The lanes of a wavefront that reach this point together share ONE atomicAdd.
+__device__ __forceinline__ void record_hit(const FusedOut &fo, unsigned long long row,
+                                           unsigned col, unsigned cols, float score)
 {
-    const unsigned long long slot_i = atomicAdd(fo.hit_count, 1ull);
+    const unsigned long long active = __ballot(1);
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)active) - 1;
+    unsigned long long base = 0;
+    if (lane == leader)
+        base = atomicAdd(fo.hit_count, (unsigned long long)__popcll(active));
+    base = __shfl(base, leader);
+    const unsigned long long slot_i = base + __popcll(active & ((1ull << lane) - 1ull));
     if (slot_i < fo.hit_capacity) {
         HitRecord r;
-        r.key = fo.job_key | flat;
+        r.key = fo.job_key | (fo.key_rows ? col * fo.key_rows + row : row * cols + col);
         r.value = score;
         r.pad = 0;
         fo.hits[slot_i] = r;  // one 16-byte store
@@ -288,7 +299,7 @@ __device__ __forceinline__ void rescan_rows(const uint8_t *__restrict__ seq_col,
         for (int j = 0; j < M; ++j)
             sc = sc + tabf[s[j] * TS + j];
         if (sc >= fo.threshold)
-            record_hit(fo, (unsigned long long)r * 32ull + col, sc);
+            record_hit(fo, (unsigned long long)r, (unsigned)col, 32u, sc);
     }
 }
 
@@ -334,7 +345,8 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
     }
     unsigned long long stream = (bid * (BLK / 64) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
-    if (stream >= nstreams)
+    const bool idle = stream >= nstreams;  // re-does the last stream, reports nothing
+    if (idle)
         stream = nstreams - 1;
     unsigned long long o0 = row_begin + stream * T;
     if (o0 + T > row_end)
@@ -415,6 +427,11 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         const float *tabf = reinterpret_cast<const float *>(lds_raw);
         const long long first_row = (long long)(o0 - row_begin);  // = orow0 + M - 1
         const long long orow0 = first_row - (M - 1);
+        // every cell is reported once: the shifted last stream skips the rows the
+        // stream before it owns, idle half-waves report nothing
+        const long long own_row = (long long)(stream * T);
+        if (idle)
+            hit_groups = 0;
         while (hit_groups) {
             const int bit = __ffsll((long long)hit_groups) - 1;
             hit_groups &= hit_groups - 1;
@@ -423,8 +440,8 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
             if (g1 > ngroups)
                 g1 = ngroups;
             long long r0 = orow0 + (long long)(g0 * M);
-            if (r0 < first_row)
-                r0 = first_row;  // group 0 completes only the stream's first row
+            if (r0 < own_row)
+                r0 = own_row;  // >= first_row: group 0 completes only the stream's first row
             rescan_rows<M, WIDE>(seq_col, tabf, r0, orow0 + (long long)(g1 * M), col, fo);
         }
     }
@@ -485,7 +502,7 @@ __global__ __launch_bounds__(kBlock) void score_generic(
             }
         } else {
             if (score >= fo.threshold)
-                record_hit(fo, cell, score);
+                record_hit(fo, r, (unsigned)c, (unsigned)cols, score);
         }
     }
     if (MODE == MODE_ARGMAX) {

@@ -137,7 +137,8 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter(
     const int col = lane & 31;
     unsigned long long stream =
         ((unsigned long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
-    if (stream >= nstreams)
+    const bool idle = stream >= nstreams;  // re-does the last stream, reports nothing
+    if (idle)
         stream = nstreams - 1;
     unsigned long long o0 = row_begin + stream * T;
     if (o0 + T > row_end)
@@ -196,6 +197,11 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter(
     // (g-1)*MP+1 .. g*MP)
     const uint8_t *seq_col = seq + row_begin * 32 + col;
     const long long first_row = (long long)(o0 - row_begin);
+    // every cell is reported once: the shifted last stream skips the rows the stream
+    // before it owns, idle half-waves report nothing
+    const long long own_row = (long long)(stream * T);
+    if (idle)
+        hit_groups = 0;
     while (hit_groups) {
         const int bit = __ffsll((long long)hit_groups) - 1;
         hit_groups &= hit_groups - 1;
@@ -207,7 +213,10 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter(
         long long i1 = (long long)((g1 - 1) * MP + 1);
         if (i1 > (long long)T)
             i1 = (long long)T;
-        rescan_rows<M, 0>(seq_col, tabf, first_row + i0, first_row + i1, col, fo);
+        long long r0 = first_row + i0;
+        if (r0 < own_row)
+            r0 = own_row;
+        rescan_rows<M, 0>(seq_col, tabf, r0, first_row + i1, col, fo);
     }
 }
 

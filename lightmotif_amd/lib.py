@@ -782,9 +782,9 @@ class Hit:
 
 class Scanner:
     """All positions with ``score >= threshold`` and ``position + M <= L``
-    (scan.rs:185-190), found by the fused score+threshold kernel -- the u8
-    prefilter of scan.rs:169-178 is a CPU-cache trick the GPU path does not need
-    because the f32 scores never leave registers."""
+    (scan.rs:185-190), found by the fused score+threshold kernel: a packed u16
+    discrete prefilter (the device form of scan.rs:169-178's DiscreteMatrix) with exact
+    f32 re-scoring of the candidates; hits come back ordered by position."""
 
     def __init__(self, pssm: ScoringMatrix, sequence: StripedSequence, threshold: float = 0.0,
                  block_size: int = 256):

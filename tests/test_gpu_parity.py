@@ -149,6 +149,31 @@ def test_g5_scanner_like_test_scanner_py(pli):
         assert h.position == w["position"] and abs(h.score - w["score"]) < 1e-5
 
 
+@pytest.mark.parametrize("length,frac", [(100_003, 0.5), (250_000, 0.01), (64, 1.0), (999_999, 1e-4)])
+def test_scanner_dense_hit_lists_come_back_in_position_order(pli, length, frac):
+    """Scanner hits = every position p with score(p) >= t and p + M <= L (scan.rs:185-190),
+    each exactly once, in ascending position -- also when a large share of the cells
+    qualifies (the device-side ordering of the hit list, hits.hip)."""
+    rng = np.random.default_rng(length)
+    m = 9
+    enc = rng.integers(0, 4, length, dtype=np.uint8)
+    p = random_pssm(rng, m, 5)
+    p[:, 4] = rng.normal(0, 2, m)                      # finite N weights: the padded tail scores too
+    ref = co.stripe(enc, 32, 5)
+    co.configure_wrap(ref, m - 1)
+    want, _ = co.score_rows(ref, p)
+    rows = want.shape[0]
+    pos_scores = want[:, :32].T.reshape(-1)[: length - m + 1]     # position = col * rows + row
+    t = float(np.sort(pos_scores)[max(0, int(len(pos_scores) * (1 - frac)) - 1)]) if frac < 1 else -1e30
+    wpos = np.nonzero(pos_scores >= np.float32(t))[0]
+    seq = pli.stripe(lm.EncodedSequence(enc), 32)
+    seq.configure_wrap(m - 1)
+    hits = list(lm.Scanner(lm.ScoringMatrix(p), seq, threshold=t))
+    assert [h.position for h in hits] == wpos.tolist()
+    assert np.array_equal(bits([h.score for h in hits]), bits(pos_scores[wpos]))
+    assert rows * 32 >= length
+
+
 def test_g7_empty_row_range_does_not_fail(pli):
     g = GOLD["G7_empty_range"]
     seq = pli.stripe(lm.EncodedSequence(g["sequence"]), g["columns"])
