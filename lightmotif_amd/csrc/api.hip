@@ -86,11 +86,11 @@ static int check_score_args(const lm_hip_pssm *pssm, size_t seq_rows_total, size
     return LM_HIP_OK;
 }
 
-// Builds the LDS image of score_c32_prefilter<M>: [exact f32 table | u16 layout EVEN |
-// u16 layout ODD] and the affine map discrete ~ (score - offset) / factor.  Follows the
+// Builds the LDS image of score_c32_prefilter<M>: [u16 layout EVEN | u16 layout ODD]
+// and the affine map discrete ~ (score - offset) / factor.  Follows the
 // idea of DiscreteMatrix (pwm/mod.rs:665-696: per-row offsets, one global factor,
 // weights rounded UP) on 16 bits.  Returns false when no sound prefilter exists.
-static bool build_prefilter(lm_hip_pssm &p, const std::vector<float> &table, std::vector<unsigned> *image)
+static bool build_prefilter(lm_hip_pssm &p, std::vector<unsigned> *image)
 {
     const int m = (int)p.m, k = (int)p.k;
     if (m < 1 || p.wide)
@@ -133,9 +133,7 @@ static bool build_prefilter(lm_hip_pssm &p, const std::vector<float> &table, std
             d[(size_t)(j + shift) * k + s] = q;
         }
     image->assign((size_t)prefilter_image_dw(m, k), 0u);
-    static_assert(sizeof(float) == sizeof(unsigned), "f32 table is stored in dwords");
-    memcpy(image->data(), table.data(), table.size() * sizeof(float));
-    unsigned *even = image->data() + (size_t)k * table_stride(m);
+    unsigned *even = image->data();
     unsigned *odd = even + (size_t)k * dsd;
     for (int s = 0; s < k; ++s)
         for (int w = 0; w < mp / 2; ++w) {
@@ -386,7 +384,7 @@ int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stri
             // discrete prefilter image (score_prefilter.hpp); absent when the matrix has
             // NaN / +inf entries or no spread -- the exact f32 fused kernel is used then
             std::vector<unsigned> image;
-            if (build_prefilter(*p, table, &image)) {
+            if (build_prefilter(*p, &image)) {
                 e = hipMalloc(&p->d_image, image.size() * sizeof(unsigned));
                 if (e != hipSuccess)
                     return cleanup(fail(LM_HIP_ERR_OOM, "hipMalloc(prefilter) failed: %s", hipGetErrorString(e)));

@@ -70,6 +70,7 @@ struct lm_hip_ctx {
     bool xcd_remap = false;      // A/B knob of the store kernel (lm_hip_ctx_set_xcd_remap)
     int num_cus = 256;
     unsigned long long last_hit_count = 0;  // sizes the next fused-threshold hit list
+    unsigned long long last_cand_count = 0; // ... and its candidate list
     const char *last_kernel = "";
 };
 
@@ -85,7 +86,7 @@ struct lm_hip_pssm {
     // Row-major dense copy for the generic kernel: d_dense[j * k + s].
     float *d_dense = nullptr;
     // Discrete prefilter of the fused threshold scan (score_prefilter.hpp): LDS image
-    // (exact f32 table | u16 layout EVEN | u16 layout ODD) and the affine map
+    // (u16 layout EVEN | u16 layout ODD) and the affine map
     // discrete = (score - pre_offset) / pre_factor, pre_emax = f32 rounding-error bound.
     unsigned *d_image = nullptr;
     bool has_prefilter = false;

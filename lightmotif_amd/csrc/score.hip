@@ -357,11 +357,92 @@ int launch_score_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, int first_cell_rule
 
 // ---- fused threshold --------------------------------------------------------------------
 
-// Fused score+threshold of `n` jobs: every job appends (key, score) records to one
-// shared device list, key = (job << 40) | row-major cell index or sequence position;
-// hits.hip then orders the list on the device (the reference's row-major push order,
-// pli/mod.rs:212-218, or ascending position) and the result is copied straight into
-// the arrays handed to the caller.  Two synchronisations: the hit count, the result.
+// Exact re-scoring of the candidate row ranges the fused threshold kernels flagged
+// (the GPU form of scan.rs:187-190: `score_position` on the prefilter's candidates).
+// One half-wave per candidate piece (<= 32 rows of one column): lane L re-computes
+// output row r0 + L with the reference's add order -- M sequential f32 adds from
+// +0.0, pli/mod.rs:98-102 -- and appends it to the hit list when score >= t.  The
+// symbol loads of neighbouring lanes are 32 bytes apart and the windows of
+// neighbouring rows overlap, so a piece touches ~(nrows + M) cache sectors once.
+struct RescoreJob {
+    const uint8_t *seq;    // row `row_begin` of the striped matrix (C = 32, stride 32)
+    const float *dense;    // M x K weights, row-major
+    unsigned m, k;
+    float threshold;
+    unsigned pad;
+    unsigned long long key_rows;
+};
+
+// Hits are staged in LDS and flushed with ONE global atomicAdd per ~1000 records: a
+// million per-hit atomics on the single list counter would serialise in L2 (measured:
+// 6 ms per 1e6 hits).
+constexpr int kHitStage = 1024;
+
+__global__ __launch_bounds__(kBlock) void rescore_candidates(const RescoreJob *__restrict__ jobs,
+                                                             const FusedOut fo)
+{
+    __shared__ HitRecord stage[kHitStage];
+    __shared__ unsigned nstage;
+    __shared__ unsigned long long gbase;
+    if (threadIdx.x == 0)
+        nstage = 0;
+    __syncthreads();
+    unsigned long long n = *fo.cand_count;
+    if (n > fo.cand_capacity)
+        n = fo.cand_capacity;  // overflow: the launcher re-runs the batch with more room
+    const unsigned lane = threadIdx.x & 31;
+    const unsigned long long stride = (unsigned long long)gridDim.x * (kBlock / 32);
+    auto flush = [&]() {  // block-uniform
+        __syncthreads();
+        const unsigned cnt = nstage;
+        if (threadIdx.x == 0 && cnt)
+            gbase = atomicAdd(fo.hit_count, (unsigned long long)cnt);
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < cnt; i += kBlock)
+            if (gbase + i < fo.hit_capacity)
+                fo.hits[gbase + i] = stage[i];
+        __syncthreads();
+        if (threadIdx.x == 0)
+            nstage = 0;
+        __syncthreads();
+    };
+    // block-uniform trip count: one candidate piece per half-wave per round
+    for (unsigned long long c0 = (unsigned long long)blockIdx.x * (kBlock / 32); c0 < n; c0 += stride) {
+        const unsigned long long c = c0 + (threadIdx.x >> 5);
+        if (c < n) {
+            const Candidate cd = fo.cands[c];
+            const RescoreJob jb = jobs[cd.key >> 40];
+            if (lane < cd.nrows) {
+                const unsigned long long row = (cd.key & ((1ull << 40) - 1)) + lane;
+                const uint8_t *p = jb.seq + row * 32 + cd.col;
+                float sc = 0.0f;
+#pragma unroll 4
+                for (unsigned j = 0; j < jb.m; ++j)
+                    sc = sc + jb.dense[j * jb.k + p[j * 32]];
+                if (sc >= jb.threshold) {
+                    HitRecord r;
+                    r.key = (cd.key & ~((1ull << 40) - 1)) |
+                            (jb.key_rows ? cd.col * jb.key_rows + row : row * 32ull + cd.col);
+                    r.value = sc;
+                    r.pad = 0;
+                    stage[atomicAdd(&nstage, 1u)] = r;  // <= kBlock records per round
+                }
+            }
+        }
+        __syncthreads();
+        if (nstage > kHitStage - kBlock)
+            flush();
+    }
+    flush();
+}
+
+// Fused score+threshold of `n` jobs.  The C = 32 kernels flag candidate row ranges
+// (discrete prefilter or exact f32 compare), `rescore_candidates` turns them into
+// (key, score) hit records, key = (job << 40) | row-major cell index or sequence
+// position; hits.hip then orders the list on the device (the reference's row-major
+// push order, pli/mod.rs:212-218, or ascending position) and the result is copied
+// straight into the arrays handed to the caller.  Two synchronisations: the counts,
+// the result.
 int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const float *ts, size_t n,
                                  HitKeys keys, HitOutput *out)
 {
@@ -383,30 +464,40 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
     }
     // Hit-list capacity: room for a 1.2e-4 hit rate over the whole batch (the CLI's
     // default p-value is 1e-5, main.rs:487), at least what the previous call on this
-    // context needed, never more than every cell.  An overflow re-runs the batch once
-    // with the exact count.
+    // context needed, never more than every cell; twice that many candidate pieces.
+    // An overflow of either list re-runs the batch with the exact counts.
     unsigned long long cap = std::max<unsigned long long>(total_cells / 8192, 1 << 16);
     cap = std::max(cap, ctx->last_hit_count + ctx->last_hit_count / 2);
     cap = std::min(cap, total_cells + 64);
+    unsigned long long ccap = std::max(2 * cap, ctx->last_cand_count + ctx->last_cand_count / 2);
+    std::vector<RescoreJob> rjobs(n);
     for (int attempt = 0; attempt < 3; ++attempt) {
-        // layout: [count u64][pad to 16][HitRecord x cap]
-        const size_t bytes = 16 + cap * sizeof(HitRecord);
-        LM_TRY(ctx->scratch.reserve(bytes));
+        // layout: [hit count u64][candidate count u64][HitRecord x cap][Candidate x ccap][jobs]
+        const size_t off_cands = 16 + cap * sizeof(HitRecord);
+        const size_t off_jobs = off_cands + ccap * sizeof(Candidate);
+        LM_TRY(ctx->scratch.reserve(off_jobs + n * sizeof(RescoreJob)));
         char *base = static_cast<char *>(ctx->scratch.ptr);
         FusedOut fo{};
         fo.hit_count = reinterpret_cast<unsigned long long *>(base);
+        fo.cand_count = fo.hit_count + 1;
         fo.hits = reinterpret_cast<HitRecord *>(base + 16);
         fo.hit_capacity = cap;
+        fo.cands = reinterpret_cast<Candidate *>(base + off_cands);
+        fo.cand_capacity = ccap;
+        RescoreJob *d_jobs = reinterpret_cast<RescoreJob *>(base + off_jobs);
         LM_HIP_TRY(hipMemsetAsync(base, 0, 16, ctx->stream));
         const bool two_streams = n > 1;
         if (two_streams)
             LM_TRY(batch_fork(ctx));
+        bool any_candidates = false;
         for (size_t i = 0; i < n; ++i) {
             const ScoreArgs &a = jobs[i];
             hipStream_t st = (two_streams && (i & 1)) ? ctx->aux_stream : ctx->stream;
             fo.threshold = ts[i];
             fo.job_key = (unsigned long long)i << 40;
             fo.key_rows = keys == HitKeys::Position ? (unsigned long long)(a.row_end - a.row_begin) : 0;
+            rjobs[i] = RescoreJob{a.d_seq + a.row_begin * a.seq_stride, a.pssm->d_dense,
+                                  (unsigned)a.pssm->m, (unsigned)a.pssm->k, ts[i], 0, fo.key_rows};
             // discrete prefilter (score_prefilter.hpp) when a sound one exists and the
             // threshold maps into its 16-bit range; exact f32 kernel otherwise
             if (a.pssm->has_prefilter && ctx->use_prefilter && std::isfinite(ts[i])) {
@@ -419,6 +510,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
                     ctx->last_kernel = "score_c32_prefilter";
                     LM_HIP_TRY(fn(pp.grid, pp.lds, st, a.d_seq, a.pssm->d_image, (int)a.pssm->k,
                                   a.row_begin, a.row_end, pp.T, pp.nstreams, td, fo));
+                    any_candidates = true;
                     continue;
                 }
             }
@@ -428,8 +520,9 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
                 ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_THRESHOLD);
                 LM_HIP_TRY(fn(p.grid, p.lds, st, a.d_seq, a.pssm->d_table,
                               (int)a.pssm->k, a.row_begin, a.row_end, p.T, p.nstreams, nullptr, fo));
+                any_candidates = true;
             } else {
-                ctx->last_kernel = "score_generic<2>";
+                ctx->last_kernel = "score_generic<2>";  // appends hits directly
                 const unsigned long long ncells =
                     (unsigned long long)(a.row_end - a.row_begin) * a.cols;
                 LM_TRY(launch_generic<MODE_THRESHOLD>(ctx, a, fo, generic_grid(ctx, ncells), st));
@@ -437,9 +530,23 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
         }
         if (two_streams)
             LM_TRY(batch_join(ctx));
-        LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, base, 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (any_candidates) {
+            LM_HIP_TRY(hipMemcpyAsync(d_jobs, rjobs.data(), n * sizeof(RescoreJob), hipMemcpyHostToDevice,
+                                      ctx->stream));
+            hipLaunchKernelGGL(rescore_candidates, dim3((unsigned)ctx->num_cus * 8), dim3(kBlock), 0,
+                               ctx->stream, d_jobs, fo);
+            LM_HIP_TRY(hipGetLastError());
+        }
+        LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, base, 16, hipMemcpyDeviceToHost, ctx->stream));
         LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-        const unsigned long long count = *static_cast<unsigned long long *>(ctx->pinned);
+        const unsigned long long count = static_cast<unsigned long long *>(ctx->pinned)[0];
+        const unsigned long long ncand = static_cast<unsigned long long *>(ctx->pinned)[1];
+        ctx->last_cand_count = ncand;
+        if (ncand > ccap) {
+            // the hit count of a truncated candidate list means nothing yet
+            ccap = ncand + ncand / 8 + 64;
+            continue;
+        }
         ctx->last_hit_count = count;
         if (count > cap) {
             cap = count + count / 8 + 64;

@@ -68,6 +68,14 @@ struct __attribute__((aligned(16))) HitRecord {
     unsigned pad;
 };
 
+// One row range of one column that may hold hits: output rows [r0, r0 + nrows) of
+// column `col`, r0 relative to the job's row_begin; key = (job << 40) | r0, nrows <= 32.
+struct __attribute__((aligned(16))) Candidate {
+    unsigned long long key;
+    unsigned nrows;
+    unsigned col;
+};
+
 struct FusedOut {
     // MODE_ARGMAX: one record per block
     ArgmaxRecord *block_best;
@@ -78,6 +86,10 @@ struct FusedOut {
     unsigned long long job_key;     // batch scans: (job index << 40), OR-ed into the key
     unsigned long long hit_capacity;
     unsigned long long key_rows;    // 0: key = row * cols + col; else key = col * key_rows + row
+    // MODE_THRESHOLD of the C = 32 kernels: candidate ranges for rescore_candidates
+    unsigned long long *cand_count;
+    Candidate *cands;
+    unsigned long long cand_capacity;
 };
 
 // Ordering used by every argmax reduction: larger value wins; equal values ->
@@ -278,28 +290,40 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
     }
 }
 
-// Slow path of the fused threshold: re-scores output rows [r0, r1) of this lane's
-// column with the same add order and appends the cells with score >= t.  The M
-// symbol loads of a row are independent and issued together; rows run in a loop.
-template <int M, int WIDE>
-__device__ __forceinline__ void rescan_rows(const uint8_t *__restrict__ seq_col,
-                                            const float *__restrict__ tabf, const long long r0,
-                                            const long long r1, const int col, const FusedOut &fo)
+// Tail of the fused threshold kernels.  After its stream a lane only knows WHICH row
+// ranges of its column may hold a hit (one bit per range in `hit_groups`); it appends
+// them, cut into pieces of at most 32 rows, to the candidate list.  The pieces are
+// re-scored exactly by `rescore_candidates` (score.hip) -- like the reference Scanner,
+// which collects candidate positions from the discrete scores and re-scores them with
+// `score_position` (scan.rs:179-190) -- with one half-wave per piece, so that the
+// symbol loads of neighbouring rows share cache lines.  `range(bit, r0, r1)` maps a
+// bit to output rows [r0, r1) relative to row_begin.
+template <typename Range>
+__device__ __forceinline__ void emit_candidates(unsigned long long hit_groups, const int col,
+                                                const FusedOut &fo, Range range)
 {
-    constexpr int TS = table_stride(M, WIDE);
-#pragma unroll 1
-    for (long long r = r0; r < r1; ++r) {
-        const uint8_t *p = seq_col + r * 32;
-        unsigned s[M];
-#pragma unroll
-        for (int j = 0; j < M; ++j)
-            s[j] = p[j * 32];
-        float sc = 0.0f;
-#pragma unroll
-        for (int j = 0; j < M; ++j)
-            sc = sc + tabf[s[j] * TS + j];
-        if (sc >= fo.threshold)
-            record_hit(fo, (unsigned long long)r, (unsigned)col, 32u, sc);
+    while (hit_groups) {
+        const int bit = __ffsll((long long)hit_groups) - 1;
+        hit_groups &= hit_groups - 1;
+        long long r0, r1;
+        range(bit, r0, r1);
+        for (; r0 < r1; r0 += 32) {
+            const unsigned long long active = __ballot(1);
+            const int lane = threadIdx.x & 63;
+            const int leader = __ffsll((long long)active) - 1;
+            unsigned long long base = 0;
+            if (lane == leader)
+                base = atomicAdd(fo.cand_count, (unsigned long long)__popcll(active));
+            base = __shfl(base, leader);
+            const unsigned long long slot_i = base + __popcll(active & ((1ull << lane) - 1ull));
+            if (slot_i < fo.cand_capacity) {
+                Candidate c;
+                c.key = fo.job_key | (unsigned long long)r0;
+                c.nrows = (unsigned)(r1 - r0 < 32 ? r1 - r0 : 32);
+                c.col = (unsigned)col;
+                fo.cands[slot_i] = c;  // one 16-byte store
+            }
+        }
     }
 }
 
@@ -423,27 +447,24 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
     note_group();
 
     if (MODE == MODE_THRESHOLD) {
-        const uint8_t *seq_col = seq + row_begin * 32 + col;
-        const float *tabf = reinterpret_cast<const float *>(lds_raw);
         const long long first_row = (long long)(o0 - row_begin);  // = orow0 + M - 1
-        const long long orow0 = first_row - (M - 1);
         // every cell is reported once: the shifted last stream skips the rows the
         // stream before it owns, idle half-waves report nothing
         const long long own_row = (long long)(stream * T);
         if (idle)
             hit_groups = 0;
-        while (hit_groups) {
-            const int bit = __ffsll((long long)hit_groups) - 1;
-            hit_groups &= hit_groups - 1;
+        // bit b <-> groups [b*G, (b+1)*G): group g completes output rows
+        // orow0 + g*M .. orow0 + g*M + M-1, of which group 0 only the stream's first row
+        emit_candidates(hit_groups, col, fo, [=](int bit, long long &r0, long long &r1) {
             const unsigned long long g0 = (unsigned long long)bit * G;
             unsigned long long g1 = g0 + G;
             if (g1 > ngroups)
                 g1 = ngroups;
-            long long r0 = orow0 + (long long)(g0 * M);
+            r0 = first_row - (M - 1) + (long long)(g0 * M);
             if (r0 < own_row)
-                r0 = own_row;  // >= first_row: group 0 completes only the stream's first row
-            rescan_rows<M, WIDE>(seq_col, tabf, r0, orow0 + (long long)(g1 * M), col, fo);
-        }
+                r0 = own_row;  // >= first_row
+            r1 = first_row - (M - 1) + (long long)(g1 * M);
+        });
     }
 
     if (MODE == MODE_ARGMAX) {

@@ -13,8 +13,9 @@
 //   * two accumulators share one VGPR and are advanced by ONE v_pk_add_u16, and a
 //     symbol's whole column is M*2 bytes of LDS instead of M*4 -> half the LDS
 //     traffic and half the adds of the f32 kernel, which is LDS-bound;
-//   * candidates are re-scored with the exact f32 table by the same out-of-line
-//     `rescan_rows` the f32 fused kernel uses, so results are bit-identical to it.
+//   * flagged row ranges go to the candidate list and are re-scored with the exact
+//     f32 weights by `rescore_candidates` (score.hip), the same path the f32 fused
+//     kernel uses, so results are bit-identical to it.
 //
 // Soundness (no false negatives): with P' = P where finite and the row minimum where
 // P = -inf, off_j = min_s P'[j][s], O = sum off_j, factor = (sum_j max_s P'[j][s] - O)
@@ -37,10 +38,10 @@ namespace lm {
 constexpr int prefilter_mp(int m) { return (m + 1) / 2 * 2; }
 // dwords per symbol row of one discrete layout: 4 * odd >= MP / 2 (conflict-free b128)
 constexpr int prefilter_stride_dw(int m) { return 4 * (((prefilter_mp(m) / 2 + 3) / 4) | 1); }
-// total dwords of the LDS image: exact f32 table | layout EVEN | layout ODD
+// total dwords of the LDS image: layout EVEN | layout ODD
 constexpr int prefilter_image_dw(int m, int k)
 {
-    return k * table_stride(m) + 2 * k * prefilter_stride_dw(m);
+    return 2 * k * prefilter_stride_dw(m);
 }
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -129,8 +130,7 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter(
             dst[i] = src[i];
     }
     __syncthreads();
-    const float *tabf = reinterpret_cast<const float *>(lds_raw);
-    const char *tab_even = lds_raw + (size_t)K * table_stride(M) * 4;
+    const char *tab_even = lds_raw;
     const char *tab_odd = tab_even + (size_t)K * prefilter_stride_dw(M) * 4;
 
     const int lane = threadIdx.x & 63;
@@ -192,19 +192,15 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter(
     prefilter_group<M, PFE, PHASE_LAST>(acc2, sym, sp, tab_even, tab_odd, td, flag);
     note_group();
 
-    // exact re-scoring of the flagged groups (outputs are counted from the stream's
+    // the flagged groups become candidates for exact re-scoring (outputs are counted from the stream's
     // first TRUE output row; group 0 completes output 0, group g >= 1 outputs
-    // (g-1)*MP+1 .. g*MP)
-    const uint8_t *seq_col = seq + row_begin * 32 + col;
+    // (g-1)*MP+1 .. g*MP).  Every cell is reported once: the shifted last stream skips
+    // the rows the stream before it owns, idle half-waves report nothing.
     const long long first_row = (long long)(o0 - row_begin);
-    // every cell is reported once: the shifted last stream skips the rows the stream
-    // before it owns, idle half-waves report nothing
     const long long own_row = (long long)(stream * T);
     if (idle)
         hit_groups = 0;
-    while (hit_groups) {
-        const int bit = __ffsll((long long)hit_groups) - 1;
-        hit_groups &= hit_groups - 1;
+    emit_candidates(hit_groups, col, fo, [=](int bit, long long &r0, long long &r1) {
         const unsigned long long g0 = (unsigned long long)bit * G;
         unsigned long long g1 = g0 + G;
         if (g1 > ngroups)
@@ -213,11 +209,11 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter(
         long long i1 = (long long)((g1 - 1) * MP + 1);
         if (i1 > (long long)T)
             i1 = (long long)T;
-        long long r0 = first_row + i0;
+        r0 = first_row + i0;
         if (r0 < own_row)
             r0 = own_row;
-        rescan_rows<M, 0>(seq_col, tabf, r0, first_row + i1, col, fo);
-    }
+        r1 = first_row + i1;
+    });
 }
 
 using PrefilterLauncher = hipError_t (*)(dim3 grid, size_t lds_bytes, hipStream_t stream,
