@@ -407,19 +407,48 @@ __global__ __launch_bounds__(kBlock) void rescore_candidates(const RescoreJob *_
         __syncthreads();
     };
     // block-uniform trip count: one candidate piece per half-wave per round
+    __shared__ uint8_t window[kBlock / 32][96];  // symbols of rows r0 .. r0 + nrows + M - 2
     for (unsigned long long c0 = (unsigned long long)blockIdx.x * (kBlock / 32); c0 < n; c0 += stride) {
         const unsigned long long c = c0 + (threadIdx.x >> 5);
         if (c < n) {
             const Candidate cd = fo.cands[c];
             const RescoreJob jb = jobs[cd.key >> 40];
+            const unsigned long long r0 = cd.key & ((1ull << 40) - 1);
+            // every symbol of the piece's column window is loaded once (<= 3 loads per
+            // lane, all in flight together) and shared through LDS
+            uint8_t *win = window[threadIdx.x >> 5];
+            const unsigned nsym = cd.nrows + jb.m - 1;  // <= 32 + 35
+            const uint8_t *p = jb.seq + r0 * 32 + cd.col;
+            uint8_t s0 = 0, s1 = 0, s2 = 0;
+            if (lane < nsym)
+                s0 = p[(unsigned long long)lane * 32];
+            if (lane + 32 < nsym)
+                s1 = p[(unsigned long long)(lane + 32) * 32];
+            if (lane + 64 < nsym)
+                s2 = p[(unsigned long long)(lane + 64) * 32];
+            win[lane] = s0;
+            win[lane + 32] = s1;
+            win[lane + 64] = s2;
+            // (a half-wave runs in lockstep inside its wavefront: no barrier needed
+            // between the LDS writes above and the reads below)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             if (lane < cd.nrows) {
-                const unsigned long long row = (cd.key & ((1ull << 40) - 1)) + lane;
-                const uint8_t *p = jb.seq + row * 32 + cd.col;
                 float sc = 0.0f;
-#pragma unroll 4
-                for (unsigned j = 0; j < jb.m; ++j)
-                    sc = sc + jb.dense[j * jb.k + p[j * 32]];
+                unsigned j = 0;
+                for (; j + 8 <= jb.m; j += 8) {
+                    float w[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        w[q] = jb.dense[(j + q) * jb.k + win[lane + j + q]];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        sc = sc + w[q];
+                }
+                for (; j < jb.m; ++j)
+                    sc = sc + jb.dense[j * jb.k + win[lane + j]];
                 if (sc >= jb.threshold) {
+                    const unsigned long long row = r0 + lane;
                     HitRecord r;
                     r.key = (cd.key & ~((1ull << 40) - 1)) |
                             (jb.key_rows ? cd.col * jb.key_rows + row : row * 32ull + cd.col);

@@ -297,31 +297,55 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
 // which collects candidate positions from the discrete scores and re-scores them with
 // `score_position` (scan.rs:179-190) -- with one half-wave per piece, so that the
 // symbol loads of neighbouring rows share cache lines.  `range(bit, r0, r1)` maps a
-// bit to output rows [r0, r1) relative to row_begin.
+// bit to output rows [r0, r1) relative to row_begin.//
+// The whole workgroup reserves its slots with ONE global atomicAdd (atomics on the
+// single list counter serialise in L2 at ~6 ns each; a counter bump per wavefront and
+// loop trip cost 0.4 ms per launch at 1e6 candidates): count, workgroup prefix sum,
+// reserve, write.  Every thread of the workgroup must call this.
 template <typename Range>
-__device__ __forceinline__ void emit_candidates(unsigned long long hit_groups, const int col,
+__device__ __forceinline__ void emit_candidates(const unsigned long long hit_groups, const int col,
                                                 const FusedOut &fo, Range range)
 {
-    while (hit_groups) {
-        const int bit = __ffsll((long long)hit_groups) - 1;
-        hit_groups &= hit_groups - 1;
+    __shared__ unsigned wave_total[16];
+    __shared__ unsigned long long block_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    unsigned mine = 0;
+    for (unsigned long long m = hit_groups; m; m &= m - 1) {
         long long r0, r1;
-        range(bit, r0, r1);
-        for (; r0 < r1; r0 += 32) {
-            const unsigned long long active = __ballot(1);
-            const int lane = threadIdx.x & 63;
-            const int leader = __ffsll((long long)active) - 1;
-            unsigned long long base = 0;
-            if (lane == leader)
-                base = atomicAdd(fo.cand_count, (unsigned long long)__popcll(active));
-            base = __shfl(base, leader);
-            const unsigned long long slot_i = base + __popcll(active & ((1ull << lane) - 1ull));
-            if (slot_i < fo.cand_capacity) {
+        range(__ffsll((long long)m) - 1, r0, r1);
+        if (r1 > r0)
+            mine += (unsigned)((r1 - r0 + 31) / 32);
+    }
+    unsigned incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned y = __shfl_up(incl, off);
+        if (lane >= off)
+            incl += y;
+    }
+    if (lane == 63)
+        wave_total[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned tot = 0;
+        for (int w = 0; w < nwaves; ++w)
+            tot += wave_total[w];
+        block_base = tot ? atomicAdd(fo.cand_count, (unsigned long long)tot) : 0ull;
+    }
+    __syncthreads();
+    unsigned long long slot = block_base + incl - mine;
+    for (int w = 0; w < wave; ++w)
+        slot += wave_total[w];
+    for (unsigned long long m = hit_groups; m; m &= m - 1) {
+        long long r0, r1;
+        range(__ffsll((long long)m) - 1, r0, r1);
+        for (; r0 < r1; r0 += 32, ++slot) {
+            if (slot < fo.cand_capacity) {
                 Candidate c;
                 c.key = fo.job_key | (unsigned long long)r0;
                 c.nrows = (unsigned)(r1 - r0 < 32 ? r1 - r0 : 32);
                 c.col = (unsigned)col;
-                fo.cands[slot_i] = c;  // one 16-byte store
+                fo.cands[slot] = c;  // one 16-byte store
             }
         }
     }
