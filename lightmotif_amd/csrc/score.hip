@@ -1,7 +1,10 @@
 // score.hip -- launch logic of the scoring kernels (kernel bodies: score_kernels.hpp).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -500,6 +503,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
     cap = std::min(cap, total_cells + 64);
     unsigned long long ccap = std::max(2 * cap, ctx->last_cand_count + ctx->last_cand_count / 2);
     std::vector<RescoreJob> rjobs(n);
+    const auto t_begin = std::chrono::steady_clock::now();
     for (int attempt = 0; attempt < 3; ++attempt) {
         // layout: [hit count u64][candidate count u64][HitRecord x cap][Candidate x ccap][jobs]
         const size_t off_cands = 16 + cap * sizeof(HitRecord);
@@ -581,8 +585,17 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
             cap = count + count / 8 + 64;
             continue;
         }
-        return order_hits(ctx, fo.hits, count, n, max_low, keys == HitKeys::Position ? 1 : 0,
-                          jobs[0].cols, out);
+        const auto t_scan = std::chrono::steady_clock::now();
+        const int st = order_hits(ctx, fo.hits, count, n, max_low, keys == HitKeys::Position ? 1 : 0,
+                                  jobs[0].cols, out);
+        if (getenv("LM_HIP_TRACE")) {
+            const auto t_end = std::chrono::steady_clock::now();
+            fprintf(stderr, "[lm_hip] fused threshold: %zu jobs, %llu candidates, %llu hits; scan+rescore "
+                            "%.3f ms, order+read-back %.3f ms\n", n, ncand, count,
+                    std::chrono::duration<double, std::milli>(t_scan - t_begin).count(),
+                    std::chrono::duration<double, std::milli>(t_end - t_scan).count());
+        }
+        return st;
     }
     return fail(LM_HIP_ERR_HIP, "fused threshold: hit list kept overflowing");
 }

@@ -51,6 +51,22 @@ def stride(cols: int, elem_size: int) -> int:
 # --- Pipeline -----------------------------------------------------------------
 
 
+class _HostBlock:
+    """A malloc'ed block returned by the library, exposed to numpy through the array
+    interface and released with ``lm_hip_free`` when the last array on it dies."""
+
+    def __init__(self, L, addr: int, nbytes: int):
+        self._L, self._addr = L, addr
+        self.__array_interface__ = {"data": (addr, False), "shape": (nbytes,), "typestr": "|u1",
+                                    "version": 3}
+
+    def __del__(self):
+        try:
+            self._L.lm_hip_free(C.c_void_p(self._addr))
+        except Exception:  # interpreter shutdown
+            pass
+
+
 class Pipeline:
     """``Pipeline<A, Hip>``: owns a device context (stream + scratch)."""
 
@@ -242,12 +258,7 @@ class Pipeline:
         check(self._L.lm_hip_scan_threshold_batch(self._h, handles, ts, n, seq._h, counts,
                                                   C.byref(ptr), C.byref(vals)))
         total = sum(counts)
-        try:
-            values = (np.ctypeslib.as_array(vals, shape=(total,)).copy() if total
-                      else np.zeros(0, np.float32))
-        finally:
-            if vals:
-                self._L.lm_hip_free(vals)
+        values = self._take_array(vals, total, np.float32)
         coords = self._take_coords_array(ptr, total)
         out, pos = [], 0
         for i in range(n):
@@ -275,15 +286,20 @@ class Pipeline:
                                                    C.byref(best), C.byref(value)))
         return ((best.row, best.col), float(value.value)) if found.value else None
 
+    def _take_array(self, ptr, count: int, dtype) -> np.ndarray:
+        """Wraps a malloc'ed result of the library WITHOUT copying it; the block is
+        handed back to ``lm_hip_free`` when the last view of the array dies."""
+        addr = C.cast(ptr, C.c_void_p).value
+        if not addr or count == 0:
+            if addr:
+                self._L.lm_hip_free(C.c_void_p(addr))
+            return np.zeros(0, dtype=dtype)
+        block = _HostBlock(self._L, addr, count * np.dtype(dtype).itemsize)
+        return np.asarray(block).view(dtype)
+
     def _take_coords_array(self, ptr, n: int) -> np.ndarray:
-        try:
-            if n == 0:
-                return np.zeros((0, 2), dtype=np.int64)
-            arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_size_t)), shape=(n, 2))
-            return arr.astype(np.int64)
-        finally:
-            if ptr:
-                self._L.lm_hip_free(ptr)
+        # lm_hip_coords = {size_t row, col}; indices stay far below 2^63
+        return self._take_array(ptr, 2 * n, np.int64).reshape(n, 2)
 
     def threshold_dptr(self, scores_ptr: int, rows: int, stride_: int, columns: int,
                        threshold: float) -> np.ndarray:
@@ -301,13 +317,7 @@ class Pipeline:
         check(self._L.lm_hip_score_threshold_f32_dptr(
             self._h, pssm._device(self), C.c_void_p(seq_ptr), seq_rows_total, seq_stride, columns,
             wrap, length, row_begin, row_end, threshold, C.byref(ptr), C.byref(vals), C.byref(n)))
-        try:
-            values = (np.ctypeslib.as_array(vals, shape=(n.value,)).copy() if n.value
-                      else np.zeros(0, np.float32))
-        finally:
-            if vals:
-                self._L.lm_hip_free(vals)
-        return self._take_coords_array(ptr, n.value), values
+        return self._take_coords_array(ptr, n.value), self._take_array(vals, n.value, np.float32)
 
     def score_argmax_dptr(self, pssm: "ScoringMatrix", seq_ptr: int, seq_rows_total: int,
                           seq_stride: int, columns: int, wrap: int, length: int, row_begin: int,
