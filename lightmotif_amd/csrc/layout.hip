@@ -195,6 +195,66 @@ __global__ __launch_bounds__(kBlock) void stripe_kernel_fast(const uint8_t *__re
     }
 }
 
+// C = 32, stride 32 (the layout every scoring kernel runs on).  Phase 1 keeps the
+// input's orientation: a lane loads 16 consecutive rows of one column with ONE 16-byte
+// load (a wavefront reads 1 KB of a column per instruction -- with dword loads the
+// kernel was bound by the load-request rate: 2.7 vs 5.1 TB/s, tools/kbench/stripe_bench)
+// and stores them to tile[c][piece], consecutive lanes -> consecutive LDS addresses.
+// Phase 2 gives every lane ONE output row: 32 byte reads tile[c][row] (consecutive
+// lanes -> consecutive bytes of one LDS row: 16 dwords per wavefront, no conflicts),
+// packed into two 16-byte stores, so a wavefront writes 2 KB of contiguous output per
+// pair of store instructions.
+constexpr int kStripeRows = 4 * kBlock;
+
+__global__ __launch_bounds__(kBlock) void stripe_kernel_c32(const uint8_t *__restrict__ enc,
+                                                            const unsigned long long len,
+                                                            const unsigned long long rows,
+                                                            const uint8_t def,
+                                                            uint8_t *__restrict__ data)
+{
+    __shared__ uint4 tile[32][kStripeRows / 16];
+    const unsigned long long r0 = (unsigned long long)blockIdx.x * kStripeRows;
+    constexpr unsigned per_col = kStripeRows / 16;  // 16-row pieces per column
+#pragma unroll 4
+    for (unsigned p = threadIdx.x; p < 32 * per_col; p += kBlock) {
+        const unsigned c = p / per_col, q = p % per_col;
+        const unsigned long long r = r0 + 16ull * q;
+        const unsigned long long i = (unsigned long long)c * rows + r;  // pli/mod.rs:192
+        uint4 v;
+        if (r + 15 < rows && i + 15 < len) {
+            __builtin_memcpy(&v, enc + i, 16);  // unaligned 16-byte load
+        } else {
+            unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const unsigned b = (r + k < rows) ? (i + k < len ? enc[i + k] : def) : 0;  // :195
+                w[k / 4] |= b << (8 * (k % 4));
+            }
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        tile[c][q] = v;
+    }
+    __syncthreads();
+    const uint8_t *tb = reinterpret_cast<const uint8_t *>(&tile[0][0]);
+#pragma unroll 1
+    for (int it = 0; it < kStripeRows / kBlock; ++it) {
+        const unsigned lr = it * kBlock + threadIdx.x;
+        const unsigned long long row = r0 + lr;
+        if (row < rows) {
+            unsigned w[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const unsigned b0 = tb[(4 * g + 0) * kStripeRows + lr], b1 = tb[(4 * g + 1) * kStripeRows + lr];
+                const unsigned b2 = tb[(4 * g + 2) * kStripeRows + lr], b3 = tb[(4 * g + 3) * kStripeRows + lr];
+                w[g] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+            }
+            uint4 *dst = reinterpret_cast<uint4 *>(data + row * 32);
+            dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+    }
+}
+
 // Wrap rows in closed form.  seq.rs:373-378 runs
 //     for i in 0..m { data[rows+i][j] = data[i][j+1] (j < C-1); data[rows+i][C-1] = default }
 // sequentially in place, so for i >= rows the source row is itself a wrap row
@@ -244,7 +304,12 @@ int launch_stripe(lm_hip_ctx *ctx, const uint8_t *d_encoded, size_t len, size_t 
 {
     const unsigned long long rows = (len + cols - 1) / cols;  // pli/mod.rs:182
     const size_t fast_lds = (size_t)kFastTileRows * (stride + 4);
-    if (rows && stride % 4 == 0 && fast_lds <= 60 * 1024 &&
+    if (rows && cols == 32 && stride == 32 && reinterpret_cast<uintptr_t>(d_data) % 16 == 0) {
+        const unsigned grid = (unsigned)((rows + kStripeRows - 1) / kStripeRows);
+        hipLaunchKernelGGL(stripe_kernel_c32, dim3(grid), dim3(kBlock), 0, ctx->stream, d_encoded,
+                           (unsigned long long)len, rows, default_symbol, d_data);
+        LM_HIP_TRY(hipGetLastError());
+    } else if (rows && stride % 4 == 0 && fast_lds <= 60 * 1024 &&
         reinterpret_cast<uintptr_t>(d_data) % 4 == 0) {
         const unsigned grid = (unsigned)((rows + kFastTileRows - 1) / kFastTileRows);
         hipLaunchKernelGGL(stripe_kernel_fast, dim3(grid), dim3(kBlock), fast_lds, ctx->stream,

@@ -113,9 +113,9 @@ int launch_argmax(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t st
                            (unsigned long long)rows, (unsigned long long)stride, (unsigned)cols,
                            recs + 1);
     LM_HIP_TRY(hipGetLastError());
-    LM_TRY(finalize_argmax_materialised(ctx, recs + 1, grid, d_scores, first_cell_rule, recs));
-    LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, recs, sizeof(ArgmaxRecord), hipMemcpyDeviceToHost,
-                              ctx->stream));
+    // the finalize kernel writes the record straight into pinned host memory
+    LM_TRY(finalize_argmax_materialised(ctx, recs + 1, grid, d_scores, first_cell_rule,
+                                        static_cast<ArgmaxRecord *>(ctx->pinned)));
     LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     *out = *static_cast<const ArgmaxRecord *>(ctx->pinned);
     return LM_HIP_OK;

@@ -314,7 +314,21 @@ int launch_score_argmax_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
     ArgmaxRecord *results = reinterpret_cast<ArgmaxRecord *>(base);
     ArgmaxRecord *blocks = reinterpret_cast<ArgmaxRecord *>(base + off_blocks);
     FinalizeJob *d_jobs = reinterpret_cast<FinalizeJob *>(base + off_jobs);
-    std::vector<FinalizeJob> fj(n);
+    // Small batches skip both copies: the job table is written into the context's
+    // pinned (device-visible) buffer, the finalize kernel reads it from there and
+    // writes the results next to it, and the host reads them after the one
+    // synchronisation.  A single short scan is launch-latency bound, so the two
+    // staged copies were a third of its wall time.
+    const size_t pin_jobs_off = (sizeof(ArgmaxRecord) * n + 63) / 64 * 64;
+    const bool zero_copy = pin_jobs_off + sizeof(FinalizeJob) * n <= kPinnedBytes;
+    std::vector<FinalizeJob> fj_heap(zero_copy ? 0 : n);
+    FinalizeJob *fj = zero_copy
+                          ? reinterpret_cast<FinalizeJob *>(static_cast<char *>(ctx->pinned) + pin_jobs_off)
+                          : fj_heap.data();
+    if (zero_copy) {
+        d_jobs = fj;
+        results = static_cast<ArgmaxRecord *>(ctx->pinned);
+    }
     size_t pos = 0;
     const bool two_streams = n > 1;
     if (two_streams)
@@ -341,14 +355,18 @@ int launch_score_argmax_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
     }
     if (two_streams)
         LM_TRY(batch_join(ctx));
-    LM_HIP_TRY(hipMemcpyAsync(d_jobs, fj.data(), sizeof(FinalizeJob) * n, hipMemcpyHostToDevice,
-                              ctx->stream));
+    if (!zero_copy)
+        LM_HIP_TRY(hipMemcpyAsync(d_jobs, fj, sizeof(FinalizeJob) * n, hipMemcpyHostToDevice,
+                                  ctx->stream));
     hipLaunchKernelGGL(argmax_finalize_batch, dim3((unsigned)n), dim3(kBlock), 0, ctx->stream,
                        d_jobs, first_cell_rule, results);
     LM_HIP_TRY(hipGetLastError());
-    LM_HIP_TRY(hipMemcpyAsync(out, results, sizeof(ArgmaxRecord) * n, hipMemcpyDeviceToHost,
-                              ctx->stream));
+    if (!zero_copy)
+        LM_HIP_TRY(hipMemcpyAsync(out, results, sizeof(ArgmaxRecord) * n, hipMemcpyDeviceToHost,
+                                  ctx->stream));
     LM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // also keeps `fj` alive long enough
+    if (zero_copy)
+        memcpy(out, results, sizeof(ArgmaxRecord) * n);
     return LM_HIP_OK;
 }
 

@@ -97,6 +97,22 @@ def test_full_size_properties(gpu_pli, length, m, k):
     assert np.array_equal(f_hits, want_hits)
     assert np.array_equal(f_vals, scores[want_hits[:, 0], want_hits[:, 1]].cpu().numpy())
 
+    # (5b) a ~1e-3 tail: the candidate list, the re-scoring kernel and the device-side
+    # ordering of the hit list at ~10^6 hits per Gbp, with and without the prefilter
+    t3 = float(torch.quantile(flat[:8_000_000][torch.isfinite(flat[:8_000_000])], 1 - 1e-3))
+    want_hits = torch.nonzero(scores >= t3).cpu().numpy()
+    want_vals = scores[want_hits[:, 0], want_hits[:, 1]].cpu().numpy()
+    for on in (True, False):
+        pli.set_prefilter(on)
+        try:
+            f_hits, f_vals = pli.score_threshold_dptr(pssm, seq.data_ptr(), rows + m - 1, COLS, COLS, m - 1,
+                                                      length, 0, rows, t3)
+        finally:
+            pli.set_prefilter(True)
+        assert np.array_equal(f_hits, want_hits), f"prefilter={on}"
+        assert np.array_equal(f_vals, want_vals)
+    del want_hits, want_vals, f_hits, f_vals
+
     # (6) the padded tail really scores -inf (N/X column is -inf, pwm/mod.rs:422-423)
     n_pad = rows * COLS - (length + 1 - m)
     tail = torch.arange(length + 1 - m, rows * COLS, device=scores.device)
