@@ -470,6 +470,78 @@ public:
         return out;
     }
 
+    // Encode + Stripe of raw text in one go, on the device (pli/mod.rs:47-66 + 166-175):
+    // the text is uploaded once, encoded and striped by the kernels.  Throws InvalidSymbol.
+    StripedSequence<A> stripe_text(const std::string &text, size_t columns = 32, bool lossy = false) const
+    {
+        lm_hip_seq *h = nullptr;
+        size_t bad = 0;
+        const int st = lm_hip_seq_from_ascii(ctx_->ctx, A::code, reinterpret_cast<const uint8_t *>(text.data()),
+                                             text.size(), columns, lossy ? 1 : 0, &h, &bad);
+        if (st == LM_HIP_ERR_INVALID_SYMBOL)
+            throw InvalidSymbol(text[bad]);
+        check(st);
+        return StripedSequence<A>(ctx_, h);
+    }
+
+    // Many motifs over one resident sequence (the CLI's fan-out, lightmotif-cli main.rs:554-561):
+    // per motif the best cell and its score, or nullopt when the sequence is shorter than the motif.
+    struct Best {
+        MatrixCoordinates cell;
+        float score;
+    };
+    std::vector<std::optional<Best>> scan_argmax_batch(const std::vector<const ScoringMatrix<A> *> &pssms,
+                                                       const StripedSequence<A> &seq) const
+    {
+        const size_t n = pssms.size();
+        std::vector<const lm_hip_pssm *> handles(n);
+        for (size_t i = 0; i < n; ++i)
+            handles[i] = pssms[i]->device(ctx_->ctx);
+        std::vector<int> found(n);
+        std::vector<lm_hip_coords> best(n);
+        std::vector<float> value(n);
+        check(lm_hip_scan_argmax_batch(ctx_->ctx, handles.data(), n, seq.handle(), found.data(), best.data(),
+                                       value.data()));
+        std::vector<std::optional<Best>> out(n);
+        for (size_t i = 0; i < n; ++i)
+            if (found[i])
+                out[i] = Best{{best[i].row, best[i].col}, value[i]};
+        return out;
+    }
+    // per motif: the cells with score >= thresholds[i] in row-major order, with their scores
+    struct Cells {
+        std::vector<MatrixCoordinates> coords;
+        std::vector<float> scores;
+    };
+    std::vector<Cells> scan_threshold_batch(const std::vector<const ScoringMatrix<A> *> &pssms,
+                                            const std::vector<float> &thresholds,
+                                            const StripedSequence<A> &seq) const
+    {
+        const size_t n = pssms.size();
+        if (thresholds.size() != n)
+            throw std::invalid_argument("one threshold per motif");
+        std::vector<const lm_hip_pssm *> handles(n);
+        for (size_t i = 0; i < n; ++i)
+            handles[i] = pssms[i]->device(ctx_->ctx);
+        std::vector<size_t> counts(n);
+        lm_hip_coords *c = nullptr;
+        float *v = nullptr;
+        check(lm_hip_scan_threshold_batch(ctx_->ctx, handles.data(), thresholds.data(), n, seq.handle(),
+                                          counts.data(), &c, &v));
+        std::vector<Cells> out(n);
+        size_t pos = 0;
+        for (size_t i = 0; i < n; ++i) {
+            out[i].coords.resize(counts[i]);
+            out[i].scores.assign(v + pos, v + pos + counts[i]);
+            for (size_t k = 0; k < counts[i]; ++k)
+                out[i].coords[k] = {c[pos + k].row, c[pos + k].col};
+            pos += counts[i];
+        }
+        lm_hip_free(c);
+        lm_hip_free(v);
+        return out;
+    }
+
 private:
     explicit Pipeline(std::shared_ptr<CtxHandle> c) : ctx_(std::move(c)) {}
     std::shared_ptr<CtxHandle> ctx_;

@@ -134,6 +134,68 @@ static void test_scanner(const Pipeline<Dna> &pli)
     }
 }
 
+// Many motifs over one resident sequence (lightmotif-cli main.rs:554-561 fans the motifs
+// out with rayon; here one batched call): each motif must give what the single-motif
+// trait calls give (tests/dna.rs:104-137 literals for the golden motif).
+static void test_batch(const Pipeline<Dna> &pli)
+{
+    auto striped = pli.stripe_text(SEQUENCE);                         // device-side encode + stripe
+    const auto reference = pli.stripe(EncodedSequence<Dna>::encode(SEQUENCE));
+    const auto a = striped.matrix(), b = reference.matrix();
+    CHECK(a.rows() == b.rows());
+    for (size_t r = 0; r < a.rows() && r < b.rows(); ++r)
+        for (size_t c = 0; c < 32; ++c)
+            CHECK(a(r, c) == b(r, c));
+    const auto pssm = golden_pssm();
+    // a second, shorter motif: the first 8 columns of the golden one
+    DenseMatrix<float> head(8, Dna::K);
+    for (size_t i = 0; i < 8; ++i)
+        for (size_t j = 0; j < Dna::K; ++j)
+            head(i, j) = pssm.matrix()(i, j);
+    const ScoringMatrix<Dna> shorter(pssm.background, head);
+    striped.configure(pssm);
+    const std::vector<const ScoringMatrix<Dna> *> motifs = {&pssm, &shorter};
+
+    const auto best = pli.scan_argmax_batch(motifs, striped);
+    CHECK(best.size() == 2 && best[0] && best[1]);
+    for (size_t i = 0; i < 2 && i < best.size(); ++i) {
+        const auto scores = pli.score(*motifs[i], striped);
+        const auto want = pli.argmax(scores);
+        CHECK(want && best[i] && *want == best[i]->cell);
+        CHECK(best[i] && best[i]->score == *scores.max());
+    }
+    if (best.size() == 2 && best[0]) {
+        const size_t rows = striped.matrix().rows() - striped.wrap();
+        CHECK(best[0]->cell.col * rows + best[0]->cell.row == 18);     // tests/dna.rs:104-111
+    }
+
+    const auto cells = pli.scan_threshold_batch(motifs, {-10.0f, -4.0f}, striped);
+    CHECK(cells.size() == 2);
+    for (size_t i = 0; i < 2 && i < cells.size(); ++i) {
+        const auto scores = pli.score(*motifs[i], striped);
+        const auto want = pli.threshold(scores, i == 0 ? -10.0f : -4.0f);
+        CHECK(want == cells[i].coords);
+        const auto m = scores.matrix();
+        for (size_t k = 0; k < cells[i].coords.size(); ++k)
+            CHECK(cells[i].scores[k] == m(cells[i].coords[k].row, cells[i].coords[k].col));
+    }
+    if (cells.size() == 2) {
+        std::vector<size_t> idx;
+        const size_t rows = pli.score(pssm, striped).rows();
+        for (const auto &c : cells[0].coords)
+            idx.push_back(c.col * rows + c.row);
+        std::sort(idx.begin(), idx.end());
+        CHECK((idx == std::vector<size_t>{18, 27, 32}));              // tests/dna.rs:124-128
+    }
+    bool threw = false;
+    try {
+        pli.stripe_text("ATGCZ");                                     // tests/encode.rs: unknown symbol
+    } catch (const InvalidSymbol &e) {
+        threw = e.symbol == 'Z';
+    }
+    CHECK(threw);
+}
+
 // tests/stripe.rs:17-45
 static void test_stripe(const Pipeline<Dna> &pli, const std::string &sequence, size_t columns)
 {
@@ -221,6 +283,7 @@ int main()
     }
     test_stripe_literals(pli);
     test_scanner(pli);
+    test_batch(pli);
     test_encode(pli);
     test_edge_cases(pli);
     if (failures) {
