@@ -126,13 +126,14 @@ def config5(pli):
     for _ in range(20):
         it()
     t = timeit(it, 50)
+    store_kernel = pli.last_kernel
 
     def fused():
         return pli.score_argmax_dptr(pssm, seq.data_ptr(), rows + m - 1, COLS, COLS, m - 1, length, 0, rows)
 
     assert fused() == pli.argmax_dptr(out.data_ptr(), rows, COLS, COLS)
     tf = timeit(fused, 30)
-    return {"config": "c5: protein (K=21) len-12 PSSM x 200 Mres, score() materialised", "kernel": pli.last_kernel,
+    return {"config": "c5: protein (K=21) len-12 PSSM x 200 Mres, score() materialised", "kernel": store_kernel,
             "ms": round(t * 1e3, 4), "Gpos_per_s": round(rows * COLS / t / 1e9, 1),
             "GBps": round(5 * rows * COLS / t / 1e9, 1), "hbm_frac": round(5 * rows * COLS / t / 8e12, 4),
             "fused_argmax_ms": round(tf * 1e3, 4), "fused_argmax_Gpos_per_s": round(rows * COLS / tf / 1e9, 1),
