@@ -10,6 +10,8 @@ A symbol may not appear twice and all rows must have the same length
 """
 from __future__ import annotations
 
+import gzip
+import os
 import re
 from dataclasses import dataclass
 from typing import Iterator, Optional, TextIO, Union
@@ -32,8 +34,10 @@ class Record:
 def read(file: Union[str, TextIO], *, protein: bool = False) -> Iterator[Record]:
     """Iterate over the records of a JASPAR-2016 formatted file (jaspar16/mod.rs:139)."""
     close = False
-    if isinstance(file, str):
-        file, close = open(file, "r"), True
+    if isinstance(file, (str, os.PathLike)):
+        path = os.fspath(file)
+        file = gzip.open(path, "rt") if path.endswith(".gz") else open(path, "r")
+        close = True
     try:
         header, rows = None, []
         for line in file:

@@ -78,3 +78,24 @@ def test_score_distribution_score_literals():
     assert abs(cdf.score(0.00033) - 8.765) < 5e-4
     assert cdf.pvalue(-1e9) == 1.0 and cdf.pvalue(1e9) == 0.0
     assert cdf.score(1.0) == cdf.unscale(cdf.min_score) and cdf.score(0.0) == cdf.unscale(cdf.max_score)
+
+
+def test_jaspar2024_core_fixture():
+    """The reference's bench fixture (lightmotif-io/benches/JASPAR2024.pwm, committed gzipped as
+    data): 2 346 DNA count matrices whose length histogram is the one SURVEY.md 8(d) quotes for
+    configs[2]; every record must parse and convert to a PSSM like the CLI does (main.rs:473-478)."""
+    from pathlib import Path
+    records = list(lmio.read(Path(__file__).parent / "golden" / "JASPAR2024.pwm.gz"))
+    assert len(records) == 2346
+    hist = {}
+    for r in records:
+        hist[len(r.matrix)] = hist.get(len(r.matrix), 0) + 1
+    assert hist == {4: 21, 5: 48, 6: 284, 7: 347, 8: 454, 9: 280, 10: 281, 11: 157, 12: 97, 13: 99,
+                    14: 85, 15: 72, 16: 40, 17: 21, 18: 14, 19: 19, 20: 8, 21: 11, 22: 1, 24: 2,
+                    29: 2, 30: 1, 31: 1, 33: 1}
+    assert sum(k * v for k, v in hist.items()) == 22090
+    assert records[0].id == "MA0004.1" and records[0].description == "Arnt"
+    first = records[0].matrix
+    assert first.data[:, :4].tolist()[0] == [4, 16, 0, 0]          # A C T G columns of position 0
+    pssm = first.normalize(0.1).log_odds()
+    assert np.isfinite(pssm.data[:, :4]).all() and np.isneginf(pssm.data[:, 4]).all()
