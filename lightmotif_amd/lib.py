@@ -642,6 +642,20 @@ class ScoringMatrix:
         """pwm/mod.rs:640-648 (the caller configures the wrap rows, like in Rust)."""
         return sequence._pli.score(self, sequence)
 
+    def _extreme_score(self, pick) -> float:
+        total = np.float32(0.0)
+        for row in self.data[:, :self.k - 1]:      # the default symbol (N / X) is left out
+            total = np.float32(total + pick(row))
+        return float(total)
+
+    def min_score(self) -> float:
+        """pwm/mod.rs:592-602: sum over positions of the lowest weight (f32, in row order)."""
+        return self._extreme_score(np.min)
+
+    def max_score(self) -> float:
+        """pwm/mod.rs:605-615: sum over positions of the highest weight."""
+        return self._extreme_score(np.max)
+
     @property
     def score_distribution(self):
         """pwm/mod.rs:698-705 ``to_score_distribution`` (MEME-style, pwm/dist.rs)."""
