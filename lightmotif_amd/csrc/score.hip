@@ -6,8 +6,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <thread>
+#include <tuple>
 #include <numeric>
 
 #include "score_prefilter.hpp"
@@ -91,7 +93,8 @@ struct C32Plan {
 // allocator (kbench6_place.txt, `bench.py --ab`: 1.00 vs 0.97 ms on the same box) --
 // eight distant windows instead of one compact one; the compact window is the
 // robust choice.
-static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store, bool prefilter = false)
+static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store, bool prefilter = false,
+                        size_t batch = 1)
 {
     C32Plan p;
     const size_t K = a.pssm->k;
@@ -114,7 +117,9 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store, b
     // Enough workgroups for several rounds of the chip's resident capacity (6 x 256 CUs
     // of 8-stream workgroups), so the last partial round costs little; the fused
     // kernels run back to back per motif, where that tail is paid every launch.
-    const unsigned long long want_streams = (unsigned long long)ctx->num_cus * (store ? 64 : 128);
+    // (a multi-job launch brings `batch` times as many workgroups, so each job needs fewer)
+    const unsigned long long want_streams =
+        std::max<unsigned long long>((unsigned long long)ctx->num_cus * (store ? 64 : 128) / batch, 64);
     if (n / target < want_streams)
         target = std::max<unsigned long long>(n / want_streams, 1);
     target = std::min<unsigned long long>(target, 1ull << 30);  // step indices are 32-bit
@@ -286,11 +291,46 @@ __global__ __launch_bounds__(kBlock) void argmax_finalize_batch(const FinalizeJo
     }
 }
 
-static unsigned argmax_grid(const lm_hip_ctx *ctx, const ScoreArgs &a)
+// Jobs of a batch that can share ONE launch (grid.y = jobs): same kernel, motif length,
+// alphabet and sequence rows.  Many short per-motif launches lose ~15 % to their ramps
+// and to the short streams a small grid needs; a launch per motif LENGTH keeps streams
+// long and the chip full (2 346 JASPAR motifs -> ~50 launches).
+enum : int { KIND_GENERIC = 0, KIND_EXACT = 1, KIND_PREFILTER = 2 };
+struct JobGroup {
+    int kind = KIND_GENERIC;
+    std::vector<size_t> idx;  // job indices, ascending
+    C32Plan plan;
+};
+
+template <typename KindOf>
+static std::vector<JobGroup> group_jobs(const lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
+                                        KindOf kind_of)
 {
-    const C32Plan p = plan_c32(ctx, a, false);
-    const unsigned long long ncells = (unsigned long long)(a.row_end - a.row_begin) * a.cols;
-    return p.ok ? p.grid.x : generic_grid(ctx, ncells).x;
+    typedef std::tuple<int, size_t, size_t, const uint8_t *, size_t, size_t> Key;
+    std::map<Key, size_t> where;
+    std::vector<JobGroup> groups;
+    for (size_t i = 0; i < n; ++i) {
+        const ScoreArgs &a = jobs[i];
+        const int kind = kind_of(i);
+        if (kind == KIND_GENERIC) {  // one launch each
+            groups.push_back(JobGroup{kind, {i}, C32Plan{}});
+            continue;
+        }
+        const Key key(kind, a.pssm->m, a.pssm->k, a.d_seq, a.row_begin, a.row_end);
+        auto it = where.find(key);
+        if (it == where.end() || groups[it->second].idx.size() >= 32768) {  // grid.y <= 65535
+            where[key] = groups.size();
+            groups.push_back(JobGroup{kind, {i}, C32Plan{}});
+        } else {
+            groups[it->second].idx.push_back(i);
+        }
+    }
+    for (JobGroup &g : groups)
+        if (g.kind != KIND_GENERIC) {
+            g.plan = plan_c32(ctx, jobs[g.idx[0]], false, g.kind == KIND_PREFILTER, g.idx.size());
+            g.plan.grid.y = (unsigned)g.idx.size();
+        }
+    return groups;
 }
 
 // Fused score+argmax of `n` independent jobs (one motif each): the n scoring kernels
@@ -301,12 +341,18 @@ int launch_score_argmax_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
 {
     if (n == 0)
         return LM_HIP_OK;
+    const std::vector<JobGroup> groups = group_jobs(ctx, jobs, n, [&](size_t i) {
+        return plan_c32(ctx, jobs[i], false).ok ? KIND_EXACT : KIND_GENERIC;
+    });
     std::vector<unsigned> grids(n);
     size_t total_blocks = 0;
-    for (size_t i = 0; i < n; ++i) {
-        grids[i] = argmax_grid(ctx, jobs[i]);
-        total_blocks += grids[i];
-    }
+    for (const JobGroup &g : groups)
+        for (size_t i : g.idx) {
+            const unsigned long long ncells =
+                (unsigned long long)(jobs[i].row_end - jobs[i].row_begin) * jobs[i].cols;
+            grids[i] = g.kind == KIND_GENERIC ? generic_grid(ctx, ncells).x : g.plan.grid.x;
+            total_blocks += grids[i];
+        }
     const size_t off_blocks = sizeof(ArgmaxRecord) * n;
     const size_t off_jobs = off_blocks + sizeof(ArgmaxRecord) * total_blocks;
     LM_TRY(ctx->scratch.reserve(off_jobs + sizeof(FinalizeJob) * n));
@@ -329,29 +375,57 @@ int launch_score_argmax_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
         d_jobs = fj;
         results = static_cast<ArgmaxRecord *>(ctx->pinned);
     }
-    size_t pos = 0;
-    const bool two_streams = n > 1;
+    // block records: job i owns grids[i] records starting at block_pos[i]
+    std::vector<size_t> block_pos(n);
+    {
+        size_t pos = 0;
+        for (size_t i = 0; i < n; ++i) {
+            block_pos[i] = pos;
+            pos += grids[i];
+        }
+    }
+    std::vector<BatchParams> bparams(n);
+    BatchParams *d_bparams = nullptr;
+    if (n > 1) {
+        for (size_t i = 0; i < n; ++i)
+            bparams[i] = BatchParams{jobs[i].pssm->d_table, blocks + block_pos[i], 0.0f, 0u, 0ull};
+        LM_TRY(ctx->scratch2.reserve(sizeof(BatchParams) * n));
+        d_bparams = static_cast<BatchParams *>(ctx->scratch2.ptr);
+    }
+    std::vector<BatchParams> ordered;  // in launch order: the jobs of a group are contiguous
+    ordered.reserve(n);
+    for (const JobGroup &g : groups)
+        for (size_t i : g.idx)
+            ordered.push_back(bparams[i]);
+    if (n > 1)
+        LM_HIP_TRY(hipMemcpyAsync(d_bparams, ordered.data(), sizeof(BatchParams) * n,
+                                  hipMemcpyHostToDevice, ctx->stream));
+    const bool two_streams = groups.size() > 1;
     if (two_streams)
         LM_TRY(batch_fork(ctx));
-    for (size_t i = 0; i < n; ++i) {
-        const ScoreArgs &a = jobs[i];
-        const C32Plan p = plan_c32(ctx, a, false);
-        hipStream_t st = (two_streams && (i & 1)) ? ctx->aux_stream : ctx->stream;
+    size_t launch = 0, bp_pos = 0;
+    for (const JobGroup &g : groups) {
+        const ScoreArgs &a = jobs[g.idx[0]];
+        hipStream_t st = (two_streams && (launch++ & 1)) ? ctx->aux_stream : ctx->stream;
         FusedOut fo{};
-        fo.block_best = blocks + pos;
-        if (p.ok) {
+        fo.block_best = blocks + block_pos[g.idx[0]];
+        if (g.kind == KIND_EXACT) {
+            fo.batch = n > 1 ? d_bparams + bp_pos : nullptr;
             ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_ARGMAX, false, a.pssm->wide);
             ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_ARGMAX);
-            LM_HIP_TRY(fn(p.grid, p.lds, st, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
-                          a.row_begin, a.row_end, p.T, p.nstreams, nullptr, fo));
+            LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
+                          a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, nullptr, fo));
         } else {
             ctx->last_kernel = "score_generic<1>";
-            LM_TRY(launch_generic<MODE_ARGMAX>(ctx, a, fo, dim3(grids[i]), st));
+            LM_TRY(launch_generic<MODE_ARGMAX>(ctx, a, fo, dim3(grids[g.idx[0]]), st));
         }
-        fj[i] = FinalizeJob{blocks + pos, grids[i], (int)a.pssm->m, (int)a.pssm->k,
+        bp_pos += g.idx.size();
+    }
+    for (size_t i = 0; i < n; ++i) {
+        const ScoreArgs &a = jobs[i];
+        fj[i] = FinalizeJob{blocks + block_pos[i], grids[i], (int)a.pssm->m, (int)a.pssm->k,
                             a.d_seq + a.row_begin * a.seq_stride,
                             (unsigned long long)a.seq_stride, a.pssm->d_dense};
-        pos += grids[i];
     }
     if (two_streams)
         LM_TRY(batch_join(ctx));
@@ -522,11 +596,43 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
     unsigned long long ccap = std::max(2 * cap, ctx->last_cand_count + ctx->last_cand_count / 2);
     std::vector<RescoreJob> rjobs(n);
     const auto t_begin = std::chrono::steady_clock::now();
+    // which kernel scores each job: the discrete prefilter (score_prefilter.hpp) when a
+    // sound one exists and the threshold maps into its 16-bit range, the exact f32
+    // kernel otherwise, the generic kernel for shapes the C = 32 kernels do not cover
+    std::vector<unsigned> tds(n, 0);
+    const std::vector<JobGroup> groups = group_jobs(ctx, jobs, n, [&](size_t i) {
+        const ScoreArgs &a = jobs[i];
+        if (a.pssm->has_prefilter && ctx->use_prefilter && std::isfinite(ts[i])) {
+            const double scaled = std::floor(((double)ts[i] - a.pssm->pre_offset) / a.pssm->pre_factor) -
+                                  std::ceil(a.pssm->pre_emax / a.pssm->pre_factor) - 1.0;
+            if (scaled >= 1.0 && plan_c32(ctx, a, false, true).ok) {
+                tds[i] = scaled > 65535.0 ? 65535u : (unsigned)scaled;
+                return (int)KIND_PREFILTER;
+            }
+        }
+        return plan_c32(ctx, a, false).ok ? (int)KIND_EXACT : (int)KIND_GENERIC;
+    });
+    const unsigned long long key_rows =
+        keys == HitKeys::Position ? (unsigned long long)(jobs[0].row_end - jobs[0].row_begin) : 0;
+    std::vector<BatchParams> bparams;  // in launch order: the jobs of a group are contiguous
+    bparams.reserve(n);
+    for (const JobGroup &g : groups)
+        for (size_t i : g.idx) {
+            const ScoreArgs &a = jobs[i];
+            if (keys == HitKeys::Position && a.row_end - a.row_begin != key_rows)
+                return fail(LM_HIP_ERR_BAD_ARGS, "fused threshold: position keys need equal row ranges");
+            bparams.push_back(BatchParams{g.kind == KIND_PREFILTER ? (const void *)a.pssm->d_image
+                                                                   : (const void *)a.pssm->d_table,
+                                          nullptr, ts[i], tds[i], (unsigned long long)i << 40});
+            rjobs[i] = RescoreJob{a.d_seq + a.row_begin * a.seq_stride, a.pssm->d_dense,
+                                  (unsigned)a.pssm->m, (unsigned)a.pssm->k, ts[i], 0, key_rows};
+        }
     for (int attempt = 0; attempt < 3; ++attempt) {
-        // layout: [hit count u64][candidate count u64][HitRecord x cap][Candidate x ccap][jobs]
+        // layout: [hit count u64][candidate count u64][HitRecord x cap][Candidate x ccap][jobs][batch]
         const size_t off_cands = 16 + cap * sizeof(HitRecord);
         const size_t off_jobs = off_cands + ccap * sizeof(Candidate);
-        LM_TRY(ctx->scratch.reserve(off_jobs + n * sizeof(RescoreJob)));
+        const size_t off_batch = off_jobs + (n * sizeof(RescoreJob) + 15) / 16 * 16;
+        LM_TRY(ctx->scratch.reserve(off_batch + n * sizeof(BatchParams)));
         char *base = static_cast<char *>(ctx->scratch.ptr);
         FusedOut fo{};
         fo.hit_count = reinterpret_cast<unsigned long long *>(base);
@@ -535,42 +641,37 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
         fo.hit_capacity = cap;
         fo.cands = reinterpret_cast<Candidate *>(base + off_cands);
         fo.cand_capacity = ccap;
+        fo.key_rows = key_rows;
         RescoreJob *d_jobs = reinterpret_cast<RescoreJob *>(base + off_jobs);
+        BatchParams *d_bparams = reinterpret_cast<BatchParams *>(base + off_batch);
         LM_HIP_TRY(hipMemsetAsync(base, 0, 16, ctx->stream));
-        const bool two_streams = n > 1;
+        if (n > 1)
+            LM_HIP_TRY(hipMemcpyAsync(d_bparams, bparams.data(), n * sizeof(BatchParams),
+                                      hipMemcpyHostToDevice, ctx->stream));
+        const bool two_streams = groups.size() > 1;
         if (two_streams)
             LM_TRY(batch_fork(ctx));
         bool any_candidates = false;
-        for (size_t i = 0; i < n; ++i) {
+        size_t launch = 0, bp_pos = 0;
+        for (const JobGroup &g : groups) {
+            const size_t i = g.idx[0];
             const ScoreArgs &a = jobs[i];
-            hipStream_t st = (two_streams && (i & 1)) ? ctx->aux_stream : ctx->stream;
+            hipStream_t st = (two_streams && (launch++ & 1)) ? ctx->aux_stream : ctx->stream;
             fo.threshold = ts[i];
             fo.job_key = (unsigned long long)i << 40;
-            fo.key_rows = keys == HitKeys::Position ? (unsigned long long)(a.row_end - a.row_begin) : 0;
-            rjobs[i] = RescoreJob{a.d_seq + a.row_begin * a.seq_stride, a.pssm->d_dense,
-                                  (unsigned)a.pssm->m, (unsigned)a.pssm->k, ts[i], 0, fo.key_rows};
-            // discrete prefilter (score_prefilter.hpp) when a sound one exists and the
-            // threshold maps into its 16-bit range; exact f32 kernel otherwise
-            if (a.pssm->has_prefilter && ctx->use_prefilter && std::isfinite(ts[i])) {
-                const C32Plan pp = plan_c32(ctx, a, false, true);
-                const double scaled = std::floor(((double)ts[i] - a.pssm->pre_offset) / a.pssm->pre_factor) -
-                                      std::ceil(a.pssm->pre_emax / a.pssm->pre_factor) - 1.0;
-                if (pp.ok && scaled >= 1.0) {
-                    const unsigned td = scaled > 65535.0 ? 65535u : (unsigned)scaled;
-                    PrefilterLauncher fn = score_c32_prefilter_lookup((int)a.pssm->m);
-                    ctx->last_kernel = "score_c32_prefilter";
-                    LM_HIP_TRY(fn(pp.grid, pp.lds, st, a.d_seq, a.pssm->d_image, (int)a.pssm->k,
-                                  a.row_begin, a.row_end, pp.T, pp.nstreams, td, fo));
-                    any_candidates = true;
-                    continue;
-                }
-            }
-            const C32Plan p = plan_c32(ctx, a, false);
-            if (p.ok) {
+            fo.batch = (n > 1 && g.kind != KIND_GENERIC) ? d_bparams + bp_pos : nullptr;
+            bp_pos += g.idx.size();
+            if (g.kind == KIND_PREFILTER) {
+                PrefilterLauncher fn = score_c32_prefilter_lookup((int)a.pssm->m);
+                ctx->last_kernel = "score_c32_prefilter";
+                LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, a.pssm->d_image, (int)a.pssm->k,
+                              a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, tds[i], fo));
+                any_candidates = true;
+            } else if (g.kind == KIND_EXACT) {
                 ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_THRESHOLD, false, a.pssm->wide);
                 ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_THRESHOLD);
-                LM_HIP_TRY(fn(p.grid, p.lds, st, a.d_seq, a.pssm->d_table,
-                              (int)a.pssm->k, a.row_begin, a.row_end, p.T, p.nstreams, nullptr, fo));
+                LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
+                              a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, nullptr, fo));
                 any_candidates = true;
             } else {
                 ctx->last_kernel = "score_generic<2>";  // appends hits directly

@@ -76,6 +76,16 @@ struct __attribute__((aligned(16))) Candidate {
     unsigned col;
 };
 
+// Per-job parameters of a multi-job launch (grid.y = jobs of one motif length over the
+// same sequence rows): block (x, y) works for job y.
+struct BatchParams {
+    const void *table;        // transposed f32 table, or the prefilter's LDS image
+    ArgmaxRecord *block_best; // MODE_ARGMAX: gridDim.x records of this job
+    float threshold;          // MODE_THRESHOLD (exact kernel)
+    unsigned td;              // prefilter kernel: discrete threshold
+    unsigned long long job_key;
+};
+
 struct FusedOut {
     // MODE_ARGMAX: one record per block
     ArgmaxRecord *block_best;
@@ -90,6 +100,8 @@ struct FusedOut {
     unsigned long long *cand_count;
     Candidate *cands;
     unsigned long long cand_capacity;
+    // non-null: a multi-job launch, the fields above that differ per job come from batch[blockIdx.y]
+    const BatchParams *batch;
 };
 
 // Ordering used by every argmax reduction: larger value wins; equal values ->
@@ -365,9 +377,17 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
     const uint8_t *__restrict__ seq, const float *__restrict__ table, const int K,
     const unsigned long long row_begin, const unsigned long long row_end,
     const unsigned long long T, const unsigned long long nstreams, float *__restrict__ out,
-    const FusedOut fo)
+    const FusedOut fo_in)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    FusedOut fo = fo_in;
+    if (MODE != MODE_STORE && fo_in.batch) {  // multi-job launch: this block's job (wave-uniform)
+        const BatchParams bp = fo_in.batch[blockIdx.y];
+        table = static_cast<const float *>(bp.table);
+        fo.block_best = bp.block_best;
+        fo.threshold = bp.threshold;
+        fo.job_key = bp.job_key;
+    }
     if (WIDE) {
         float *dst = reinterpret_cast<float *>(lds_raw);
         const int nf = K * table_stride(M, true);

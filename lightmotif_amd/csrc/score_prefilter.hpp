@@ -115,9 +115,16 @@ template <int M, int PF = LM_SCORE_PF>
 __global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter(
     const uint8_t *__restrict__ seq, const unsigned *__restrict__ image, const int K,
     const unsigned long long row_begin, const unsigned long long row_end,
-    const unsigned long long T, const unsigned long long nstreams, const unsigned td,
-    const FusedOut fo)
+    const unsigned long long T, const unsigned long long nstreams, unsigned td,
+    const FusedOut fo_in)
 {
+    FusedOut fo = fo_in;
+    if (fo_in.batch) {  // multi-job launch: this block's job (wave-uniform)
+        const BatchParams bp = fo_in.batch[blockIdx.y];
+        image = static_cast<const unsigned *>(bp.table);
+        td = bp.td;
+        fo.job_key = bp.job_key;
+    }
     constexpr int MP = prefilter_mp(M);
     constexpr int SHIFT = MP - M;
     constexpr int NP = MP / 2;
