@@ -450,3 +450,42 @@ def test_prefilter_is_skipped_when_it_cannot_be_sound(pli):
     rc, _ = pli.score_threshold(lm.ScoringMatrix(p), seq, float("-inf"))   # selects everything non-NaN
     assert pli.last_kernel.startswith("score_c32<10,2>")
     assert len(rc) == want.shape[0] * 32
+
+
+def test_entry_points_are_thread_safe(pli):
+    """Callers use the reference concurrently (CLI worker threads main.rs:270, Python with the GIL
+    released lib.rs:865): a context serialises its own work, separate contexts run side by side."""
+    import threading
+    rng = np.random.default_rng(5150)
+    enc = rng.integers(0, 4, 200_003, dtype=np.uint8)
+    motifs = [random_pssm(rng, m, 5) for m in (6, 11, 20, 27)]
+    ref = co.stripe(enc, 32, 5)
+    co.configure_wrap(ref, 26)
+    wants = [co.score_rows(ref, p)[0] for p in motifs]
+    want_am = [co.argmax(w, 32) for w in wants]
+    ts = [float(np.sort(w[:, :32][np.isfinite(w[:, :32])])[-300]) for w in wants]
+    want_th = [[tuple(map(int, rc)) for rc in co.threshold(w, 32, t)] for w, t in zip(wants, ts)]
+    other = lm.Pipeline.hip()
+    errors = []
+
+    def worker(p, k):
+        try:
+            seq = p.stripe(lm.EncodedSequence(enc), 32)
+            seq.configure_wrap(26)
+            for it in range(6):
+                i = (k + it) % len(motifs)
+                pssm = lm.ScoringMatrix(motifs[i])
+                scores = p.score(pssm, seq)
+                assert np.array_equal(bits(scores.matrix()[:, :32]), bits(wants[i][:, :32]))
+                assert p.argmax(scores) == want_am[i]
+                assert p.score_argmax(pssm, seq)[0] == want_am[i]
+                assert p.score_threshold(pssm, seq, ts[i])[0] == want_th[i]
+        except Exception as e:  # noqa: BLE001 - reported to the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(pli if k % 2 == 0 else other, k)) for k in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
