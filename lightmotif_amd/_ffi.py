@@ -7,6 +7,7 @@ own error (``LM_HIP_ERR_NO_DEVICE`` without a gfx950 GPU).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "csrc" / "liblightmotif_hip.so"
@@ -109,11 +110,13 @@ def lib() -> C.CDLL:
     """Loads the shared library (raises if it has not been built)."""
     global _lib
     if _lib is None:
-        if not LIB_PATH.exists():
+        # LM_HIP_LIBRARY: another build of the same ABI (A/B runs of two kernel versions)
+        path = Path(os.environ.get("LM_HIP_LIBRARY", LIB_PATH))
+        if not path.exists():
             raise ImportError(
-                f"{LIB_PATH} is missing: build it with `python -m lightmotif_amd.build` "
+                f"{path} is missing: build it with `python -m lightmotif_amd.build` "
                 "(there is no CPU fallback)")
-        L = C.CDLL(str(LIB_PATH))
+        L = C.CDLL(str(path))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res

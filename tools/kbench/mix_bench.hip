@@ -69,6 +69,102 @@ __global__ __launch_bounds__(256) void mix_burst(const unsigned *in, f32x4 *out,
     }
 }
 
+// the score kernel's own access pattern without its arithmetic: a half-wave walks T
+// consecutive rows of 32 columns (1 byte read, 1 float written per lane and step)
+template <int PFD>
+__global__ __launch_bounds__(256) void mix_rows(const uint8_t *in, float *out, unsigned long long rows,
+                                                unsigned long long T)
+{
+    const unsigned long long stream = ((unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + ((threadIdx.x & 63) >> 5);
+    const unsigned col = threadIdx.x & 31;
+    unsigned long long r0 = stream * T;
+    if (r0 >= rows) return;
+    unsigned long long r1 = r0 + T < rows ? r0 + T : rows;
+    const uint8_t *ip = in + r0 * 32 + col;
+    float *op = out + r0 * 32 + col;
+    unsigned ring[PFD];
+#pragma unroll
+    for (int k = 0; k < PFD; ++k) ring[k] = ip[k * 32];
+    for (unsigned long long r = r0; r < r1; r += PFD) {
+#pragma unroll
+        for (int k = 0; k < PFD; ++k) {
+            const unsigned s = ring[k];
+            ring[k] = ip[(k + PFD) * 32];
+            if (r + k < r1)
+                __builtin_nontemporal_store((float)s, op + k * 32);
+        }
+        ip += PFD * 32;
+        op += PFD * 32;
+    }
+}
+
+// the score kernel's pattern with 4 rows gathered per store: lane (c) writes 16 bytes of row
+// r + (c & 3), columns 4*(c >> 2).. -- what a 4x4 quad transpose (DPP, no LDS) would allow:
+// a half-wave store covers 512 contiguous bytes
+template <int PFD>
+__global__ __launch_bounds__(256) void mix_rows_q(const uint8_t *in, float *out, unsigned long long rows,
+                                                  unsigned long long T)
+{
+    const unsigned long long stream = ((unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + ((threadIdx.x & 63) >> 5);
+    const unsigned col = threadIdx.x & 31;
+    unsigned long long r0 = stream * T;
+    if (r0 >= rows) return;
+    unsigned long long r1 = r0 + T < rows ? r0 + T : rows;
+    const uint8_t *ip = in + r0 * 32 + col;
+    f32x4 *op = reinterpret_cast<f32x4 *>(out + (r0 + (col & 3)) * 32 + (col >> 2) * 4);
+    unsigned ring[PFD];
+#pragma unroll
+    for (int k = 0; k < PFD; ++k) ring[k] = ip[k * 32];
+    for (unsigned long long r = r0; r < r1; r += PFD) {
+#pragma unroll
+        for (int k = 0; k < PFD; k += 4) {
+            unsigned s[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s[q] = ring[k + q];
+                ring[k + q] = ip[(k + q + PFD) * 32];
+            }
+            if (r + k + 3 < r1) {
+                f32x4 v = {(float)s[0], (float)s[1], (float)s[2], (float)s[3]};
+                __builtin_nontemporal_store(v, op + k * 8);
+            }
+        }
+        ip += PFD * 32;
+        op += PFD * 8;
+    }
+}
+
+// same, but 8 completed rows of a stream are staged in LDS and written as 1 KB by the whole wavefront
+__global__ __launch_bounds__(256) void mix_rows_lds(const uint8_t *in, f32x4 *out, unsigned long long rows,
+                                                    unsigned long long T)
+{
+    __shared__ float stage[8][8 * 32];  // per stream of the block: 8 rows x 32 floats
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5;
+    const unsigned long long stream = ((unsigned long long)blockIdx.x * 4 + wave) * 2 + half;
+    const unsigned col = lane & 31;
+    const unsigned long long r0 = stream * T;     // T multiple of 8; rows multiple of T assumed by the caller
+    if (r0 >= rows) return;
+    const uint8_t *ip = in + r0 * 32 + col;
+    float *mine = stage[wave * 2 + half];
+    for (unsigned long long r = 0; r < T; r += 8) {
+        unsigned s[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] = ip[(r + k) * 32];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mine[k * 32 + col] = (float)s[k];
+        __builtin_amdgcn_wave_barrier();
+        // each stream's 1 KB goes out as 64 lanes x 16 B; the wavefront does its two streams in turn
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float *src = stage[wave * 2 + h];
+            const unsigned long long sr0 = (stream - half + h) * T + r;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(src + lane * 4);
+            __builtin_nontemporal_store(v, out + (sr0 * 32) / 4 + lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 __global__ __launch_bounds__(256) void fill(f32x4 *out, unsigned long long n16)
 {
     for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n16;
@@ -114,6 +210,21 @@ int main(int argc, char **argv)
         snprintf(nm, sizeof nm, "fill(4W) g=%d", g);
         float ms = timeit([&] { hipLaunchKernelGGL(fill, dim3(g), dim3(256), 0, 0, (f32x4 *)out, n / 4); }, 20);
         printf("%-28s %8.3f ms  %7.1f GB/s\n", nm, ms, 4.0 * n / ms / 1e6);
+    }
+    {
+        const unsigned long long rows = n / 32;
+        for (unsigned long long T : {56ull, 60ull, 61ull, 64ull, 72ull, 80ull, 96ull, 128ull, 61ull, 64ull}) {
+            const unsigned long long nstreams = (rows + T - 1) / T;
+            const unsigned grid = (unsigned)((nstreams + 7) / 8);
+            char nm[64];
+            snprintf(nm, sizeof nm, "mix_rows<12> T=%llu", T);
+            rep(nm, timeit([&] { hipLaunchKernelGGL(mix_rows<12>, dim3(grid), dim3(256), 0, 0, in, out, rows, T); }, 20));
+            snprintf(nm, sizeof nm, "mix_rows_q<12> T=%llu", T);
+            rep(nm, timeit([&] { hipLaunchKernelGGL(mix_rows_q<12>, dim3(grid), dim3(256), 0, 0, in, out, rows, T); }, 20));
+            snprintf(nm, sizeof nm, "mix_rows_lds T=%llu", T);
+            const unsigned long long rows8 = rows / T * T;
+            rep(nm, timeit([&] { hipLaunchKernelGGL(mix_rows_lds, dim3((unsigned)(rows8 / T / 8)), dim3(256), 0, 0, in, (f32x4 *)out, rows8, T); }, 20));
+        }
     }
     return 0;
 }
