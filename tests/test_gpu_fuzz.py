@@ -1,0 +1,83 @@
+"""Seeded differential test: random shapes, motif lengths, row ranges, stream lengths and
+thresholds through every entry point of the path, GPU vs the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+import lightmotif_amd as lm
+from oracle import c_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("seed", range(240))
+def test_random_configuration(pli, seed):
+    rng = np.random.default_rng(90_000 + seed)
+    protein = seed % 7 == 3
+    k = 21 if protein else 5
+    m = int(rng.integers(1, 41))
+    length = int(rng.choice([m, m + 1, 33, 1000, 4097, 20_000, 131_072, 250_001]))
+    length = max(length, 1)
+    cols = 32 if seed % 5 else int(rng.choice([1, 3, 16, 33]))
+    enc = rng.integers(0, k - (1 if seed % 3 else 0), length, dtype=np.uint8)  # sometimes with N / X
+    kind = rng.choice(["normal", "ties", "finite_default", "neg_inf_cells"])
+    p = np.zeros((m, co.stride(k, 4)), np.float32)
+    p[:, :k] = rng.integers(-3, 4, (m, k)) if kind == "ties" else rng.normal(0, 2, (m, k))
+    if kind != "finite_default":
+        p[:, k - 1] = -np.inf
+    if kind == "neg_inf_cells":
+        p[rng.random((m, co.stride(k, 4))) < 0.05] = -np.inf
+    extra_wrap = int(rng.integers(0, 3))
+
+    ref = co.stripe(enc, cols, k)
+    co.configure_wrap(ref, max(m - 1, 0) + extra_wrap)
+    rows_total = ref.rows
+    a = int(rng.integers(0, max(rows_total, 1)))
+    b = int(rng.integers(a, rows_total + 1))
+    if seed % 2 == 0:
+        a, b = 0, rows_total
+    want, want_mi = co.score_rows(ref, p, a, b)
+
+    seq = pli.stripe(lm.EncodedSequence(enc, protein=protein), cols)
+    seq.configure_wrap(max(m - 1, 0) + extra_wrap)
+    pssm = lm.ScoringMatrix(p, protein=protein)
+    rps = int(rng.choice([0, 0, 7, 33, 64, 1000, 50_000]))
+    pli.set_rows_per_stream(rps)
+    pli.set_prefilter(bool(seed % 4))
+    try:
+        scores = lm.StripedScores.empty(pli, cols)
+        pli.score_rows_into(pssm, seq, range(a, b), scores)
+        got = scores.matrix()
+        assert got.shape == want.shape and scores.max_index == want_mi
+        assert np.array_equal(bits(got[:, :cols]), bits(want[:, :cols])), pli.last_kernel
+        assert pli.argmax(scores) == co.argmax(want, cols)
+        fused = pli.score_argmax(pssm, seq, range(a, b))
+        if want.shape[0] == 0:
+            assert fused is None
+            return
+        assert fused[0] == co.argmax(want, cols), pli.last_kernel
+        finite = np.sort(want[:, :cols][np.isfinite(want[:, :cols])])
+        ts = [0.0]
+        if finite.size:
+            qs = rng.choice([0.0, 0.5, 0.9, 0.999, 1.0], 2)
+            ts += [float(finite[min(int(q * (finite.size - 1)), finite.size - 1)]) for q in qs]
+            ts.append(float(finite[-1]) + 1.0)
+        for t in ts:
+            wrc = [tuple(map(int, rc)) for rc in co.threshold(want, cols, float(t))]
+            assert pli.threshold(scores, float(t)) == wrc
+            frc, fval = pli.score_threshold(pssm, seq, float(t), range(a, b))
+            assert frc == wrc, (t, pli.last_kernel)
+            assert np.array_equal(bits(fval), bits([want[r, c] for r, c in wrc]))
+        if not protein and a == 0 and b == rows_total and cols == 32 and length >= m:
+            t = ts[min(1, len(ts) - 1)]
+            by_pos = want[:, :32].T.reshape(-1)[: length - m + 1]
+            hits = list(lm.Scanner(pssm, seq, threshold=t))
+            wpos = np.nonzero(by_pos >= np.float32(t))[0]
+            assert [h.position for h in hits] == wpos.tolist()
+            assert np.array_equal(bits([h.score for h in hits]), bits(by_pos[wpos]))
+    finally:
+        pli.set_rows_per_stream(0)
+        pli.set_prefilter(True)
