@@ -336,8 +336,8 @@ static std::vector<JobGroup> group_jobs(const lm_hip_ctx *ctx, const ScoreArgs *
 // Fused score+argmax of `n` independent jobs (one motif each): the n scoring kernels
 // are enqueued back to back, each leaving per-workgroup records in its own region,
 // then ONE finalize launch reduces every job and ONE synchronisation returns.
-int launch_score_argmax_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
-                              int first_cell_rule, ArgmaxRecord *out)
+static int launch_score_argmax_exact(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
+                                     int first_cell_rule, ArgmaxRecord *out)
 {
     if (n == 0)
         return LM_HIP_OK;
@@ -444,11 +444,6 @@ int launch_score_argmax_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
     return LM_HIP_OK;
 }
 
-int launch_score_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, int first_cell_rule,
-                        ArgmaxRecord *out)
-{
-    return launch_score_argmax_batch(ctx, &a, 1, first_cell_rule, out);
-}
 
 // ---- fused threshold --------------------------------------------------------------------
 
@@ -717,6 +712,371 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
         return st;
     }
     return fail(LM_HIP_ERR_HIP, "fused threshold: hit list kept overflowing");
+}
+
+// ---- fused argmax through the prefilter ---------------------------------------------------------
+//
+// For large inputs the maximum is found like the Scanner finds hits: (1) the exact scores of
+// an evenly spread SAMPLE of the job's rows give a lower bound L of the maximum (it IS a score of
+// the matrix); (2) the packed 16-bit prefilter scan flags every row range that may hold a
+// score >= L; (3) `rescore_candidates` turns them into exact hits -- all cells with score
+// >= L, so the maximum and every tie of it are among them; (4) the hit list is reduced with
+// the Generic rule: greatest score, ties -> greatest row-major index (pli/mod.rs:144-151).
+// The scan costs half the LDS traffic and adds of the exact kernel (0.42 vs 0.66 ms per Gbp
+// at M = 20); sample, re-scoring and reduction add a few tens of microseconds.  PSSMs with
+// a prefilter have no NaN / +inf weights, so no score is NaN and the first-cell rule is
+// moot.  Jobs whose sample is all -inf, or whose lists overflow (many cells tie with the
+// bound), are left to the exact kernel.
+
+struct SampleJob {
+    const uint8_t *seq;  // row `row_begin` of the striped matrix (C = 32, stride 32)
+    const float *dense;  // M x K weights
+    unsigned m, k;
+    unsigned long long nchunks, stride;  // chunk c starts at row c * stride
+    double pre_offset, pre_factor, pre_emax;
+};
+
+__device__ __forceinline__ unsigned ordered_bits(float v)
+{
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone map f32 -> u32 (no NaN here)
+}
+__device__ __forceinline__ float from_ordered_bits(unsigned k)
+{
+    return __builtin_bit_cast(float, (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+constexpr unsigned kOrderedNegInf = 0x007fffffu;  // ordered_bits(-inf)
+
+// grid (blocks, jobs): exact scores of `nchunks` chunks of kSampleRows x 32 cells spread evenly
+// over the job's rows.  Chunks, not single cells: a lone cell costs M cache sectors for M
+// bytes (3.9 M scattered cells = 1.3 ms), a chunk reads its rows once.
+constexpr unsigned kSampleRows = kBlock / 32;  // one row per half-wave: a chunk is one pass of the block
+__global__ __launch_bounds__(kBlock) void argmax_sample(const SampleJob *__restrict__ jobs,
+                                                        unsigned *__restrict__ bound)
+{
+    const SampleJob jb = jobs[blockIdx.y];
+    unsigned best = kOrderedNegInf;
+    const unsigned col = threadIdx.x & 31, sub = threadIdx.x >> 5;
+    for (unsigned long long c = blockIdx.x; c < jb.nchunks; c += gridDim.x) {
+        const unsigned long long r0 = c * jb.stride;  // chunk rows r0 .. r0 + kSampleRows - 1
+        const uint8_t *p = jb.seq + (r0 + sub) * 32 + col;
+        float sc = 0.0f;
+        unsigned j = 0;
+        for (; j + 4 <= jb.m; j += 4) {  // 4 independent symbol loads, then 4 independent weights
+            unsigned sy[4];
+            float w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                sy[q] = p[(j + q) * 32];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                w[q] = jb.dense[(j + q) * jb.k + sy[q]];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                sc = sc + w[q];
+        }
+        for (; j < jb.m; ++j)
+            sc = sc + jb.dense[j * jb.k + p[j * 32]];
+        const unsigned key = ordered_bits(sc);
+        best = key > best ? key : best;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = __shfl_xor(best, off);
+        best = o > best ? o : best;
+    }
+    // one atomic per workgroup: same-address atomics serialise at ~6 ns each
+    __shared__ unsigned wave_best[kBlock / 64];
+    if ((threadIdx.x & 63) == 0)
+        wave_best[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w)
+            best = wave_best[w] > best ? wave_best[w] : best;
+        if (best != kOrderedNegInf)
+            atomicMax(&bound[blockIdx.y], best);
+    }
+}
+
+// one thread per job: lower bound -> f32 threshold of the re-scoring and discrete threshold
+// of the scan (same formula as launch_score_threshold_batch); td = 0xffffffff = "skip"
+__global__ void argmax_prepare(const SampleJob *__restrict__ jobs, const unsigned n,
+                               const unsigned *__restrict__ bound, RescoreJob *__restrict__ rjobs,
+                               BatchParams *__restrict__ bparams)
+{
+    const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n)
+        return;
+    unsigned td = 0xffffffffu;
+    float t = INFINITY;
+    if (bound[j] != kOrderedNegInf) {
+        t = from_ordered_bits(bound[j]);
+        const double scaled = floor(((double)t - jobs[j].pre_offset) / jobs[j].pre_factor) -
+                              ceil(jobs[j].pre_emax / jobs[j].pre_factor) - 1.0;
+        if (scaled >= 1.0)
+            td = scaled > 65535.0 ? 65535u : (unsigned)scaled;
+        else
+            t = INFINITY;  // the bound is too low for the 16-bit range: leave the job to the exact kernel
+    }
+    rjobs[j].threshold = t;
+    bparams[j].td = td;
+}
+
+// reduction of the hit list: per job the greatest score, then the greatest key among its ties
+__global__ __launch_bounds__(kBlock) void hits_best_value(const HitRecord *__restrict__ hits,
+                                                          const unsigned long long *__restrict__ count,
+                                                          const unsigned long long capacity,
+                                                          unsigned *__restrict__ best_value)
+{
+    unsigned long long n = *count;
+    if (n > capacity)
+        n = capacity;
+    // the list is clustered by job: when a wavefront's records belong to one job it
+    // reduces them first and issues ONE atomic
+    const unsigned long long span = (unsigned long long)gridDim.x * kBlock;
+    for (unsigned long long i0 = (unsigned long long)blockIdx.x * kBlock; i0 < n; i0 += span) {
+        const unsigned long long i = i0 + threadIdx.x;
+        const bool live = i < n;
+        const unsigned long long job = live ? hits[i].key >> 40 : ~0ull;
+        unsigned v = live ? ordered_bits(hits[i].value) : 0u;
+        const unsigned long long job0 = __shfl(job, 0);
+        if (__all(job == job0 || !live)) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned o = __shfl_xor(v, off);
+                v = o > v ? o : v;
+            }
+            if ((threadIdx.x & 63) == 0 && job0 != ~0ull)
+                atomicMax(&best_value[job0], v);
+        } else if (live) {
+            atomicMax(&best_value[job], v);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void hits_best_key(const HitRecord *__restrict__ hits,
+                                                        const unsigned long long *__restrict__ count,
+                                                        const unsigned long long capacity,
+                                                        const unsigned *__restrict__ best_value,
+                                                        unsigned long long *__restrict__ best_key)
+{
+    unsigned long long n = *count;
+    if (n > capacity)
+        n = capacity;
+    const unsigned long long span = (unsigned long long)gridDim.x * kBlock;
+    for (unsigned long long i0 = (unsigned long long)blockIdx.x * kBlock; i0 < n; i0 += span) {
+        const unsigned long long i = i0 + threadIdx.x;
+        const bool live = i < n;
+        HitRecord h{};
+        if (live)
+            h = hits[i];
+        const unsigned long long job = live ? h.key >> 40 : ~0ull;
+        // 0 = none / not a tie of the job's best score
+        unsigned long long k = (live && ordered_bits(h.value) == best_value[job])
+                                   ? (h.key & ((1ull << 40) - 1)) + 1 : 0ull;
+        const unsigned long long job0 = __shfl(job, 0);
+        if (__all(job == job0 || !live)) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long o = __shfl_xor(k, off);
+                k = o > k ? o : k;
+            }
+            if ((threadIdx.x & 63) == 0 && k != 0)
+                atomicMax(&best_key[job0], k);
+        } else if (k != 0) {
+            atomicMax(&best_key[job], k);
+        }
+    }
+}
+
+__global__ void argmax_collect(const unsigned n, const unsigned *__restrict__ best_value,
+                               const unsigned long long *__restrict__ best_key,
+                               ArgmaxRecord *__restrict__ out)
+{
+    const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n)
+        return;
+    ArgmaxRecord r;
+    r.found = best_key[j] != 0;
+    r.value = from_ordered_bits(best_value[j]);
+    r.index = (long long)best_key[j] - 1;
+    out[j] = r;
+}
+
+constexpr unsigned long long kPrefilterArgmaxMinCells = 32ull << 20;  // below: launch-latency bound
+
+// Tries the candidate route for the jobs that qualify; done[i] = 1 and out[i] filled for
+// the ones it settled.  Anything else (small jobs, odd shapes, no prefilter, all -inf
+// samples, list overflow) is left for the exact kernel.
+static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n, ArgmaxRecord *out,
+                               char *done)
+{
+    std::vector<size_t> pick;
+    for (size_t i = 0; i < n; ++i) {
+        const ScoreArgs &a = jobs[i];
+        const unsigned long long cells = (unsigned long long)(a.row_end - a.row_begin) * a.cols;
+        // short motifs have few distinct scores: the best k-mer alone occurs cells / (K-1)^M
+        // times and every occurrence is a hit -- only worth it while that stays ~ the sample rate
+        const double kmers = std::pow((double)(a.pssm->k - 1), (double)a.pssm->m);
+        if (a.pssm->has_prefilter && a.pssm->m >= 2 && cells >= kPrefilterArgmaxMinCells &&
+            cells < (1ull << 40) && kmers >= (double)cells / 512.0 && plan_c32(ctx, a, false, true).ok)
+            pick.push_back(i);
+    }
+    const size_t nq = pick.size();
+    if (nq == 0 || nq > (1u << 20))
+        return LM_HIP_OK;
+    std::vector<ScoreArgs> qjobs(nq);
+    std::vector<SampleJob> sjobs(nq);
+    std::vector<RescoreJob> rjobs(nq);
+    unsigned long long max_chunks = 0;
+    for (size_t q = 0; q < nq; ++q) {
+        const ScoreArgs &a = jobs[pick[q]];
+        qjobs[q] = a;
+        // 1/1024 of the rows, in chunks of kSampleRows rows spread evenly (rows >= 2^20 here)
+        const unsigned long long rows = a.row_end - a.row_begin;
+        const unsigned long long nchunks = std::max<unsigned long long>(rows / 1024 / kSampleRows, 32);
+        max_chunks = std::max(max_chunks, nchunks);
+        sjobs[q] = SampleJob{a.d_seq + a.row_begin * a.seq_stride, a.pssm->d_dense, (unsigned)a.pssm->m,
+                             (unsigned)a.pssm->k, nchunks, (rows - kSampleRows) / (nchunks - 1),
+                             a.pssm->pre_offset, a.pssm->pre_factor, a.pssm->pre_emax};
+        rjobs[q] = RescoreJob{sjobs[q].seq, a.pssm->d_dense, (unsigned)a.pssm->m, (unsigned)a.pssm->k,
+                              INFINITY, 0, 0};
+    }
+    const std::vector<JobGroup> groups =
+        group_jobs(ctx, qjobs.data(), nq, [](size_t) { return (int)KIND_PREFILTER; });
+    std::vector<BatchParams> bparams;  // launch order; rjobs / sjobs are permuted the same way
+    std::vector<size_t> order;
+    for (const JobGroup &g : groups)
+        for (size_t q : g.idx)
+            order.push_back(q);
+    std::vector<SampleJob> sj(nq);
+    std::vector<RescoreJob> rj(nq);
+    for (size_t pos = 0; pos < nq; ++pos) {
+        const size_t q = order[pos];
+        sj[pos] = sjobs[q];
+        rj[pos] = rjobs[q];
+        bparams.push_back(BatchParams{qjobs[q].pssm->d_image, nullptr, 0.0f, 0xffffffffu,
+                                      (unsigned long long)pos << 40});
+    }
+    // ~1024 cells tie with or beat the bound of a 1/1024 sample; leave room for 8x that
+    const unsigned long long cap = nq * 8192 + (1 << 16), ccap = 4 * cap;
+    const size_t off_bound = 16, off_bval = off_bound + (nq * 4 + 15) / 16 * 16;
+    const size_t off_bkey = off_bval + (nq * 4 + 15) / 16 * 16;
+    const size_t off_hits = off_bkey + nq * 8;
+    const size_t off_cands = off_hits + cap * sizeof(HitRecord);
+    const size_t off_rj = off_cands + ccap * sizeof(Candidate);
+    const size_t off_bp = off_rj + (nq * sizeof(RescoreJob) + 15) / 16 * 16;
+    const size_t off_sj = off_bp + (nq * sizeof(BatchParams) + 15) / 16 * 16;
+    const size_t off_res = off_sj + (nq * sizeof(SampleJob) + 15) / 16 * 16;
+    LM_TRY(ctx->scratch.reserve(off_res + nq * sizeof(ArgmaxRecord)));
+    char *base = static_cast<char *>(ctx->scratch.ptr);
+    FusedOut fo{};
+    fo.hit_count = reinterpret_cast<unsigned long long *>(base);
+    fo.cand_count = fo.hit_count + 1;
+    unsigned *d_bound = reinterpret_cast<unsigned *>(base + off_bound);
+    unsigned *d_bval = reinterpret_cast<unsigned *>(base + off_bval);
+    unsigned long long *d_bkey = reinterpret_cast<unsigned long long *>(base + off_bkey);
+    fo.hits = reinterpret_cast<HitRecord *>(base + off_hits);
+    fo.hit_capacity = cap;
+    fo.cands = reinterpret_cast<Candidate *>(base + off_cands);
+    fo.cand_capacity = ccap;
+    RescoreJob *d_rj = reinterpret_cast<RescoreJob *>(base + off_rj);
+    BatchParams *d_bp = reinterpret_cast<BatchParams *>(base + off_bp);
+    SampleJob *d_sj = reinterpret_cast<SampleJob *>(base + off_sj);
+    ArgmaxRecord *d_res = reinterpret_cast<ArgmaxRecord *>(base + off_res);
+    hipStream_t st = ctx->stream;
+    // ordered_bits(-inf) = 0x007fffff: byte-wise memset cannot write it, a tiny fill can
+    LM_HIP_TRY(hipMemsetAsync(base, 0, off_hits, st));
+    std::vector<unsigned> init(nq, kOrderedNegInf);
+    LM_HIP_TRY(hipMemcpyAsync(d_bound, init.data(), nq * 4, hipMemcpyHostToDevice, st));
+    LM_HIP_TRY(hipMemcpyAsync(d_bval, init.data(), nq * 4, hipMemcpyHostToDevice, st));
+    LM_HIP_TRY(hipMemcpyAsync(d_rj, rj.data(), nq * sizeof(RescoreJob), hipMemcpyHostToDevice, st));
+    LM_HIP_TRY(hipMemcpyAsync(d_bp, bparams.data(), nq * sizeof(BatchParams), hipMemcpyHostToDevice, st));
+    LM_HIP_TRY(hipMemcpyAsync(d_sj, sj.data(), nq * sizeof(SampleJob), hipMemcpyHostToDevice, st));
+    const unsigned sgrid = (unsigned)std::min<unsigned long long>(
+        max_chunks, std::max<unsigned long long>((unsigned long long)ctx->num_cus * 8 / nq, 16));
+    hipLaunchKernelGGL(argmax_sample, dim3(sgrid, (unsigned)nq), dim3(kBlock), 0, st, d_sj, d_bound);
+    hipLaunchKernelGGL(argmax_prepare, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, d_sj,
+                       (unsigned)nq, d_bound, d_rj, d_bp);
+    LM_HIP_TRY(hipGetLastError());
+    const bool two_streams = groups.size() > 1;
+    if (two_streams)
+        LM_TRY(batch_fork(ctx));
+    size_t launch = 0, bp_pos = 0;
+    for (const JobGroup &g : groups) {
+        const ScoreArgs &a = qjobs[g.idx[0]];
+        hipStream_t ls = (two_streams && (launch++ & 1)) ? ctx->aux_stream : st;
+        fo.batch = d_bp + bp_pos;
+        bp_pos += g.idx.size();
+        PrefilterLauncher fn = score_c32_prefilter_lookup((int)a.pssm->m);
+        ctx->last_kernel = "score_c32_prefilter";
+        LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, ls, a.d_seq, a.pssm->d_image, (int)a.pssm->k, a.row_begin,
+                      a.row_end, g.plan.T, g.plan.nstreams, 0xffffffffu, fo));
+    }
+    if (two_streams)
+        LM_TRY(batch_join(ctx));
+    fo.batch = nullptr;
+    hipLaunchKernelGGL(rescore_candidates, dim3((unsigned)ctx->num_cus * 8), dim3(kBlock), 0, st, d_rj, fo);
+    const unsigned hgrid = (unsigned)ctx->num_cus * 2;
+    hipLaunchKernelGGL(hits_best_value, dim3(hgrid), dim3(kBlock), 0, st, fo.hits, fo.hit_count, cap, d_bval);
+    hipLaunchKernelGGL(hits_best_key, dim3(hgrid), dim3(kBlock), 0, st, fo.hits, fo.hit_count, cap, d_bval,
+                       d_bkey);
+    const bool pin = 16 + nq * sizeof(ArgmaxRecord) <= kPinnedBytes;
+    ArgmaxRecord *res = pin ? reinterpret_cast<ArgmaxRecord *>(static_cast<char *>(ctx->pinned) + 16) : d_res;
+    hipLaunchKernelGGL(argmax_collect, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (unsigned)nq,
+                       d_bval, d_bkey, res);
+    LM_HIP_TRY(hipGetLastError());
+    std::vector<ArgmaxRecord> host_res(pin ? 0 : nq);
+    LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, base, 16, hipMemcpyDeviceToHost, st));
+    if (!pin)
+        LM_HIP_TRY(hipMemcpyAsync(host_res.data(), d_res, nq * sizeof(ArgmaxRecord), hipMemcpyDeviceToHost, st));
+    LM_HIP_TRY(hipStreamSynchronize(st));
+    const unsigned long long nhits = static_cast<unsigned long long *>(ctx->pinned)[0];
+    const unsigned long long ncand = static_cast<unsigned long long *>(ctx->pinned)[1];
+    if (nhits > cap || ncand > ccap)
+        return LM_HIP_OK;  // truncated lists prove nothing: the exact kernel takes over
+    const ArgmaxRecord *r = pin ? res : host_res.data();
+    for (size_t pos = 0; pos < nq; ++pos)
+        if (r[pos].found) {
+            const size_t i = pick[order[pos]];
+            out[i] = r[pos];
+            done[i] = 1;
+        }
+    return LM_HIP_OK;
+}
+
+// Fused score+argmax of `n` independent jobs: the candidate route where it applies, the
+// exact kernel for the rest.
+int launch_score_argmax_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
+                              int first_cell_rule, ArgmaxRecord *out)
+{
+    if (n == 0)
+        return LM_HIP_OK;
+    std::vector<char> done(n, 0);
+    if (ctx->use_prefilter)
+        LM_TRY(argmax_by_prefilter(ctx, jobs, n, out, done.data()));
+    std::vector<ScoreArgs> rest;
+    std::vector<size_t> rest_idx;
+    for (size_t i = 0; i < n; ++i)
+        if (!done[i]) {
+            rest.push_back(jobs[i]);
+            rest_idx.push_back(i);
+        }
+    if (rest.empty())
+        return LM_HIP_OK;
+    if (rest.size() == n)
+        return launch_score_argmax_exact(ctx, jobs, n, first_cell_rule, out);
+    std::vector<ArgmaxRecord> recs(rest.size());
+    LM_TRY(launch_score_argmax_exact(ctx, rest.data(), rest.size(), first_cell_rule, recs.data()));
+    for (size_t k = 0; k < rest.size(); ++k)
+        out[rest_idx[k]] = recs[k];
+    return LM_HIP_OK;
+}
+
+int launch_score_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, int first_cell_rule,
+                        ArgmaxRecord *out)
+{
+    return launch_score_argmax_batch(ctx, &a, 1, first_cell_rule, out);
 }
 
 int finalize_argmax_materialised(lm_hip_ctx *ctx, const ArgmaxRecord *d_blocks, unsigned nblocks,

@@ -173,3 +173,52 @@ def test_more_positions_than_u32_max(gpu_pli):
     f_hits, _ = pli.score_threshold_dptr(pssm, seq.data_ptr(), rows + m - 1, COLS, COLS, m - 1, length,
                                          0, rows, got[1] - 1e-3)
     assert np.array_equal(f_hits, hits)
+
+
+@pytest.mark.parametrize("kind", ["normal", "ties", "late_maximum", "mostly_n"])
+def test_fused_argmax_candidate_route_against_oracle(gpu_pli, kind):
+    """Above 32 Mi cells the fused argmax takes the sample -> prefilter scan -> exact re-scoring
+    route (score.hip: argmax_by_prefilter).  It must return the Generic answer -- the LAST
+    maximal cell -- also when many cells tie (lists overflow -> exact kernel), when the sample
+    misses the region holding the maximum, and when most of the sample is -inf."""
+    import lightmotif_amd as lm
+    from oracle import c_oracle as co
+    pli = gpu_pli
+    rng = np.random.default_rng({"normal": 1, "ties": 2, "late_maximum": 3, "mostly_n": 4}[kind])
+    length, m = 34_000_123, 16
+    enc = rng.integers(0, 4, length, dtype=np.uint8)
+    p = np.zeros((m, 8), np.float32)
+    p[:, :4] = rng.integers(-2, 3, (m, 4)) if kind == "ties" else rng.normal(0, 2, (m, 4))
+    p[:, 4] = -np.inf
+    if kind == "late_maximum":
+        # the consensus occurs exactly once, in the last striped rows of the last column
+        best = "".join("ACTG"[i] for i in p[:, :4].argmax(axis=1))
+        enc[length - 40:length - 40 + m] = [("ACTG").index(ch) for ch in best]
+    if kind == "mostly_n":
+        enc[rng.random(length) < 0.97] = 4
+    ref = co.stripe(enc, 32, 5)
+    co.configure_wrap(ref, m - 1)
+    want, _ = co.score_rows(ref, p)
+    seq = pli.stripe(lm.EncodedSequence(enc), 32)
+    seq.configure_wrap(m - 1)
+    pssm = lm.ScoringMatrix(p)
+    got = pli.score_argmax(pssm, seq)
+    assert got[0] == co.argmax(want, 32)
+    assert np.float32(got[1]).view(np.uint32) == np.float32(co.max_(want, 32)).view(np.uint32)
+    if kind == "normal":
+        assert pli.last_kernel == "score_c32_prefilter"
+        pli.set_prefilter(False)
+        try:
+            assert pli.score_argmax(pssm, seq) == got and pli.last_kernel.startswith("score_c32<16,1>")
+        finally:
+            pli.set_prefilter(True)
+    # a batch mixing a qualifying motif, a short one (too many ties -> exact kernel) and a long one
+    others = [lm.ScoringMatrix(np.ascontiguousarray(p[:5])), pssm,
+              lm.ScoringMatrix(np.concatenate([p, p[:4]]))]
+    seq.configure_wrap(19)
+    ref20 = co.stripe(enc, 32, 5)
+    co.configure_wrap(ref20, 19)
+    res = pli.scan_argmax_batch(others, seq)
+    for q, r in zip(others, res):
+        w, _ = co.score_rows(ref20, q.data)
+        assert r[0] == co.argmax(w, 32), len(q)
