@@ -121,7 +121,9 @@ def config3(pli):
             "fused_threshold_s": round(t_th, 4), "fused_threshold_Gcell_per_s": round(cells / t_th / 1e9, 1),
             "threshold_hits_total": int(sum(len(r[0]) for r in res)),
             "lds_gather_ceiling_Tlookup_per_s": 39.3,
-            "note": "sequence (100 MB) stays in L2/Infinity Cache; LDS-gather bound, no HBM fraction quoted"}
+            "note": "sequence (100 MB) stays in L2/Infinity Cache; LDS-gather bound, no HBM fraction quoted; "
+                    "lookups/s counts M f32 lookups per cell although motifs with 4^M >= cells/512 take the "
+                    "packed-u16 candidate route (DESIGN 4.1c), so it is an equivalent rate"}
 
 
 def config5(pli):
