@@ -52,13 +52,24 @@ __device__ __forceinline__ unsigned pk_add_u16(unsigned a, unsigned b)
     return __builtin_bit_cast(unsigned, (u16x2)(x + y));
 }
 
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b)
+{
+    const u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(x, y));
+}
+
+// `mx` collects (packed max) every register that holds a just-completed sum.  Its other half
+// is the partial sum of an output still in flight; weights are >= 0, so a partial sum that
+// reaches td belongs to an output that will reach it too -- taking it into the maximum can
+// only flag a group early (an extra exact re-scoring), never hide a hit.  One v_pk_max_u16
+// per step instead of extract + compare + select.
 template <int M, int PF, int PHASE>
 __device__ __forceinline__ void prefilter_group(unsigned (&acc2)[prefilter_mp(M) / 2],
                                                 unsigned (&sym)[prefilter_mp(M)],
                                                 const uint8_t *__restrict__ sp,
                                                 const char *__restrict__ tab_even,
                                                 const char *__restrict__ tab_odd,
-                                                const unsigned td, unsigned &flag)
+                                                unsigned &mx)
 {
     constexpr int MP = prefilter_mp(M);
     constexpr int NP = MP / 2;
@@ -99,11 +110,8 @@ __device__ __forceinline__ void prefilter_group(unsigned (&acc2)[prefilter_mp(M)
         // slot (k+1) mod MP received its last weight: compare, then clear it for the
         // output that starts in it at the next step
         const int sc = (k + 1) % MP;
-        const unsigned v = (sc & 1) ? (acc2[sc / 2] >> 16) : (acc2[sc / 2] & 0xffffu);
-        if (PHASE != PHASE_FIRST || k == MP - 1) {
-            if (v >= td)
-                flag = 1;
-        }
+        if (PHASE != PHASE_FIRST || k == MP - 1)
+            mx = pk_max_u16(mx, acc2[sc / 2]);
         acc2[sc / 2] &= (sc & 1) ? 0x0000ffffu : 0xffff0000u;
     }
 }
@@ -178,25 +186,26 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter(
     unsigned long long hit_groups = 0;
     const unsigned long long G = (ngroups + 63) / 64;  // groups per bit
     unsigned long long gbit = 1, gleft = G;
-    unsigned flag = 0;
+    unsigned mx = 0;
     auto note_group = [&]() {
+        const bool flag = (mx & 0xffffu) >= td || (mx >> 16) >= td;
         hit_groups |= flag ? gbit : 0ull;
-        flag = 0;
+        mx = 0;
         if (--gleft == 0) {
             gleft = G;
             gbit <<= 1;
         }
     };
 
-    prefilter_group<M, PFE, PHASE_FIRST>(acc2, sym, sp, tab_even, tab_odd, td, flag);
+    prefilter_group<M, PFE, PHASE_FIRST>(acc2, sym, sp, tab_even, tab_odd, mx);
     note_group();
     for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
         sp += MP * 32;
-        prefilter_group<M, PFE, PHASE_MAIN>(acc2, sym, sp, tab_even, tab_odd, td, flag);
+        prefilter_group<M, PFE, PHASE_MAIN>(acc2, sym, sp, tab_even, tab_odd, mx);
         note_group();
     }
     sp += MP * 32;
-    prefilter_group<M, PFE, PHASE_LAST>(acc2, sym, sp, tab_even, tab_odd, td, flag);
+    prefilter_group<M, PFE, PHASE_LAST>(acc2, sym, sp, tab_even, tab_odd, mx);
     note_group();
 
     // the flagged groups become candidates for exact re-scoring (outputs are counted from the stream's
