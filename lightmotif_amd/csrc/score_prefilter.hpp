@@ -10,7 +10,8 @@
 //
 //   * weights are u16 (the reference uses u8 for AVX2's byte shuffles; 16 bits keep
 //     the false-positive rate negligible and cannot overflow: sum <= 65000 + M);
-//   * two accumulators share one VGPR and are advanced by ONE v_pk_add_u16, and a
+//   * two accumulators share one VGPR and are advanced by ONE 32-bit add (sums cannot carry
+//     across the halves), and a
 //     symbol's whole column is M*2 bytes of LDS instead of M*4 -> half the LDS
 //     traffic and half the adds of the f32 kernel, which is LDS-bound;
 //   * flagged row ranges go to the candidate list and are re-scored with the exact
@@ -46,10 +47,13 @@ constexpr int prefilter_image_dw(int m, int k)
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
+// Adds two pairs of u16 accumulators.  No 16-bit sum can exceed 65000 + 2M < 65536 (host
+// side, build_prefilter), so nothing ever carries from the low into the high half and a
+// plain 32-bit add IS the packed add -- v_add_u32 issues at twice the rate of v_pk_add_u16
+// on this part (tools/kbench/valu_bench: 64 vs 38 T lane-instr/s).
 __device__ __forceinline__ unsigned pk_add_u16(unsigned a, unsigned b)
 {
-    const u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
-    return __builtin_bit_cast(unsigned, (u16x2)(x + y));
+    return a + b;
 }
 
 __device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b)
