@@ -13,7 +13,7 @@
 #include <cstring>
 #include <new>
 
-#include "score_prefilter.hpp"
+#include "score_prefilter2.hpp"
 
 namespace lm {
 
@@ -90,7 +90,7 @@ static int check_score_args(const lm_hip_pssm *pssm, size_t seq_rows_total, size
 // and the affine map discrete ~ (score - offset) / factor.  Follows the
 // idea of DiscreteMatrix (pwm/mod.rs:665-696: per-row offsets, one global factor,
 // weights rounded UP) on 16 bits.  Returns false when no sound prefilter exists.
-static bool build_prefilter(lm_hip_pssm &p, std::vector<unsigned> *image)
+static bool build_prefilter(lm_hip_pssm &p, std::vector<unsigned> *image, std::vector<unsigned> *image2)
 {
     const int m = (int)p.m, k = (int)p.k;
     if (m < 1 || p.wide)
@@ -144,6 +144,27 @@ static bool build_prefilter(lm_hip_pssm &p, std::vector<unsigned> *image)
             even[(size_t)s * dsd + w] = e_lo | (e_hi << 16);
             odd[(size_t)s * dsd + w] = o_lo | (o_hi << 16);
         }
+    // pair-symbol table of score_c32_prefilter2<M> (DNA only): row (a, b) holds
+    // E[e] = d[e-1][a] + d[e][b] over the motif padded to an ODD length M' by a leading
+    // zero row; dword m = (lo E[2m+1], hi E[2m]).  Same weights, same sums, same bound.
+    image2->clear();
+    if (k == 5) {
+        const int mo = prefilter2_mo(m), shift2 = mo - m, np2 = prefilter2_npair(m);
+        const int dsd2 = prefilter2_stride_dw(m);
+        auto dq = [&](int j, int s) -> unsigned {  // padded discrete weight, 0 outside 0..mo-1
+            if (j < shift2 || j >= mo)
+                return 0u;
+            return d[(size_t)(j - shift2 + shift) * k + s];
+        };
+        image2->assign((size_t)prefilter2_image_dw(m), 0u);
+        for (int a = 0; a < 5; ++a)
+            for (int b = 0; b < 5; ++b) {
+                unsigned *row = image2->data() + (size_t)dna_pair_row((unsigned)a, (unsigned)b) * dsd2;
+                auto entry = [&](int e) -> unsigned { return e > mo ? 0u : dq(e - 1, a) + dq(e, b); };
+                for (int w = 0; w < np2; ++w)
+                    row[w] = entry(2 * w + 1) | (entry(2 * w) << 16);
+            }
+    }
     p.pre_offset = offset;
     p.pre_factor = factor;
     // |f32 sum - real sum| <= (M-1) * 2^-24 * sum |terms|  (each add rounds to nearest)
@@ -231,6 +252,8 @@ static int ctx_create(int device, void *stream, bool borrow, lm_hip_ctx **out)
         return fail(LM_HIP_ERR_OOM, "out of host memory");
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
+    if (const char *e = getenv("LM_HIP_PAIR_PREFILTER"))  // A/B switch: 0 = one symbol per lookup
+        ctx->pair_prefilter = atoi(e) != 0;
     if (borrow) {
         ctx->stream = static_cast<hipStream_t>(stream);
         ctx->owns_stream = false;
@@ -384,7 +407,8 @@ int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stri
             // discrete prefilter image (score_prefilter.hpp); absent when the matrix has
             // NaN / +inf entries or no spread -- the exact f32 fused kernel is used then
             std::vector<unsigned> image;
-            if (build_prefilter(*p, &image)) {
+            std::vector<unsigned> image2;
+            if (build_prefilter(*p, &image, &image2)) {
                 e = hipMalloc(&p->d_image, image.size() * sizeof(unsigned));
                 if (e != hipSuccess)
                     return cleanup(fail(LM_HIP_ERR_OOM, "hipMalloc(prefilter) failed: %s", hipGetErrorString(e)));
@@ -394,6 +418,17 @@ int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stri
                     e = hipStreamSynchronize(ctx->stream);
                 if (e != hipSuccess)
                     return cleanup(fail(LM_HIP_ERR_HIP, "prefilter upload failed: %s", hipGetErrorString(e)));
+                if (!image2.empty()) {  // DNA: pair-symbol table (score_prefilter2.hpp)
+                    e = hipMalloc(&p->d_image2, image2.size() * sizeof(unsigned));
+                    if (e == hipSuccess)
+                        e = hipMemcpyAsync(p->d_image2, image2.data(), image2.size() * sizeof(unsigned),
+                                           hipMemcpyHostToDevice, ctx->stream);
+                    if (e == hipSuccess)
+                        e = hipStreamSynchronize(ctx->stream);
+                    if (e != hipSuccess)
+                        return cleanup(fail(LM_HIP_ERR_HIP, "pair prefilter upload failed: %s",
+                                            hipGetErrorString(e)));
+                }
                 p->has_prefilter = true;
             }
         }
@@ -416,6 +451,8 @@ int lm_hip_pssm_destroy(lm_hip_pssm *p)
         (void)hipFree(p->d_table);
     if (p->d_image)
         (void)hipFree(p->d_image);
+    if (p->d_image2)
+        (void)hipFree(p->d_image2);
     delete p;
     return LM_HIP_OK;
 }

@@ -68,6 +68,7 @@ struct lm_hip_ctx {
     size_t rows_per_stream = 0; // 0 = default
     bool use_prefilter = true;  // fused threshold: packed 16-bit discrete prefilter (A/B knob)
     bool xcd_remap = false;      // A/B knob of the store kernel (lm_hip_ctx_set_xcd_remap)
+    bool pair_prefilter = true;  // DNA prefilter scans look up two symbols at a time
     int num_cus = 256;
     unsigned long long last_hit_count = 0;  // sizes the next fused-threshold hit list
     unsigned long long last_cand_count = 0; // ... and its candidate list
@@ -89,6 +90,7 @@ struct lm_hip_pssm {
     // (u16 layout EVEN | u16 layout ODD) and the affine map
     // discrete = (score - pre_offset) / pre_factor, pre_emax = f32 rounding-error bound.
     unsigned *d_image = nullptr;
+    unsigned *d_image2 = nullptr;  // DNA only: pair-symbol table of score_prefilter2.hpp
     bool has_prefilter = false;
     double pre_offset = 0, pre_factor = 0, pre_emax = 0;
 };

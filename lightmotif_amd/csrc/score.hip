@@ -12,38 +12,48 @@
 #include <tuple>
 #include <numeric>
 
-#include "score_prefilter.hpp"
+#include "score_prefilter2.hpp"
 
 namespace lm {
 
 // ---- registry of the unrolled C=32 kernels ---------------------------------------
 
-void register_score_c32_0(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre);
-void register_score_c32_1(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre);
-void register_score_c32_2(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre);
-void register_score_c32_3(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre);
-void register_score_c32_4(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre);
-void register_score_c32_5(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre);
-void register_score_c32_6(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre);
-void register_score_c32_7(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre);
-void register_score_c32_8(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre);
+void register_score_c32_0(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre,
+                          PrefilterLauncher *pre2);
+void register_score_c32_1(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre,
+                          PrefilterLauncher *pre2);
+void register_score_c32_2(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre,
+                          PrefilterLauncher *pre2);
+void register_score_c32_3(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre,
+                          PrefilterLauncher *pre2);
+void register_score_c32_4(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre,
+                          PrefilterLauncher *pre2);
+void register_score_c32_5(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre,
+                          PrefilterLauncher *pre2);
+void register_score_c32_6(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre,
+                          PrefilterLauncher *pre2);
+void register_score_c32_7(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre,
+                          PrefilterLauncher *pre2);
+void register_score_c32_8(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre,
+                          PrefilterLauncher *pre2);
 
 static ScoreC32Launcher g_c32[kMaxFastM + 1][kRegistrySlots];
 static PrefilterLauncher g_pre[kMaxFastM + 1];
+static PrefilterLauncher g_pre2[kMaxFastM + 1];
 static char g_c32_names[kMaxFastM + 1][3][32];
 static std::once_flag g_c32_once;
 
 static void init_registry()
 {
-    register_score_c32_0(g_c32, g_pre);
-    register_score_c32_1(g_c32, g_pre);
-    register_score_c32_2(g_c32, g_pre);
-    register_score_c32_3(g_c32, g_pre);
-    register_score_c32_4(g_c32, g_pre);
-    register_score_c32_5(g_c32, g_pre);
-    register_score_c32_6(g_c32, g_pre);
-    register_score_c32_7(g_c32, g_pre);
-    register_score_c32_8(g_c32, g_pre);
+    register_score_c32_0(g_c32, g_pre, g_pre2);
+    register_score_c32_1(g_c32, g_pre, g_pre2);
+    register_score_c32_2(g_c32, g_pre, g_pre2);
+    register_score_c32_3(g_c32, g_pre, g_pre2);
+    register_score_c32_4(g_c32, g_pre, g_pre2);
+    register_score_c32_5(g_c32, g_pre, g_pre2);
+    register_score_c32_6(g_c32, g_pre, g_pre2);
+    register_score_c32_7(g_c32, g_pre, g_pre2);
+    register_score_c32_8(g_c32, g_pre, g_pre2);
     for (int m = 0; m <= kMaxFastM; ++m)
         for (int mode = 0; mode < 3; ++mode)
             snprintf(g_c32_names[m][mode], sizeof g_c32_names[m][mode], "score_c32<%d,%d>", m, mode);
@@ -65,6 +75,12 @@ PrefilterLauncher score_c32_prefilter_lookup(int M)
 {
     std::call_once(g_c32_once, init_registry);
     return (M >= 1 && M <= kMaxFastM) ? g_pre[M] : nullptr;
+}
+
+PrefilterLauncher score_c32_prefilter2_lookup(int M)
+{
+    std::call_once(g_c32_once, init_registry);
+    return (M >= 1 && M <= kMaxFastM) ? g_pre2[M] : nullptr;
 }
 
 const char *score_c32_name(int M, int mode)
@@ -93,21 +109,28 @@ struct C32Plan {
 // allocator (kbench6_place.txt, `bench.py --ab`: 1.00 vs 0.97 ms on the same box) --
 // eight distant windows instead of one compact one; the compact window is the
 // robust choice.
-static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store, bool prefilter = false,
+// `prefilter`: 0 = exact kernels, 1 = one-symbol prefilter (streams of q*MP + 1 rows),
+// 2 = pair-symbol prefilter (streams of q*RING + 2 rows)
+static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store, int prefilter = 0,
                         size_t batch = 1)
 {
     C32Plan p;
     const size_t K = a.pssm->k;
-    // the prefilter kernel rotates over the motif padded to an even length
-    const size_t M = prefilter ? (size_t)prefilter_mp((int)a.pssm->m) : a.pssm->m;
+    // rows per unrolled group: the motif length, padded for the prefilter kernels
+    const size_t M = prefilter == 2   ? (size_t)prefilter2_ring((int)a.pssm->m)
+                     : prefilter == 1 ? (size_t)prefilter_mp((int)a.pssm->m)
+                                      : a.pssm->m;
+    const size_t extra = prefilter == 2 ? 2 : 1;  // rows of a stream beyond q groups
     const unsigned long long n = a.row_end - a.row_begin;
     if (a.cols != 32 || a.seq_stride != 32 || (store && a.out_stride != 32))
         return p;
-    if (a.pssm->m < 1 || a.pssm->m > (size_t)kMaxFastM || n < M + 1)
+    if (a.pssm->m < 1 || a.pssm->m > (size_t)kMaxFastM || n < M + extra)
         return p;
-    const size_t lds = prefilter
-        ? (size_t)prefilter_image_dw((int)a.pssm->m, (int)K) * 4
-        : std::max<size_t>(K * table_stride((int)M, a.pssm->wide) * sizeof(float), 64);
+    if (prefilter == 2 && (K != 5 || !a.pssm->d_image2 || a.pssm->m < 2))
+        return p;
+    const size_t lds = prefilter == 2   ? (size_t)prefilter2_image_dw((int)a.pssm->m) * 4
+                       : prefilter == 1 ? (size_t)prefilter_image_dw((int)a.pssm->m, (int)K) * 4
+                                        : std::max<size_t>(K * table_stride((int)M, a.pssm->wide) * sizeof(float), 64);
     if (lds > 60 * 1024)
         return p;
     // The fused kernels write nothing, so they are LDS/VALU-bound and prefer long
@@ -124,11 +147,11 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store, b
         target = std::max<unsigned long long>(n / want_streams, 1);
     target = std::min<unsigned long long>(target, 1ull << 30);  // step indices are 32-bit
     unsigned long long q = std::max<unsigned long long>((target + M / 2) / M, 1);
-    if (q * M + 1 > n)
-        q = (n - 1) / M;
+    if (q * M + extra > n)
+        q = (n - extra) / M;
     if (q < 1)
         return p;
-    p.T = q * M + 1;
+    p.T = q * M + extra;
     p.nstreams = (n + p.T - 1) / p.T;
     p.grid = dim3((unsigned)((p.nstreams + kStreamsPerBlock - 1) / kStreamsPerBlock));
     p.lds = lds;
@@ -295,7 +318,7 @@ __global__ __launch_bounds__(kBlock) void argmax_finalize_batch(const FinalizeJo
 // alphabet and sequence rows.  Many short per-motif launches lose ~15 % to their ramps
 // and to the short streams a small grid needs; a launch per motif LENGTH keeps streams
 // long and the chip full (2 346 JASPAR motifs -> ~50 launches).
-enum : int { KIND_GENERIC = 0, KIND_EXACT = 1, KIND_PREFILTER = 2 };
+enum : int { KIND_GENERIC = 0, KIND_EXACT = 1, KIND_PREFILTER = 2, KIND_PREFILTER2 = 3 };
 struct JobGroup {
     int kind = KIND_GENERIC;
     std::vector<size_t> idx;  // job indices, ascending
@@ -327,7 +350,8 @@ static std::vector<JobGroup> group_jobs(const lm_hip_ctx *ctx, const ScoreArgs *
     }
     for (JobGroup &g : groups)
         if (g.kind != KIND_GENERIC) {
-            g.plan = plan_c32(ctx, jobs[g.idx[0]], false, g.kind == KIND_PREFILTER, g.idx.size());
+            g.plan = plan_c32(ctx, jobs[g.idx[0]], false,
+                              g.kind == KIND_PREFILTER2 ? 2 : (g.kind == KIND_PREFILTER ? 1 : 0), g.idx.size());
             g.plan.grid.y = (unsigned)g.idx.size();
         }
     return groups;
@@ -600,9 +624,12 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
         if (a.pssm->has_prefilter && ctx->use_prefilter && std::isfinite(ts[i])) {
             const double scaled = std::floor(((double)ts[i] - a.pssm->pre_offset) / a.pssm->pre_factor) -
                                   std::ceil(a.pssm->pre_emax / a.pssm->pre_factor) - 1.0;
-            if (scaled >= 1.0 && plan_c32(ctx, a, false, true).ok) {
+            if (scaled >= 1.0) {
                 tds[i] = scaled > 65535.0 ? 65535u : (unsigned)scaled;
-                return (int)KIND_PREFILTER;
+                if (ctx->pair_prefilter && plan_c32(ctx, a, false, 2).ok)
+                    return (int)KIND_PREFILTER2;  // DNA: two symbols per lookup
+                if (plan_c32(ctx, a, false, 1).ok)
+                    return (int)KIND_PREFILTER;
             }
         }
         return plan_c32(ctx, a, false).ok ? (int)KIND_EXACT : (int)KIND_GENERIC;
@@ -616,8 +643,9 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
             const ScoreArgs &a = jobs[i];
             if (keys == HitKeys::Position && a.row_end - a.row_begin != key_rows)
                 return fail(LM_HIP_ERR_BAD_ARGS, "fused threshold: position keys need equal row ranges");
-            bparams.push_back(BatchParams{g.kind == KIND_PREFILTER ? (const void *)a.pssm->d_image
-                                                                   : (const void *)a.pssm->d_table,
+            bparams.push_back(BatchParams{g.kind == KIND_PREFILTER2  ? (const void *)a.pssm->d_image2
+                                          : g.kind == KIND_PREFILTER ? (const void *)a.pssm->d_image
+                                                                     : (const void *)a.pssm->d_table,
                                           nullptr, ts[i], tds[i], (unsigned long long)i << 40});
             rjobs[i] = RescoreJob{a.d_seq + a.row_begin * a.seq_stride, a.pssm->d_dense,
                                   (unsigned)a.pssm->m, (unsigned)a.pssm->k, ts[i], 0, key_rows};
@@ -656,11 +684,13 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
             fo.job_key = (unsigned long long)i << 40;
             fo.batch = (n > 1 && g.kind != KIND_GENERIC) ? d_bparams + bp_pos : nullptr;
             bp_pos += g.idx.size();
-            if (g.kind == KIND_PREFILTER) {
-                PrefilterLauncher fn = score_c32_prefilter_lookup((int)a.pssm->m);
-                ctx->last_kernel = "score_c32_prefilter";
-                LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, a.pssm->d_image, (int)a.pssm->k,
-                              a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, tds[i], fo));
+            if (g.kind == KIND_PREFILTER || g.kind == KIND_PREFILTER2) {
+                const bool pairs = g.kind == KIND_PREFILTER2;
+                PrefilterLauncher fn = pairs ? score_c32_prefilter2_lookup((int)a.pssm->m)
+                                             : score_c32_prefilter_lookup((int)a.pssm->m);
+                ctx->last_kernel = pairs ? "score_c32_prefilter2" : "score_c32_prefilter";
+                LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, pairs ? a.pssm->d_image2 : a.pssm->d_image,
+                              (int)a.pssm->k, a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, tds[i], fo));
                 any_candidates = true;
             } else if (g.kind == KIND_EXACT) {
                 ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_THRESHOLD, false, a.pssm->wide);
@@ -919,7 +949,8 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
         // times and every occurrence is a hit -- only worth it while that stays ~ the sample rate
         const double kmers = std::pow((double)(a.pssm->k - 1), (double)a.pssm->m);
         if (a.pssm->has_prefilter && a.pssm->m >= 2 && cells >= kPrefilterArgmaxMinCells &&
-            cells < (1ull << 40) && kmers >= (double)cells / 512.0 && plan_c32(ctx, a, false, true).ok)
+            cells < (1ull << 40) && kmers >= (double)cells / 512.0 &&
+            (plan_c32(ctx, a, false, 1).ok || plan_c32(ctx, a, false, 2).ok))
             pick.push_back(i);
     }
     const size_t nq = pick.size();
@@ -942,8 +973,14 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
         rjobs[q] = RescoreJob{sjobs[q].seq, a.pssm->d_dense, (unsigned)a.pssm->m, (unsigned)a.pssm->k,
                               INFINITY, 0, 0};
     }
-    const std::vector<JobGroup> groups =
-        group_jobs(ctx, qjobs.data(), nq, [](size_t) { return (int)KIND_PREFILTER; });
+    const std::vector<JobGroup> groups = group_jobs(ctx, qjobs.data(), nq, [&](size_t q) {
+        return (ctx->pair_prefilter && plan_c32(ctx, qjobs[q], false, 2).ok) ? (int)KIND_PREFILTER2
+                                                                             : (int)KIND_PREFILTER;
+    });
+    std::vector<char> pairs_of(nq, 0);
+    for (const JobGroup &g : groups)
+        for (size_t q : g.idx)
+            pairs_of[q] = g.kind == KIND_PREFILTER2;
     std::vector<BatchParams> bparams;  // launch order; rjobs / sjobs are permuted the same way
     std::vector<size_t> order;
     for (const JobGroup &g : groups)
@@ -955,8 +992,8 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
         const size_t q = order[pos];
         sj[pos] = sjobs[q];
         rj[pos] = rjobs[q];
-        bparams.push_back(BatchParams{qjobs[q].pssm->d_image, nullptr, 0.0f, 0xffffffffu,
-                                      (unsigned long long)pos << 40});
+        bparams.push_back(BatchParams{pairs_of[q] ? qjobs[q].pssm->d_image2 : qjobs[q].pssm->d_image, nullptr,
+                                      0.0f, 0xffffffffu, (unsigned long long)pos << 40});
     }
     // ~1024 cells tie with or beat the bound of a 1/1024 sample; leave room for 8x that
     const unsigned long long cap = nq * 8192 + (1 << 16), ccap = 4 * cap;
@@ -1008,10 +1045,12 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
         hipStream_t ls = (two_streams && (launch++ & 1)) ? ctx->aux_stream : st;
         fo.batch = d_bp + bp_pos;
         bp_pos += g.idx.size();
-        PrefilterLauncher fn = score_c32_prefilter_lookup((int)a.pssm->m);
-        ctx->last_kernel = "score_c32_prefilter";
-        LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, ls, a.d_seq, a.pssm->d_image, (int)a.pssm->k, a.row_begin,
-                      a.row_end, g.plan.T, g.plan.nstreams, 0xffffffffu, fo));
+        const bool pairs = g.kind == KIND_PREFILTER2;
+        PrefilterLauncher fn = pairs ? score_c32_prefilter2_lookup((int)a.pssm->m)
+                                     : score_c32_prefilter_lookup((int)a.pssm->m);
+        ctx->last_kernel = pairs ? "score_c32_prefilter2" : "score_c32_prefilter";
+        LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, ls, a.d_seq, pairs ? a.pssm->d_image2 : a.pssm->d_image,
+                      (int)a.pssm->k, a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, 0xffffffffu, fo));
     }
     if (two_streams)
         LM_TRY(batch_join(ctx));

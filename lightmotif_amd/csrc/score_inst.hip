@@ -1,7 +1,7 @@
 // score_inst.hip -- instantiates score_c32<M, MODE> for M in [LM_M_LO, LM_M_HI].
 // Compiled several times with different -DLM_M_LO/-DLM_M_HI/-DLM_INST_ID so the
 // fully unrolled kernels build in parallel (see build.py).
-#include "score_prefilter.hpp"
+#include "score_prefilter2.hpp"
 
 #ifndef LM_M_LO
 #error "LM_M_LO / LM_M_HI / LM_INST_ID must be defined"
@@ -14,9 +14,12 @@ namespace lm {
 
 template <int M>
 struct RegisterRange {
-    static void run(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre)
+    static void run(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre,
+                    PrefilterLauncher *pre2)
     {
         pre[M] = &score_c32_prefilter_launch<M>;
+        if constexpr (M >= 2)
+            pre2[M] = &score_c32_prefilter2_launch<M>;
         tab[M][MODE_STORE] = &score_c32_launch<M, MODE_STORE>;
         tab[M][MODE_ARGMAX] = &score_c32_launch<M, MODE_ARGMAX>;
         tab[M][MODE_THRESHOLD] = &score_c32_launch<M, MODE_THRESHOLD>;
@@ -28,14 +31,14 @@ struct RegisterRange {
         tab[M][4 + MODE_THRESHOLD] = &score_c32_launch<M, MODE_THRESHOLD, LM_SCORE_XCD_REMAP, 1>;
 #endif
         if constexpr (M < LM_M_HI)
-            RegisterRange<M + 1>::run(tab, pre);
+            RegisterRange<M + 1>::run(tab, pre, pre2);
     }
 };
 
 void LM_CAT(register_score_c32_, LM_INST_ID)(ScoreC32Launcher (*tab)[kRegistrySlots],
-                                             PrefilterLauncher *pre)
+                                             PrefilterLauncher *pre, PrefilterLauncher *pre2)
 {
-    RegisterRange<LM_M_LO>::run(tab, pre);
+    RegisterRange<LM_M_LO>::run(tab, pre, pre2);
 }
 
 }  // namespace lm

@@ -1,0 +1,244 @@
+// score_prefilter2.hpp -- DNA prefilter scan over PAIRS of symbols.
+//
+// The discrete prefilter (score_prefilter.hpp) only has to over-estimate, and its weights
+// are integers: their sum does not depend on the order of the additions.  That frees the
+// scan from the one-symbol-per-lookup shape of the exact kernel.  Two consecutive input
+// rows (symbols a, b) are looked up TOGETHER: the LDS table row of the pair holds, for
+// every output they touch, the sum of the two weights they contribute,
+//
+//     E[e][(a, b)] = d[e-1][a] + d[e][b]        e = 0 .. M'   (out-of-range terms are 0)
+//
+// so one row of (M'+1) u16 entries advances all in-flight outputs by two input rows: half
+// the LDS bytes and half the adds per position of the one-symbol prefilter, and a quarter
+// of the exact f32 kernel's.  The table has 25 rows for DNA (K = 5), ordered so that the 16
+// pairs without N occupy rows 0..15 -- distinct 16-byte LDS slots, conflict-free reads.
+//
+// Geometry.  The motif is padded to a length M' = 3 (mod 4) by leading all-zero rows, so
+// M'+1 = RING is a multiple of 4 (see the symbol loads below) and the two outputs completed by a pair of rows always
+// share one accumulator dword: outputs 2t, 2t+1 live in dword t mod NPAIR (NPAIR = RING/2,
+// low half = even output).  At super-step u (input rows 2u, 2u+1 of the stream) dword t
+// receives table dword m = u - t = (lo E[2m+1], hi E[2m]); after m = NPAIR-1 both outputs
+// are complete, the dword joins the packed running maximum and restarts at zero.  One LDS
+// layout suffices (no even/odd step parity).  A stream sweeps T = q*RING + 2 outputs in
+// q+1 groups of NPAIR super-steps; group 0 completes local outputs 0 and 1, group g >= 1
+// the outputs (g-1)*RING + 2 .. g*RING + 1.
+//
+// Everything downstream (group bitmask -> candidates -> exact re-scoring) is shared with
+// score_prefilter.hpp, so the hit lists are bit-identical to the exact kernel's.
+#pragma once
+
+#include "score_prefilter.hpp"
+
+namespace lm {
+
+constexpr int prefilter2_mo(int m) { return m | 3; }                    // padded length M' = 3 (mod 4)
+constexpr int prefilter2_ring(int m) { return prefilter2_mo(m) + 1; }   // input rows per group
+constexpr int prefilter2_npair(int m) { return prefilter2_ring(m) / 2; }
+// dwords per table row: 4 * odd >= NPAIR (rows 0..15 then sit in distinct 16-byte slots)
+constexpr int prefilter2_stride_dw(int m) { return 4 * (((prefilter2_npair(m) + 3) / 4) | 1); }
+constexpr int kPairRows = 25;  // DNA symbol pairs
+constexpr int prefilter2_image_dw(int m) { return kPairRows * prefilter2_stride_dw(m); }
+
+// table row of the pair (a, b): the 16 pairs of A, C, T, G first
+__host__ __device__ __forceinline__ unsigned dna_pair_row(unsigned a, unsigned b)
+{
+    unsigned idx = 4u * a + b;  // a, b < 4: 0..15;  a == 4: 16..20
+    if (b == 4u && a != 4u)
+        idx = 21u + a;          // (a, N), a < 4: 21..24
+    return idx;
+}
+
+// Symbol loads.  A byte load per lane and row moves 64 bytes per wavefront instruction, and
+// at > 3 Tpos/s the scan is bound by that request rate, not by LDS or VALU.  So the lanes
+// of a quad (columns 4i..4i+3) fetch a 4 x 4 block of symbols with ONE dword load each --
+// lane q reads row r+q, columns 4i..4i+3; a half-wave instruction covers 4 rows = 128
+// contiguous bytes -- and every lane picks its column out of its neighbours' registers:
+// symbol(row r+t, own column) = byte (lane & 3) of the dword held by quad lane t (one DPP
+// quad broadcast + one bit-field extract).  RING is a multiple of 4, so blocks never
+// straddle a group; `blk` is a ring of the RING/4 blocks of a group, prefetched PFB ahead.
+template <int T4>
+__device__ __forceinline__ unsigned quad_symbol(unsigned block_dword, unsigned shift)
+{
+    const unsigned x = (unsigned)__builtin_amdgcn_mov_dpp((int)block_dword, T4 * 0x55, 0xf, 0xf, true);
+    return (x >> shift) & 0xffu;
+}
+
+template <int M, int PFB, int PHASE>
+__device__ __forceinline__ void prefilter2_group(unsigned (&acc)[prefilter2_npair(M)],
+                                                 unsigned (&blk)[prefilter2_ring(M) / 4],
+                                                 const uint8_t *__restrict__ spq, const unsigned shq,
+                                                 const char *__restrict__ tab, unsigned &mx)
+{
+    constexpr int RING = prefilter2_ring(M);
+    constexpr int NB = RING / 4;
+    constexpr int NP = prefilter2_npair(M);
+    constexpr int NV = (NP + 3) / 4;
+    constexpr unsigned DSB = prefilter2_stride_dw(M) * 4;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        // this super-step's two symbols: rows 2k, 2k+1 of the group = block k/2, rows (2k)%4, +1
+        const unsigned d = blk[k / 2];
+        const unsigned a = (k & 1) ? quad_symbol<2>(d, shq) : quad_symbol<0>(d, shq);
+        const unsigned b = (k & 1) ? quad_symbol<3>(d, shq) : quad_symbol<1>(d, shq);
+        // a block is free once its second pair is taken: request the block PFB ahead
+        if ((k & 1) && (PHASE != PHASE_LAST || k / 2 + PFB < NB))
+            blk[(k / 2 + PFB) % NB] = *reinterpret_cast<const unsigned *>(spq + (k / 2 + PFB) * 128);
+        const unsigned idx = dna_pair_row(a, b);
+        const char *row = static_cast<const char *>(__builtin_assume_aligned(tab + __umul24(idx, DSB), 16));
+        unsigned w[NV * 4];
+#pragma unroll
+        for (int q = 0; q < NP / 4; ++q) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(row + 16 * q);
+            w[4 * q + 0] = v.x;
+            w[4 * q + 1] = v.y;
+            w[4 * q + 2] = v.z;
+            w[4 * q + 3] = v.w;
+        }
+        if (NP % 4 >= 2) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(row + 16 * (NP / 4));
+            w[4 * (NP / 4) + 0] = v.x;
+            w[4 * (NP / 4) + 1] = v.y;
+        }
+        if (NP % 2 == 1)
+            w[NP - 1] = *reinterpret_cast<const unsigned *>(row + 4 * (NP - 1));
+#pragma unroll
+        for (int m = 0; m < NP; ++m)
+            acc[(k - m + NP) % NP] = pk_add_u16(acc[(k - m + NP) % NP], w[m]);
+        // dword (k+1) mod NP received its last entry: both of its outputs are complete
+        const int c = (k + 1) % NP;
+        if (PHASE != PHASE_FIRST || k == NP - 1)
+            mx = pk_max_u16(mx, acc[c]);
+        acc[c] = 0;
+    }
+}
+
+template <int M>
+__global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter2(
+    const uint8_t *__restrict__ seq, const unsigned *__restrict__ image, const int K,
+    const unsigned long long row_begin, const unsigned long long row_end,
+    const unsigned long long T, const unsigned long long nstreams, unsigned td,
+    const FusedOut fo_in)
+{
+    FusedOut fo = fo_in;
+    if (fo_in.batch) {  // multi-job launch: this block's job (wave-uniform)
+        const BatchParams bp = fo_in.batch[blockIdx.y];
+        image = static_cast<const unsigned *>(bp.table);
+        td = bp.td;
+        fo.job_key = bp.job_key;
+    }
+    (void)K;
+    constexpr int MO = prefilter2_mo(M);
+    constexpr int SHIFT = MO - M;
+    constexpr int RING = prefilter2_ring(M);
+    constexpr int NP = prefilter2_npair(M);
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    {
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
+        const uint4 *src = reinterpret_cast<const uint4 *>(image);
+        constexpr int n4 = prefilter2_image_dw(M) / 4;
+        for (int i = threadIdx.x; i < n4; i += kBlock)
+            dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 31;
+    unsigned long long stream =
+        ((unsigned long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    const bool idle = stream >= nstreams;  // re-does the last stream, reports nothing
+    if (idle)
+        stream = nstreams - 1;
+    unsigned long long o0 = row_begin + stream * T;
+    if (o0 + T > row_end)
+        o0 = row_end - T;
+
+    // padded output l covers input rows (o0 - SHIFT) + l .. + MO - 1; the first SHIFT of them
+    // carry all-zero weight rows, so rows before the matrix are never loaded (their
+    // "symbols" read as 0, a valid table row)
+    const long long in0 = (long long)o0 - SHIFT;               // first input row of the stream
+    const unsigned shq = 8u * (col & 3);
+    const uint8_t *spq = seq + (in0 + (col & 3)) * 32 + (col >> 2) * 4;  // this lane's row of a block
+    constexpr int NB = RING / 4;
+    constexpr int PFB = NB > 3 ? 3 : NB;                       // blocks requested ahead of use (<= NB:
+                                                               // a request reuses a slot only after its last read)
+    unsigned acc[NP];
+    unsigned blk[NB];
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+        acc[i] = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+        blk[j] = 0;
+    // prologue: block 0 (rows in0 .. in0+3; a lane whose row lies before the matrix skips
+    // it) and the next PFB - 1 blocks
+    if (in0 + (long long)(col & 3) >= 0)
+        blk[0] = *reinterpret_cast<const unsigned *>(spq);
+#pragma unroll
+    for (int j = 1; j < PFB; ++j)
+        blk[j] = *reinterpret_cast<const unsigned *>(spq + j * 128);
+
+    const unsigned long long ngroups = (T - 2) / RING + 1;  // exact: T = q*RING + 2
+    unsigned long long hit_groups = 0;
+    const unsigned long long G = (ngroups + 63) / 64;  // groups per bit
+    unsigned long long gbit = 1, gleft = G;
+    unsigned mx = 0;
+    auto note_group = [&]() {
+        const bool flag = (mx & 0xffffu) >= td || (mx >> 16) >= td;
+        hit_groups |= flag ? gbit : 0ull;
+        mx = 0;
+        if (--gleft == 0) {
+            gleft = G;
+            gbit <<= 1;
+        }
+    };
+
+    prefilter2_group<M, PFB, PHASE_FIRST>(acc, blk, spq, shq, lds_raw, mx);
+    note_group();
+    for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
+        spq += RING * 32;
+        prefilter2_group<M, PFB, PHASE_MAIN>(acc, blk, spq, shq, lds_raw, mx);
+        note_group();
+    }
+    if (ngroups > 1) {
+        spq += RING * 32;
+        prefilter2_group<M, PFB, PHASE_LAST>(acc, blk, spq, shq, lds_raw, mx);
+        note_group();
+    }
+
+    // flagged groups -> candidate row ranges (group 0: outputs 0, 1; group g >= 1: outputs
+    // (g-1)*RING + 2 .. g*RING + 1, counted from the stream's first output row)
+    const long long first_row = (long long)(o0 - row_begin);
+    const long long own_row = (long long)(stream * T);
+    if (idle)
+        hit_groups = 0;
+    emit_candidates(hit_groups, col, fo, [=](int bit, long long &r0, long long &r1) {
+        const unsigned long long g0 = (unsigned long long)bit * G;
+        unsigned long long g1 = g0 + G;
+        if (g1 > ngroups)
+            g1 = ngroups;
+        const long long i0 = g0 == 0 ? 0 : (long long)((g0 - 1) * RING + 2);
+        long long i1 = (long long)((g1 - 1) * RING + 2);
+        if (i1 > (long long)T)
+            i1 = (long long)T;
+        r0 = first_row + i0;
+        if (r0 < own_row)
+            r0 = own_row;
+        r1 = first_row + i1;
+    });
+}
+
+template <int M>
+hipError_t score_c32_prefilter2_launch(dim3 grid, size_t lds_bytes, hipStream_t stream,
+                                       const uint8_t *seq, const unsigned *image, int K,
+                                       unsigned long long row_begin, unsigned long long row_end,
+                                       unsigned long long T, unsigned long long nstreams,
+                                       unsigned td, FusedOut fo)
+{
+    hipLaunchKernelGGL((score_c32_prefilter2<M>), grid, dim3(kBlock), lds_bytes, stream, seq, image,
+                       K, row_begin, row_end, T, nstreams, td, fo);
+    return hipGetLastError();
+}
+
+PrefilterLauncher score_c32_prefilter2_lookup(int M);
+
+}  // namespace lm

@@ -428,7 +428,7 @@ def test_prefilter_and_exact_fused_threshold_agree(pli, m, kind):
     # with a meaningful threshold the prefilter kernel is the one that runs
     pli.score_threshold(pssm, seq, float(finite[-50]))
     if m >= 2:
-        assert pli.last_kernel == "score_c32_prefilter"
+        assert pli.last_kernel .startswith("score_c32_prefilter")
 
 
 def test_prefilter_is_skipped_when_it_cannot_be_sound(pli):
