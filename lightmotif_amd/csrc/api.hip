@@ -252,6 +252,8 @@ static int ctx_create(int device, void *stream, bool borrow, lm_hip_ctx **out)
         return fail(LM_HIP_ERR_OOM, "out of host memory");
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
+    if (const char *e = getenv("LM_HIP_QUAD_LOADS"))  // A/B switch of the store kernel's symbol loads
+        ctx->quad_loads = atoi(e) != 0;
     if (const char *e = getenv("LM_HIP_PAIR_PREFILTER"))  // A/B switch: 0 = one symbol per lookup
         ctx->pair_prefilter = atoi(e) != 0;
     if (borrow) {

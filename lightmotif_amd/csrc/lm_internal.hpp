@@ -69,6 +69,7 @@ struct lm_hip_ctx {
     bool use_prefilter = true;  // fused threshold: packed 16-bit discrete prefilter (A/B knob)
     bool xcd_remap = false;      // A/B knob of the store kernel (lm_hip_ctx_set_xcd_remap)
     bool pair_prefilter = true;  // DNA prefilter scans look up two symbols at a time
+    bool quad_loads = true;      // store kernel: quad-gathered dword symbol loads (M % 4 == 0; +1 %)
     int num_cus = 256;
     unsigned long long last_hit_count = 0;  // sizes the next fused-threshold hit list
     unsigned long long last_cand_count = 0; // ... and its candidate list

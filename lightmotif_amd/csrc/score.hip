@@ -83,6 +83,12 @@ PrefilterLauncher score_c32_prefilter2_lookup(int M)
     return (M >= 1 && M <= kMaxFastM) ? g_pre2[M] : nullptr;
 }
 
+ScoreC32Launcher score_c32_lookup_ql(int M)
+{
+    std::call_once(g_c32_once, init_registry);
+    return (M >= 1 && M <= kMaxFastM) ? g_c32[M][7] : nullptr;
+}
+
 const char *score_c32_name(int M, int mode)
 {
     std::call_once(g_c32_once, init_registry);
@@ -198,6 +204,9 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
     const C32Plan p = plan_c32(ctx, a, true);
     if (p.ok) {
         ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_STORE, ctx->xcd_remap, a.pssm->wide);
+        if (ctx->quad_loads && !ctx->xcd_remap && !a.pssm->wide && score_c32_lookup_ql((int)a.pssm->m) &&
+            reinterpret_cast<uintptr_t>(a.d_seq) % 4 == 0)
+            fn = score_c32_lookup_ql((int)a.pssm->m);  // dword symbol loads (M % 4 == 0)
         ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_STORE);
         LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
                       a.row_begin, a.row_end, p.T, p.nstreams, a.d_out, fo));

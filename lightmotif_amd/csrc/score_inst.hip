@@ -24,6 +24,8 @@ struct RegisterRange {
         tab[M][MODE_ARGMAX] = &score_c32_launch<M, MODE_ARGMAX>;
         tab[M][MODE_THRESHOLD] = &score_c32_launch<M, MODE_THRESHOLD>;
         tab[M][3] = &score_c32_launch<M, MODE_STORE, 1>;
+        if constexpr (M % 4 == 0)
+            tab[M][7] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 0, 1>;
 #if defined(LM_SCORE_BUILD_WIDE)
         // 8-byte-read variant for K > 16; not built by default, see api.hip (pssm_create)
         tab[M][4 + MODE_STORE] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1>;

@@ -228,6 +228,17 @@ __device__ __forceinline__ void lds_fetch_column(float (&w)[4 * ((M + 3) / 4)],
     }
 }
 
+// Quad-gathered symbol loads: the lanes of a quad (columns 4i..4i+3) fetch a 4 x 4 block of
+// symbols with ONE dword load each (lane q: row r+q, columns 4i..4i+3) and every lane picks
+// its own column out of its neighbours' registers: symbol(row r+t) = byte (lane & 3) of the
+// dword held by quad lane t.  `shift` = 8 * (lane & 3).
+template <int T4>
+__device__ __forceinline__ unsigned quad_symbol(unsigned block_dword, unsigned shift)
+{
+    const unsigned x = (unsigned)__builtin_amdgcn_mov_dpp((int)block_dword, T4 * 0x55, 0xf, 0xf, true);
+    return (x >> shift) & 0xffu;
+}
+
 enum : int { PHASE_FIRST = 0, PHASE_MAIN = 1, PHASE_LAST = 2 };
 
 // One group of M consecutive steps of one lane.  `sp` -> symbol byte of the
@@ -236,21 +247,33 @@ enum : int { PHASE_FIRST = 0, PHASE_MAIN = 1, PHASE_LAST = 2 };
 // the group's first step (in the FIRST group only step M-1 completes a row).
 // `sym` is a ring of symbol bytes indexed by step mod M (only ~PF are live),
 // `wc` carries the prefetched LDS column across steps when LP = 1.
-template <int M, int MODE, int PF, int LP, int PHASE, int WIDE>
+template <int M, int MODE, int PF, int LP, int PHASE, int WIDE, int QL = 0>
 __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
                                             float (&wc)[4 * ((M + 3) / 4)],
                                             const uint8_t *__restrict__ sp,
                                             const char *__restrict__ tab,
                                             float *__restrict__ op, const unsigned tbase,
                                             const int col, float &best_v, unsigned &best_t,
-                                            const FusedOut &fo)
+                                            const FusedOut &fo, const unsigned shq = 0)
 {
     constexpr int NW = 4 * ((M + 3) / 4);
+    constexpr int NB = M / 4;                  // QL: 4-row symbol blocks per group (M % 4 == 0)
+    constexpr int PFB = NB > 3 ? 3 : NB;       // QL: blocks requested ahead of use
 #pragma unroll
     for (int k = 0; k < M; ++k) {
         // (1) request the symbol byte PF steps ahead (stays inside the stream's
         //     T+M-1 input rows: the LAST group does not look past its end)
-        if (PF > 0) {
+        unsigned s_now = 0;
+        if (QL) {
+            // sym[] holds dword blocks (see quad_symbol); `sp` = this lane's row of block 0
+            const unsigned d = sym[k / 4];
+            s_now = (k % 4 == 0)   ? quad_symbol<0>(d, shq)
+                    : (k % 4 == 1) ? quad_symbol<1>(d, shq)
+                    : (k % 4 == 2) ? quad_symbol<2>(d, shq)
+                                   : quad_symbol<3>(d, shq);
+            if (k % 4 == 3 && (PHASE != PHASE_LAST || k / 4 + PFB < NB))
+                sym[(k / 4 + PFB) % NB] = *reinterpret_cast<const unsigned *>(sp + (k / 4 + PFB) * 128);
+        } else if (PF > 0) {
             if (PHASE != PHASE_LAST || k + PF < M)
                 sym[(k + PF) % M] = sp[(k + PF) * 32];
         } else {
@@ -258,7 +281,9 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
         }
         // (2) the PSSM column of this step's symbol
         float w[NW];
-        if (LP) {
+        if (QL) {
+            lds_fetch_column<M, WIDE>(w, tab, s_now);
+        } else if (LP) {
 #pragma unroll
             for (int i = 0; i < NW; ++i)
                 w[i] = wc[i];
@@ -372,7 +397,7 @@ __device__ __forceinline__ void emit_candidates(const unsigned long long hit_gro
 #define LM_SCORE_XCD_REMAP 0
 #endif
 template <int M, int MODE, int PF = LM_SCORE_PF, int LP = LM_SCORE_LP, int BLK = LM_BLOCK,
-          int XCD = LM_SCORE_XCD_REMAP, int MINW = LM_SCORE_MIN_WAVES(M), int WIDE = 0>
+          int XCD = LM_SCORE_XCD_REMAP, int MINW = LM_SCORE_MIN_WAVES(M), int WIDE = 0, int QLREQ = 0>
 __global__ __launch_bounds__(BLK, MINW) void score_c32(
     const uint8_t *__restrict__ seq, const float *__restrict__ table, const int K,
     const unsigned long long row_begin, const unsigned long long row_end,
@@ -420,7 +445,10 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
     if (o0 + T > row_end)
         o0 = row_end - T;
 
-    const uint8_t *sp = seq + o0 * 32 + col;
+    // quad-gathered symbol loads need whole 4-row blocks per group
+    constexpr int QL = (QLREQ && M % 4 == 0 && LP == 0) ? 1 : 0;
+    const unsigned shq = 8u * (col & 3);
+    const uint8_t *sp = QL ? seq + (o0 + (col & 3)) * 32 + (col >> 2) * 4 : seq + o0 * 32 + col;
     // output row completed by step t is o0 + t - (M-1); `op` tracks step 0 of the group
     const long long orow = (long long)(o0 - row_begin) - (M - 1);
     float *op = (MODE == MODE_STORE) ? out + orow * 32 + col : nullptr;
@@ -435,9 +463,16 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         acc[j] = 0.0f;
         sym[j] = 0;
     }
+    if (QL) {
+        constexpr int NB = M / 4, PFB = NB > 3 ? 3 : NB;
 #pragma unroll
-    for (int j = 0; j < PFE; ++j)
-        sym[j] = sp[j * 32];
+        for (int j = 0; j < PFB; ++j)
+            sym[j] = *reinterpret_cast<const unsigned *>(sp + j * 128);
+    } else {
+#pragma unroll
+        for (int j = 0; j < PFE; ++j)
+            sym[j] = sp[j * 32];
+    }
 #pragma unroll
     for (int i = 0; i < NW; ++i)
         wc[i] = 0.0f;
@@ -470,24 +505,24 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         }
     };
 
-    score_group<M, MODE, PFE, LPE, PHASE_FIRST, WIDE>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
-                                                best_t, fo);
+    score_group<M, MODE, PFE, LPE, PHASE_FIRST, WIDE, QL>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
+                                                best_t, fo, shq);
     note_group();
     for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
         sp += M * 32;
         tbase += M;
         if (MODE == MODE_STORE)
             op += M * 32;
-        score_group<M, MODE, PFE, LPE, PHASE_MAIN, WIDE>(acc, sym, wc, sp, lds_raw, op, tbase, col,
-                                                   best_v, best_t, fo);
+        score_group<M, MODE, PFE, LPE, PHASE_MAIN, WIDE, QL>(acc, sym, wc, sp, lds_raw, op, tbase, col,
+                                                   best_v, best_t, fo, shq);
         note_group();
     }
     sp += M * 32;
     tbase += M;
     if (MODE == MODE_STORE)
         op += M * 32;
-    score_group<M, MODE, PFE, LPE, PHASE_LAST, WIDE>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
-                                               best_t, fo);
+    score_group<M, MODE, PFE, LPE, PHASE_LAST, WIDE, QL>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
+                                               best_t, fo, shq);
     note_group();
 
     if (MODE == MODE_THRESHOLD) {
@@ -590,14 +625,14 @@ using ScoreC32Launcher = hipError_t (*)(dim3 grid, size_t lds_bytes, hipStream_t
                                         unsigned long long T, unsigned long long nstreams,
                                         float *out, FusedOut fo);
 
-template <int M, int MODE, int XCD = LM_SCORE_XCD_REMAP, int WIDE = 0>
+template <int M, int MODE, int XCD = LM_SCORE_XCD_REMAP, int WIDE = 0, int QL = 0>
 hipError_t score_c32_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, const uint8_t *seq,
                             const float *table, int K, unsigned long long row_begin,
                             unsigned long long row_end, unsigned long long T,
                             unsigned long long nstreams, float *out, FusedOut fo)
 {
     hipLaunchKernelGGL((score_c32<M, MODE, LM_SCORE_PF, LM_SCORE_LP, LM_BLOCK, XCD,
-                                  LM_SCORE_MIN_WAVES(M), WIDE>), grid,
+                                  LM_SCORE_MIN_WAVES(M), WIDE, QL>), grid,
                        dim3(kBlock), lds_bytes, stream, seq, table, K, row_begin, row_end, T,
                        nstreams, out, fo);
     return hipGetLastError();
@@ -608,6 +643,7 @@ hipError_t score_c32_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, con
 // [4..6] = modes for wide alphabets (K > 16).
 constexpr int kRegistrySlots = 8;
 ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap = false, bool wide = false);
+ScoreC32Launcher score_c32_lookup_ql(int M);
 const char *score_c32_name(int M, int mode);
 
 }  // namespace lm

@@ -56,13 +56,6 @@ __host__ __device__ __forceinline__ unsigned dna_pair_row(unsigned a, unsigned b
 // symbol(row r+t, own column) = byte (lane & 3) of the dword held by quad lane t (one DPP
 // quad broadcast + one bit-field extract).  RING is a multiple of 4, so blocks never
 // straddle a group; `blk` is a ring of the RING/4 blocks of a group, prefetched PFB ahead.
-template <int T4>
-__device__ __forceinline__ unsigned quad_symbol(unsigned block_dword, unsigned shift)
-{
-    const unsigned x = (unsigned)__builtin_amdgcn_mov_dpp((int)block_dword, T4 * 0x55, 0xf, 0xf, true);
-    return (x >> shift) & 0xffu;
-}
-
 template <int M, int PFB, int PHASE>
 __device__ __forceinline__ void prefilter2_group(unsigned (&acc)[prefilter2_npair(M)],
                                                  unsigned (&blk)[prefilter2_ring(M) / 4],
