@@ -210,26 +210,39 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, unsigned long long coun
         free(host_values);
         return fail(LM_HIP_ERR_OOM, "fused threshold: cannot allocate %llu hits on the host", count);
     }
-    // job offsets: through pinned memory when they fit, else straight into the vector
+    // Read-back.  starts | records | values are contiguous in scratch2: small results come back
+    // as ONE copy into the pinned buffer (a copy into pageable memory costs ~15 us each),
+    // large ones go straight into the arrays handed to the caller.
     const size_t starts_bytes = (njobs + 1) * 8;
-    void *starts_dst = starts_bytes <= kPinnedBytes ? ctx->pinned
-                                                    : static_cast<void *>(out->job_start.data());
     static_assert(sizeof(size_t) == 8, "job offsets are read back as 64-bit values");
-    hipError_t e = hipMemcpyAsync(starts_dst, starts, starts_bytes, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(host, d_out, count * rec_bytes, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess && host_values)
-        e = hipMemcpyAsync(host_values, d_values, count * sizeof(float), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess)
-        e = hipStreamSynchronize(st);
+    const size_t block_bytes = off_values + count * sizeof(float) - off_starts;
+    hipError_t e;
+    if (block_bytes <= (256u << 10)) {
+        e = hipMemcpyAsync(ctx->pinned, base + off_starts, block_bytes, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(st);
+        if (e == hipSuccess) {
+            const char *pin = static_cast<const char *>(ctx->pinned);
+            memcpy(out->job_start.data(), pin, starts_bytes);
+            memcpy(host, pin + (off_out - off_starts), count * rec_bytes);
+            if (host_values)
+                memcpy(host_values, pin + (off_values - off_starts), count * sizeof(float));
+        }
+    } else {
+        e = hipMemcpyAsync(out->job_start.data(), starts, starts_bytes, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(host, d_out, count * rec_bytes, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && host_values)
+            e = hipMemcpyAsync(host_values, d_values, count * sizeof(float), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(st);
+    }
     if (e != hipSuccess) {
         free(host);
         free(host_values);
         return fail(LM_HIP_ERR_HIP, "fused threshold: ordering the hit list failed: %s",
                     hipGetErrorString(e));
     }
-    if (starts_dst == ctx->pinned)
-        memcpy(out->job_start.data(), ctx->pinned, starts_bytes);
     out->total = (size_t)count;
     if (emit == 0) {
         out->coords = static_cast<lm_hip_coords *>(host);

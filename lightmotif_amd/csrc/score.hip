@@ -1006,8 +1006,8 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
     }
     // ~1024 cells tie with or beat the bound of a 1/1024 sample; leave room for 8x that
     const unsigned long long cap = nq * 8192 + (1 << 16), ccap = 4 * cap;
-    const size_t off_bound = 16, off_bval = off_bound + (nq * 4 + 15) / 16 * 16;
-    const size_t off_bkey = off_bval + (nq * 4 + 15) / 16 * 16;
+    const size_t off_bound = 16, off_bval = off_bound + nq * 4;  // contiguous: one 32-bit fill inits both
+    const size_t off_bkey = (off_bval + nq * 4 + 15) / 16 * 16;
     const size_t off_hits = off_bkey + nq * 8;
     const size_t off_cands = off_hits + cap * sizeof(HitRecord);
     const size_t off_rj = off_cands + ccap * sizeof(Candidate);
@@ -1031,14 +1031,28 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
     SampleJob *d_sj = reinterpret_cast<SampleJob *>(base + off_sj);
     ArgmaxRecord *d_res = reinterpret_cast<ArgmaxRecord *>(base + off_res);
     hipStream_t st = ctx->stream;
-    // ordered_bits(-inf) = 0x007fffff: byte-wise memset cannot write it, a tiny fill can
-    LM_HIP_TRY(hipMemsetAsync(base, 0, off_hits, st));
-    std::vector<unsigned> init(nq, kOrderedNegInf);
-    LM_HIP_TRY(hipMemcpyAsync(d_bound, init.data(), nq * 4, hipMemcpyHostToDevice, st));
-    LM_HIP_TRY(hipMemcpyAsync(d_bval, init.data(), nq * 4, hipMemcpyHostToDevice, st));
-    LM_HIP_TRY(hipMemcpyAsync(d_rj, rj.data(), nq * sizeof(RescoreJob), hipMemcpyHostToDevice, st));
-    LM_HIP_TRY(hipMemcpyAsync(d_bp, bparams.data(), nq * sizeof(BatchParams), hipMemcpyHostToDevice, st));
-    LM_HIP_TRY(hipMemcpyAsync(d_sj, sj.data(), nq * sizeof(SampleJob), hipMemcpyHostToDevice, st));
+    LM_HIP_TRY(hipMemsetAsync(base, 0, 16, st));
+    LM_HIP_TRY(hipMemsetAsync(d_bkey, 0, nq * 8, st));
+    LM_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_bound), (int)kOrderedNegInf, 2 * nq, st));
+    // A handful of jobs: the job tables live in the pinned (device-visible) buffer and the
+    // kernels read / update them there -- three staged copies from pageable memory cost more
+    // than the whole sample pass.  Big batches amortise the copies and keep the tables in HBM.
+    const size_t pin_tables = (16 + nq * sizeof(ArgmaxRecord) + 63) / 64 * 64;
+    const size_t pin_bp = pin_tables + (nq * sizeof(RescoreJob) + 63) / 64 * 64;
+    const size_t pin_sj = pin_bp + (nq * sizeof(BatchParams) + 63) / 64 * 64;
+    if (nq <= 64 && pin_sj + nq * sizeof(SampleJob) <= kPinnedBytes) {
+        char *pinb = static_cast<char *>(ctx->pinned);
+        d_rj = reinterpret_cast<RescoreJob *>(pinb + pin_tables);
+        d_bp = reinterpret_cast<BatchParams *>(pinb + pin_bp);
+        d_sj = reinterpret_cast<SampleJob *>(pinb + pin_sj);
+        memcpy(d_rj, rj.data(), nq * sizeof(RescoreJob));
+        memcpy(d_bp, bparams.data(), nq * sizeof(BatchParams));
+        memcpy(d_sj, sj.data(), nq * sizeof(SampleJob));
+    } else {
+        LM_HIP_TRY(hipMemcpyAsync(d_rj, rj.data(), nq * sizeof(RescoreJob), hipMemcpyHostToDevice, st));
+        LM_HIP_TRY(hipMemcpyAsync(d_bp, bparams.data(), nq * sizeof(BatchParams), hipMemcpyHostToDevice, st));
+        LM_HIP_TRY(hipMemcpyAsync(d_sj, sj.data(), nq * sizeof(SampleJob), hipMemcpyHostToDevice, st));
+    }
     const unsigned sgrid = (unsigned)std::min<unsigned long long>(
         max_chunks, std::max<unsigned long long>((unsigned long long)ctx->num_cus * 8 / nq, 16));
     hipLaunchKernelGGL(argmax_sample, dim3(sgrid, (unsigned)nq), dim3(kBlock), 0, st, d_sj, d_bound);
