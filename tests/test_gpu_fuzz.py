@@ -13,7 +13,12 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
-@pytest.mark.parametrize("seed", range(240))
+import os
+
+SEEDS = range(int(os.environ.get("LM_FUZZ_FIRST", "0")), int(os.environ.get("LM_FUZZ_LAST", "240")))
+
+
+@pytest.mark.parametrize("seed", SEEDS)
 def test_random_configuration(pli, seed):
     rng = np.random.default_rng(90_000 + seed)
     protein = seed % 7 == 3
@@ -81,3 +86,51 @@ def test_random_configuration(pli, seed):
     finally:
         pli.set_rows_per_stream(0)
         pli.set_prefilter(True)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_batch(pli, seed):
+    """Random many-motif batches (equal lengths share a launch, odd shapes go to the generic kernel,
+    some thresholds select nothing or everything): every job must equal its own oracle result."""
+    rng = np.random.default_rng(70_000 + seed)
+    length = int(rng.choice([5_000, 40_000, 150_001]))
+    enc = rng.integers(0, 5 if seed % 4 == 0 else 4, length, dtype=np.uint8)
+    n = int(rng.integers(1, 13))
+    pool = [int(x) for x in rng.integers(1, 41, 4)]          # few distinct lengths -> grouped launches
+    lengths = [int(rng.choice(pool)) for _ in range(n)]
+    pssms_np = []
+    for i, m in enumerate(lengths):
+        p = np.zeros((m, 8), np.float32)
+        p[:, :5] = rng.integers(-2, 3, (m, 5)) if (seed + i) % 3 == 0 else rng.normal(0, 2, (m, 5))
+        if (seed + i) % 5:
+            p[:, 4] = -np.inf
+        pssms_np.append(p)
+    wrap = max(lengths) - 1
+    ref = co.stripe(enc, 32, 5)
+    co.configure_wrap(ref, wrap)
+    seq = pli.stripe(lm.EncodedSequence(enc), 32)
+    seq.configure_wrap(wrap)
+    pssms = [lm.ScoringMatrix(p) for p in pssms_np]
+    wants = [co.score_rows(ref, p)[0] for p in pssms_np]
+    ts = []
+    for w in wants:
+        finite = np.sort(w[:, :32][np.isfinite(w[:, :32])])
+        q = float(rng.choice([0.0, 0.5, 0.99, 0.9999, 1.0]))
+        ts.append(float(finite[min(int(q * (finite.size - 1)), finite.size - 1)]) if finite.size else 0.0)
+        if rng.random() < 0.15:
+            ts[-1] = float(finite[-1]) + 1.0 if finite.size else 1.0
+    pli.set_prefilter(bool(seed % 3))
+    try:
+        got_am = pli.scan_argmax_batch(pssms, seq)
+        got_th = pli.scan_threshold_batch(pssms, ts, seq)
+    finally:
+        pli.set_prefilter(True)
+    for i, w in enumerate(wants):
+        if w.shape[0] == 0:
+            assert got_am[i] is None and len(got_th[i][0]) == 0
+            continue
+        assert got_am[i][0] == co.argmax(w, 32), (i, lengths[i])
+        assert bits(np.float32(got_am[i][1])) == bits(co.max_(w, 32))
+        wrc = co.threshold(w, 32, ts[i]).astype(np.int64).reshape(-1, 2)
+        assert np.array_equal(got_th[i][0], wrc), (i, lengths[i], ts[i])
+        assert np.array_equal(bits(got_th[i][1]), bits(w[wrc[:, 0], wrc[:, 1]]))
