@@ -279,6 +279,11 @@ int lm_hip_scores_info(const lm_hip_scores *scores, size_t *rows, size_t *stride
                        size_t *max_index, const float **d_data);
 /* Copies rows x stride floats back. */
 int lm_hip_scores_download(lm_hip_ctx *ctx, const lm_hip_scores *scores, float *dst);
+/* Rows [row_begin, row_end) only, (row_end - row_begin) x stride floats: what
+ * `scores[i]` (Index<usize>, scores.rs:246-254) and windowed reads need without moving
+ * a multi-gigabyte matrix. */
+int lm_hip_scores_download_rows(lm_hip_ctx *ctx, const lm_hip_scores *scores, size_t row_begin,
+                                size_t row_end, float *dst);
 int lm_hip_scores_destroy(lm_hip_scores *scores);
 
 /* Score::score_rows_into on handles; resizes `scores` like scores.resize. */

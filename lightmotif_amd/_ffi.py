@@ -92,6 +92,7 @@ SIGNATURES = {
     "lm_hip_scores_create": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
     "lm_hip_scores_info": (C.c_int, [_vp, _szp, _szp, _szp, _szp, C.POINTER(_vp)]),
     "lm_hip_scores_download": (C.c_int, [_vp, _vp, _vp]),
+    "lm_hip_scores_download_rows": (C.c_int, [_vp, _vp, _sz, _sz, _vp]),
     "lm_hip_scores_destroy": (C.c_int, [_vp]),
     "lm_hip_score_rows_into": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _vp]),
     "lm_hip_score_into": (C.c_int, [_vp, _vp, _vp, _vp]),

@@ -987,6 +987,27 @@ int lm_hip_scores_download(lm_hip_ctx *ctx, const lm_hip_scores *s, float *dst)
     return LM_HIP_OK;
 }
 
+int lm_hip_scores_download_rows(lm_hip_ctx *ctx, const lm_hip_scores *s, size_t row_begin,
+                                size_t row_end, float *dst)
+{
+    if (!ctx || !s)
+        return fail(LM_HIP_ERR_BAD_ARGS, "scores_download_rows: null argument");
+    if (row_begin > row_end || row_end > s->rows)
+        return fail(LM_HIP_ERR_BAD_ARGS, "scores_download_rows: rows %zu..%zu of %zu", row_begin, row_end,
+                    s->rows);
+    if (row_begin == row_end)
+        return LM_HIP_OK;
+    if (!dst)
+        return fail(LM_HIP_ERR_BAD_ARGS, "scores_download_rows: null destination");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    LM_HIP_TRY(hipMemcpyAsync(dst, s->d_data + row_begin * s->stride,
+                              (row_end - row_begin) * s->stride * sizeof(float), hipMemcpyDeviceToHost,
+                              ctx->stream));
+    LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return LM_HIP_OK;
+}
+
 int lm_hip_scores_destroy(lm_hip_scores *s)
 {
     if (!s)

@@ -1,6 +1,5 @@
 // score.hip -- launch logic of the scoring kernels (kernel bodies: score_kernels.hpp).
 #include <algorithm>
-#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -8,9 +7,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
-#include <thread>
 #include <tuple>
-#include <numeric>
 
 #include "score_prefilter2.hpp"
 

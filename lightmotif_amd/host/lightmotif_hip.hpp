@@ -326,6 +326,15 @@ public:
         check(lm_hip_scores_download(ctx_->ctx, h_, m.ptr()));
         return m;
     }
+    float at(size_t index) const                                 // Index<usize>, scores.rs:246-254
+    {
+        const Info i = info();
+        if (index >= i.rows * i.cols)
+            throw std::out_of_range("score index out of range");
+        std::vector<float> row(i.stride);
+        check(lm_hip_scores_download_rows(ctx_->ctx, h_, index % i.rows, index % i.rows + 1, row.data()));
+        return row[index / i.rows];
+    }
     size_t offset(MatrixCoordinates mc) const { return mc.col * info().rows + mc.row; }  // scores.rs:155-157
     size_t len() const                                           // scores.rs:274-279
     {

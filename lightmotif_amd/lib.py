@@ -772,7 +772,14 @@ class StripedScores:
         if not 0 <= index < n:
             raise IndexError(index)
         rows = self.rows
-        return float(self.matrix()[index % rows, index // rows])
+        return float(self.rows_matrix(index % rows, index % rows + 1)[0, index // rows])
+
+    def rows_matrix(self, row_begin: int, row_end: int) -> np.ndarray:
+        """Host copy of rows ``[row_begin, row_end)`` only (``(n, stride)`` f32)."""
+        out = np.empty((max(row_end - row_begin, 0), self.stride), dtype=np.float32)
+        check(self._pli._L.lm_hip_scores_download_rows(self._pli._h, self._h, row_begin, row_end,
+                                                       out.ctypes.data))
+        return out
 
     def argmax(self) -> Optional[int]:
         """scores.rs:190-192"""

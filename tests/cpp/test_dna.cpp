@@ -116,6 +116,8 @@ static void test_threshold(const Pipeline<Dna> &pli, size_t columns)
     std::sort(indices.begin(), indices.end());
     CHECK((indices == std::vector<size_t>{10, 13, 14, 18, 24, 27, 32, 35, 40, 47}));
     CHECK(result.threshold(10.0f).empty());                          // README.md:89-90
+    CHECK(std::fabs(result.at(18) - (-5.50167f)) < 1e-5f);           // scores[i], scores.rs:246-254
+    CHECK(result.at(0) == -23.07094f);
 }
 
 // scan.rs:279-353 / lightmotif-py test_scanner.py:64-80

@@ -174,6 +174,23 @@ def test_scanner_dense_hit_lists_come_back_in_position_order(pli, length, frac):
     assert rows * 32 >= length
 
 
+def test_indexing_reads_single_rows(pli):
+    """``scores[i]`` = cell (i % rows, i / rows) (scores.rs:246-254), fetched without downloading
+    the matrix; windows of rows come back like the corresponding slice of the full copy."""
+    g, pssm, seq = golden_objects(pli)
+    scores = pssm.calculate(seq)
+    full = scores.matrix()
+    for i, want in enumerate(g["expected"]):
+        assert abs(scores[i] - want) < 1e-5
+    assert scores[-1] == scores[len(scores) - 1]
+    with pytest.raises(IndexError):
+        scores[len(scores)]
+    assert np.array_equal(bits(scores.rows_matrix(1, 2)), bits(full[1:2]))
+    assert scores.rows_matrix(2, 2).shape == (0, full.shape[1])
+    with pytest.raises(lm.LightmotifHipError):
+        scores.rows_matrix(0, full.shape[0] + 1)
+
+
 def test_g7_empty_row_range_does_not_fail(pli):
     g = GOLD["G7_empty_range"]
     seq = pli.stripe(lm.EncodedSequence(g["sequence"]), g["columns"])
