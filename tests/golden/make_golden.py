@@ -6,7 +6,7 @@ that its own tests pin with no literal (ties, NaN, the padded tail, protein,
 odd geometries) are fixed by running the C restatement of the Generic pipeline
 (oracle/lm_oracle.c, itself pinned by tests/golden/reference_vectors.json and
 cross-checked against the independent numpy restatement).  Re-run with
-    python tools/make_golden.py
+    python tests/golden/make_golden.py
 Inputs and expected outputs are stored as arrays; nothing of the reference's
 source text is included.
 """
@@ -15,7 +15,7 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 from oracle import c_oracle as co, np_oracle as no  # noqa: E402
 
