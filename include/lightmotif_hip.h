@@ -110,6 +110,15 @@ int lm_hip_ctx_set_xcd_remap(lm_hip_ctx *ctx, int enabled);
  * reference Scanner's DiscreteMatrix prefilter, scan.rs:169-198) and re-scored exactly;
  * 0 = every position is scored in f32.  The hit lists are identical either way. */
 int lm_hip_ctx_set_prefilter(lm_hip_ctx *ctx, int enabled);
+/* lm_hip_score_rows_into / lm_hip_score_into on handles: 1 (default) = for matrices of at least
+ * 8 Mi cells the store kernel also tracks the maximum, and a following lm_hip_argmax on the
+ * same lm_hip_scores (the reference's score_into + argmax flow, lightmotif-bench dna.rs:
+ * 104-107) is a 16-byte read instead of a second pass over the matrix (1.65 -> 1.03 ms per
+ * Gbp for the pair; the two tiny reduction launches add ~2 % to a score_into that is never
+ * followed by argmax); 0 = plain store.  The cached result is invalidated by the library's
+ * own writes to the handle -- not by external writes through the device pointer of
+ * lm_hip_scores_info. */
+int lm_hip_ctx_set_track_argmax(lm_hip_ctx *ctx, int enabled);
 /* Name of the kernel the last score call on this context launched
  * (for profiling tools); valid until the next call. */
 const char *lm_hip_ctx_last_kernel(lm_hip_ctx *ctx);

@@ -60,6 +60,7 @@ SIGNATURES = {
     "lm_hip_ctx_set_rows_per_stream": (C.c_int, [_vp, _sz]),
     "lm_hip_ctx_set_xcd_remap": (C.c_int, [_vp, C.c_int]),
     "lm_hip_ctx_set_prefilter": (C.c_int, [_vp, C.c_int]),
+    "lm_hip_ctx_set_track_argmax": (C.c_int, [_vp, C.c_int]),
     "lm_hip_ctx_last_kernel": (C.c_char_p, [_vp]),
     "lm_hip_pssm_create": (C.c_int, [_vp, _vp, _sz, _sz, _sz, C.POINTER(_vp)]),
     "lm_hip_pssm_destroy": (C.c_int, [_vp]),

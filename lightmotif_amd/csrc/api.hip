@@ -252,6 +252,8 @@ static int ctx_create(int device, void *stream, bool borrow, lm_hip_ctx **out)
         return fail(LM_HIP_ERR_OOM, "out of host memory");
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
+    if (const char *e = getenv("LM_HIP_TRACK_ARGMAX"))  // A/B switch: 0 = plain store in score_into
+        ctx->track_argmax = atoi(e) != 0;
     if (const char *e = getenv("LM_HIP_QUAD_LOADS"))  // A/B switch of the store kernel's symbol loads
         ctx->quad_loads = atoi(e) != 0;
     if (const char *e = getenv("LM_HIP_PAIR_PREFILTER"))  // A/B switch: 0 = one symbol per lookup
@@ -345,6 +347,14 @@ int lm_hip_ctx_set_prefilter(lm_hip_ctx *ctx, int enabled)
     if (!ctx)
         return fail(LM_HIP_ERR_BAD_ARGS, "null context");
     ctx->use_prefilter = enabled != 0;
+    return LM_HIP_OK;
+}
+
+int lm_hip_ctx_set_track_argmax(lm_hip_ctx *ctx, int enabled)
+{
+    if (!ctx)
+        return fail(LM_HIP_ERR_BAD_ARGS, "null context");
+    ctx->track_argmax = enabled != 0;
     return LM_HIP_OK;
 }
 
@@ -956,6 +966,11 @@ int lm_hip_scores_create(lm_hip_ctx *ctx, size_t cols, lm_hip_scores **out)
     s->device = ctx->device;
     s->cols = cols;
     s->stride = lm_hip_stride(cols, sizeof(float));
+    {
+        DeviceGuard guard(ctx->device);
+        if (hipMalloc(&s->d_best, sizeof(ArgmaxRecord)) != hipSuccess)
+            s->d_best = nullptr;  // no cached argmax then; everything else works
+    }
     *out = s;
     return LM_HIP_OK;
 }
@@ -1015,6 +1030,8 @@ int lm_hip_scores_destroy(lm_hip_scores *s)
     DeviceGuard guard(s->device);
     if (s->d_data)
         (void)hipFree(s->d_data);
+    if (s->d_best)
+        (void)hipFree(s->d_best);
     delete s;
     return LM_HIP_OK;
 }
@@ -1052,12 +1069,23 @@ int lm_hip_score_rows_into(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hi
                             row_begin, row_end));
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard guard(ctx->device);
+    scores->best_valid = false;
     if (seq->length < pssm->m || row_begin >= row_end)  // pli/mod.rs:85-88
         return scores_resize(ctx, scores, 0, 0);
     LM_TRY(scores_resize(ctx, scores, row_end - row_begin, seq->length + 1 - pssm->m));
     ScoreArgs a{pssm, seq->d_data, seq->stride, seq->cols, row_begin, row_end, scores->d_data,
                 scores->stride};
-    return launch_score_store(ctx, a);
+    // the reference's flow is score_into + argmax (lightmotif-bench dna.rs:104-107): the
+    // store kernel tracks the best cell on the way, so that lm_hip_argmax on this handle is
+    // a 16-byte read instead of a second pass over 4 B per position
+    // (small inputs are launch-latency bound: the extra reduction launch costs more than the
+    //  second pass it saves)
+    if (!scores->d_best || !ctx->track_argmax || (row_end - row_begin) * seq->cols < (8u << 20))
+        return launch_score_store(ctx, a);
+    bool tracked = false;
+    LM_TRY(launch_score_store_argmax(ctx, a, scores->d_best, &tracked));
+    scores->best_valid = tracked;
+    return LM_HIP_OK;
 }
 
 int lm_hip_score_into(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *seq,
@@ -1073,6 +1101,15 @@ int lm_hip_argmax(lm_hip_ctx *ctx, const lm_hip_scores *s, int *found, lm_hip_co
 {
     if (!s)
         return fail(LM_HIP_ERR_BAD_ARGS, "argmax: null scores");
+    if (ctx && found && s->best_valid && s->rows) {  // tracked by the kernel that wrote the scores
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        DeviceGuard guard(ctx->device);
+        LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, s->d_best, sizeof(ArgmaxRecord), hipMemcpyDeviceToHost,
+                                  ctx->stream));
+        LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        record_to_coords(*static_cast<const ArgmaxRecord *>(ctx->pinned), s->cols, found, best, value);
+        return LM_HIP_OK;
+    }
     return lm_hip_argmax_f32_dptr(ctx, s->d_data, s->rows, s->stride, s->cols, found, best, value);
 }
 

@@ -70,6 +70,7 @@ struct lm_hip_ctx {
     bool xcd_remap = false;      // A/B knob of the store kernel (lm_hip_ctx_set_xcd_remap)
     bool pair_prefilter = true;  // DNA prefilter scans look up two symbols at a time
     bool quad_loads = true;      // store kernel: quad-gathered dword symbol loads (M % 4 == 0; +1 %)
+    bool track_argmax = true;    // score_into on handles also tracks the best cell (cached argmax)
     int num_cus = 256;
     unsigned long long last_hit_count = 0;  // sizes the next fused-threshold hit list
     unsigned long long last_cand_count = 0; // ... and its candidate list
@@ -110,6 +111,10 @@ struct lm_hip_scores {
     float *d_data = nullptr;
     size_t capacity_rows = 0;
     size_t rows = 0, stride = 0, cols = 0, max_index = 0;
+    // argmax of the matrix as tracked by the store kernel that last wrote it (device record;
+    // valid until the next library write into this handle)
+    lm::ArgmaxRecord *d_best = nullptr;
+    bool best_valid = false;
 };
 
 namespace lm {
@@ -129,6 +134,11 @@ struct ScoreArgs {
 
 // Materialising score kernels.
 int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a);
+// ... also leaving the argmax of the written rows in *d_result (device); *tracked = false
+// when the shape falls back to a plain store
+int launch_score_store_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *d_result, bool *tracked);
+int finalize_argmax_materialised(lm_hip_ctx *ctx, const ArgmaxRecord *d_blocks, unsigned nblocks,
+                                 const float *d_scores, int first_cell_rule, ArgmaxRecord *d_out);
 // Fused score+argmax: leaves one ArgmaxRecord at ctx->scratch (device) -> out.
 int launch_score_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, int first_cell_rule, ArgmaxRecord *out);
 // Result of a fused score+threshold batch: malloc'ed host arrays in key order (the

@@ -80,6 +80,12 @@ PrefilterLauncher score_c32_prefilter2_lookup(int M)
     return (M >= 1 && M <= kMaxFastM) ? g_pre2[M] : nullptr;
 }
 
+ScoreC32Launcher score_c32_lookup_store_argmax(int M)
+{
+    std::call_once(g_c32_once, init_registry);
+    return (M >= 1 && M <= kMaxFastM) ? g_c32[M][8] : nullptr;
+}
+
 ScoreC32Launcher score_c32_lookup_ql(int M)
 {
     std::call_once(g_c32_once, init_registry);
@@ -212,6 +218,126 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
     ctx->last_kernel = "score_generic<0>";
     const unsigned long long ncells = (unsigned long long)(a.row_end - a.row_begin) * a.cols;
     return launch_generic<MODE_STORE>(ctx, a, fo, generic_grid(ctx, ncells));
+}
+
+__global__ void argmax_fold(const ArgmaxRecord *__restrict__ blocks, const unsigned nblocks,
+                            ArgmaxRecord *__restrict__ out);  // defined with the other reductions below
+
+// Final step of the store+argmax flow, ONE workgroup: (1) reduce the (max value, workgroup)
+// records with the Generic rule (greater value; ties -> later workgroup = later rows) and
+// apply the first-cell NaN rule on the stored matrix; (2) find the LAST cell of the winning
+// workgroup's rows whose stored score equals that value -- the Generic argmax (pli/mod.rs:
+// 144-151).  The winning workgroup wrote <= 8 streams x T rows; they are re-read 16 bytes
+// per lane.
+__global__ __launch_bounds__(kBlock) void argmax_finalize_locate(
+    const ArgmaxRecord *__restrict__ recs, const unsigned nrecs, const float *__restrict__ scores,
+    const unsigned long long rows, const unsigned long long T, const unsigned long long nstreams,
+    ArgmaxRecord *__restrict__ out)
+{
+    __shared__ float sm_v[kBlock / 64];
+    __shared__ long long sm_i[kBlock / 64];
+    __shared__ float win_v;
+    __shared__ long long win_i;
+    float v = -INFINITY;
+    long long wg = -1;
+    for (unsigned b = threadIdx.x; b < nrecs; b += kBlock)
+        if (recs[b].found)
+            best_merge(v, wg, recs[b].value, recs[b].index);
+    best_block_reduce(v, wg, sm_v, sm_i);
+    if (threadIdx.x == 0) {
+        const float first = scores[0];
+        if (first != first) {  // scores[0][0] is NaN: nothing ever compares >= it (pli/mod.rs:142-146)
+            ArgmaxRecord o;
+            o.value = first;
+            o.index = 0;
+            o.found = 1;
+            *out = o;
+            wg = -2;
+        } else if (wg < 0) {
+            ArgmaxRecord o;
+            o.value = v;
+            o.index = -1;
+            o.found = 0;
+            *out = o;
+        }
+        win_v = v;
+        win_i = wg;
+    }
+    __syncthreads();
+    v = win_v;
+    wg = win_i;
+    if (wg < 0)
+        return;
+    // stream s covers rows [min(s*T, rows - T), +T): the workgroup's streams form one run
+    unsigned long long s0 = (unsigned long long)wg * kStreamsPerBlock, s1 = s0 + kStreamsPerBlock;
+    if (s1 > nstreams)
+        s1 = nstreams;
+    const unsigned long long last = rows - T;
+    const unsigned long long lo = s0 * T < last ? s0 * T : last;
+    const unsigned long long hi = ((s1 - 1) * T < last ? (s1 - 1) * T : last) + T;
+    long long best = -1;
+    const float4 *s4 = reinterpret_cast<const float4 *>(scores);
+    for (unsigned long long i = lo * 8 + threadIdx.x; i < hi * 8; i += kBlock) {  // 8 float4 per row
+        const float4 x = s4[i];
+        if (x.x == v) best = (long long)(4 * i);
+        if (x.y == v) best = (long long)(4 * i + 1);
+        if (x.z == v) best = (long long)(4 * i + 2);
+        if (x.w == v) best = (long long)(4 * i + 3);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const long long o = __shfl_xor(best, off);
+        best = o > best ? o : best;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+        sm_i[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w)
+            best = sm_i[w] > best ? sm_i[w] : best;
+        ArgmaxRecord o;
+        o.index = best;
+        o.found = best >= 0;
+        o.value = best >= 0 ? scores[best] : v;  // the cell's own bits (-0.0 == +0.0)
+        *out = o;
+    }
+}
+
+// Store + running best: the scores are written exactly like launch_score_store does; the
+// kernel's per-workgroup (max value, workgroup) records are reduced (Generic rule, first-cell
+// NaN rule on the stored matrix) and `argmax_locate` finds the cell in the winning
+// workgroup's rows; the result lands in `d_result`, all on the same stream.  Returns
+// *tracked = false (after a plain store) for shapes the C = 32 kernels do not cover.
+int launch_score_store_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *d_result, bool *tracked)
+{
+    *tracked = false;
+    const C32Plan p = plan_c32(ctx, a, true);
+    ScoreC32Launcher fn = p.ok && !a.pssm->wide ? score_c32_lookup_store_argmax((int)a.pssm->m) : nullptr;
+    if (!fn || reinterpret_cast<uintptr_t>(a.d_seq) % 4 != 0)
+        return launch_score_store(ctx, a);
+    if (a.out_stride != 32)
+        return launch_score_store(ctx, a);
+    const unsigned nrec = p.grid.x * (kBlock / 64);  // one record per wavefront
+    LM_TRY(ctx->scratch.reserve(sizeof(ArgmaxRecord) * ((size_t)nrec + 256 + 1)));
+    FusedOut fo{};
+    fo.block_best = static_cast<ArgmaxRecord *>(ctx->scratch.ptr);
+    ArgmaxRecord *folded = fo.block_best + nrec;
+    ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_STORE);
+    LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, a.pssm->d_table, (int)a.pssm->k, a.row_begin,
+                  a.row_end, p.T, p.nstreams, a.d_out, fo));
+    const ArgmaxRecord *recs = fo.block_best;
+    unsigned n = nrec;
+    if (n > 4096) {  // ~256 K wavefront records per Gbp: fold them to 256 first
+        hipLaunchKernelGGL(argmax_fold, dim3(256), dim3(kBlock), 0, ctx->stream, recs, n, folded);
+        recs = folded;
+        n = 256;
+    }
+    hipLaunchKernelGGL(argmax_finalize_locate, dim3(1), dim3(kBlock), 0, ctx->stream, recs, n, a.d_out,
+                       (unsigned long long)(a.row_end - a.row_begin), p.T, p.nstreams, d_result);
+    LM_HIP_TRY(hipGetLastError());
+    *tracked = true;
+    return LM_HIP_OK;
 }
 
 // ---- fused argmax ---------------------------------------------------------------------
@@ -1138,9 +1264,37 @@ int launch_score_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, int first_cell_rule
     return launch_score_argmax_batch(ctx, &a, 1, first_cell_rule, out);
 }
 
+// Many block records (the store kernel runs ~64 K small workgroups per Gbp): a first level
+// of 256 workgroups folds them to 256 records in place of one workgroup reading a megabyte.
+__global__ __launch_bounds__(kBlock) void argmax_fold(const ArgmaxRecord *__restrict__ blocks,
+                                                      const unsigned nblocks,
+                                                      ArgmaxRecord *__restrict__ out)
+{
+    __shared__ float sm_v[kBlock / 64];
+    __shared__ long long sm_i[kBlock / 64];
+    float v = -INFINITY;
+    long long i = -1;
+    for (unsigned b = blockIdx.x * kBlock + threadIdx.x; b < nblocks; b += gridDim.x * kBlock)
+        if (blocks[b].found)
+            best_merge(v, i, blocks[b].value, blocks[b].index);
+    best_block_reduce(v, i, sm_v, sm_i);
+    if (threadIdx.x == 0) {
+        out[blockIdx.x].value = v;
+        out[blockIdx.x].index = i;
+        out[blockIdx.x].found = i >= 0;
+    }
+}
+
+// `d_blocks` must have room for 256 more records behind the first `nblocks` when nblocks > 4096.
 int finalize_argmax_materialised(lm_hip_ctx *ctx, const ArgmaxRecord *d_blocks, unsigned nblocks,
                                  const float *d_scores, int first_cell_rule, ArgmaxRecord *d_out)
 {
+    if (nblocks > 4096) {
+        ArgmaxRecord *folded = const_cast<ArgmaxRecord *>(d_blocks) + nblocks;
+        hipLaunchKernelGGL(argmax_fold, dim3(256), dim3(kBlock), 0, ctx->stream, d_blocks, nblocks, folded);
+        d_blocks = folded;
+        nblocks = 256;
+    }
     hipLaunchKernelGGL(argmax_finalize, dim3(1), dim3(kBlock), 0, ctx->stream, d_blocks, nblocks,
                        d_scores, (const uint8_t *)nullptr, 0ull, (const float *)nullptr, 0, 0,
                        first_cell_rule, d_out);

@@ -26,6 +26,7 @@ struct RegisterRange {
         tab[M][3] = &score_c32_launch<M, MODE_STORE, 1>;
         if constexpr (M % 4 == 0)
             tab[M][7] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 0, 1>;
+        tab[M][8] = &score_c32_launch<M, MODE_STORE_ARGMAX, LM_SCORE_XCD_REMAP, 0, 1>;
 #if defined(LM_SCORE_BUILD_WIDE)
         // 8-byte-read variant for K > 16; not built by default, see api.hip (pssm_create)
         tab[M][4 + MODE_STORE] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1>;

@@ -58,7 +58,11 @@ constexpr int table_stride(int m, bool wide = false)
     return wide ? 2 * (((m + 1) / 2) | 1) : 4 * (((m + 3) / 4) | 1);
 }
 
-enum : int { MODE_STORE = 0, MODE_ARGMAX = 1, MODE_THRESHOLD = 2 };
+// MODE_STORE_ARGMAX: writes the scores AND tracks the running best, so that the argmax of a
+// freshly scored matrix (the reference's score_into + argmax flow) needs no second pass
+enum : int { MODE_STORE = 0, MODE_ARGMAX = 1, MODE_THRESHOLD = 2, MODE_STORE_ARGMAX = 3 };
+constexpr bool mode_stores(int mode) { return mode == MODE_STORE || mode == MODE_STORE_ARGMAX; }
+constexpr bool mode_tracks_best(int mode) { return mode == MODE_ARGMAX || mode == MODE_STORE_ARGMAX; }
 
 // One above-threshold cell: key = (job << 40) | flat index (row * cols + col).  Flat
 // indices stay below 2^40 for anything that fits in 288 GB of HBM.
@@ -304,17 +308,23 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
         // (4) the slot started at step k-(M-1) is complete.
         if (PHASE != PHASE_FIRST || k == M - 1) {
             const float score = acc[(k + 1) % M];
-            if (MODE == MODE_STORE) {
+            if (mode_stores(MODE)) {
                 if (LM_SCORE_NT_STORE)
                     __builtin_nontemporal_store(score, op + k * 32);
                 else
                     op[k * 32] = score;
+            }
+            if (MODE == MODE_STORE_ARGMAX) {
+                // value only (one v_max_f32; NaN operands are ignored, the NaN start value
+                // survives only if every score was NaN): the cell is located afterwards in
+                // the stored matrix.  Tracking the index too cost the store kernel 15 %.
+                best_v = __builtin_fmaxf(best_v, score);
             } else if (MODE == MODE_ARGMAX) {
                 if (score >= best_v) {  // same `>=` as pli/mod.rs:146, NaN never passes
                     best_v = score;
                     best_t = tbase + k;  // scalar + constant: no per-lane arithmetic
                 }
-            } else {
+            } else if (MODE == MODE_THRESHOLD) {
                 // Hits are rare (a p = 1e-5 tail).  The hot loop only tracks the
                 // lane's "saw a hit" flag (v_cmp + v_cndmask); a group with a
                 // flagged lane is re-scored out of line by rescan_rows.  Recording
@@ -406,7 +416,7 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     FusedOut fo = fo_in;
-    if (MODE != MODE_STORE && fo_in.batch) {  // multi-job launch: this block's job (wave-uniform)
+    if (!mode_stores(MODE) && fo_in.batch) {  // multi-job launch: this block's job (wave-uniform)
         const BatchParams bp = fo_in.batch[blockIdx.y];
         table = static_cast<const float *>(bp.table);
         fo.block_best = bp.block_best;
@@ -451,7 +461,7 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
     const uint8_t *sp = QL ? seq + (o0 + (col & 3)) * 32 + (col >> 2) * 4 : seq + o0 * 32 + col;
     // output row completed by step t is o0 + t - (M-1); `op` tracks step 0 of the group
     const long long orow = (long long)(o0 - row_begin) - (M - 1);
-    float *op = (MODE == MODE_STORE) ? out + orow * 32 + col : nullptr;
+    float *op = mode_stores(MODE) ? out + orow * 32 + col : nullptr;
 
     constexpr int NW = 4 * ((M + 3) / 4);
     constexpr int PFE = PF < M ? PF : M - 1;  // look-ahead stays inside one group
@@ -479,7 +489,7 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
     constexpr int LPE = (PFE >= 1) ? LP : 0;
     if (LPE)
         lds_fetch_column<M, WIDE>(wc, lds_raw, sym[0]);
-    float best_v = -INFINITY;
+    float best_v = (MODE == MODE_STORE_ARGMAX) ? __builtin_nanf("") : -INFINITY;
     // argmax mode: step index of the lane's best score (0xffffffff = none);
     // threshold mode: "this group saw a hit" flag
     unsigned best_t = (MODE == MODE_THRESHOLD) ? 0u : 0xffffffffu;
@@ -511,7 +521,7 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
     for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
         sp += M * 32;
         tbase += M;
-        if (MODE == MODE_STORE)
+        if (mode_stores(MODE))
             op += M * 32;
         score_group<M, MODE, PFE, LPE, PHASE_MAIN, WIDE, QL>(acc, sym, wc, sp, lds_raw, op, tbase, col,
                                                    best_v, best_t, fo, shq);
@@ -519,7 +529,7 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
     }
     sp += M * 32;
     tbase += M;
-    if (MODE == MODE_STORE)
+    if (mode_stores(MODE))
         op += M * 32;
     score_group<M, MODE, PFE, LPE, PHASE_LAST, WIDE, QL>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
                                                best_t, fo, shq);
@@ -546,7 +556,19 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         });
     }
 
-    if (MODE == MODE_ARGMAX) {
+    if (MODE == MODE_STORE_ARGMAX) {
+        // one record per WAVEFRONT (no workgroup barrier at the end of a short-lived
+        // workgroup: with ~80 steps per stream the barrier + LDS reduce cost 15 %);
+        // "index" = the workgroup, ties go to the later rows
+        long long idx = best_v != best_v ? -1 : (long long)bid;
+        best_wave_reduce(best_v, idx);
+        if ((threadIdx.x & 63) == 0) {
+            ArgmaxRecord *rec = fo.block_best + (size_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+            rec->value = best_v;
+            rec->index = idx;
+            rec->found = idx >= 0;
+        }
+    } else if (mode_tracks_best(MODE)) {
         // the table is dead: reuse the dynamic LDS (>= 64 B) as reduction scratch
         __syncthreads();
         long long *sm_i = reinterpret_cast<long long *>(lds_raw);
@@ -641,9 +663,10 @@ hipError_t score_c32_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, con
 // Filled by the score_inst_*.hip translation units; [M][MODE], nullptr if absent.
 // Registry row: [0..2] = modes, [3] = store kernel WITH the XCD remap (A/B knob),
 // [4..6] = modes for wide alphabets (K > 16).
-constexpr int kRegistrySlots = 8;
+constexpr int kRegistrySlots = 10;
 ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap = false, bool wide = false);
 ScoreC32Launcher score_c32_lookup_ql(int M);
+ScoreC32Launcher score_c32_lookup_store_argmax(int M);
 const char *score_c32_name(int M, int mode);
 
 }  // namespace lm

@@ -118,6 +118,11 @@ class Pipeline:
     def set_prefilter(self, enabled: bool) -> None:
         check(self._L.lm_hip_ctx_set_prefilter(self._h, int(enabled)))
 
+    def set_track_argmax(self, enabled: bool) -> None:
+        """``score_into`` on large matrices also tracks the maximum so that ``argmax`` on the
+        same scores is free (default on)."""
+        check(self._L.lm_hip_ctx_set_track_argmax(self._h, int(enabled)))
+
     def set_xcd_remap(self, enabled: bool) -> None:
         check(self._L.lm_hip_ctx_set_xcd_remap(self._h, int(enabled)))
 

@@ -222,3 +222,52 @@ def test_fused_argmax_candidate_route_against_oracle(gpu_pli, kind):
     for q, r in zip(others, res):
         w, _ = co.score_rows(ref20, q.data)
         assert r[0] == co.argmax(w, 32), len(q)
+
+
+@pytest.mark.parametrize("kind", ["normal", "ties", "all_neg_inf", "nan_weights", "first_cell_nan"])
+def test_tracked_argmax_of_score_into(gpu_pli, kind):
+    """score_into on >= 8 Mi cells tracks the maximum in the store kernel; argmax on the same
+    handle must still be the Generic answer (last maximal cell; NaN never wins; a NaN in cell
+    (0, 0) wins outright), equal to the second-pass reduction, with the knob on and off."""
+    import lightmotif_amd as lm
+    from oracle import c_oracle as co
+    pli = gpu_pli
+    rng = np.random.default_rng({"normal": 11, "ties": 12, "all_neg_inf": 13, "nan_weights": 14,
+                                 "first_cell_nan": 15}[kind])
+    length, m = 9_000_017, 12
+    enc = rng.integers(0, 4, length, dtype=np.uint8)
+    p = np.zeros((m, 8), np.float32)
+    p[:, :4] = rng.integers(-1, 2, (m, 4)) if kind == "ties" else rng.normal(0, 2, (m, 4))
+    p[:, 4] = -np.inf
+    if kind == "all_neg_inf":
+        enc[:] = 4
+    if kind == "nan_weights":
+        p[3, 1] = np.nan                       # every window with a C at offset 3 scores NaN
+    if kind == "first_cell_nan":
+        p[0, int(enc[0])] = np.nan             # cell (0, 0) is NaN (and many others)
+    ref = co.stripe(enc, 32, 5)
+    co.configure_wrap(ref, m - 1)
+    want, _ = co.score_rows(ref, p)
+    want_am = co.argmax(want, 32)
+    seq = pli.stripe(lm.EncodedSequence(enc), 32)
+    seq.configure_wrap(m - 1)
+    pssm = lm.ScoringMatrix(p)
+    for on in (True, False):
+        pli.set_track_argmax(on)
+        try:
+            scores = pli.score(pssm, seq)
+            got = pli.argmax(scores)
+            gmax = pli.max(scores)
+        finally:
+            pli.set_track_argmax(True)
+        assert got == want_am, (kind, on)
+        wmax = co.max_(want, 32)
+        assert np.float32(gmax).view(np.uint32) == np.float32(wmax).view(np.uint32), (kind, on)
+        assert pli.argmax_dptr(scores.data_ptr, scores.rows, 32, 32)[0] == want_am
+    # scoring another motif into the same handle replaces the cached result
+    p2 = p.copy()
+    p2[:, :4] = rng.normal(0, 2, (m, 4))
+    p2[np.isnan(p2)] = 0.5
+    want2, _ = co.score_rows(ref, p2)
+    pli.score_into(lm.ScoringMatrix(p2), seq, scores)
+    assert pli.argmax(scores) == co.argmax(want2, 32)
