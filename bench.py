@@ -143,7 +143,7 @@ def main() -> None:
         g_rows = idx % total_rows
         mine = (g_rows >= rows * rank) & (g_rows < rows * (rank + 1))
         shard[(g_rows[mine] - rows * rank), (idx[mine] // total_rows)] = 4
-    D.exchange_halo(shard, m - 1, COLS, 4)              # RCCL send/recv of (M-1) x 32 bytes
+    D.exchange_halo(shard, m - 1, COLS, 4)              # RCCL all_gather of (M-1) x 32 bytes per rank
     scores = torch.empty((rows, COLS), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
 

@@ -152,15 +152,16 @@ def exchange_halo(shard: torch.Tensor, halo_rows: int, columns: int, default_sym
         return shard
     head = shard[:halo_rows].contiguous()
     if world > 1 and head.is_cuda and dist.get_backend(group) == "gloo":
-        head = head.cpu()  # gloo has no device-to-device send/recv: stage through the host
+        head = head.cpu()  # gloo collectives run on host tensors: stage through the host
     if world == 1:
         recv = head
     else:
-        recv = torch.empty_like(head)
-        dst, src = (rank - 1) % world, (rank + 1) % world
-        ops = [dist.P2POp(dist.isend, head, dst, group), dist.P2POp(dist.irecv, recv, src, group)]
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+        # every rank needs the head rows of its successor: (M-1) x 32 bytes each.  An
+        # all_gather of all heads (a few KB in total) is the sturdiest way to move them --
+        # no point-to-point pairing to get wrong, one collective every rank enters alike.
+        heads = [torch.empty_like(head) for _ in range(world)]
+        dist.all_gather(heads, head, group=group)
+        recv = heads[(rank + 1) % world]
     if rank == world - 1:
         wrapped = torch.zeros_like(recv)
         wrapped[:, :columns - 1] = recv[:, 1:columns]
