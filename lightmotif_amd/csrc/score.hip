@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void argmax_finalize_locate(
 
 // Store + running best: the scores are written exactly like launch_score_store does; the
 // kernel's per-workgroup (max value, workgroup) records are reduced (Generic rule, first-cell
-// NaN rule on the stored matrix) and `argmax_locate` finds the cell in the winning
+// NaN rule on the stored matrix) and the cell is found in the winning
 // workgroup's rows; the result lands in `d_result`, all on the same stream.  Returns
 // *tracked = false (after a plain store) for shapes the C = 32 kernels do not cover.
 int launch_score_store_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *d_result, bool *tracked)
