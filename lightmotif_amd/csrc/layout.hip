@@ -26,7 +26,7 @@ __global__ __launch_bounds__(kBlock) void encode_kernel(const uint8_t *__restric
     {
         // abc.rs:106-108 "ACTGN", abc.rs:193-256 "ACDEFGHIKLMNPQRSTVWYX"
         const char *order = protein ? "ACDEFGHIKLMNPQRSTVWYX" : "ACTGN";
-        const int k = protein ? 21 : 5;
+        const unsigned k = protein ? 21u : 5u;
         lut[threadIdx.x] = 0xff;
         __syncthreads();
         if (threadIdx.x < k)
