@@ -1065,7 +1065,10 @@ __global__ void argmax_collect(const unsigned n, const unsigned *__restrict__ be
     out[j] = r;
 }
 
-constexpr unsigned long long kPrefilterArgmaxMinCells = 32ull << 20;  // below: launch-latency bound
+// The route has ~60 us of fixed cost per call (sample, five small launches): it pays from
+// ~100 M cells per call on (measured crossover at M = 20), whether in one job or in a batch.
+constexpr unsigned long long kPrefilterArgmaxMinCells = 8ull << 20;     // per job
+constexpr unsigned long long kPrefilterArgmaxMinTotal = 100ull * 1000 * 1000;  // per call
 
 // Tries the candidate route for the jobs that qualify; done[i] = 1 and out[i] filled for
 // the ones it settled.  Anything else (small jobs, odd shapes, no prefilter, all -inf
@@ -1086,7 +1089,10 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
             pick.push_back(i);
     }
     const size_t nq = pick.size();
-    if (nq == 0 || nq > (1u << 20))
+    unsigned long long picked_cells = 0;
+    for (size_t i : pick)
+        picked_cells += (unsigned long long)(jobs[i].row_end - jobs[i].row_begin) * jobs[i].cols;
+    if (nq == 0 || nq > (1u << 20) || picked_cells < kPrefilterArgmaxMinTotal)
         return LM_HIP_OK;
     std::vector<ScoreArgs> qjobs(nq);
     std::vector<SampleJob> sjobs(nq);

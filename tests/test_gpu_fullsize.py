@@ -177,7 +177,7 @@ def test_more_positions_than_u32_max(gpu_pli):
 
 @pytest.mark.parametrize("kind", ["normal", "ties", "late_maximum", "mostly_n"])
 def test_fused_argmax_candidate_route_against_oracle(gpu_pli, kind):
-    """Above 32 Mi cells the fused argmax takes the sample -> prefilter scan -> exact re-scoring
+    """From ~100 M cells per call the fused argmax takes the sample -> prefilter scan -> exact re-scoring
     route (score.hip: argmax_by_prefilter).  It must return the Generic answer -- the LAST
     maximal cell -- also when many cells tie (lists overflow -> exact kernel), when the sample
     misses the region holding the maximum, and when most of the sample is -inf."""
@@ -185,7 +185,7 @@ def test_fused_argmax_candidate_route_against_oracle(gpu_pli, kind):
     from oracle import c_oracle as co
     pli = gpu_pli
     rng = np.random.default_rng({"normal": 1, "ties": 2, "late_maximum": 3, "mostly_n": 4}[kind])
-    length, m = 34_000_123, 16
+    length, m = 104_000_123, 16
     enc = rng.integers(0, 4, length, dtype=np.uint8)
     p = np.zeros((m, 8), np.float32)
     p[:, :4] = rng.integers(-2, 3, (m, 4)) if kind == "ties" else rng.normal(0, 2, (m, 4))
