@@ -88,7 +88,10 @@ def test_random_configuration(pli, seed):
         pli.set_prefilter(True)
 
 
-@pytest.mark.parametrize("seed", range(40))
+BATCH_SEEDS = range(int(os.environ.get("LM_FUZZ_BATCH_FIRST", "0")), int(os.environ.get("LM_FUZZ_BATCH_LAST", "40")))
+
+
+@pytest.mark.parametrize("seed", BATCH_SEEDS)
 def test_random_batch(pli, seed):
     """Random many-motif batches (equal lengths share a launch, odd shapes go to the generic kernel,
     some thresholds select nothing or everything): every job must equal its own oracle result."""
