@@ -137,3 +137,40 @@ def test_random_batch(pli, seed):
         wrc = co.threshold(w, 32, ts[i]).astype(np.int64).reshape(-1, 2)
         assert np.array_equal(got_th[i][0], wrc), (i, lengths[i], ts[i])
         assert np.array_equal(bits(got_th[i][1]), bits(w[wrc[:, 0], wrc[:, 1]]))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_large(pli, seed):
+    """Sizes where the big-input routes switch on (tracked argmax of score_into from 8 Mi cells,
+    candidate-route fused argmax from ~100 M cells): random motif lengths and matrix kinds
+    against the C oracle."""
+    rng = np.random.default_rng(50_000 + seed)
+    m = int(rng.integers(6, 37))
+    length = int(rng.choice([9_000_000, 40_000_000, 101_000_000])) + int(rng.integers(0, 97))
+    enc = rng.integers(0, 4, length, dtype=np.uint8)
+    if seed % 3 == 0:
+        enc[rng.random(length) < 0.01] = 4
+    p = np.zeros((m, 8), np.float32)
+    p[:, :4] = rng.integers(-2, 3, (m, 4)) if seed % 4 == 1 else rng.normal(0, 2, (m, 4))
+    p[:, 4] = -np.inf if seed % 5 else rng.normal(0, 2, m)
+    ref = co.stripe(enc, 32, 5)
+    co.configure_wrap(ref, m - 1)
+    want, _ = co.score_rows(ref, p)
+    want_am = co.argmax(want, 32)
+    seq = pli.stripe(lm.EncodedSequence(enc), 32)
+    seq.configure_wrap(m - 1)
+    pssm = lm.ScoringMatrix(p)
+    fused = pli.score_argmax(pssm, seq)
+    assert fused[0] == want_am, (m, length, pli.last_kernel)
+    assert bits(np.float32(fused[1])) == bits(co.max_(want, 32))
+    scores = pli.score(pssm, seq)
+    assert pli.argmax(scores) == want_am                       # tracked by the store kernel
+    sample = scores.rows_matrix(0, min(scores.rows, 4096))
+    assert np.array_equal(bits(sample[:, :32]), bits(want[:sample.shape[0], :32]))
+    finite = want[:, :32][np.isfinite(want[:, :32])]
+    t = float(np.partition(finite, -2000)[-2000]) if finite.size > 2000 else 0.0
+    wrc = co.threshold(want, 32, t).astype(np.int64).reshape(-1, 2)
+    rc, vals = pli.score_threshold_dptr(pssm, seq.data_ptr, seq.rows + seq.wrap, 32, 32, seq.wrap,
+                                        length, 0, seq.rows, t)
+    assert np.array_equal(rc, wrc), (m, length, t)
+    assert np.array_equal(bits(vals), bits(want[wrc[:, 0], wrc[:, 1]]))
