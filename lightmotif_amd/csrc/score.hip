@@ -135,7 +135,9 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store, i
         return p;
     if (a.pssm->m < 1 || a.pssm->m > (size_t)kMaxFastM || n < M + extra)
         return p;
-    if (prefilter == 2 && (K != 5 || !a.pssm->d_image2 || a.pssm->m < 2))
+    // (the pair-symbol kernel fetches symbols with dword loads: 4-byte aligned matrix)
+    if (prefilter == 2 && (K != 5 || !a.pssm->d_image2 || a.pssm->m < 2 ||
+                           reinterpret_cast<uintptr_t>(a.d_seq) % 4 != 0))
         return p;
     const size_t lds = prefilter == 2   ? (size_t)prefilter2_image_dw((int)a.pssm->m) * 4
                        : prefilter == 1 ? (size_t)prefilter_image_dw((int)a.pssm->m, (int)K) * 4
