@@ -271,3 +271,39 @@ def test_tracked_argmax_of_score_into(gpu_pli, kind):
     want2, _ = co.score_rows(ref, p2)
     pli.score_into(lm.ScoringMatrix(p2), seq, scores)
     assert pli.argmax(scores) == co.argmax(want2, 32)
+
+
+@pytest.mark.parametrize("offset", [1, 2, 3])
+def test_unaligned_sequence_pointer(gpu_pli, offset):
+    """Device pointers handed over by a caller need not be 4-byte aligned: the kernels that fetch
+    symbols with dword loads must step aside (byte-load variants), results unchanged."""
+    pli = gpu_pli
+    dev = torch.device("cuda", 0)
+    length, m = 3_000_017, 20
+    rows = -(-length // COLS)
+    rng = np.random.default_rng(offset)
+    sites = ["".join("ACTG"[i] for i in rng.integers(0, 4, m)) for _ in range(10)]
+    pssm = lm.create(sites).counts.normalize(0.1).log_odds()
+    flat = torch.zeros((rows + m - 1) * COLS + 8, dtype=torch.uint8, device=dev)
+    aligned = flat[: (rows + m - 1) * COLS].view(rows + m - 1, COLS)
+    aligned[:rows] = torch.randint(0, 4, (rows, COLS), dtype=torch.uint8, device=dev)
+    pli.configure_wrap_dptr(aligned.data_ptr(), rows, COLS, COLS, m - 1, 4)
+    shifted = torch.zeros_like(flat)
+    shifted[offset: offset + aligned.numel()] = aligned.reshape(-1)
+    ptr_a, ptr_u = aligned.data_ptr(), shifted.data_ptr() + offset
+    assert ptr_u % 4 == offset % 4
+    out_a = torch.empty((rows, COLS), dtype=torch.float32, device=dev)
+    out_u = torch.empty_like(out_a)
+    pli.score_dptr(pssm, ptr_a, rows + m - 1, COLS, COLS, m - 1, length, 0, rows, out_a.data_ptr(), COLS)
+    pli.score_dptr(pssm, ptr_u, rows + m - 1, COLS, COLS, m - 1, length, 0, rows, out_u.data_ptr(), COLS)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a.view(torch.int32), out_u.view(torch.int32))
+    am_a = pli.score_argmax_dptr(pssm, ptr_a, rows + m - 1, COLS, COLS, m - 1, length, 0, rows)
+    am_u = pli.score_argmax_dptr(pssm, ptr_u, rows + m - 1, COLS, COLS, m - 1, length, 0, rows)
+    assert am_a == am_u
+    t = float(torch.quantile(out_a.view(-1)[:4_000_000], 1 - 1e-4))
+    th_a = pli.score_threshold_dptr(pssm, ptr_a, rows + m - 1, COLS, COLS, m - 1, length, 0, rows, t)
+    assert pli.last_kernel == "score_c32_prefilter2"
+    th_u = pli.score_threshold_dptr(pssm, ptr_u, rows + m - 1, COLS, COLS, m - 1, length, 0, rows, t)
+    assert pli.last_kernel == "score_c32_prefilter"
+    assert np.array_equal(th_a[0], th_u[0]) and np.array_equal(th_a[1], th_u[1]) and len(th_a[0]) > 50
