@@ -401,6 +401,16 @@ public:
     // Pipeline::avx2() -> Result<Self, UnsupportedBackend> (pli/mod.rs:401-407)
     static Pipeline hip(int device = 0) { return Pipeline(std::make_shared<CtxHandle>(device)); }
 
+    // the best cell and its score; the cells with score >= t in row-major order
+    struct Best {
+        MatrixCoordinates cell;
+        float score;
+    };
+    struct Cells {
+        std::vector<MatrixCoordinates> coords;
+        std::vector<float> scores;
+    };
+
     // Encode (pli/mod.rs:47-50)
     EncodedSequence<A> encode(const std::string &text) const { return EncodedSequence<A>::encode(text); }
 
@@ -479,6 +489,42 @@ public:
         return out;
     }
 
+    // score + argmax / score + threshold without materialising the scores (what the bench
+    // harness dna.rs:104-107 and the Scanner need); same results as score() followed by
+    // argmax() / threshold(), cells in row-major order
+    std::optional<Best> score_argmax(const ScoringMatrix<A> &pssm, const StripedSequence<A> &seq) const
+    {
+        const SeqView v = view(seq);
+        int found = 0;
+        lm_hip_coords best{};
+        float value = 0;
+        check(lm_hip_score_argmax_f32_dptr(ctx_->ctx, pssm.device(ctx_->ctx), v.data, v.rows + v.wrap, v.stride,
+                                           v.cols, v.wrap, v.length, 0, v.rows, &found, &best, &value));
+        if (!found)
+            return std::nullopt;
+        return Best{{best.row, best.col}, value};
+    }
+    Cells score_threshold(const ScoringMatrix<A> &pssm, const StripedSequence<A> &seq, float t) const
+    {
+        const SeqView v = view(seq);
+        lm_hip_coords *c = nullptr;
+        float *vals = nullptr;
+        size_t n = 0;
+        check(lm_hip_score_threshold_f32_dptr(ctx_->ctx, pssm.device(ctx_->ctx), v.data, v.rows + v.wrap,
+                                              v.stride, v.cols, v.wrap, v.length, 0, v.rows, t, &c, &vals, &n));
+        Cells out;
+        out.coords.resize(n);
+        out.scores.assign(vals, vals + n);
+        for (size_t k = 0; k < n; ++k)
+            out.coords[k] = {c[k].row, c[k].col};
+        lm_hip_free(c);
+        lm_hip_free(vals);
+        return out;
+    }
+    // tuning knobs of the context (results never depend on them)
+    void set_prefilter(bool on) const { check(lm_hip_ctx_set_prefilter(ctx_->ctx, on ? 1 : 0)); }
+    void set_track_argmax(bool on) const { check(lm_hip_ctx_set_track_argmax(ctx_->ctx, on ? 1 : 0)); }
+
     // Encode + Stripe of raw text in one go, on the device (pli/mod.rs:47-66 + 166-175):
     // the text is uploaded once, encoded and striped by the kernels.  Throws InvalidSymbol.
     StripedSequence<A> stripe_text(const std::string &text, size_t columns = 32, bool lossy = false) const
@@ -495,10 +541,6 @@ public:
 
     // Many motifs over one resident sequence (the CLI's fan-out, lightmotif-cli main.rs:554-561):
     // per motif the best cell and its score, or nullopt when the sequence is shorter than the motif.
-    struct Best {
-        MatrixCoordinates cell;
-        float score;
-    };
     std::vector<std::optional<Best>> scan_argmax_batch(const std::vector<const ScoringMatrix<A> *> &pssms,
                                                        const StripedSequence<A> &seq) const
     {
@@ -518,10 +560,6 @@ public:
         return out;
     }
     // per motif: the cells with score >= thresholds[i] in row-major order, with their scores
-    struct Cells {
-        std::vector<MatrixCoordinates> coords;
-        std::vector<float> scores;
-    };
     std::vector<Cells> scan_threshold_batch(const std::vector<const ScoringMatrix<A> *> &pssms,
                                             const std::vector<float> &thresholds,
                                             const StripedSequence<A> &seq) const
@@ -552,6 +590,16 @@ public:
     }
 
 private:
+    struct SeqView {
+        const uint8_t *data = nullptr;
+        size_t length = 0, wrap = 0, rows = 0, stride = 0, cols = 0;
+    };
+    static SeqView view(const StripedSequence<A> &seq)
+    {
+        SeqView v;
+        check(lm_hip_seq_info(seq.handle(), &v.length, &v.wrap, &v.rows, &v.stride, &v.cols, &v.data));
+        return v;
+    }
     explicit Pipeline(std::shared_ptr<CtxHandle> c) : ctx_(std::move(c)) {}
     std::shared_ptr<CtxHandle> ctx_;
 };

@@ -158,6 +158,19 @@ static void test_batch(const Pipeline<Dna> &pli)
     striped.configure(pssm);
     const std::vector<const ScoringMatrix<Dna> *> motifs = {&pssm, &shorter};
 
+    // fused single-motif forms == score() followed by argmax() / threshold(), knobs change nothing
+    for (bool on : {true, false}) {
+        pli.set_prefilter(on);
+        pli.set_track_argmax(on);
+        const auto scores = pli.score(pssm, striped);
+        const auto fused = pli.score_argmax(pssm, striped);
+        CHECK(fused && pli.argmax(scores) && fused->cell == *pli.argmax(scores) && fused->score == *scores.max());
+        const auto cells = pli.score_threshold(pssm, striped, -15.0f);
+        CHECK(cells.coords == pli.threshold(scores, -15.0f) && cells.coords.size() == 10);
+    }
+    pli.set_prefilter(true);
+    pli.set_track_argmax(true);
+
     const auto best = pli.scan_argmax_batch(motifs, striped);
     CHECK(best.size() == 2 && best[0] && best[1]);
     for (size_t i = 0; i < 2 && i < best.size(); ++i) {
