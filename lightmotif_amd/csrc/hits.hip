@@ -41,23 +41,36 @@ __device__ __forceinline__ unsigned long long bucket_start(
     return b < nbuckets ? tiles[b / kScanTile] + offsets[b] : count;
 }
 
+// Every kernel reads the record count from the device counter the scans bumped (clamped to
+// the list capacity), so the ordering can be enqueued BEFORE the host knows the count.
+__device__ __forceinline__ unsigned long long live_count(const unsigned long long *count_ptr,
+                                                         const unsigned long long cap)
+{
+    const unsigned long long n = *count_ptr;
+    return n < cap ? n : cap;
+}
+
 __global__ __launch_bounds__(kBlock) void hits_bucket_count(const HitRecord *__restrict__ hits,
-                                                            const unsigned long long count,
+                                                            const unsigned long long *__restrict__ count_ptr,
+                                                            const unsigned long long cap,
                                                             const int shift,
                                                             const unsigned long long nb,
                                                             unsigned *__restrict__ counts)
 {
+    const unsigned long long count = live_count(count_ptr, cap);
     for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < count;
          i += (unsigned long long)gridDim.x * kBlock)
         atomicAdd(&counts[bucket_of(hits[i].key, shift, nb)], 1u);
 }
 
 __global__ __launch_bounds__(kBlock) void hits_bucket_scatter(
-    const HitRecord *__restrict__ hits, const unsigned long long count, const int shift,
+    const HitRecord *__restrict__ hits, const unsigned long long *__restrict__ count_ptr,
+    const unsigned long long cap, const int shift,
     const unsigned long long nb, const unsigned long long *__restrict__ offsets,
     const unsigned long long *__restrict__ tiles, unsigned *__restrict__ counts,
     HitRecord *__restrict__ grouped)
 {
+    const unsigned long long count = live_count(count_ptr, cap);
     for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < count;
          i += (unsigned long long)gridDim.x * kBlock) {
         const HitRecord r = hits[i];
@@ -71,18 +84,25 @@ __global__ __launch_bounds__(kBlock) void hits_bucket_scatter(
 // EMIT 1: lm_hip_hit {low, score} (Scanner: low is the sequence position)
 template <int EMIT>
 __global__ __launch_bounds__(kBlock) void hits_rank_emit(
-    const HitRecord *__restrict__ grouped, const unsigned long long count, const int shift,
+    const HitRecord *__restrict__ grouped, const unsigned long long *__restrict__ count_ptr,
+    const unsigned long long cap, const int shift,
     const unsigned long long nb, const unsigned long long nbuckets,
     const unsigned long long *__restrict__ offsets, const unsigned long long *__restrict__ tiles,
     const unsigned long long cols, lm_hip_coords *__restrict__ coords, float *__restrict__ values,
-    lm_hip_hit *__restrict__ out_hits)
+    lm_hip_hit *__restrict__ out_hits, const unsigned long long max_bucket, unsigned *__restrict__ abort_flag,
+    void *__restrict__ pre_out, float *__restrict__ pre_values, const unsigned long long pre)
 {
+    const unsigned long long count = live_count(count_ptr, cap);
     for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < count;
          i += (unsigned long long)gridDim.x * kBlock) {
         const HitRecord r = grouped[i];
         const unsigned long long b = bucket_of(r.key, shift, nb);
         const unsigned long long lo = bucket_start(b, nbuckets, count, offsets, tiles);
         const unsigned long long hi = bucket_start(b + 1, nbuckets, count, offsets, tiles);
+        if (hi - lo > max_bucket) {  // the bucket geometry was guessed far too coarse: give up, the
+            *abort_flag = 1u;        // host re-runs the ordering with the true count
+            continue;
+        }
         unsigned long long rank = 0;
         for (unsigned long long k = lo; k < hi; ++k) {
             const unsigned long long other = grouped[k].key;
@@ -96,22 +116,35 @@ __global__ __launch_bounds__(kBlock) void hits_rank_emit(
             c.col = low - c.row * cols;
             coords[pos] = c;
             values[pos] = r.value;
+            if (pos < pre) {  // the head of the list is mirrored into the staging block
+                static_cast<lm_hip_coords *>(pre_out)[pos] = c;
+                pre_values[pos] = r.value;
+            }
         } else {
             lm_hip_hit h;
             h.position = low;
             h.score = r.value;
             out_hits[pos] = h;
+            if (pos < pre)
+                static_cast<lm_hip_hit *>(pre_out)[pos] = h;
         }
     }
 }
 
 __global__ void hits_job_starts(const unsigned long long njobs, const unsigned long long nb,
-                                const unsigned long long nbuckets, const unsigned long long count,
+                                const unsigned long long nbuckets,
+                                const unsigned long long *__restrict__ count_ptr, const unsigned long long cap,
                                 const unsigned long long *__restrict__ offsets,
                                 const unsigned long long *__restrict__ tiles,
-                                unsigned long long *__restrict__ starts)
+                                unsigned long long *__restrict__ starts,
+                                unsigned long long *__restrict__ header)
 {
+    const unsigned long long count = live_count(count_ptr, cap);
     const unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0 && header) {  // raw counters {hits, candidates} for the host
+        header[0] = count_ptr[0];
+        header[1] = count_ptr[1];
+    }
     if (j <= njobs)
         starts[j] = bucket_start(j * nb, nbuckets, count, offsets, tiles);
 }
@@ -131,26 +164,43 @@ void HitOutput::release()
     total = 0;
 }
 
-// `d_hits`: `count` records (in ctx->scratch) of `njobs` jobs whose keys' low parts are
-// all below `max_low`.  On success `out` owns malloc'ed host arrays in key order and
-// job_start[j] .. job_start[j + 1] delimit job j.  Uses ctx->scratch2; synchronises.
-int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, unsigned long long count, size_t njobs,
-               unsigned long long max_low, int emit, size_t cols, HitOutput *out)
+// `d_hits`: the records (in ctx->scratch) of `njobs` jobs whose keys' low parts are all below
+// `max_low`; `d_counters` = the two device counters {hits, candidates} the scans bumped.
+//
+// count == ~0 ("speculative"): the host does not know the count yet.  The ordering is
+// enqueued right behind the scans with a bucket geometry sized for `expected` records and
+// every array sized for `cap`; counters, job offsets and the first kPrefix records come
+// back in one pinned copy behind ONE synchronisation -- the usual p = 1e-5 scan then costs
+// one host round trip instead of two.  *status: 0 = done, 1 = a list overflowed (counts in
+// counts_out, nothing produced), 2 = counts fine but the geometry guess was too coarse
+// (the caller runs the exact form).  With a known `count` the geometry is exact.
+// On success `out` owns malloc'ed host arrays in key order and job_start[j] ..
+// job_start[j + 1] delimit job j.  Uses ctx->scratch2; synchronises.
+constexpr unsigned long long kPrefix = 12800;  // x 20 B = 256 KB
+
+int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long long *d_counters,
+               unsigned long long count, unsigned long long cap, unsigned long long cand_cap,
+               unsigned long long expected, size_t njobs, unsigned long long max_low, int emit, size_t cols,
+               HitOutput *out, int *status, unsigned long long counts_out[2])
 {
+    const bool speculative = count == ~0ull;
+    *status = 0;
     out->job_start.assign(njobs + 1, 0);
     out->total = 0;
-    if (count == 0)
+    if (!speculative && count == 0)
         return LM_HIP_OK;
     if (max_low == 0)
         max_low = 1;
     if (max_low > kLowMask + 1)
         return fail(LM_HIP_ERR_CAPACITY, "fused threshold: %llu cells per job exceed the 2^40 key space",
                     max_low);
+    const unsigned long long sized_for = speculative ? std::max<unsigned long long>(expected, 4096) : count;
+    const unsigned long long room = speculative ? cap : count;  // records the arrays must hold
     // ~8 records per bucket on average; at most 2^26 buckets
     int shift = 5;
     {
         const long double universe = (long double)max_low * (long double)njobs;
-        while (shift < 40 && ((long double)(1ull << shift) * (long double)count < 8.0L * universe))
+        while (shift < 40 && ((long double)(1ull << shift) * (long double)sized_for < 8.0L * universe))
             ++shift;
         while (shift < 40 && (((max_low - 1) >> shift) + 1) * njobs > (1ull << 26))
             ++shift;
@@ -161,14 +211,22 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, unsigned long long coun
 
     const size_t rec_bytes = emit == 0 ? sizeof(lm_hip_coords) : sizeof(lm_hip_hit);
     const size_t off_grouped = 0;
-    const size_t off_counts = off_grouped + align16(count * sizeof(HitRecord));
+    const size_t off_counts = off_grouped + align16(room * sizeof(HitRecord));
     const size_t off_offsets = off_counts + align16(nbuckets * 4);
     const size_t off_tiles = off_offsets + align16(nbuckets * 8);
     const size_t off_total = off_tiles + align16(ntiles * 8);
-    const size_t off_starts = off_total + 16;
-    const size_t off_out = off_starts + align16((njobs + 1) * 8);
-    const size_t off_values = off_out + align16(count * rec_bytes);
-    const size_t bytes = off_values + align16(count * sizeof(float));
+    // head of the list mirrored into the staging block: the previous call's length with headroom,
+    // bounded so that the staging copy stays a small pinned transfer
+    const unsigned long long pre =
+        speculative ? std::min(room, std::min<unsigned long long>(std::max<unsigned long long>(sized_for, 2048), kPrefix)) : 0;
+    const size_t off_header = off_total + 16;  // staging block: counters | abort | starts | head of the list
+    const size_t off_abort = off_header + 16;
+    const size_t off_starts = off_abort + 16;
+    const size_t off_pre_out = off_starts + align16((njobs + 1) * 8);
+    const size_t off_pre_values = off_pre_out + align16(pre * rec_bytes);
+    const size_t off_out = off_pre_values + align16(pre * sizeof(float));
+    const size_t off_values = off_out + align16(room * rec_bytes);
+    const size_t bytes = off_values + align16(room * sizeof(float));
     LM_TRY(ctx->scratch2.reserve(bytes));
     char *base = static_cast<char *>(ctx->scratch2.ptr);
     HitRecord *grouped = reinterpret_cast<HitRecord *>(base + off_grouped);
@@ -176,32 +234,109 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, unsigned long long coun
     unsigned long long *offsets = reinterpret_cast<unsigned long long *>(base + off_offsets);
     unsigned long long *tiles = reinterpret_cast<unsigned long long *>(base + off_tiles);
     unsigned long long *total = reinterpret_cast<unsigned long long *>(base + off_total);
+    unsigned long long *header = reinterpret_cast<unsigned long long *>(base + off_header);
+    unsigned *abort_flag = reinterpret_cast<unsigned *>(base + off_abort);
+    void *pre_out = base + off_pre_out;
+    float *pre_values = reinterpret_cast<float *>(base + off_pre_values);
     unsigned long long *starts = reinterpret_cast<unsigned long long *>(base + off_starts);
     void *d_out = base + off_out;
     float *d_values = reinterpret_cast<float *>(base + off_values);
+    const unsigned long long max_bucket = speculative ? 2048 : ~0ull;
 
     hipStream_t st = ctx->stream;
-    const unsigned grid = (unsigned)std::min<unsigned long long>((count + kBlock - 1) / kBlock,
-                                                                 (unsigned long long)ctx->num_cus * 32);
+    const unsigned grid = (unsigned)std::max<unsigned long long>(
+        std::min<unsigned long long>((sized_for + kBlock - 1) / kBlock, (unsigned long long)ctx->num_cus * 32), 1);
     LM_HIP_TRY(hipMemsetAsync(counts, 0, nbuckets * 4, st));
-    hipLaunchKernelGGL(hits_bucket_count, dim3(grid), dim3(kBlock), 0, st, d_hits, count, shift, nb,
+    LM_HIP_TRY(hipMemsetAsync(abort_flag, 0, 16, st));
+    hipLaunchKernelGGL(hits_bucket_count, dim3(grid), dim3(kBlock), 0, st, d_hits, d_counters, cap, shift, nb,
                        counts);
     LM_TRY(launch_scan_u32(ctx, counts, nbuckets, offsets, tiles, total));
-    hipLaunchKernelGGL(hits_bucket_scatter, dim3(grid), dim3(kBlock), 0, st, d_hits, count, shift, nb,
+    hipLaunchKernelGGL(hits_bucket_scatter, dim3(grid), dim3(kBlock), 0, st, d_hits, d_counters, cap, shift, nb,
                        offsets, tiles, counts, grouped);
     if (emit == 0)
-        hipLaunchKernelGGL(hits_rank_emit<0>, dim3(grid), dim3(kBlock), 0, st, grouped, count, shift,
+        hipLaunchKernelGGL(hits_rank_emit<0>, dim3(grid), dim3(kBlock), 0, st, grouped, d_counters, cap, shift,
                            nb, nbuckets, offsets, tiles, (unsigned long long)cols,
                            static_cast<lm_hip_coords *>(d_out), d_values,
-                           static_cast<lm_hip_hit *>(nullptr));
+                           static_cast<lm_hip_hit *>(nullptr), max_bucket, abort_flag, pre_out, pre_values, pre);
     else
-        hipLaunchKernelGGL(hits_rank_emit<1>, dim3(grid), dim3(kBlock), 0, st, grouped, count, shift,
+        hipLaunchKernelGGL(hits_rank_emit<1>, dim3(grid), dim3(kBlock), 0, st, grouped, d_counters, cap, shift,
                            nb, nbuckets, offsets, tiles, (unsigned long long)cols,
                            static_cast<lm_hip_coords *>(nullptr), static_cast<float *>(nullptr),
-                           static_cast<lm_hip_hit *>(d_out));
+                           static_cast<lm_hip_hit *>(d_out), max_bucket, abort_flag, pre_out, pre_values, pre);
     hipLaunchKernelGGL(hits_job_starts, dim3((unsigned)((njobs + 1 + 255) / 256)), dim3(256), 0, st,
-                       (unsigned long long)njobs, nb, nbuckets, count, offsets, tiles, starts);
+                       (unsigned long long)njobs, nb, nbuckets, d_counters, cap, offsets, tiles, starts,
+                       speculative ? header : static_cast<unsigned long long *>(nullptr));
     LM_HIP_TRY(hipGetLastError());
+
+    static_assert(sizeof(size_t) == 8, "job offsets are read back as 64-bit values");
+    const size_t starts_bytes = (njobs + 1) * 8;
+    char *pin = static_cast<char *>(ctx->pinned);
+    if (speculative) {
+        // one pinned block = the staging block: counters | abort flag | starts | head of the list
+        const size_t p_abort = off_abort - off_header, p_starts = off_starts - off_header;
+        const size_t p_out = off_pre_out - off_header, p_values = off_pre_values - off_header;
+        const size_t block = off_out - off_header;
+        if (block > kPinnedBytes) {
+            *status = 2;  // too many jobs for the staging block: exact form
+            LM_HIP_TRY(hipMemcpyAsync(pin, d_counters, 16, hipMemcpyDeviceToHost, st));
+            LM_HIP_TRY(hipStreamSynchronize(st));
+            counts_out[0] = reinterpret_cast<unsigned long long *>(pin)[0];
+            counts_out[1] = reinterpret_cast<unsigned long long *>(pin)[1];
+            if (counts_out[0] > cap || counts_out[1] > cand_cap)
+                *status = 1;
+            return LM_HIP_OK;
+        }
+        LM_HIP_TRY(hipMemcpyAsync(pin, base + off_header, block, hipMemcpyDeviceToHost, st));
+        LM_HIP_TRY(hipStreamSynchronize(st));
+        counts_out[0] = reinterpret_cast<unsigned long long *>(pin)[0];
+        counts_out[1] = reinterpret_cast<unsigned long long *>(pin)[1];
+        if (counts_out[0] > cap || counts_out[1] > cand_cap) {
+            *status = 1;
+            return LM_HIP_OK;
+        }
+        if (*reinterpret_cast<unsigned *>(pin + p_abort)) {
+            *status = 2;
+            return LM_HIP_OK;
+        }
+        count = counts_out[0];
+        if (count == 0)
+            return LM_HIP_OK;
+        void *host = malloc(count * rec_bytes);
+        float *host_values = emit == 0 ? static_cast<float *>(malloc(count * sizeof(float))) : nullptr;
+        if (!host || (emit == 0 && !host_values)) {
+            free(host);
+            free(host_values);
+            return fail(LM_HIP_ERR_OOM, "fused threshold: cannot allocate %llu hits on the host", count);
+        }
+        memcpy(out->job_start.data(), pin + p_starts, starts_bytes);
+        const unsigned long long have = std::min(count, pre);
+        memcpy(host, pin + p_out, have * rec_bytes);
+        if (host_values)
+            memcpy(host_values, pin + p_values, have * sizeof(float));
+        if (count > have) {  // long list: the rest comes straight from the device
+            hipError_t e = hipMemcpyAsync(static_cast<char *>(host) + have * rec_bytes,
+                                          static_cast<char *>(d_out) + have * rec_bytes,
+                                          (count - have) * rec_bytes, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && host_values)
+                e = hipMemcpyAsync(host_values + have, d_values + have, (count - have) * sizeof(float),
+                                   hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(st);
+            if (e != hipSuccess) {
+                free(host);
+                free(host_values);
+                return fail(LM_HIP_ERR_HIP, "fused threshold: read-back failed: %s", hipGetErrorString(e));
+            }
+        }
+        out->total = (size_t)count;
+        if (emit == 0) {
+            out->coords = static_cast<lm_hip_coords *>(host);
+            out->values = host_values;
+        } else {
+            out->hits = static_cast<lm_hip_hit *>(host);
+        }
+        return LM_HIP_OK;
+    }
 
     void *host = malloc(count * rec_bytes);
     float *host_values = emit == 0 ? static_cast<float *>(malloc(count * sizeof(float))) : nullptr;
@@ -213,16 +348,13 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, unsigned long long coun
     // Read-back.  starts | records | values are contiguous in scratch2: small results come back
     // as ONE copy into the pinned buffer (a copy into pageable memory costs ~15 us each),
     // large ones go straight into the arrays handed to the caller.
-    const size_t starts_bytes = (njobs + 1) * 8;
-    static_assert(sizeof(size_t) == 8, "job offsets are read back as 64-bit values");
     const size_t block_bytes = off_values + count * sizeof(float) - off_starts;
     hipError_t e;
     if (block_bytes <= (256u << 10)) {
-        e = hipMemcpyAsync(ctx->pinned, base + off_starts, block_bytes, hipMemcpyDeviceToHost, st);
+        e = hipMemcpyAsync(pin, base + off_starts, block_bytes, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess)
             e = hipStreamSynchronize(st);
         if (e == hipSuccess) {
-            const char *pin = static_cast<const char *>(ctx->pinned);
             memcpy(out->job_start.data(), pin, starts_bytes);
             memcpy(host, pin + (off_out - off_starts), count * rec_bytes);
             if (host_values)

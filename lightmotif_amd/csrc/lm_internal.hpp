@@ -71,6 +71,7 @@ struct lm_hip_ctx {
     bool pair_prefilter = true;  // DNA prefilter scans look up two symbols at a time
     bool quad_loads = true;      // store kernel: quad-gathered dword symbol loads (M % 4 == 0; +1 %)
     bool track_argmax = true;    // score_into on handles also tracks the best cell (cached argmax)
+    bool speculate_order = true; // fused threshold: order the hit list before the host knows its length
     int num_cus = 256;
     unsigned long long last_hit_count = 0;  // sizes the next fused-threshold hit list
     unsigned long long last_cand_count = 0; // ... and its candidate list
@@ -168,8 +169,11 @@ int launch_score_argmax_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
 
 // hits.hip: device-side ordering of the fused kernels' hit list
 struct HitRecord;
-int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, unsigned long long count, size_t njobs,
-               unsigned long long max_low, int emit, size_t cols, HitOutput *out);
+// count == ~0: speculative (the host has not read the counters yet); see hits.hip
+int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long long *d_counters,
+               unsigned long long count, unsigned long long cap, unsigned long long cand_cap,
+               unsigned long long expected, size_t njobs, unsigned long long max_low, int emit, size_t cols,
+               HitOutput *out, int *status, unsigned long long counts_out[2]);
 
 // reduce.hip: exclusive scan of n u32 counts (async on ctx->stream); the offset of
 // element i is tiles[i / kScanTile] + offsets[i], *total the grand total.

@@ -848,32 +848,64 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
                                ctx->stream, d_jobs, fo);
             LM_HIP_TRY(hipGetLastError());
         }
-        LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, base, 16, hipMemcpyDeviceToHost, ctx->stream));
-        LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-        const unsigned long long count = static_cast<unsigned long long *>(ctx->pinned)[0];
-        const unsigned long long ncand = static_cast<unsigned long long *>(ctx->pinned)[1];
-        ctx->last_cand_count = ncand;
-        if (ncand > ccap) {
-            // the hit count of a truncated candidate list means nothing yet
-            ccap = ncand + ncand / 8 + 64;
-            continue;
-        }
-        ctx->last_hit_count = count;
-        if (count > cap) {
-            cap = count + count / 8 + 64;
-            continue;
-        }
+        const int emit = keys == HitKeys::Position ? 1 : 0;
+        unsigned long long count = 0, ncand = 0;
         const auto t_scan = std::chrono::steady_clock::now();
-        const int st = order_hits(ctx, fo.hits, count, n, max_low, keys == HitKeys::Position ? 1 : 0,
-                                  jobs[0].cols, out);
+        bool ordered = false;
+        if (attempt == 0 && ctx->speculate_order) {
+            // First try: enqueue the ordering right behind the scans, sized from the previous
+            // call's count, and learn the counts from the same single synchronisation.
+            int status = 0;
+            unsigned long long counts[2] = {0, 0};
+            LM_TRY(order_hits(ctx, fo.hits, fo.hit_count, ~0ull, cap, ccap, ctx->last_hit_count + ctx->last_hit_count / 4,
+                              n, max_low, emit, jobs[0].cols, out, &status, counts));
+            count = counts[0];
+            ncand = counts[1];
+            ordered = status == 0;
+            if (status == 1) {  // a list overflowed: grow and run the scans again
+                ctx->last_cand_count = ncand;
+                if (ncand > ccap) {
+                    ccap = ncand + ncand / 8 + 64;
+                    continue;
+                }
+                ctx->last_hit_count = count;
+                cap = count + count / 8 + 64;
+                continue;
+            }
+        } else {
+            LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, base, 16, hipMemcpyDeviceToHost, ctx->stream));
+            LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+            count = static_cast<unsigned long long *>(ctx->pinned)[0];
+            ncand = static_cast<unsigned long long *>(ctx->pinned)[1];
+            if (ncand > ccap) {
+                // the hit count of a truncated candidate list means nothing yet
+                ctx->last_cand_count = ncand;
+                ccap = ncand + ncand / 8 + 64;
+                continue;
+            }
+            if (count > cap) {
+                ctx->last_hit_count = count;
+                cap = count + count / 8 + 64;
+                continue;
+            }
+        }
+        ctx->last_cand_count = ncand;
+        ctx->last_hit_count = count;
+        if (!ordered) {  // exact form: the count is known
+            int status = 0;
+            unsigned long long counts[2];
+            LM_TRY(order_hits(ctx, fo.hits, fo.hit_count, count, cap, ccap, count, n, max_low, emit, jobs[0].cols,
+                              out, &status, counts));
+        }
         if (getenv("LM_HIP_TRACE")) {
             const auto t_end = std::chrono::steady_clock::now();
-            fprintf(stderr, "[lm_hip] fused threshold: %zu jobs, %llu candidates, %llu hits; scan+rescore "
-                            "%.3f ms, order+read-back %.3f ms\n", n, ncand, count,
+            fprintf(stderr, "[lm_hip] fused threshold: %zu jobs, %llu candidates, %llu hits; %s; scans enqueued in "
+                            "%.3f ms, wait + ordering + read-back %.3f ms\n", n, ncand, count,
+                    ordered ? "ordered behind the scans (one synchronisation)" : "ordered after reading the count",
                     std::chrono::duration<double, std::milli>(t_scan - t_begin).count(),
                     std::chrono::duration<double, std::milli>(t_end - t_scan).count());
         }
-        return st;
+        return LM_HIP_OK;
     }
     return fail(LM_HIP_ERR_HIP, "fused threshold: hit list kept overflowing");
 }

@@ -307,3 +307,32 @@ def test_unaligned_sequence_pointer(gpu_pli, offset):
     th_u = pli.score_threshold_dptr(pssm, ptr_u, rows + m - 1, COLS, COLS, m - 1, length, 0, rows, t)
     assert pli.last_kernel == "score_c32_prefilter"
     assert np.array_equal(th_a[0], th_u[0]) and np.array_equal(th_a[1], th_u[1]) and len(th_a[0]) > 50
+
+
+def test_hit_ordering_with_and_without_known_count(monkeypatch):
+    """The fused threshold orders its hit list either after reading the count
+    (LM_HIP_SPECULATE_ORDER=0) or before (default; sized from the previous call and redone
+    when that guess is off): both give the materialised result whatever the call history."""
+    torch.cuda.set_device(0)
+    stream = torch.cuda.current_stream().cuda_stream
+    plis = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("LM_HIP_SPECULATE_ORDER", flag)
+        plis[flag] = lm.Pipeline.hip(0, stream=stream)
+    length, m = 40_000_003, 10
+    seq, rows, pssm = make_workload(plis["1"], length, m, 5, seed=77)
+    scores = score_all(plis["1"], pssm, seq, rows, m, length)
+    flat = scores.flatten()
+    sample = flat[torch.randint(0, flat.numel(), (1 << 20,), device=flat.device)]
+    qs = torch.tensor([1.0, 0.99999, 0.9, 0.999999, 0.999, 1.0, 0.97, 0.9999], device=flat.device)
+    ts = torch.quantile(sample, qs).tolist()
+    ts[0] = float(flat.max()) + 1.0  # no hit at all
+    ts[5] = float(flat.max())        # the best cell(s) only
+    for t in ts:  # the hit count jumps by orders of magnitude between calls
+        want = torch.nonzero(scores >= t).cpu().numpy()  # the padded tail scores -inf
+        want_vals = scores[want[:, 0], want[:, 1]].cpu().numpy()
+        for flag, pli in plis.items():
+            hits, vals = pli.score_threshold_dptr(pssm, seq.data_ptr(), rows + m - 1, COLS, COLS, m - 1,
+                                                  length, 0, rows, t)
+            assert np.array_equal(hits, want), (flag, t)
+            assert np.array_equal(vals, want_vals), (flag, t)
