@@ -212,21 +212,38 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
     const size_t rec_bytes = emit == 0 ? sizeof(lm_hip_coords) : sizeof(lm_hip_hit);
     const size_t off_grouped = 0;
     const size_t off_counts = off_grouped + align16(room * sizeof(HitRecord));
-    const size_t off_offsets = off_counts + align16(nbuckets * 4);
+    const size_t off_offsets = off_counts + (nbuckets * 4 + 255) / 256 * 256;
     const size_t off_tiles = off_offsets + align16(nbuckets * 8);
     const size_t off_total = off_tiles + align16(ntiles * 8);
     // head of the list mirrored into the staging block: the previous call's length with headroom,
     // bounded so that the staging copy stays a small pinned transfer
     const unsigned long long pre =
         speculative ? std::min(room, std::min<unsigned long long>(std::max<unsigned long long>(sized_for, 2048), kPrefix)) : 0;
-    const size_t off_header = off_total + 16;  // staging block: counters | abort | starts | head of the list
-    const size_t off_abort = off_header + 16;
-    const size_t off_starts = off_abort + 16;
-    const size_t off_pre_out = off_starts + align16((njobs + 1) * 8);
-    const size_t off_pre_values = off_pre_out + align16(pre * rec_bytes);
-    const size_t off_out = off_pre_values + align16(pre * sizeof(float));
+    // exact form: starts | records | values contiguous in scratch2 (one read-back copy)
+    const size_t off_starts = off_total + 16;
+    const size_t off_out = off_starts + align16((njobs + 1) * 8);
     const size_t off_values = off_out + align16(room * rec_bytes);
     const size_t bytes = off_values + align16(room * sizeof(float));
+    // speculative form: the staging block -- counters | abort flag | starts | head of the list --
+    // lives in the context's pinned host buffer and the kernels write it THERE (posted writes
+    // over PCIe, visible after the stream synchronisation): no copy command, no memset
+    const size_t p_abort = 16, p_starts = 32;
+    const size_t p_out = p_starts + align16((njobs + 1) * 8);
+    const size_t p_values = p_out + align16(pre * rec_bytes);
+    const size_t p_bytes = p_values + align16(pre * sizeof(float));
+    char *pin = static_cast<char *>(ctx->pinned);
+    static_assert(sizeof(size_t) == 8, "job offsets are read back as 64-bit values");
+    const size_t starts_bytes = (njobs + 1) * 8;
+    if (speculative && p_bytes > kPinnedBytes / 2) {
+        *status = 2;  // too many jobs for the staging block: the caller runs the exact form
+        LM_HIP_TRY(hipMemcpyAsync(pin, d_counters, 16, hipMemcpyDeviceToHost, ctx->stream));
+        LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        counts_out[0] = reinterpret_cast<unsigned long long *>(pin)[0];
+        counts_out[1] = reinterpret_cast<unsigned long long *>(pin)[1];
+        if (counts_out[0] > cap || counts_out[1] > cand_cap)
+            *status = 1;
+        return LM_HIP_OK;
+    }
     LM_TRY(ctx->scratch2.reserve(bytes));
     char *base = static_cast<char *>(ctx->scratch2.ptr);
     HitRecord *grouped = reinterpret_cast<HitRecord *>(base + off_grouped);
@@ -234,20 +251,22 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
     unsigned long long *offsets = reinterpret_cast<unsigned long long *>(base + off_offsets);
     unsigned long long *tiles = reinterpret_cast<unsigned long long *>(base + off_tiles);
     unsigned long long *total = reinterpret_cast<unsigned long long *>(base + off_total);
-    unsigned long long *header = reinterpret_cast<unsigned long long *>(base + off_header);
-    unsigned *abort_flag = reinterpret_cast<unsigned *>(base + off_abort);
-    void *pre_out = base + off_pre_out;
-    float *pre_values = reinterpret_cast<float *>(base + off_pre_values);
-    unsigned long long *starts = reinterpret_cast<unsigned long long *>(base + off_starts);
+    unsigned long long *header = reinterpret_cast<unsigned long long *>(pin);
+    unsigned *abort_flag = reinterpret_cast<unsigned *>(pin + p_abort);
+    void *pre_out = pin + p_out;
+    float *pre_values = reinterpret_cast<float *>(pin + p_values);
+    unsigned long long *starts =
+        reinterpret_cast<unsigned long long *>(speculative ? pin + p_starts : base + off_starts);
     void *d_out = base + off_out;
     float *d_values = reinterpret_cast<float *>(base + off_values);
+    if (speculative)
+        memset(pin, 0, 32);  // counters and abort flag (the previous call's results were consumed)
     const unsigned long long max_bucket = speculative ? 2048 : ~0ull;
 
     hipStream_t st = ctx->stream;
     const unsigned grid = (unsigned)std::max<unsigned long long>(
         std::min<unsigned long long>((sized_for + kBlock - 1) / kBlock, (unsigned long long)ctx->num_cus * 32), 1);
-    LM_HIP_TRY(hipMemsetAsync(counts, 0, nbuckets * 4, st));
-    LM_HIP_TRY(hipMemsetAsync(abort_flag, 0, 16, st));
+    LM_HIP_TRY(hipMemsetAsync(counts, 0, (nbuckets * 4 + 255) / 256 * 256, st));  // whole 256-B units: one fill kernel
     hipLaunchKernelGGL(hits_bucket_count, dim3(grid), dim3(kBlock), 0, st, d_hits, d_counters, cap, shift, nb,
                        counts);
     LM_TRY(launch_scan_u32(ctx, counts, nbuckets, offsets, tiles, total));
@@ -268,25 +287,7 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
                        speculative ? header : static_cast<unsigned long long *>(nullptr));
     LM_HIP_TRY(hipGetLastError());
 
-    static_assert(sizeof(size_t) == 8, "job offsets are read back as 64-bit values");
-    const size_t starts_bytes = (njobs + 1) * 8;
-    char *pin = static_cast<char *>(ctx->pinned);
     if (speculative) {
-        // one pinned block = the staging block: counters | abort flag | starts | head of the list
-        const size_t p_abort = off_abort - off_header, p_starts = off_starts - off_header;
-        const size_t p_out = off_pre_out - off_header, p_values = off_pre_values - off_header;
-        const size_t block = off_out - off_header;
-        if (block > kPinnedBytes) {
-            *status = 2;  // too many jobs for the staging block: exact form
-            LM_HIP_TRY(hipMemcpyAsync(pin, d_counters, 16, hipMemcpyDeviceToHost, st));
-            LM_HIP_TRY(hipStreamSynchronize(st));
-            counts_out[0] = reinterpret_cast<unsigned long long *>(pin)[0];
-            counts_out[1] = reinterpret_cast<unsigned long long *>(pin)[1];
-            if (counts_out[0] > cap || counts_out[1] > cand_cap)
-                *status = 1;
-            return LM_HIP_OK;
-        }
-        LM_HIP_TRY(hipMemcpyAsync(pin, base + off_header, block, hipMemcpyDeviceToHost, st));
         LM_HIP_TRY(hipStreamSynchronize(st));
         counts_out[0] = reinterpret_cast<unsigned long long *>(pin)[0];
         counts_out[1] = reinterpret_cast<unsigned long long *>(pin)[1];

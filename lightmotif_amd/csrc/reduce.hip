@@ -243,6 +243,31 @@ __global__ __launch_bounds__(kScanTile) void scan_level2(unsigned long long *__r
         *grand_total = carry;
 }
 
+// Both levels in one workgroup, for short inputs (a p = 1e-5 hit list has ~1 500 buckets):
+// tile after tile with a running carry; same outputs as scan_level1 + scan_level2.
+constexpr unsigned long long kScanSmallTiles = 3;  // beyond that the sequential tiles cost more than a launch
+__global__ __launch_bounds__(kScanTile) void scan_small(const unsigned *__restrict__ counts,
+                                                        const unsigned long long n,
+                                                        unsigned long long *__restrict__ offsets,
+                                                        unsigned long long *__restrict__ tile_totals,
+                                                        unsigned long long *__restrict__ grand_total)
+{
+    unsigned long long carry = 0;
+    for (unsigned long long base = 0, t = 0; base < n; base += kScanTile, ++t) {
+        const unsigned long long i = base + threadIdx.x;
+        const unsigned long long x = i < n ? counts[i] : 0;
+        unsigned long long total;
+        const unsigned long long ex = block_exclusive_scan_1024(x, &total);
+        if (i < n)
+            offsets[i] = ex;
+        if (threadIdx.x == 0)
+            tile_totals[t] = carry;
+        carry += total;
+    }
+    if (threadIdx.x == 0)
+        *grand_total = carry;
+}
+
 // One workgroup looks at kBlock consecutive chunks: their counts are loaded with one
 // coalesced read, and only chunks that contain hits (rare: a p = 1e-5 tail touches
 // ~4 % of the 4096-cell chunks) are re-read and compacted, in chunk order.
@@ -301,6 +326,11 @@ int launch_scan_u32(lm_hip_ctx *ctx, const unsigned *counts, unsigned long long 
                     unsigned long long *total)
 {
     const unsigned long long ntiles = (n + kScanTile - 1) / kScanTile;
+    if (ntiles <= kScanSmallTiles) {
+        hipLaunchKernelGGL(scan_small, dim3(1), dim3(kScanTile), 0, ctx->stream, counts, n, offsets, tiles, total);
+        LM_HIP_TRY(hipGetLastError());
+        return LM_HIP_OK;
+    }
     hipLaunchKernelGGL(scan_level1, dim3((unsigned)ntiles), dim3(kScanTile), 0, ctx->stream, counts, n,
                        offsets, tiles);
     hipLaunchKernelGGL(scan_level2, dim3(1), dim3(kScanTile), 0, ctx->stream, tiles, ntiles, total);

@@ -624,9 +624,11 @@ struct RescoreJob {
 // Hits are staged in LDS and flushed with ONE global atomicAdd per ~1000 records: a
 // million per-hit atomics on the single list counter would serialise in L2 (measured:
 // 6 ms per 1e6 hits).
-constexpr int kHitStage = 1024;
+constexpr int kRescoreBlock = 1024;  // big workgroups: one global atomic per workgroup and flush, and
+constexpr int kHitStage = 4096;      // 2 048 small workgroups' atomics on one counter cost 12 us per launch
+constexpr int kRescoreBlocksPerCu = 2;
 
-__global__ __launch_bounds__(kBlock) void rescore_candidates(const RescoreJob *__restrict__ jobs,
+__global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const RescoreJob *__restrict__ jobs,
                                                              const FusedOut fo)
 {
     __shared__ HitRecord stage[kHitStage];
@@ -639,14 +641,14 @@ __global__ __launch_bounds__(kBlock) void rescore_candidates(const RescoreJob *_
     if (n > fo.cand_capacity)
         n = fo.cand_capacity;  // overflow: the launcher re-runs the batch with more room
     const unsigned lane = threadIdx.x & 31;
-    const unsigned long long stride = (unsigned long long)gridDim.x * (kBlock / 32);
+    const unsigned long long stride = (unsigned long long)gridDim.x * (kRescoreBlock / 32);
     auto flush = [&]() {  // block-uniform
         __syncthreads();
         const unsigned cnt = nstage;
         if (threadIdx.x == 0 && cnt)
             gbase = atomicAdd(fo.hit_count, (unsigned long long)cnt);
         __syncthreads();
-        for (unsigned i = threadIdx.x; i < cnt; i += kBlock)
+        for (unsigned i = threadIdx.x; i < cnt; i += kRescoreBlock)
             if (gbase + i < fo.hit_capacity)
                 fo.hits[gbase + i] = stage[i];
         __syncthreads();
@@ -655,8 +657,8 @@ __global__ __launch_bounds__(kBlock) void rescore_candidates(const RescoreJob *_
         __syncthreads();
     };
     // block-uniform trip count: one candidate piece per half-wave per round
-    __shared__ uint8_t window[kBlock / 32][96];  // symbols of rows r0 .. r0 + nrows + M - 2
-    for (unsigned long long c0 = (unsigned long long)blockIdx.x * (kBlock / 32); c0 < n; c0 += stride) {
+    __shared__ uint8_t window[kRescoreBlock / 32][96];  // symbols of rows r0 .. r0 + nrows + M - 2
+    for (unsigned long long c0 = (unsigned long long)blockIdx.x * (kRescoreBlock / 32); c0 < n; c0 += stride) {
         const unsigned long long c = c0 + (threadIdx.x >> 5);
         if (c < n) {
             const Candidate cd = fo.cands[c];
@@ -702,12 +704,12 @@ __global__ __launch_bounds__(kBlock) void rescore_candidates(const RescoreJob *_
                             (jb.key_rows ? cd.col * jb.key_rows + row : row * 32ull + cd.col);
                     r.value = sc;
                     r.pad = 0;
-                    stage[atomicAdd(&nstage, 1u)] = r;  // <= kBlock records per round
+                    stage[atomicAdd(&nstage, 1u)] = r;  // <= kRescoreBlock records per round
                 }
             }
         }
         __syncthreads();
-        if (nstage > kHitStage - kBlock)
+        if (nstage > kHitStage - kRescoreBlock)
             flush();
     }
     flush();
@@ -785,26 +787,42 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
                                   (unsigned)a.pssm->m, (unsigned)a.pssm->k, ts[i], 0, key_rows};
         }
     for (int attempt = 0; attempt < 3; ++attempt) {
-        // layout: [hit count u64][candidate count u64][HitRecord x cap][Candidate x ccap][jobs][batch]
-        const size_t off_cands = 16 + cap * sizeof(HitRecord);
-        const size_t off_jobs = off_cands + ccap * sizeof(Candidate);
+        // layout: [hit count u64][candidate count u64][jobs][batch][HitRecord x cap][Candidate x ccap];
+        // the head -- zeroed counters and the two job tables -- is assembled in the upper half of the
+        // pinned buffer and reaches the device as ONE copy
+        // (the counters get 256 bytes of their own: the scans' atomics on them would otherwise
+        // fight with every read of a job table entry in the same cache line -- measured +30 % on the
+        // re-scoring kernel at 10^6 hits)
+        const size_t off_jobs = 256;
         const size_t off_batch = off_jobs + (n * sizeof(RescoreJob) + 15) / 16 * 16;
-        LM_TRY(ctx->scratch.reserve(off_batch + n * sizeof(BatchParams)));
+        const size_t off_hits = off_batch + (n * sizeof(BatchParams) + 15) / 16 * 16;
+        const size_t off_cands = off_hits + cap * sizeof(HitRecord);
+        LM_TRY(ctx->scratch.reserve(off_cands + ccap * sizeof(Candidate)));
         char *base = static_cast<char *>(ctx->scratch.ptr);
         FusedOut fo{};
         fo.hit_count = reinterpret_cast<unsigned long long *>(base);
         fo.cand_count = fo.hit_count + 1;
-        fo.hits = reinterpret_cast<HitRecord *>(base + 16);
+        fo.hits = reinterpret_cast<HitRecord *>(base + off_hits);
         fo.hit_capacity = cap;
         fo.cands = reinterpret_cast<Candidate *>(base + off_cands);
         fo.cand_capacity = ccap;
         fo.key_rows = key_rows;
         RescoreJob *d_jobs = reinterpret_cast<RescoreJob *>(base + off_jobs);
         BatchParams *d_bparams = reinterpret_cast<BatchParams *>(base + off_batch);
-        LM_HIP_TRY(hipMemsetAsync(base, 0, 16, ctx->stream));
-        if (n > 1)
-            LM_HIP_TRY(hipMemcpyAsync(d_bparams, bparams.data(), n * sizeof(BatchParams),
-                                      hipMemcpyHostToDevice, ctx->stream));
+        if (off_hits <= kPinnedBytes / 2) {
+            char *head = static_cast<char *>(ctx->pinned) + kPinnedBytes / 2;
+            memset(head, 0, off_jobs);
+            memcpy(head + off_jobs, rjobs.data(), n * sizeof(RescoreJob));
+            if (n > 1)
+                memcpy(head + off_batch, bparams.data(), n * sizeof(BatchParams));
+            LM_HIP_TRY(hipMemcpyAsync(base, head, n > 1 ? off_hits : off_batch, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            LM_HIP_TRY(hipMemsetAsync(base, 0, 16, ctx->stream));
+            LM_HIP_TRY(hipMemcpyAsync(d_jobs, rjobs.data(), n * sizeof(RescoreJob), hipMemcpyHostToDevice,
+                                      ctx->stream));
+            LM_HIP_TRY(hipMemcpyAsync(d_bparams, bparams.data(), n * sizeof(BatchParams), hipMemcpyHostToDevice,
+                                      ctx->stream));
+        }
         const bool two_streams = groups.size() > 1;
         if (two_streams)
             LM_TRY(batch_fork(ctx));
@@ -842,9 +860,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
         if (two_streams)
             LM_TRY(batch_join(ctx));
         if (any_candidates) {
-            LM_HIP_TRY(hipMemcpyAsync(d_jobs, rjobs.data(), n * sizeof(RescoreJob), hipMemcpyHostToDevice,
-                                      ctx->stream));
-            hipLaunchKernelGGL(rescore_candidates, dim3((unsigned)ctx->num_cus * 8), dim3(kBlock), 0,
+            hipLaunchKernelGGL(rescore_candidates, dim3((unsigned)ctx->num_cus * kRescoreBlocksPerCu), dim3(kRescoreBlock), 0,
                                ctx->stream, d_jobs, fo);
             LM_HIP_TRY(hipGetLastError());
         }
@@ -947,6 +963,7 @@ constexpr unsigned kOrderedNegInf = 0x007fffffu;  // ordered_bits(-inf)
 // over the job's rows.  Chunks, not single cells: a lone cell costs M cache sectors for M
 // bytes (3.9 M scattered cells = 1.3 ms), a chunk reads its rows once.
 constexpr unsigned kSampleRows = kBlock / 32;  // one row per half-wave: a chunk is one pass of the block
+constexpr unsigned kMaxSampleM = kMaxFastM;    // the candidate route needs a prefilter kernel: M <= kMaxFastM
 __global__ __launch_bounds__(kBlock) void argmax_sample(const SampleJob *__restrict__ jobs,
                                                         unsigned *__restrict__ bound)
 {
@@ -956,23 +973,21 @@ __global__ __launch_bounds__(kBlock) void argmax_sample(const SampleJob *__restr
     for (unsigned long long c = blockIdx.x; c < jb.nchunks; c += gridDim.x) {
         const unsigned long long r0 = c * jb.stride;  // chunk rows r0 .. r0 + kSampleRows - 1
         const uint8_t *p = jb.seq + (r0 + sub) * 32 + col;
+        // all symbol loads of the cell in flight at once, then all weight loads, then the
+        // reference's add order: one HBM latency + one L2 latency per chunk instead of M / 4 of each
+        // (rows past the motif re-read its last row; the wrap rows keep the address valid)
+        unsigned sy[kMaxSampleM];
+        float w[kMaxSampleM];
+#pragma unroll
+        for (unsigned j = 0; j < kMaxSampleM; ++j)
+            sy[j] = p[(j < jb.m ? j : jb.m - 1) * 32];
+#pragma unroll
+        for (unsigned j = 0; j < kMaxSampleM; ++j)
+            w[j] = jb.dense[(j < jb.m ? j : jb.m - 1) * jb.k + sy[j]];
         float sc = 0.0f;
-        unsigned j = 0;
-        for (; j + 4 <= jb.m; j += 4) {  // 4 independent symbol loads, then 4 independent weights
-            unsigned sy[4];
-            float w[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                sy[q] = p[(j + q) * 32];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                w[q] = jb.dense[(j + q) * jb.k + sy[q]];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                sc = sc + w[q];
-        }
-        for (; j < jb.m; ++j)
-            sc = sc + jb.dense[j * jb.k + p[j * 32]];
+        for (unsigned j = 0; j < kMaxSampleM; ++j)
+            sc = j < jb.m ? sc + w[j] : sc;
         const unsigned key = ordered_bits(sc);
         best = key > best ? key : best;
     }
@@ -1087,9 +1102,15 @@ __global__ __launch_bounds__(kBlock) void hits_best_key(const HitRecord *__restr
 
 __global__ void argmax_collect(const unsigned n, const unsigned *__restrict__ best_value,
                                const unsigned long long *__restrict__ best_key,
-                               ArgmaxRecord *__restrict__ out)
+                               ArgmaxRecord *__restrict__ out,
+                               const unsigned long long *__restrict__ counters,
+                               unsigned long long *__restrict__ counters_out)
 {
     const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0 && counters_out) {  // {hits, candidates}: the host checks them for overflow
+        counters_out[0] = counters[0];
+        counters_out[1] = counters[1];
+    }
     if (j >= n)
         return;
     ArgmaxRecord r;
@@ -1169,15 +1190,18 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
     }
     // ~1024 cells tie with or beat the bound of a 1/1024 sample; leave room for 8x that
     const unsigned long long cap = nq * 8192 + (1 << 16), ccap = 4 * cap;
-    const size_t off_bound = 16, off_bval = off_bound + nq * 4;  // contiguous: one 32-bit fill inits both
+    // layout: the head -- counters | sample bounds | best values | best keys | the three job tables --
+    // is assembled in the upper half of the pinned buffer and reaches the device as ONE copy
+    // (three memsets and three staged copies from pageable memory cost more than the sample pass)
+    const size_t off_bound = 256, off_bval = off_bound + nq * 4;  // the counters keep their cache lines to themselves
     const size_t off_bkey = (off_bval + nq * 4 + 15) / 16 * 16;
-    const size_t off_hits = off_bkey + nq * 8;
-    const size_t off_cands = off_hits + cap * sizeof(HitRecord);
-    const size_t off_rj = off_cands + ccap * sizeof(Candidate);
+    const size_t off_rj = off_bkey + nq * 8;
     const size_t off_bp = off_rj + (nq * sizeof(RescoreJob) + 15) / 16 * 16;
     const size_t off_sj = off_bp + (nq * sizeof(BatchParams) + 15) / 16 * 16;
     const size_t off_res = off_sj + (nq * sizeof(SampleJob) + 15) / 16 * 16;
-    LM_TRY(ctx->scratch.reserve(off_res + nq * sizeof(ArgmaxRecord)));
+    const size_t off_hits = off_res + nq * sizeof(ArgmaxRecord);
+    const size_t off_cands = off_hits + cap * sizeof(HitRecord);
+    LM_TRY(ctx->scratch.reserve(off_cands + ccap * sizeof(Candidate)));
     char *base = static_cast<char *>(ctx->scratch.ptr);
     FusedOut fo{};
     fo.hit_count = reinterpret_cast<unsigned long long *>(base);
@@ -1194,24 +1218,19 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
     SampleJob *d_sj = reinterpret_cast<SampleJob *>(base + off_sj);
     ArgmaxRecord *d_res = reinterpret_cast<ArgmaxRecord *>(base + off_res);
     hipStream_t st = ctx->stream;
-    LM_HIP_TRY(hipMemsetAsync(base, 0, 16, st));
-    LM_HIP_TRY(hipMemsetAsync(d_bkey, 0, nq * 8, st));
-    LM_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_bound), (int)kOrderedNegInf, 2 * nq, st));
-    // A handful of jobs: the job tables live in the pinned (device-visible) buffer and the
-    // kernels read / update them there -- three staged copies from pageable memory cost more
-    // than the whole sample pass.  Big batches amortise the copies and keep the tables in HBM.
-    const size_t pin_tables = (16 + nq * sizeof(ArgmaxRecord) + 63) / 64 * 64;
-    const size_t pin_bp = pin_tables + (nq * sizeof(RescoreJob) + 63) / 64 * 64;
-    const size_t pin_sj = pin_bp + (nq * sizeof(BatchParams) + 63) / 64 * 64;
-    if (nq <= 64 && pin_sj + nq * sizeof(SampleJob) <= kPinnedBytes) {
-        char *pinb = static_cast<char *>(ctx->pinned);
-        d_rj = reinterpret_cast<RescoreJob *>(pinb + pin_tables);
-        d_bp = reinterpret_cast<BatchParams *>(pinb + pin_bp);
-        d_sj = reinterpret_cast<SampleJob *>(pinb + pin_sj);
-        memcpy(d_rj, rj.data(), nq * sizeof(RescoreJob));
-        memcpy(d_bp, bparams.data(), nq * sizeof(BatchParams));
-        memcpy(d_sj, sj.data(), nq * sizeof(SampleJob));
+    if (off_res <= kPinnedBytes / 2) {
+        char *head = static_cast<char *>(ctx->pinned) + kPinnedBytes / 2;
+        memset(head, 0, off_rj);
+        for (size_t q = 0; q < 2 * nq; ++q)  // bounds and best values start at -inf
+            reinterpret_cast<unsigned *>(head + off_bound)[q] = kOrderedNegInf;
+        memcpy(head + off_rj, rj.data(), nq * sizeof(RescoreJob));
+        memcpy(head + off_bp, bparams.data(), nq * sizeof(BatchParams));
+        memcpy(head + off_sj, sj.data(), nq * sizeof(SampleJob));
+        LM_HIP_TRY(hipMemcpyAsync(base, head, off_res, hipMemcpyHostToDevice, st));
     } else {
+        LM_HIP_TRY(hipMemsetAsync(base, 0, 16, st));
+        LM_HIP_TRY(hipMemsetAsync(d_bkey, 0, nq * 8, st));
+        LM_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_bound), (int)kOrderedNegInf, 2 * nq, st));
         LM_HIP_TRY(hipMemcpyAsync(d_rj, rj.data(), nq * sizeof(RescoreJob), hipMemcpyHostToDevice, st));
         LM_HIP_TRY(hipMemcpyAsync(d_bp, bparams.data(), nq * sizeof(BatchParams), hipMemcpyHostToDevice, st));
         LM_HIP_TRY(hipMemcpyAsync(d_sj, sj.data(), nq * sizeof(SampleJob), hipMemcpyHostToDevice, st));
@@ -1241,20 +1260,23 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
     if (two_streams)
         LM_TRY(batch_join(ctx));
     fo.batch = nullptr;
-    hipLaunchKernelGGL(rescore_candidates, dim3((unsigned)ctx->num_cus * 8), dim3(kBlock), 0, st, d_rj, fo);
+    hipLaunchKernelGGL(rescore_candidates, dim3((unsigned)ctx->num_cus * kRescoreBlocksPerCu), dim3(kRescoreBlock), 0, st, d_rj, fo);
     const unsigned hgrid = (unsigned)ctx->num_cus * 2;
     hipLaunchKernelGGL(hits_best_value, dim3(hgrid), dim3(kBlock), 0, st, fo.hits, fo.hit_count, cap, d_bval);
     hipLaunchKernelGGL(hits_best_key, dim3(hgrid), dim3(kBlock), 0, st, fo.hits, fo.hit_count, cap, d_bval,
                        d_bkey);
-    const bool pin = 16 + nq * sizeof(ArgmaxRecord) <= kPinnedBytes;
+    // results and the two list counters are written straight into the pinned buffer's lower half
+    const bool pin = 16 + nq * sizeof(ArgmaxRecord) <= kPinnedBytes / 2;
     ArgmaxRecord *res = pin ? reinterpret_cast<ArgmaxRecord *>(static_cast<char *>(ctx->pinned) + 16) : d_res;
     hipLaunchKernelGGL(argmax_collect, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (unsigned)nq,
-                       d_bval, d_bkey, res);
+                       d_bval, d_bkey, res, fo.hit_count,
+                       pin ? static_cast<unsigned long long *>(ctx->pinned) : static_cast<unsigned long long *>(nullptr));
     LM_HIP_TRY(hipGetLastError());
     std::vector<ArgmaxRecord> host_res(pin ? 0 : nq);
-    LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, base, 16, hipMemcpyDeviceToHost, st));
-    if (!pin)
+    if (!pin) {
+        LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, base, 16, hipMemcpyDeviceToHost, st));
         LM_HIP_TRY(hipMemcpyAsync(host_res.data(), d_res, nq * sizeof(ArgmaxRecord), hipMemcpyDeviceToHost, st));
+    }
     LM_HIP_TRY(hipStreamSynchronize(st));
     const unsigned long long nhits = static_cast<unsigned long long *>(ctx->pinned)[0];
     const unsigned long long ncand = static_cast<unsigned long long *>(ctx->pinned)[1];
