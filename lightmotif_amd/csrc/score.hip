@@ -965,7 +965,7 @@ constexpr unsigned kOrderedNegInf = 0x007fffffu;  // ordered_bits(-inf)
 constexpr unsigned kSampleRows = kBlock / 32;  // one row per half-wave: a chunk is one pass of the block
 constexpr unsigned kMaxSampleM = kMaxFastM;    // the candidate route needs a prefilter kernel: M <= kMaxFastM
 __global__ __launch_bounds__(kBlock) void argmax_sample(const SampleJob *__restrict__ jobs,
-                                                        unsigned *__restrict__ bound)
+                                                        unsigned *__restrict__ partial)
 {
     const SampleJob jb = jobs[blockIdx.y];
     unsigned best = kOrderedNegInf;
@@ -996,7 +996,8 @@ __global__ __launch_bounds__(kBlock) void argmax_sample(const SampleJob *__restr
         const unsigned o = __shfl_xor(best, off);
         best = o > best ? o : best;
     }
-    // one atomic per workgroup: same-address atomics serialise at ~6 ns each
+    // one record per workgroup, folded by argmax_prepare: 2 048 atomics on one address would
+    // serialise at ~6 ns each (12 us, more than the sampling itself)
     __shared__ unsigned wave_best[kBlock / 64];
     if ((threadIdx.x & 63) == 0)
         wave_best[threadIdx.x >> 6] = best;
@@ -1004,24 +1005,35 @@ __global__ __launch_bounds__(kBlock) void argmax_sample(const SampleJob *__restr
     if (threadIdx.x == 0) {
         for (int w = 1; w < kBlock / 64; ++w)
             best = wave_best[w] > best ? wave_best[w] : best;
-        if (best != kOrderedNegInf)
-            atomicMax(&bound[blockIdx.y], best);
+        partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = best;
     }
 }
 
-// one thread per job: lower bound -> f32 threshold of the re-scoring and discrete threshold
-// of the scan (same formula as launch_score_threshold_batch); td = 0xffffffff = "skip"
-__global__ void argmax_prepare(const SampleJob *__restrict__ jobs, const unsigned n,
-                               const unsigned *__restrict__ bound, RescoreJob *__restrict__ rjobs,
-                               BatchParams *__restrict__ bparams)
+// one wavefront per job: folds the sample's per-workgroup records into the lower bound, then
+// lower bound -> f32 threshold of the re-scoring and discrete threshold of the scan (same
+// formula as launch_score_threshold_batch); td = 0xffffffff = "skip"
+__global__ __launch_bounds__(64) void argmax_prepare(const SampleJob *__restrict__ jobs, const unsigned n,
+                                                     const unsigned *__restrict__ partial, const unsigned nper,
+                                                     RescoreJob *__restrict__ rjobs,
+                                                     BatchParams *__restrict__ bparams)
 {
-    const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n)
+    const unsigned j = blockIdx.x;
+    unsigned bound = kOrderedNegInf;
+    for (unsigned i = threadIdx.x; i < nper; i += 64) {
+        const unsigned v = partial[(size_t)j * nper + i];
+        bound = v > bound ? v : bound;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = __shfl_xor(bound, off);
+        bound = o > bound ? o : bound;
+    }
+    if (threadIdx.x != 0)
         return;
     unsigned td = 0xffffffffu;
     float t = INFINITY;
-    if (bound[j] != kOrderedNegInf) {
-        t = from_ordered_bits(bound[j]);
+    if (bound != kOrderedNegInf) {
+        t = from_ordered_bits(bound);
         const double scaled = floor(((double)t - jobs[j].pre_offset) / jobs[j].pre_factor) -
                               ceil(jobs[j].pre_emax / jobs[j].pre_factor) - 1.0;
         if (scaled >= 1.0)
@@ -1193,7 +1205,9 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
     // layout: the head -- counters | sample bounds | best values | best keys | the three job tables --
     // is assembled in the upper half of the pinned buffer and reaches the device as ONE copy
     // (three memsets and three staged copies from pageable memory cost more than the sample pass)
-    const size_t off_bound = 256, off_bval = off_bound + nq * 4;  // the counters keep their cache lines to themselves
+    const unsigned sgrid = (unsigned)std::min<unsigned long long>(
+        max_chunks, std::max<unsigned long long>((unsigned long long)ctx->num_cus * 8 / nq, 16));
+    const size_t off_bval = 256;  // the counters keep their cache lines to themselves
     const size_t off_bkey = (off_bval + nq * 4 + 15) / 16 * 16;
     const size_t off_rj = off_bkey + nq * 8;
     const size_t off_bp = off_rj + (nq * sizeof(RescoreJob) + 15) / 16 * 16;
@@ -1201,12 +1215,13 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
     const size_t off_res = off_sj + (nq * sizeof(SampleJob) + 15) / 16 * 16;
     const size_t off_hits = off_res + nq * sizeof(ArgmaxRecord);
     const size_t off_cands = off_hits + cap * sizeof(HitRecord);
-    LM_TRY(ctx->scratch.reserve(off_cands + ccap * sizeof(Candidate)));
+    const size_t off_partial = off_cands + ccap * sizeof(Candidate);  // the sample's per-workgroup maxima
+    LM_TRY(ctx->scratch.reserve(off_partial + nq * sgrid * sizeof(unsigned)));
     char *base = static_cast<char *>(ctx->scratch.ptr);
     FusedOut fo{};
     fo.hit_count = reinterpret_cast<unsigned long long *>(base);
     fo.cand_count = fo.hit_count + 1;
-    unsigned *d_bound = reinterpret_cast<unsigned *>(base + off_bound);
+    unsigned *d_partial = reinterpret_cast<unsigned *>(base + off_partial);
     unsigned *d_bval = reinterpret_cast<unsigned *>(base + off_bval);
     unsigned long long *d_bkey = reinterpret_cast<unsigned long long *>(base + off_bkey);
     fo.hits = reinterpret_cast<HitRecord *>(base + off_hits);
@@ -1221,8 +1236,8 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
     if (off_res <= kPinnedBytes / 2) {
         char *head = static_cast<char *>(ctx->pinned) + kPinnedBytes / 2;
         memset(head, 0, off_rj);
-        for (size_t q = 0; q < 2 * nq; ++q)  // bounds and best values start at -inf
-            reinterpret_cast<unsigned *>(head + off_bound)[q] = kOrderedNegInf;
+        for (size_t q = 0; q < nq; ++q)  // best values start at -inf
+            reinterpret_cast<unsigned *>(head + off_bval)[q] = kOrderedNegInf;
         memcpy(head + off_rj, rj.data(), nq * sizeof(RescoreJob));
         memcpy(head + off_bp, bparams.data(), nq * sizeof(BatchParams));
         memcpy(head + off_sj, sj.data(), nq * sizeof(SampleJob));
@@ -1230,16 +1245,14 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
     } else {
         LM_HIP_TRY(hipMemsetAsync(base, 0, 16, st));
         LM_HIP_TRY(hipMemsetAsync(d_bkey, 0, nq * 8, st));
-        LM_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_bound), (int)kOrderedNegInf, 2 * nq, st));
+        LM_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_bval), (int)kOrderedNegInf, nq, st));
         LM_HIP_TRY(hipMemcpyAsync(d_rj, rj.data(), nq * sizeof(RescoreJob), hipMemcpyHostToDevice, st));
         LM_HIP_TRY(hipMemcpyAsync(d_bp, bparams.data(), nq * sizeof(BatchParams), hipMemcpyHostToDevice, st));
         LM_HIP_TRY(hipMemcpyAsync(d_sj, sj.data(), nq * sizeof(SampleJob), hipMemcpyHostToDevice, st));
     }
-    const unsigned sgrid = (unsigned)std::min<unsigned long long>(
-        max_chunks, std::max<unsigned long long>((unsigned long long)ctx->num_cus * 8 / nq, 16));
-    hipLaunchKernelGGL(argmax_sample, dim3(sgrid, (unsigned)nq), dim3(kBlock), 0, st, d_sj, d_bound);
-    hipLaunchKernelGGL(argmax_prepare, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, d_sj,
-                       (unsigned)nq, d_bound, d_rj, d_bp);
+    hipLaunchKernelGGL(argmax_sample, dim3(sgrid, (unsigned)nq), dim3(kBlock), 0, st, d_sj, d_partial);
+    hipLaunchKernelGGL(argmax_prepare, dim3((unsigned)nq), dim3(64), 0, st, d_sj, (unsigned)nq, d_partial, sgrid,
+                       d_rj, d_bp);
     LM_HIP_TRY(hipGetLastError());
     const bool two_streams = groups.size() > 1;
     if (two_streams)
