@@ -18,6 +18,7 @@
 // HIP kernels.  Misuse that panics in the reference throws std::runtime_error here.
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -151,6 +152,7 @@ public:
 
     size_t len() const { return info().length; }
     size_t wrap() const { return info().wrap; }
+    size_t rows() const { return info().rows; }  // sequence rows, without the wrap rows
     size_t columns() const { return info().cols; }
     // Reconfigure for a motif (seq.rs:362-366)
     void configure(const ScoringMatrix<A> &motif)
@@ -487,6 +489,35 @@ public:
             out[i] = Hit{h[i].position, h[i].score};
         lm_hip_free(h);
         return out;
+    }
+
+    // The order in which the reference's Scanner YIELDS those hits: blocks of `block_size` rows
+    // ascending, inside a block the last cell in row-major order first (hits are pushed in
+    // Threshold order and popped from the end of the vector, scan.rs:184-198).  `rows` =
+    // seq.rows() (position = col * rows + row, scan.rs:185).
+    static std::vector<Hit> scan_order(std::vector<Hit> hits, size_t rows, size_t block_size = 256)
+    {
+        if (rows == 0 || block_size == 0)
+            return hits;
+        std::sort(hits.begin(), hits.end(), [=](const Hit &a, const Hit &b) {
+            const size_t ra = a.position % rows, rb = b.position % rows;
+            if (ra / block_size != rb / block_size)
+                return ra / block_size < rb / block_size;
+            if (ra != rb)
+                return ra > rb;
+            return a.position / rows > b.position / rows;
+        });
+        return hits;
+    }
+
+    // Scanner::max (scan.rs:200-249): greater score wins, equal scores go to the greater position
+    static std::optional<Hit> scan_max(const std::vector<Hit> &hits)
+    {
+        std::optional<Hit> best;
+        for (const Hit &h : hits)
+            if (!best || h.score > best->score || (h.score == best->score && h.position > best->position))
+                best = h;
+        return best;
     }
 
     // score + argmax / score + threshold without materialising the scores (what the bench

@@ -816,17 +816,32 @@ class Hit:
         return f"Hit(position={self.position}, score={self.score})"
 
 
+# lm_hip_hit {size_t position; float score;} as the C compiler lays it out
+_HIT_DTYPE = np.dtype({"names": ["position", "score"], "formats": ["<u8", "<f4"],
+                       "offsets": [_ffi.Hit.position.offset, _ffi.Hit.score.offset],
+                       "itemsize": C.sizeof(_ffi.Hit)})
+
+
 class Scanner:
     """All positions with ``score >= threshold`` and ``position + M <= L``
     (scan.rs:185-190), found by the fused score+threshold kernel: a packed u16
     discrete prefilter (the device form of scan.rs:169-178's DiscreteMatrix) with exact
-    f32 re-scoring of the candidates; hits come back ordered by position."""
+    f32 re-scoring of the candidates.
+
+    Iteration yields the hits in the reference's order: blocks of ``block_size`` rows in
+    ascending order (scan.rs:174-176, 196), and inside a block the LAST cell in row-major
+    (row, col) order first -- the reference pushes a block's hits in ``Threshold`` order and
+    pops them from the end of the vector (scan.rs:184-198).  ``positions`` / ``scores`` hold
+    the same hits in ascending position, as the device returns them."""
 
     def __init__(self, pssm: ScoringMatrix, sequence: StripedSequence, threshold: float = 0.0,
                  block_size: int = 256):
         if pssm.protein or sequence.protein:
             raise ValueError("scanner only supports DNA")  # lib.rs scan()
+        if block_size < 1:
+            raise ValueError("block_size must be positive")
         self.block_size = block_size
+        self.threshold = threshold
         if sequence.wrap < len(pssm) - 1:  # scan.rs:127-131 panics
             raise ValueError(f"not enough wrapping rows for motif of length {len(pssm)}")
         pli = sequence._pli
@@ -834,20 +849,45 @@ class Scanner:
         check(pli._L.lm_hip_scan_f32(pli._h, pssm._device(pli), sequence._h, threshold,
                                      C.byref(ptr), C.byref(n)))
         try:
-            hits = [Hit(int(ptr[i].position), float(ptr[i].score)) for i in range(n.value)]
+            raw = np.frombuffer(C.string_at(ptr, n.value * C.sizeof(_ffi.Hit)) if n.value else b"",
+                                dtype=_HIT_DTYPE)
         finally:
             if ptr:
                 pli._L.lm_hip_free(ptr)
-        hits.reverse()  # popped from the end: ascending positions come out first
-        self._hits = hits
+        #: the hits in ascending position (int64) and their f32 scores
+        self.positions = raw["position"].astype(np.int64)
+        self.scores = raw["score"].astype(np.float32)
+        rows = max(sequence.rows, 1)
+        row, col = self.positions % rows, self.positions // rows
+        # yield order: block ascending, then (row, col) descending
+        self._order = np.lexsort((-col, -row, row // block_size))
+        self._next = 0
 
     def __iter__(self) -> "Scanner":
         return self
 
     def __next__(self) -> Hit:
-        if not self._hits:
+        if self._next >= self._order.size:
             raise StopIteration
-        return self._hits.pop()
+        i = self._order[self._next]
+        self._next += 1
+        return Hit(int(self.positions[i]), float(self.scores[i]))
+
+    def __len__(self) -> int:
+        """Hits not yet yielded."""
+        return int(self._order.size - self._next)
+
+    def max(self) -> Optional[Hit]:
+        """scan.rs:200-249: the best hit not yet yielded; greater score wins, equal scores
+        go to the greater position (scan.rs:237).  Consumes the scanner."""
+        rest = self._order[self._next:]
+        self._next = self._order.size
+        if rest.size == 0:
+            return None
+        sc, pos = self.scores[rest], self.positions[rest]
+        top = np.nonzero(sc == sc.max())[0]
+        i = top[np.argmax(pos[top])]
+        return Hit(int(pos[i]), float(sc[i]))
 
 
 # --- module-level helpers (lib.rs:1335-1451) ---------------------------------------------------

@@ -119,3 +119,44 @@ def unstripe(scores: np.ndarray, cols: int, max_index: int) -> np.ndarray:
     end = min(max_index, rows * cols)
     i = np.arange(end)
     return scores[i % rows, i // rows] if rows else np.zeros(0, np.float32)
+
+
+def scanner_collect(scores: np.ndarray, cols: int, length: int, m: int, t: float,
+                    block_size: int = 256) -> list[tuple[int, np.float32]]:
+    """scan.rs:166-198 (`Scanner::next` until exhaustion), with an exact prefilter: the
+    u8 DiscreteMatrix pass only selects candidates, every hit is decided by the f32
+    `score_position` (scan.rs:187-190), so the yielded (position, score) sequence is fixed
+    by the f32 scores.  Blocks of `block_size` rows in ascending order (scan.rs:174-176,
+    196); inside a block the candidates are pushed in `Threshold`'s row-major order
+    (scan.rs:184, pli/mod.rs:212-218) and yielded by `Vec::pop` (scan.rs:198): LAST pushed
+    first.  `scores` = full score matrix (rows x >= cols) of the configured sequence.
+    """
+    rows = scores.shape[0]
+    out: list[tuple[int, np.float32]] = []
+    tt = np.float32(t)
+    for row0 in range(0, rows, max(block_size, 1)):
+        block: list[tuple[int, np.float32]] = []
+        for r in range(row0, min(row0 + block_size, rows)):
+            for c in range(cols):
+                index = c * rows + r                       # scan.rs:185
+                if index + m <= length:                    # scan.rs:186
+                    s = scores[r, c]
+                    if s >= tt:                            # scan.rs:188
+                        block.append((index, s))
+        while block:
+            out.append(block.pop())                        # scan.rs:198
+    return out
+
+
+def scanner_max(scores: np.ndarray, cols: int, length: int, m: int, t: float):
+    """scan.rs:200-249 (`Scanner::max` on a fresh scanner) for inputs where the discrete
+    under-estimate does not matter: the best hit with `score >= t`; greater score wins,
+    equal scores go to the greater position (scan.rs:237).  (The reference also accepts, as
+    its FIRST candidate only, a cell whose u8 score reaches the scaled threshold while its
+    f32 score is below `t`, and does not test `index + M <= L` here; neither can be the best
+    hit when some valid position scores >= t and padded windows score -inf.)"""
+    best = None
+    for index, s in scanner_collect(scores, cols, length, m, t, block_size=1 << 30):
+        if best is None or s > best[1] or (s == best[1] and index > best[0]):
+            best = (index, s)
+    return best

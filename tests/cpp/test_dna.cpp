@@ -134,6 +134,18 @@ static void test_scanner(const Pipeline<Dna> &pli)
         CHECK(hits[1].position == 27 && std::fabs(hits[1].score - (-6.4345555f)) < 1e-5f);
         CHECK(hits[2].position == 32 && std::fabs(hits[2].score - (-8.961102f)) < 1e-5f);
     }
+    // the reference's yield order (scan.rs:184-198): 64 bp at C = 32 are 2 rows, the hits sit in
+    // cells (0, 9), (1, 13), (0, 16); one block of 256 rows pushes 18, 32, 27 and pops 27, 32, 18;
+    // blocks of one row yield 32, 18 (row 0) and then 27
+    const auto one_block = Pipeline<Dna>::scan_order(hits, striped.rows());
+    CHECK(one_block.size() == 3 && one_block[0].position == 27 && one_block[1].position == 32 &&
+          one_block[2].position == 18);
+    const auto row_blocks = Pipeline<Dna>::scan_order(hits, striped.rows(), 1);
+    CHECK(row_blocks.size() == 3 && row_blocks[0].position == 32 && row_blocks[1].position == 18 &&
+          row_blocks[2].position == 27);
+    const auto best = Pipeline<Dna>::scan_max(hits);  // scan.rs:317-333
+    CHECK(best && best->position == 18 && std::fabs(best->score - (-5.50167f)) < 1e-5f);
+    CHECK(!Pipeline<Dna>::scan_max({}));
 }
 
 // Many motifs over one resident sequence (lightmotif-cli main.rs:554-561 fans the motifs

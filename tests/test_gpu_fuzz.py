@@ -79,10 +79,10 @@ def test_random_configuration(pli, seed):
         if not protein and a == 0 and b == rows_total and cols == 32 and length >= m:
             t = ts[min(1, len(ts) - 1)]
             by_pos = want[:, :32].T.reshape(-1)[: length - m + 1]
-            hits = list(lm.Scanner(pssm, seq, threshold=t))
+            scanner = lm.Scanner(pssm, seq, threshold=t)
             wpos = np.nonzero(by_pos >= np.float32(t))[0]
-            assert [h.position for h in hits] == wpos.tolist()
-            assert np.array_equal(bits([h.score for h in hits]), bits(by_pos[wpos]))
+            assert scanner.positions.tolist() == wpos.tolist()
+            assert np.array_equal(bits(scanner.scores), bits(by_pos[wpos]))
     finally:
         pli.set_rows_per_stream(0)
         pli.set_prefilter(True)

@@ -11,6 +11,7 @@ import pytest
 
 import lightmotif_amd as lm
 from oracle import c_oracle as co
+from oracle import np_oracle as no
 
 pytestmark = pytest.mark.gpu
 
@@ -150,10 +151,11 @@ def test_g5_scanner_like_test_scanner_py(pli):
 
 
 @pytest.mark.parametrize("length,frac", [(100_003, 0.5), (250_000, 0.01), (64, 1.0), (999_999, 1e-4)])
-def test_scanner_dense_hit_lists_come_back_in_position_order(pli, length, frac):
+def test_scanner_dense_hit_lists(pli, length, frac):
     """Scanner hits = every position p with score(p) >= t and p + M <= L (scan.rs:185-190),
-    each exactly once, in ascending position -- also when a large share of the cells
-    qualifies (the device-side ordering of the hit list, hits.hip)."""
+    each exactly once; `positions` ascending (the device-side ordering of the hit list,
+    hits.hip), iteration in the reference's block-wise pop order -- also when a large share of
+    the cells qualifies."""
     rng = np.random.default_rng(length)
     m = 9
     enc = rng.integers(0, 4, length, dtype=np.uint8)
@@ -168,10 +170,31 @@ def test_scanner_dense_hit_lists_come_back_in_position_order(pli, length, frac):
     wpos = np.nonzero(pos_scores >= np.float32(t))[0]
     seq = pli.stripe(lm.EncodedSequence(enc), 32)
     seq.configure_wrap(m - 1)
-    hits = list(lm.Scanner(lm.ScoringMatrix(p), seq, threshold=t))
-    assert [h.position for h in hits] == wpos.tolist()
-    assert np.array_equal(bits([h.score for h in hits]), bits(pos_scores[wpos]))
+    scanner = lm.Scanner(lm.ScoringMatrix(p), seq, threshold=t)
+    assert scanner.positions.tolist() == wpos.tolist()
+    assert np.array_equal(bits(scanner.scores), bits(pos_scores[wpos]))
     assert rows * 32 >= length
+    # iteration = the reference's yield order (blocks ascending, last pushed first; scan.rs:184-198)
+    for block_size in (256, 1, 7):
+        if block_size != 256 and length > 300_000:
+            continue
+        want_seq = no.scanner_collect(want, 32, length, m, t, block_size)
+        got_seq = list(lm.Scanner(lm.ScoringMatrix(p), seq, threshold=t, block_size=block_size))
+        assert [h.position for h in got_seq] == [i for i, _ in want_seq]
+        assert np.array_equal(bits([h.score for h in got_seq]), bits([x for _, x in want_seq]))
+    best = no.scanner_max(want, 32, length, m, t)                    # scan.rs:200-249
+    got = lm.Scanner(lm.ScoringMatrix(p), seq, threshold=t).max()
+    assert (got.position, np.float32(got.score)) == (best[0], best[1])
+    it = lm.Scanner(lm.ScoringMatrix(p), seq, threshold=t)
+    first = next(it)                                                  # max() sees what is left
+    rest = [h for h in no.scanner_collect(want, 32, length, m, t, 256)][1:]
+    if rest:
+        bi, bs = max(rest, key=lambda h: (h[1], h[0]))
+        after = it.max()
+        assert (after.position, np.float32(after.score)) == (bi, bs) and len(it) == 0
+    else:
+        assert it.max() is None
+    assert first.position == no.scanner_collect(want, 32, length, m, t, 256)[0][0]
 
 
 def test_indexing_reads_single_rows(pli):

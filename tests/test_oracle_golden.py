@@ -82,6 +82,26 @@ def test_g5_scanner_hits_by_brute_force():
         assert abs(h[1] - w["score"]) < 1e-5
 
 
+def test_g5_scanner_restatement_yield_order_and_max():
+    """`Scanner::next` / `Scanner::max` restated (scan.rs:166-249): the golden hit set
+    (scan.rs:290-297, 311-314) whatever the block size, yielded block by block with the last
+    pushed hit first, and the best hit of scan.rs:327-333."""
+    _, s, pssm = golden_setup(32)
+    scores, _ = co.score_rows(s, pssm)
+    want = GOLD["G5_scanner"]["threshold_m10"]
+    length, m = len(GOLD["G1_scores"]["sequence"]), pssm.shape[0]
+    for block_size in (256, 1, 2):
+        seq = no.scanner_collect(scores, 32, length, m, -10.0, block_size)
+        assert sorted(i for i, _ in seq) == [w["position"] for w in want]
+    # 64 bp at C = 32: 2 rows; the hits are cells (0, 9), (1, 13), (0, 16)
+    assert [i for i, _ in no.scanner_collect(scores, 32, length, m, -10.0, 256)] == [27, 32, 18]
+    assert [i for i, _ in no.scanner_collect(scores, 32, length, m, -10.0, 1)] == [32, 18, 27]
+    assert no.scanner_collect(scores, 32, length, m, 0.0) == []
+    best = no.scanner_max(scores, 32, length, m, -10.0)
+    assert best[0] == 18 and abs(float(best[1]) - (-5.50167)) < 1e-5
+    assert no.scanner_max(scores, 32, length, m, 0.0) is None
+
+
 def test_g6_stride_table():
     for c in GOLD["G6_stride"]["cases"]:
         assert co.stride(c["cols"], c["elem"]) == c["stride"]
