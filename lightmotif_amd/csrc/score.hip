@@ -627,6 +627,7 @@ struct RescoreJob {
 constexpr int kRescoreBlock = 1024;  // big workgroups: one global atomic per workgroup and flush, and
 constexpr int kHitStage = 4096;      // 2 048 small workgroups' atomics on one counter cost 12 us per launch
 constexpr int kRescoreBlocksPerCu = 2;
+constexpr int kRescoreCheck = 2;     // rounds between two flush decisions
 
 __global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const RescoreJob *__restrict__ jobs,
                                                              const FusedOut fo)
@@ -658,6 +659,7 @@ __global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const Rescor
     };
     // block-uniform trip count: one candidate piece per half-wave per round
     __shared__ uint8_t window[kRescoreBlock / 32][96];  // symbols of rows r0 .. r0 + nrows + M - 2
+    unsigned round = 0;
     for (unsigned long long c0 = (unsigned long long)blockIdx.x * (kRescoreBlock / 32); c0 < n; c0 += stride) {
         const unsigned long long c = c0 + (threadIdx.x >> 5);
         if (c < n) {
@@ -708,9 +710,18 @@ __global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const Rescor
                 }
             }
         }
-        __syncthreads();
-        if (nstage > kHitStage - kRescoreBlock)
-            flush();
+        // Every kRescoreCheck rounds the workgroup agrees on whether to flush: a round stages at
+        // most kRescoreBlock records, so the stage must have room for kRescoreCheck more rounds.
+        // Between checks the wavefronts run free and overlap their load chains.  The count is
+        // read between two barriers: a wavefront that raced ahead into the next round must not
+        // be able to change what a slower one reads (the decision has to be uniform).
+        if (++round % kRescoreCheck == 0) {
+            __syncthreads();
+            const unsigned cnt = nstage;
+            __syncthreads();
+            if (cnt > kHitStage - kRescoreCheck * kRescoreBlock)
+                flush();
+        }
     }
     flush();
 }

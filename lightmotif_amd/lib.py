@@ -750,6 +750,15 @@ class StripedScores:
         check(self._pli._L.lm_hip_scores_download(self._pli._h, self._h, out.ctypes.data))
         return out
 
+    def __array__(self, dtype=None, copy=None) -> np.ndarray:
+        """``numpy.asarray(scores)``: the reference exports the matrix through the buffer
+        protocol as a read-only (columns, rows) view with strides (4, stride * 4)
+        (lib.rs:1051-1085, 1129-1139), i.e. ``a[col, row]`` -- flattened in C order that is
+        the score of every position ``col * rows + row`` in sequence order."""
+        a = self.matrix()[:, :self.columns].T
+        a.flags.writeable = False
+        return a if dtype is None else a.astype(dtype)
+
     def offset(self, row: int, col: int) -> int:
         """scores.rs:155-157"""
         return col * self.rows + row

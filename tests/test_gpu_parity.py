@@ -206,6 +206,10 @@ def test_indexing_reads_single_rows(pli):
     for i, want in enumerate(g["expected"]):
         assert abs(scores[i] - want) < 1e-5
     assert scores[-1] == scores[len(scores) - 1]
+    view = np.asarray(scores)                                            # lib.rs:1051-1085, 1129-1139
+    assert view.shape == (scores.columns, scores.rows) and view.dtype == np.float32
+    assert not view.flags.writeable
+    assert np.array_equal(bits(view.ravel()[: len(scores)]), bits(scores.unstripe()))
     with pytest.raises(IndexError):
         scores[len(scores)]
     assert np.array_equal(bits(scores.rows_matrix(1, 2)), bits(full[1:2]))
