@@ -30,4 +30,8 @@ for p in glob.glob(out + "/prof/**/*kernel_trace.csv", recursive=True):
         w = csv.DictWriter(f, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(rows)
 PY
 rm -rf "$OUT/prof"
+for pv in 1e-5 1e-3; do
+  GRAFT_REPO_ROOT=$ROOT bash "$ROOT/tools/timeline_threshold.sh" $pv 2>/dev/null | grep -v simple_timer > "$OUT/timeline_fused_p$pv.txt"
+done
+cd "$ROOT"
 tail -c 600 "$OUT/bench_default.json"; echo; head -5 "$OUT/bench_kernel_stats.csv" | cut -c1-200
