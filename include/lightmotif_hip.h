@@ -184,6 +184,44 @@ int lm_hip_threshold_f32_dptr(lm_hip_ctx *ctx, const float *d_scores, size_t row
                               size_t stride, size_t cols, float t,
                               lm_hip_coords **coords, size_t *n);
 
+/* ---- Score / Maximum / Threshold on u8 (DiscreteMatrix scores) ------------- */
+
+/* Score<u8, A, C>::score_rows_into with the weights of a DiscreteMatrix
+ * (pwm/mod.rs:754-791; what Scanner::next scores first, scan.rs:174-178).
+ *   weights          dm.matrix()[0].as_ptr() ON THE HOST: m rows of weights_stride bytes,
+ *                    k = A::K used per row (DenseMatrix<u8, K>; 400 bytes at most, copied per call)
+ *   d_seq .. row_end as lm_hip_score_f32_dptr
+ *   d_out            u8 scores on the device, (row_end-row_begin) rows of out_stride bytes
+ *   saturate         1: the saturating byte adds of the SIMD back-ends (avx2.rs:336
+ *                    `_mm256_adds_epu8`; what `dispatch` runs on x86-64) -> min(sum, 255);
+ *                    0: Generic's `+=` on u8 (pli/mod.rs:98-102, wrapping in release
+ *                    builds) -> sum mod 256.  They agree whenever no sum exceeds 255.
+ * Same pre-checks, degenerate cases and *out_rows / *max_index as the f32 form.
+ * Asynchronous on the context's stream. */
+int lm_hip_score_u8_dptr(lm_hip_ctx *ctx, const uint8_t *weights, size_t m, size_t weights_stride,
+                         size_t k, const uint8_t *d_seq, size_t seq_rows_total, size_t seq_stride,
+                         size_t cols, size_t wrap, size_t length, size_t row_begin, size_t row_end,
+                         uint8_t *d_out, size_t out_stride, int saturate,
+                         size_t *out_rows, size_t *max_index);
+
+/* The same on a resident sequence handle, scores returned to the HOST: `out` receives
+ * (row_end-row_begin) rows of out_stride bytes (`cols` written per row), i.e. the
+ * StripedScores<u8, C> matrix a Rust caller owns (scores.matrix_mut()[0].as_mut_ptr()).
+ * Synchronises. */
+int lm_hip_score_u8(lm_hip_ctx *ctx, const uint8_t *weights, size_t m, size_t weights_stride,
+                    size_t k, const lm_hip_seq *seq, size_t row_begin, size_t row_end, int saturate,
+                    uint8_t *out, size_t out_stride, size_t *out_rows, size_t *max_index);
+
+/* Maximum<u8, C>::argmax / max, Generic semantics (pli/mod.rs:135-160; scan.rs:181 takes
+ * `max`): the maximal cell that is LAST in (row, col) order.  Synchronises. */
+int lm_hip_argmax_u8_dptr(lm_hip_ctx *ctx, const uint8_t *d_scores, size_t rows, size_t stride,
+                          size_t cols, int *found, lm_hip_coords *best, uint8_t *value);
+
+/* Threshold<u8, C>::threshold (pli/mod.rs:210-221; scan.rs:184): every (row, col) with
+ * x >= t in row-major order; *coords malloc'ed, release with lm_hip_free.  Synchronises. */
+int lm_hip_threshold_u8_dptr(lm_hip_ctx *ctx, const uint8_t *d_scores, size_t rows, size_t stride,
+                             size_t cols, uint8_t t, lm_hip_coords **coords, size_t *n);
+
 /* ---- fused score + reduce (no score matrix is written) -------------------- */
 
 /* Equivalent to score_rows_into followed by argmax on the result

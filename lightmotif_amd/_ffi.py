@@ -70,6 +70,11 @@ SIGNATURES = {
     "lm_hip_argmax_f32_dptr": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _ip, _cp, _fp]),
     "lm_hip_argmax_shard_f32_dptr": (C.c_int, [_vp, _vp, _sz, _sz, _sz, C.c_int, _ip, _cp, _fp]),
     "lm_hip_threshold_f32_dptr": (C.c_int, [_vp, _vp, _sz, _sz, _sz, C.c_float, C.POINTER(_cp), _szp]),
+    "lm_hip_score_u8_dptr": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz,
+                                      _vp, _sz, C.c_int, _szp, _szp]),
+    "lm_hip_score_u8": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _vp, _sz, _sz, C.c_int, _vp, _sz, _szp, _szp]),
+    "lm_hip_argmax_u8_dptr": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _ip, _cp, C.POINTER(C.c_uint8)]),
+    "lm_hip_threshold_u8_dptr": (C.c_int, [_vp, _vp, _sz, _sz, _sz, C.c_uint8, C.POINTER(_cp), _szp]),
     "lm_hip_score_argmax_f32_dptr": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz,
                                               _ip, _cp, _fp]),
     "lm_hip_score_argmax_shard_f32_dptr": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz,

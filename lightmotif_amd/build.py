@@ -28,7 +28,7 @@ FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
          f"-I{ROOT / 'include'}", f"-I{CSRC}"]
 # score_inst.hip is compiled 9 times: motif lengths 4*i+1 .. 4*i+4 (M = 1 .. 36)
 INST = [(i, 4 * i + 1, 4 * i + 4) for i in range(9)]
-UNITS = ["score.hip", "reduce.hip", "hits.hip", "layout.hip", "api.hip"]
+UNITS = ["score.hip", "reduce.hip", "hits.hip", "discrete.hip", "layout.hip", "api.hip"]
 
 
 def _hipcc() -> str:

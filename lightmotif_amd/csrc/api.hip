@@ -95,7 +95,7 @@ static bool build_prefilter(lm_hip_pssm &p, std::vector<unsigned> *image, std::v
     const int m = (int)p.m, k = (int)p.k;
     if (m < 1 || p.wide)
         return false;
-    const int mp = prefilter_mp(m), shift = mp - m, dsd = prefilter_stride_dw(m);
+    const int mp = prefilter_mp(m), shift = mp - m;
     std::vector<double> off(m), top(m);
     double offset = 0, range = 0, abs_sum = 0;
     for (int j = 0; j < m; ++j) {
@@ -133,17 +133,7 @@ static bool build_prefilter(lm_hip_pssm &p, std::vector<unsigned> *image, std::v
             d[(size_t)(j + shift) * k + s] = q;
         }
     image->assign((size_t)prefilter_image_dw(m, k), 0u);
-    unsigned *even = image->data();
-    unsigned *odd = even + (size_t)k * dsd;
-    for (int s = 0; s < k; ++s)
-        for (int w = 0; w < mp / 2; ++w) {
-            const unsigned e_lo = d[(size_t)(2 * w) * k + s];
-            const unsigned e_hi = d[(size_t)((2 * w - 1 + mp) % mp) * k + s];
-            const unsigned o_lo = d[(size_t)(2 * w + 1) * k + s];
-            const unsigned o_hi = d[(size_t)(2 * w) * k + s];
-            even[(size_t)s * dsd + w] = e_lo | (e_hi << 16);
-            odd[(size_t)s * dsd + w] = o_lo | (o_hi << 16);
-        }
+    prefilter_pack_image(d.data(), m, k, image->data());
     // pair-symbol table of score_c32_prefilter2<M> (DNA only): row (a, b) holds
     // E[e] = d[e-1][a] + d[e][b] over the motif padded to an ODD length M' by a leading
     // zero row; dword m = (lo E[2m+1], hi E[2m]).  Same weights, same sums, same bound.
@@ -498,6 +488,120 @@ int lm_hip_score_f32_dptr(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const uint8_
     DeviceGuard guard(ctx->device);
     ScoreArgs a{pssm, d_seq, seq_stride, cols, row_begin, row_end, d_out, out_stride};
     return launch_score_store(ctx, a);
+}
+
+int lm_hip_score_u8_dptr(lm_hip_ctx *ctx, const uint8_t *weights, size_t m, size_t weights_stride,
+                         size_t k, const uint8_t *d_seq, size_t seq_rows_total, size_t seq_stride,
+                         size_t cols, size_t wrap, size_t length, size_t row_begin, size_t row_end,
+                         uint8_t *d_out, size_t out_stride, int saturate, size_t *out_rows,
+                         size_t *max_index)
+{
+    if (!ctx)
+        return fail(LM_HIP_ERR_BAD_ARGS, "null context");
+    if (!weights || m == 0 || k == 0 || weights_stride < k)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score_u8: bad discrete matrix (%zu x %zu, stride %zu)", m, k,
+                    weights_stride);
+    lm_hip_pssm shape;  // the geometry checks only look at the motif length
+    shape.m = m;
+    shape.k = k;
+    LM_TRY(check_score_args(&shape, seq_rows_total, seq_stride, cols, wrap, row_begin, row_end));
+    if (length < m || row_begin >= row_end) {  // pli/mod.rs:85-88
+        if (out_rows) *out_rows = 0;
+        if (max_index) *max_index = 0;
+        return LM_HIP_OK;
+    }
+    if (!d_seq || !d_out || out_stride < cols)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score_u8: null buffer or out stride %zu < columns %zu", out_stride,
+                    cols);
+    if (out_rows) *out_rows = row_end - row_begin;  // pli/mod.rs:91
+    if (max_index) *max_index = length + 1 - m;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    DiscreteArgs a{weights, m, weights_stride, k, d_seq, seq_stride, cols, row_begin, row_end, d_out,
+                   out_stride, saturate != 0};
+    return launch_score_u8(ctx, a);
+}
+
+int lm_hip_score_u8(lm_hip_ctx *ctx, const uint8_t *weights, size_t m, size_t weights_stride, size_t k,
+                    const lm_hip_seq *seq, size_t row_begin, size_t row_end, int saturate, uint8_t *out,
+                    size_t out_stride, size_t *out_rows, size_t *max_index)
+{
+    if (!ctx || !seq)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score_u8: null argument");
+    if (!weights || m == 0 || k == 0 || weights_stride < k)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score_u8: bad discrete matrix (%zu x %zu, stride %zu)", m, k,
+                    weights_stride);
+    lm_hip_pssm shape;
+    shape.m = m;
+    shape.k = k;
+    LM_TRY(check_score_args(&shape, seq->rows + seq->wrap, seq->stride, seq->cols, seq->wrap, row_begin,
+                            row_end));
+    if (seq->length < m || row_begin >= row_end) {  // pli/mod.rs:85-88
+        if (out_rows) *out_rows = 0;
+        if (max_index) *max_index = 0;
+        return LM_HIP_OK;
+    }
+    if (!out || out_stride < seq->cols)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score_u8: null buffer or out stride %zu < columns %zu", out_stride,
+                    seq->cols);
+    if (out_rows) *out_rows = row_end - row_begin;
+    if (max_index) *max_index = seq->length + 1 - m;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    const size_t nrows = row_end - row_begin, cols = seq->cols;
+    LM_TRY(ctx->scratch.reserve(nrows * cols));
+    uint8_t *d_out = static_cast<uint8_t *>(ctx->scratch.ptr);
+    DiscreteArgs a{weights, m, weights_stride, k, seq->d_data, seq->stride, cols, row_begin, row_end, d_out,
+                   cols, saturate != 0};
+    LM_TRY(launch_score_u8(ctx, a));
+    LM_HIP_TRY(out_stride == cols
+                   ? hipMemcpyAsync(out, d_out, nrows * cols, hipMemcpyDeviceToHost, ctx->stream)
+                   : hipMemcpy2DAsync(out, out_stride, d_out, cols, cols, nrows, hipMemcpyDeviceToHost,
+                                      ctx->stream));
+    LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return LM_HIP_OK;
+}
+
+int lm_hip_argmax_u8_dptr(lm_hip_ctx *ctx, const uint8_t *d_scores, size_t rows, size_t stride, size_t cols,
+                          int *found, lm_hip_coords *best, uint8_t *value)
+{
+    if (!ctx || !found)
+        return fail(LM_HIP_ERR_BAD_ARGS, "argmax_u8: null argument");
+    *found = 0;
+    if (rows == 0)  // pli/mod.rs:136-138
+        return LM_HIP_OK;
+    if (!d_scores || cols == 0 || stride < cols)
+        return fail(LM_HIP_ERR_BAD_ARGS, "argmax_u8: bad matrix (stride %zu, columns %zu)", stride, cols);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    ArgmaxRecord rec{};
+    LM_TRY(launch_argmax_u8(ctx, d_scores, rows, stride, cols, &rec));
+    *found = rec.found;
+    if (rec.found) {
+        if (best) {
+            best->row = (size_t)(rec.index / (long long)cols);
+            best->col = (size_t)(rec.index % (long long)cols);
+        }
+        if (value)
+            *value = (uint8_t)rec.value;
+    }
+    return LM_HIP_OK;
+}
+
+int lm_hip_threshold_u8_dptr(lm_hip_ctx *ctx, const uint8_t *d_scores, size_t rows, size_t stride,
+                             size_t cols, uint8_t t, lm_hip_coords **coords, size_t *n)
+{
+    if (!ctx || !coords || !n)
+        return fail(LM_HIP_ERR_BAD_ARGS, "threshold_u8: null argument");
+    *coords = nullptr;
+    *n = 0;
+    if (rows == 0)
+        return LM_HIP_OK;
+    if (!d_scores || cols == 0 || stride < cols)
+        return fail(LM_HIP_ERR_BAD_ARGS, "threshold_u8: bad matrix (stride %zu, columns %zu)", stride, cols);
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    return launch_threshold_u8(ctx, d_scores, rows, stride, cols, t, coords, n);
 }
 
 static void record_to_coords(const ArgmaxRecord &rec, size_t cols, int *found, lm_hip_coords *best,

@@ -135,6 +135,22 @@ struct ScoreArgs {
 
 // Materialising score kernels.
 int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a);
+
+// Score<u8, ..> with a DiscreteMatrix (score.hip; reductions in discrete.hip)
+struct DiscreteArgs {
+    const uint8_t *weights;   // HOST: M x wstride u8 (DenseMatrix<u8, K>, pwm/mod.rs:757)
+    size_t m, wstride, k;
+    const uint8_t *d_seq;     // row 0 of the striped matrix (device)
+    size_t seq_stride, cols, row_begin, row_end;
+    uint8_t *d_out;           // row 0 of the u8 scores = sequence row row_begin (device)
+    size_t out_stride;
+    bool saturate;            // true: avx2.rs:336 saturating adds; false: Generic's wrapping `+=`
+};
+int launch_score_u8(lm_hip_ctx *ctx, const DiscreteArgs &a);
+int launch_argmax_u8(lm_hip_ctx *ctx, const uint8_t *d_scores, size_t rows, size_t stride, size_t cols,
+                     ArgmaxRecord *out);
+int launch_threshold_u8(lm_hip_ctx *ctx, const uint8_t *d_scores, size_t rows, size_t stride, size_t cols,
+                        unsigned t, lm_hip_coords **coords, size_t *n);
 // ... also leaving the argmax of the written rows in *d_result (device); *tracked = false
 // when the shape falls back to a plain store
 int launch_score_store_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *d_result, bool *tracked);

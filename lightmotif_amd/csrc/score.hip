@@ -10,6 +10,7 @@
 #include <tuple>
 
 #include "score_prefilter2.hpp"
+#include "score_u8.hpp"
 
 namespace lm {
 
@@ -90,6 +91,12 @@ ScoreC32Launcher score_c32_lookup_ql(int M)
 {
     std::call_once(g_c32_once, init_registry);
     return (M >= 1 && M <= kMaxFastM) ? g_c32[M][7] : nullptr;
+}
+
+ScoreC32Launcher score_c32_lookup_u8(int M)
+{
+    std::call_once(g_c32_once, init_registry);
+    return (M >= 1 && M <= kMaxFastM) ? g_c32[M][kSlotU8] : nullptr;
 }
 
 const char *score_c32_name(int M, int mode)
@@ -220,6 +227,79 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
     ctx->last_kernel = "score_generic<0>";
     const unsigned long long ncells = (unsigned long long)(a.row_end - a.row_begin) * a.cols;
     return launch_generic<MODE_STORE>(ctx, a, fo, generic_grid(ctx, ncells));
+}
+
+// ---- Store, u8 scores of a DiscreteMatrix --------------------------------------------------
+
+// Any geometry: one thread per cell, weights read from a dense M x K byte table (cached).
+__global__ __launch_bounds__(kBlock) void score_generic_u8(
+    const uint8_t *__restrict__ seq, const unsigned long long seq_stride, const unsigned cols,
+    const uint8_t *__restrict__ dense, const unsigned m, const unsigned k,
+    const unsigned long long row_begin, const unsigned long long row_end, uint8_t *__restrict__ out,
+    const unsigned long long out_stride, const unsigned wrap_mask)
+{
+    const unsigned long long ncells = (row_end - row_begin) * cols;
+    for (unsigned long long cell = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; cell < ncells;
+         cell += (unsigned long long)gridDim.x * kBlock) {
+        const unsigned long long r = cell / cols;
+        const unsigned c = (unsigned)(cell - r * cols);
+        const uint8_t *sp = seq + (row_begin + r) * seq_stride + c;
+        unsigned sum = 0;  // exact: m * 255 fits easily
+        for (unsigned j = 0; j < m; ++j)
+            sum += dense[j * k + sp[j * seq_stride]];
+        out[r * out_stride + c] = (uint8_t)(wrap_mask ? (sum & wrap_mask) : (sum < 255u ? sum : 255u));
+    }
+}
+
+int launch_score_u8(lm_hip_ctx *ctx, const DiscreteArgs &a)
+{
+    const int m = (int)a.m, k = (int)a.k;
+    const unsigned wrap_mask = a.saturate ? 0u : 0xffu;
+    // plan with the f32 planner: same stream geometry as the packed prefilter scan
+    lm_hip_pssm shape;
+    shape.m = a.m;
+    shape.k = a.k;
+    ScoreArgs sa{&shape, a.d_seq, a.seq_stride, a.cols, a.row_begin, a.row_end, nullptr, a.out_stride};
+    const C32Plan p = plan_c32(ctx, sa, true, 1);
+    ScoreC32Launcher fn = p.ok ? score_c32_lookup_u8(m) : nullptr;
+    // device copies (scratch2): [packed image | dense table], staged through the pinned buffer
+    const size_t image_bytes = fn ? (size_t)prefilter_image_dw(m, k) * 4 : 0;
+    const size_t dense_bytes = ((size_t)m * k + 15) / 16 * 16;
+    LM_TRY(ctx->scratch2.reserve(image_bytes + dense_bytes));
+    // (the call returns without synchronising, so the tables are staged in pageable memory: the
+    // runtime copies that out before hipMemcpyAsync returns; the shared pinned buffer could be
+    // overwritten by the next call while this copy is still queued)
+    std::vector<char> stage_buf(image_bytes + dense_bytes, 0);
+    char *stage = stage_buf.data();
+    if (fn) {
+        const int mp = prefilter_mp(m), shift = mp - m;
+        std::vector<unsigned> d((size_t)mp * k, 0u);
+        for (int j = 0; j < m; ++j)
+            for (int s = 0; s < k; ++s)
+                d[(size_t)(j + shift) * k + s] = a.weights[(size_t)j * a.wstride + s];
+        prefilter_pack_image(d.data(), m, k, reinterpret_cast<unsigned *>(stage));
+    }
+    for (int j = 0; j < m; ++j)
+        memcpy(stage + image_bytes + (size_t)j * k, a.weights + (size_t)j * a.wstride, (size_t)k);
+    char *dev = static_cast<char *>(ctx->scratch2.ptr);
+    LM_HIP_TRY(hipMemcpyAsync(dev, stage, image_bytes + dense_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (fn) {
+        FusedOut fo{};
+        fo.key_rows = wrap_mask;
+        ctx->last_kernel = "score_c32_u8";
+        LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, reinterpret_cast<const float *>(dev), k, a.row_begin,
+                      a.row_end, p.T, p.nstreams, reinterpret_cast<float *>(a.d_out), fo));
+        return LM_HIP_OK;
+    }
+    ctx->last_kernel = "score_generic_u8";
+    const unsigned long long ncells = (unsigned long long)(a.row_end - a.row_begin) * a.cols;
+    hipLaunchKernelGGL(score_generic_u8, generic_grid(ctx, ncells), dim3(kBlock), 0, ctx->stream, a.d_seq,
+                       (unsigned long long)a.seq_stride, (unsigned)a.cols,
+                       reinterpret_cast<const uint8_t *>(dev + image_bytes), (unsigned)m, (unsigned)k,
+                       (unsigned long long)a.row_begin, (unsigned long long)a.row_end, a.d_out,
+                       (unsigned long long)a.out_stride, wrap_mask);
+    LM_HIP_TRY(hipGetLastError());
+    return LM_HIP_OK;
 }
 
 __global__ void argmax_fold(const ArgmaxRecord *__restrict__ blocks, const unsigned nblocks,

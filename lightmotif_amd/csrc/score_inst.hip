@@ -2,6 +2,7 @@
 // Compiled several times with different -DLM_M_LO/-DLM_M_HI/-DLM_INST_ID so the
 // fully unrolled kernels build in parallel (see build.py).
 #include "score_prefilter2.hpp"
+#include "score_u8.hpp"
 
 #ifndef LM_M_LO
 #error "LM_M_LO / LM_M_HI / LM_INST_ID must be defined"
@@ -27,6 +28,7 @@ struct RegisterRange {
         if constexpr (M % 4 == 0)
             tab[M][7] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 0, 1>;
         tab[M][8] = &score_c32_launch<M, MODE_STORE_ARGMAX, LM_SCORE_XCD_REMAP, 0, 1>;
+        tab[M][kSlotU8] = &score_c32_u8_launch<M>;  // DiscreteMatrix scores (score_u8.hpp)
 #if defined(LM_SCORE_BUILD_WIDE)
         // 8-byte-read variant for K > 16; not built by default, see api.hip (pssm_create)
         tab[M][4 + MODE_STORE] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1>;

@@ -45,6 +45,26 @@ constexpr int prefilter_image_dw(int m, int k)
     return 2 * k * prefilter_stride_dw(m);
 }
 
+// Host side: packs the padded discrete weights d[j * k + s], j < prefilter_mp(m) (row 0 = the
+// all-zero padding row when m is odd), into the LDS image [layout EVEN | layout ODD].
+inline void prefilter_pack_image(const unsigned *d, int m, int k, unsigned *image)
+{
+    const int mp = prefilter_mp(m), dsd = prefilter_stride_dw(m);
+    for (int i = 0; i < prefilter_image_dw(m, k); ++i)
+        image[i] = 0u;
+    unsigned *even = image;
+    unsigned *odd = even + (size_t)k * dsd;
+    for (int s = 0; s < k; ++s)
+        for (int w = 0; w < mp / 2; ++w) {
+            const unsigned e_lo = d[(size_t)(2 * w) * k + s];
+            const unsigned e_hi = d[(size_t)((2 * w - 1 + mp) % mp) * k + s];
+            const unsigned o_lo = d[(size_t)(2 * w + 1) * k + s];
+            const unsigned o_hi = d[(size_t)(2 * w) * k + s];
+            even[(size_t)s * dsd + w] = e_lo | (e_hi << 16);
+            odd[(size_t)s * dsd + w] = o_lo | (o_hi << 16);
+        }
+}
+
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 // Adds two pairs of u16 accumulators.  No 16-bit sum can exceed 65000 + 2M < 65536 (host
@@ -67,13 +87,19 @@ __device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b)
 // reaches td belongs to an output that will reach it too -- taking it into the maximum can
 // only flag a group early (an extra exact re-scoring), never hide a hit.  One v_pk_max_u16
 // per step instead of extract + compare + select.
-template <int M, int PF, int PHASE>
+//
+// STORE = 1 (score_u8.hpp): the sums are a DiscreteMatrix's u8 scores; every completed sum is
+// written to `op[k * 32]` (`op` = the lane's cell of the group's first completed output;
+// the FIRST group completes one output only), clamped to 255 (`sat_mask` = 0: the
+// saturating adds of avx2.rs:336) or reduced mod 256 (`sat_mask` = 0xff: Generic's `+=`).
+template <int M, int PF, int PHASE, int STORE = 0>
 __device__ __forceinline__ void prefilter_group(unsigned (&acc2)[prefilter_mp(M) / 2],
                                                 unsigned (&sym)[prefilter_mp(M)],
                                                 const uint8_t *__restrict__ sp,
                                                 const char *__restrict__ tab_even,
                                                 const char *__restrict__ tab_odd,
-                                                unsigned &mx)
+                                                unsigned &mx, uint8_t *__restrict__ op = nullptr,
+                                                const unsigned wrap_mask = 0)
 {
     constexpr int MP = prefilter_mp(M);
     constexpr int NP = MP / 2;
@@ -114,8 +140,15 @@ __device__ __forceinline__ void prefilter_group(unsigned (&acc2)[prefilter_mp(M)
         // slot (k+1) mod MP received its last weight: compare, then clear it for the
         // output that starts in it at the next step
         const int sc = (k + 1) % MP;
-        if (PHASE != PHASE_FIRST || k == MP - 1)
+        if (STORE) {
+            if (PHASE != PHASE_FIRST || k == MP - 1) {
+                const unsigned sum = (sc & 1) ? (acc2[sc / 2] >> 16) : (acc2[sc / 2] & 0xffffu);
+                const unsigned v = wrap_mask ? (sum & wrap_mask) : (sum < 255u ? sum : 255u);
+                op[(PHASE == PHASE_FIRST ? 0 : k) * 32] = (uint8_t)v;
+            }
+        } else if (PHASE != PHASE_FIRST || k == MP - 1) {
             mx = pk_max_u16(mx, acc2[sc / 2]);
+        }
         acc2[sc / 2] &= (sc & 1) ? 0x0000ffffu : 0xffff0000u;
     }
 }

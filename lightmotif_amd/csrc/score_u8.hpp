@@ -1,0 +1,104 @@
+// score_u8.hpp -- `Score<u8, A, C>` for C = 32: the scores of a DiscreteMatrix
+// (lightmotif/src/pwm/mod.rs:754-791), materialised as a u8 StripedScores matrix.
+//
+// Reference bodies: Generic adds the M weights with `+=` on u8 (pli/mod.rs:98-102, wrapping
+// in release builds), AVX2 / SSE2 / NEON with saturating byte adds (avx2.rs:336
+// `_mm256_adds_epu8`).  The weights are non-negative integers, so both are functions of the
+// EXACT integer sum: min(sum, 255) and sum mod 256.  The exact sum is what the packed
+// 16-bit rotating-accumulator scan of score_prefilter.hpp computes (M * 255 < 65536: no
+// carry between the halves), so this kernel is that scan with the DiscreteMatrix's own
+// weights in the LDS image and a byte store where the prefilter compares.
+//
+// Traffic: 1 B read + 1 B written per cell (SURVEY 8a "32 B in, 32 B out per row").
+#pragma once
+
+#include "score_prefilter.hpp"
+
+namespace lm {
+
+// `image` = prefilter image built from the u8 weights (api.hip: pack_prefilter_image);
+// `out` = row `row_begin` of the u8 score matrix, row stride 32.
+template <int M, int PF = LM_SCORE_PF>
+__global__ __launch_bounds__(kBlock, 6) void score_c32_u8(
+    const uint8_t *__restrict__ seq, const unsigned *__restrict__ image, const int K,
+    const unsigned long long row_begin, const unsigned long long row_end,
+    const unsigned long long T, const unsigned long long nstreams, uint8_t *__restrict__ out,
+    const unsigned wrap_mask)
+{
+    constexpr int MP = prefilter_mp(M);
+    constexpr int SHIFT = MP - M;
+    constexpr int NP = MP / 2;
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    {
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
+        const uint4 *src = reinterpret_cast<const uint4 *>(image);
+        const int n4 = prefilter_image_dw(M, K) / 4;
+        for (int i = threadIdx.x; i < n4; i += kBlock)
+            dst[i] = src[i];
+    }
+    __syncthreads();
+    const char *tab_even = lds_raw;
+    const char *tab_odd = tab_even + (size_t)K * prefilter_stride_dw(M) * 4;
+
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 31;
+    unsigned long long stream =
+        ((unsigned long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    if (stream >= nstreams)  // idle half-waves redo the last stream (same bytes, same values)
+        stream = nstreams - 1;
+    unsigned long long o0 = row_begin + stream * T;
+    if (o0 + T > row_end)    // the last stream is shifted back and overlaps its neighbour
+        o0 = row_end - T;
+
+    const uint8_t *sp = seq + (long long)(o0 - SHIFT) * 32 + col;
+    constexpr int PFE = PF < MP ? PF : MP - 1;
+    unsigned acc2[NP];
+    unsigned sym[MP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+        acc2[i] = 0;
+#pragma unroll
+    for (int j = 0; j < MP; ++j)
+        sym[j] = 0;
+#pragma unroll
+    for (int j = 0; j < PFE; ++j) {
+        if (j == 0 && SHIFT) {
+            if (o0 > 0)  // row -1 does not exist; its weight row is all zero anyway
+                sym[0] = sp[0];
+        } else {
+            sym[j] = sp[j * 32];
+        }
+    }
+
+    // group 0 completes output 0, group g >= 1 outputs (g-1)*MP+1 .. g*MP
+    const unsigned long long ngroups = (T + MP - 1) / MP;  // exact: T = q*MP + 1, >= 2
+    uint8_t *op = out + (o0 - row_begin) * 32 + col;
+    unsigned mx = 0;
+    prefilter_group<M, PFE, PHASE_FIRST, 1>(acc2, sym, sp, tab_even, tab_odd, mx, op, wrap_mask);
+    op += 32;
+    for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
+        sp += MP * 32;
+        prefilter_group<M, PFE, PHASE_MAIN, 1>(acc2, sym, sp, tab_even, tab_odd, mx, op, wrap_mask);
+        op += MP * 32;
+    }
+    sp += MP * 32;
+    prefilter_group<M, PFE, PHASE_LAST, 1>(acc2, sym, sp, tab_even, tab_odd, mx, op, wrap_mask);
+}
+
+// Registry shim with the ScoreC32Launcher signature (slot kSlotU8 of the registry): `table`
+// carries the packed u16 image, `out` the u8 score matrix, `fo.key_rows` the wrap mask.
+template <int M>
+hipError_t score_c32_u8_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, const uint8_t *seq,
+                               const float *table, int K, unsigned long long row_begin,
+                               unsigned long long row_end, unsigned long long T,
+                               unsigned long long nstreams, float *out, FusedOut fo)
+{
+    hipLaunchKernelGGL((score_c32_u8<M>), grid, dim3(kBlock), lds_bytes, stream, seq,
+                       reinterpret_cast<const unsigned *>(table), K, row_begin, row_end, T, nstreams,
+                       reinterpret_cast<uint8_t *>(out), (unsigned)fo.key_rows);
+    return hipGetLastError();
+}
+
+constexpr int kSlotU8 = 9;
+
+}  // namespace lm

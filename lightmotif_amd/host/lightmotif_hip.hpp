@@ -194,6 +194,25 @@ inline std::vector<float> uniform_background()  // abc.rs:473-487
     return bg;
 }
 
+// pwm/mod.rs:754-791: u8 weights that over-estimate the f32 scores
+template <class A>
+class DiscreteMatrix {
+public:
+    DiscreteMatrix(DenseMatrix<uint8_t> d, float f, std::vector<float> offs, float off)
+        : data(std::move(d)), factor(f), offsets(std::move(offs)), offset(off) {}
+    size_t len() const { return data.rows(); }
+    const DenseMatrix<uint8_t> &matrix() const { return data; }
+    // pwm/mod.rs:777-779: rounds DOWN (an f32 threshold -> a u8 threshold); Rust's saturating `as u8`
+    uint8_t scale(float score) const { return to_u8(std::floor((score - offset) / factor)); }
+    // pwm/mod.rs:783-785
+    float unscale(uint8_t score) const { return (float)score * factor + offset; }
+    static uint8_t to_u8(float x) { return x != x ? 0 : x <= 0.0f ? 0 : x >= 255.0f ? 255 : (uint8_t)x; }
+    DenseMatrix<uint8_t> data;
+    float factor;
+    std::vector<float> offsets;
+    float offset;
+};
+
 template <class A>
 class ScoringMatrix {  // pwm/mod.rs:561-564
 public:
@@ -211,6 +230,40 @@ public:
     ScoringMatrix(const ScoringMatrix &o) : background(o.background), data(o.data) {}
     size_t len() const { return data.rows(); }
     const DenseMatrix<float> &matrix() const { return data; }
+    // pwm/mod.rs:604-615: sum over the rows of the best weight among the K-1 real symbols
+    float max_score() const
+    {
+        float total = 0.0f;
+        for (size_t i = 0; i < data.rows(); ++i) {
+            float best = data(i, 0);
+            for (size_t j = 1; j + 1 < A::K; ++j)
+                best = data(i, j) > best ? data(i, j) : best;
+            total += best;
+        }
+        return total;
+    }
+    // pwm/mod.rs:665-696
+    DiscreteMatrix<A> to_discrete() const
+    {
+        const float top = max_score();
+        std::vector<float> offsets(data.rows());
+        float offset = 0.0f;
+        for (size_t i = 0; i < data.rows(); ++i) {
+            float lo = std::numeric_limits<float>::infinity();
+            for (size_t j = 0; j + 1 < A::K; ++j) {
+                const float x = std::isinf(data(i, j)) ? -top : data(i, j);
+                lo = x < lo ? x : lo;
+            }
+            offsets[i] = lo;
+            offset += lo;
+        }
+        const float factor = (top - offset) / 255.0f;
+        DenseMatrix<uint8_t> d(data.rows(), A::K);
+        for (size_t i = 0; i < data.rows(); ++i)
+            for (size_t j = 0; j < A::K; ++j)
+                d(i, j) = DiscreteMatrix<A>::to_u8(std::ceil((data(i, j) - offsets[i]) / factor));
+        return DiscreteMatrix<A>(std::move(d), factor, std::move(offsets), offset);
+    }
     lm_hip_pssm *device(lm_hip_ctx *ctx) const
     {
         if (!dev_ || dev_ctx_ != ctx) {
@@ -449,6 +502,26 @@ public:
         StripedScores s = empty_scores(seq.columns());
         score_into(pssm, seq, s);
         return s;
+    }
+    // Score<u8, A, C>::score with a DiscreteMatrix (pli/mod.rs:72-129): the u8 StripedScores the
+    // Scanner computes first (scan.rs:174-178), returned on the host.  `saturate`: the SIMD
+    // back-ends' saturating adds (avx2.rs:336) or Generic's wrapping `+=`.
+    struct DiscreteScores {
+        DenseMatrix<uint8_t> data;
+        size_t max_index;
+        // scores.rs:246-254: the score of position i
+        uint8_t at(size_t i) const { return data(i % data.rows(), i / data.rows()); }
+        size_t len() const { return max_index; }
+    };
+    DiscreteScores score(const DiscreteMatrix<A> &dm, const StripedSequence<A> &seq, bool saturate = true) const
+    {
+        size_t rows = 0, max_index = 0;
+        DenseMatrix<uint8_t> out(seq.rows(), seq.columns());
+        check(lm_hip_score_u8(ctx_->ctx, dm.data.ptr(), dm.data.rows(), dm.data.stride(), A::K, seq.handle(), 0,
+                              seq.rows(), saturate ? 1 : 0, out.ptr(), out.stride(), &rows, &max_index));
+        if (rows == 0)
+            return DiscreteScores{DenseMatrix<uint8_t>(0, seq.columns()), 0};
+        return DiscreteScores{std::move(out), max_index};
     }
     // Maximum::argmax / max (pli/mod.rs:135-160)
     std::optional<MatrixCoordinates> argmax(const StripedScores &scores) const

@@ -26,7 +26,7 @@ from ._ffi import Coords, InvalidSymbol, LightmotifHipError, UnsupportedBackend,
 
 __all__ = [
     "Pipeline", "EncodedSequence", "StripedSequence", "CountMatrix", "WeightMatrix",
-    "ScoringMatrix", "StripedScores", "Scanner", "Hit", "Motif", "create", "stripe", "scan",
+    "ScoringMatrix", "DiscreteMatrix", "StripedScores", "Scanner", "Hit", "Motif", "create", "stripe", "scan",
     "UnsupportedBackend", "InvalidSymbol", "LightmotifHipError", "DEFAULT_COLUMNS",
 ]
 
@@ -312,6 +312,47 @@ class Pipeline:
         ptr, n = C.POINTER(Coords)(), C.c_size_t(0)
         check(self._L.lm_hip_threshold_f32_dptr(self._h, C.c_void_p(scores_ptr), rows, stride_,
                                                 columns, threshold, C.byref(ptr), C.byref(n)))
+        return self._take_coords_array(ptr, n.value)
+
+    # -- Score / Maximum / Threshold on u8: a DiscreteMatrix's scores ----------------------------
+
+    def score_discrete(self, dm: "DiscreteMatrix", seq: "StripedSequence", rows: Optional[range] = None,
+                       saturate: bool = True) -> Tuple[np.ndarray, int]:
+        """``Score<u8, ..>::score_rows_into(&dm, &seq, rows, &mut scores)`` (pli/mod.rs:72-106):
+        the u8 score matrix ``(rows, stride(C, 1))`` on the host and ``max_index``.
+        ``saturate``: the SIMD back-ends' saturating adds (avx2.rs:336) or Generic's wrapping."""
+        rows = range(0, seq.rows) if rows is None else rows
+        n = max(rows.stop - rows.start, 0)
+        st = stride(seq.columns, 1)
+        out = np.zeros((n, st), dtype=np.uint8)
+        orow, mi = C.c_size_t(0), C.c_size_t(0)
+        check(self._L.lm_hip_score_u8(self._h, dm.data.ctypes.data, len(dm), dm.data.shape[1], dm.k,
+                                      seq._h, rows.start, max(rows.stop, rows.start), int(saturate),
+                                      out.ctypes.data, st, C.byref(orow), C.byref(mi)))
+        return out[:orow.value], int(mi.value)
+
+    def score_u8_dptr(self, dm: "DiscreteMatrix", seq_ptr: int, seq_rows_total: int, seq_stride: int,
+                      columns: int, wrap: int, length: int, row_begin: int, row_end: int, out_ptr: int,
+                      out_stride: int, saturate: bool = True) -> Tuple[int, int]:
+        orow, mi = C.c_size_t(0), C.c_size_t(0)
+        check(self._L.lm_hip_score_u8_dptr(self._h, dm.data.ctypes.data, len(dm), dm.data.shape[1], dm.k,
+                                           C.c_void_p(seq_ptr), seq_rows_total, seq_stride, columns, wrap,
+                                           length, row_begin, row_end, C.c_void_p(out_ptr), out_stride,
+                                           int(saturate), C.byref(orow), C.byref(mi)))
+        return int(orow.value), int(mi.value)
+
+    def argmax_u8_dptr(self, scores_ptr: int, rows: int, stride_: int, columns: int):
+        """``Maximum<u8, C>`` (pli/mod.rs:135-160): ``((row, col), value)`` or ``None``."""
+        found, best, value = C.c_int(0), Coords(), C.c_uint8(0)
+        check(self._L.lm_hip_argmax_u8_dptr(self._h, C.c_void_p(scores_ptr), rows, stride_, columns,
+                                            C.byref(found), C.byref(best), C.byref(value)))
+        return ((best.row, best.col), int(value.value)) if found.value else None
+
+    def threshold_u8_dptr(self, scores_ptr: int, rows: int, stride_: int, columns: int, t: int) -> np.ndarray:
+        """``Threshold<u8, C>`` (pli/mod.rs:210-221): (n, 2) int64 (row, col) in row-major order."""
+        ptr, n = C.POINTER(Coords)(), C.c_size_t(0)
+        check(self._L.lm_hip_threshold_u8_dptr(self._h, C.c_void_p(scores_ptr), rows, stride_, columns,
+                                               C.c_uint8(t), C.byref(ptr), C.byref(n)))
         return self._take_coords_array(ptr, n.value)
 
     def score_threshold_dptr(self, pssm: "ScoringMatrix", seq_ptr: int, seq_rows_total: int,
@@ -661,6 +702,29 @@ class ScoringMatrix:
         """pwm/mod.rs:605-615: sum over positions of the highest weight."""
         return self._extreme_score(np.max)
 
+    def to_discrete(self) -> "DiscreteMatrix":
+        """pwm/mod.rs:665-696: u8 weights that over-estimate the scores, in f32 arithmetic like
+        the reference (row offsets = row minima over the K-1 real symbols with -inf counted
+        as -max_score, one global factor = (max_score - offset) / 255, weights rounded UP and
+        converted with Rust's saturating ``as u8``)."""
+        k = self.k
+        p = self.data[:, :k]
+        max_score = np.float32(self.max_score())
+        offsets = np.empty(len(self), np.float32)
+        for j in range(len(self)):
+            row = np.where(np.isinf(p[j, :k - 1]), np.float32(-max_score), p[j, :k - 1])
+            offsets[j] = row.min()
+        offset = np.float32(0.0)
+        for x in offsets:
+            offset = np.float32(offset + x)
+        factor = np.float32(np.float32(max_score - offset) / np.float32(255))
+        with np.errstate(invalid="ignore", over="ignore", divide="ignore"):
+            scaled = np.ceil((p - offsets[:, None]).astype(np.float32) / factor)
+            scaled = np.where(np.isnan(scaled), np.float32(0), np.clip(scaled, 0, 255))
+        data = np.zeros((len(self), stride(k, 1)), dtype=np.uint8)  # DenseMatrix<u8, K>
+        data[:, :k] = scaled.astype(np.uint8)
+        return DiscreteMatrix(data, float(factor), offsets, float(offset), protein=self.protein)
+
     @property
     def score_distribution(self):
         """pwm/mod.rs:698-705 ``to_score_distribution`` (MEME-style, pwm/dist.rs)."""
@@ -688,6 +752,32 @@ class ScoringMatrix:
             raise ValueError("cannot complement a protein matrix")
         comp = [2, 3, 0, 1, 4]
         return ScoringMatrix(self.data[::-1, :5][:, comp], self.background, protein=False)
+
+
+class DiscreteMatrix:
+    """pwm/mod.rs:754-791 ``{data: DenseMatrix<u8, K>, factor, offsets, offset}``."""
+
+    def __init__(self, data: np.ndarray, factor: float, offsets: np.ndarray, offset: float, *,
+                 protein: bool = False):
+        self.data = np.ascontiguousarray(data, dtype=np.uint8)
+        self.factor, self.offsets, self.offset, self.protein = factor, offsets, offset, protein
+
+    @property
+    def k(self) -> int:
+        return _k(self.protein)
+
+    def __len__(self) -> int:
+        return self.data.shape[0]
+
+    def scale(self, score: float) -> int:
+        """pwm/mod.rs:777-779: rounds DOWN (f32 -> u8 threshold), saturating ``as u8``."""
+        with np.errstate(invalid="ignore", over="ignore", divide="ignore"):
+            v = np.floor(np.float32(np.float32(score) - np.float32(self.offset)) / np.float32(self.factor))
+        return 0 if v != v else int(min(max(v, 0), 255))
+
+    def unscale(self, score: int) -> float:
+        """pwm/mod.rs:783-785"""
+        return float(np.float32(np.float32(score) * np.float32(self.factor) + np.float32(self.offset)))
 
 
 # --- scores -----------------------------------------------------------------------------

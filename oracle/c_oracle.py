@@ -211,6 +211,23 @@ def score_rows(s: Striped, pssm: np.ndarray, row_begin: int | None = None,
     return out[:orow.value], int(mi.value)
 
 
+def score_rows_u8(s: Striped, weights: np.ndarray, row_begin: int | None = None,
+                  row_end: int | None = None):
+    """Generic `Score<u8, ..>` with a DiscreteMatrix's weights ``(M, stride) u8`` (wrapping
+    `+=`, pli/mod.rs:98-102).  Returns (scores[(rows, stride(cols, 1)) u8], max_index)."""
+    a = 0 if row_begin is None else row_begin
+    b = s.rows if row_end is None else row_end
+    ost = stride(s.cols, 1)
+    n = max(b - a, 0)
+    out = aligned_empty((n, ost), np.uint8)
+    out[:] = 0
+    orow, mi = C.c_size_t(0), C.c_size_t(0)
+    weights = np.ascontiguousarray(weights, dtype=np.uint8)
+    lib().lmo_score_rows_u8(_p8(s.data), s.stride, s.cols, s.length, _p8(weights), weights.shape[0],
+                            weights.shape[1], a, b, _p8(out), ost, C.byref(orow), C.byref(mi))
+    return out[:orow.value], int(mi.value)
+
+
 def argmax(scores: np.ndarray, cols: int):
     r, c = C.c_size_t(0), C.c_size_t(0)
     scores = np.ascontiguousarray(scores, dtype=np.float32)

@@ -160,3 +160,63 @@ def scanner_max(scores: np.ndarray, cols: int, length: int, m: int, t: float):
         if best is None or s > best[1] or (s == best[1] and index > best[0]):
             best = (index, s)
     return best
+
+
+# ---- DiscreteMatrix (pwm/mod.rs:665-696, 754-791) ------------------------------------------
+
+
+def _rust_f32_to_u8(x: np.ndarray) -> np.ndarray:
+    """Rust `f32 as u8`: saturating, NaN -> 0."""
+    x = np.asarray(x, dtype=np.float32)
+    with np.errstate(invalid="ignore"):
+        y = np.where(np.isnan(x), np.float32(0), np.clip(x, np.float32(0), np.float32(255)))
+    return np.trunc(y).astype(np.uint8)
+
+
+def to_discrete(pssm: np.ndarray, k: int):
+    """pwm/mod.rs:665-696 `ScoringMatrix::to_discrete` in f32 arithmetic.  `pssm` is
+    ``(M, >= k) f32``; returns (weights ``(M, k) u8``, factor, offsets ``(M,) f32``, offset).
+    max_score (pwm/mod.rs:604-615) = sum over rows of the row maximum over the first
+    k-1 symbols; a -inf weight counts as -max_score for the row minimum."""
+    p = np.asarray(pssm, dtype=np.float32)[:, :k]
+    m = p.shape[0]
+    max_score = np.float32(0)
+    for j in range(m):                              # sequential f32 sum, as `.sum::<f32>()`
+        max_score = np.float32(max_score + p[j, :k - 1].max())
+    offsets = np.empty(m, np.float32)
+    for j in range(m):
+        row = np.where(np.isinf(p[j, :k - 1]), np.float32(-max_score), p[j, :k - 1])
+        offsets[j] = row.min()
+    offset = np.float32(0)
+    for j in range(m):
+        offset = np.float32(offset + offsets[j])
+    factor = np.float32(np.float32(max_score - offset) / np.float32(255))
+    with np.errstate(invalid="ignore", over="ignore"):
+        scaled = np.ceil((p - offsets[:, None]).astype(np.float32) / factor)
+    return _rust_f32_to_u8(scaled), factor, offsets, offset
+
+
+def discrete_scale(score: float, factor, offset) -> int:
+    """pwm/mod.rs:777-779: floor((score - offset) / factor) as u8."""
+    with np.errstate(invalid="ignore", over="ignore"):
+        v = np.floor(np.float32(np.float32(score) - offset) / factor)
+    return int(_rust_f32_to_u8(np.array([v]))[0])
+
+
+def discrete_unscale(score: int, factor, offset) -> np.float32:
+    """pwm/mod.rs:783-785"""
+    return np.float32(np.float32(score) * factor + offset)
+
+
+def score_rows_u8_saturating(data: np.ndarray, cols: int, length: int, weights: np.ndarray,
+                             row_begin: int, row_end: int) -> np.ndarray:
+    """avx2.rs:294-347: per row, M saturating byte adds (`_mm256_adds_epu8`, :336) of the
+    shuffled weights, from zero.  ``data`` = striped matrix incl. wrap rows."""
+    m = weights.shape[0]
+    if length < m or row_begin >= row_end:
+        return np.zeros((0, cols), np.uint8)
+    out = np.zeros((row_end - row_begin, cols), np.uint16)
+    for j in range(m):
+        y = weights[j][data[row_begin + j: row_end + j, :cols]].astype(np.uint16)
+        out = np.minimum(out + y, 255)             # adds_epu8
+    return out.astype(np.uint8)

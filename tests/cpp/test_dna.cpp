@@ -120,6 +120,28 @@ static void test_threshold(const Pipeline<Dna> &pli, size_t columns)
     CHECK(result.at(0) == -23.07094f);
 }
 
+// tests/dna.rs:93-120 `test_score_discrete`: unscale(u8 score) >= the f32 score, position by position
+static void test_score_discrete(const Pipeline<Dna> &pli)
+{
+    auto striped = pli.stripe(EncodedSequence<Dna>::encode(SEQUENCE));
+    const auto pssm = golden_pssm();
+    const auto dm = pssm.to_discrete();
+    striped.configure(pssm);
+    const auto result = pli.score(dm, striped);
+    CHECK(result.len() == sizeof(EXPECTED) / sizeof(EXPECTED[0]));
+    for (size_t i = 0; i < result.len(); ++i)
+        CHECK(dm.unscale(result.at(i)) >= EXPECTED[i]);
+    // no sum reaches 255 here, so Generic's wrapping adds give the same matrix
+    const auto wrapped = pli.score(dm, striped, false);
+    for (size_t i = 0; i < result.len(); ++i)
+        CHECK(wrapped.at(i) == result.at(i));
+    // scan.rs:169-172: the scaled threshold under-estimates, so every hit of the Scanner test
+    // (positions 18, 27, 32 at t = -10) passes the u8 test
+    const uint8_t t = dm.scale(-10.0f);
+    CHECK(result.at(18) >= t && result.at(27) >= t && result.at(32) >= t);
+    CHECK(dm.scale(-1e30f) == 0 && dm.scale(1e30f) == 255);
+}
+
 // scan.rs:279-353 / lightmotif-py test_scanner.py:64-80
 static void test_scanner(const Pipeline<Dna> &pli)
 {
@@ -309,6 +331,7 @@ int main()
         test_stripe(pli, SEQUENCE, columns);
     }
     test_stripe_literals(pli);
+    test_score_discrete(pli);
     test_scanner(pli);
     test_batch(pli);
     test_encode(pli);

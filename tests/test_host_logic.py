@@ -63,3 +63,26 @@ def test_scoring_matrix_from_dict_and_reverse_complement():
 def test_stride_helper():
     for c in GOLD["G6_stride"]["cases"]:
         assert lib.stride(c["cols"], c["elem"]) == c["stride"]
+
+
+def test_to_discrete_equals_the_oracle_restatement():
+    """pwm/mod.rs:665-696, 777-785 (host side of `Score<u8, ..>`): weights, factor, offsets,
+    scale / unscale, for the golden PSSM, a pseudocount-0 PSSM (-inf weights) and protein."""
+    from oracle import np_oracle as no
+    g = GOLD["G1_scores"]
+    rng = np.random.default_rng(8)
+    prot_sites = ["".join(lib.PROTEIN_SYMBOLS[i] for i in rng.integers(0, 20, 9)) for _ in range(6)]
+    for pssm in (lm.create(g["patterns"]).counts.normalize(0.1).log_odds(),
+                 lm.create(g["patterns"]).pssm,
+                 lm.create(prot_sites, protein=True).counts.normalize(0.1).log_odds()):
+        dm = pssm.to_discrete()
+        w, factor, offsets, offset = no.to_discrete(pssm.data, pssm.k)
+        assert dm.data.shape == (len(pssm), lib.stride(pssm.k, 1))
+        assert np.array_equal(dm.data[:, :pssm.k], w) and not dm.data[:, pssm.k:].any()
+        assert np.float32(dm.factor) == factor and np.float32(dm.offset) == offset
+        assert np.array_equal(np.asarray(dm.offsets, np.float32), offsets)
+        for t in (-30.0, -10.0, 0.0, 3.5, pssm.max_score(), 1e9, float("-inf")):
+            assert dm.scale(t) == no.discrete_scale(t, factor, offset)
+        for q in (0, 1, 100, 255):
+            assert np.float32(dm.unscale(q)) == no.discrete_unscale(q, factor, offset)
+        assert dm.scale(pssm.max_score()) <= 255

@@ -102,6 +102,27 @@ def test_g5_scanner_restatement_yield_order_and_max():
     assert no.scanner_max(scores, 32, length, m, 0.0) is None
 
 
+def test_discrete_matrix_restatement_on_the_golden_pssm():
+    """pwm/mod.rs:665-696 + tests/dna.rs:93-120 (`test_score_discrete`): the u8 scores of the
+    golden PSSM's DiscreteMatrix, unscaled, are >= the 50 expected f32 scores; the Generic
+    (wrapping) and SIMD (saturating) bodies agree here; scale() under-estimates."""
+    g = GOLD["G1_scores"]
+    _, s, pssm = golden_setup(32)
+    weights, factor, offsets, offset = no.to_discrete(pssm, 5)
+    assert weights.shape == (pssm.shape[0], 5) and weights.max() <= 255
+    assert (weights[:, 4] == 0).all()                      # N scores -inf -> `as u8` = 0
+    u8, mi = co.score_rows_u8(s, weights)
+    assert mi == len(g["expected"])
+    rows = u8.shape[0]
+    for i, want in enumerate(g["expected"]):
+        assert no.discrete_unscale(int(u8[i % rows, i // rows]), factor, offset) >= want
+    sat = no.score_rows_u8_saturating(s.data, 32, len(g["sequence"]), weights, 0, s.rows)
+    assert np.array_equal(sat, u8[:, :32])
+    f32, _ = co.score_rows(s, pssm)
+    for t in (-10.0, -15.0, 0.0):                          # scan.rs:169-190: no false negatives
+        assert (u8[:, :32][f32[:, :32] >= np.float32(t)] >= no.discrete_scale(t, factor, offset)).all()
+
+
 def test_g6_stride_table():
     for c in GOLD["G6_stride"]["cases"]:
         assert co.stride(c["cols"], c["elem"]) == c["stride"]

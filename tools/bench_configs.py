@@ -173,9 +173,37 @@ def config_layout(pli):
             "note": "algorithmic traffic 2 B per symbol each; HBM-bound byte kernels"}
 
 
+def config_u8(pli):
+    """SURVEY 8a `score_u8_*` / 8(f) rank 2: `Score<u8, ..>` with a DiscreteMatrix plus the u8
+    reductions the Scanner runs on it (1 B read + 1 B written per cell; 1 B read per cell)."""
+    length, m = 1_000_000_000, 20
+    seq, rows = resident_sequence(pli, length, 5, m - 1, 11)
+    dm = motif(np.random.default_rng(2), m).to_discrete()
+    out = torch.empty((rows, COLS), dtype=torch.uint8, device=seq.device)
+
+    def score():
+        pli.score_u8_dptr(dm, seq.data_ptr(), rows + m - 1, COLS, COLS, m - 1, length, 0, rows,
+                          out.data_ptr(), COLS)
+
+    for _ in range(3):
+        score()
+    t_sc = timeit(score, 20)
+    kernel = pli.last_kernel
+    t_am = timeit(lambda: pli.argmax_u8_dptr(out.data_ptr(), rows, COLS, COLS), 10)
+    t = int(out[: 1 << 20].max()) - 2
+    t_th = timeit(lambda: pli.threshold_u8_dptr(out.data_ptr(), rows, COLS, COLS, t), 10)
+    nh = pli.threshold_u8_dptr(out.data_ptr(), rows, COLS, COLS, t).shape[0]
+    return {"config": "u8: DiscreteMatrix (M = 20) x 1 Gbp, Score<u8> materialised + Maximum<u8> + Threshold<u8>",
+            "kernel": kernel, "score_ms": round(t_sc * 1e3, 4), "score_Gpos_per_s": round(length / t_sc / 1e9, 1),
+            "score_GBps": round(2 * length / t_sc / 1e9, 1), "score_hbm_frac": round(2 * length / t_sc / 8e12, 3),
+            "argmax_ms": round(t_am * 1e3, 4), "argmax_GBps": round(length / t_am / 1e9, 1),
+            "threshold_ms": round(t_th * 1e3, 4), "threshold_hits": int(nh),
+            "note": "wall time per call incl. launch + synchronisation; algorithmic traffic 2 B / 1 B per cell"}
+
+
 if __name__ == "__main__":
     torch.cuda.set_device(0)
     pli = lm.Pipeline.hip(0, stream=torch.cuda.current_stream().cuda_stream)
-    which = sys.argv[1:] or ["c1", "c5", "layout", "c3"]
+    which = sys.argv[1:] or ["c1", "c5", "layout", "u8", "c3"]
     for name in which:
-        print(json.dumps({"c1": config1, "c3": config3, "c5": config5, "layout": config_layout}[name](pli)), flush=True)
+        print(json.dumps({"c1": config1, "c3": config3, "c5": config5, "layout": config_layout, "u8": config_u8}[name](pli)), flush=True)

@@ -11,7 +11,7 @@ git -C $ROOT archive $REV include lightmotif_amd/csrc | tar -x -C $W
 SRC=$W/lightmotif_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fno-fast-math -I$W/include -I$SRC"
 OBJS=""
-for u in score reduce hits layout api; do
+for u in score reduce hits discrete layout api; do
   hipcc $FLAGS -c $SRC/$u.hip -o $W/$u.o & OBJS="$OBJS $W/$u.o"
 done
 for i in 0 1 2 3 4 5 6 7 8; do
