@@ -139,21 +139,8 @@ static bool build_prefilter(lm_hip_pssm &p, std::vector<unsigned> *image, std::v
     // zero row; dword m = (lo E[2m+1], hi E[2m]).  Same weights, same sums, same bound.
     image2->clear();
     if (k == 5) {
-        const int mo = prefilter2_mo(m), shift2 = mo - m, np2 = prefilter2_npair(m);
-        const int dsd2 = prefilter2_stride_dw(m);
-        auto dq = [&](int j, int s) -> unsigned {  // padded discrete weight, 0 outside 0..mo-1
-            if (j < shift2 || j >= mo)
-                return 0u;
-            return d[(size_t)(j - shift2 + shift) * k + s];
-        };
         image2->assign((size_t)prefilter2_image_dw(m), 0u);
-        for (int a = 0; a < 5; ++a)
-            for (int b = 0; b < 5; ++b) {
-                unsigned *row = image2->data() + (size_t)dna_pair_row((unsigned)a, (unsigned)b) * dsd2;
-                auto entry = [&](int e) -> unsigned { return e > mo ? 0u : dq(e - 1, a) + dq(e, b); };
-                for (int w = 0; w < np2; ++w)
-                    row[w] = entry(2 * w + 1) | (entry(2 * w) << 16);
-            }
+        prefilter2_pack_image(d.data() + (size_t)shift * k, m, image2->data());
     }
     p.pre_offset = offset;
     p.pre_factor = factor;
@@ -287,6 +274,7 @@ int lm_hip_ctx_destroy(lm_hip_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     ctx->scratch.release();
     ctx->scratch2.release();
+    ctx->u8_tables.release();
     if (ctx->pinned)
         (void)hipHostFree(ctx->pinned);
     if (ctx->aux_stream) {

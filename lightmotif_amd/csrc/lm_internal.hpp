@@ -76,6 +76,10 @@ struct lm_hip_ctx {
     unsigned long long last_hit_count = 0;  // sizes the next fused-threshold hit list
     unsigned long long last_cand_count = 0; // ... and its candidate list
     const char *last_kernel = "";
+    // lm_hip_score_u8*: device tables of the DiscreteMatrix used last (a scanner scores the same
+    // matrix block after block); `u8_key` = {m, k, pairs} + the weights they were built from
+    lm::Scratch u8_tables;
+    std::vector<uint8_t> u8_key;
 };
 
 struct lm_hip_pssm {

@@ -93,10 +93,10 @@ ScoreC32Launcher score_c32_lookup_ql(int M)
     return (M >= 1 && M <= kMaxFastM) ? g_c32[M][7] : nullptr;
 }
 
-ScoreC32Launcher score_c32_lookup_u8(int M)
+ScoreC32Launcher score_c32_lookup_u8(int M, bool pairs)
 {
     std::call_once(g_c32_once, init_registry);
-    return (M >= 1 && M <= kMaxFastM) ? g_c32[M][kSlotU8] : nullptr;
+    return (M >= 1 && M <= kMaxFastM) ? g_c32[M][pairs ? kSlotU8Pairs : kSlotU8] : nullptr;
 }
 
 const char *score_c32_name(int M, int mode)
@@ -128,7 +128,7 @@ struct C32Plan {
 // `prefilter`: 0 = exact kernels, 1 = one-symbol prefilter (streams of q*MP + 1 rows),
 // 2 = pair-symbol prefilter (streams of q*RING + 2 rows)
 static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store, int prefilter = 0,
-                        size_t batch = 1)
+                        size_t batch = 1, unsigned long long default_rows = 0)
 {
     C32Plan p;
     const size_t K = a.pssm->k;
@@ -153,7 +153,9 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store, i
         return p;
     // The fused kernels write nothing, so they are LDS/VALU-bound and prefer long
     // streams (fewer fill steps): T=1001 0.69 ms vs T=61 0.79 ms on the same input.
-    unsigned long long target = ctx->rows_per_stream ? ctx->rows_per_stream : (store ? 64 : 1024);
+    unsigned long long target = ctx->rows_per_stream ? ctx->rows_per_stream
+                                : default_rows         ? default_rows
+                                                       : (store ? 64 : 1024);
     // keep at least ~4 streams per SIMD lane-half in flight on small inputs
     // Enough workgroups for several rounds of the chip's resident capacity (6 x 256 CUs
     // of 8-stream workgroups), so the last partial round costs little; the fused
@@ -255,38 +257,61 @@ int launch_score_u8(lm_hip_ctx *ctx, const DiscreteArgs &a)
 {
     const int m = (int)a.m, k = (int)a.k;
     const unsigned wrap_mask = a.saturate ? 0u : 0xffu;
-    // plan with the f32 planner: same stream geometry as the packed prefilter scan
+    // plan with the f32 planner: same stream geometry as the packed prefilter scans.  DNA takes
+    // the pair-symbol scan (two rows per lookup) when the matrix allows dword symbol loads.
     lm_hip_pssm shape;
     shape.m = a.m;
     shape.k = a.k;
+    shape.d_image2 = reinterpret_cast<unsigned *>(sizeof(unsigned));  // "has a pair table" for the planner; never read
     ScoreArgs sa{&shape, a.d_seq, a.seq_stride, a.cols, a.row_begin, a.row_end, nullptr, a.out_stride};
-    const C32Plan p = plan_c32(ctx, sa, true, 1);
-    ScoreC32Launcher fn = p.ok ? score_c32_lookup_u8(m) : nullptr;
-    // device copies (scratch2): [packed image | dense table], staged through the pinned buffer
-    const size_t image_bytes = fn ? (size_t)prefilter_image_dw(m, k) * 4 : 0;
+    // (both fast kernels write dwords: the score matrix must be 4-byte aligned)
+    const bool out_aligned = reinterpret_cast<uintptr_t>(a.d_out) % 4 == 0;
+    // streams of ~128 rows: 1 B + 1 B per cell leaves the kernel between the f32 store kernel
+    // (HBM-bound, short streams) and the scans (issue-bound, long streams); measured at 1 Gbp
+    // x M = 20: T = 64 0.449 ms, 128 0.426, 256 0.434, 1024 0.456, 4096 0.486
+    C32Plan p = (out_aligned && ctx->pair_prefilter) ? plan_c32(ctx, sa, true, 2, 1, 128) : C32Plan();
+    const bool pairs = p.ok;
+    if (!pairs && out_aligned)
+        p = plan_c32(ctx, sa, true, 1, 1, 128);
+    ScoreC32Launcher fn = p.ok ? score_c32_lookup_u8(m, pairs) : nullptr;
+    // device copies (scratch2): [packed image | dense table]
+    const size_t image_bytes = !fn ? 0 : pairs ? (size_t)prefilter2_image_dw(m) * 4 : (size_t)prefilter_image_dw(m, k) * 4;
     const size_t dense_bytes = ((size_t)m * k + 15) / 16 * 16;
-    LM_TRY(ctx->scratch2.reserve(image_bytes + dense_bytes));
-    // (the call returns without synchronising, so the tables are staged in pageable memory: the
-    // runtime copies that out before hipMemcpyAsync returns; the shared pinned buffer could be
-    // overwritten by the next call while this copy is still queued)
-    std::vector<char> stage_buf(image_bytes + dense_bytes, 0);
-    char *stage = stage_buf.data();
-    if (fn) {
-        const int mp = prefilter_mp(m), shift = mp - m;
-        std::vector<unsigned> d((size_t)mp * k, 0u);
-        for (int j = 0; j < m; ++j)
-            for (int s = 0; s < k; ++s)
-                d[(size_t)(j + shift) * k + s] = a.weights[(size_t)j * a.wstride + s];
-        prefilter_pack_image(d.data(), m, k, reinterpret_cast<unsigned *>(stage));
-    }
+    // The tables live in a buffer of their own and are rebuilt only when the matrix changes.
+    // (The call returns without synchronising, so they are staged in pageable memory: the
+    // runtime copies that out before hipMemcpyAsync returns, whereas the shared pinned buffer
+    // could be overwritten by the next call while the copy is still queued.)
+    std::vector<uint8_t> key{(uint8_t)(m & 0xff), (uint8_t)((m >> 8) & 0xff), (uint8_t)((m >> 16) & 0xff),
+                             (uint8_t)k, (uint8_t)(fn ? (pairs ? 2 : 1) : 0)};
     for (int j = 0; j < m; ++j)
-        memcpy(stage + image_bytes + (size_t)j * k, a.weights + (size_t)j * a.wstride, (size_t)k);
-    char *dev = static_cast<char *>(ctx->scratch2.ptr);
-    LM_HIP_TRY(hipMemcpyAsync(dev, stage, image_bytes + dense_bytes, hipMemcpyHostToDevice, ctx->stream));
+        key.insert(key.end(), a.weights + (size_t)j * a.wstride, a.weights + (size_t)j * a.wstride + k);
+    if (key != ctx->u8_key || ctx->u8_tables.bytes < image_bytes + dense_bytes) {
+        LM_TRY(ctx->u8_tables.reserve(std::max<size_t>(image_bytes + dense_bytes, 64 * 1024)));
+        std::vector<char> stage_buf(image_bytes + dense_bytes, 0);
+        char *stage = stage_buf.data();
+        if (fn) {
+            const int mp = prefilter_mp(m), shift = pairs ? 0 : mp - m;
+            std::vector<unsigned> d((size_t)(m + shift) * k, 0u);
+            for (int j = 0; j < m; ++j)
+                for (int s = 0; s < k; ++s)
+                    d[(size_t)(j + shift) * k + s] = a.weights[(size_t)j * a.wstride + s];
+            if (pairs)
+                prefilter2_pack_image(d.data(), m, reinterpret_cast<unsigned *>(stage));
+            else
+                prefilter_pack_image(d.data(), m, k, reinterpret_cast<unsigned *>(stage));
+        }
+        for (int j = 0; j < m; ++j)
+            memcpy(stage + image_bytes + (size_t)j * k, a.weights + (size_t)j * a.wstride, (size_t)k);
+        ctx->u8_key.clear();  // stays empty if the copy fails
+        LM_HIP_TRY(hipMemcpyAsync(ctx->u8_tables.ptr, stage, image_bytes + dense_bytes, hipMemcpyHostToDevice,
+                                  ctx->stream));
+        ctx->u8_key = std::move(key);
+    }
+    char *dev = static_cast<char *>(ctx->u8_tables.ptr);
     if (fn) {
         FusedOut fo{};
         fo.key_rows = wrap_mask;
-        ctx->last_kernel = "score_c32_u8";
+        ctx->last_kernel = pairs ? "score_c32_u8_pairs" : "score_c32_u8";
         LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, reinterpret_cast<const float *>(dev), k, a.row_begin,
                       a.row_end, p.T, p.nstreams, reinterpret_cast<float *>(a.d_out), fo));
         return LM_HIP_OK;

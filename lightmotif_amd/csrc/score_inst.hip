@@ -1,7 +1,6 @@
 // score_inst.hip -- instantiates score_c32<M, MODE> for M in [LM_M_LO, LM_M_HI].
 // Compiled several times with different -DLM_M_LO/-DLM_M_HI/-DLM_INST_ID so the
 // fully unrolled kernels build in parallel (see build.py).
-#include "score_prefilter2.hpp"
 #include "score_u8.hpp"
 
 #ifndef LM_M_LO
@@ -29,6 +28,8 @@ struct RegisterRange {
             tab[M][7] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 0, 1>;
         tab[M][8] = &score_c32_launch<M, MODE_STORE_ARGMAX, LM_SCORE_XCD_REMAP, 0, 1>;
         tab[M][kSlotU8] = &score_c32_u8_launch<M>;  // DiscreteMatrix scores (score_u8.hpp)
+        if constexpr (M >= 2)
+            tab[M][kSlotU8Pairs] = &score_c32_u8_pairs_launch<M>;
 #if defined(LM_SCORE_BUILD_WIDE)
         // 8-byte-read variant for K > 16; not built by default, see api.hip (pssm_create)
         tab[M][4 + MODE_STORE] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1>;

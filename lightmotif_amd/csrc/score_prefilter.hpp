@@ -82,6 +82,12 @@ __device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b)
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(x, y));
 }
 
+__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b)
+{
+    const u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(x, y));
+}
+
 // `mx` collects (packed max) every register that holds a just-completed sum.  Its other half
 // is the partial sum of an output still in flight; weights are >= 0, so a partial sum that
 // reaches td belongs to an output that will reach it too -- taking it into the maximum can
@@ -101,6 +107,14 @@ __device__ __forceinline__ void prefilter_group(unsigned (&acc2)[prefilter_mp(M)
                                                 unsigned &mx, uint8_t *__restrict__ op = nullptr,
                                                 const unsigned wrap_mask = 0)
 {
+    // STORE: quad-transposed stores (see below).  Lane q = lane & 3 of a quad writes row k0 + q of
+    // the quad's columns: `oq` = that dword for k0 = 0; the byte selectors pick byte q of two
+    // neighbours' packs into bytes (0, 1) resp. (2, 3) of the result, 0x0c = constant zero.
+    const unsigned q = STORE ? (threadIdx.x & 3u) : 0u;
+    uint8_t *oq = STORE ? op - q + q * 32 : nullptr;
+    const unsigned sel_lo = 0x0c0c0000u | q | ((4u + q) << 8);
+    const unsigned sel_hi = 0x00000c0cu | (q << 16) | ((4u + q) << 24);
+    unsigned pack = 0;
     constexpr int MP = prefilter_mp(M);
     constexpr int NP = MP / 2;
     constexpr int NV = (NP + 3) / 4;
@@ -144,7 +158,24 @@ __device__ __forceinline__ void prefilter_group(unsigned (&acc2)[prefilter_mp(M)
             if (PHASE != PHASE_FIRST || k == MP - 1) {
                 const unsigned sum = (sc & 1) ? (acc2[sc / 2] >> 16) : (acc2[sc / 2] & 0xffffu);
                 const unsigned v = wrap_mask ? (sum & wrap_mask) : (sum < 255u ? sum : 255u);
-                op[(PHASE == PHASE_FIRST ? 0 : k) * 32] = (uint8_t)v;
+                constexpr int KQ = MP / 4 * 4;  // steps covered by whole 4-row blocks
+                if (PHASE == PHASE_FIRST || k >= KQ) {
+                    op[(PHASE == PHASE_FIRST ? 0 : k) * 32] = (uint8_t)v;
+                } else {
+                    // Four completed rows are packed per lane (byte t = row k0 + t of the lane's
+                    // column) and transposed inside each quad of lanes: lane q ends up with row
+                    // k0 + q of the quad's four columns = ONE dword store, and a half-wave
+                    // instruction covers 4 rows x 32 columns = 128 contiguous bytes instead of 32.
+                    pack = (k % 4 == 0) ? v : pack | (v << (8 * (k % 4)));
+                    if (k % 4 == 3) {
+                        const unsigned p0 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0x00, 0xf, 0xf, true);
+                        const unsigned p1 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0x55, 0xf, 0xf, true);
+                        const unsigned p2 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0xaa, 0xf, 0xf, true);
+                        const unsigned p3 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0xff, 0xf, 0xf, true);
+                        const unsigned row = __builtin_amdgcn_perm(p1, p0, sel_lo) | __builtin_amdgcn_perm(p3, p2, sel_hi);
+                        *reinterpret_cast<unsigned *>(oq + (k - 3) * 32) = row;
+                    }
+                }
             }
         } else if (PHASE != PHASE_FIRST || k == MP - 1) {
             mx = pk_max_u16(mx, acc2[sc / 2]);

@@ -48,6 +48,25 @@ __host__ __device__ __forceinline__ unsigned dna_pair_row(unsigned a, unsigned b
     return idx;
 }
 
+// Host side: the pair table from the unpadded discrete weights d[j * 5 + s], j < m.
+inline void prefilter2_pack_image(const unsigned *d, int m, unsigned *image2)
+{
+    const int mo = prefilter2_mo(m), shift2 = mo - m, np2 = prefilter2_npair(m);
+    const int dsd2 = prefilter2_stride_dw(m);
+    auto dq = [&](int j, int s) -> unsigned {  // padded weight, 0 outside shift2 .. mo-1
+        return (j < shift2 || j >= mo) ? 0u : d[(size_t)(j - shift2) * 5 + s];
+    };
+    for (int i = 0; i < prefilter2_image_dw(m); ++i)
+        image2[i] = 0u;
+    for (int a = 0; a < 5; ++a)
+        for (int b = 0; b < 5; ++b) {
+            unsigned *row = image2 + (size_t)dna_pair_row((unsigned)a, (unsigned)b) * dsd2;
+            auto entry = [&](int e) -> unsigned { return e > mo ? 0u : dq(e - 1, a) + dq(e, b); };
+            for (int w = 0; w < np2; ++w)
+                row[w] = entry(2 * w + 1) | (entry(2 * w) << 16);
+        }
+}
+
 // Symbol loads.  A byte load per lane and row moves 64 bytes per wavefront instruction, and
 // at > 3 Tpos/s the scan is bound by that request rate, not by LDS or VALU.  So the lanes
 // of a quad (columns 4i..4i+3) fetch a 4 x 4 block of symbols with ONE dword load each --
@@ -56,12 +75,25 @@ __host__ __device__ __forceinline__ unsigned dna_pair_row(unsigned a, unsigned b
 // symbol(row r+t, own column) = byte (lane & 3) of the dword held by quad lane t (one DPP
 // quad broadcast + one bit-field extract).  RING is a multiple of 4, so blocks never
 // straddle a group; `blk` is a ring of the RING/4 blocks of a group, prefetched PFB ahead.
-template <int M, int PFB, int PHASE>
+//
+// STORE = 1 (score_u8.hpp): the sums are a DiscreteMatrix's u8 scores.  A super-step completes
+// two rows of the lane's column; two super-steps make a 4-row block that is transposed inside
+// the quad of lanes and written with one dword store per lane (128 contiguous bytes per
+// half-wave instruction).  `op` = the lane's cell of the group's first completed row; the
+// FIRST group completes rows 0 and 1 only (byte stores).  `wrap_mask` as in prefilter_group.
+template <int M, int PFB, int PHASE, int STORE = 0>
 __device__ __forceinline__ void prefilter2_group(unsigned (&acc)[prefilter2_npair(M)],
                                                  unsigned (&blk)[prefilter2_ring(M) / 4],
                                                  const uint8_t *__restrict__ spq, const unsigned shq,
-                                                 const char *__restrict__ tab, unsigned &mx)
+                                                 const char *__restrict__ tab, unsigned &mx,
+                                                 uint8_t *__restrict__ op = nullptr,
+                                                 const unsigned wrap_mask = 0)
 {
+    const unsigned q = STORE ? (threadIdx.x & 3u) : 0u;
+    uint8_t *oq = STORE ? op - q + q * 32 : nullptr;  // lane q of a quad writes row +q, the quad's 4 columns
+    const unsigned sel_lo = 0x0c0c0000u | q | ((4u + q) << 8);
+    const unsigned sel_hi = 0x00000c0cu | (q << 16) | ((4u + q) << 24);
+    unsigned pack = 0;
     constexpr int RING = prefilter2_ring(M);
     constexpr int NB = RING / 4;
     constexpr int NP = prefilter2_npair(M);
@@ -99,8 +131,28 @@ __device__ __forceinline__ void prefilter2_group(unsigned (&acc)[prefilter2_npai
             acc[(k - m + NP) % NP] = pk_add_u16(acc[(k - m + NP) % NP], w[m]);
         // dword (k+1) mod NP received its last entry: both of its outputs are complete
         const int c = (k + 1) % NP;
-        if (PHASE != PHASE_FIRST || k == NP - 1)
+        if (STORE) {
+            if (PHASE != PHASE_FIRST || k == NP - 1) {
+                // (lo, hi) = (even row, odd row): clamp or mask both halves at once
+                const unsigned r = wrap_mask ? (acc[c] & 0x00ff00ffu) : pk_min_u16(acc[c], 0x00ff00ffu);
+                if (PHASE == PHASE_FIRST) {
+                    op[0] = (uint8_t)(r & 0xffu);
+                    op[32] = (uint8_t)(r >> 16);
+                } else if ((k & 1) == 0) {
+                    pack = __builtin_amdgcn_perm(r, r, 0x0c0c0200u);            // bytes 0, 1 = rows 2k, 2k+1
+                } else {
+                    pack |= __builtin_amdgcn_perm(r, r, 0x02000c0cu);           // bytes 2, 3
+                    const unsigned p0 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0x00, 0xf, 0xf, true);
+                    const unsigned p1 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0x55, 0xf, 0xf, true);
+                    const unsigned p2 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0xaa, 0xf, 0xf, true);
+                    const unsigned p3 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0xff, 0xf, 0xf, true);
+                    const unsigned row = __builtin_amdgcn_perm(p1, p0, sel_lo) | __builtin_amdgcn_perm(p3, p2, sel_hi);
+                    *reinterpret_cast<unsigned *>(oq + 2 * (k - 1) * 32) = row;
+                }
+            }
+        } else if (PHASE != PHASE_FIRST || k == NP - 1) {
             mx = pk_max_u16(mx, acc[c]);
+        }
         acc[c] = 0;
     }
 }

@@ -12,7 +12,7 @@
 // Traffic: 1 B read + 1 B written per cell (SURVEY 8a "32 B in, 32 B out per row").
 #pragma once
 
-#include "score_prefilter.hpp"
+#include "score_prefilter2.hpp"
 
 namespace lm {
 
@@ -85,6 +85,89 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_u8(
     prefilter_group<M, PFE, PHASE_LAST, 1>(acc2, sym, sp, tab_even, tab_odd, mx, op, wrap_mask);
 }
 
+// DNA, M >= 2: the same sums from the pair-symbol scan of score_prefilter2.hpp (two input rows
+// per LDS lookup, dword symbol loads).  `image` = pair table of the u8 weights
+// (prefilter2_pack_image); the sequence matrix must be 4-byte aligned.
+template <int M>
+__global__ __launch_bounds__(kBlock, 6) void score_c32_u8_pairs(
+    const uint8_t *__restrict__ seq, const unsigned *__restrict__ image,
+    const unsigned long long row_begin, const unsigned long long row_end,
+    const unsigned long long T, const unsigned long long nstreams, uint8_t *__restrict__ out,
+    const unsigned wrap_mask)
+{
+    constexpr int MO = prefilter2_mo(M);
+    constexpr int SHIFT = MO - M;
+    constexpr int RING = prefilter2_ring(M);
+    constexpr int NP = prefilter2_npair(M);
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    {
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
+        const uint4 *src = reinterpret_cast<const uint4 *>(image);
+        constexpr int n4 = prefilter2_image_dw(M) / 4;
+        for (int i = threadIdx.x; i < n4; i += kBlock)
+            dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 31;
+    unsigned long long stream =
+        ((unsigned long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    if (stream >= nstreams)  // idle half-waves redo the last stream (same bytes, same values)
+        stream = nstreams - 1;
+    unsigned long long o0 = row_begin + stream * T;
+    if (o0 + T > row_end)
+        o0 = row_end - T;
+
+    const long long in0 = (long long)o0 - SHIFT;  // first input row of the stream (padding rows: weight 0)
+    const unsigned shq = 8u * (col & 3);
+    const uint8_t *spq = seq + (in0 + (col & 3)) * 32 + (col >> 2) * 4;  // this lane's row of a block
+    constexpr int NB = RING / 4;
+    constexpr int PFB = NB > 3 ? 3 : NB;
+    unsigned acc[NP];
+    unsigned blk[NB];
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+        acc[i] = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+        blk[j] = 0;
+    if (in0 + (long long)(col & 3) >= 0)
+        blk[0] = *reinterpret_cast<const unsigned *>(spq);
+#pragma unroll
+    for (int j = 1; j < PFB; ++j)
+        blk[j] = *reinterpret_cast<const unsigned *>(spq + j * 128);
+
+    // group 0 completes rows 0 and 1, group g >= 1 rows (g-1)*RING + 2 .. g*RING + 1
+    const unsigned long long ngroups = (T - 2) / RING + 1;  // exact: T = q*RING + 2
+    uint8_t *op = out + (o0 - row_begin) * 32 + col;
+    unsigned mx = 0;
+    prefilter2_group<M, PFB, PHASE_FIRST, 1>(acc, blk, spq, shq, lds_raw, mx, op, wrap_mask);
+    op += 2 * 32;
+    for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
+        spq += RING * 32;
+        prefilter2_group<M, PFB, PHASE_MAIN, 1>(acc, blk, spq, shq, lds_raw, mx, op, wrap_mask);
+        op += RING * 32;
+    }
+    if (ngroups > 1) {
+        spq += RING * 32;
+        prefilter2_group<M, PFB, PHASE_LAST, 1>(acc, blk, spq, shq, lds_raw, mx, op, wrap_mask);
+    }
+}
+
+template <int M>
+hipError_t score_c32_u8_pairs_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, const uint8_t *seq,
+                                     const float *table, int K, unsigned long long row_begin,
+                                     unsigned long long row_end, unsigned long long T,
+                                     unsigned long long nstreams, float *out, FusedOut fo)
+{
+    (void)K;
+    hipLaunchKernelGGL((score_c32_u8_pairs<M>), grid, dim3(kBlock), lds_bytes, stream, seq,
+                       reinterpret_cast<const unsigned *>(table), row_begin, row_end, T, nstreams,
+                       reinterpret_cast<uint8_t *>(out), (unsigned)fo.key_rows);
+    return hipGetLastError();
+}
+
 // Registry shim with the ScoreC32Launcher signature (slot kSlotU8 of the registry): `table`
 // carries the packed u16 image, `out` the u8 score matrix, `fo.key_rows` the wrap mask.
 template <int M>
@@ -99,6 +182,6 @@ hipError_t score_c32_u8_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, 
     return hipGetLastError();
 }
 
-constexpr int kSlotU8 = 9;
+constexpr int kSlotU8 = 9, kSlotU8Pairs = 10;
 
 }  // namespace lm

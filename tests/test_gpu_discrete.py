@@ -81,9 +81,9 @@ def test_u8_scores_reductions_and_row_ranges(pli, length, m, protein, top, cols)
             if 0 <= a <= b <= rows and got.shape[0]:
                 part, _ = pli.score_discrete(dm, seq, rows=range(a, b), saturate=saturate)
                 assert np.array_equal(part[:, :cols], want[a:b, :cols])
-    if cols == 32 and 1 <= m <= 36 and rows >= m + 3:
-        assert pli.last_kernel == "score_c32_u8"
-    else:
+    if cols == 32 and 1 <= m <= 36 and rows >= (m | 3) + 3:
+        assert pli.last_kernel == ("score_c32_u8_pairs" if not protein and m >= 2 else "score_c32_u8")
+    elif cols != 32 or m > 36:
         assert pli.last_kernel == "score_generic_u8"
     if want_sat.shape[0] == 0:
         return
@@ -103,6 +103,44 @@ def test_u8_scores_reductions_and_row_ranges(pli, length, m, protein, top, cols)
     t = int(want_sat.max())
     assert np.array_equal(pli.threshold_u8_dptr(padded.data_ptr(), dev.shape[0], cols + 5, cols, t),
                           np.argwhere(want_sat[:, :cols] >= t))
+
+
+@pytest.mark.parametrize("m", [2, 3, 4, 9, 20, 23, 36])
+def test_one_symbol_scan_and_unaligned_buffers(monkeypatch, m):
+    """The DNA pair-symbol scan can be switched off (LM_HIP_PAIR_PREFILTER=0 -> one symbol per
+    lookup) and needs 4-byte aligned matrices; every route gives the same bytes."""
+    monkeypatch.setenv("LM_HIP_PAIR_PREFILTER", "0")
+    single = lm.Pipeline.hip(0)
+    monkeypatch.delenv("LM_HIP_PAIR_PREFILTER")
+    paired = lm.Pipeline.hip(0)
+    rng = np.random.default_rng(m)
+    length = 70_001
+    rows = -(-length // 32)
+    enc = rng.integers(0, 5, length, dtype=np.uint8)
+    weights = rng.integers(0, 256, (m, 5), dtype=np.uint8)
+    dm = lm.DiscreteMatrix(weights, 1.0, np.zeros(m, np.float32), 0.0)
+    ref = co.stripe(enc, 32, 5)
+    co.configure_wrap(ref, m)
+    want = no.score_rows_u8_saturating(ref.data, 32, length, weights, 0, rows)
+    base = torch.zeros((rows + m - 1) * 32 + 64, dtype=torch.uint8, device="cuda")
+    outb = torch.zeros(rows * 32 + 64, dtype=torch.uint8, device="cuda")
+    host = torch.from_numpy(np.ascontiguousarray(ref.data[: rows + m - 1, :32]).reshape(-1))
+    for pli, name in ((paired, "score_c32_u8_pairs"), (single, "score_c32_u8")):
+        for so, oo in ((0, 0), (1, 0), (0, 2), (3, 1)):
+            base[so: so + host.numel()] = host.cuda()
+            outb.zero_()
+            torch.cuda.synchronize()
+            pli.score_u8_dptr(dm, base.data_ptr() + so, rows + m - 1, 32, 32, m - 1, length, 0, rows,
+                              outb.data_ptr() + oo, 32)
+            torch.cuda.synchronize()
+            got = outb[oo: oo + rows * 32].cpu().numpy().reshape(rows, 32)
+            assert np.array_equal(got, want), (name, so, oo, pli.last_kernel)
+            if oo % 4:
+                assert pli.last_kernel == "score_generic_u8"
+            elif so % 4 == 0:
+                assert pli.last_kernel == name
+            else:
+                assert pli.last_kernel == "score_c32_u8"   # byte symbol loads need no alignment
 
 
 def test_scanner_prefilter_property_on_discrete_scores(pli):
@@ -160,7 +198,7 @@ def test_full_size_u8_scores(pli):
     assert pli.score_u8_dptr(dm, seq.data_ptr(), rows + m - 1, 32, 32, m - 1, length, 0, rows,
                              out.data_ptr(), 32) == (rows, length + 1 - m)
     torch.cuda.synchronize()
-    assert pli.last_kernel == "score_c32_u8"
+    assert pli.last_kernel == "score_c32_u8_pairs"
     for a in (0, rows // 2 - 333, rows - 2048):
         win = seq[a: a + 2048 + m - 1].cpu().numpy()
         want = no.score_rows_u8_saturating(win, 32, 1 << 40, dm.data[:, :5], 0, 2048)

@@ -189,16 +189,24 @@ def config_u8(pli):
         score()
     t_sc = timeit(score, 20)
     kernel = pli.last_kernel
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for a, b in ev:  # the pipeline runs on torch's current stream here
+        a.record()
+        score()
+        b.record()
+    torch.cuda.synchronize()
+    t_ev = float(np.median([a.elapsed_time(b) for a, b in ev])) * 1e-3
     t_am = timeit(lambda: pli.argmax_u8_dptr(out.data_ptr(), rows, COLS, COLS), 10)
     t = int(out[: 1 << 20].max()) - 2
     t_th = timeit(lambda: pli.threshold_u8_dptr(out.data_ptr(), rows, COLS, COLS, t), 10)
     nh = pli.threshold_u8_dptr(out.data_ptr(), rows, COLS, COLS, t).shape[0]
     return {"config": "u8: DiscreteMatrix (M = 20) x 1 Gbp, Score<u8> materialised + Maximum<u8> + Threshold<u8>",
-            "kernel": kernel, "score_ms": round(t_sc * 1e3, 4), "score_Gpos_per_s": round(length / t_sc / 1e9, 1),
-            "score_GBps": round(2 * length / t_sc / 1e9, 1), "score_hbm_frac": round(2 * length / t_sc / 8e12, 3),
+            "kernel": kernel, "score_call_ms": round(t_sc * 1e3, 4), "score_kernel_ms": round(t_ev * 1e3, 4),
+            "score_Gpos_per_s": round(length / t_ev / 1e9, 1),
+            "score_GBps": round(2 * length / t_ev / 1e9, 1), "score_hbm_frac": round(2 * length / t_ev / 8e12, 3),
             "argmax_ms": round(t_am * 1e3, 4), "argmax_GBps": round(length / t_am / 1e9, 1),
             "threshold_ms": round(t_th * 1e3, 4), "threshold_hits": int(nh),
-            "note": "wall time per call incl. launch + synchronisation; algorithmic traffic 2 B / 1 B per cell"}
+            "note": "score_kernel_ms from HIP events on the launch stream, the other times are wall time per call incl. launch + synchronisation; algorithmic traffic 2 B / 1 B per cell"}
 
 
 if __name__ == "__main__":
