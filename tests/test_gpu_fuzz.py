@@ -5,6 +5,7 @@ import pytest
 
 import lightmotif_amd as lm
 from oracle import c_oracle as co
+from oracle import np_oracle as no
 
 pytestmark = pytest.mark.gpu
 
@@ -60,6 +61,17 @@ def test_random_configuration(pli, seed):
         assert np.array_equal(bits(got[:, :cols]), bits(want[:, :cols])), pli.last_kernel
         assert pli.argmax(scores) == co.argmax(want, cols)
         fused = pli.score_argmax(pssm, seq, range(a, b))
+        # Score<u8, ..> with random discrete weights on the same geometry: both overflow flavours
+        top = min(int(rng.choice([3, 255 // m + 1, 255])), 255)
+        dm = lm.DiscreteMatrix(rng.integers(0, top + 1, (m, k), dtype=np.uint8), 1.0, np.zeros(m, np.float32), 0.0,
+                               protein=protein)
+        want_wrap, wmi = co.score_rows_u8(ref, dm.data, a, b)
+        got_wrap, gmi = pli.score_discrete(dm, seq, rows=range(a, b), saturate=False)
+        assert gmi == wmi and np.array_equal(got_wrap[:, :cols], want_wrap[:, :cols]), pli.last_kernel
+        if want_wrap.shape[0]:
+            want_sat = no.score_rows_u8_saturating(ref.data, cols, length, dm.data, a, b)
+            got_sat, _ = pli.score_discrete(dm, seq, rows=range(a, b), saturate=True)
+            assert np.array_equal(got_sat[:, :cols], want_sat), pli.last_kernel
         if want.shape[0] == 0:
             assert fused is None
             return
