@@ -16,42 +16,36 @@ namespace lm {
 
 // ---- registry of the unrolled C=32 kernels ---------------------------------------
 
-void register_score_c32_0(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre,
-                          PrefilterLauncher *pre2);
-void register_score_c32_1(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre,
-                          PrefilterLauncher *pre2);
-void register_score_c32_2(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre,
-                          PrefilterLauncher *pre2);
-void register_score_c32_3(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre,
-                          PrefilterLauncher *pre2);
-void register_score_c32_4(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre,
-                          PrefilterLauncher *pre2);
-void register_score_c32_5(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre,
-                          PrefilterLauncher *pre2);
-void register_score_c32_6(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre,
-                          PrefilterLauncher *pre2);
-void register_score_c32_7(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre,
-                          PrefilterLauncher *pre2);
-void register_score_c32_8(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre,
-                          PrefilterLauncher *pre2);
+void register_score_c32_0(const KernelRegistry &r);
+void register_score_c32_1(const KernelRegistry &r);
+void register_score_c32_2(const KernelRegistry &r);
+void register_score_c32_3(const KernelRegistry &r);
+void register_score_c32_4(const KernelRegistry &r);
+void register_score_c32_5(const KernelRegistry &r);
+void register_score_c32_6(const KernelRegistry &r);
+void register_score_c32_7(const KernelRegistry &r);
+void register_score_c32_8(const KernelRegistry &r);
 
 static ScoreC32Launcher g_c32[kMaxFastM + 1][kRegistrySlots];
 static PrefilterLauncher g_pre[kMaxFastM + 1];
 static PrefilterLauncher g_pre2[kMaxFastM + 1];
+static ScoreU8Launcher g_u8[kMaxFastM + 1];
+static ScoreU8Launcher g_u8_pairs[kMaxFastM + 1];
 static char g_c32_names[kMaxFastM + 1][3][32];
 static std::once_flag g_c32_once;
 
 static void init_registry()
 {
-    register_score_c32_0(g_c32, g_pre, g_pre2);
-    register_score_c32_1(g_c32, g_pre, g_pre2);
-    register_score_c32_2(g_c32, g_pre, g_pre2);
-    register_score_c32_3(g_c32, g_pre, g_pre2);
-    register_score_c32_4(g_c32, g_pre, g_pre2);
-    register_score_c32_5(g_c32, g_pre, g_pre2);
-    register_score_c32_6(g_c32, g_pre, g_pre2);
-    register_score_c32_7(g_c32, g_pre, g_pre2);
-    register_score_c32_8(g_c32, g_pre, g_pre2);
+    const KernelRegistry r{g_c32, g_pre, g_pre2, g_u8, g_u8_pairs};
+    register_score_c32_0(r);
+    register_score_c32_1(r);
+    register_score_c32_2(r);
+    register_score_c32_3(r);
+    register_score_c32_4(r);
+    register_score_c32_5(r);
+    register_score_c32_6(r);
+    register_score_c32_7(r);
+    register_score_c32_8(r);
     for (int m = 0; m <= kMaxFastM; ++m)
         for (int mode = 0; mode < 3; ++mode)
             snprintf(g_c32_names[m][mode], sizeof g_c32_names[m][mode], "score_c32<%d,%d>", m, mode);
@@ -93,10 +87,10 @@ ScoreC32Launcher score_c32_lookup_ql(int M)
     return (M >= 1 && M <= kMaxFastM) ? g_c32[M][7] : nullptr;
 }
 
-ScoreC32Launcher score_c32_lookup_u8(int M, bool pairs)
+ScoreU8Launcher score_c32_lookup_u8(int M, bool pairs)
 {
     std::call_once(g_c32_once, init_registry);
-    return (M >= 1 && M <= kMaxFastM) ? g_c32[M][pairs ? kSlotU8Pairs : kSlotU8] : nullptr;
+    return (M >= 1 && M <= kMaxFastM) ? (pairs ? g_u8_pairs[M] : g_u8[M]) : nullptr;
 }
 
 const char *score_c32_name(int M, int mode)
@@ -127,28 +121,44 @@ struct C32Plan {
 // robust choice.
 // `prefilter`: 0 = exact kernels, 1 = one-symbol prefilter (streams of q*MP + 1 rows),
 // 2 = pair-symbol prefilter (streams of q*RING + 2 rows)
+// what the planner needs to know about the matrix (a.pssm may be absent: u8 scores)
+struct MotifShape {
+    size_t m, k;
+    bool wide, pair_table;
+};
+
+static C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const ScoreArgs &a, bool store,
+                        int prefilter = 0, size_t batch = 1, unsigned long long default_rows = 0);
+
 static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store, int prefilter = 0,
-                        size_t batch = 1, unsigned long long default_rows = 0)
+                        size_t batch = 1)
+{
+    const MotifShape ms{a.pssm->m, a.pssm->k, a.pssm->wide, a.pssm->d_image2 != nullptr};
+    return plan_c32(ctx, ms, a, store, prefilter, batch);
+}
+
+static C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const ScoreArgs &a, bool store,
+                        int prefilter, size_t batch, unsigned long long default_rows)
 {
     C32Plan p;
-    const size_t K = a.pssm->k;
+    const size_t K = ms.k;
     // rows per unrolled group: the motif length, padded for the prefilter kernels
-    const size_t M = prefilter == 2   ? (size_t)prefilter2_ring((int)a.pssm->m)
-                     : prefilter == 1 ? (size_t)prefilter_mp((int)a.pssm->m)
-                                      : a.pssm->m;
+    const size_t M = prefilter == 2   ? (size_t)prefilter2_ring((int)ms.m)
+                     : prefilter == 1 ? (size_t)prefilter_mp((int)ms.m)
+                                      : ms.m;
     const size_t extra = prefilter == 2 ? 2 : 1;  // rows of a stream beyond q groups
     const unsigned long long n = a.row_end - a.row_begin;
     if (a.cols != 32 || a.seq_stride != 32 || (store && a.out_stride != 32))
         return p;
-    if (a.pssm->m < 1 || a.pssm->m > (size_t)kMaxFastM || n < M + extra)
+    if (ms.m < 1 || ms.m > (size_t)kMaxFastM || n < M + extra)
         return p;
     // (the pair-symbol kernel fetches symbols with dword loads: 4-byte aligned matrix)
-    if (prefilter == 2 && (K != 5 || !a.pssm->d_image2 || a.pssm->m < 2 ||
+    if (prefilter == 2 && (K != 5 || !ms.pair_table || ms.m < 2 ||
                            reinterpret_cast<uintptr_t>(a.d_seq) % 4 != 0))
         return p;
-    const size_t lds = prefilter == 2   ? (size_t)prefilter2_image_dw((int)a.pssm->m) * 4
-                       : prefilter == 1 ? (size_t)prefilter_image_dw((int)a.pssm->m, (int)K) * 4
-                                        : std::max<size_t>(K * table_stride((int)M, a.pssm->wide) * sizeof(float), 64);
+    const size_t lds = prefilter == 2   ? (size_t)prefilter2_image_dw((int)ms.m) * 4
+                       : prefilter == 1 ? (size_t)prefilter_image_dw((int)ms.m, (int)K) * 4
+                                        : std::max<size_t>(K * table_stride((int)M, ms.wide) * sizeof(float), 64);
     if (lds > 60 * 1024)
         return p;
     // The fused kernels write nothing, so they are LDS/VALU-bound and prefer long
@@ -259,21 +269,18 @@ int launch_score_u8(lm_hip_ctx *ctx, const DiscreteArgs &a)
     const unsigned wrap_mask = a.saturate ? 0u : 0xffu;
     // plan with the f32 planner: same stream geometry as the packed prefilter scans.  DNA takes
     // the pair-symbol scan (two rows per lookup) when the matrix allows dword symbol loads.
-    lm_hip_pssm shape;
-    shape.m = a.m;
-    shape.k = a.k;
-    shape.d_image2 = reinterpret_cast<unsigned *>(sizeof(unsigned));  // "has a pair table" for the planner; never read
-    ScoreArgs sa{&shape, a.d_seq, a.seq_stride, a.cols, a.row_begin, a.row_end, nullptr, a.out_stride};
+    const MotifShape ms{a.m, a.k, false, true};
+    ScoreArgs sa{nullptr, a.d_seq, a.seq_stride, a.cols, a.row_begin, a.row_end, nullptr, a.out_stride};
     // (both fast kernels write dwords: the score matrix must be 4-byte aligned)
     const bool out_aligned = reinterpret_cast<uintptr_t>(a.d_out) % 4 == 0;
     // streams of ~128 rows: 1 B + 1 B per cell leaves the kernel between the f32 store kernel
     // (HBM-bound, short streams) and the scans (issue-bound, long streams); measured at 1 Gbp
     // x M = 20: T = 64 0.449 ms, 128 0.426, 256 0.434, 1024 0.456, 4096 0.486
-    C32Plan p = (out_aligned && ctx->pair_prefilter) ? plan_c32(ctx, sa, true, 2, 1, 128) : C32Plan();
+    C32Plan p = (out_aligned && ctx->pair_prefilter) ? plan_c32(ctx, ms, sa, true, 2, 1, 128) : C32Plan();
     const bool pairs = p.ok;
     if (!pairs && out_aligned)
-        p = plan_c32(ctx, sa, true, 1, 1, 128);
-    ScoreC32Launcher fn = p.ok ? score_c32_lookup_u8(m, pairs) : nullptr;
+        p = plan_c32(ctx, ms, sa, true, 1, 1, 128);
+    ScoreU8Launcher fn = p.ok ? score_c32_lookup_u8(m, pairs) : nullptr;
     // device copies (scratch2): [packed image | dense table]
     const size_t image_bytes = !fn ? 0 : pairs ? (size_t)prefilter2_image_dw(m) * 4 : (size_t)prefilter_image_dw(m, k) * 4;
     const size_t dense_bytes = ((size_t)m * k + 15) / 16 * 16;
@@ -309,11 +316,9 @@ int launch_score_u8(lm_hip_ctx *ctx, const DiscreteArgs &a)
     }
     char *dev = static_cast<char *>(ctx->u8_tables.ptr);
     if (fn) {
-        FusedOut fo{};
-        fo.key_rows = wrap_mask;
         ctx->last_kernel = pairs ? "score_c32_u8_pairs" : "score_c32_u8";
-        LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, reinterpret_cast<const float *>(dev), k, a.row_begin,
-                      a.row_end, p.T, p.nstreams, reinterpret_cast<float *>(a.d_out), fo));
+        LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, reinterpret_cast<const unsigned *>(dev), k, a.row_begin,
+                      a.row_end, p.T, p.nstreams, a.d_out, wrap_mask));
         return LM_HIP_OK;
     }
     ctx->last_kernel = "score_generic_u8";

@@ -14,37 +14,33 @@ namespace lm {
 
 template <int M>
 struct RegisterRange {
-    static void run(ScoreC32Launcher (*tab)[kRegistrySlots], PrefilterLauncher *pre,
-                    PrefilterLauncher *pre2)
+    static void run(const KernelRegistry &r)
     {
-        pre[M] = &score_c32_prefilter_launch<M>;
-        if constexpr (M >= 2)
-            pre2[M] = &score_c32_prefilter2_launch<M>;
-        tab[M][MODE_STORE] = &score_c32_launch<M, MODE_STORE>;
-        tab[M][MODE_ARGMAX] = &score_c32_launch<M, MODE_ARGMAX>;
-        tab[M][MODE_THRESHOLD] = &score_c32_launch<M, MODE_THRESHOLD>;
-        tab[M][3] = &score_c32_launch<M, MODE_STORE, 1>;
+        r.pre[M] = &score_c32_prefilter_launch<M>;
+        r.u8[M] = &score_c32_u8_launch<M>;  // DiscreteMatrix scores (score_u8.hpp)
+        if constexpr (M >= 2) {
+            r.pre2[M] = &score_c32_prefilter2_launch<M>;
+            r.u8_pairs[M] = &score_c32_u8_pairs_launch<M>;
+        }
+        ScoreC32Launcher *tab = r.c32[M];
+        tab[MODE_STORE] = &score_c32_launch<M, MODE_STORE>;
+        tab[MODE_ARGMAX] = &score_c32_launch<M, MODE_ARGMAX>;
+        tab[MODE_THRESHOLD] = &score_c32_launch<M, MODE_THRESHOLD>;
+        tab[3] = &score_c32_launch<M, MODE_STORE, 1>;
         if constexpr (M % 4 == 0)
-            tab[M][7] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 0, 1>;
-        tab[M][8] = &score_c32_launch<M, MODE_STORE_ARGMAX, LM_SCORE_XCD_REMAP, 0, 1>;
-        tab[M][kSlotU8] = &score_c32_u8_launch<M>;  // DiscreteMatrix scores (score_u8.hpp)
-        if constexpr (M >= 2)
-            tab[M][kSlotU8Pairs] = &score_c32_u8_pairs_launch<M>;
+            tab[7] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 0, 1>;
+        tab[8] = &score_c32_launch<M, MODE_STORE_ARGMAX, LM_SCORE_XCD_REMAP, 0, 1>;
 #if defined(LM_SCORE_BUILD_WIDE)
         // 8-byte-read variant for K > 16; not built by default, see api.hip (pssm_create)
-        tab[M][4 + MODE_STORE] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1>;
-        tab[M][4 + MODE_ARGMAX] = &score_c32_launch<M, MODE_ARGMAX, LM_SCORE_XCD_REMAP, 1>;
-        tab[M][4 + MODE_THRESHOLD] = &score_c32_launch<M, MODE_THRESHOLD, LM_SCORE_XCD_REMAP, 1>;
+        tab[4 + MODE_STORE] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1>;
+        tab[4 + MODE_ARGMAX] = &score_c32_launch<M, MODE_ARGMAX, LM_SCORE_XCD_REMAP, 1>;
+        tab[4 + MODE_THRESHOLD] = &score_c32_launch<M, MODE_THRESHOLD, LM_SCORE_XCD_REMAP, 1>;
 #endif
         if constexpr (M < LM_M_HI)
-            RegisterRange<M + 1>::run(tab, pre, pre2);
+            RegisterRange<M + 1>::run(r);
     }
 };
 
-void LM_CAT(register_score_c32_, LM_INST_ID)(ScoreC32Launcher (*tab)[kRegistrySlots],
-                                             PrefilterLauncher *pre, PrefilterLauncher *pre2)
-{
-    RegisterRange<LM_M_LO>::run(tab, pre, pre2);
-}
+void LM_CAT(register_score_c32_, LM_INST_ID)(const KernelRegistry &r) { RegisterRange<LM_M_LO>::run(r); }
 
 }  // namespace lm

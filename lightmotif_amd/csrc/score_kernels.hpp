@@ -664,7 +664,7 @@ hipError_t score_c32_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, con
 // Registry row: [0..2] = modes, [3] = store kernel WITH the XCD remap (A/B knob),
 // [4..6] = modes for wide alphabets (K > 16), [7] = store kernel with quad-gathered symbol
 // loads (M % 4 == 0), [8] = store + running maximum (score_into on handles).
-constexpr int kRegistrySlots = 11;
+constexpr int kRegistrySlots = 9;
 ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap = false, bool wide = false);
 ScoreC32Launcher score_c32_lookup_ql(int M);
 ScoreC32Launcher score_c32_lookup_store_argmax(int M);

@@ -155,33 +155,41 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_u8_pairs(
     }
 }
 
-template <int M>
-hipError_t score_c32_u8_pairs_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, const uint8_t *seq,
-                                     const float *table, int K, unsigned long long row_begin,
-                                     unsigned long long row_end, unsigned long long T,
-                                     unsigned long long nstreams, float *out, FusedOut fo)
-{
-    (void)K;
-    hipLaunchKernelGGL((score_c32_u8_pairs<M>), grid, dim3(kBlock), lds_bytes, stream, seq,
-                       reinterpret_cast<const unsigned *>(table), row_begin, row_end, T, nstreams,
-                       reinterpret_cast<uint8_t *>(out), (unsigned)fo.key_rows);
-    return hipGetLastError();
-}
+// Host-side launch shims of the two u8 kernels (one type: K is ignored by the pair scan).
+using ScoreU8Launcher = hipError_t (*)(dim3 grid, size_t lds_bytes, hipStream_t stream, const uint8_t *seq,
+                                       const unsigned *image, int K, unsigned long long row_begin,
+                                       unsigned long long row_end, unsigned long long T,
+                                       unsigned long long nstreams, uint8_t *out, unsigned wrap_mask);
 
-// Registry shim with the ScoreC32Launcher signature (slot kSlotU8 of the registry): `table`
-// carries the packed u16 image, `out` the u8 score matrix, `fo.key_rows` the wrap mask.
 template <int M>
 hipError_t score_c32_u8_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, const uint8_t *seq,
-                               const float *table, int K, unsigned long long row_begin,
-                               unsigned long long row_end, unsigned long long T,
-                               unsigned long long nstreams, float *out, FusedOut fo)
+                               const unsigned *image, int K, unsigned long long row_begin,
+                               unsigned long long row_end, unsigned long long T, unsigned long long nstreams,
+                               uint8_t *out, unsigned wrap_mask)
 {
-    hipLaunchKernelGGL((score_c32_u8<M>), grid, dim3(kBlock), lds_bytes, stream, seq,
-                       reinterpret_cast<const unsigned *>(table), K, row_begin, row_end, T, nstreams,
-                       reinterpret_cast<uint8_t *>(out), (unsigned)fo.key_rows);
+    hipLaunchKernelGGL((score_c32_u8<M>), grid, dim3(kBlock), lds_bytes, stream, seq, image, K, row_begin,
+                       row_end, T, nstreams, out, wrap_mask);
     return hipGetLastError();
 }
 
-constexpr int kSlotU8 = 9, kSlotU8Pairs = 10;
+template <int M>
+hipError_t score_c32_u8_pairs_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, const uint8_t *seq,
+                                     const unsigned *image, int K, unsigned long long row_begin,
+                                     unsigned long long row_end, unsigned long long T,
+                                     unsigned long long nstreams, uint8_t *out, unsigned wrap_mask)
+{
+    (void)K;
+    hipLaunchKernelGGL((score_c32_u8_pairs<M>), grid, dim3(kBlock), lds_bytes, stream, seq, image, row_begin,
+                       row_end, T, nstreams, out, wrap_mask);
+    return hipGetLastError();
+}
+
+// What a score_inst_*.hip translation unit fills in for its range of motif lengths
+// (arrays indexed by M; see score.hip: init_registry).
+struct KernelRegistry {
+    ScoreC32Launcher (*c32)[kRegistrySlots];
+    PrefilterLauncher *pre, *pre2;
+    ScoreU8Launcher *u8, *u8_pairs;
+};
 
 }  // namespace lm
