@@ -11,6 +11,8 @@ timeout 400 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.e
 timeout 300 python tools/bench_configs.py > "$OUT/bench_configs.json" 2> "$OUT/bench_configs.err"
 timeout 200 python tools/api_overhead.py > "$OUT/api_overhead.json" 2> "$OUT/api_overhead.err"
 timeout 100 tools/kbench/stripe_bench > "$OUT/stripe_bench.txt" 2>&1
+# the same box's ceiling for the store kernel: trivial kernels moving its 1 B read : 4 B written mix
+timeout 100 tools/kbench/mix_bench > "$OUT/mix_bench.txt" 2>&1
 timeout 200 python tools/handle_flow.py > "$OUT/handle_flow.json" 2> "$OUT/handle_flow.err"
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
     --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 5 --dist-backend gloo --single-device \
