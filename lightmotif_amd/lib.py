@@ -943,9 +943,16 @@ class Scanner:
         self.threshold = threshold
         if sequence.wrap < len(pssm) - 1:  # scan.rs:127-131 panics
             raise ValueError(f"not enough wrapping rows for motif of length {len(pssm)}")
-        pli = sequence._pli
+        self._pssm, self._seq = pssm, sequence
+        self._positions: Optional[np.ndarray] = None  # filled by the first use (one fused scan)
+        self._scores: Optional[np.ndarray] = None
+        self._order: Optional[np.ndarray] = None
+        self._next = 0
+
+    def _scan(self, threshold: float) -> Tuple[np.ndarray, np.ndarray]:
+        pli = self._seq._pli
         ptr, n = C.POINTER(_ffi.Hit)(), C.c_size_t(0)
-        check(pli._L.lm_hip_scan_f32(pli._h, pssm._device(pli), sequence._h, threshold,
+        check(pli._L.lm_hip_scan_f32(pli._h, self._pssm._device(pli), self._seq._h, threshold,
                                      C.byref(ptr), C.byref(n)))
         try:
             raw = np.frombuffer(C.string_at(ptr, n.value * C.sizeof(_ffi.Hit)) if n.value else b"",
@@ -953,40 +960,82 @@ class Scanner:
         finally:
             if ptr:
                 pli._L.lm_hip_free(ptr)
-        #: the hits in ascending position (int64) and their f32 scores
-        self.positions = raw["position"].astype(np.int64)
-        self.scores = raw["score"].astype(np.float32)
-        rows = max(sequence.rows, 1)
-        row, col = self.positions % rows, self.positions // rows
+        return raw["position"].astype(np.int64), raw["score"].astype(np.float32)
+
+    def _collect(self) -> None:
+        if self._order is not None:
+            return
+        self._positions, self._scores = self._scan(self.threshold)
+        rows = max(self._seq.rows, 1)
+        row, col = self._positions % rows, self._positions // rows
         # yield order: block ascending, then (row, col) descending
-        self._order = np.lexsort((-col, -row, row // block_size))
-        self._next = 0
+        self._order = np.lexsort((-col, -row, row // self.block_size))
+
+    @property
+    def positions(self) -> np.ndarray:
+        """The hits' positions in ascending order (int64)."""
+        self._collect()
+        return self._positions
+
+    @property
+    def scores(self) -> np.ndarray:
+        """The f32 scores of ``positions``."""
+        self._collect()
+        return self._scores
 
     def __iter__(self) -> "Scanner":
         return self
 
     def __next__(self) -> Hit:
+        self._collect()
         if self._next >= self._order.size:
             raise StopIteration
         i = self._order[self._next]
         self._next += 1
-        return Hit(int(self.positions[i]), float(self.scores[i]))
+        return Hit(int(self._positions[i]), float(self._scores[i]))
 
     def __len__(self) -> int:
         """Hits not yet yielded."""
+        self._collect()
         return int(self._order.size - self._next)
 
-    def max(self) -> Optional[Hit]:
-        """scan.rs:200-249: the best hit not yet yielded; greater score wins, equal scores
-        go to the greater position (scan.rs:237).  Consumes the scanner."""
-        rest = self._order[self._next:]
-        self._next = self._order.size
-        if rest.size == 0:
+    @staticmethod
+    def _best(pos: np.ndarray, sc: np.ndarray) -> Optional[Hit]:
+        if sc.size == 0:
             return None
-        sc, pos = self.scores[rest], self.positions[rest]
         top = np.nonzero(sc == sc.max())[0]
         i = top[np.argmax(pos[top])]
         return Hit(int(pos[i]), float(sc[i]))
+
+    def max(self) -> Optional[Hit]:
+        """scan.rs:200-249: the best hit not yet yielded; greater score wins, equal scores
+        go to the greater position (scan.rs:237).  Consumes the scanner.
+
+        On a fresh scanner the hit list is never built (a low threshold would select most of
+        the sequence): the fused argmax gives the greatest score S of the matrix, and one
+        scan at max(threshold, S) returns the few valid positions that reach it."""
+        if self._order is None:
+            pli = self._seq._pli
+            top = pli.score_argmax(self._pssm, self._seq)
+            if top is None:
+                self._order = np.zeros(0, np.int64)
+                return None
+            s_max = top[1]
+            if s_max == s_max and s_max >= self.threshold:
+                pos, sc = self._scan(s_max)
+                if sc.size:  # valid positions (position + M <= L) that reach the matrix maximum
+                    self._order = np.zeros(0, np.int64)
+                    self._positions, self._scores = pos[:0], sc[:0]
+                    return self._best(pos, sc)
+                # the maximum sits in the padded tail only (finite weights for N): full list
+            elif s_max == s_max:
+                self._order = np.zeros(0, np.int64)  # nothing reaches the threshold
+                self._positions, self._scores = np.zeros(0, np.int64), np.zeros(0, np.float32)
+                return None
+            self._collect()
+        rest = self._order[self._next:]
+        self._next = self._order.size
+        return self._best(self._positions[rest], self._scores[rest])
 
 
 # --- module-level helpers (lib.rs:1335-1451) ---------------------------------------------------

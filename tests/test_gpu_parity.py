@@ -197,6 +197,31 @@ def test_scanner_dense_hit_lists(pli, length, frac):
     assert first.position == no.scanner_collect(want, 32, length, m, t, 256)[0][0]
 
 
+def test_scanner_max_does_not_build_the_hit_list(pli):
+    """`Scanner::max` on a fresh scanner (scan.rs:200-249) with a threshold that selects every
+    position: the best hit comes from the fused argmax + one scan at its score, the full hit
+    list is never materialised; ties go to the greater POSITION, not the later (row, col) cell."""
+    rng = np.random.default_rng(12)
+    length, m = 300_000, 6
+    enc = rng.integers(0, 4, length, dtype=np.uint8)
+    p = np.zeros((m, 8), np.float32)
+    p[:, :4] = rng.integers(0, 2, (m, 4))            # many exact ties at the maximum
+    p[:, 4] = -np.inf
+    seq = pli.stripe(lm.EncodedSequence(enc), 32)
+    seq.configure_wrap(m - 1)
+    sc = lm.Scanner(lm.ScoringMatrix(p), seq, threshold=-1e30)
+    best = sc.max()
+    assert sc._positions is None or sc._positions.size == 0      # nothing was collected
+    ref = co.stripe(enc, 32, 5)
+    co.configure_wrap(ref, m - 1)
+    want, _ = co.score_rows(ref, p)
+    by_pos = want[:, :32].T.reshape(-1)[: length - m + 1]
+    top = np.nonzero(by_pos == by_pos.max())[0]
+    assert top.size > 1 and (best.position, best.score) == (int(top[-1]), float(by_pos.max()))
+    assert lm.Scanner(lm.ScoringMatrix(p), seq, threshold=float(by_pos.max()) + 0.5).max() is None
+    assert len(sc) == 0 and sc.max() is None                      # consumed
+
+
 def test_indexing_reads_single_rows(pli):
     """``scores[i]`` = cell (i % rows, i / rows) (scores.rs:246-254), fetched without downloading
     the matrix; windows of rows come back like the corresponding slice of the full copy."""
