@@ -3,6 +3,8 @@ the reference's Scanner runs first, scan.rs:174-184) against the oracle: bit-exa
 both overflow behaviours (Generic's wrapping `+=`, the SIMD back-ends' saturating adds), the
 reference's own property test (tests/dna.rs:93-120), odd geometries through the generic kernel,
 and BASELINE's full size through window samples."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -12,6 +14,7 @@ from oracle import c_oracle as co
 from oracle import np_oracle as no
 
 pytestmark = pytest.mark.gpu
+PAIRS = os.environ.get("LM_HIP_PAIR_PREFILTER", "1") != "0"   # the A/B knob may be set for a whole run
 GOLD_SEQ = "ATGTCCCAACAACGATACCCCGAGCCCATCGCCGTCATCGGCTCGGCATGCAGATTCCCAGGCG"
 PATTERNS = ["GTTGACCTTATCAAC", "GTTGATCCAGTCAAC"]
 
@@ -82,7 +85,7 @@ def test_u8_scores_reductions_and_row_ranges(pli, length, m, protein, top, cols)
                 part, _ = pli.score_discrete(dm, seq, rows=range(a, b), saturate=saturate)
                 assert np.array_equal(part[:, :cols], want[a:b, :cols])
     if cols == 32 and 1 <= m <= 36 and rows >= (m | 3) + 3:
-        assert pli.last_kernel == ("score_c32_u8_pairs" if not protein and m >= 2 else "score_c32_u8")
+        assert pli.last_kernel == ("score_c32_u8_pairs" if PAIRS and not protein and m >= 2 else "score_c32_u8")
     elif cols != 32 or m > 36:
         assert pli.last_kernel == "score_generic_u8"
     if want_sat.shape[0] == 0:
@@ -198,7 +201,7 @@ def test_full_size_u8_scores(pli):
     assert pli.score_u8_dptr(dm, seq.data_ptr(), rows + m - 1, 32, 32, m - 1, length, 0, rows,
                              out.data_ptr(), 32) == (rows, length + 1 - m)
     torch.cuda.synchronize()
-    assert pli.last_kernel == "score_c32_u8_pairs"
+    assert pli.last_kernel == ("score_c32_u8_pairs" if PAIRS else "score_c32_u8")
     for a in (0, rows // 2 - 333, rows - 2048):
         win = seq[a: a + 2048 + m - 1].cpu().numpy()
         want = no.score_rows_u8_saturating(win, 32, 1 << 40, dm.data[:, :5], 0, 2048)

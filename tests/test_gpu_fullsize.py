@@ -2,6 +2,8 @@
 window samples against the oracle, row-range consistency, exact scaling by powers of
 two, argmax / threshold against an independent torch formulation, fused == materialised.
 Also the protein configuration (K = 21, M = 12, 200 Mres)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -303,7 +305,8 @@ def test_unaligned_sequence_pointer(gpu_pli, offset):
     assert am_a == am_u
     t = float(torch.quantile(out_a.view(-1)[:4_000_000], 1 - 1e-4))
     th_a = pli.score_threshold_dptr(pssm, ptr_a, rows + m - 1, COLS, COLS, m - 1, length, 0, rows, t)
-    assert pli.last_kernel == "score_c32_prefilter2"
+    pairs = os.environ.get("LM_HIP_PAIR_PREFILTER", "1") != "0"   # A/B knob of a whole run
+    assert pli.last_kernel == ("score_c32_prefilter2" if pairs else "score_c32_prefilter")
     th_u = pli.score_threshold_dptr(pssm, ptr_u, rows + m - 1, COLS, COLS, m - 1, length, 0, rows, t)
     assert pli.last_kernel == "score_c32_prefilter"
     assert np.array_equal(th_a[0], th_u[0]) and np.array_equal(th_a[1], th_u[1]) and len(th_a[0]) > 50
