@@ -133,6 +133,12 @@ int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stri
 int lm_hip_pssm_destroy(lm_hip_pssm *pssm);
 size_t lm_hip_pssm_len(const lm_hip_pssm *pssm);
 
+/* ScoringMatrix::<Dna>::reverse_complement (pwm/mod.rs:566-577): a new resident matrix with
+ * rows reversed and the columns of complementary nucleotides swapped (A<->T, C<->G, N kept;
+ * abc.rs Dna::complement) -- the second strand of `lightmotif-cli --reverse` (main.rs) without
+ * a host round trip.  DNA matrices (k == 5) only: LM_HIP_ERR_BAD_ARGS otherwise. */
+int lm_hip_pssm_reverse_complement(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, lm_hip_pssm **out);
+
 /* ---- Score (device pointers) ---------------------------------------------- */
 
 /*

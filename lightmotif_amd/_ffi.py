@@ -63,6 +63,7 @@ SIGNATURES = {
     "lm_hip_ctx_set_track_argmax": (C.c_int, [_vp, C.c_int]),
     "lm_hip_ctx_last_kernel": (C.c_char_p, [_vp]),
     "lm_hip_pssm_create": (C.c_int, [_vp, _vp, _sz, _sz, _sz, C.POINTER(_vp)]),
+    "lm_hip_pssm_reverse_complement": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
     "lm_hip_pssm_destroy": (C.c_int, [_vp]),
     "lm_hip_pssm_len": (_sz, [_vp]),
     "lm_hip_score_f32_dptr": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz, _vp, _sz,

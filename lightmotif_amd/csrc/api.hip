@@ -432,6 +432,22 @@ int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stri
     return LM_HIP_OK;
 }
 
+int lm_hip_pssm_reverse_complement(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, lm_hip_pssm **out)
+{
+    if (!ctx || !pssm || !out)
+        return fail(LM_HIP_ERR_BAD_ARGS, "pssm_reverse_complement: null argument");
+    *out = nullptr;
+    if (pssm->k != 5)
+        return fail(LM_HIP_ERR_BAD_ARGS, "pssm_reverse_complement: only DNA matrices (K = 5) have a complement");
+    static const int comp[5] = {2, 3, 0, 1, 4};  // A C T G N -> T G A C N
+    const size_t m = pssm->m, k = pssm->k;
+    std::vector<float> rc(m * k);
+    for (size_t i = 0; i < m; ++i)  // pwm/mod.rs:570-574
+        for (size_t s = 0; s < k; ++s)
+            rc[i * k + s] = pssm->host[(m - 1 - i) * k + comp[s]];
+    return lm_hip_pssm_create(ctx, rc.data(), m, k, k, out);
+}
+
 int lm_hip_pssm_destroy(lm_hip_pssm *p)
 {
     if (!p)

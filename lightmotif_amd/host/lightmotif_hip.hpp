@@ -242,6 +242,17 @@ public:
         }
         return total;
     }
+    // pwm/mod.rs:566-577 (ComplementableAlphabet = Dna): rows reversed, A<->T and C<->G swapped
+    ScoringMatrix reverse_complement() const
+    {
+        static_assert(A::K == 5, "only the DNA alphabet has a complement");
+        static const size_t comp[5] = {2, 3, 0, 1, 4};
+        DenseMatrix<float> out(data.rows(), A::K);
+        for (size_t i = 0; i < data.rows(); ++i)
+            for (size_t s = 0; s < A::K; ++s)
+                out(i, s) = data(data.rows() - 1 - i, comp[s]);
+        return ScoringMatrix(background, std::move(out));
+    }
     // pwm/mod.rs:665-696
     DiscreteMatrix<A> to_discrete() const
     {
@@ -455,6 +466,8 @@ class Pipeline {
 public:
     // Pipeline::avx2() -> Result<Self, UnsupportedBackend> (pli/mod.rs:401-407)
     static Pipeline hip(int device = 0) { return Pipeline(std::make_shared<CtxHandle>(device)); }
+    // the library context behind this pipeline, for direct C-ABI calls
+    lm_hip_ctx *context() const { return ctx_->ctx; }
 
     // the best cell and its score; the cells with score >= t in row-major order
     struct Best {

@@ -747,11 +747,18 @@ class ScoringMatrix:
         return self.score_distribution.score(pvalue)
 
     def reverse_complement(self) -> "ScoringMatrix":
-        """pwm/mod.rs:566-577 (DNA: A<->T, C<->G, N->N)."""
+        """pwm/mod.rs:566-577 (DNA: A<->T, C<->G, N->N).  Device copies of ``self`` get their
+        complement made by the library (``lm_hip_pssm_reverse_complement``), without an upload."""
         if self.protein:
             raise ValueError("cannot complement a protein matrix")
         comp = [2, 3, 0, 1, 4]
-        return ScoringMatrix(self.data[::-1, :5][:, comp], self.background, protein=False)
+        rc = ScoringMatrix(self.data[::-1, :5][:, comp], self.background, protein=False)
+        for key, h in self._dev.items():
+            pli = self._plis[key]
+            out = C.c_void_p()
+            check(pli._L.lm_hip_pssm_reverse_complement(pli._h, h, C.byref(out)))
+            rc._dev[key], rc._plis[key] = out, pli
+        return rc
 
 
 class DiscreteMatrix:

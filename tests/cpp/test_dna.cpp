@@ -142,6 +142,45 @@ static void test_score_discrete(const Pipeline<Dna> &pli)
     CHECK(dm.scale(-1e30f) == 0 && dm.scale(1e30f) == 255);
 }
 
+// pwm/mod.rs:566-577: the reverse complement of the matrix scores the reverse complement of the
+// sequence like the matrix scores the sequence (position i <-> L - M - i); the library's resident
+// form (lm_hip_pssm_reverse_complement) gives the same matrix
+static void test_reverse_complement(const Pipeline<Dna> &pli, lm_hip_ctx *ctx)
+{
+    const auto pssm = golden_pssm();
+    const auto rc = pssm.reverse_complement();
+    std::string rev(SEQUENCE);
+    std::reverse(rev.begin(), rev.end());
+    for (char &c : rev)
+        c = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
+    auto fwd = pli.stripe(EncodedSequence<Dna>::encode(SEQUENCE));
+    auto bwd = pli.stripe(EncodedSequence<Dna>::encode(rev));
+    fwd.configure(pssm);
+    bwd.configure(rc);
+    const auto a = pli.score(pssm, fwd), b = pli.score(rc, bwd);
+    const size_t n = a.len();
+    CHECK(n == 50 && b.len() == n);
+    for (size_t i = 0; i < n; ++i)
+        CHECK(std::fabs(a.at(i) - b.at(n - 1 - i)) < 1e-4f);  // same terms, added in the opposite order
+    lm_hip_pssm *dev_rc = nullptr;
+    CHECK(lm_hip_pssm_reverse_complement(ctx, pssm.device(ctx), &dev_rc) == LM_HIP_OK);
+    if (dev_rc) {
+        int found = 0, found2 = 0;
+        lm_hip_coords best{}, best2{};
+        float v = 0, v2 = 0;
+        lm_hip_seq *h = bwd.handle();
+        size_t len = 0, wrap = 0, rows = 0, stride = 0, cols = 0;
+        const uint8_t *dptr = nullptr;
+        CHECK(lm_hip_seq_info(h, &len, &wrap, &rows, &stride, &cols, &dptr) == LM_HIP_OK);
+        CHECK(lm_hip_score_argmax_f32_dptr(ctx, dev_rc, dptr, rows + wrap, stride, cols, wrap, len, 0, rows, &found,
+                                           &best, &v) == LM_HIP_OK);
+        CHECK(lm_hip_score_argmax_f32_dptr(ctx, rc.device(ctx), dptr, rows + wrap, stride, cols, wrap, len, 0, rows,
+                                           &found2, &best2, &v2) == LM_HIP_OK);
+        CHECK(found && found2 && best.row == best2.row && best.col == best2.col && v == v2);
+        lm_hip_pssm_destroy(dev_rc);
+    }
+}
+
 // scan.rs:279-353 / lightmotif-py test_scanner.py:64-80
 static void test_scanner(const Pipeline<Dna> &pli)
 {
@@ -332,6 +371,7 @@ int main()
     }
     test_stripe_literals(pli);
     test_score_discrete(pli);
+    test_reverse_complement(pli, pli.context());
     test_scanner(pli);
     test_batch(pli);
     test_encode(pli);

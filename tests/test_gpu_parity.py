@@ -222,6 +222,30 @@ def test_scanner_max_does_not_build_the_hit_list(pli):
     assert len(sc) == 0 and sc.max() is None                      # consumed
 
 
+def test_reverse_complement_on_the_device(pli):
+    """pwm/mod.rs:566-577: the library's resident reverse complement is the matrix the host mirror
+    builds; scoring the reverse-complemented sequence with it mirrors the forward scores."""
+    rng = np.random.default_rng(21)
+    length, m = 50_000, 13
+    text = "".join("ACGT"[i] for i in rng.integers(0, 4, length))
+    sites = ["".join("ACGT"[i] for i in rng.integers(0, 4, m)) for _ in range(7)]
+    pssm = lm.create(sites).counts.normalize(0.1).log_odds()
+    seq = lm.stripe(text)
+    fwd = pssm.calculate(seq).unstripe()                      # uploads pssm to this pipeline
+    assert pssm._dev
+    rc = pssm.reverse_complement()
+    assert set(rc._dev) == set(pssm._dev)                    # made by lm_hip_pssm_reverse_complement
+    host_only = lm.ScoringMatrix(rc.data, rc.background)     # same matrix, uploaded from the host
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rseq = lm.stripe("".join(comp[c] for c in reversed(text)))
+    a = rc.calculate(rseq)
+    b = host_only.calculate(rseq)
+    assert np.array_equal(bits(a.unstripe()), bits(b.unstripe())) and a.argmax() == b.argmax()
+    assert np.allclose(a.unstripe()[::-1], fwd, atol=1e-4)   # same terms, opposite add order
+    with pytest.raises(ValueError):
+        lm.create(["ACDEF"], protein=True).pssm.reverse_complement()
+
+
 def test_indexing_reads_single_rows(pli):
     """``scores[i]`` = cell (i % rows, i / rows) (scores.rs:246-254), fetched without downloading
     the matrix; windows of rows come back like the corresponding slice of the full copy."""
