@@ -13,7 +13,7 @@
 //                           keys there; the final slot is bucket start + rank, written
 //                           directly in the caller's output format
 //
-// `shift` is chosen from the hit density so that a bucket holds ~8 records on
+// `shift` is chosen from the hit density so that a bucket holds ~1 record on
 // average; a bucket never holds more records than it has cells (2^shift), which bounds
 // step 4 at 8 x (cells of the batch) comparisons whatever the distribution of hits.
 #include <algorithm>
@@ -196,11 +196,14 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
                     max_low);
     const unsigned long long sized_for = speculative ? std::max<unsigned long long>(expected, 4096) : count;
     const unsigned long long room = speculative ? cap : count;  // records the arrays must hold
-    // ~8 records per bucket on average; at most 2^26 buckets
+    // ~1 record per bucket on average; at most 2^26 buckets.  (Ranking is quadratic in the bucket
+    // size and the density is far from uniform across jobs: in the JASPAR batch a length-4 motif
+    // has 150 x the average hit density; at 8 records per average bucket its buckets held 2 800
+    // records and hits_rank_emit took 7 ms of the batch's 47.)
     int shift = 5;
     {
         const long double universe = (long double)max_low * (long double)njobs;
-        while (shift < 40 && ((long double)(1ull << shift) * (long double)sized_for < 8.0L * universe))
+        while (shift < 40 && ((long double)(1ull << shift) * (long double)sized_for < 1.0L * universe))
             ++shift;
         while (shift < 40 && (((max_low - 1) >> shift) + 1) * njobs > (1ull << 26))
             ++shift;
@@ -261,7 +264,10 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
     float *d_values = reinterpret_cast<float *>(base + off_values);
     if (speculative)
         memset(pin, 0, 32);  // counters and abort flag (the previous call's results were consumed)
-    const unsigned long long max_bucket = speculative ? 2048 : ~0ull;
+    // a guess that is off by orders of magnitude (first call of a context: 4 096 expected, millions
+    // found) leaves hundreds of records per bucket and a quadratic ranking pass (23 ms on the JASPAR
+    // batch): give up early, the exact form costs a fraction of a millisecond
+    const unsigned long long max_bucket = speculative ? 256 : ~0ull;
 
     hipStream_t st = ctx->stream;
     const unsigned grid = (unsigned)std::max<unsigned long long>(
