@@ -339,3 +339,50 @@ def test_hit_ordering_with_and_without_known_count(monkeypatch):
                                                   length, 0, rows, t)
             assert np.array_equal(hits, want), (flag, t)
             assert np.array_equal(vals, want_vals), (flag, t)
+
+
+@pytest.mark.parametrize("m,kind", [(1, "random"), (3, "random"), (5, "ties"), (6, "random"), (6, "absent_in_suffix"),
+                                    (4, "only_at_the_end"), (7, "finite_n"), (9, "random"), (5, "range")])
+def test_fused_argmax_of_short_motifs_from_the_last_rows(monkeypatch, m, kind):
+    """Short motifs are settled from the last rows of the range when those hold a best k-mer
+    (score == sum of the row maxima); otherwise the usual routes run.  Both must give the
+    Generic argmax (pli/mod.rs:135-155) -- also when the best k-mer is missing from the suffix,
+    sits in the very last valid window only, ties abound, N has finite weights, or a row
+    range is scored."""
+    monkeypatch.setenv("LM_HIP_SUFFIX_ARGMAX", "0")
+    plain = lm.Pipeline.hip(0)
+    monkeypatch.delenv("LM_HIP_SUFFIX_ARGMAX")
+    suffix = lm.Pipeline.hip(0)
+    rng = np.random.default_rng(1000 + m)
+    length = 6_000_011
+    enc = rng.integers(0, 4, length, dtype=np.uint8)
+    p = np.zeros((m, 8), np.float32)
+    p[:, :4] = rng.integers(-2, 3, (m, 4)) if kind == "ties" else rng.normal(0, 2, (m, 4))
+    p[:, 4] = rng.normal(0, 1, m) if kind == "finite_n" else -np.inf
+    best = p[:, :4].argmax(axis=1).astype(np.uint8)
+    rows = -(-length // 32)
+    if kind in ("absent_in_suffix", "only_at_the_end"):
+        worst = p[:, :4].argmin(axis=1)
+        # the last 60 000 rows of every column avoid the best k-mer's first symbol
+        ref = co.stripe(enc, 32, 5)
+        view = ref.data[:rows, :32]
+        tail = view[rows - 60_000:]
+        tail[tail == best[0]] = np.uint8(worst[0] if worst[0] != best[0] else (best[0] + 1) % 4)
+        enc = view.T.reshape(-1)[:length].copy()
+        if kind == "only_at_the_end":
+            enc[length - m:] = best                      # the very last valid window
+    ref = co.stripe(enc, 32, 5)
+    co.configure_wrap(ref, m - 1)
+    a, b = (rows // 5, rows - 777) if kind == "range" else (0, rows)
+    want, _ = co.score_rows(ref, p, a, b)
+    want_cell = co.argmax(want, 32)
+    want_val = want[want_cell]
+    pssm = lm.ScoringMatrix(p)
+    for pli in (suffix, plain):
+        seq = pli.stripe(lm.EncodedSequence(enc), 32)
+        seq.configure_wrap(m - 1)
+        got = pli.score_argmax(pssm, seq, range(a, b))
+        assert got[0] == want_cell and np.float32(got[1]) == want_val, (kind, pli is suffix)
+        many = pli.scan_argmax_batch([pssm, pssm.reverse_complement(), pssm], seq)
+        if kind != "range":
+            assert many[0] == got and many[2] == got
