@@ -386,3 +386,30 @@ def test_fused_argmax_of_short_motifs_from_the_last_rows(monkeypatch, m, kind):
         many = pli.scan_argmax_batch([pssm, pssm.reverse_complement(), pssm], seq)
         if kind != "range":
             assert many[0] == got and many[2] == got
+
+
+def test_fused_argmax_suffix_route_random_motifs(pli):
+    """Many random short motifs (lengths 1..8, small-integer weights = many ties, some with a
+    scoring N) over one 5 Mbp sequence: batch and single calls equal the oracle's Generic argmax."""
+    rng = np.random.default_rng(4242)
+    length = 5_000_003
+    enc = rng.integers(0, 5, length, dtype=np.uint8)
+    enc[rng.random(length) < 0.98] %= 4                      # a sprinkle of N
+    ref = co.stripe(enc, 32, 5)
+    co.configure_wrap(ref, 8)
+    seq = pli.stripe(lm.EncodedSequence(enc), 32)
+    seq.configure_wrap(8)
+    pssms, wants = [], []
+    for i in range(24):
+        m = int(rng.integers(1, 9))
+        p = np.zeros((m, 8), np.float32)
+        p[:, :4] = rng.integers(-3, 4, (m, 4)) if i % 3 == 0 else rng.normal(0, 2, (m, 4))
+        p[:, 4] = rng.normal(-1, 1, m) if i % 4 == 1 else -np.inf
+        want, _ = co.score_rows(ref, p)
+        cell = co.argmax(want, 32)
+        pssms.append(lm.ScoringMatrix(p))
+        wants.append((cell, float(want[cell])))
+    got = pli.scan_argmax_batch(pssms, seq)
+    assert got == wants
+    for k in (0, 7, 13):
+        assert pli.score_argmax(pssms[k], seq) == wants[k]
