@@ -1167,6 +1167,33 @@ __global__ __launch_bounds__(64) void argmax_prepare(const SampleJob *__restrict
 }
 
 // reduction of the hit list: per job the greatest score, then the greatest key among its ties
+// atomicMax(&target[job], value) for every live lane, with ONE atomic per distinct job of the
+// wavefront: the list is clustered by job in runs shorter than a wavefront (a re-scoring
+// workgroup stages the hits of several rounds = several jobs before it flushes), and a
+// wavefront-wide atomic with 64 different addresses costs 64 operations -- 10^6 records took
+// 2.4 ms that way.  `value` 0 = nothing to contribute (0 is below every real value here).
+template <typename T>
+__device__ __forceinline__ void wave_atomic_max_by_job(const unsigned long long job, const T value,
+                                                       const bool live, T *__restrict__ target)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long active = __ballot(live);
+    while (active) {  // wave-uniform
+        const int leader = __ffsll((long long)active) - 1;
+        const unsigned long long j = __shfl(job, leader);
+        const bool mine = live && job == j;
+        T x = mine ? value : (T)0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const T o = __shfl_xor(x, off);
+            x = o > x ? o : x;
+        }
+        if (lane == leader && x != (T)0)
+            atomicMax(&target[j], x);
+        active &= ~__ballot(mine);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void hits_best_value(const HitRecord *__restrict__ hits,
                                                           const unsigned long long *__restrict__ count,
                                                           const unsigned long long capacity,
@@ -1175,26 +1202,14 @@ __global__ __launch_bounds__(kBlock) void hits_best_value(const HitRecord *__res
     unsigned long long n = *count;
     if (n > capacity)
         n = capacity;
-    // the list is clustered by job: when a wavefront's records belong to one job it
-    // reduces them first and issues ONE atomic
     const unsigned long long span = (unsigned long long)gridDim.x * kBlock;
     for (unsigned long long i0 = (unsigned long long)blockIdx.x * kBlock; i0 < n; i0 += span) {
         const unsigned long long i = i0 + threadIdx.x;
         const bool live = i < n;
-        const unsigned long long job = live ? hits[i].key >> 40 : ~0ull;
-        unsigned v = live ? ordered_bits(hits[i].value) : 0u;
-        const unsigned long long job0 = __shfl(job, 0);
-        if (__all(job == job0 || !live)) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned o = __shfl_xor(v, off);
-                v = o > v ? o : v;
-            }
-            if ((threadIdx.x & 63) == 0 && job0 != ~0ull)
-                atomicMax(&best_value[job0], v);
-        } else if (live) {
-            atomicMax(&best_value[job], v);
-        }
+        HitRecord h{};
+        if (live)
+            h = hits[i];
+        wave_atomic_max_by_job(h.key >> 40, live ? ordered_bits(h.value) : 0u, live, best_value);
     }
 }
 
@@ -1214,22 +1229,11 @@ __global__ __launch_bounds__(kBlock) void hits_best_key(const HitRecord *__restr
         HitRecord h{};
         if (live)
             h = hits[i];
-        const unsigned long long job = live ? h.key >> 40 : ~0ull;
-        // 0 = none / not a tie of the job's best score
-        unsigned long long k = (live && ordered_bits(h.value) == best_value[job])
-                                   ? (h.key & ((1ull << 40) - 1)) + 1 : 0ull;
-        const unsigned long long job0 = __shfl(job, 0);
-        if (__all(job == job0 || !live)) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned long long o = __shfl_xor(k, off);
-                k = o > k ? o : k;
-            }
-            if ((threadIdx.x & 63) == 0 && k != 0)
-                atomicMax(&best_key[job0], k);
-        } else if (k != 0) {
-            atomicMax(&best_key[job], k);
-        }
+        const unsigned long long job = h.key >> 40;
+        // 0 = not a tie of the job's best score
+        const unsigned long long k = (live && ordered_bits(h.value) == best_value[job])
+                                         ? (h.key & ((1ull << 40) - 1)) + 1 : 0ull;
+        wave_atomic_max_by_job(job, k, live, best_key);
     }
 }
 
@@ -1416,6 +1420,9 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
     LM_HIP_TRY(hipStreamSynchronize(st));
     const unsigned long long nhits = static_cast<unsigned long long *>(ctx->pinned)[0];
     const unsigned long long ncand = static_cast<unsigned long long *>(ctx->pinned)[1];
+    if (getenv("LM_HIP_TRACE"))
+        fprintf(stderr, "[lm_hip] candidate-route argmax: %zu jobs, %llu candidates (room %llu), %llu hits (room %llu)\n",
+                nq, ncand, ccap, nhits, cap);
     if (nhits > cap || ncand > ccap)
         return LM_HIP_OK;  // truncated lists prove nothing: the exact kernel takes over
     const ArgmaxRecord *r = pin ? res : host_res.data();
