@@ -16,7 +16,7 @@ timeout 100 tools/kbench/mix_bench > "$OUT/mix_bench.txt" 2>&1
 timeout 200 python tools/handle_flow.py > "$OUT/handle_flow.json" 2> "$OUT/handle_flow.err"
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
     --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 5 --dist-backend gloo --single-device \
-    --length 400000000 --no-cpu-baseline > "$OUT/bench_2rank_gloo_single_device.json" 2> "$OUT/bench_2rank.err"
+    --length 400000000 --no-cpu-baseline 2> "$OUT/bench_2rank.err" | grep '^{' > "$OUT/bench_2rank_gloo_single_device.json"  # (gloo prints a banner on stdout)
 ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv \
     -d "$OUT/prof" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/prof_bench.json" 2> "$OUT/prof.err" )
 python - "$OUT" <<'PY'
