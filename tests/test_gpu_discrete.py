@@ -219,3 +219,37 @@ def test_full_size_u8_scores(pli):
     pli.score_u8_dptr(dm, seq.data_ptr(), rows + m - 1, 32, 32, m - 1, length, 777, 5777, part.data_ptr(), 32)
     torch.cuda.synchronize()
     assert torch.equal(part, out[777:5777])
+
+
+def test_no_device_memory_growth_over_repeated_calls():
+    """Contexts, PSSMs (incl. the library-made reverse complement), sequences, u8 scoring with
+    changing matrices, fused calls: device memory returns to where it started."""
+    rng = np.random.default_rng(77)
+    enc = rng.integers(0, 4, 300_000, dtype=np.uint8)
+
+    def cycle():
+        pli = lm.Pipeline.hip(0)
+        seq = pli.stripe(lm.EncodedSequence(enc), 32)
+        seq.configure_wrap(19)
+        for i in range(6):
+            m = int(rng.integers(2, 20))
+            sites = ["".join("ACTG"[j] for j in rng.integers(0, 4, m)) for _ in range(5)]
+            pssm = lm.create(sites).counts.normalize(0.1).log_odds()
+            pssm.calculate(seq).argmax()
+            rc = pssm.reverse_complement()
+            pli.score_argmax(rc, seq)
+            pli.score_threshold(pssm, seq, 3.0)
+            pli.score_discrete(pssm.to_discrete(), seq, saturate=bool(i % 2))
+            list(lm.Scanner(pssm, seq, threshold=5.0))
+        del seq, pli
+
+    cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(25):
+        cycle()
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (64 << 20), f"device memory shrank by {(free0 - free1) >> 20} MiB"
