@@ -235,6 +235,8 @@ static int ctx_create(int device, void *stream, bool borrow, lm_hip_ctx **out)
         ctx->speculate_order = atoi(e) != 0;
     if (const char *e = getenv("LM_HIP_SUFFIX_ARGMAX"))  // A/B switch: 0 = always scan the whole range
         ctx->suffix_argmax = atoi(e) != 0;
+    if (const char *e = getenv("LM_HIP_MULTI_MOTIF"))  // A/B switch: 0 = one motif per workgroup pass
+        ctx->multi_motif = atoi(e) != 0;
     if (const char *e = getenv("LM_HIP_QUAD_LOADS"))  // A/B switch of the store kernel's symbol loads
         ctx->quad_loads = atoi(e) != 0;
     if (const char *e = getenv("LM_HIP_PAIR_PREFILTER"))  // A/B switch: 0 = one symbol per lookup

@@ -31,12 +31,13 @@ static PrefilterLauncher g_pre[kMaxFastM + 1];
 static PrefilterLauncher g_pre2[kMaxFastM + 1];
 static ScoreU8Launcher g_u8[kMaxFastM + 1];
 static ScoreU8Launcher g_u8_pairs[kMaxFastM + 1];
+static PrefilterMultiLauncher g_pre2_multi[kMaxFastM + 1];
 static char g_c32_names[kMaxFastM + 1][3][32];
 static std::once_flag g_c32_once;
 
 static void init_registry()
 {
-    const KernelRegistry r{g_c32, g_pre, g_pre2, g_u8, g_u8_pairs};
+    const KernelRegistry r{g_c32, g_pre, g_pre2, g_u8, g_u8_pairs, g_pre2_multi};
     register_score_c32_0(r);
     register_score_c32_1(r);
     register_score_c32_2(r);
@@ -73,6 +74,12 @@ PrefilterLauncher score_c32_prefilter2_lookup(int M)
 {
     std::call_once(g_c32_once, init_registry);
     return (M >= 1 && M <= kMaxFastM) ? g_pre2[M] : nullptr;
+}
+
+PrefilterMultiLauncher score_c32_prefilter2_multi_lookup(int M)
+{
+    std::call_once(g_c32_once, init_registry);
+    return (M >= 1 && M <= kMaxFastM) ? g_pre2_multi[M] : nullptr;
 }
 
 ScoreC32Launcher score_c32_lookup_store_argmax(int M)
@@ -893,9 +900,16 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
     });
     const unsigned long long key_rows =
         keys == HitKeys::Position ? (unsigned long long)(jobs[0].row_end - jobs[0].row_begin) : 0;
-    std::vector<BatchParams> bparams;  // in launch order: the jobs of a group are contiguous
-    bparams.reserve(n);
-    for (const JobGroup &g : groups)
+    // job table in launch order: the jobs of a group are contiguous from group_pos[g] on.  Groups
+    // of the pair scan with several jobs run `per_pass[g]` motifs per pass
+    // (score_c32_prefilter2_multi) and are padded to a multiple of that with entries that flag nothing.
+    std::vector<BatchParams> bparams;
+    std::vector<size_t> group_pos(groups.size());
+    std::vector<int> per_pass(groups.size(), 1);
+    bparams.reserve(n + 4 * groups.size());
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const JobGroup &g = groups[gi];
+        group_pos[gi] = bparams.size();
         for (size_t i : g.idx) {
             const ScoreArgs &a = jobs[i];
             if (keys == HitKeys::Position && a.row_end - a.row_begin != key_rows)
@@ -907,6 +921,18 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
             rjobs[i] = RescoreJob{a.d_seq + a.row_begin * a.seq_stride, a.pssm->d_dense,
                                   (unsigned)a.pssm->m, (unsigned)a.pssm->k, ts[i], 0, key_rows};
         }
+        const int m = (int)jobs[g.idx[0]].pssm->m;
+        if (g.kind == KIND_PREFILTER2 && ctx->multi_motif && n > 1 && g.idx.size() >= 2 &&
+            score_c32_prefilter2_multi_lookup(m)) {
+            per_pass[gi] = prefilter2_multi(m);
+            while ((bparams.size() - group_pos[gi]) % per_pass[gi]) {
+                BatchParams pad = bparams.back();
+                pad.td = 0xffffffffu;  // no sum reaches it: the padding job flags nothing
+                bparams.push_back(pad);
+            }
+        }
+    }
+    const size_t nbp = bparams.size();
     for (int attempt = 0; attempt < 3; ++attempt) {
         // layout: [hit count u64][candidate count u64][jobs][batch][HitRecord x cap][Candidate x ccap];
         // the head -- zeroed counters and the two job tables -- is assembled in the upper half of the
@@ -916,7 +942,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
         // re-scoring kernel at 10^6 hits)
         const size_t off_jobs = 256;
         const size_t off_batch = off_jobs + (n * sizeof(RescoreJob) + 15) / 16 * 16;
-        const size_t off_hits = off_batch + (n * sizeof(BatchParams) + 15) / 16 * 16;
+        const size_t off_hits = off_batch + (nbp * sizeof(BatchParams) + 15) / 16 * 16;
         const size_t off_cands = off_hits + cap * sizeof(HitRecord);
         LM_TRY(ctx->scratch.reserve(off_cands + ccap * sizeof(Candidate)));
         char *base = static_cast<char *>(ctx->scratch.ptr);
@@ -935,29 +961,37 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
             memset(head, 0, off_jobs);
             memcpy(head + off_jobs, rjobs.data(), n * sizeof(RescoreJob));
             if (n > 1)
-                memcpy(head + off_batch, bparams.data(), n * sizeof(BatchParams));
+                memcpy(head + off_batch, bparams.data(), nbp * sizeof(BatchParams));
             LM_HIP_TRY(hipMemcpyAsync(base, head, n > 1 ? off_hits : off_batch, hipMemcpyHostToDevice, ctx->stream));
         } else {
             LM_HIP_TRY(hipMemsetAsync(base, 0, 16, ctx->stream));
             LM_HIP_TRY(hipMemcpyAsync(d_jobs, rjobs.data(), n * sizeof(RescoreJob), hipMemcpyHostToDevice,
                                       ctx->stream));
-            LM_HIP_TRY(hipMemcpyAsync(d_bparams, bparams.data(), n * sizeof(BatchParams), hipMemcpyHostToDevice,
+            LM_HIP_TRY(hipMemcpyAsync(d_bparams, bparams.data(), nbp * sizeof(BatchParams), hipMemcpyHostToDevice,
                                       ctx->stream));
         }
         const bool two_streams = groups.size() > 1;
         if (two_streams)
             LM_TRY(batch_fork(ctx));
         bool any_candidates = false;
-        size_t launch = 0, bp_pos = 0;
-        for (const JobGroup &g : groups) {
+        size_t launch = 0;
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            const JobGroup &g = groups[gi];
+            const size_t bp_pos = group_pos[gi];
             const size_t i = g.idx[0];
             const ScoreArgs &a = jobs[i];
             hipStream_t st = (two_streams && (launch++ & 1)) ? ctx->aux_stream : ctx->stream;
             fo.threshold = ts[i];
             fo.job_key = (unsigned long long)i << 40;
             fo.batch = (n > 1 && g.kind != KIND_GENERIC) ? d_bparams + bp_pos : nullptr;
-            bp_pos += g.idx.size();
-            if (g.kind == KIND_PREFILTER || g.kind == KIND_PREFILTER2) {
+            if (per_pass[gi] > 1) {  // several motifs of this length per pass over the sequence
+                dim3 grid = g.plan.grid;
+                grid.y = (unsigned)((g.idx.size() + per_pass[gi] - 1) / per_pass[gi]);
+                ctx->last_kernel = "score_c32_prefilter2_multi";
+                LM_HIP_TRY(score_c32_prefilter2_multi_lookup((int)a.pssm->m)(grid, st, a.d_seq, a.row_begin, a.row_end,
+                                                                            g.plan.T, g.plan.nstreams, fo));
+                any_candidates = true;
+            } else if (g.kind == KIND_PREFILTER || g.kind == KIND_PREFILTER2) {
                 const bool pairs = g.kind == KIND_PREFILTER2;
                 PrefilterLauncher fn = pairs ? score_c32_prefilter2_lookup((int)a.pssm->m)
                                              : score_c32_prefilter_lookup((int)a.pssm->m);
@@ -1314,36 +1348,58 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
         for (size_t q : g.idx)
             pairs_of[q] = g.kind == KIND_PREFILTER2;
     std::vector<BatchParams> bparams;  // launch order; rjobs / sjobs are permuted the same way
-    std::vector<size_t> order;
-    for (const JobGroup &g : groups)
-        for (size_t q : g.idx)
+    // positions in launch order; groups of the pair scan with several jobs run `per_pass[g]`
+    // motifs per pass and are padded to a multiple of that (a padding position samples nothing,
+    // so argmax_prepare leaves its td at "skip" and it flags nothing)
+    std::vector<size_t> order, group_pos(groups.size());
+    std::vector<char> is_pad;
+    std::vector<int> per_pass(groups.size(), 1);
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const JobGroup &g = groups[gi];
+        group_pos[gi] = order.size();
+        for (size_t q : g.idx) {
             order.push_back(q);
-    std::vector<SampleJob> sj(nq);
-    std::vector<RescoreJob> rj(nq);
-    for (size_t pos = 0; pos < nq; ++pos) {
+            is_pad.push_back(0);
+        }
+        const int m = (int)qjobs[g.idx[0]].pssm->m;
+        if (g.kind == KIND_PREFILTER2 && ctx->multi_motif && g.idx.size() >= 2 &&
+            score_c32_prefilter2_multi_lookup(m)) {
+            per_pass[gi] = prefilter2_multi(m);
+            while ((order.size() - group_pos[gi]) % per_pass[gi]) {
+                order.push_back(g.idx.back());
+                is_pad.push_back(1);
+            }
+        }
+    }
+    const size_t npos = order.size();
+    std::vector<SampleJob> sj(npos);
+    std::vector<RescoreJob> rj(npos);
+    for (size_t pos = 0; pos < npos; ++pos) {
         const size_t q = order[pos];
         sj[pos] = sjobs[q];
+        if (is_pad[pos])
+            sj[pos].nchunks = 0;
         rj[pos] = rjobs[q];
         bparams.push_back(BatchParams{pairs_of[q] ? qjobs[q].pssm->d_image2 : qjobs[q].pssm->d_image, nullptr,
                                       0.0f, 0xffffffffu, (unsigned long long)pos << 40});
     }
     // ~1024 cells tie with or beat the bound of a 1/1024 sample; leave room for 8x that
-    const unsigned long long cap = nq * 8192 + (1 << 16), ccap = 4 * cap;
+    const unsigned long long cap = npos * 8192 + (1 << 16), ccap = 4 * cap;
     // layout: the head -- counters | sample bounds | best values | best keys | the three job tables --
     // is assembled in the upper half of the pinned buffer and reaches the device as ONE copy
     // (three memsets and three staged copies from pageable memory cost more than the sample pass)
     const unsigned sgrid = (unsigned)std::min<unsigned long long>(
-        max_chunks, std::max<unsigned long long>((unsigned long long)ctx->num_cus * 8 / nq, 16));
+        max_chunks, std::max<unsigned long long>((unsigned long long)ctx->num_cus * 8 / npos, 16));
     const size_t off_bval = 256;  // the counters keep their cache lines to themselves
-    const size_t off_bkey = (off_bval + nq * 4 + 15) / 16 * 16;
-    const size_t off_rj = off_bkey + nq * 8;
-    const size_t off_bp = off_rj + (nq * sizeof(RescoreJob) + 15) / 16 * 16;
-    const size_t off_sj = off_bp + (nq * sizeof(BatchParams) + 15) / 16 * 16;
-    const size_t off_res = off_sj + (nq * sizeof(SampleJob) + 15) / 16 * 16;
-    const size_t off_hits = off_res + nq * sizeof(ArgmaxRecord);
+    const size_t off_bkey = (off_bval + npos * 4 + 15) / 16 * 16;
+    const size_t off_rj = off_bkey + npos * 8;
+    const size_t off_bp = off_rj + (npos * sizeof(RescoreJob) + 15) / 16 * 16;
+    const size_t off_sj = off_bp + (npos * sizeof(BatchParams) + 15) / 16 * 16;
+    const size_t off_res = off_sj + (npos * sizeof(SampleJob) + 15) / 16 * 16;
+    const size_t off_hits = off_res + npos * sizeof(ArgmaxRecord);
     const size_t off_cands = off_hits + cap * sizeof(HitRecord);
     const size_t off_partial = off_cands + ccap * sizeof(Candidate);  // the sample's per-workgroup maxima
-    LM_TRY(ctx->scratch.reserve(off_partial + nq * sgrid * sizeof(unsigned)));
+    LM_TRY(ctx->scratch.reserve(off_partial + npos * sgrid * sizeof(unsigned)));
     char *base = static_cast<char *>(ctx->scratch.ptr);
     FusedOut fo{};
     fo.hit_count = reinterpret_cast<unsigned long long *>(base);
@@ -1363,33 +1419,41 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
     if (off_res <= kPinnedBytes / 2) {
         char *head = static_cast<char *>(ctx->pinned) + kPinnedBytes / 2;
         memset(head, 0, off_rj);
-        for (size_t q = 0; q < nq; ++q)  // best values start at -inf
+        for (size_t q = 0; q < npos; ++q)  // best values start at -inf
             reinterpret_cast<unsigned *>(head + off_bval)[q] = kOrderedNegInf;
-        memcpy(head + off_rj, rj.data(), nq * sizeof(RescoreJob));
-        memcpy(head + off_bp, bparams.data(), nq * sizeof(BatchParams));
-        memcpy(head + off_sj, sj.data(), nq * sizeof(SampleJob));
+        memcpy(head + off_rj, rj.data(), npos * sizeof(RescoreJob));
+        memcpy(head + off_bp, bparams.data(), npos * sizeof(BatchParams));
+        memcpy(head + off_sj, sj.data(), npos * sizeof(SampleJob));
         LM_HIP_TRY(hipMemcpyAsync(base, head, off_res, hipMemcpyHostToDevice, st));
     } else {
         LM_HIP_TRY(hipMemsetAsync(base, 0, 16, st));
-        LM_HIP_TRY(hipMemsetAsync(d_bkey, 0, nq * 8, st));
-        LM_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_bval), (int)kOrderedNegInf, nq, st));
-        LM_HIP_TRY(hipMemcpyAsync(d_rj, rj.data(), nq * sizeof(RescoreJob), hipMemcpyHostToDevice, st));
-        LM_HIP_TRY(hipMemcpyAsync(d_bp, bparams.data(), nq * sizeof(BatchParams), hipMemcpyHostToDevice, st));
-        LM_HIP_TRY(hipMemcpyAsync(d_sj, sj.data(), nq * sizeof(SampleJob), hipMemcpyHostToDevice, st));
+        LM_HIP_TRY(hipMemsetAsync(d_bkey, 0, npos * 8, st));
+        LM_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_bval), (int)kOrderedNegInf, npos, st));
+        LM_HIP_TRY(hipMemcpyAsync(d_rj, rj.data(), npos * sizeof(RescoreJob), hipMemcpyHostToDevice, st));
+        LM_HIP_TRY(hipMemcpyAsync(d_bp, bparams.data(), npos * sizeof(BatchParams), hipMemcpyHostToDevice, st));
+        LM_HIP_TRY(hipMemcpyAsync(d_sj, sj.data(), npos * sizeof(SampleJob), hipMemcpyHostToDevice, st));
     }
-    hipLaunchKernelGGL(argmax_sample, dim3(sgrid, (unsigned)nq), dim3(kBlock), 0, st, d_sj, d_partial);
-    hipLaunchKernelGGL(argmax_prepare, dim3((unsigned)nq), dim3(64), 0, st, d_sj, (unsigned)nq, d_partial, sgrid,
+    hipLaunchKernelGGL(argmax_sample, dim3(sgrid, (unsigned)npos), dim3(kBlock), 0, st, d_sj, d_partial);
+    hipLaunchKernelGGL(argmax_prepare, dim3((unsigned)npos), dim3(64), 0, st, d_sj, (unsigned)npos, d_partial, sgrid,
                        d_rj, d_bp);
     LM_HIP_TRY(hipGetLastError());
     const bool two_streams = groups.size() > 1;
     if (two_streams)
         LM_TRY(batch_fork(ctx));
-    size_t launch = 0, bp_pos = 0;
-    for (const JobGroup &g : groups) {
+    size_t launch = 0;
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const JobGroup &g = groups[gi];
         const ScoreArgs &a = qjobs[g.idx[0]];
         hipStream_t ls = (two_streams && (launch++ & 1)) ? ctx->aux_stream : st;
-        fo.batch = d_bp + bp_pos;
-        bp_pos += g.idx.size();
+        fo.batch = d_bp + group_pos[gi];
+        if (per_pass[gi] > 1) {  // several motifs of this length per pass over the sequence
+            dim3 grid = g.plan.grid;
+            grid.y = (unsigned)((g.idx.size() + per_pass[gi] - 1) / per_pass[gi]);
+            ctx->last_kernel = "score_c32_prefilter2_multi";
+            LM_HIP_TRY(score_c32_prefilter2_multi_lookup((int)a.pssm->m)(grid, ls, a.d_seq, a.row_begin, a.row_end,
+                                                                        g.plan.T, g.plan.nstreams, fo));
+            continue;
+        }
         const bool pairs = g.kind == KIND_PREFILTER2;
         PrefilterLauncher fn = pairs ? score_c32_prefilter2_lookup((int)a.pssm->m)
                                      : score_c32_prefilter_lookup((int)a.pssm->m);
@@ -1406,27 +1470,27 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
     hipLaunchKernelGGL(hits_best_key, dim3(hgrid), dim3(kBlock), 0, st, fo.hits, fo.hit_count, cap, d_bval,
                        d_bkey);
     // results and the two list counters are written straight into the pinned buffer's lower half
-    const bool pin = 16 + nq * sizeof(ArgmaxRecord) <= kPinnedBytes / 2;
+    const bool pin = 16 + npos * sizeof(ArgmaxRecord) <= kPinnedBytes / 2;
     ArgmaxRecord *res = pin ? reinterpret_cast<ArgmaxRecord *>(static_cast<char *>(ctx->pinned) + 16) : d_res;
-    hipLaunchKernelGGL(argmax_collect, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (unsigned)nq,
+    hipLaunchKernelGGL(argmax_collect, dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, st, (unsigned)npos,
                        d_bval, d_bkey, res, fo.hit_count,
                        pin ? static_cast<unsigned long long *>(ctx->pinned) : static_cast<unsigned long long *>(nullptr));
     LM_HIP_TRY(hipGetLastError());
-    std::vector<ArgmaxRecord> host_res(pin ? 0 : nq);
+    std::vector<ArgmaxRecord> host_res(pin ? 0 : npos);
     if (!pin) {
         LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, base, 16, hipMemcpyDeviceToHost, st));
-        LM_HIP_TRY(hipMemcpyAsync(host_res.data(), d_res, nq * sizeof(ArgmaxRecord), hipMemcpyDeviceToHost, st));
+        LM_HIP_TRY(hipMemcpyAsync(host_res.data(), d_res, npos * sizeof(ArgmaxRecord), hipMemcpyDeviceToHost, st));
     }
     LM_HIP_TRY(hipStreamSynchronize(st));
     const unsigned long long nhits = static_cast<unsigned long long *>(ctx->pinned)[0];
     const unsigned long long ncand = static_cast<unsigned long long *>(ctx->pinned)[1];
     if (getenv("LM_HIP_TRACE"))
         fprintf(stderr, "[lm_hip] candidate-route argmax: %zu jobs, %llu candidates (room %llu), %llu hits (room %llu)\n",
-                nq, ncand, ccap, nhits, cap);
+                npos, ncand, ccap, nhits, cap);
     if (nhits > cap || ncand > ccap)
         return LM_HIP_OK;  // truncated lists prove nothing: the exact kernel takes over
     const ArgmaxRecord *r = pin ? res : host_res.data();
-    for (size_t pos = 0; pos < nq; ++pos)
+    for (size_t pos = 0; pos < npos; ++pos)
         if (r[pos].found) {
             const size_t i = pick[order[pos]];
             out[i] = r[pos];

@@ -21,6 +21,8 @@ struct RegisterRange {
         if constexpr (M >= 2) {
             r.pre2[M] = &score_c32_prefilter2_launch<M>;
             r.u8_pairs[M] = &score_c32_u8_pairs_launch<M>;
+            if constexpr (prefilter2_multi(M) > 1)
+                r.pre2_multi[M] = &score_c32_prefilter2_multi_launch<M>;
         }
         ScoreC32Launcher *tab = r.c32[M];
         tab[MODE_STORE] = &score_c32_launch<M, MODE_STORE>;

@@ -272,6 +272,198 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter2(
     });
 }
 
+// ---- several motifs of one length per pass ------------------------------------------------------
+//
+// On many-motif batches the sequence is cache-resident and the scan is bound by instruction
+// issue; about half of a super-step's instructions fetch and decode the two symbols and
+// compute the table row -- work that does not depend on the motif.  This kernel advances NM
+// motifs of the same length per pass: one decode, NM table reads / adds / maxima.  Launched
+// with grid.y = ceil(jobs / NM) on the `batch` array (padded to a multiple of NM with entries
+// whose td = 0xffffffff flags nothing).
+constexpr int prefilter2_multi(int m)  // motifs per pass: bounded by the accumulator registers
+{
+    return prefilter2_npair(m) <= 6 ? 4 : prefilter2_npair(m) <= 12 ? 2 : 1;
+}
+
+template <int M, int NM, int PFB, int PHASE>
+__device__ __forceinline__ void prefilter2_group_multi(unsigned (&acc)[NM][prefilter2_npair(M)],
+                                                       unsigned (&blk)[prefilter2_ring(M) / 4],
+                                                       const uint8_t *__restrict__ spq, const unsigned shq,
+                                                       const char *__restrict__ tab, unsigned (&mx)[NM])
+{
+    constexpr int RING = prefilter2_ring(M);
+    constexpr int NB = RING / 4;
+    constexpr int NP = prefilter2_npair(M);
+    constexpr int NV = (NP + 3) / 4;
+    constexpr unsigned DSB = prefilter2_stride_dw(M) * 4;
+    constexpr unsigned IMG = prefilter2_image_dw(M) * 4;  // bytes per motif's table
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const unsigned d = blk[k / 2];
+        const unsigned a = (k & 1) ? quad_symbol<2>(d, shq) : quad_symbol<0>(d, shq);
+        const unsigned b = (k & 1) ? quad_symbol<3>(d, shq) : quad_symbol<1>(d, shq);
+        if ((k & 1) && (PHASE != PHASE_LAST || k / 2 + PFB < NB))
+            blk[(k / 2 + PFB) % NB] = *reinterpret_cast<const unsigned *>(spq + (k / 2 + PFB) * 128);
+        const char *row0 = tab + __umul24(dna_pair_row(a, b), DSB);
+#pragma unroll
+        for (int mi = 0; mi < NM; ++mi) {
+            const char *row = static_cast<const char *>(__builtin_assume_aligned(row0 + mi * IMG, 16));
+            unsigned w[NV * 4];
+#pragma unroll
+            for (int q = 0; q < NP / 4; ++q) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(row + 16 * q);
+                w[4 * q + 0] = v.x;
+                w[4 * q + 1] = v.y;
+                w[4 * q + 2] = v.z;
+                w[4 * q + 3] = v.w;
+            }
+            if (NP % 4 >= 2) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(row + 16 * (NP / 4));
+                w[4 * (NP / 4) + 0] = v.x;
+                w[4 * (NP / 4) + 1] = v.y;
+            }
+            if (NP % 2 == 1)
+                w[NP - 1] = *reinterpret_cast<const unsigned *>(row + 4 * (NP - 1));
+#pragma unroll
+            for (int m = 0; m < NP; ++m)
+                acc[mi][(k - m + NP) % NP] = pk_add_u16(acc[mi][(k - m + NP) % NP], w[m]);
+            const int c = (k + 1) % NP;
+            if (PHASE != PHASE_FIRST || k == NP - 1)
+                mx[mi] = pk_max_u16(mx[mi], acc[mi][c]);
+            acc[mi][c] = 0;
+        }
+    }
+}
+
+template <int M, int NM>
+__global__ __launch_bounds__(kBlock, 4) void score_c32_prefilter2_multi(
+    const uint8_t *__restrict__ seq, const unsigned long long row_begin, const unsigned long long row_end,
+    const unsigned long long T, const unsigned long long nstreams, const FusedOut fo_in)
+{
+    static_assert(prefilter2_image_dw(M) % 4 == 0, "tables are copied 16 bytes at a time");
+    constexpr int MO = prefilter2_mo(M);
+    constexpr int SHIFT = MO - M;
+    constexpr int RING = prefilter2_ring(M);
+    constexpr int NP = prefilter2_npair(M);
+    constexpr int IMG_DW = prefilter2_image_dw(M);
+    const BatchParams *bps = fo_in.batch + (size_t)blockIdx.y * NM;  // this workgroup's NM jobs
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+#pragma unroll
+    for (int mi = 0; mi < NM; ++mi) {
+        uint4 *dst = reinterpret_cast<uint4 *>(lds_raw) + mi * (IMG_DW / 4);
+        const uint4 *src = static_cast<const uint4 *>(bps[mi].table);
+        for (int i = threadIdx.x; i < IMG_DW / 4; i += kBlock)
+            dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 31;
+    unsigned long long stream =
+        ((unsigned long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    const bool idle = stream >= nstreams;
+    if (idle)
+        stream = nstreams - 1;
+    unsigned long long o0 = row_begin + stream * T;
+    if (o0 + T > row_end)
+        o0 = row_end - T;
+    const long long in0 = (long long)o0 - SHIFT;
+    const unsigned shq = 8u * (col & 3);
+    const uint8_t *spq = seq + (in0 + (col & 3)) * 32 + (col >> 2) * 4;
+    constexpr int NB = RING / 4;
+    constexpr int PFB = NB > 3 ? 3 : NB;
+    unsigned acc[NM][NP];
+    unsigned blk[NB];
+#pragma unroll
+    for (int mi = 0; mi < NM; ++mi)
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            acc[mi][i] = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+        blk[j] = 0;
+    if (in0 + (long long)(col & 3) >= 0)
+        blk[0] = *reinterpret_cast<const unsigned *>(spq);
+#pragma unroll
+    for (int j = 1; j < PFB; ++j)
+        blk[j] = *reinterpret_cast<const unsigned *>(spq + j * 128);
+
+    const unsigned long long ngroups = (T - 2) / RING + 1;
+    const unsigned long long G = (ngroups + 63) / 64;
+    unsigned long long gbit = 1, gleft = G;
+    unsigned long long hit_groups[NM];
+    unsigned mx[NM], td[NM];
+#pragma unroll
+    for (int mi = 0; mi < NM; ++mi) {
+        hit_groups[mi] = 0;
+        mx[mi] = 0;
+        td[mi] = bps[mi].td;
+    }
+    auto note_group = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < NM; ++mi) {
+            const bool flag = (mx[mi] & 0xffffu) >= td[mi] || (mx[mi] >> 16) >= td[mi];
+            hit_groups[mi] |= flag ? gbit : 0ull;
+            mx[mi] = 0;
+        }
+        if (--gleft == 0) {
+            gleft = G;
+            gbit <<= 1;
+        }
+    };
+    prefilter2_group_multi<M, NM, PFB, PHASE_FIRST>(acc, blk, spq, shq, lds_raw, mx);
+    note_group();
+    for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
+        spq += RING * 32;
+        prefilter2_group_multi<M, NM, PFB, PHASE_MAIN>(acc, blk, spq, shq, lds_raw, mx);
+        note_group();
+    }
+    if (ngroups > 1) {
+        spq += RING * 32;
+        prefilter2_group_multi<M, NM, PFB, PHASE_LAST>(acc, blk, spq, shq, lds_raw, mx);
+        note_group();
+    }
+
+    const long long first_row = (long long)(o0 - row_begin);
+    const long long own_row = (long long)(stream * T);
+#pragma unroll
+    for (int mi = 0; mi < NM; ++mi) {
+        FusedOut fo = fo_in;
+        fo.job_key = bps[mi].job_key;
+        emit_candidates(idle ? 0ull : hit_groups[mi], col, fo, [=](int bit, long long &r0, long long &r1) {
+            const unsigned long long g0 = (unsigned long long)bit * G;
+            unsigned long long g1 = g0 + G;
+            if (g1 > ngroups)
+                g1 = ngroups;
+            const long long i0 = g0 == 0 ? 0 : (long long)((g0 - 1) * RING + 2);
+            long long i1 = (long long)((g1 - 1) * RING + 2);
+            if (i1 > (long long)T)
+                i1 = (long long)T;
+            r0 = first_row + i0;
+            if (r0 < own_row)
+                r0 = own_row;
+            r1 = first_row + i1;
+        });
+        __syncthreads();  // emit_candidates' shared scratch is reused by the next motif
+    }
+}
+
+// grid.y = groups of NM jobs; `fo.batch` = the (padded) job table of the launch
+using PrefilterMultiLauncher = hipError_t (*)(dim3 grid, hipStream_t stream, const uint8_t *seq,
+                                              unsigned long long row_begin, unsigned long long row_end,
+                                              unsigned long long T, unsigned long long nstreams, FusedOut fo);
+
+template <int M>
+hipError_t score_c32_prefilter2_multi_launch(dim3 grid, hipStream_t stream, const uint8_t *seq,
+                                             unsigned long long row_begin, unsigned long long row_end,
+                                             unsigned long long T, unsigned long long nstreams, FusedOut fo)
+{
+    constexpr int NM = prefilter2_multi(M);
+    hipLaunchKernelGGL((score_c32_prefilter2_multi<M, NM>), grid, dim3(kBlock),
+                       (size_t)NM * prefilter2_image_dw(M) * 4, stream, seq, row_begin, row_end, T, nstreams, fo);
+    return hipGetLastError();
+}
+
 template <int M>
 hipError_t score_c32_prefilter2_launch(dim3 grid, size_t lds_bytes, hipStream_t stream,
                                        const uint8_t *seq, const unsigned *image, int K,

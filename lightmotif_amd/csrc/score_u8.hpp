@@ -190,6 +190,7 @@ struct KernelRegistry {
     ScoreC32Launcher (*c32)[kRegistrySlots];
     PrefilterLauncher *pre, *pre2;
     ScoreU8Launcher *u8, *u8_pairs;
+    PrefilterMultiLauncher *pre2_multi;  // several motifs per pass (prefilter2_multi(M) > 1)
 };
 
 }  // namespace lm

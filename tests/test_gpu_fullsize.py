@@ -413,3 +413,28 @@ def test_fused_argmax_suffix_route_random_motifs(pli):
     assert got == wants
     for k in (0, 7, 13):
         assert pli.score_argmax(pssms[k], seq) == wants[k]
+
+
+def test_candidate_route_argmax_batches_share_passes(gpu_pli):
+    """Three and five motifs of one length over 40 Mbp each (>= 100 M cells per call: the candidate
+    route; several motifs per pass, padded job table): the batch equals the single-motif calls."""
+    pli = gpu_pli
+    length = 40_000_000
+    for m, count in ((12, 3), (10, 5)):
+        seq, rows, _ = make_workload(pli, length, m, 5, seed=31 + m)
+        rng = np.random.default_rng(m)
+        pssms = []
+        for _ in range(count):
+            sites = ["".join("ACTG"[i] for i in rng.integers(0, 4, m)) for _ in range(8)]
+            pssms.append(lm.create(sites).counts.normalize(0.1).log_odds())
+        singles = [pli.score_argmax_dptr(p, seq.data_ptr(), rows + m - 1, COLS, COLS, m - 1, length, 0, rows)
+                   for p in pssms]
+        handle = lm.StripedSequence.from_device(pli, seq, length, m - 1) if hasattr(lm.StripedSequence, "from_device") else None
+        if handle is None:
+            host = seq[:rows].cpu().numpy()
+            enc = host.T.reshape(-1)[:length].copy()
+            handle = pli.stripe(lm.EncodedSequence(enc), 32)
+            handle.configure_wrap(m - 1)
+        batch = pli.scan_argmax_batch(pssms, handle)
+        assert pli.last_kernel in ("score_c32_prefilter2_multi", "argmax_collect", "score_c32_prefilter2")
+        assert batch == singles

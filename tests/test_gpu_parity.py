@@ -246,6 +246,33 @@ def test_reverse_complement_on_the_device(pli):
         lm.create(["ACDEF"], protein=True).pssm.reverse_complement()
 
 
+@pytest.mark.parametrize("m,count", [(4, 5), (9, 7), (11, 2), (13, 3), (22, 5), (30, 3)])
+def test_several_motifs_of_one_length_per_pass(pli, m, count):
+    """Batches of equal-length DNA motifs run several motifs per pass of the pair scan
+    (score_c32_prefilter2_multi; job table padded when the count is not a multiple): every
+    job must equal its own oracle result, also next to a motif of another length."""
+    rng = np.random.default_rng(100 * m + count)
+    length = 150_001
+    enc = rng.integers(0, 4, length, dtype=np.uint8)
+    ref = co.stripe(enc, 32, 5)
+    co.configure_wrap(ref, 40)
+    seq = pli.stripe(lm.EncodedSequence(enc), 32)
+    seq.configure_wrap(40)
+    mats = [random_pssm(rng, m, 5) for _ in range(count)] + [random_pssm(rng, m + 1, 5)]
+    pssms = [lm.ScoringMatrix(p) for p in mats]
+    wants = [co.score_rows(ref, p)[0] for p in mats]
+    ts = [float(np.sort(w[:, :32][np.isfinite(w[:, :32])])[-(50 + 40 * i)]) for i, w in enumerate(wants)]
+    got = pli.scan_threshold_batch(pssms, ts, seq)
+    if m <= 23:
+        assert pli.last_kernel in ("score_c32_prefilter2_multi", "score_c32_prefilter2")
+    for (coords, vals), w, t in zip(got, wants, ts):
+        assert np.array_equal(coords, co.threshold(w, 32, t))
+        assert np.array_equal(bits(vals), bits(w[coords[:, 0], coords[:, 1]]))
+    best = pli.scan_argmax_batch(pssms, seq)
+    for b, w in zip(best, wants):
+        assert b[0] == co.argmax(w, 32)
+
+
 def test_indexing_reads_single_rows(pli):
     """``scores[i]`` = cell (i % rows, i / rows) (scores.rs:246-254), fetched without downloading
     the matrix; windows of rows come back like the corresponding slice of the full copy."""
