@@ -282,7 +282,7 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter2(
 // whose td = 0xffffffff flags nothing).
 constexpr int prefilter2_multi(int m)  // motifs per pass: bounded by the accumulator registers
 {
-    return prefilter2_npair(m) <= 6 ? 4 : prefilter2_npair(m) <= 12 ? 2 : 1;
+    return prefilter2_npair(m) <= 8 ? 4 : prefilter2_npair(m) <= 16 ? 2 : 1;
 }
 
 template <int M, int NM, int PFB, int PHASE>
