@@ -6,6 +6,7 @@
 //   Score::score_into (pli/mod.rs:109-117), StripedScores::{argmax,threshold}
 //     (scores.rs:181-213).
 #include <algorithm>
+#include <sys/mman.h>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -147,6 +148,18 @@ static bool build_prefilter(lm_hip_pssm &p, std::vector<unsigned> *image, std::v
     // |f32 sum - real sum| <= (M-1) * 2^-24 * sum |terms|  (each add rounds to nearest)
     p.pre_emax = (double)m * std::ldexp(1.0, -24) * abs_sum * 1.5;
     return true;
+}
+
+void *result_alloc(size_t bytes)
+{
+    constexpr size_t kHuge = 2u << 20;
+    if (bytes < 4 * kHuge)
+        return malloc(bytes);
+    void *p = nullptr;
+    if (posix_memalign(&p, kHuge, (bytes + kHuge - 1) / kHuge * kHuge) != 0)
+        return malloc(bytes);
+    (void)madvise(p, (bytes + kHuge - 1) / kHuge * kHuge, MADV_HUGEPAGE);  // advisory: plain pages if unavailable
+    return p;
 }
 
 static int default_ctx(lm_hip_ctx **out)

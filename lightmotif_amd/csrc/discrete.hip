@@ -207,7 +207,7 @@ int launch_threshold_u8(lm_hip_ctx *ctx, const uint8_t *d_scores, size_t rows, s
     const unsigned long long count = *static_cast<unsigned long long *>(ctx->pinned);
     if (count == 0)
         return LM_HIP_OK;
-    lm_hip_coords *host = static_cast<lm_hip_coords *>(malloc(count * sizeof(lm_hip_coords)));
+    lm_hip_coords *host = static_cast<lm_hip_coords *>(result_alloc(count * sizeof(lm_hip_coords)));
     if (!host)
         return fail(LM_HIP_ERR_OOM, "threshold_u8: cannot allocate %llu hits on the host", count);
     int st = ctx->scratch2.reserve(count * sizeof(lm_hip_coords));

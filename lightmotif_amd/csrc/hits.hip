@@ -308,8 +308,8 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
         count = counts_out[0];
         if (count == 0)
             return LM_HIP_OK;
-        void *host = malloc(count * rec_bytes);
-        float *host_values = emit == 0 ? static_cast<float *>(malloc(count * sizeof(float))) : nullptr;
+        void *host = result_alloc(count * rec_bytes);
+        float *host_values = emit == 0 ? static_cast<float *>(result_alloc(count * sizeof(float))) : nullptr;
         if (!host || (emit == 0 && !host_values)) {
             free(host);
             free(host_values);
@@ -345,8 +345,8 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
         return LM_HIP_OK;
     }
 
-    void *host = malloc(count * rec_bytes);
-    float *host_values = emit == 0 ? static_cast<float *>(malloc(count * sizeof(float))) : nullptr;
+    void *host = result_alloc(count * rec_bytes);
+    float *host_values = emit == 0 ? static_cast<float *>(result_alloc(count * sizeof(float))) : nullptr;
     if (!host || (emit == 0 && !host_values)) {
         free(host);
         free(host_values);

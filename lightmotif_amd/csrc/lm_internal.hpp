@@ -51,6 +51,12 @@ struct ArgmaxRecord {
 
 constexpr size_t kPinnedBytes = 4u << 20;  // pinned staging buffer per context
 
+// Host arrays handed to the caller (released with lm_hip_free = free).  Large ones are
+// 2 MB-aligned and marked for transparent huge pages: a fresh 50 MB block otherwise takes
+// ~13 000 first-touch page faults while the read-back lands in it (25 ms on the JASPAR batch,
+// more than half of the scans it follows).
+void *result_alloc(size_t bytes);
+
 }  // namespace lm
 
 // ---- opaque handle definitions ------------------------------------------------

@@ -370,7 +370,7 @@ int launch_threshold(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t
     if (count == 0)
         return LM_HIP_OK;
 
-    lm_hip_coords *host = static_cast<lm_hip_coords *>(malloc(count * sizeof(lm_hip_coords)));
+    lm_hip_coords *host = static_cast<lm_hip_coords *>(result_alloc(count * sizeof(lm_hip_coords)));
     if (!host)
         return fail(LM_HIP_ERR_OOM, "threshold: cannot allocate %llu hits on the host", count);
     int st = ctx->scratch2.reserve(count * sizeof(lm_hip_coords));

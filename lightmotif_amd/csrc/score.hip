@@ -1518,21 +1518,28 @@ constexpr unsigned long long kSuffixMinRows = 1ull << 15;  // keeps the streams 
 static int argmax_by_suffix(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n, ArgmaxRecord *out,
                             char *done)
 {
-    std::vector<ScoreArgs> subs;
-    std::vector<size_t> idx;
-    std::vector<float> bound;
+    // Two ways to look at a suffix.  Where a best k-mer is dense in it (short motifs) the exact
+    // argmax kernel scores it.  Where it is sparse, the suffix may be long (up to half the
+    // range) and the fused THRESHOLD at t = B scans it instead: the packed pair scan flags the
+    // cells that can reach B, the exact re-scoring keeps those that do, and the last hit in
+    // row-major order is the argmax.
+    std::vector<ScoreArgs> subs, tsubs;
+    std::vector<size_t> idx, tidx;
+    std::vector<float> bound, tbound;
     for (size_t i = 0; i < n; ++i) {
         const ScoreArgs &a = jobs[i];
         const lm_hip_pssm *p = a.pssm;
         if (done[i] || !p->has_prefilter || p->m < 1)  // has_prefilter: no NaN / +inf weights
             continue;
         const unsigned long long rows = a.row_end - a.row_begin;
-        const double need_cells = kSuffixExpectedOccurrences * std::pow((double)(p->k - 1), (double)p->m);
+        const double kmers = std::pow((double)(p->k - 1), (double)p->m);
+        const double need_cells = kSuffixExpectedOccurrences * kmers;
         if (!(need_cells < 1e15))
             continue;
         const unsigned long long need_rows =
             std::max<unsigned long long>((unsigned long long)(need_cells / (double)a.cols) + 1, kSuffixMinRows);
-        if (need_rows > rows / 4)
+        const bool dense = (double)need_rows * (double)a.cols / kmers > 256.0;  // expected hits at t = B
+        if (need_rows > (dense ? rows / 4 : rows / 2))
             continue;
         float b = 0.0f;  // the score of a best k-mer: row maxima added in motif order
         for (size_t j = 0; j < p->m; ++j) {
@@ -1545,22 +1552,45 @@ static int argmax_by_suffix(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n, Ar
             continue;
         ScoreArgs sub = a;
         sub.row_begin = a.row_end - need_rows;
-        subs.push_back(sub);
-        idx.push_back(i);
-        bound.push_back(b);
+        (dense ? subs : tsubs).push_back(sub);
+        (dense ? idx : tidx).push_back(i);
+        (dense ? bound : tbound).push_back(b);
     }
-    if (subs.empty())
-        return LM_HIP_OK;
-    std::vector<ArgmaxRecord> recs(subs.size());
-    LM_TRY(launch_score_argmax_exact(ctx, subs.data(), subs.size(), 0, recs.data()));
-    for (size_t q = 0; q < subs.size(); ++q) {
-        const ArgmaxRecord &r = recs[q];
-        if (!r.found || !(r.value == bound[q]))
-            continue;  // no best k-mer among the last rows
-        const size_t i = idx[q];
-        out[i] = r;
-        out[i].index += (long long)((subs[q].row_begin - jobs[i].row_begin) * jobs[i].cols);
-        done[i] = 1;
+    if (!subs.empty()) {
+        std::vector<ArgmaxRecord> recs(subs.size());
+        LM_TRY(launch_score_argmax_exact(ctx, subs.data(), subs.size(), 0, recs.data()));
+        for (size_t q = 0; q < subs.size(); ++q) {
+            const ArgmaxRecord &r = recs[q];
+            if (!r.found || !(r.value == bound[q]))
+                continue;  // no best k-mer among the last rows
+            const size_t i = idx[q];
+            out[i] = r;
+            out[i].index += (long long)((subs[q].row_begin - jobs[i].row_begin) * jobs[i].cols);
+            done[i] = 1;
+        }
+    }
+    if (!tsubs.empty()) {
+        // (the list-size memory of the threshold calls belongs to the caller's threshold scans)
+        const unsigned long long keep_hits = ctx->last_hit_count, keep_cands = ctx->last_cand_count;
+        HitOutput ho;
+        const int st = launch_score_threshold_batch(ctx, tsubs.data(), tbound.data(), tsubs.size(), HitKeys::RowMajor, &ho);
+        ctx->last_hit_count = keep_hits;
+        ctx->last_cand_count = keep_cands;
+        if (st != LM_HIP_OK) {
+            ho.release();
+            return st;
+        }
+        for (size_t q = 0; q < tsubs.size(); ++q) {
+            if (ho.job_start[q + 1] == ho.job_start[q])
+                continue;  // no best k-mer among the last rows
+            const size_t last = ho.job_start[q + 1] - 1, i = tidx[q];
+            out[i].value = ho.values[last];
+            out[i].found = 1;
+            out[i].index = (long long)((ho.coords[last].row + (tsubs[q].row_begin - jobs[i].row_begin)) * jobs[i].cols +
+                                       ho.coords[last].col);
+            done[i] = 1;
+        }
+        ho.release();
     }
     return LM_HIP_OK;
 }
