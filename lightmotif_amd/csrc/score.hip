@@ -1384,7 +1384,10 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
                                       0.0f, 0xffffffffu, (unsigned long long)pos << 40});
     }
     // ~1024 cells tie with or beat the bound of a 1/1024 sample; leave room for 8x that
-    const unsigned long long cap = npos * 8192 + (1 << 16), ccap = 4 * cap;
+    // (bounded at 32 M / 128 M records = 2.5 GB for very large batches: lists that overflow send
+    // the batch to the exact kernel, they never change a result)
+    const unsigned long long cap = std::min<unsigned long long>(npos * 8192 + (1 << 16), 32ull << 20),
+                             ccap = 4 * cap;
     // layout: the head -- counters | sample bounds | best values | best keys | the three job tables --
     // is assembled in the upper half of the pinned buffer and reaches the device as ONE copy
     // (three memsets and three staged copies from pageable memory cost more than the sample pass)
