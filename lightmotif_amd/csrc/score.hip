@@ -1119,6 +1119,28 @@ constexpr unsigned kOrderedNegInf = 0x007fffffu;  // ordered_bits(-inf)
 // bytes (3.9 M scattered cells = 1.3 ms), a chunk reads its rows once.
 constexpr unsigned kSampleRows = kBlock / 32;  // one row per half-wave: a chunk is one pass of the block
 constexpr unsigned kMaxSampleM = kMaxFastM;    // the candidate route needs a prefilter kernel: M <= kMaxFastM
+// exact score of the cell at `p` for a motif of at most MAXM rows: all symbol loads in flight at
+// once, then all weight loads, then the reference's add order -- one HBM latency + one L2 latency
+// per chunk instead of M / 4 of each (slots past the motif re-read its last row; the wrap rows
+// keep the address valid)
+template <unsigned MAXM>
+__device__ __forceinline__ float sample_cell(const SampleJob &jb, const uint8_t *__restrict__ p)
+{
+    unsigned sy[MAXM];
+    float w[MAXM];
+#pragma unroll
+    for (unsigned j = 0; j < MAXM; ++j)
+        sy[j] = p[(j < jb.m ? j : jb.m - 1) * 32];
+#pragma unroll
+    for (unsigned j = 0; j < MAXM; ++j)
+        w[j] = jb.dense[(j < jb.m ? j : jb.m - 1) * jb.k + sy[j]];
+    float sc = 0.0f;
+#pragma unroll
+    for (unsigned j = 0; j < MAXM; ++j)
+        sc = j < jb.m ? sc + w[j] : sc;
+    return sc;
+}
+
 __global__ __launch_bounds__(kBlock) void argmax_sample(const SampleJob *__restrict__ jobs,
                                                         unsigned *__restrict__ partial)
 {
@@ -1128,21 +1150,10 @@ __global__ __launch_bounds__(kBlock) void argmax_sample(const SampleJob *__restr
     for (unsigned long long c = blockIdx.x; c < jb.nchunks; c += gridDim.x) {
         const unsigned long long r0 = c * jb.stride;  // chunk rows r0 .. r0 + kSampleRows - 1
         const uint8_t *p = jb.seq + (r0 + sub) * 32 + col;
-        // all symbol loads of the cell in flight at once, then all weight loads, then the
-        // reference's add order: one HBM latency + one L2 latency per chunk instead of M / 4 of each
-        // (rows past the motif re-read its last row; the wrap rows keep the address valid)
-        unsigned sy[kMaxSampleM];
-        float w[kMaxSampleM];
-#pragma unroll
-        for (unsigned j = 0; j < kMaxSampleM; ++j)
-            sy[j] = p[(j < jb.m ? j : jb.m - 1) * 32];
-#pragma unroll
-        for (unsigned j = 0; j < kMaxSampleM; ++j)
-            w[j] = jb.dense[(j < jb.m ? j : jb.m - 1) * jb.k + sy[j]];
-        float sc = 0.0f;
-#pragma unroll
-        for (unsigned j = 0; j < kMaxSampleM; ++j)
-            sc = j < jb.m ? sc + w[j] : sc;
+        // (three unroll depths: most motifs of a batch are short, and every slot costs two loads)
+        const float sc = jb.m <= 12   ? sample_cell<12>(jb, p)
+                         : jb.m <= 24 ? sample_cell<24>(jb, p)
+                                      : sample_cell<kMaxSampleM>(jb, p);
         const unsigned key = ordered_bits(sc);
         best = key > best ? key : best;
     }
