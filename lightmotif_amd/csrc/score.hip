@@ -848,8 +848,9 @@ __global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const Rescor
 // (key, score) hit records, key = (job << 40) | row-major cell index or sequence
 // position; hits.hip then orders the list on the device (the reference's row-major
 // push order, pli/mod.rs:212-218, or ascending position) and the result is copied
-// straight into the arrays handed to the caller.  Two synchronisations: the counts,
-// the result.
+// straight into the arrays handed to the caller.  One synchronisation when the ordering can be
+// enqueued behind the scans (hits.hip: speculative form), two when the count is read first.
+// Equal-length DNA motifs of a batch share passes over the sequence (score_c32_prefilter2_multi).
 int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const float *ts, size_t n,
                                  HitKeys keys, HitOutput *out)
 {
