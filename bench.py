@@ -8,8 +8,12 @@ row-sharded with an M-1-row halo, configs[3]).
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A *step* is one full ``score_into`` (pli/mod.rs:109-117) of the rank's shard into a
-resident StripedScores matrix: 1 B read + 4 B written per position.  Inputs are
-resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+resident StripedScores matrix: 1 B read + 4 B written per position.  At N > 1 every step
+also produces what ``scores.argmax()`` returns for the WHOLE sequence: the shard's argmax
+(tracked by the store kernel) merged over RCCL through the C ABI's own communicator
+("wall time of the slowest rank incl. the RCCL merge").  Inputs (SplitMix64
+stream) are resident in HBM before the timed region; a time-based preheat runs
+before the counted warm-up.  Rank 0 prints ONE JSON line.
 
 PyTorch is plumbing only (device buffers, stream, process group); every timed
 kernel is the hand-written HIP code behind include/lightmotif_hip.h.
@@ -36,6 +40,49 @@ from lightmotif_amd import distributed as D  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_POS = 5      # 1 B symbol read + 4 B f32 score written
 COLS = 32
+# Secondary ceiling: every position gathers M f32 weights from LDS, 4*M bytes at
+# 256 B/clk/CU (ds_read_b128, MI355X_MICROARCH.md "LDS") x 256 CUs x 2.4 GHz
+LDS_PEAK_BYTES_PER_S = 256 * 256 * 2.4e9
+
+_M64 = (1 << 64) - 1
+
+
+def _i64(x: int) -> int:
+    """Python int -> the int64 with the same 64 bits (torch has no uint64 arithmetic)."""
+    x &= _M64
+    return x - (1 << 64) if x >> 63 else x
+
+
+def _lsr(x: torch.Tensor, n: int) -> torch.Tensor:
+    """Logical right shift of int64 bit patterns."""
+    return (x >> n) & ((1 << (64 - n)) - 1)
+
+
+def splitmix64_bases(pos: torch.Tensor, seed: int) -> torch.Tensor:
+    """base at sequence position `pos` (int64 tensor) of the counter-based
+    SplitMix64 stream -- word w = mix(seed + (w + 1) * 0x9E3779B97F4A7C15) holds positions
+    32w .. 32w+31, two bits each, low bits first; uniform over {A, C, T, G} = {0, 1, 2, 3}."""
+    w = pos >> 5
+    z = (w + 1) * _i64(0x9E3779B97F4A7C15) + _i64(seed)         # int64 arithmetic wraps like u64
+    z = (z ^ _lsr(z, 30)) * _i64(0xBF58476D1CE4E5B9)
+    z = (z ^ _lsr(z, 27)) * _i64(0x94D049BB133111EB)
+    z = z ^ _lsr(z, 31)
+    return ((z >> ((pos & 31) * 2)) & 3).to(torch.uint8)
+
+
+def synth_shard(rows: int, row0: int, total_rows: int, total_length: int, halo: int, dev, seed: int = 0x5EED0001,
+                chunk: int = 1 << 21) -> torch.Tensor:
+    """Rows [row0, row0 + rows) of the striped matrix (pli/mod.rs:191-196: position i at
+    [i % R][i / R], N past the end) of the synthetic sequence, + `halo` uninitialised rows."""
+    shard = torch.empty((rows + halo, COLS), dtype=torch.uint8, device=dev)
+    cols = torch.arange(COLS, device=dev, dtype=torch.int64)[None, :] * total_rows
+    for a in range(0, rows, chunk):
+        b = min(a + chunk, rows)
+        pos = cols + (torch.arange(a, b, device=dev, dtype=torch.int64)[:, None] + row0)
+        v = splitmix64_bases(pos, seed)
+        v[pos >= total_length] = 4
+        shard[a:b] = v
+    return shard
 
 
 def synth_pssm(m: int, seed: int = 0x5EED0002) -> lm.ScoringMatrix:
@@ -97,6 +144,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--length", type=int, default=1_000_000_000, help="positions per GPU")
     ap.add_argument("--motif-len", type=int, default=20)
+    ap.add_argument("--preheat-ms", type=float, default=300.0,
+                    help="untimed launches for at least this long BEFORE the counted warm-up: the first "
+                         "~50 launches of a fresh process run ~6 %% slow while the clocks ramp")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-sample", type=int, default=256_000_000, help="positions in the CPU sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -104,6 +154,9 @@ def main() -> None:
     ap.add_argument("--dist-backend", default="nccl",
                     help="development: 'gloo' + --single-device exercises the N>1 control flow on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="development: every rank uses cuda:0")
+    ap.add_argument("--merge", default="auto", choices=["auto", "cabi", "torch"],
+                    help="transport of the per-step argmax merge at N > 1: the C ABI's own RCCL communicator "
+                         "(lm_hip_comm_*, default on nccl) or torch.distributed (gloo runs)")
     ap.add_argument("--ab", action="store_true",
                     help="development: interleaved A/B of the store kernel's tuning knobs, then exit")
     args = ap.parse_args()
@@ -130,37 +183,65 @@ def main() -> None:
     rows = -(-args.length // COLS)            # striped rows owned by this rank
     total_rows = rows * world
     total_length = args.length * world
+    row0 = rows * rank
     pssm = synth_pssm(m)
 
-    # --- resident inputs -------------------------------------------------------------
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(0x5EED0001 + rank)
-    shard = torch.empty((rows + m - 1, COLS), dtype=torch.uint8, device=dev)
-    shard[:rows] = torch.randint(0, 4, (rows, COLS), dtype=torch.uint8, device=dev, generator=gen)
-    # positions past the end of the global sequence are the default symbol N (pli/mod.rs:194-196)
-    if total_length < total_rows * COLS:
-        idx = torch.arange(total_length, total_rows * COLS, device=dev)
-        g_rows = idx % total_rows
-        mine = (g_rows >= rows * rank) & (g_rows < rows * (rank + 1))
-        shard[(g_rows[mine] - rows * rank), (idx[mine] // total_rows)] = 4
+    # --- resident inputs (SplitMix64 stream, seed 0x5EED0001, 2 bits per base) -------
+    shard = synth_shard(rows, row0, total_rows, total_length, m - 1, dev)
     D.exchange_halo(shard, m - 1, COLS, 4)              # RCCL all_gather of (M-1) x 32 bytes per rank
-    scores = torch.empty((rows, COLS), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
 
     stream = torch.cuda.current_stream()
     pli = lm.Pipeline.hip(local_rank, stream=stream.cuda_stream)
     if args.rows_per_stream:
         pli.set_rows_per_stream(args.rows_per_stream)
+    seq = pli.adopt_sequence(shard.data_ptr(), rows, m - 1, COLS, COLS, total_length)  # borrowed device matrix
+    scores_h = lm.StripedScores.empty(pli, COLS)
+    pli.score_into(pssm, seq, scores_h)                  # allocates the resident StripedScores
+    torch.cuda.synchronize()
 
-    def step() -> None:
-        pli.score_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS, m - 1, total_length,
-                       0, rows, scores.data_ptr(), COLS)
+    use_cabi = world > 1 and (args.merge == "cabi" or (args.merge == "auto" and args.dist_backend == "nccl"))
+    comm, comm_note = None, None
+    if use_cabi:
+        try:
+            comm = D.CabiComm.from_torch(pli, device=coll_dev)
+        except lm.LightmotifHipError as e:      # e.g. no librccl next to a non-torch host: say so, use torch's
+            comm_note = f"C-ABI communicator unavailable ({e}); merge carried by torch.distributed"
+        flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # all ranks or none
+        if int(flag.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
+    scores_h.set_first_cell_rule(rank == 0)
+    pli.set_track_argmax(world > 1)            # N = 1 times the plain store kernel (configs[1])
+
+    def step():
+        """N = 1: one score_into (pli/mod.rs:109-117) into the resident StripedScores.
+        N > 1 (configs[3]): the same on this rank's row shard, plus the argmax of the shard
+        (tracked by the store kernel, first-cell rule on rank 0 only) and its merge over RCCL --
+        SURVEY 8(d): "wall time of the slowest rank incl. the RCCL merge"."""
+        pli.score_into(pssm, seq, scores_h)
+        if world == 1:
+            return None
+        if comm is not None:
+            return comm.argmax_sharded(scores_h, row0)   # device-side all_gather + combine, one 16-B read-back
+        loc = pli.argmax_handle_shard(scores_h, first_cell_rule=rank == 0)
+        return D.merge_argmax(loc, row0, device=coll_dev)
 
     def barrier() -> None:
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # time-based preheat (outside the counted warm-up), then the W counted warm-up steps
+    t_pre = time.perf_counter()
+    n_pre = 0
+    while (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms:
+        for _ in range(8):
+            pli.score_into(pssm, seq, scores_h)
+        torch.cuda.synchronize()
+        n_pre += 8
+    preheat_ms = (time.perf_counter() - t_pre) * 1e3
     for _ in range(args.warmup):
         step()
     barrier()
@@ -175,7 +256,7 @@ def main() -> None:
                 pli.set_rows_per_stream(t)
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(stream)
-                step()
+                pli.score_into(pssm, seq, scores_h)
                 b.record(stream)
                 torch.cuda.synchronize()
                 times[(x, t)].append(a.elapsed_time(b))
@@ -184,14 +265,21 @@ def main() -> None:
         return
 
     # --- timed region: exactly K steps ---------------------------------------------------
+    # HIP events on the launch stream bracket the score kernel of every step (the context
+    # enqueues on torch's current stream, so torch.cuda.Event sees it)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
+    merged = None
     for a, b in ev:
         a.record(stream)
-        step()
+        pli.score_into(pssm, seq, scores_h)
         b.record(stream)
+        if world > 1:
+            merged = (comm.argmax_sharded(scores_h, row0) if comm is not None else
+                      D.merge_argmax(pli.argmax_handle_shard(scores_h, first_cell_rule=rank == 0), row0,
+                                     device=coll_dev))
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -200,8 +288,9 @@ def main() -> None:
         elapsed = float(t.item())
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     kernel_avg_ms = float(np.mean(kernel_ms))
+    kernel_med_ms = float(np.median(kernel_ms))
 
-    # --- the final merge (outside the timed region; reported in "extras") -------------------
+    # --- reductions / merge on the last step's matrix (outside the timed region; "extras") --------
     def timed(fn, reps=5):
         best, out = None, None
         for _ in range(reps):
@@ -213,22 +302,31 @@ def main() -> None:
             best = dt if best is None else min(best, dt)
         return best, out
 
-    row0 = rows * rank
-    am_ms, am = timed(lambda: pli.argmax_dptr(scores.data_ptr(), rows, COLS, COLS, first_cell_rule=rank == 0))
+    sc_ptr = scores_h.data_ptr
+    am_ms, am = timed(lambda: pli.argmax_dptr(sc_ptr, rows, COLS, COLS, first_cell_rule=rank == 0))
     fam_ms, fam = timed(lambda: pli.score_argmax_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS,
                                                       m - 1, total_length, 0, rows, first_cell_rule=rank == 0))
     assert am == fam, (am, fam)
     mg_ms, best = timed(lambda: D.merge_argmax(am, row0, device=coll_dev))
+    if merged is not None:
+        assert merged == best, ("per-step merge differs from the merge of the materialised argmax", merged, best)
     # threshold ~ the p = 1e-5 tail the CLI defaults to (main.rs:487): estimated from a sample
-    sample = scores[: min(rows, 1 << 20)].flatten()
+    sample = torch.from_numpy(scores_h.rows_matrix(0, min(rows, 1 << 18))[:, :COLS].reshape(-1))
     thr_t = float(torch.quantile(sample[torch.isfinite(sample)][:8_000_000].float(), 1 - 1e-5))
-    th_ms, hits = timed(lambda: pli.threshold_dptr(scores.data_ptr(), rows, COLS, COLS, thr_t), reps=5)
+    if world > 1:   # one threshold for the whole job: rank 0's estimate
+        tt = torch.tensor([thr_t], dtype=torch.float64, device=coll_dev)
+        dist.broadcast(tt, src=0)
+        thr_t = float(tt.item())
+    th_ms, hits = timed(lambda: pli.threshold_dptr(sc_ptr, rows, COLS, COLS, thr_t), reps=5)
     fth_ms, fhits = timed(lambda: pli.score_threshold_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS,
                                                           m - 1, total_length, 0, rows, thr_t), reps=5)
     assert np.array_equal(hits, fhits[0]), "fused threshold differs from materialised threshold"
-    all_hits = D.merge_threshold(hits, row0, device=coll_dev)
+    mt_ms, all_hits = timed(lambda: (comm.merge_threshold(hits, row0) if comm is not None else
+                                     D.merge_threshold(hits, row0, device=coll_dev)), reps=3)
 
     if rank != 0:
+        if comm is not None:
+            comm.close()
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -237,7 +335,8 @@ def main() -> None:
     positions = rows * COLS * world * args.steps
     value = positions / elapsed / 1e9
     achieved = BYTES_PER_POS * rows * COLS / (kernel_avg_ms * 1e-3) / 1e9
-    traffic = None
+    lds_bytes_per_s = 4 * m * rows * COLS / (kernel_avg_ms * 1e-3)
+    traffic, traffic_source = None, None
     pmc = ROOT / "profiles" / "pmc_traffic.json"
     if pmc.exists():
         try:
@@ -247,8 +346,13 @@ def main() -> None:
             if (j.get("algorithmic_bytes_per_launch") == BYTES_PER_POS * rows * COLS and m == 20
                     and not args.rows_per_stream):
                 traffic = j.get("hbm_bytes_per_launch")
+                traffic_source = "offline PMC: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this " \
+                                 "command (profiles/pmc_traffic.json), not measured by this run"
         except (OSError, ValueError):
             traffic = None
+    step_desc = ("score_into" if world == 1 else
+                 "score_into of the rank's row shard + tracked shard argmax + RCCL merge of the argmax records "
+                 f"({'C-ABI communicator' if comm is not None else 'torch.distributed ' + args.dist_backend})")
     out = {
         "metric": "scored positions/sec", "value": round(value, 2), "unit": "Gpos/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -256,34 +360,45 @@ def main() -> None:
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": f"score(): len-{m} DNA PSSM x {args.length} bp striped sequence per GPU "
-                        f"(C=32, K=5, {rows} rows + {m - 1} halo rows), scores materialised in HBM",
+                        f"(C=32, K=5, {rows} rows + {m - 1} halo rows), scores materialised in HBM; "
+                        f"step = {step_desc}",
             "positions_per_gpu": rows * COLS, "motif_len": m, "parallelism": f"row-shard x{world}",
+            "inputs": "SplitMix64 stream seed 0x5EED0001, 2 bits/base (SURVEY 8d), PSSM seed 0x5EED0002",
+            "preheat_ms": round(preheat_ms, 1), "preheat_launches": n_pre,
+            **({"merge_note": comm_note} if comm_note else {}),
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "kernel": kernel_name, "kernel_avg_ms": round(kernel_avg_ms, 4),
+            "kernel_median_ms": round(kernel_med_ms, 4),
+            "frac_at_median": round(BYTES_PER_POS * rows * COLS / (kernel_med_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "algorithmic_bytes_per_launch": BYTES_PER_POS * rows * COLS,
             "read_gbs": round(achieved / 5, 1), "write_gbs": round(achieved * 4 / 5, 1),
+            "lds_frac": round(lds_bytes_per_s / LDS_PEAK_BYTES_PER_S, 4),
+            "lds_note": f"secondary ceiling: {4 * m} B of LDS gathers per position against 256 B/clk/CU x 256 CUs x 2.4 GHz",
         },
         "extras": {
             "argmax_ms": round(am_ms, 4), "fused_score_argmax_ms": round(fam_ms, 4),
             "fused_score_argmax_gpos": round(rows * COLS / fam_ms / 1e6, 1),
             "merge_argmax_ms": round(mg_ms, 4), "threshold_ms": round(th_ms, 4),
             "fused_score_threshold_ms": round(fth_ms, 4), "threshold_t": round(thr_t, 4),
-            "threshold_hits": len(all_hits), "argmax_global": [int(best[0][0]), int(best[0][1])],
+            "merge_threshold_ms": round(mt_ms, 4),
+            "threshold_hits": int(len(all_hits)), "argmax_global": [int(best[0][0]), int(best[0][1])],
             "kernel_ms_min": round(min(kernel_ms), 4), "kernel_ms_max": round(max(kernel_ms), 4),
         },
     }
     if world == 1 and not args.no_cpu_baseline:
         srows = min(rows, max(args.cpu_sample // COLS, 1))
         seq_sample = shard[:srows + m - 1].cpu().numpy()
-        gpu_sample = scores[:srows].cpu().numpy()
+        gpu_sample = scores_h.rows_matrix(0, srows)
         out["cpu_baseline"] = cpu_baseline(seq_sample, total_length, pssm.data, gpu_sample,
                                            args.cpu_seconds)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -52,7 +52,8 @@ typedef enum lm_hip_status {
     LM_HIP_ERR_OOM = 4,         /* host or device allocation failed */
     LM_HIP_ERR_NO_DEVICE = 5,   /* no gfx950 device: maps to UnsupportedBackend (err.rs:34) */
     LM_HIP_ERR_INVALID_SYMBOL = 6, /* Encode: InvalidSymbol (err.rs:10) */
-    LM_HIP_ERR_CAPACITY = 7     /* caller-provided output buffer too small */
+    LM_HIP_ERR_CAPACITY = 7,    /* caller-provided buffer too small (output list, adopted matrix) */
+    LM_HIP_ERR_COMM = 8         /* RCCL missing, or a collective / communicator call failed */
 } lm_hip_status;
 
 /* (row, col) of a cell of a striped matrix -- dense.rs:28-39 MatrixCoordinates. */
@@ -71,6 +72,7 @@ typedef struct lm_hip_ctx lm_hip_ctx;       /* device + stream + scratch */
 typedef struct lm_hip_pssm lm_hip_pssm;     /* ScoringMatrix data resident on the device */
 typedef struct lm_hip_seq lm_hip_seq;       /* StripedSequence resident on the device */
 typedef struct lm_hip_scores lm_hip_scores; /* StripedScores<f32> resident on the device */
+typedef struct lm_hip_comm lm_hip_comm;     /* RCCL communicator of a row-sharded job */
 
 /* ---- library ------------------------------------------------------------ */
 
@@ -79,6 +81,10 @@ const char *lm_hip_last_error(void);
 /* Pipeline::avx2()/neon() -> Result<_, UnsupportedBackend> (pli/mod.rs:401-407):
  * number of usable devices; 0 devices is reported through *count, not an error. */
 int lm_hip_device_count(int *count);
+/* HIP ordinal of the index-th usable (gfx950) device, 0 <= index < lm_hip_device_count: the
+ * value lm_hip_ctx_create and $LM_HIP_DEVICE take.  On a node with other GPUs in between,
+ * iterate over this instead of range(count).  LM_HIP_ERR_NO_DEVICE past the end. */
+int lm_hip_device_ordinal(int index, int *ordinal);
 /* Frees buffers this library returned to the caller (threshold / hit lists). */
 void lm_hip_free(void *p);
 
@@ -89,6 +95,8 @@ size_t lm_hip_stride(size_t cols, size_t elem_size);
 
 /* `Pipeline::dispatch()` is re-created per call in the reference
  * (pwm/mod.rs:646, scores.rs:182); the GPU state it would need lives here. */
+/* `device` is a HIP ordinal (what hipSetDevice / torch.device("cuda", i) / LOCAL_RANK use);
+ * LM_HIP_ERR_NO_DEVICE if it is not a gfx950 device (lm_hip_device_ordinal lists those). */
 int lm_hip_ctx_create(int device, lm_hip_ctx **out);
 /* Borrow an existing hipStream_t (e.g. PyTorch's current stream) instead of
  * creating one.  The stream must outlive the context. */
@@ -276,9 +284,11 @@ int lm_hip_scan_threshold_batch(lm_hip_ctx *ctx, const lm_hip_pssm *const *pssms
 /* Scanner (scan.rs:96-250), collected: every position with score >= threshold and
  * position + M <= L (scan.rs:185-190), as (position, f32 score) sorted by position
  * (the reference yields them in block-LIFO order and callers sort, scan.rs:291).
- * Runs the fused score+threshold kernel on exact f32 scores; the reference's u8
- * DiscreteMatrix prefilter (scan.rs:169-178) is a CPU-cache device with the same
- * result.  Errors with LM_HIP_ERR_WRAP if wrap < M-1 (scan.rs:127-131 panics).
+ * Like the reference Scanner (scan.rs:169-198) it finds candidates with a discretised
+ * over-estimate of the PSSM (a packed 16-bit prefilter here, u8 DiscreteMatrix there) and
+ * re-scores them exactly in f32, so the hits are those of the exact scores;
+ * lm_hip_ctx_set_prefilter(ctx, 0) scores every position in f32 instead (same result).
+ * Errors with LM_HIP_ERR_WRAP if wrap < M-1 (scan.rs:127-131 panics).
  * *hits is malloc'ed (NULL when *n == 0); release with lm_hip_free. */
 int lm_hip_scan_f32(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *seq,
                     float threshold, lm_hip_hit **hits, size_t *n);
@@ -295,7 +305,9 @@ int lm_hip_encode_dptr(lm_hip_ctx *ctx, char alphabet, const uint8_t *d_ascii, s
 
 /* Stripe::stripe_into (pli/mod.rs:178-200) + configure_wrap(wrap)
  * (seq.rs:369-381): writes ceil(len/cols)+wrap rows of `stride` bytes.
- * Padding bytes past `cols` in each row are zeroed (dense.rs:144-147). */
+ * Bytes past `cols` in each row (struct padding of the reference's Row, unspecified there)
+ * are set to the default symbol, like every element of a fresh row (dense.rs:144-147
+ * `resize_with(rows, Default::default)`), so every byte of the matrix is a valid symbol. */
 int lm_hip_stripe_dptr(lm_hip_ctx *ctx, const uint8_t *d_encoded, size_t len, size_t cols,
                        uint8_t default_symbol, size_t wrap, uint8_t *d_data, size_t stride);
 
@@ -307,11 +319,21 @@ int lm_hip_configure_wrap_dptr(lm_hip_ctx *ctx, uint8_t *d_data, size_t rows, si
 /* ---- resident handles ------------------------------------------------------ */
 
 /* Upload an existing StripedSequence (seq.rs:288-294): data = matrix()[0].as_ptr(),
- * rows_total = matrix().rows() (incl. wrap), k = alphabet size (default symbol = k-1). */
+ * rows_total = matrix().rows() (incl. wrap -- any wrap, e.g. configure_wrap(max_m) of the
+ * CLI), k = alphabet size (default symbol = k-1).  The `cols` live bytes of every row must
+ * be symbols < k (LM_HIP_ERR_INVALID_SYMBOL otherwise; the reference's symbols are enums,
+ * abc.rs:113-135).  The raw *_dptr entry points do NOT check this: bytes >= k there read
+ * past the PSSM tables (garbage scores), which is the caller's precondition to keep. */
 int lm_hip_seq_upload(lm_hip_ctx *ctx, const uint8_t *data, size_t rows_total, size_t stride,
                       size_t cols, size_t wrap, size_t length, size_t k, lm_hip_seq **out);
+/* The same for a matrix that already lives on the device and stays the CALLER's (a buffer of the
+ * host application, a torch tensor, one row shard of a multi-GPU job): nothing is copied or
+ * checked, lm_hip_seq_destroy does not free it, and lm_hip_seq_configure_wrap can only grow the
+ * wrap inside the rows_total rows handed over (LM_HIP_ERR_CAPACITY beyond). */
+int lm_hip_seq_adopt_dptr(lm_hip_ctx *ctx, uint8_t *d_data, size_t rows_total, size_t stride,
+                          size_t cols, size_t wrap, size_t length, size_t k, lm_hip_seq **out);
 /* EncodedSequence::to_striped (seq.rs:168-175) on the device: uploads `len`
- * symbol bytes and stripes them there. */
+ * symbol bytes (each < k, else LM_HIP_ERR_INVALID_SYMBOL) and stripes them there. */
 int lm_hip_seq_from_encoded(lm_hip_ctx *ctx, const uint8_t *encoded, size_t len, size_t cols,
                             size_t k, lm_hip_seq **out);
 /* Same, from ASCII text: encode (strict or lossy) + stripe on the device. */
@@ -350,6 +372,72 @@ int lm_hip_argmax(lm_hip_ctx *ctx, const lm_hip_scores *scores, int *found,
                   lm_hip_coords *best, float *value);
 int lm_hip_threshold(lm_hip_ctx *ctx, const lm_hip_scores *scores, float t,
                      lm_hip_coords **coords, size_t *n);
+
+/* ---- row-sharded jobs across the GPUs of a node --------------- */
+
+/*
+ * The path shards by ROW RANGES: Score::score_rows_into takes `rows: Range<usize>` for exactly
+ * this (pli/mod.rs:72-78) and output row r needs input rows r .. r+M-1 only (pli/mod.rs:99-101).
+ * One process per GPU holds rows [a_g, b_g) of the striped matrix plus an M-1-row halo and
+ * scores them with the entry points above -- no collective.  What has to come out is what
+ * StripedScores::{argmax, max, threshold} return for the WHOLE matrix (scores.rs:181-213);
+ * the functions below produce it over RCCL (bound directly by this library: librccl.so.1 is
+ * opened on first use; LM_HIP_ERR_COMM when it is absent).  Collectives: every rank of the
+ * communicator must make the same call.
+ */
+
+/* A StripedScores that is one row shard: enabled = 0 when it does NOT hold the matrix's first
+ * row, so Maximum::argmax's "scores[0][0] is NaN -> (0,0)" rule (pli/mod.rs:142-146) is skipped
+ * by lm_hip_argmax and by the maximum the store kernel tracks in lm_hip_score_into.  Default 1. */
+int lm_hip_scores_set_first_cell_rule(lm_hip_scores *scores, int enabled);
+
+/* The merge rule itself, on host arrays (for hosts with their own transport -- MPI, a Rust
+ * channel): n per-shard results in ascending row order, rows already GLOBAL, each computed
+ * with the first-cell rule on the shard holding row 0 only.  Result = Maximum::argmax of the
+ * whole matrix (pli/mod.rs:135-155): greatest value; ties -> the LAST cell in (row, col)
+ * order; NaN never wins except as that first-cell (0,0).  No device needed. */
+int lm_hip_combine_argmax(const int *found, const lm_hip_coords *best, const float *value, size_t n,
+                          int *found_out, lm_hip_coords *best_out, float *value_out);
+
+#define LM_HIP_COMM_ID_BYTES 128
+/* ncclGetUniqueId: call on ONE rank, hand the 128 bytes to the others (MPI_Bcast, a file, a
+ * torch store ...), then every rank calls lm_hip_comm_create (ncclCommInitRank; blocks until
+ * all nranks ranks arrive).  One GPU per rank. */
+int lm_hip_comm_unique_id(uint8_t *id);
+int lm_hip_comm_create(lm_hip_ctx *ctx, const uint8_t *id, int nranks, int rank, lm_hip_comm **out);
+int lm_hip_comm_destroy(lm_hip_comm *comm);
+int lm_hip_comm_info(const lm_hip_comm *comm, int *rank, int *nranks);
+
+/* Set-up: fills rows [rows, rows + halo_rows) of this rank's shard with the first halo_rows rows
+ * of rank+1's shard; the last rank receives rank 0's rows turned into the reference's wrap rows
+ * (seq.rs:373-378: wrap[i][j] = data[i][j+1], last column = default symbol).  One all_gather
+ * of halo_rows x stride bytes per rank.  Every shard needs >= halo_rows rows.  Synchronises. */
+int lm_hip_exchange_halo_dptr(lm_hip_ctx *ctx, lm_hip_comm *comm, uint8_t *d_shard, size_t rows,
+                              size_t stride, size_t cols, size_t halo_rows, uint8_t default_symbol);
+
+/* StripedScores::argmax / max (scores.rs:181-192) of the whole matrix from this rank's shard
+ * result (row relative to the shard; computed with first_cell_rule = (row_offset == 0)) --
+ * one all_gather of a 32-byte record per rank, then lm_hip_combine_argmax.  Every rank gets
+ * the same answer, rows GLOBAL. */
+int lm_hip_merge_argmax(lm_hip_ctx *ctx, lm_hip_comm *comm, int found_local,
+                        const lm_hip_coords *best_local, float value_local, size_t row_offset,
+                        int *found, lm_hip_coords *best, float *value);
+/* The same starting from the resident shard: uses the maximum the store kernel tracked when
+ * lm_hip_score_into wrote `scores` (with lm_hip_scores_set_first_cell_rule(scores,
+ * row_offset == 0)), else one pass over the shard; the record never leaves the device before
+ * the all_gather. */
+int lm_hip_argmax_sharded(lm_hip_ctx *ctx, lm_hip_comm *comm, const lm_hip_scores *scores,
+                          size_t row_offset, int *found, lm_hip_coords *best, float *value);
+/* Maximum::max (pli/mod.rs:158-160) when no NaN can occur (NaN contributions are dropped). */
+int lm_hip_merge_max(lm_hip_ctx *ctx, lm_hip_comm *comm, int found_local, float value_local,
+                     int *found, float *value);
+/* StripedScores::threshold (scores.rs:207-213) of the whole matrix: this rank's row-major list
+ * (rows relative to the shard) -> the concatenation over ranks in rank order with GLOBAL rows,
+ * which is the reference's row-major push order (pli/mod.rs:212-218).  Counts travel by
+ * all_gather, lists by one exact-length broadcast per rank.  *all is malloc'ed on every rank
+ * (NULL when *n_all == 0); release with lm_hip_free. */
+int lm_hip_merge_threshold(lm_hip_ctx *ctx, lm_hip_comm *comm, const lm_hip_coords *coords, size_t n,
+                           size_t row_offset, lm_hip_coords **all, size_t *n_all);
 
 /* ---- host-pointer convenience forms (synchronous, PCIe both ways) ---------- */
 

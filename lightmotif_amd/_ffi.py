@@ -12,7 +12,7 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "csrc" / "liblightmotif_hip.so"
 
-OK, ERR_BAD_ARGS, ERR_WRAP, ERR_HIP, ERR_OOM, ERR_NO_DEVICE, ERR_INVALID_SYMBOL, ERR_CAPACITY = range(8)
+OK, ERR_BAD_ARGS, ERR_WRAP, ERR_HIP, ERR_OOM, ERR_NO_DEVICE, ERR_INVALID_SYMBOL, ERR_CAPACITY, ERR_COMM = range(9)
 
 
 class Coords(C.Structure):
@@ -50,6 +50,7 @@ SIGNATURES = {
     "lm_hip_abi_version": (C.c_int, []),
     "lm_hip_last_error": (C.c_char_p, []),
     "lm_hip_device_count": (C.c_int, [_ip]),
+    "lm_hip_device_ordinal": (C.c_int, [C.c_int, _ip]),
     "lm_hip_free": (None, [_vp]),
     "lm_hip_stride": (_sz, [_sz, _sz]),
     "lm_hip_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
@@ -105,6 +106,19 @@ SIGNATURES = {
     "lm_hip_score_into": (C.c_int, [_vp, _vp, _vp, _vp]),
     "lm_hip_argmax": (C.c_int, [_vp, _vp, _ip, _cp, _fp]),
     "lm_hip_threshold": (C.c_int, [_vp, _vp, C.c_float, C.POINTER(_cp), _szp]),
+    # row-sharded jobs
+    "lm_hip_seq_adopt_dptr": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, C.POINTER(_vp)]),
+    "lm_hip_scores_set_first_cell_rule": (C.c_int, [_vp, C.c_int]),
+    "lm_hip_combine_argmax": (C.c_int, [_ip, _cp, _fp, _sz, _ip, _cp, _fp]),
+    "lm_hip_comm_unique_id": (C.c_int, [_vp]),
+    "lm_hip_comm_create": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "lm_hip_comm_destroy": (C.c_int, [_vp]),
+    "lm_hip_comm_info": (C.c_int, [_vp, _ip, _ip]),
+    "lm_hip_exchange_halo_dptr": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint8]),
+    "lm_hip_merge_argmax": (C.c_int, [_vp, _vp, C.c_int, _cp, C.c_float, _sz, _ip, _cp, _fp]),
+    "lm_hip_argmax_sharded": (C.c_int, [_vp, _vp, _vp, _sz, _ip, _cp, _fp]),
+    "lm_hip_merge_max": (C.c_int, [_vp, _vp, C.c_int, C.c_float, _ip, _fp]),
+    "lm_hip_merge_threshold": (C.c_int, [_vp, _vp, _cp, _sz, _sz, C.POINTER(_cp), _szp]),
     "lm_hip_score_f32": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _sz, _vp, _sz, _sz, _sz, _sz, _sz, _vp,
                                   _sz, _szp, _szp]),
     "lm_hip_argmax_f32": (C.c_int, [_vp, _sz, _sz, _sz, _ip, _cp, _fp]),
@@ -141,4 +155,6 @@ def check(status: int) -> None:
     msg = lib().lm_hip_last_error().decode("utf-8", "replace")
     if status == ERR_NO_DEVICE:
         raise UnsupportedBackend(status, msg)
+    if status == ERR_INVALID_SYMBOL:
+        raise InvalidSymbol(msg)
     raise LightmotifHipError(status, msg)

@@ -28,7 +28,7 @@ FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
          f"-I{ROOT / 'include'}", f"-I{CSRC}"]
 # score_inst.hip is compiled 9 times: motif lengths 4*i+1 .. 4*i+4 (M = 1 .. 36)
 INST = [(i, 4 * i + 1, 4 * i + 4) for i in range(9)]
-UNITS = ["score.hip", "reduce.hip", "hits.hip", "discrete.hip", "layout.hip", "api.hip"]
+UNITS = ["score.hip", "reduce.hip", "hits.hip", "discrete.hip", "layout.hip", "api.hip", "comm.hip"]
 
 
 def _hipcc() -> str:
@@ -73,8 +73,9 @@ def build(force: bool = False, jobs: int | None = None) -> Path:
         with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
             list(ex.map(_run, cmds))
     if cmds or force or not LIB.exists():
+        # -ldl: comm.hip opens librccl.so.1 on first use (no link-time dependency on RCCL)
         _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB),
-              *map(str, objs)])
+              *map(str, objs), "-ldl"])
     return LIB
 
 

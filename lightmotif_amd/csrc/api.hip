@@ -52,23 +52,6 @@ void Scratch::release()
     bytes = 0;
 }
 
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = true;
-    explicit DeviceGuard(int dev)
-    {
-        if (hipGetDevice(&prev) != hipSuccess)
-            prev = -1;
-        if (prev != dev)
-            ok = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DeviceGuard()
-    {
-        if (prev >= 0)
-            (void)hipSetDevice(prev);
-    }
-};
-
 static int check_score_args(const lm_hip_pssm *pssm, size_t seq_rows_total, size_t seq_stride,
                             size_t cols, size_t wrap, size_t row_begin, size_t row_end)
 {
@@ -204,6 +187,24 @@ int lm_hip_device_count(int *count)
     }
     *count = usable;
     return LM_HIP_OK;
+}
+
+int lm_hip_device_ordinal(int index, int *ordinal)
+{
+    if (!ordinal || index < 0)
+        return fail(LM_HIP_ERR_BAD_ARGS, "device_ordinal: bad argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        n = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0 &&
+            index-- == 0) {
+            *ordinal = d;
+            return LM_HIP_OK;
+        }
+    }
+    return fail(LM_HIP_ERR_NO_DEVICE, "fewer usable (gfx950) devices than index + 1");
 }
 
 void lm_hip_free(void *p) { free(p); }
@@ -910,8 +911,20 @@ int lm_hip_configure_wrap_dptr(lm_hip_ctx *ctx, uint8_t *d_data, size_t rows, si
 
 // ---- resident handles ---------------------------------------------------------------------------------
 
+// Symbols are enums in the reference (abc.rs:113-135, 231-256); through the C ABI they are
+// bytes, and a byte >= k would index past the M x K tables of the kernels.
+static int check_symbols(lm_hip_ctx *ctx, const uint8_t *d_data, size_t rows, size_t stride, size_t cols,
+                         size_t k, const char *what)
+{
+    unsigned mx = 0;
+    LM_TRY(launch_max_symbol(ctx, d_data, rows, stride, cols, &mx));
+    if (mx >= k)
+        return fail(LM_HIP_ERR_INVALID_SYMBOL, "%s: symbol byte %u is not below the alphabet size %zu", what, mx, k);
+    return LM_HIP_OK;
+}
+
 static int seq_alloc(lm_hip_ctx *ctx, size_t rows, size_t stride, size_t cols, size_t length,
-                     size_t k, lm_hip_seq **out)
+                     size_t k, lm_hip_seq **out, size_t min_capacity_rows = 0)
 {
     lm_hip_seq *s = new (std::nothrow) lm_hip_seq();
     if (!s)
@@ -922,7 +935,7 @@ static int seq_alloc(lm_hip_ctx *ctx, size_t rows, size_t stride, size_t cols, s
     s->cols = cols;
     s->length = length;
     s->k = k;
-    s->capacity_rows = rows + 32;  // seq.rs:285 DEFAULT_EXTRA_ROWS
+    s->capacity_rows = std::max(rows + 32, min_capacity_rows);  // seq.rs:285 DEFAULT_EXTRA_ROWS
     hipError_t e = hipMalloc(&s->d_data, s->capacity_rows * stride);
     if (e != hipSuccess) {
         delete s;
@@ -945,11 +958,8 @@ int lm_hip_seq_upload(lm_hip_ctx *ctx, const uint8_t *data, size_t rows_total, s
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard guard(ctx->device);
     lm_hip_seq *s = nullptr;
-    LM_TRY(seq_alloc(ctx, rows_total - wrap, stride, cols, length, k, &s));
-    if (s->capacity_rows < rows_total) {
-        lm_hip_seq_destroy(s);
-        return fail(LM_HIP_ERR_BAD_ARGS, "seq_upload: wrap too large");
-    }
+    // any wrap the caller's matrix already has (configure_wrap(max_m) of the CLI, M = 40 / 64 ...)
+    LM_TRY(seq_alloc(ctx, rows_total - wrap, stride, cols, length, k, &s, rows_total));
     s->wrap = wrap;
     if (rows_total) {
         hipError_t e = hipMemcpyAsync(s->d_data, data, rows_total * stride, hipMemcpyHostToDevice, ctx->stream);
@@ -959,16 +969,48 @@ int lm_hip_seq_upload(lm_hip_ctx *ctx, const uint8_t *data, size_t rows_total, s
             lm_hip_seq_destroy(s);
             return fail(LM_HIP_ERR_HIP, "sequence upload failed: %s", hipGetErrorString(e));
         }
+        const int st = check_symbols(ctx, s->d_data, rows_total, stride, cols, k, "seq_upload");
+        if (st != LM_HIP_OK) {
+            lm_hip_seq_destroy(s);
+            return st;
+        }
     }
     *out = s;
     return LM_HIP_OK;
 }
 
+int lm_hip_seq_adopt_dptr(lm_hip_ctx *ctx, uint8_t *d_data, size_t rows_total, size_t stride, size_t cols,
+                          size_t wrap, size_t length, size_t k, lm_hip_seq **out)
+{
+    if (!ctx || !out || (rows_total && !d_data))
+        return fail(LM_HIP_ERR_BAD_ARGS, "seq_adopt: null argument");
+    *out = nullptr;
+    if (cols == 0 || stride < cols || wrap > rows_total || k == 0 || k > 256)
+        return fail(LM_HIP_ERR_BAD_ARGS, "seq_adopt: bad geometry");
+    lm_hip_seq *s = new (std::nothrow) lm_hip_seq();
+    if (!s)
+        return fail(LM_HIP_ERR_OOM, "out of host memory");
+    s->device = ctx->device;
+    s->d_data = d_data;
+    s->owns = false;
+    s->capacity_rows = rows_total;
+    s->rows = rows_total - wrap;
+    s->wrap = wrap;
+    s->stride = stride;
+    s->cols = cols;
+    s->length = length;
+    s->k = k;
+    *out = s;
+    return LM_HIP_OK;
+}
+
 static int seq_from_device_encoded(lm_hip_ctx *ctx, const uint8_t *d_enc, size_t len, size_t cols,
-                                   size_t k, lm_hip_seq **out)
+                                   size_t k, lm_hip_seq **out, bool validate)
 {
     const size_t rows = (len + cols - 1) / cols;
     const size_t stride = lm_hip_stride(cols, 1);
+    if (validate)  // bytes from the caller: the encode kernel's own output needs no check
+        LM_TRY(check_symbols(ctx, d_enc, 1, len, len, k, "seq_from_encoded"));
     lm_hip_seq *s = nullptr;
     LM_TRY(seq_alloc(ctx, rows, stride, cols, len, k, &s));
     int st = launch_stripe(ctx, d_enc, len, cols, (uint8_t)(k - 1), 0, s->d_data, stride);
@@ -994,7 +1036,7 @@ int lm_hip_seq_from_encoded(lm_hip_ctx *ctx, const uint8_t *encoded, size_t len,
     uint8_t *d_enc = static_cast<uint8_t *>(ctx->scratch2.ptr);
     if (len)
         LM_HIP_TRY(hipMemcpyAsync(d_enc, encoded, len, hipMemcpyHostToDevice, ctx->stream));
-    return seq_from_device_encoded(ctx, d_enc, len, cols, k, out);
+    return seq_from_device_encoded(ctx, d_enc, len, cols, k, out, true);
 }
 
 int lm_hip_seq_from_ascii(lm_hip_ctx *ctx, char alphabet, const uint8_t *ascii, size_t len,
@@ -1013,7 +1055,7 @@ int lm_hip_seq_from_ascii(lm_hip_ctx *ctx, char alphabet, const uint8_t *ascii, 
     if (len)
         LM_HIP_TRY(hipMemcpyAsync(d_ascii, ascii, len, hipMemcpyHostToDevice, ctx->stream));
     LM_TRY(launch_encode(ctx, alphabet, d_ascii, len, lossy, d_enc, bad_index));
-    return seq_from_device_encoded(ctx, d_enc, len, cols, alphabet == 'P' ? 21 : 5, out);
+    return seq_from_device_encoded(ctx, d_enc, len, cols, alphabet == 'P' ? 21 : 5, out, false);
 }
 
 int lm_hip_seq_configure_wrap(lm_hip_ctx *ctx, lm_hip_seq *seq, size_t m)
@@ -1024,6 +1066,9 @@ int lm_hip_seq_configure_wrap(lm_hip_ctx *ctx, lm_hip_seq *seq, size_t m)
         return LM_HIP_OK;
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard guard(ctx->device);
+    if (seq->rows + m > seq->capacity_rows && !seq->owns)
+        return fail(LM_HIP_ERR_CAPACITY, "configure_wrap: the adopted matrix has room for %zu rows, %zu needed",
+                    seq->capacity_rows, seq->rows + m);
     if (seq->rows + m > seq->capacity_rows) {
         const size_t cap = seq->rows + m + 32;
         uint8_t *nd = nullptr;
@@ -1077,7 +1122,7 @@ int lm_hip_seq_destroy(lm_hip_seq *seq)
     if (!seq)
         return LM_HIP_OK;
     DeviceGuard guard(seq->device);
-    if (seq->d_data)
+    if (seq->d_data && seq->owns)
         (void)hipFree(seq->d_data);
     delete seq;
     return LM_HIP_OK;
@@ -1210,7 +1255,7 @@ int lm_hip_score_rows_into(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hi
     if (!scores->d_best || !ctx->track_argmax || (row_end - row_begin) * seq->cols < (8u << 20))
         return launch_score_store(ctx, a);
     bool tracked = false;
-    LM_TRY(launch_score_store_argmax(ctx, a, scores->d_best, &tracked));
+    LM_TRY(launch_score_store_argmax(ctx, a, scores->d_best, &tracked, scores->first_cell_rule ? 1 : 0));
     scores->best_valid = tracked;
     return LM_HIP_OK;
 }
@@ -1237,7 +1282,18 @@ int lm_hip_argmax(lm_hip_ctx *ctx, const lm_hip_scores *s, int *found, lm_hip_co
         record_to_coords(*static_cast<const ArgmaxRecord *>(ctx->pinned), s->cols, found, best, value);
         return LM_HIP_OK;
     }
-    return lm_hip_argmax_f32_dptr(ctx, s->d_data, s->rows, s->stride, s->cols, found, best, value);
+    return lm_hip_argmax_shard_f32_dptr(ctx, s->d_data, s->rows, s->stride, s->cols, s->first_cell_rule ? 1 : 0,
+                                        found, best, value);
+}
+
+int lm_hip_scores_set_first_cell_rule(lm_hip_scores *s, int enabled)
+{
+    if (!s)
+        return fail(LM_HIP_ERR_BAD_ARGS, "scores_set_first_cell_rule: null scores");
+    if (s->first_cell_rule != (enabled != 0))
+        s->best_valid = false;
+    s->first_cell_rule = enabled != 0;
+    return LM_HIP_OK;
 }
 
 int lm_hip_threshold(lm_hip_ctx *ctx, const lm_hip_scores *s, float t, lm_hip_coords **coords,

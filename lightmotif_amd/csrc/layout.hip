@@ -4,8 +4,9 @@
 //   encode          lightmotif/src/pli/mod.rs:56-66 + Symbol::from_ascii (abc.rs:166-171,
 //                   296-325); lossy form seq.rs:122-129
 //   stripe          pli/mod.rs:178-200: position i -> data[i % rows][i / rows],
-//                   cells past the end = default symbol, row padding zeroed
-//                   (dense.rs:144-147)
+//                   cells past the end = default symbol; fresh rows are T::default() =
+//                   the default symbol (dense.rs:144-147), and so is the alignment
+//                   padding past `cols` here (unspecified struct padding in the reference)
 //   configure_wrap  seq.rs:369-381
 // All integer/byte work, HBM-bound: coalesced loads, LDS-tiled transpose.
 #include <algorithm>
@@ -106,6 +107,60 @@ int launch_encode(lm_hip_ctx *ctx, char alphabet, const uint8_t *d_ascii, size_t
     return LM_HIP_OK;
 }
 
+// ---- symbol validation ----------------------------------------------------------------------
+// The reference's symbols are enums, so a StripedSequence cannot hold a byte >= K.  Bytes
+// entering through the C ABI can; they would index past the M x K tables of the scoring
+// kernels.  One pass over the `cols` live bytes of every row (4 B / lane when the layout
+// allows) finds the largest symbol.
+__global__ __launch_bounds__(kBlock) void max_symbol_kernel(const uint8_t *__restrict__ data,
+                                                            const unsigned long long rows,
+                                                            const unsigned long long stride,
+                                                            const unsigned cols,
+                                                            unsigned *__restrict__ out)
+{
+    unsigned m = 0;
+    if (stride == cols && cols % 4 == 0 && reinterpret_cast<uintptr_t>(data) % 4 == 0) {
+        const unsigned long long n4 = rows * cols / 4;
+        const unsigned *d4 = reinterpret_cast<const unsigned *>(data);
+        for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < n4;
+             i += (unsigned long long)gridDim.x * kBlock) {
+            const unsigned w = d4[i];
+            m = max(max(m, w & 0xff), max((w >> 8) & 0xff, max((w >> 16) & 0xff, w >> 24)));
+        }
+    } else {
+        const unsigned long long n = rows * cols;
+        for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < n;
+             i += (unsigned long long)gridDim.x * kBlock)
+            m = max(m, (unsigned)data[(i / cols) * stride + i % cols]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        m = max(m, (unsigned)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0 && m)
+        atomicMax(out, m);
+}
+
+int launch_max_symbol(lm_hip_ctx *ctx, const uint8_t *d_data, size_t rows, size_t stride, size_t cols,
+                      unsigned *max_symbol)
+{
+    *max_symbol = 0;
+    if (rows == 0 || cols == 0)
+        return LM_HIP_OK;
+    LM_TRY(ctx->scratch.reserve(16));
+    unsigned *d_max = static_cast<unsigned *>(ctx->scratch.ptr);
+    LM_HIP_TRY(hipMemsetAsync(d_max, 0, 4, ctx->stream));
+    const unsigned long long work = (unsigned long long)rows * cols / 4 + 1;
+    const unsigned grid = (unsigned)std::min<unsigned long long>((work + kBlock - 1) / kBlock,
+                                                                 (unsigned long long)ctx->num_cus * 32);
+    hipLaunchKernelGGL(max_symbol_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_data,
+                       (unsigned long long)rows, (unsigned long long)stride, (unsigned)cols, d_max);
+    LM_HIP_TRY(hipGetLastError());
+    LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, d_max, 4, hipMemcpyDeviceToHost, ctx->stream));
+    LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *max_symbol = *static_cast<unsigned *>(ctx->pinned);
+    return LM_HIP_OK;
+}
+
 // ---- stripe -------------------------------------------------------------------------------
 
 // One workgroup transposes a tile of TR striped rows: for each column c the TR
@@ -125,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void stripe_kernel(const uint8_t *__restric
     const unsigned pitch = (unsigned)stride + 1;
     const unsigned long long r = r0 + threadIdx.x;
     for (unsigned c = 0; c < stride; ++c) {
-        uint8_t v = 0;  // alignment padding past `cols` (dense.rs:144-147)
+        uint8_t v = def;  // alignment padding past `cols`: default symbol (dense.rs:144-147)
         if (c < cols && r < rows) {
             const unsigned long long i = (unsigned long long)c * rows + r;  // pli/mod.rs:192
             v = i < len ? enc[i] : def;                                     // pli/mod.rs:195
@@ -169,7 +224,7 @@ __global__ __launch_bounds__(kBlock) void stripe_kernel_fast(const uint8_t *__re
             v = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const unsigned b = (r + q < rows) ? (i + q < len ? enc[i + q] : def) : 0;  // :195
+                const unsigned b = (r + q < rows && i + q < len) ? enc[i + q] : def;  // :195
                 v |= b << (8 * q);
             }
         }
@@ -179,11 +234,12 @@ __global__ __launch_bounds__(kBlock) void stripe_kernel_fast(const uint8_t *__re
         t[2 * pitch] = (uint8_t)(v >> 16);
         t[3 * pitch] = (uint8_t)(v >> 24);
     }
-    // alignment padding past `cols` is zero (dense.rs:144-147)
+    // alignment padding past `cols`: the default symbol, like every element of a fresh row
+    // (dense.rs:144-147)
     for (unsigned c = cols; c < stride; ++c)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            tile[(4u * threadIdx.x + q) * pitch + c] = 0;
+            tile[(4u * threadIdx.x + q) * pitch + c] = def;
     __syncthreads();
     const unsigned long long nrows = rows - r0 < kFastTileRows ? rows - r0 : kFastTileRows;
     const unsigned dw_per_row = stride / 4;
@@ -260,7 +316,8 @@ __global__ __launch_bounds__(kBlock) void stripe_kernel_c32(const uint8_t *__res
 // sequentially in place, so for i >= rows the source row is itself a wrap row
 // written earlier in the loop; unrolling that recursion gives
 //     wrap[i][j] = orig[i % rows][j + 1 + i / rows]   if that column exists, else default.
-// With rows == 0 the loop reads the (zero-filled) row it is writing: zeros, then default.
+// With rows == 0 the loop reads the fresh row it is writing (T::default() = the default
+// symbol, dense.rs:144-147): every cell is the default symbol.
 __global__ __launch_bounds__(kBlock) void wrap_kernel(uint8_t *__restrict__ data,
                                                       const unsigned long long rows,
                                                       const unsigned long long stride,
@@ -272,10 +329,10 @@ __global__ __launch_bounds__(kBlock) void wrap_kernel(uint8_t *__restrict__ data
          b += (unsigned long long)gridDim.x * kBlock) {
         const unsigned long long i = b / stride;
         const unsigned j = (unsigned)(b - i * stride);
-        uint8_t v = 0;
+        uint8_t v = def;  // padding past `cols` and the rows == 0 case: default symbol
         if (j < cols) {
             if (rows == 0) {
-                v = (j == cols - 1) ? def : 0;
+                v = def;
             } else {
                 const unsigned long long src_col = (unsigned long long)j + 1 + i / rows;
                 v = src_col < cols ? data[(i % rows) * stride + src_col] : def;

@@ -33,6 +33,24 @@ int fail(int status, const char *fmt, ...) __attribute__((format(printf, 2, 3)))
             return _s;               \
     } while (0)
 
+// Makes `dev` current for the scope of a call, restores the caller's device afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess)
+            prev = -1;
+        if (prev != dev)
+            ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+
 // ---- device scratch ---------------------------------------------------------
 
 struct Scratch {
@@ -117,6 +135,7 @@ struct lm_hip_seq {
     size_t rows = 0;           // non-wrap rows = ceil(length / cols)
     size_t wrap = 0;
     size_t stride = 0, cols = 0, length = 0, k = 0;
+    bool owns = true;          // false: d_data is the caller's (lm_hip_seq_adopt_dptr)
 };
 
 struct lm_hip_scores {
@@ -128,6 +147,9 @@ struct lm_hip_scores {
     // valid until the next library write into this handle)
     lm::ArgmaxRecord *d_best = nullptr;
     bool best_valid = false;
+    // 0: this StripedScores is a row shard that does NOT hold the matrix's first cell, so the
+    // "scores[0][0] is NaN -> (0,0)" rule of Maximum::argmax is skipped (lm_hip_scores_set_first_cell_rule)
+    bool first_cell_rule = true;
 };
 
 namespace lm {
@@ -165,7 +187,8 @@ int launch_threshold_u8(lm_hip_ctx *ctx, const uint8_t *d_scores, size_t rows, s
                         unsigned t, lm_hip_coords **coords, size_t *n);
 // ... also leaving the argmax of the written rows in *d_result (device); *tracked = false
 // when the shape falls back to a plain store
-int launch_score_store_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *d_result, bool *tracked);
+int launch_score_store_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *d_result, bool *tracked,
+                              int first_cell_rule = 1);
 int finalize_argmax_materialised(lm_hip_ctx *ctx, const ArgmaxRecord *d_blocks, unsigned nblocks,
                                  const float *d_scores, int first_cell_rule, ArgmaxRecord *d_out);
 // Fused score+argmax: leaves one ArgmaxRecord at ctx->scratch (device) -> out.
@@ -212,11 +235,16 @@ int launch_scan_u32(lm_hip_ctx *ctx, const unsigned *counts, unsigned long long 
 
 int launch_argmax(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride,
                   size_t cols, int first_cell_rule, ArgmaxRecord *out);
+int launch_argmax_device(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride,
+                         size_t cols, int first_cell_rule, ArgmaxRecord *d_out);
 int launch_threshold(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride,
                      size_t cols, float t, lm_hip_coords **coords, size_t *n);
 
 int launch_encode(lm_hip_ctx *ctx, char alphabet, const uint8_t *d_ascii, size_t len, int lossy,
                   uint8_t *d_dst, size_t *bad_index);
+// largest symbol byte among the `cols` live bytes of `rows` rows (synchronises)
+int launch_max_symbol(lm_hip_ctx *ctx, const uint8_t *d_data, size_t rows, size_t stride, size_t cols,
+                      unsigned *max_symbol);
 int launch_stripe(lm_hip_ctx *ctx, const uint8_t *d_encoded, size_t len, size_t cols,
                   uint8_t default_symbol, size_t wrap, uint8_t *d_data, size_t stride);
 int launch_wrap(lm_hip_ctx *ctx, uint8_t *d_data, size_t rows, size_t stride, size_t cols,

@@ -95,8 +95,10 @@ __global__ __launch_bounds__(kBlock) void argmax_strided(const float *__restrict
     }
 }
 
-int launch_argmax(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride, size_t cols,
-                  int first_cell_rule, ArgmaxRecord *out)
+// Enqueues the argmax of a materialised matrix; the record lands at `d_out` (device memory, or
+// pinned host memory the device can write).  No synchronisation.
+int launch_argmax_device(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride, size_t cols,
+                         int first_cell_rule, ArgmaxRecord *d_out)
 {
     const unsigned long long ncells = (unsigned long long)rows * cols;
     const unsigned grid = (unsigned)std::max<unsigned long long>(
@@ -113,9 +115,15 @@ int launch_argmax(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t st
                            (unsigned long long)rows, (unsigned long long)stride, (unsigned)cols,
                            recs + 1);
     LM_HIP_TRY(hipGetLastError());
+    return finalize_argmax_materialised(ctx, recs + 1, grid, d_scores, first_cell_rule, d_out);
+}
+
+int launch_argmax(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride, size_t cols,
+                  int first_cell_rule, ArgmaxRecord *out)
+{
     // the finalize kernel writes the record straight into pinned host memory
-    LM_TRY(finalize_argmax_materialised(ctx, recs + 1, grid, d_scores, first_cell_rule,
-                                        static_cast<ArgmaxRecord *>(ctx->pinned)));
+    LM_TRY(launch_argmax_device(ctx, d_scores, rows, stride, cols, first_cell_rule,
+                                static_cast<ArgmaxRecord *>(ctx->pinned)));
     LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     *out = *static_cast<const ArgmaxRecord *>(ctx->pinned);
     return LM_HIP_OK;

@@ -351,7 +351,7 @@ __global__ void argmax_fold(const ArgmaxRecord *__restrict__ blocks, const unsig
 __global__ __launch_bounds__(kBlock) void argmax_finalize_locate(
     const ArgmaxRecord *__restrict__ recs, const unsigned nrecs, const float *__restrict__ scores,
     const unsigned long long rows, const unsigned long long T, const unsigned long long nstreams,
-    ArgmaxRecord *__restrict__ out)
+    const int first_cell_rule, ArgmaxRecord *__restrict__ out)
 {
     __shared__ float sm_v[kBlock / 64];
     __shared__ long long sm_i[kBlock / 64];
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(kBlock) void argmax_finalize_locate(
             best_merge(v, wg, recs[b].value, recs[b].index);
     best_block_reduce(v, wg, sm_v, sm_i);
     if (threadIdx.x == 0) {
-        const float first = scores[0];
+        const float first = first_cell_rule ? scores[0] : 0.0f;  // row shards that do not hold row 0 skip the rule
         if (first != first) {  // scores[0][0] is NaN: nothing ever compares >= it (pli/mod.rs:142-146)
             ArgmaxRecord o;
             o.value = first;
@@ -428,7 +428,8 @@ __global__ __launch_bounds__(kBlock) void argmax_finalize_locate(
 // NaN rule on the stored matrix) and the cell is found in the winning
 // workgroup's rows; the result lands in `d_result`, all on the same stream.  Returns
 // *tracked = false (after a plain store) for shapes the C = 32 kernels do not cover.
-int launch_score_store_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *d_result, bool *tracked)
+int launch_score_store_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *d_result, bool *tracked,
+                              int first_cell_rule)
 {
     *tracked = false;
     const C32Plan p = plan_c32(ctx, a, true);
@@ -453,7 +454,7 @@ int launch_score_store_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord 
         n = 256;
     }
     hipLaunchKernelGGL(argmax_finalize_locate, dim3(1), dim3(kBlock), 0, ctx->stream, recs, n, a.d_out,
-                       (unsigned long long)(a.row_end - a.row_begin), p.T, p.nstreams, d_result);
+                       (unsigned long long)(a.row_end - a.row_begin), p.T, p.nstreams, first_cell_rule, d_result);
     LM_HIP_TRY(hipGetLastError());
     *tracked = true;
     return LM_HIP_OK;

@@ -1,26 +1,43 @@
 """Sharding of the scoring path across the GPUs of one node.
 
-The path shards embarrassingly: output row ``r`` depends only on input rows
-``r .. r+M-1`` (pli/mod.rs:99-101), which is why ``score_rows_into`` takes a row
-range (pli/mod.rs:72-78).  One process per GPU owns a contiguous range of the
-``R`` striped rows plus an ``M-1``-row halo; scoring needs NO collective.  RCCL
-(``torch.distributed`` backend "nccl") is used only for
+The path shards embarrassingly, in two ways:
+
+* **rows of one long sequence** -- output row ``r`` depends only on input rows
+  ``r .. r+M-1`` (pli/mod.rs:99-101), which is why ``score_rows_into`` takes a row
+  range (pli/mod.rs:72-78).  One process per GPU owns a contiguous range of the
+  ``R`` striped rows plus an ``M-1``-row halo; scoring needs NO collective;
+* **motifs of a many-motif batch** -- the reference CLI sends every motif against
+  every sequence as independent jobs (lightmotif-cli main.rs:502-561).  Every rank
+  holds the whole (100 MB-scale) sequence and scans its share of the motif list
+  (``shard_motifs``, balanced on sum(M)); results are gathered in motif order
+  (``scan_argmax_batch_sharded`` / ``scan_threshold_batch_sharded``).
+
+RCCL is used only for
 
 * the one-off halo hand-over at set-up (each rank receives the first ``M-1`` rows
   of its successor; the last rank receives rank 0's rows to build the
   reference's wrap rows, seq.rs:373-378), and
-* the final merge: ``all_gather`` of one 24-byte ``(score, row, col)`` record per
-  rank for argmax, ``all_gather`` of hit counts + padded hit lists for threshold.
+* the final merge: ``all_gather`` of one 32-byte ``(found, score, row, col)`` record
+  per rank for argmax; hit counts + exact-length hit lists for threshold.
 
-Payloads are bytes to kilobytes, so xGMI bandwidth is irrelevant; latency is all
-that matters.  The same code runs on CPU tensors with the ``gloo`` backend, which
-is how the tests cover world_size > 1 without GPUs.
+Two transports carry the merge:
+
+* the C ABI's own communicator (``lm_hip_comm_*`` / ``lm_hip_merge_*`` in
+  include/lightmotif_hip.h, RCCL bound directly by the library) -- what a Rust or
+  C++ host uses, and what ``bench.py`` times on GPUs;
+* ``torch.distributed`` (backend "nccl" = RCCL, or "gloo" on CPU tensors, which is
+  how the tests cover world_size > 1 without GPUs).
+
+The merge *rules* live in the pure functions ``combine_argmax`` /
+``combine_threshold`` below (and, identically, in csrc/comm.hip); both transports
+only move the records.
 """
 from __future__ import annotations
 
 import struct
 from typing import List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -61,36 +78,33 @@ def _world(group=None) -> Tuple[int, int]:
     return dist.get_rank(group), dist.get_world_size(group)
 
 
-def merge_argmax(local: Optional[Tuple[Tuple[int, int], float]], row_offset: int,
-                 device: torch.device | str = "cpu", group=None):
-    """Global ``Maximum::argmax`` from per-shard results.
+def _coll_device(device, group=None):
+    """gloo moves host tensors only; nccl (= RCCL) device tensors only."""
+    if dist.is_initialized() and dist.get_backend(group) == "gloo":
+        return torch.device("cpu")
+    return torch.device(device)
 
-    ``local`` is ``((row, col), value)`` of this rank's shard (rows relative to the
-    shard) computed WITHOUT the first-cell rule on ranks > 0, or ``None`` if the
-    shard is empty; ``row_offset`` is the shard's first global row.  Every rank
-    returns the same ``((row, col), value)`` in global coordinates (or ``None``).
+
+# ---- the merge rules (pure) -------------------------------------------------------
+
+
+def combine_argmax(records: Sequence[Optional[Tuple[Tuple[int, int], float]]]):
+    """Global ``Maximum::argmax`` from per-shard results given in ascending row order.
+
+    ``records[g]`` is ``((row, col), value)`` in GLOBAL row coordinates, computed
+    WITHOUT the first-cell rule on every shard but the one holding row 0
+    (``lm_hip_argmax_shard_f32_dptr(first_cell_rule = g == 0)``), or ``None`` for an
+    empty shard.
 
     Rule (pli/mod.rs:135-155): maximal score; ties go to the LAST cell in
     (row, col) order; NaN never wins, except that a NaN in the matrix's very first
-    cell -- reported by rank 0 through the first-cell rule -- wins outright.
+    cell -- reported by shard 0 through the first-cell rule -- wins outright.
     """
-    rank, world = _world(group)
-    rec = torch.zeros(4, dtype=torch.int64)
-    if local is not None:
-        (r, c), v = local
-        rec[0], rec[1], rec[2], rec[3] = 1, _f32_bits(v), r + row_offset, c
-    if world == 1:
-        recs = [rec]
-    else:
-        rec = rec.to(device)
-        bufs = [torch.empty_like(rec) for _ in range(world)]
-        dist.all_gather(bufs, rec, group=group)
-        recs = [b.cpu() for b in bufs]
     best = None
-    for i, b in enumerate(recs):
-        if int(b[0]) == 0:
+    for rec in records:
+        if rec is None:
             continue
-        v, r, c = _bits_f32(int(b[1])), int(b[2]), int(b[3])
+        (r, c), v = rec
         if v != v:          # NaN can only be the first-cell rule of the shard holding row 0
             if r == 0 and c == 0:
                 return (0, 0), v
@@ -100,37 +114,82 @@ def merge_argmax(local: Optional[Tuple[Tuple[int, int], float]], row_offset: int
     return best
 
 
-def merge_threshold(local_coords: Sequence[Tuple[int, int]], row_offset: int,
-                    device: torch.device | str = "cpu", group=None) -> List[Tuple[int, int]]:
-    """Global ``Threshold::threshold`` list: shards hold ascending contiguous row
-    ranges, so concatenating the per-shard row-major lists in rank order IS the
-    reference's row-major order (pli/mod.rs:212-218)."""
+def combine_threshold(lists: Sequence[np.ndarray], row_offsets: Sequence[int]) -> np.ndarray:
+    """Global ``Threshold::threshold`` list as an ``(n, 2)`` int64 array: shards hold
+    ascending contiguous row ranges, so concatenating the per-shard row-major lists in
+    shard order IS the reference's row-major order (pli/mod.rs:212-218)."""
+    parts = []
+    for coords, off in zip(lists, row_offsets):
+        a = np.asarray(coords, dtype=np.int64).reshape(-1, 2).copy()
+        a[:, 0] += off
+        parts.append(a)
+    return np.concatenate(parts, axis=0) if parts else np.zeros((0, 2), np.int64)
+
+
+# ---- torch.distributed transport ----------------------------------------------------
+
+
+def merge_argmax(local: Optional[Tuple[Tuple[int, int], float]], row_offset: int,
+                 device: torch.device | str = "cpu", group=None):
+    """``combine_argmax`` over the ranks of ``group``: ``local`` is this rank's shard
+    result with rows relative to the shard, ``row_offset`` the shard's first global row.
+    Every rank returns the same ``((row, col), value)`` (or ``None``)."""
     rank, world = _world(group)
-    import numpy as np
-    mine = torch.from_numpy(np.asarray(local_coords, dtype=np.int64).reshape(-1, 2).copy())
-    mine[:, 0] += row_offset
+    rec = torch.zeros(4, dtype=torch.int64)
+    if local is not None:
+        (r, c), v = local
+        rec[0], rec[1], rec[2], rec[3] = 1, _f32_bits(v), r + row_offset, c
     if world == 1:
-        return [(int(r), int(c)) for r, c in mine.tolist()]
-    n = torch.tensor([mine.shape[0]], dtype=torch.int64, device=device)
+        recs = [rec]
+    else:
+        rec = rec.to(_coll_device(device, group))
+        bufs = [torch.empty_like(rec) for _ in range(world)]
+        dist.all_gather(bufs, rec, group=group)
+        recs = [b.cpu() for b in bufs]
+    return combine_argmax([None if int(b[0]) == 0 else ((int(b[2]), int(b[3])), _bits_f32(int(b[1])))
+                           for b in recs])
+
+
+def _gather_exact(mine: torch.Tensor, device, group=None) -> List[torch.Tensor]:
+    """Variable-length gather of 2-D int64/float tensors along dim 0: counts by
+    ``all_gather``, then one broadcast per rank with that rank's exact length -- no
+    padding to the longest list (at a 1e-3 hit rate a rank holds ~1e6 records)."""
+    rank, world = _world(group)
+    dev = _coll_device(device, group)
+    n = torch.tensor([mine.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.empty_like(n) for _ in range(world)]
     dist.all_gather(counts, n, group=group)
     counts = [int(x.item()) for x in counts]
-    cap = max(max(counts), 1)
-    padded = torch.zeros((cap, 2), dtype=torch.int64, device=device)
-    padded[:mine.shape[0]] = mine.to(device)
-    bufs = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(bufs, padded, group=group)
-    out: List[Tuple[int, int]] = []
-    for cnt, buf in zip(counts, bufs):
-        out.extend((int(r), int(c)) for r, c in buf[:cnt].cpu().tolist())
+    out = []
+    for src, cnt in enumerate(counts):
+        buf = mine.to(dev) if src == rank else torch.empty((cnt,) + tuple(mine.shape[1:]),
+                                                           dtype=mine.dtype, device=dev)
+        if cnt:
+            src_global = src if group is None else dist.get_global_rank(group, src)
+            dist.broadcast(buf, src=src_global, group=group)
+        out.append(buf)
     return out
+
+
+def merge_threshold(local_coords, row_offset: int, device: torch.device | str = "cpu",
+                    group=None) -> np.ndarray:
+    """``combine_threshold`` over the ranks of ``group``.  ``local_coords`` is this rank's
+    ``(n, 2)`` array (or list) of (row, col) in row-major order with rows relative to the
+    shard.  Returns the global ``(N, 2)`` int64 array on every rank."""
+    rank, world = _world(group)
+    mine = np.asarray(local_coords, dtype=np.int64).reshape(-1, 2).copy()
+    mine[:, 0] += row_offset
+    if world == 1:
+        return mine
+    bufs = _gather_exact(torch.from_numpy(mine), device, group)
+    return np.concatenate([b.cpu().numpy() for b in bufs], axis=0)
 
 
 def merge_max(local: Optional[float], device: torch.device | str = "cpu", group=None) -> Optional[float]:
     """``Maximum::max`` across shards (value of the merged argmax when no NaN is involved)."""
     rank, world = _world(group)
     t = torch.tensor([float("-inf") if local is None else local, 0.0 if local is None else 1.0],
-                     dtype=torch.float32, device=device)
+                     dtype=torch.float32, device=_coll_device(device, group) if world > 1 else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t[0]) if float(t[1]) > 0 else None
@@ -163,9 +222,193 @@ def exchange_halo(shard: torch.Tensor, halo_rows: int, columns: int, default_sym
         dist.all_gather(heads, head, group=group)
         recv = heads[(rank + 1) % world]
     if rank == world - 1:
-        wrapped = torch.zeros_like(recv)
+        wrapped = torch.full_like(recv, default_symbol)   # padding past `columns` too (dense.rs fill)
         wrapped[:, :columns - 1] = recv[:, 1:columns]
-        wrapped[:, columns - 1] = default_symbol
         recv = wrapped
     shard[rows:] = recv.to(shard.device)
     return shard
+
+
+# ---- many-motif batches sharded by motif (configs[2] across GPUs) ------------------
+
+
+def scan_argmax_batch_sharded(pli, pssms, seq, device: torch.device | str = "cpu", group=None,
+                              parts: Optional[List[List[int]]] = None):
+    """``Pipeline.scan_argmax_batch`` with the motif list split over the ranks.
+
+    Every rank holds the whole sequence (``seq``) and the whole motif list; rank g scans
+    ``shard_motifs(...)[g]`` with ONE batched call and the per-motif results are gathered
+    back into motif order.  Returns, on every rank, the list a single-process
+    ``pli.scan_argmax_batch(pssms, seq)`` returns."""
+    rank, world = _world(group)
+    if parts is None:
+        parts = shard_motifs([len(p) for p in pssms], world)
+    mine = parts[rank]
+    local = pli.scan_argmax_batch([pssms[i] for i in mine], seq) if mine else []
+    rec = np.zeros((len(mine), 5), np.int64)
+    for j, (i, res) in enumerate(zip(mine, local)):
+        rec[j, 0] = i
+        if res is not None:
+            rec[j, 1:] = (1, _f32_bits(res[1]), res[0][0], res[0][1])
+    if world == 1:
+        allrec = rec
+    else:
+        allrec = np.concatenate([b.cpu().numpy() for b in _gather_exact(torch.from_numpy(rec), device, group)])
+    out: List[Optional[Tuple[Tuple[int, int], float]]] = [None] * len(pssms)
+    for i, found, bits, r, c in allrec.tolist():
+        out[i] = ((r, c), _bits_f32(bits)) if found else None
+    return out
+
+
+def scan_threshold_batch_sharded(pli, pssms, thresholds, seq, device: torch.device | str = "cpu",
+                                 group=None, parts: Optional[List[List[int]]] = None):
+    """``Pipeline.scan_threshold_batch`` with the motif list split over the ranks: per
+    motif ``(coords (n_i, 2) int64 in row-major order, values (n_i,) f32)``, in motif
+    order, identical on every rank to the single-process call."""
+    rank, world = _world(group)
+    if parts is None:
+        parts = shard_motifs([len(p) for p in pssms], world)
+    mine = parts[rank]
+    local = pli.scan_threshold_batch([pssms[i] for i in mine], [thresholds[i] for i in mine], seq) if mine else []
+    if world == 1:
+        out = [None] * len(pssms)
+        for i, res in zip(mine, local):
+            out[i] = res
+        return out
+    head = np.zeros((len(mine), 2), np.int64)           # (motif, hit count)
+    for j, (i, (coords, _)) in enumerate(zip(mine, local)):
+        head[j] = (i, len(coords))
+    n_local = int(head[:, 1].sum())
+    body = np.zeros((n_local, 3), np.int64)             # (row, col, f32 bits) per hit
+    pos = 0
+    for coords, vals in local:
+        n = len(coords)
+        body[pos:pos + n, :2] = coords
+        body[pos:pos + n, 2] = np.asarray(vals, np.float32).view(np.int32)
+        pos += n
+    heads = [b.cpu().numpy() for b in _gather_exact(torch.from_numpy(head), device, group)]
+    bodies = [b.cpu().numpy() for b in _gather_exact(torch.from_numpy(body), device, group)]
+    out = [None] * len(pssms)
+    for h, b in zip(heads, bodies):
+        pos = 0
+        for i, n in h.tolist():
+            seg = b[pos:pos + n]
+            out[i] = (np.ascontiguousarray(seg[:, :2]),
+                      np.ascontiguousarray(seg[:, 2]).astype(np.int32).view(np.float32))
+            pos += n
+    return out
+
+
+# ---- the C ABI's own RCCL communicator (what a Rust / C++ host uses) ------------------
+
+
+class CabiComm:
+    """``lm_hip_comm_*`` / ``lm_hip_merge_*`` of include/lightmotif_hip.h: RCCL bound directly
+    by the library, no torch in the data path.  ``torch.distributed`` (or any other channel)
+    is needed once, to hand rank 0's 128-byte unique id to the other ranks."""
+
+    def __init__(self, pli, unique_id: bytes, nranks: int, rank: int):
+        import ctypes as C
+        from . import _ffi
+        self._pli, self._L, self._C = pli, pli._L, C
+        self.rank, self.nranks = rank, nranks
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _ffi.check(self._L.lm_hip_comm_create(pli._h, buf, nranks, rank, C.byref(h)))
+        self._h = h
+
+    @staticmethod
+    def unique_id(pli) -> bytes:
+        import ctypes as C
+        from . import _ffi
+        buf = (C.c_uint8 * 128)()
+        _ffi.check(pli._L.lm_hip_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def from_torch(cls, pli, device: torch.device | str = "cpu", group=None) -> "CabiComm":
+        """Rank 0 draws the unique id, ``torch.distributed`` broadcasts its 128 bytes."""
+        rank, world = _world(group)
+        dev = _coll_device(device, group) if world > 1 else torch.device("cpu")
+        t = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            t = torch.frombuffer(bytearray(cls.unique_id(pli)), dtype=torch.uint8).clone()
+        if world > 1:
+            t = t.to(dev)
+            dist.broadcast(t, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+        return cls(pli, bytes(t.cpu().numpy().tobytes()), world, rank)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._L.lm_hip_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def exchange_halo(self, shard: torch.Tensor, halo_rows: int, columns: int, default_symbol: int) -> None:
+        from . import _ffi
+        rows = shard.shape[0] - halo_rows
+        _ffi.check(self._L.lm_hip_exchange_halo_dptr(self._pli._h, self._h, self._C.c_void_p(shard.data_ptr()),
+                                                     rows, shard.shape[1], columns, halo_rows, default_symbol))
+
+    def merge_argmax(self, local, row_offset: int):
+        from . import _ffi
+        C = self._C
+        found, best, value = C.c_int(0), _ffi.Coords(), C.c_float(0)
+        loc = _ffi.Coords()
+        v = 0.0
+        if local is not None:
+            (loc.row, loc.col), v = local
+        _ffi.check(self._L.lm_hip_merge_argmax(self._pli._h, self._h, int(local is not None), C.byref(loc), v,
+                                               row_offset, C.byref(found), C.byref(best), C.byref(value)))
+        return ((best.row, best.col), float(value.value)) if found.value else None
+
+    def argmax_sharded(self, scores, row_offset: int):
+        """``StripedScores::argmax`` of the whole matrix from the resident shard ``scores``."""
+        from . import _ffi
+        C = self._C
+        found, best, value = C.c_int(0), _ffi.Coords(), C.c_float(0)
+        _ffi.check(self._L.lm_hip_argmax_sharded(self._pli._h, self._h, scores._h, row_offset, C.byref(found),
+                                                 C.byref(best), C.byref(value)))
+        return ((best.row, best.col), float(value.value)) if found.value else None
+
+    def merge_max(self, local: Optional[float]) -> Optional[float]:
+        from . import _ffi
+        C = self._C
+        found, value = C.c_int(0), C.c_float(0)
+        _ffi.check(self._L.lm_hip_merge_max(self._pli._h, self._h, int(local is not None),
+                                            0.0 if local is None else local, C.byref(found), C.byref(value)))
+        return float(value.value) if found.value else None
+
+    def merge_threshold(self, local_coords, row_offset: int) -> np.ndarray:
+        from . import _ffi
+        C = self._C
+        mine = np.ascontiguousarray(np.asarray(local_coords, dtype=np.uint64).reshape(-1, 2))
+        ptr, n = C.POINTER(_ffi.Coords)(), C.c_size_t(0)
+        _ffi.check(self._L.lm_hip_merge_threshold(self._pli._h, self._h,
+                                                  mine.ctypes.data_as(C.POINTER(_ffi.Coords)), mine.shape[0],
+                                                  row_offset, C.byref(ptr), C.byref(n)))
+        return self._pli._take_coords_array(ptr, n.value)
+
+
+def combine_argmax_cabi(records):
+    """``combine_argmax`` through the C ABI's host-side rule (``lm_hip_combine_argmax``): the
+    restatement a non-Python host links against; the tests hold the two against each other."""
+    import ctypes as C
+    from . import _ffi
+    L = _ffi.lib()
+    n = len(records)
+    found = (C.c_int * n)()
+    best = (_ffi.Coords * n)()
+    value = (C.c_float * n)()
+    for i, rec in enumerate(records):
+        if rec is not None:
+            found[i] = 1
+            (best[i].row, best[i].col), value[i] = rec
+    fo, bo, vo = C.c_int(0), _ffi.Coords(), C.c_float(0)
+    _ffi.check(L.lm_hip_combine_argmax(found, best, value, n, C.byref(fo), C.byref(bo), C.byref(vo)))
+    return ((bo.row, bo.col), float(vo.value)) if fo.value else None

@@ -92,6 +92,16 @@ class Pipeline:
         check(_ffi.lib().lm_hip_device_count(C.byref(n)))
         return n.value
 
+    @staticmethod
+    def device_ordinals() -> List[int]:
+        """HIP ordinals of the usable (gfx950) devices -- what ``Pipeline.hip(device)`` takes;
+        on a node with other GPUs in between this is not ``range(device_count())``."""
+        out, o = [], C.c_int(0)
+        for i in range(Pipeline.device_count()):
+            check(_ffi.lib().lm_hip_device_ordinal(i, C.byref(o)))
+            out.append(o.value)
+        return out
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             self._L.lm_hip_ctx_destroy(self._h)
@@ -165,6 +175,19 @@ class Pipeline:
                                         columns, wrap, length, _k(protein), C.byref(h)))
         return StripedSequence(self, h, protein)
 
+    def adopt_sequence(self, data_ptr: int, rows: int, wrap: int, columns: int, stride_: int,
+                       length: int, protein: bool = False, keepalive=None) -> "StripedSequence":
+        """A StripedSequence over a striped matrix that already lives on the device and stays
+        the caller's (``(rows + wrap) x stride`` bytes at ``data_ptr``, e.g. a torch tensor or
+        one row shard of a multi-GPU job): nothing is copied.  ``keepalive`` is held by the
+        returned object so the buffer outlives it."""
+        h = C.c_void_p()
+        check(self._L.lm_hip_seq_adopt_dptr(self._h, C.c_void_p(data_ptr), rows + wrap, stride_, columns,
+                                            wrap, length, _k(protein), C.byref(h)))
+        seq = StripedSequence(self, h, protein)
+        seq._keepalive = keepalive
+        return seq
+
     # -- Score (pli/mod.rs:69-130) ----------------------------------------------
 
     def score_rows_into(self, pssm: "ScoringMatrix", seq: "StripedSequence", rows: range,
@@ -195,6 +218,13 @@ class Pipeline:
         found, best, value = C.c_int(0), Coords(), C.c_float(0)
         check(self._L.lm_hip_argmax(self._h, scores._h, C.byref(found), C.byref(best), C.byref(value)))
         return bool(found.value), best, float(value.value)
+
+    def argmax_handle_shard(self, scores: "StripedScores", first_cell_rule: bool):
+        """``((row, col), value)`` of one row shard held in a handle (rows relative to the
+        shard), with the first-cell rule applied only when the shard holds row 0."""
+        scores.set_first_cell_rule(first_cell_rule)
+        found, best, value = self._argmax(scores)
+        return ((best.row, best.col), value) if found else None
 
     def threshold(self, scores: "StripedScores", threshold: float) -> List[Tuple[int, int]]:
         ptr, n = C.POINTER(Coords)(), C.c_size_t(0)
@@ -836,6 +866,11 @@ class StripedScores:
     @property
     def data_ptr(self) -> int:
         return self._info()[4]
+
+    def set_first_cell_rule(self, enabled: bool) -> None:
+        """This StripedScores is a row shard of a larger matrix: ``enabled=False`` when it does
+        not hold the matrix's first row (Maximum::argmax's NaN first-cell rule is skipped)."""
+        check(self._pli._L.lm_hip_scores_set_first_cell_rule(self._h, int(bool(enabled))))
 
     def is_empty(self) -> bool:
         return self.rows == 0

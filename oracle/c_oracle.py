@@ -157,7 +157,7 @@ def stripe(encoded: np.ndarray, cols: int = 32, k: int = DNA_K, extra_rows: int 
     st = stride(cols, 1)
     rows = -(-len(encoded) // cols)
     buf = aligned_empty((rows + extra_rows, st), np.uint8)
-    buf[:] = 0
+    buf[:] = k - 1   # spare rows like fresh DenseMatrix rows: T::default() (dense.rs:144-147)
     got = lib().lmo_stripe(_p8(encoded), len(encoded), cols, k - 1, _p8(buf), st)
     assert got == rows
     s = Striped(buf[:rows], len(encoded), 0, cols, k)
@@ -173,7 +173,7 @@ def configure_wrap(s: Striped, m: int) -> Striped:
     need = rows + m
     if need > s._buf.shape[0]:
         nb = aligned_empty((need + 32, s.stride), np.uint8)
-        nb[:] = 0
+        nb[:] = s.k - 1
         nb[:s.data.shape[0]] = s.data
         s._buf = nb
     wrap = lib().lmo_configure_wrap(_p8(s._buf), rows, s.stride, s.cols, s.wrap, m, s.k - 1)

@@ -66,9 +66,13 @@ size_t lmo_stripe(const uint8_t *seq, size_t len, size_t cols,
     const size_t rows = (len + cols - 1) / cols; /* pli/mod.rs:182 */
     if (rows == 0)
         return 0;
-    /* dense.rs:144-147: fresh rows are zero-filled (including the alignment
-     * padding past `cols`). */
-    memset(data, 0, rows * stride);
+    /* dense.rs:144-147: `resize_with(rows, Default::default)` -- every element of a
+     * fresh row is T::default(), which for Nucleotide / AminoAcid is the LAST symbol
+     * (N = 4 / X = 20, abc.rs:113-135, 231-256), not zero.  The bytes between `cols`
+     * and `stride` are struct padding of the reference's Row (unspecified there); this
+     * restatement and the HIP back-end fill them with the default symbol too, so that
+     * every byte of the matrix is a valid symbol index. */
+    memset(data, default_symbol, rows * stride);
     for (size_t i = 0; i < len; i++) /* pli/mod.rs:191-193 */
         data[(i % rows) * stride + (i / rows)] = seq[i];
     for (size_t i = len; i < rows * cols; i++) /* pli/mod.rs:194-196 */
@@ -82,8 +86,8 @@ size_t lmo_configure_wrap(uint8_t *data, size_t rows, size_t stride,
 {
     if (new_wrap <= old_wrap) /* seq.rs:370 */
         return old_wrap;
-    /* seq.rs:372: resize to rows + m (new rows zero-filled) */
-    memset(data + (rows + old_wrap) * stride, 0,
+    /* seq.rs:372: resize to rows + m (new rows = default symbol, dense.rs:144-147) */
+    memset(data + (rows + old_wrap) * stride, default_symbol,
            (new_wrap - old_wrap) * stride);
     for (size_t i = 0; i < new_wrap; i++) { /* seq.rs:373-378 */
         for (size_t j = 0; j + 1 < cols; j++)

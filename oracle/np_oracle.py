@@ -30,7 +30,7 @@ def stripe(encoded: np.ndarray, cols: int, default: int) -> np.ndarray:
     """pli/mod.rs:178-200: position i -> data[i % rows][i / rows]."""
     n = len(encoded)
     rows = -(-n // cols)
-    data = np.zeros((rows, stride(cols, 1)), dtype=np.uint8)
+    data = np.full((rows, stride(cols, 1)), default, dtype=np.uint8)   # dense.rs:144-147: T::default()
     if rows == 0:
         return data
     i = np.arange(rows * cols)
@@ -44,7 +44,7 @@ def configure_wrap(data: np.ndarray, rows: int, cols: int, wrap: int, m: int, de
     """seq.rs:369-381.  Returns (data, wrap)."""
     if m <= wrap:
         return data, wrap
-    out = np.zeros((rows + m, data.shape[1]), dtype=np.uint8)
+    out = np.full((rows + m, data.shape[1]), default, dtype=np.uint8)  # resize: T::default()
     out[:rows + wrap] = data[:rows + wrap]
     for i in range(m):
         out[rows + i, :cols - 1] = out[i, 1:cols]

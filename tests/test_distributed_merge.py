@@ -55,12 +55,12 @@ def _worker(rank, world, port, case, q):
             am = tuple(map(int, cand[-1]))
         loc = None if am is None else (am, float(sc[am]))
         got_am = D.merge_argmax(loc, a)
-        got_thr = D.merge_threshold([tuple(map(int, x)) for x in co.threshold(sc, cols, case["t"])], a)
+        got_thr = D.merge_threshold(co.threshold(sc, cols, case["t"]), a)
         got_max = D.merge_max(None if loc is None else loc[1])
         want_sc, _ = co.score_rows(full, pssm)
         want_am = co.argmax(want_sc, cols)
-        want_thr = [tuple(map(int, x)) for x in co.threshold(want_sc, cols, case["t"])]
-        ok = (got_am[0] == want_am and got_thr == want_thr)
+        want_thr = np.asarray(co.threshold(want_sc, cols, case["t"]), np.int64).reshape(-1, 2)
+        ok = (got_am[0] == want_am and got_thr.dtype == np.int64 and np.array_equal(got_thr, want_thr))
         if not case.get("nan_first"):
             ok = ok and np.float32(got_am[1]) == want_sc[want_am] and np.float32(got_max) == want_sc[want_am]
         q.put((rank, ok, got_am, want_am, len(got_thr), len(want_thr)))
@@ -110,5 +110,131 @@ def test_single_process_merges_are_identity():
     from lightmotif_amd import distributed as D
     assert D.merge_argmax(((3, 4), 1.5), 10) == ((13, 4), 1.5)
     assert D.merge_argmax(None, 0) is None
-    assert D.merge_threshold([(0, 1), (2, 3)], 5) == [(5, 1), (7, 3)]
+    assert D.merge_threshold([(0, 1), (2, 3)], 5).tolist() == [[5, 1], [7, 3]]
+    assert D.merge_threshold([], 5).shape == (0, 2)
+    # the pure rules: ties -> the later (row, col); NaN only through the first-cell rule of shard 0
+    nan = float("nan")
+    assert D.combine_argmax([((1, 2), 3.0), None, ((9, 0), 3.0)]) == ((9, 0), 3.0)
+    assert D.combine_argmax([((1, 31), 3.0), ((1, 2), 3.0)]) == ((1, 31), 3.0)
+    assert D.combine_argmax([((0, 0), nan), ((9, 0), 3.0)])[0] == (0, 0)
+    assert D.combine_argmax([None, None]) is None
+    assert D.combine_threshold([np.array([[0, 1]]), np.zeros((0, 2)), np.array([[0, 0], [3, 4]])],
+                               [0, 10, 20]).tolist() == [[0, 1], [20, 0], [23, 4]]
     assert D.merge_max(2.5) == 2.5 and D.merge_max(None) is None
+
+
+def test_c_abi_combine_rule_equals_the_python_rule():
+    """lm_hip_combine_argmax (host-side C, no device needed) against distributed.combine_argmax on
+    random record lists with ties, empty shards, NaN values and the first-cell (0,0) NaN."""
+    from lightmotif_amd import distributed as D
+    rng = np.random.default_rng(7)
+    nan = float("nan")
+    for trial in range(300):
+        n = int(rng.integers(1, 9))
+        recs, row = [], 0
+        for g in range(n):
+            span = int(rng.integers(1, 50))
+            kind = rng.integers(0, 6)
+            if kind == 0:
+                recs.append(None)
+            elif kind == 1 and g == 0:
+                recs.append(((0, 0), nan))                      # first-cell rule of the shard holding row 0
+            elif kind == 1:
+                recs.append(((row + int(rng.integers(0, span)), int(rng.integers(0, 32))), nan))  # must be ignored
+            else:
+                recs.append(((row + int(rng.integers(0, span)), int(rng.integers(0, 32))),
+                             float(np.float32(rng.integers(-2, 3)))))
+            row += span
+        want = D.combine_argmax(recs)
+        got = D.combine_argmax_cabi(recs)
+        if want is None:
+            assert got is None
+        else:
+            assert got[0] == want[0] and (got[1] == want[1] or (got[1] != got[1] and want[1] != want[1])), (recs, got, want)
+
+
+class _OraclePipeline:
+    """Stand-in for Pipeline in the CPU run of the motif-sharded batch: scores with the oracle."""
+
+    def __init__(self, striped):
+        self.s = striped
+
+    def _scores(self, p):
+        from oracle import c_oracle as co
+        return co.score_rows(self.s, p.data)[0]
+
+    def scan_argmax_batch(self, pssms, seq):
+        from oracle import c_oracle as co
+        out = []
+        for p in pssms:
+            sc = self._scores(p)
+            cell = co.argmax(sc, 32)
+            out.append(None if cell is None else (cell, float(sc[cell])))
+        return out
+
+    def scan_threshold_batch(self, pssms, ts, seq):
+        from oracle import c_oracle as co
+        out = []
+        for p, t in zip(pssms, ts):
+            sc = self._scores(p)
+            rc = np.asarray(co.threshold(sc, 32, t), np.int64).reshape(-1, 2)
+            out.append((rc, sc[rc[:, 0], rc[:, 1]].astype(np.float32)))
+        return out
+
+
+class _P:
+    def __init__(self, data):
+        self.data = data
+
+    def __len__(self):
+        return self.data.shape[0]
+
+
+def _motif_worker(rank, world, port, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lightmotif_amd import distributed as D
+        from oracle import c_oracle as co
+        rng = np.random.default_rng(99)
+        enc = rng.integers(0, 4, 6_000, dtype=np.uint8)
+        s = co.stripe(enc, 32, 5)
+        co.configure_wrap(s, 32)
+        pssms = []
+        for m in [4, 33, 8, 8, 12, 5, 20, 9, 6, 15, 7]:
+            p = np.zeros((m, 8), np.float32)
+            p[:, :4] = rng.integers(-2, 3, (m, 4)) if m % 2 else rng.normal(0, 2, (m, 4))
+            p[:, 4] = -np.inf
+            pssms.append(_P(p))
+        ts = [1.5 + 0.1 * i for i in range(len(pssms))]
+        pli = _OraclePipeline(s)
+        want_am = pli.scan_argmax_batch(pssms, None)
+        want_th = pli.scan_threshold_batch(pssms, ts, None)
+        got_am = D.scan_argmax_batch_sharded(pli, pssms, None)
+        got_th = D.scan_threshold_batch_sharded(pli, pssms, ts, None)
+        ok = got_am == want_am and len(got_th) == len(want_th)
+        for (gc, gv), (wc, wv) in zip(got_th, want_th):
+            ok = ok and np.array_equal(gc, wc) and np.array_equal(gv.view(np.uint32), wv.view(np.uint32))
+        parts = D.shard_motifs([len(p) for p in pssms], world)
+        q.put((rank, bool(ok), len(parts[rank])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_motif_sharded_batch_equals_single_process(world):
+    """configs[2] across GPUs: every rank scans its share of the motif list over the whole
+    sequence; the gathered per-motif results equal the single-process batch (main.rs:502-561)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_motif_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in results), results
+    assert all(n > 0 for _, _, n in results)

@@ -1,0 +1,370 @@
+"""The BASELINE.json configurations that had no `-m gpu` run in round 1, at config scale:
+
+* C1  the reference's own bench harness (lightmotif-bench/dna.rs:81-116): the MX000001-style
+      two-15-mer PSSM over a 464 165 bp sequence (the first tenth of U00096; `ecoli.txt` is
+      absent from the reference mount, so a seeded random stand-in of that length), striped
+      at C = 32 (dispatch / avx2 geometry) AND C = 1 (the Generic bench geometry, dna.rs:
+      113-116), `score_into` + `argmax` against the oracle bit for bit;
+* C3  the 2 346 matrices of the reference's `lightmotif-io/benches/JASPAR2024.pwm` (committed
+      as a data fixture), converted like the CLI (main.rs:469-498), over a 100 Mbp resident
+      sequence through `lm_hip_scan_argmax_batch` / `lm_hip_scan_threshold_batch`;
+* the multi-GPU shard entry points (`*_shard_*`, first_cell_rule = rank == 0) on ONE GPU:
+  a matrix cut into 2-3 row shards, merged with the rules of lightmotif_amd.distributed,
+  against the whole-matrix oracle (NaN first cell, cross-shard ties, all -inf).
+"""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import lightmotif_amd as lm
+from lightmotif_amd import distributed as D
+from lightmotif_amd import io as lmio
+from oracle import c_oracle as co
+
+pytestmark = pytest.mark.gpu
+COLS = 32
+FIXTURE = Path(__file__).parent / "golden" / "JASPAR2024.pwm.gz"
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def gpu_pli():
+    torch.cuda.set_device(0)
+    return lm.Pipeline.hip(0, stream=torch.cuda.current_stream().cuda_stream)
+
+
+# ---- C1 ---------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("cols", [32, 1], ids=["C32_dispatch_geometry", "C1_generic_bench_geometry"])
+def test_c1_reference_bench_harness(pli, cols):
+    """dna.rs:81-109: stripe, configure(pssm), then `score_into` + `argmax` per iteration."""
+    length = 464_165                                   # U00096 is 4 641 652 bp; dna.rs:88 takes len / 10
+    rng = np.random.default_rng(0xEC011)
+    enc = rng.integers(0, 4, length, dtype=np.uint8)
+    # plant the two sites so the maximum is a real occurrence somewhere late in the sequence
+    site = lm.EncodedSequence("GTTGACCTTATCAAC").data
+    enc[391_677:391_677 + 15] = site                   # the position the reference asserts on E. coli (dna.rs:247)
+    motif = lm.create(["GTTGACCTTATCAAC", "GTTGATCCAGTCAAC"])
+    pssm = motif.counts.normalize(0.1).log_odds()      # to_freq(0.1).to_scoring(None) (dna.rs:95-99)
+    ref = co.stripe(enc, cols, 5)
+    co.configure_wrap(ref, len(pssm) - 1)
+    want, want_mi = co.score_rows(ref, pssm.data)
+    assert np.array_equal(co.pssm_from_sites([lm.EncodedSequence(s).data for s in
+                                              ("GTTGACCTTATCAAC", "GTTGATCCAGTCAAC")])[:, :5], pssm.data[:, :5])
+
+    seq = pli.stripe(lm.EncodedSequence(enc), cols)
+    seq.configure(pssm)
+    assert (seq.rows, seq.stride, seq.wrap) == (ref.rows, 32, 14)
+    assert np.array_equal(seq.matrix()[:, :cols], ref.data[:, :cols])
+    scores = lm.StripedScores.empty(pli, cols)
+    for _ in range(3):                                 # the bench re-uses one StripedScores
+        pli.score_into(pssm, seq, scores)
+        best = pli.argmax(scores)
+    got = scores.matrix()
+    assert scores.max_index == want_mi == length - 14 and got.shape == want.shape
+    assert np.array_equal(bits(got[:, :cols]), bits(want[:, :cols]))
+    assert best == co.argmax(want, cols)
+    assert scores.offset(*best) == 391_677             # the planted best site, at either geometry
+    assert np.float32(pli.max(scores)) == want[best]
+    assert pli.score_argmax(pssm, seq) == (best, float(want[best]))
+    t = float(np.sort(want[:, :cols].ravel())[-40])
+    assert pli.threshold(scores, t) == [tuple(map(int, rc)) for rc in co.threshold(want, cols, t)]
+    assert sorted(scores.threshold(t)) == sorted(int(c) * ref.rows + int(r) for r, c in co.threshold(want, cols, t))
+
+
+# ---- C3 ---------------------------------------------------------------------------------------
+
+
+def test_c3_full_jaspar_batch_over_100_mbp(gpu_pli):
+    pli = gpu_pli
+    dev = torch.device("cuda", 0)
+    records = list(lmio.read(FIXTURE))
+    assert len(records) == 2346
+    pssms = [r.matrix.normalize(0.1).log_odds() for r in records]      # main.rs:473-478
+    lengths = np.array([len(p) for p in pssms])
+    assert lengths.min() == 4 and lengths.max() == 33 and int(lengths.sum()) == 22090   # SURVEY 8 [probe]
+    max_m = int(lengths.max())
+    length = 100_000_000
+    rows = -(-length // COLS)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0xC3)
+    mat = torch.empty((rows + max_m - 1, COLS), dtype=torch.uint8, device=dev)
+    mat[:rows] = torch.randint(0, 4, (rows, COLS), dtype=torch.uint8, device=dev, generator=gen)
+    pli.configure_wrap_dptr(mat.data_ptr(), rows, COLS, COLS, max_m - 1, 4)     # main.rs:540-546
+    torch.cuda.synchronize()
+    host = mat.cpu().numpy()
+    seq = pli.upload(host, length, max_m - 1, COLS)
+    ts = [p.score_for_pvalue(1e-5) for p in pssms]                              # main.rs:487-498
+
+    batch_am = pli.scan_argmax_batch(pssms, seq)
+    batch_th = pli.scan_threshold_batch(pssms, ts, seq)
+    assert len(batch_am) == len(batch_th) == 2346
+    total_hits = sum(len(c) for c, _ in batch_th)
+    assert 10_000 < total_hits < 50_000_000
+
+    # (1) every motif: batch == the fused single-motif calls
+    for i, p in enumerate(pssms):
+        m = len(p)
+        single = pli.score_argmax_dptr(p, seq.data_ptr, rows + max_m - 1, COLS, COLS, max_m - 1, length, 0, rows)
+        assert batch_am[i] == single, (i, m)
+        hits, vals = pli.score_threshold_dptr(p, seq.data_ptr, rows + max_m - 1, COLS, COLS, max_m - 1,
+                                              length, 0, rows, ts[i])
+        assert len(hits) == len(batch_th[i][0]), (i, m)
+        if i % 16 == 0:
+            assert np.array_equal(hits, batch_th[i][0]) and np.array_equal(bits(vals), bits(batch_th[i][1]))
+
+    # (2) >= 50 motifs covering every length 4..33 present in the fixture: the materialised
+    # matrix is pinned on the oracle over three row windows bit for bit, and the batch results
+    # are compared IN FULL with an independent torch formulation of argmax / threshold on it
+    chosen = []
+    for m in sorted(set(lengths.tolist())):
+        idx = np.flatnonzero(lengths == m)
+        chosen += idx[:: max(1, len(idx) // 3)][:3].tolist()
+    assert len(chosen) >= 50 and {int(lengths[i]) for i in chosen} == set(lengths.tolist())
+    scores = torch.empty((rows, COLS), dtype=torch.float32, device=dev)
+    for i in chosen:
+        p, m = pssms[i], int(lengths[i])
+        pli.score_dptr(p, seq.data_ptr, rows + max_m - 1, COLS, COLS, max_m - 1, length, 0, rows,
+                       scores.data_ptr(), COLS)
+        torch.cuda.synchronize()
+        for a in (0, rows // 2 + 12_345, rows - 2048):
+            b = min(a + 2048, rows)
+            win = co.Striped(host[a:b + m - 1], length, m - 1, COLS, 5)
+            want, _ = co.score_rows(win, p.data, 0, b - a)
+            assert np.array_equal(bits(scores[a:b].cpu().numpy()), bits(want)), (i, m, a)
+        flat = scores.view(-1)
+        vmax = flat.max()
+        last = int(torch.nonzero(flat == vmax)[-1])
+        assert batch_am[i] == ((last // COLS, last % COLS), float(vmax)), (i, m)
+        want_hits = torch.nonzero(scores >= ts[i])
+        assert np.array_equal(batch_th[i][0], want_hits.cpu().numpy()), (i, m)
+        assert np.array_equal(bits(batch_th[i][1]), bits(scores[want_hits[:, 0], want_hits[:, 1]].cpu().numpy()))
+
+
+# ---- the shard entry points + merge rules on one GPU -----------------------------------------
+
+
+def _planted(kind, rng, length, m):
+    enc = rng.integers(0, 4, length, dtype=np.uint8)
+    p = np.zeros((m, 8), np.float32)
+    p[:, :4] = rng.integers(-2, 3, (m, 4)) if kind in ("ties", "nan_first") else rng.normal(0, 2, (m, 4))
+    p[:, 4] = -np.inf
+    if kind == "nan_first":
+        p[0, int(enc[0])] = np.nan                     # scores[0][0] (and many other cells) are NaN
+    if kind == "all_neg_inf":
+        p[:, :4] = -np.inf
+    return enc, p
+
+
+@pytest.mark.parametrize("shards", [2, 3])
+@pytest.mark.parametrize("kind", ["random", "ties", "nan_first", "all_neg_inf", "nan_elsewhere"])
+def test_shard_entry_points_merge_to_the_whole_matrix_answer(gpu_pli, kind, shards):
+    """What rank g of a row-sharded job calls: lm_hip_argmax_shard_f32_dptr and
+    lm_hip_score_argmax_shard_f32_dptr with first_cell_rule = (g == 0) on rows [a_g, b_g) +
+    halo, then the merge (distributed.combine_*).  Must equal the Generic argmax / threshold of
+    the whole matrix (pli/mod.rs:135-155, 210-221)."""
+    pli = gpu_pli
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng([len(kind), ord(kind[0]), ord(kind[-1]), shards])
+    length, m = 3_000_017, 9
+    enc, p = _planted("random" if kind == "nan_elsewhere" else kind, rng, length, m)
+    ref = co.stripe(enc, COLS, 5)
+    co.configure_wrap(ref, m - 1)
+    rows = ref.rows
+    spans = [D.shard_rows(rows, shards, g) for g in range(shards)]
+    if kind == "nan_elsewhere":
+        # NaN cells only in a shard that does not hold row 0: its first cell is NaN, which must
+        # NOT trigger the first-cell rule there
+        a1 = spans[1][0]
+        first_sym = int(ref.data[a1, 0])
+        p[0, first_sym] = np.nan
+        if np.isnan(co.score_rows(ref, p, 0, 1)[0][0, 0]):
+            p[0, first_sym] = 0.0
+            pytest.skip("row 0 starts with the same symbol")
+    pssm = lm.ScoringMatrix(p)
+    want, _ = co.score_rows(ref, p)
+    want_am = co.argmax(want, COLS)
+    finite = want[:, :COLS][np.isfinite(want[:, :COLS])]
+    t = float(np.quantile(finite, 0.9995)) if finite.size else 0.0
+    want_thr = np.asarray(co.threshold(want, COLS, t), np.int64).reshape(-1, 2)
+
+    mats, fused, thr = [], [], []
+    for g, (a, b) in enumerate(spans):
+        shard = torch.from_numpy(ref.data[a:b + m - 1].copy()).to(dev)          # rows + halo
+        out = torch.empty((b - a, COLS), dtype=torch.float32, device=dev)
+        pli.score_dptr(pssm, shard.data_ptr(), b - a + m - 1, COLS, COLS, m - 1, length, 0, b - a,
+                       out.data_ptr(), COLS)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(out.cpu().numpy()), bits(want[a:b, :COLS]))
+        loc = pli.argmax_dptr(out.data_ptr(), b - a, COLS, COLS, first_cell_rule=g == 0)
+        fus = pli.score_argmax_dptr(pssm, shard.data_ptr(), b - a + m - 1, COLS, COLS, m - 1, length,
+                                    0, b - a, first_cell_rule=g == 0)
+        for name, rec in (("materialised", loc), ("fused", fus)):
+            if rec is not None and g > 0:
+                assert rec[1] == rec[1], f"{name}: a NaN left a shard that does not hold row 0"
+        mats.append(None if loc is None else ((loc[0][0] + a, loc[0][1]), loc[1]))
+        fused.append(None if fus is None else ((fus[0][0] + a, fus[0][1]), fus[1]))
+        thr.append(pli.threshold_dptr(out.data_ptr(), b - a, COLS, COLS, t))
+        f_hits, _ = pli.score_threshold_dptr(pssm, shard.data_ptr(), b - a + m - 1, COLS, COLS, m - 1,
+                                             length, 0, b - a, t)
+        assert np.array_equal(f_hits, thr[-1])
+    for name, recs in (("materialised", mats), ("fused", fused)):
+        got = D.combine_argmax(recs)
+        assert got is not None and got[0] == want_am, (name, got, want_am)
+        if want[want_am] == want[want_am]:
+            assert np.float32(got[1]) == want[want_am]
+        else:
+            assert got[1] != got[1]
+    got_thr = D.combine_threshold(thr, [a for a, _ in spans])
+    assert np.array_equal(got_thr, want_thr)
+    # with the rule applied on every shard (the single-GPU entry point misused) the NaN cases differ
+    if kind == "nan_elsewhere":
+        a, b = spans[1]
+        shard = torch.from_numpy(ref.data[a:b + m - 1].copy()).to(dev)
+        wrong = pli.score_argmax_dptr(pssm, shard.data_ptr(), b - a + m - 1, COLS, COLS, m - 1, length, 0, b - a,
+                                      first_cell_rule=True)
+        assert wrong[0] == (0, 0) and wrong[1] != wrong[1]
+
+
+# ---- ADVICE round 1 ---------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("wrap", [40, 63, 200])
+def test_upload_adopts_any_wrap(pli, wrap):
+    """A StripedSequence already configured for a long motif (configure_wrap(max_m) of the CLI,
+    M = 41 / 64 shapes) must be adoptable: round 1 refused wrap > 32."""
+    rng = np.random.default_rng(wrap)
+    enc = rng.integers(0, 4, 5_003, dtype=np.uint8)
+    ref = co.stripe(enc, COLS, 5, extra_rows=wrap + 8)
+    co.configure_wrap(ref, wrap)
+    seq = pli.upload(ref.data, len(enc), wrap, COLS)
+    assert (seq.rows, seq.wrap) == (ref.rows, wrap)
+    assert np.array_equal(seq.matrix(), ref.data)
+    m = min(wrap + 1, 64)
+    p = np.zeros((m, 8), np.float32)
+    p[:, :4] = rng.normal(0, 2, (m, 4))
+    p[:, 4] = -np.inf
+    want, _ = co.score_rows(ref, p)
+    got = pli.score(lm.ScoringMatrix(p), seq).matrix()
+    assert np.array_equal(bits(got[:, :COLS]), bits(want[:, :COLS]))
+
+
+def test_symbol_bytes_are_validated_at_the_handle_entry_points(pli):
+    enc = np.zeros(1000, np.uint8)
+    enc[777] = 5                                                     # not a Nucleotide
+    with pytest.raises(lm.InvalidSymbol):
+        pli.stripe(lm.EncodedSequence(enc), COLS)
+    enc[777] = 4
+    ref = co.stripe(enc, COLS, 5)
+    data = ref.data.copy()
+    data[3, 7] = 9
+    with pytest.raises(lm.InvalidSymbol):
+        pli.upload(data, len(enc), 0, COLS)
+    enc21 = np.full(100, 20, np.uint8)                               # X is a valid AminoAcid
+    assert len(pli.stripe(lm.EncodedSequence(enc21, protein=True), COLS)) == 100
+    # padding bytes past `cols` are not symbols: garbage there (a Rust Row's struct padding) is fine
+    ref16 = co.stripe(enc, 16, 5)
+    d16 = ref16.data.copy()
+    d16[:, 16:] = 0xAB
+    seq = pli.upload(d16, len(enc), 0, 16)
+    assert seq.columns == 16
+
+
+def test_padding_past_cols_is_the_default_symbol(pli):
+    """dense.rs:144-147 fills fresh rows with T::default() = N / X; stride > cols layouts keep
+    every byte a valid symbol."""
+    enc = np.arange(100, dtype=np.uint8) % 4
+    for cols in (1, 16, 33):
+        seq = pli.stripe(lm.EncodedSequence(enc), cols)
+        seq.configure_wrap(3)
+        ref = co.stripe(enc, cols, 5)
+        co.configure_wrap(ref, 3)
+        got = seq.matrix()
+        assert np.array_equal(got, ref.data)
+        assert (got[:, cols:] == 4).all()
+
+
+def test_device_ordinals_lists_usable_devices():
+    ords = lm.Pipeline.device_ordinals()
+    assert len(ords) == lm.Pipeline.device_count() >= 1
+    assert lm.Pipeline.hip(ords[0]) is not None
+
+
+def test_c_abi_communicator_single_rank(gpu_pli):
+    """lm_hip_comm_* with nranks = 1 on the box's one GPU: librccl is opened by the library
+    itself, the communicator initialises, and halo / argmax / max / threshold merges run through
+    real RCCL collectives (all_gather, broadcast) -- the degenerate world every rank-count
+    shares.  (Two ranks cannot share one GPU under RCCL; world sizes 2 and 3 are covered by the
+    gloo tests of the merge rules and by the driver's multi-GPU bench.)"""
+    pli = gpu_pli
+    dev = torch.device("cuda", 0)
+    comm = D.CabiComm.from_torch(pli)
+    assert (comm.rank, comm.nranks) == (0, 1)
+    rng = np.random.default_rng(5)
+    length, m = 2_000_003, 11
+    enc = rng.integers(0, 4, length, dtype=np.uint8)
+    p = np.zeros((m, 8), np.float32)
+    p[:, :4] = rng.integers(-2, 3, (m, 4))
+    p[:, 4] = -np.inf
+    ref = co.stripe(enc, COLS, 5)
+    rows = ref.rows
+    shard = torch.empty((rows + m - 1, COLS), dtype=torch.uint8, device=dev)
+    shard[:rows] = torch.from_numpy(ref.data[:rows].copy()).to(dev)
+    shard[rows:] = 77
+    comm.exchange_halo(shard, m - 1, COLS, 4)           # world of one: the wrap rows of seq.rs:373-378
+    co.configure_wrap(ref, m - 1)
+    assert np.array_equal(shard.cpu().numpy(), ref.data)
+    want, _ = co.score_rows(ref, p)
+    pssm = lm.ScoringMatrix(p)
+    seq = pli.adopt_sequence(shard.data_ptr(), rows, m - 1, COLS, COLS, length, keepalive=shard)
+    scores = lm.StripedScores.empty(pli, COLS)
+    pli.score_into(pssm, seq, scores)
+    want_am = co.argmax(want, COLS)
+    got = comm.argmax_sharded(scores, 0)
+    assert got == (want_am, float(want[want_am]))
+    assert comm.merge_argmax(got, 0) == got and comm.merge_argmax(None, 0) is None
+    assert comm.merge_argmax(((5, 6), 1.25), 1000) == ((1005, 6), 1.25)
+    assert comm.merge_max(2.5) == 2.5 and comm.merge_max(None) is None
+    t = float(np.sort(want[:, :COLS].ravel())[-5000])
+    hits = pli.threshold_dptr(scores.data_ptr, rows, COLS, COLS, t)
+    merged = comm.merge_threshold(hits, 123)
+    assert np.array_equal(merged[:, 0], hits[:, 0] + 123) and np.array_equal(merged[:, 1], hits[:, 1])
+    assert comm.merge_threshold(np.zeros((0, 2), np.int64), 0).shape == (0, 2)
+    # the shard flag: a NaN first cell is reported only when the rule is on
+    p2 = p.copy()
+    p2[0, int(enc[0])] = np.nan
+    pssm2 = lm.ScoringMatrix(p2)
+    for rule in (True, False):
+        scores.set_first_cell_rule(rule)
+        pli.score_into(pssm2, seq, scores)
+        rec = pli.argmax(scores), pli.max(scores)
+        mat = pli.argmax_dptr(scores.data_ptr, rows, COLS, COLS, first_cell_rule=rule)
+        assert rec[0] == mat[0]
+        assert (rec[0] == (0, 0) and rec[1] != rec[1]) if rule else (rec[1] == rec[1])
+    comm.close()
+
+
+def test_adopted_sequence_borrows_the_callers_matrix(gpu_pli):
+    pli = gpu_pli
+    dev = torch.device("cuda", 0)
+    enc = np.arange(5000, dtype=np.uint8) % 4
+    ref = co.stripe(enc, COLS, 5)
+    co.configure_wrap(ref, 9)
+    t = torch.zeros((ref.rows + 12, COLS), dtype=torch.uint8, device=dev)
+    t[:ref.rows + 9] = torch.from_numpy(ref.data.copy()).to(dev)
+    seq = pli.adopt_sequence(t.data_ptr(), ref.rows, 9, COLS, COLS, len(enc), keepalive=t)
+    assert seq.data_ptr == t.data_ptr() and (seq.rows, seq.wrap) == (ref.rows, 9)
+    seq.configure_wrap(12)                               # fits the rows handed over
+    co.configure_wrap(ref, 12)
+    assert np.array_equal(t.cpu().numpy(), ref.data)
+    with pytest.raises(lm.LightmotifHipError):
+        seq.configure_wrap(13)                           # would need a reallocation of memory it does not own
+    del seq
+    torch.cuda.synchronize()
+    assert int(t[0, 0]) == int(ref.data[0, 0])           # still the caller's, not freed

@@ -1,0 +1,48 @@
+#!/bin/bash
+# Issue / stall breakdown of the library's kernels from the SQ counters (one counter group per
+# pass, --kernel-trace only: gpurun refuses --pmc together with the hip/hsa trace domains).
+#   gpurun --timeout 1200 -- 'bash tools/collect_stalls.sh r02 "python bench.py --steps 6 --warmup 3 --no-cpu-baseline --preheat-ms 0"'
+# Units (MI355X_MICROARCH.md, "rocprofv3 PMC slots"): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_*
+# count quad-cycles summed over waves; WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES.
+TAG=${1:-r02}
+CMD=${2:-"python bench.py --steps 6 --warmup 3 --no-cpu-baseline --preheat-ms 0"}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/stalls_$TAG
+rm -rf "$OUT"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 -L > "$OUT/counters_available.txt" 2>&1
+GROUPS_=(
+ "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS"
+ "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD"
+ "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS"
+ "SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_WAVE32_LDS SQ_THREAD_CYCLES_VALU SQ_IFETCH SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_ACTIVE_INST_FLAT"
+ "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_sum TA_BUSY_avr"
+ "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_RDREQ_sum"
+ "GRBM_GUI_ACTIVE GRBM_COUNT"
+)
+i=0
+for G in "${GROUPS_[@]}"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $G --output-format csv -d "$OUT/g$i" -o p -- $CMD \
+      > "$OUT/g$i.log" 2>&1 || echo "group $i failed: $G" >> "$OUT/failed.txt"
+done
+cd "$ROOT"
+python - "$OUT" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for p in glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(p)):
+        n = r["Kernel_Name"]
+        if "lm::" not in n and "kb::" not in n:
+            continue
+        k = n[n.index("::") - 2:].split("(")[0][:48]
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(out + "/summary.txt", "w") as f:
+    for k in sorted(acc):
+        f.write(k + "\n")
+        for c, v in sorted(acc[k].items()):
+            f.write(f"    {c:34s} {sum(v)/len(v):14.5g}   (n={len(v)})\n")
+print(open(out + "/summary.txt").read()[:6000])
+PY
+rm -rf "$OUT"/g*/  # the raw per-dispatch CSVs are large
