@@ -328,10 +328,12 @@ int lm_hip_seq_upload(lm_hip_ctx *ctx, const uint8_t *data, size_t rows_total, s
                       size_t cols, size_t wrap, size_t length, size_t k, lm_hip_seq **out);
 /* The same for a matrix that already lives on the device and stays the CALLER's (a buffer of the
  * host application, a torch tensor, one row shard of a multi-GPU job): nothing is copied or
- * checked, lm_hip_seq_destroy does not free it, and lm_hip_seq_configure_wrap can only grow the
- * wrap inside the rows_total rows handed over (LM_HIP_ERR_CAPACITY beyond). */
-int lm_hip_seq_adopt_dptr(lm_hip_ctx *ctx, uint8_t *d_data, size_t rows_total, size_t stride,
-                          size_t cols, size_t wrap, size_t length, size_t k, lm_hip_seq **out);
+ * checked, lm_hip_seq_destroy does not free it.  rows_total rows (incl. `wrap` wrap rows) are
+ * valid; the buffer has room for capacity_rows >= rows_total rows, and
+ * lm_hip_seq_configure_wrap grows the wrap inside that room only (LM_HIP_ERR_CAPACITY beyond). */
+int lm_hip_seq_adopt_dptr(lm_hip_ctx *ctx, uint8_t *d_data, size_t rows_total, size_t capacity_rows,
+                          size_t stride, size_t cols, size_t wrap, size_t length, size_t k,
+                          lm_hip_seq **out);
 /* EncodedSequence::to_striped (seq.rs:168-175) on the device: uploads `len`
  * symbol bytes (each < k, else LM_HIP_ERR_INVALID_SYMBOL) and stripes them there. */
 int lm_hip_seq_from_encoded(lm_hip_ctx *ctx, const uint8_t *encoded, size_t len, size_t cols,

@@ -107,7 +107,7 @@ SIGNATURES = {
     "lm_hip_argmax": (C.c_int, [_vp, _vp, _ip, _cp, _fp]),
     "lm_hip_threshold": (C.c_int, [_vp, _vp, C.c_float, C.POINTER(_cp), _szp]),
     # row-sharded jobs
-    "lm_hip_seq_adopt_dptr": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, C.POINTER(_vp)]),
+    "lm_hip_seq_adopt_dptr": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz, C.POINTER(_vp)]),
     "lm_hip_scores_set_first_cell_rule": (C.c_int, [_vp, C.c_int]),
     "lm_hip_combine_argmax": (C.c_int, [_ip, _cp, _fp, _sz, _ip, _cp, _fp]),
     "lm_hip_comm_unique_id": (C.c_int, [_vp]),

@@ -979,13 +979,13 @@ int lm_hip_seq_upload(lm_hip_ctx *ctx, const uint8_t *data, size_t rows_total, s
     return LM_HIP_OK;
 }
 
-int lm_hip_seq_adopt_dptr(lm_hip_ctx *ctx, uint8_t *d_data, size_t rows_total, size_t stride, size_t cols,
-                          size_t wrap, size_t length, size_t k, lm_hip_seq **out)
+int lm_hip_seq_adopt_dptr(lm_hip_ctx *ctx, uint8_t *d_data, size_t rows_total, size_t capacity_rows,
+                          size_t stride, size_t cols, size_t wrap, size_t length, size_t k, lm_hip_seq **out)
 {
     if (!ctx || !out || (rows_total && !d_data))
         return fail(LM_HIP_ERR_BAD_ARGS, "seq_adopt: null argument");
     *out = nullptr;
-    if (cols == 0 || stride < cols || wrap > rows_total || k == 0 || k > 256)
+    if (cols == 0 || stride < cols || wrap > rows_total || capacity_rows < rows_total || k == 0 || k > 256)
         return fail(LM_HIP_ERR_BAD_ARGS, "seq_adopt: bad geometry");
     lm_hip_seq *s = new (std::nothrow) lm_hip_seq();
     if (!s)
@@ -993,7 +993,7 @@ int lm_hip_seq_adopt_dptr(lm_hip_ctx *ctx, uint8_t *d_data, size_t rows_total, s
     s->device = ctx->device;
     s->d_data = d_data;
     s->owns = false;
-    s->capacity_rows = rows_total;
+    s->capacity_rows = capacity_rows;
     s->rows = rows_total - wrap;
     s->wrap = wrap;
     s->stride = stride;

@@ -170,9 +170,18 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const Score
         return p;
     // The fused kernels write nothing, so they are LDS/VALU-bound and prefer long
     // streams (fewer fill steps): T=1001 0.69 ms vs T=61 0.79 ms on the same input.
+    // Store kernel: three groups per stream (T = 3M + 1) up to M = 26, where the write pattern
+    // binds and short streams keep the window of rows in flight compact (M = 12: T = 37 0.872 ms,
+    // T = 73 0.894; M = 20: T = 61 0.940, T = 121 0.970; M = 24: T = 73 1.001, T = 145 1.024);
+    // longer motifs are bound by the LDS gather and want the fill / drain groups amortised over
+    // six groups (M = 28: T = 57 1.29 ms, T = 169 1.08; M = 33: T = 67 1.30, T = 199 1.22;
+    // profiles/r02_edge_ab.txt).  Very short motifs keep ~24 rows per stream.
     unsigned long long target = ctx->rows_per_stream ? ctx->rows_per_stream
                                 : default_rows         ? default_rows
-                                                       : (store ? 64 : 1024);
+                                : !store               ? 1024
+                                : prefilter != 0       ? 64
+                                : ms.m > 26            ? 6 * M
+                                                       : std::max<size_t>(3 * M, 24);
     // keep at least ~4 streams per SIMD lane-half in flight on small inputs
     // Enough workgroups for several rounds of the chip's resident capacity (6 x 256 CUs
     // of 8-stream workgroups), so the last partial round costs little; the fused

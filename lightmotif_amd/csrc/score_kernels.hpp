@@ -232,6 +232,39 @@ __device__ __forceinline__ void lds_fetch_column(float (&w)[4 * ((M + 3) / 4)],
     }
 }
 
+// Edge groups (FIRST / LAST) need only part of the column: floats [4*C0, 4*C1).  Left to itself the
+// compiler narrows those reads to the exact floats (ds_read_b32 / b64: 85 LDS instructions in the
+// LAST group of M = 20 instead of 55), and a narrow read occupies the LDS pipeline as long as a
+// 16-byte one (SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS = 4.0 cycles across the kernel).  `volatile`
+// keeps them whole: 9 % fewer LDS cycles.  Interleaved A/B per motif length on one box
+// (profiles/r02_edge_ab.txt, 1 Gbp, best stream length each): M = 12 0.872 vs 0.884 ms, M = 16
+// 0.915 vs 0.927, M = 24 1.001 vs 1.004, M = 28 1.077 vs 1.089, M = 33 1.223 vs 1.253, M = 36
+// 1.296 vs 1.306 -- but M = 20 0.958 vs 0.940 at every stream length (the volatile reads also
+// pin the schedule of the edge groups; at five chunks per column that costs more than the
+// narrow reads do), hence the hole in the middle.
+#ifndef LM_SCORE_EDGE_B128
+#define LM_SCORE_EDGE_B128(M) ((M) <= 16 || (M) >= 24)
+#endif
+template <int M>
+__device__ __forceinline__ void lds_fetch_chunks(float (&w)[4 * ((M + 3) / 4)], const char *__restrict__ tab,
+                                                 const unsigned s, const int c0, const int c1)
+{
+    constexpr unsigned TSB = table_stride(M, false) * 4;
+    const char *row = static_cast<const char *>(__builtin_assume_aligned(tab + __umul24(s, TSB), 16));
+#pragma unroll
+    for (int q = 0; q < (M + 3) / 4; ++q) {
+        if (q < c0 || q >= c1)  // folds: the bounds are constants of the unrolled step
+            continue;
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        typedef const volatile __attribute__((address_space(3))) f32x4_t *lds_ptr;  // explicit LDS space:
+        const f32x4_t v = *(lds_ptr)(row + 16 * q);  // a volatile generic pointer would become flat_load
+        w[4 * q + 0] = v.x;
+        w[4 * q + 1] = v.y;
+        w[4 * q + 2] = v.z;
+        w[4 * q + 3] = v.w;
+    }
+}
+
 // Quad-gathered symbol loads: the lanes of a quad (columns 4i..4i+3) fetch a 4 x 4 block of
 // symbols with ONE dword load each (lane q: row r+q, columns 4i..4i+3) and every lane picks
 // its own column out of its neighbours' registers: symbol(row r+t) = byte (lane & 3) of the
@@ -285,7 +318,18 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
         }
         // (2) the PSSM column of this step's symbol
         float w[NW];
-        if (QL) {
+        if (LM_SCORE_EDGE_B128(M) && !WIDE && !LP && PHASE != PHASE_MAIN) {
+            // FIRST: outputs started at steps 0..k -> weights 0..k.  LAST: the stream's last output
+            // starts at the group's step 0, so step k still needs weights k..M-1
+            const unsigned sy = QL ? s_now : sym[k];
+#pragma unroll
+            for (int i = 0; i < NW; ++i)
+                w[i] = 0.0f;
+            if (PHASE == PHASE_FIRST)
+                lds_fetch_chunks<M>(w, tab, sy, 0, k / 4 + 1);
+            else
+                lds_fetch_chunks<M>(w, tab, sy, k / 4, (M + 3) / 4);
+        } else if (QL) {
             lds_fetch_column<M, WIDE>(w, tab, s_now);
         } else if (LP) {
 #pragma unroll

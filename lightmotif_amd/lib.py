@@ -176,13 +176,16 @@ class Pipeline:
         return StripedSequence(self, h, protein)
 
     def adopt_sequence(self, data_ptr: int, rows: int, wrap: int, columns: int, stride_: int,
-                       length: int, protein: bool = False, keepalive=None) -> "StripedSequence":
+                       length: int, protein: bool = False, keepalive=None,
+                       capacity_rows: Optional[int] = None) -> "StripedSequence":
         """A StripedSequence over a striped matrix that already lives on the device and stays
         the caller's (``(rows + wrap) x stride`` bytes at ``data_ptr``, e.g. a torch tensor or
-        one row shard of a multi-GPU job): nothing is copied.  ``keepalive`` is held by the
+        one row shard of a multi-GPU job): nothing is copied.  ``capacity_rows`` = rows the
+        buffer has room for (configure_wrap may grow into them).  ``keepalive`` is held by the
         returned object so the buffer outlives it."""
         h = C.c_void_p()
-        check(self._L.lm_hip_seq_adopt_dptr(self._h, C.c_void_p(data_ptr), rows + wrap, stride_, columns,
+        check(self._L.lm_hip_seq_adopt_dptr(self._h, C.c_void_p(data_ptr), rows + wrap,
+                                            max(capacity_rows or 0, rows + wrap), stride_, columns,
                                             wrap, length, _k(protein), C.byref(h)))
         seq = StripedSequence(self, h, protein)
         seq._keepalive = keepalive
@@ -1049,13 +1052,28 @@ class Scanner:
         i = top[np.argmax(pos[top])]
         return Hit(int(pos[i]), float(sc[i]))
 
-    def max(self) -> Optional[Hit]:
+    def max(self, strict_reference: bool = False, saturate: bool = True) -> Optional[Hit]:
         """scan.rs:200-249: the best hit not yet yielded; greater score wins, equal scores
         go to the greater position (scan.rs:237).  Consumes the scanner.
 
-        On a fresh scanner the hit list is never built (a low threshold would select most of
-        the sequence): the fused argmax gives the greatest score S of the matrix, and one
-        scan at max(threshold, S) returns the few valid positions that reach it."""
+        Default: the best VALID hit -- ``score >= threshold`` and ``position + M <= L`` like
+        every hit ``__next__`` yields (scan.rs:186-189).  On a fresh scanner the hit list is
+        never built (a low threshold would select most of the sequence): the fused argmax
+        gives the greatest score S of the matrix, and one scan at max(threshold, S) returns
+        the few valid positions that reach it.
+
+        This deviates from the reference's ``max()`` in corner cases, on purpose: there the
+        u8 DiscreteMatrix scores steer which cells are looked at, and (a) positions are not
+        tested against ``position + M <= L``, (b) while no hit is held the first candidate is
+        accepted even if its f32 score is below the threshold, (c) cells are filtered by the
+        u8 score of the current best hit, an over-estimate, so a better cell with a smaller
+        u8 score is skipped (scan.rs:227-243).  ``strict_reference=True`` reproduces all of
+        that literally from the device-computed u8 and f32 score matrices (``saturate``:
+        the u8 adds of the x86-64 ``dispatch`` pipeline, avx2.rs:336; ``False`` = Generic's
+        wrapping adds); it materialises both matrices and walks the candidates on the host,
+        so it is a parity tool, not the fast path."""
+        if strict_reference:
+            return self._max_strict(saturate)
         if self._order is None:
             pli = self._seq._pli
             top = pli.score_argmax(self._pssm, self._seq)
@@ -1078,6 +1096,59 @@ class Scanner:
         rest = self._order[self._next:]
         self._next = self._order.size
         return self._best(self._positions[rest], self._scores[rest])
+
+    def _max_strict(self, saturate: bool) -> Optional[Hit]:
+        """``Scanner::max`` of the reference as written (scan.rs:200-249).
+
+        State of the reference scanner after some ``next()`` calls: ``row`` = the block after
+        the one the last yielded hit came from, ``hits`` = the not yet yielded hits of that
+        block (scan.rs:169-198).  The same state is derived here from the complete hit list."""
+        pli, seq, pssm = self._seq._pli, self._seq, self._pssm
+        thr = np.float32(self.threshold)
+        rows, cols, m, bs = seq.rows, seq.columns, len(pssm), self.block_size
+        best: Optional[Tuple[int, np.float32]] = None
+        first_block = 0
+        if self._order is not None and self._next > 0:
+            last = self._order[self._next - 1]
+            blk = (int(self._positions[last]) % rows) // bs
+            first_block = blk + 1
+            rest = self._order[self._next:]
+            rest = rest[(self._positions[rest] % rows) // bs == blk]
+            for i in rest[::-1]:                       # the vector's order = reverse of the yield order
+                sc = np.float32(self._scores[i])       # scan.rs:207-210; max_by keeps the LAST of equals
+                if sc >= thr and (best is None or not (sc < best[1])):
+                    best = (int(self._positions[i]), sc)
+        self._order = np.zeros(0, np.int64)            # consumed (scan.rs:200 takes `self`)
+        self._positions, self._scores, self._next = np.zeros(0, np.int64), np.zeros(0, np.float32), 0
+        if rows == 0 or len(seq) < m:
+            return None if best is None else Hit(best[0], float(best[1]))
+        dm = pssm.to_discrete()
+        level = dm.scale(float(best[1])) if best is not None else dm.scale(float(thr))   # scan.rs:211-214
+        d_all, _ = pli.score_discrete(dm, seq, saturate=saturate)
+        f_all = pli.score(pssm, seq)
+        starts = np.arange(0, rows, bs)
+        block_max = np.maximum.reduceat(d_all[:, :cols].max(axis=1), starts)
+        for b in range(first_block, starts.size):
+            if int(block_max[b]) < level:              # scan.rs:227
+                continue
+            r0 = b * bs
+            d = d_all[r0:r0 + bs, :cols]
+            rr, cc = np.nonzero(d >= level)            # Threshold: row-major (row, col) order
+            fs = f_all.rows_matrix(r0, min(r0 + bs, rows))
+            for r, c in zip(rr.tolist(), cc.tolist()):
+                ds = int(d[r, c])
+                if ds < level:                         # scan.rs:229: the level moves inside the loop
+                    continue
+                index = c * rows + r0 + r
+                if index + m > rows * cols:            # seq[pos + j] past the matrix: the reference panics
+                    raise IndexError(f"Scanner.max: position {index} + {m} leaves the striped matrix")
+                score = np.float32(fs[r, c])           # = score_position (pwm/mod.rs:651-662)
+                if best is None:
+                    best = (index, score)              # scan.rs:241: no threshold test, level unchanged
+                elif score > best[1] or (score == best[1] and index > best[0]):
+                    best = (index, score)
+                    level = ds
+        return None if best is None else Hit(best[0], float(best[1]))
 
 
 # --- module-level helpers (lib.rs:1335-1451) ---------------------------------------------------

@@ -162,6 +162,46 @@ def scanner_max(scores: np.ndarray, cols: int, length: int, m: int, t: float):
     return best
 
 
+def scanner_max_strict(scores: np.ndarray, dscores: np.ndarray, cols: int, t: float, scale,
+                       block_size: int = 256, pending=()):
+    """scan.rs:200-249 `Scanner::max`, line by line, quirks included.  `scores` = the f32
+    score matrix (what `score_position` returns for cell (row, col), pwm/mod.rs:651-662),
+    `dscores` = the u8 scores of the DiscreteMatrix the reference's pipeline produces (on
+    x86-64 `dispatch` = AVX2: saturating adds, avx2.rs:336), `scale` = DiscreteMatrix::scale
+    (pwm/mod.rs:782-784), `pending` = hits already collected but not yet yielded (scan.rs:207).
+
+    Quirks reproduced on purpose: (a) no `index + M <= L` test (scan.rs:230-232); (b) while
+    no best hit exists the FIRST candidate is accepted without `score >= threshold`
+    (scan.rs:240-242) and `best_discrete` keeps the scaled threshold; (c) once a hit is held,
+    cells are filtered by the u8 score of the CURRENT best (scan.rs:229, 238), an over-estimate,
+    so a cell with a greater f32 score but a smaller u8 score is skipped."""
+    rows = scores.shape[0]
+    tt = np.float32(t)
+    best = None
+    for pos, sc in pending:                                   # scan.rs:207-210 (max_by: last of equals)
+        if sc >= tt and (best is None or not (sc < best[1])):
+            best = (pos, np.float32(sc))
+    best_discrete = scale(best[1]) if best is not None else scale(tt)   # scan.rs:211-214
+    for row0 in range(0, rows, block_size):                   # scan.rs:220-247 (blocks past the
+        end = min(row0 + block_size, rows)                    #   sequence rows are empty)
+        d = dscores[row0:end, :cols]
+        if d.size == 0 or int(d.max()) < best_discrete:       # scan.rs:227
+            continue
+        cand = np.argwhere(d >= best_discrete)                # Threshold: row-major (pli/mod.rs:212-218)
+        for r, c in cand:
+            dscore = int(d[r, c])
+            if dscore >= best_discrete:                       # scan.rs:229 (best_discrete moves)
+                index = int(c) * rows + row0 + int(r)
+                score = scores[row0 + r, c]
+                if best is not None:
+                    if score > best[1] or (score == best[1] and index > best[0]):   # scan.rs:236-239
+                        best = (index, score)
+                        best_discrete = dscore
+                else:
+                    best = (index, score)                     # scan.rs:241
+    return best
+
+
 # ---- DiscreteMatrix (pwm/mod.rs:665-696, 754-791) ------------------------------------------
 
 

@@ -358,7 +358,7 @@ def test_adopted_sequence_borrows_the_callers_matrix(gpu_pli):
     co.configure_wrap(ref, 9)
     t = torch.zeros((ref.rows + 12, COLS), dtype=torch.uint8, device=dev)
     t[:ref.rows + 9] = torch.from_numpy(ref.data.copy()).to(dev)
-    seq = pli.adopt_sequence(t.data_ptr(), ref.rows, 9, COLS, COLS, len(enc), keepalive=t)
+    seq = pli.adopt_sequence(t.data_ptr(), ref.rows, 9, COLS, COLS, len(enc), keepalive=t, capacity_rows=t.shape[0])
     assert seq.data_ptr == t.data_ptr() and (seq.rows, seq.wrap) == (ref.rows, 9)
     seq.configure_wrap(12)                               # fits the rows handed over
     co.configure_wrap(ref, 12)

@@ -609,3 +609,73 @@ def test_entry_points_are_thread_safe(pli):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("kind", ["random", "below_threshold_first_candidate", "finite_n_tail", "overestimate_skip",
+                                  "partially_consumed"])
+def test_scanner_max_strict_reference_mode(pli, kind):
+    """`Scanner.max(strict_reference=True)` walks scan.rs:200-249 as written -- u8 DiscreteMatrix
+    scores steer the candidates, no `position + M <= L` test, first candidate accepted without
+    the f32 threshold test, level = u8 score of the current best -- and must equal the oracle's
+    literal restatement (np_oracle.scanner_max_strict) on inputs built to hit each quirk; the
+    default mode must stay the best VALID hit."""
+    rng = np.random.default_rng(sum(map(ord, kind)))
+    length, m = 30_011, 9
+    enc = rng.integers(0, 4, length, dtype=np.uint8)
+    p = np.zeros((m, 8), np.float32)
+    p[:, :4] = rng.normal(0, 2, (m, 4))
+    p[:, 4] = -np.inf
+    if kind == "finite_n_tail":
+        p[:, 4] = 3.0                                   # N scores high: the padded tail holds the maximum
+        length = 30_000 - 7                             # tail cells exist (rows * 32 > L)
+        enc = enc[:length]
+    if kind == "overestimate_skip":
+        p[:, :4] = rng.integers(-3, 4, (m, 4)) + rng.random((m, 4)).astype(np.float32) * 0.3
+    ref = co.stripe(enc, 32, 5)
+    co.configure_wrap(ref, m - 1)
+    scores, _ = co.score_rows(ref, p)
+    w, factor, offsets, offset = no.to_discrete(p, 5)
+    d = no.score_rows_u8_saturating(ref.data, 32, length, w, 0, ref.rows)
+    scale = lambda x: no.discrete_scale(x, factor, offset)   # noqa: E731
+    finite = scores[:, :32][np.isfinite(scores[:, :32])]
+    t = float(np.quantile(finite, 0.999))
+    if kind == "below_threshold_first_candidate":
+        t = float(finite.max()) + 0.05                  # no f32 score reaches t; u8 over-estimates may
+    pssm = lm.ScoringMatrix(p)
+    seq = pli.stripe(lm.EncodedSequence(enc), 32)
+    seq.configure(pssm)
+    assert np.array_equal(pli.score_discrete(pssm.to_discrete(), seq)[0][:, :32], d[:, :32])
+    for bs in (256, 7):
+        pending = ()
+        sc = lm.Scanner(pssm, seq, threshold=t, block_size=bs)
+        if kind == "partially_consumed":
+            order = no.scanner_collect(scores, 32, length, m, t, bs)
+            took = [next(sc) for _ in range(3)]
+            assert [(h.position, np.float32(h.score)) for h in took] == [(i, s) for i, s in order[:3]]
+            blk = (order[2][0] % ref.rows) // bs
+            rest_same_block = [(i, s) for i, s in order[3:] if (i % ref.rows) // bs == blk]
+            pending = rest_same_block[::-1]             # the reference's vector order (popped from the end)
+            first_row = (blk + 1) * bs
+            want = no.scanner_max_strict(scores[first_row:], d[first_row:], 32, t, scale, bs, pending=pending)
+            if want is not None and want not in pending:   # block-relative -> global position
+                col, r = divmod(want[0], scores[first_row:].shape[0])
+                want = (col * ref.rows + first_row + r, want[1])
+        else:
+            want = no.scanner_max_strict(scores, d, 32, t, scale, bs)
+        got = sc.max(strict_reference=True)
+        if want is None:
+            assert got is None, (kind, bs)
+        else:
+            assert got is not None and got.position == want[0] and np.float32(got.score) == want[1], (kind, bs, got, want)
+    # the default mode: the best valid hit, whatever the u8 scores say
+    best = no.scanner_max(scores, 32, length, m, t)
+    got = lm.Scanner(pssm, seq, threshold=t).max()
+    assert (got is None) == (best is None)
+    if best is not None:
+        assert got.position == best[0] and np.float32(got.score) == best[1]
+    if kind == "below_threshold_first_candidate":
+        strict = lm.Scanner(pssm, seq, threshold=t).max(strict_reference=True)
+        assert best is None and (strict is None or strict.score < t)
+    if kind == "finite_n_tail":
+        strict = lm.Scanner(pssm, seq, threshold=t).max(strict_reference=True)
+        assert strict.position + m > length             # the reference reports a position in the padded tail

@@ -225,3 +225,28 @@ def test_avx2_argmax_agrees_when_maximum_is_unique():
     sc[:] = rng.normal(0, 1, sc.shape)
     sc[123, 17] = 99.0
     assert co.avx2_argmax(sc, 500 * 32) == co.argmax(sc, 32) == (123, 17)
+
+
+def test_g5_scanner_max_strict_restatement():
+    """`Scanner::max` restated literally (scan.rs:200-249, u8 DiscreteMatrix steering included):
+    on the reference's own test (scan.rs:327-333) it finds the same best hit (18, -5.50167) as the
+    quirk-free restatement; and the two documented quirks show up where they must."""
+    _, s, pssm = golden_setup(32)
+    scores, _ = co.score_rows(s, pssm)
+    w, factor, offsets, offset = no.to_discrete(pssm, 5)
+    d = no.score_rows_u8_saturating(s.data, 32, len(GOLD["G1_scores"]["sequence"]), w, 0, s.rows)
+    scale = lambda x: no.discrete_scale(x, factor, offset)   # noqa: E731
+    best = no.scanner_max_strict(scores, d, 32, -10.0, scale)
+    assert best[0] == 18 and abs(float(best[1]) - (-5.50167)) < 1e-5
+    for bs in (1, 2):
+        assert no.scanner_max_strict(scores, d, 32, -10.0, scale, block_size=bs)[0] == 18
+    # quirk (b): nothing reaches t = 0.0 in f32 (test_scanner.py:71-72), but the first cell whose u8
+    # score reaches scale(0.0) is accepted without the f32 test (scan.rs:240-242)
+    t = 0.0
+    assert no.scanner_max(scores, 32, len(GOLD["G1_scores"]["sequence"]), pssm.shape[0], t) is None
+    strict = no.scanner_max_strict(scores, d, 32, t, scale)
+    reach = np.argwhere(d[:, :32] >= scale(np.float32(t)))
+    if reach.size:
+        assert strict is not None and float(strict[1]) < t
+    else:
+        assert strict is None

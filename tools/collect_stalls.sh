@@ -5,8 +5,8 @@
 # Units (MI355X_MICROARCH.md, "rocprofv3 PMC slots"): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_*
 # count quad-cycles summed over waves; WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES.
 TAG=${1:-r02}
-CMD=${2:-"python bench.py --steps 6 --warmup 3 --no-cpu-baseline --preheat-ms 0"}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+CMD=${2:-"python $ROOT/bench.py --steps 6 --warmup 3 --no-cpu-baseline --preheat-ms 0"}
 OUT=$ROOT/gpurun_out/stalls_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
@@ -16,8 +16,12 @@ GROUPS_=(
  "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD"
  "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS"
  "SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_WAVE32_LDS SQ_THREAD_CYCLES_VALU SQ_IFETCH SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_ACTIVE_INST_FLAT"
+ "SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LEVEL_WAVES"
  "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_sum TA_BUSY_avr"
- "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_RDREQ_sum"
+ "TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"
+ "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum"
+ "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_RDREQ_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum"
+ "TCC_HIT_sum TCC_MISS_sum TCC_TAG_STALL_sum TCC_BUSY_sum"
  "GRBM_GUI_ACTIVE GRBM_COUNT"
 )
 i=0
@@ -38,6 +42,14 @@ for p in glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True):
             continue
         k = n[n.index("::") - 2:].split("(")[0][:48]
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+# kernel durations of the same passes (ns), to turn GRBM_GUI_ACTIVE into a clock
+for p in glob.glob(out + "/g*/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(p)):
+        n = r["Kernel_Name"]
+        if "lm::" not in n and "kb::" not in n:
+            continue
+        k = n[n.index("::") - 2:].split("(")[0][:48]
+        acc[k]["duration_ns(all passes)"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 with open(out + "/summary.txt", "w") as f:
     for k in sorted(acc):
         f.write(k + "\n")

@@ -134,6 +134,71 @@ __global__ __launch_bounds__(256) void mix_rows_q(const uint8_t *in, float *out,
     }
 }
 
+// 2 x 2 variant: lane pairs transpose two completed rows, every lane writes 8 bytes (2 columns of one
+// row); a half-wave store covers 2 rows = 256 contiguous bytes
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int PFD>
+__global__ __launch_bounds__(256) void mix_rows_p2(const uint8_t *in, float *out, unsigned long long rows,
+                                                   unsigned long long T)
+{
+    const unsigned long long stream = ((unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + ((threadIdx.x & 63) >> 5);
+    const unsigned col = threadIdx.x & 31;
+    unsigned long long r0 = stream * T;
+    if (r0 >= rows) return;
+    unsigned long long r1 = r0 + T < rows ? r0 + T : rows;
+    const uint8_t *ip = in + r0 * 32 + col;
+    f32x2 *op = reinterpret_cast<f32x2 *>(out + (r0 + (col & 1)) * 32 + (col >> 1) * 2);
+    unsigned ring[PFD];
+#pragma unroll
+    for (int k = 0; k < PFD; ++k) ring[k] = ip[k * 32];
+    for (unsigned long long r = r0; r < r1; r += PFD) {
+#pragma unroll
+        for (int k = 0; k < PFD; k += 2) {
+            unsigned s[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                s[q] = ring[k + q];
+                ring[k + q] = ip[(k + q + PFD) * 32];
+            }
+            if (r + k + 1 < r1) {
+                f32x2 v = {(float)s[0], (float)s[1]};
+                __builtin_nontemporal_store(v, op + k * 16);
+            }
+        }
+        ip += PFD * 32;
+        op += PFD * 16;
+    }
+}
+
+// the two halves of a wavefront on ADJACENT rows of one stream (row-phase split): a wavefront store
+// covers 256 contiguous bytes (dword per lane), a stream is swept by the whole wavefront
+template <int PFD>
+__global__ __launch_bounds__(256) void mix_rows_w(const uint8_t *in, float *out, unsigned long long rows,
+                                                  unsigned long long T)
+{
+    const unsigned long long stream = (unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const unsigned lane = threadIdx.x & 63;
+    unsigned long long r0 = stream * T;   // T rows per wavefront, even
+    if (r0 >= rows) return;
+    unsigned long long r1 = r0 + T < rows ? r0 + T : rows;
+    const uint8_t *ip = in + r0 * 32 + lane;          // rows r, r+1 = 64 contiguous bytes
+    float *op = out + r0 * 32 + lane;
+    unsigned ring[PFD];
+#pragma unroll
+    for (int k = 0; k < PFD; ++k) ring[k] = ip[k * 64];
+    for (unsigned long long r = r0; r < r1; r += 2 * PFD) {
+#pragma unroll
+        for (int k = 0; k < PFD; ++k) {
+            const unsigned s = ring[k];
+            ring[k] = ip[(k + PFD) * 64];
+            if (r + 2 * k + 1 < r1)
+                __builtin_nontemporal_store((float)s, op + k * 64);
+        }
+        ip += PFD * 64;
+        op += PFD * 64;
+    }
+}
+
 // same, but 8 completed rows of a stream are staged in LDS and written as 1 KB by the whole wavefront
 __global__ __launch_bounds__(256) void mix_rows_lds(const uint8_t *in, f32x4 *out, unsigned long long rows,
                                                     unsigned long long T)
@@ -221,6 +286,10 @@ int main(int argc, char **argv)
             rep(nm, timeit([&] { hipLaunchKernelGGL(mix_rows<12>, dim3(grid), dim3(256), 0, 0, in, out, rows, T); }, 20));
             snprintf(nm, sizeof nm, "mix_rows_q<12> T=%llu", T);
             rep(nm, timeit([&] { hipLaunchKernelGGL(mix_rows_q<12>, dim3(grid), dim3(256), 0, 0, in, out, rows, T); }, 20));
+            snprintf(nm, sizeof nm, "mix_rows_p2<12> T=%llu", T);
+            rep(nm, timeit([&] { hipLaunchKernelGGL(mix_rows_p2<12>, dim3(grid), dim3(256), 0, 0, in, out, rows, T); }, 20));
+            snprintf(nm, sizeof nm, "mix_rows_w<12> T=%llu", 2 * T);
+            rep(nm, timeit([&] { hipLaunchKernelGGL(mix_rows_w<12>, dim3((unsigned)(((rows + 2 * T - 1) / (2 * T) + 3) / 4)), dim3(256), 0, 0, in, out, rows, 2 * T); }, 20));
             snprintf(nm, sizeof nm, "mix_rows_lds T=%llu", T);
             const unsigned long long rows8 = rows / T * T;
             rep(nm, timeit([&] { hipLaunchKernelGGL(mix_rows_lds, dim3((unsigned)(rows8 / T / 8)), dim3(256), 0, 0, in, (f32x4 *)out, rows8, T); }, 20));
