@@ -133,16 +133,102 @@ static bool build_prefilter(lm_hip_pssm &p, std::vector<unsigned> *image, std::v
     return true;
 }
 
+// ---- result blocks ------------------------------------------------------------------------------
+// Host arrays handed to the caller (threshold / hit lists) and released with lm_hip_free.  A dense
+// hit list is tens of megabytes per call: a fresh malloc'ed block costs ~5 000 page faults while the
+// read-back lands in it and the copy engine has to stage pageable memory through bounce buffers --
+// at a p = 1e-3 hit rate (1e6 hits per Gbp, 20 MB) that was more than half of the call
+// (profiles/r01_timeline_fused_p1e-3.txt: 1.06 ms of device work in a 2.14 ms call).  Large blocks
+// therefore come from a small process-wide pool: 2 MB-aligned, page-locked (hipHostRegister, so the
+// read-back is one DMA at link rate) and REUSED when the caller frees them.  LM_HIP_RESULT_POOL_MB
+// bounds what the pool keeps when idle (default 256; 0 = no pooling, plain malloc).
+namespace {
+struct ResultBlock {
+    void *ptr;
+    size_t cap;
+    bool pinned, in_use;
+    unsigned long long stamp;
+};
+std::mutex g_pool_mu;
+std::vector<ResultBlock> g_pool;
+unsigned long long g_pool_stamp = 0;
+constexpr size_t kPoolMin = 1u << 20;  // smaller results: malloc
+
+size_t pool_budget()
+{
+    static const size_t b = [] {
+        const char *e = getenv("LM_HIP_RESULT_POOL_MB");
+        return (size_t)(e ? atoll(e) : 256) << 20;
+    }();
+    return b;
+}
+
+void pool_trim_locked()
+{
+    for (;;) {
+        size_t idle = 0;
+        int oldest = -1;
+        for (size_t i = 0; i < g_pool.size(); ++i)
+            if (!g_pool[i].in_use) {
+                idle += g_pool[i].cap;
+                if (oldest < 0 || g_pool[i].stamp < g_pool[(size_t)oldest].stamp)
+                    oldest = (int)i;
+            }
+        if (oldest < 0 || idle <= pool_budget())
+            return;
+        if (g_pool[(size_t)oldest].pinned)
+            (void)hipHostUnregister(g_pool[(size_t)oldest].ptr);
+        free(g_pool[(size_t)oldest].ptr);
+        g_pool.erase(g_pool.begin() + oldest);
+    }
+}
+}  // namespace
+
 void *result_alloc(size_t bytes)
 {
     constexpr size_t kHuge = 2u << 20;
-    if (bytes < 4 * kHuge)
+    if (bytes < kPoolMin || pool_budget() == 0)
         return malloc(bytes);
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        int pick = -1;
+        for (size_t i = 0; i < g_pool.size(); ++i)  // best fit, at most 4x too large
+            if (!g_pool[i].in_use && g_pool[i].cap >= bytes && g_pool[i].cap / 4 <= bytes &&
+                (pick < 0 || g_pool[i].cap < g_pool[(size_t)pick].cap))
+                pick = (int)i;
+        if (pick >= 0) {
+            g_pool[(size_t)pick].in_use = true;
+            return g_pool[(size_t)pick].ptr;
+        }
+    }
+    const size_t cap = (bytes + bytes / 4 + kHuge - 1) / kHuge * kHuge;  // some headroom: counts vary call to call
     void *p = nullptr;
-    if (posix_memalign(&p, kHuge, (bytes + kHuge - 1) / kHuge * kHuge) != 0)
+    if (posix_memalign(&p, kHuge, cap) != 0)
         return malloc(bytes);
-    (void)madvise(p, (bytes + kHuge - 1) / kHuge * kHuge, MADV_HUGEPAGE);  // advisory: plain pages if unavailable
+    (void)madvise(p, cap, MADV_HUGEPAGE);  // advisory: plain pages if unavailable
+    const bool pinned = hipHostRegister(p, cap, hipHostRegisterPortable) == hipSuccess;
+    if (!pinned)
+        (void)hipGetLastError();
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    g_pool.push_back(ResultBlock{p, cap, pinned, true, 0});
     return p;
+}
+
+void result_free(void *p)
+{
+    if (!p)
+        return;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        for (auto &b : g_pool)
+            if (b.ptr == p) {
+                b.in_use = false;
+                b.stamp = ++g_pool_stamp;
+                pool_trim_locked();
+                return;
+            }
+    }
+    free(p);
 }
 
 static int default_ctx(lm_hip_ctx **out)
@@ -207,7 +293,7 @@ int lm_hip_device_ordinal(int index, int *ordinal)
     return fail(LM_HIP_ERR_NO_DEVICE, "fewer usable (gfx950) devices than index + 1");
 }
 
-void lm_hip_free(void *p) { free(p); }
+void lm_hip_free(void *p) { result_free(p); }
 
 size_t lm_hip_stride(size_t cols, size_t elem_size)
 {
@@ -742,7 +828,7 @@ int lm_hip_score_threshold_f32_dptr(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, co
     if (values)
         *values = ho.values;
     else
-        free(ho.values);
+        result_free(ho.values);
     *n = ho.total;
     return LM_HIP_OK;
 }
@@ -837,7 +923,7 @@ int lm_hip_scan_threshold_batch(lm_hip_ctx *ctx, const lm_hip_pssm *const *pssms
     if (values)
         *values = ho.values;
     else
-        free(ho.values);
+        result_free(ho.values);
     return LM_HIP_OK;
 }
 

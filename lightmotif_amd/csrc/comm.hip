@@ -409,7 +409,7 @@ int lm_hip_merge_threshold(lm_hip_ctx *ctx, lm_hip_comm *comm, const lm_hip_coor
     }
     int st = comm->buf.reserve(total * sizeof(lm_hip_coords));
     if (st != LM_HIP_OK) {
-        free(res);
+        result_free(res);
         return st;
     }
     lm_hip_coords *d_all = static_cast<lm_hip_coords *>(comm->buf.ptr);
@@ -440,7 +440,7 @@ int lm_hip_merge_threshold(lm_hip_ctx *ctx, lm_hip_comm *comm, const lm_hip_coor
     if (e == hipSuccess)
         e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess || nr_ != ncclSuccess) {
-        free(res);
+        result_free(res);
         if (nr_ != ncclSuccess)
             return fail(LM_HIP_ERR_COMM, "threshold merge failed: %s", rccl().GetErrorString(nr_));
         return fail(LM_HIP_ERR_HIP, "threshold merge failed: %s", hipGetErrorString(e));

@@ -212,7 +212,7 @@ int launch_threshold_u8(lm_hip_ctx *ctx, const uint8_t *d_scores, size_t rows, s
         return fail(LM_HIP_ERR_OOM, "threshold_u8: cannot allocate %llu hits on the host", count);
     int st = ctx->scratch2.reserve(count * sizeof(lm_hip_coords));
     if (st != LM_HIP_OK) {
-        free(host);
+        result_free(host);
         return st;
     }
     lm_hip_coords *d_out = static_cast<lm_hip_coords *>(ctx->scratch2.ptr);
@@ -224,7 +224,7 @@ int launch_threshold_u8(lm_hip_ctx *ctx, const uint8_t *d_scores, size_t rows, s
     if (e == hipSuccess)
         e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
-        free(host);
+        result_free(host);
         return fail(LM_HIP_ERR_HIP, "threshold_u8 fill failed: %s", hipGetErrorString(e));
     }
     *coords = host;

@@ -155,9 +155,9 @@ size_t align16(size_t x) { return (x + 15) / 16 * 16; }
 
 void HitOutput::release()
 {
-    free(coords);
-    free(values);
-    free(hits);
+    result_free(coords);
+    result_free(values);
+    result_free(hits);
     coords = nullptr;
     values = nullptr;
     hits = nullptr;
@@ -311,8 +311,8 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
         void *host = result_alloc(count * rec_bytes);
         float *host_values = emit == 0 ? static_cast<float *>(result_alloc(count * sizeof(float))) : nullptr;
         if (!host || (emit == 0 && !host_values)) {
-            free(host);
-            free(host_values);
+            result_free(host);
+            result_free(host_values);
             return fail(LM_HIP_ERR_OOM, "fused threshold: cannot allocate %llu hits on the host", count);
         }
         memcpy(out->job_start.data(), pin + p_starts, starts_bytes);
@@ -330,8 +330,8 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
             if (e == hipSuccess)
                 e = hipStreamSynchronize(st);
             if (e != hipSuccess) {
-                free(host);
-                free(host_values);
+                result_free(host);
+                result_free(host_values);
                 return fail(LM_HIP_ERR_HIP, "fused threshold: read-back failed: %s", hipGetErrorString(e));
             }
         }
@@ -348,8 +348,8 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
     void *host = result_alloc(count * rec_bytes);
     float *host_values = emit == 0 ? static_cast<float *>(result_alloc(count * sizeof(float))) : nullptr;
     if (!host || (emit == 0 && !host_values)) {
-        free(host);
-        free(host_values);
+        result_free(host);
+        result_free(host_values);
         return fail(LM_HIP_ERR_OOM, "fused threshold: cannot allocate %llu hits on the host", count);
     }
     // Read-back.  starts | records | values are contiguous in scratch2: small results come back
@@ -377,8 +377,8 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
             e = hipStreamSynchronize(st);
     }
     if (e != hipSuccess) {
-        free(host);
-        free(host_values);
+        result_free(host);
+        result_free(host_values);
         return fail(LM_HIP_ERR_HIP, "fused threshold: ordering the hit list failed: %s",
                     hipGetErrorString(e));
     }

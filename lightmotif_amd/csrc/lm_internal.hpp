@@ -74,6 +74,7 @@ constexpr size_t kPinnedBytes = 4u << 20;  // pinned staging buffer per context
 // ~13 000 first-touch page faults while the read-back lands in it (25 ms on the JASPAR batch,
 // more than half of the scans it follows).
 void *result_alloc(size_t bytes);
+void result_free(void *p);  // what lm_hip_free does: back to the pool, or free()
 
 }  // namespace lm
 

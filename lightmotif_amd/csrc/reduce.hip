@@ -383,7 +383,7 @@ int launch_threshold(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t
         return fail(LM_HIP_ERR_OOM, "threshold: cannot allocate %llu hits on the host", count);
     int st = ctx->scratch2.reserve(count * sizeof(lm_hip_coords));
     if (st != LM_HIP_OK) {
-        free(host);
+        result_free(host);
         return st;
     }
     lm_hip_coords *d_out = static_cast<lm_hip_coords *>(ctx->scratch2.ptr);
@@ -397,7 +397,7 @@ int launch_threshold(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t
     if (e == hipSuccess)
         e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
-        free(host);
+        result_free(host);
         return fail(LM_HIP_ERR_HIP, "threshold fill failed: %s", hipGetErrorString(e));
     }
     *coords = host;

@@ -756,12 +756,35 @@ constexpr int kHitStage = 4096;      // 2 048 small workgroups' atomics on one c
 constexpr int kRescoreBlocksPerCu = 2;
 constexpr int kRescoreCheck = 2;     // rounds between two flush decisions
 
+// LDS_TAB: the launch has few jobs (one PSSM, or both strands) whose dense tables fit
+// kRescoreTabFloats: they are staged in LDS once per workgroup, and the M weight lookups of a
+// row become LDS gathers instead of M dependent global gathers through the vector cache
+// (20 per lane and piece at M = 20: the texture addresser, not arithmetic, bounded the kernel
+// at dense hit rates -- 0.34 ms for 1.7 M pieces at p = 1e-3).  Many-motif batches keep the
+// tables in global memory (2 346 JASPAR tables = 1 MB).
+constexpr int kRescoreTabFloats = 2048;
+constexpr int kRescoreTabJobs = 8;
+
+template <bool LDS_TAB>
 __global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const RescoreJob *__restrict__ jobs,
-                                                             const FusedOut fo)
+                                                             const FusedOut fo, const unsigned njobs)
 {
     __shared__ HitRecord stage[kHitStage];
     __shared__ unsigned nstage;
     __shared__ unsigned long long gbase;
+    __shared__ float tab[LDS_TAB ? kRescoreTabFloats : 1];
+    __shared__ unsigned tab_off[LDS_TAB ? kRescoreTabJobs : 1];
+    if (LDS_TAB) {
+        unsigned off = 0;
+        for (unsigned j = 0; j < njobs; ++j) {  // block-uniform
+            const unsigned nf = jobs[j].m * jobs[j].k;
+            for (unsigned i = threadIdx.x; i < nf; i += kRescoreBlock)
+                tab[off + i] = jobs[j].dense[i];
+            if (threadIdx.x == 0)
+                tab_off[j] = off;
+            off += nf;
+        }
+    }
     if (threadIdx.x == 0)
         nstage = 0;
     __syncthreads();
@@ -813,19 +836,20 @@ __global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const Rescor
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (lane < cd.nrows) {
+                const float *dense = LDS_TAB ? tab + tab_off[cd.key >> 40] : jb.dense;
                 float sc = 0.0f;
                 unsigned j = 0;
                 for (; j + 8 <= jb.m; j += 8) {
                     float w[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
-                        w[q] = jb.dense[(j + q) * jb.k + win[lane + j + q]];
+                        w[q] = dense[(j + q) * jb.k + win[lane + j + q]];
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
                         sc = sc + w[q];
                 }
                 for (; j < jb.m; ++j)
-                    sc = sc + jb.dense[j * jb.k + win[lane + j]];
+                    sc = sc + dense[j * jb.k + win[lane + j]];
                 if (sc >= jb.threshold) {
                     const unsigned long long row = r0 + lane;
                     HitRecord r;
@@ -851,6 +875,21 @@ __global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const Rescor
         }
     }
     flush();
+}
+
+static int launch_rescore(lm_hip_ctx *ctx, hipStream_t st, const RescoreJob *d_jobs, const FusedOut &fo,
+                          const RescoreJob *host_jobs, size_t n)
+{
+    size_t floats = 0;
+    for (size_t i = 0; i < n && i <= (size_t)kRescoreTabJobs; ++i)
+        floats += (size_t)host_jobs[i].m * host_jobs[i].k;
+    const dim3 grid((unsigned)ctx->num_cus * kRescoreBlocksPerCu), block(kRescoreBlock);
+    if (n <= (size_t)kRescoreTabJobs && floats <= (size_t)kRescoreTabFloats)
+        hipLaunchKernelGGL(rescore_candidates<true>, grid, block, 0, st, d_jobs, fo, (unsigned)n);
+    else
+        hipLaunchKernelGGL(rescore_candidates<false>, grid, block, 0, st, d_jobs, fo, (unsigned)n);
+    LM_HIP_TRY(hipGetLastError());
+    return LM_HIP_OK;
 }
 
 // Fused score+threshold of `n` jobs.  The C = 32 kernels flag candidate row ranges
@@ -1026,8 +1065,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
         if (two_streams)
             LM_TRY(batch_join(ctx));
         if (any_candidates) {
-            hipLaunchKernelGGL(rescore_candidates, dim3((unsigned)ctx->num_cus * kRescoreBlocksPerCu), dim3(kRescoreBlock), 0,
-                               ctx->stream, d_jobs, fo);
+            LM_TRY(launch_rescore(ctx, ctx->stream, d_jobs, fo, rjobs.data(), n));
             LM_HIP_TRY(hipGetLastError());
         }
         const int emit = keys == HitKeys::Position ? 1 : 0;
@@ -1489,7 +1527,7 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
     if (two_streams)
         LM_TRY(batch_join(ctx));
     fo.batch = nullptr;
-    hipLaunchKernelGGL(rescore_candidates, dim3((unsigned)ctx->num_cus * kRescoreBlocksPerCu), dim3(kRescoreBlock), 0, st, d_rj, fo);
+    LM_TRY(launch_rescore(ctx, st, d_rj, fo, rj.data(), npos));
     const unsigned hgrid = (unsigned)ctx->num_cus * 2;
     hipLaunchKernelGGL(hits_best_value, dim3(hgrid), dim3(kBlock), 0, st, fo.hits, fo.hit_count, cap, d_bval);
     hipLaunchKernelGGL(hits_best_key, dim3(hgrid), dim3(kBlock), 0, st, fo.hits, fo.hit_count, cap, d_bval,

@@ -44,6 +44,10 @@ namespace lm {
 
 constexpr int kMaxRpM = 64;  // largest motif score_c32_rp is instantiated for
 
+#ifndef LM_RP_SCHED_FENCE
+#define LM_RP_SCHED_FENCE 32  // motifs longer than this get scheduling fences between steps
+#endif
+
 constexpr int rp_slots(int m) { return (m + 1) / 2; }           // H: outputs in flight per lane
 constexpr int rp_group(int m) { return 2 * rp_slots(m); }       // G: steps per unrolled group
 // floats per (parity, symbol) row of the LDS image: 4 * odd >= H (16-byte reads, rows of the
@@ -123,6 +127,12 @@ __device__ __forceinline__ void rp_group_steps(float (&acc)[rp_slots(M)], unsign
     constexpr int NB = G / 4 > 0 ? G / 4 : 1, PFB = rp_pf_blocks(M);
 #pragma unroll
     for (int k = 0; k < STEPS; ++k) {
+#if LM_RP_SCHED_FENCE
+        // long motifs: keep the scheduler from hoisting the LDS reads of many steps above their
+        // adds (M = 48 needed 2.6 KB of scratch per lane without it)
+        if (M > LM_RP_SCHED_FENCE && k % 2 == 0)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         // (1) this step's symbol; request the one PF steps (QL: PFB blocks) ahead
         unsigned s_now;
         if (QL) {

@@ -626,7 +626,10 @@ def test_scanner_max_strict_reference_mode(pli, kind):
     p[:, :4] = rng.normal(0, 2, (m, 4))
     p[:, 4] = -np.inf
     if kind == "finite_n_tail":
-        p[:, 4] = 3.0                                   # N scores high: the padded tail holds the maximum
+        # N scores high in the motif's last rows only: windows that START inside the sequence and run
+        # into the padded tail hold the maximum (position + M > L), the all-N windows score low
+        p[:6, 4] = -20.0
+        p[6:, 4] = 4.0
         length = 30_000 - 7                             # tail cells exist (rows * 32 > L)
         enc = enc[:length]
     if kind == "overestimate_skip":
@@ -679,3 +682,10 @@ def test_scanner_max_strict_reference_mode(pli, kind):
     if kind == "finite_n_tail":
         strict = lm.Scanner(pssm, seq, threshold=t).max(strict_reference=True)
         assert strict.position + m > length             # the reference reports a position in the padded tail
+        # ... and where a candidate's window leaves the striped matrix, `seq[pos + j]` panics in the
+        # reference (seq.rs:433-442 indexes column C): the strict mode raises likewise
+        p2 = p.copy()
+        p2[:, 4] = 3.0
+        hot = lm.ScoringMatrix(p2)
+        with pytest.raises(IndexError):
+            lm.Scanner(hot, seq, threshold=t).max(strict_reference=True)
