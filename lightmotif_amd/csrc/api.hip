@@ -77,7 +77,7 @@ static int check_score_args(const lm_hip_pssm *pssm, size_t seq_rows_total, size
 static bool build_prefilter(lm_hip_pssm &p, std::vector<unsigned> *image, std::vector<unsigned> *image2)
 {
     const int m = (int)p.m, k = (int)p.k;
-    if (m < 1 || p.wide)
+    if (m < 1)
         return false;
     const int mp = prefilter_mp(m), shift = mp - m;
     std::vector<double> off(m), top(m);
@@ -480,13 +480,8 @@ int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stri
             return cleanup(fail(LM_HIP_ERR_HIP, "pssm upload failed: %s", hipGetErrorString(e)));
         if (m <= (size_t)kMaxFastM) {
             // transposed, padded table of score_c32<M>: table[s * ts + j] = pssm[j][s]
-            // Protein (K = 21 > 16 slots) has 2-way LDS conflicts with 16-byte reads.  The
-            // conflict-free 8-byte-read layout (`wide`, -DLM_SCORE_BUILD_WIDE) measured
-            // SLOWER on MI355X: hipcc fuses the ds_read_b64 pairs into half-rate
-            // ds_read2_b64 (protein M=12 x 200 Mres: 0.254 ms vs 0.197 ms materialised,
-            // 0.280 vs 0.183 ms fused argmax), so it stays off.
-            p->wide = false;
-            p->ts = (size_t)table_stride((int)m, p->wide);
+            // (K = 21 > 16 slots: bank conflicts remain, see table_stride in score_kernels.hpp)
+            p->ts = (size_t)table_stride((int)m);
             std::vector<float> table(k * p->ts, 0.0f);
             for (size_t s = 0; s < k; ++s)
                 for (size_t j = 0; j < m; ++j)
@@ -528,6 +523,31 @@ int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stri
                 p->has_prefilter = true;
             }
         }
+        if (m > (size_t)kMaxFastM && k <= 64) {
+            // long motifs: slices of <= kMaxFastM rows (multiples of 4 rows: dword symbol loads)
+            const size_t nparts = (m + kMaxFastM - 1) / kMaxFastM;
+            const size_t len = std::min<size_t>(((m + nparts - 1) / nparts + 3) / 4 * 4, (size_t)kMaxFastM);
+            for (size_t off = 0; off < m; off += len) {
+                lm_hip_pssm::Part part;
+                part.off = off;
+                part.m = std::min(len, m - off);
+                part.ts = (size_t)table_stride((int)part.m);
+                std::vector<float> table(k * part.ts, 0.0f);
+                for (size_t s = 0; s < k; ++s)
+                    for (size_t j = 0; j < part.m; ++j)
+                        table[s * part.ts + j] = p->host[(off + j) * k + s];
+                e = hipMalloc(&part.d_table, table.size() * sizeof(float));
+                if (e != hipSuccess)
+                    return cleanup(fail(LM_HIP_ERR_OOM, "hipMalloc(table) failed: %s", hipGetErrorString(e)));
+                p->parts.push_back(part);  // owned from here on (freed by lm_hip_pssm_destroy)
+                e = hipMemcpyAsync(part.d_table, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice,
+                                   ctx->stream);
+                if (e == hipSuccess)
+                    e = hipStreamSynchronize(ctx->stream);  // `table` dies with this scope
+                if (e != hipSuccess)
+                    return cleanup(fail(LM_HIP_ERR_HIP, "table upload failed: %s", hipGetErrorString(e)));
+            }
+        }
         e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess)
             return cleanup(fail(LM_HIP_ERR_HIP, "pssm upload failed: %s", hipGetErrorString(e)));
@@ -561,6 +581,9 @@ int lm_hip_pssm_destroy(lm_hip_pssm *p)
         (void)hipFree(p->d_dense);
     if (p->d_table)
         (void)hipFree(p->d_table);
+    for (auto &part : p->parts)
+        if (part.d_table)
+            (void)hipFree(part.d_table);
     if (p->d_image)
         (void)hipFree(p->d_image);
     if (p->d_image2)

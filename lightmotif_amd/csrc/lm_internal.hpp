@@ -117,7 +117,13 @@ struct lm_hip_pssm {
     // ts = floats per symbol row (multiple of 4, ts/4 odd), zero padded.
     float *d_table = nullptr;
     size_t ts = 0;
-    bool wide = false;  // K > 16: 8-byte LDS reads, row stride 2*odd (score_kernels.hpp)
+    // M > kMaxFastM (C = 32): slices of <= kMaxFastM rows, each with its own transposed table; the
+    // first is scored with the store kernel, the others continue from the stored partial sums
+    struct Part {
+        size_t off = 0, m = 0, ts = 0;
+        float *d_table = nullptr;
+    };
+    std::vector<Part> parts;
     // Row-major dense copy for the generic kernel: d_dense[j * k + s].
     float *d_dense = nullptr;
     // Discrete prefilter of the fused threshold scan (score_prefilter.hpp): LDS image

@@ -52,13 +52,11 @@ static void init_registry()
             snprintf(g_c32_names[m][mode], sizeof g_c32_names[m][mode], "score_c32<%d,%d>", m, mode);
 }
 
-ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap, bool wide)
+ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap)
 {
     std::call_once(g_c32_once, init_registry);
     if (M < 1 || M > kMaxFastM || mode < 0 || mode > 2)
         return nullptr;
-    if (wide)
-        return g_c32[M][4 + mode];
     if (mode == MODE_STORE && xcd_remap)
         return g_c32[M][3];
     return g_c32[M][mode];
@@ -86,6 +84,12 @@ ScoreC32Launcher score_c32_lookup_store_argmax(int M)
 {
     std::call_once(g_c32_once, init_registry);
     return (M >= 1 && M <= kMaxFastM) ? g_c32[M][8] : nullptr;
+}
+
+ScoreC32Launcher score_c32_lookup_continue(int M)
+{
+    std::call_once(g_c32_once, init_registry);
+    return (M >= 1 && M <= kMaxFastM) ? g_c32[M][9] : nullptr;
 }
 
 ScoreC32Launcher score_c32_lookup_ql(int M)
@@ -131,7 +135,7 @@ struct C32Plan {
 // what the planner needs to know about the matrix (a.pssm may be absent: u8 scores)
 struct MotifShape {
     size_t m, k;
-    bool wide, pair_table;
+    bool pair_table;
 };
 
 static C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const ScoreArgs &a, bool store,
@@ -140,7 +144,7 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const Score
 static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store, int prefilter = 0,
                         size_t batch = 1)
 {
-    const MotifShape ms{a.pssm->m, a.pssm->k, a.pssm->wide, a.pssm->d_image2 != nullptr};
+    const MotifShape ms{a.pssm->m, a.pssm->k, a.pssm->d_image2 != nullptr};
     return plan_c32(ctx, ms, a, store, prefilter, batch);
 }
 
@@ -165,7 +169,7 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const Score
         return p;
     const size_t lds = prefilter == 2   ? (size_t)prefilter2_image_dw((int)ms.m) * 4
                        : prefilter == 1 ? (size_t)prefilter_image_dw((int)ms.m, (int)K) * 4
-                                        : std::max<size_t>(K * table_stride((int)M, ms.wide) * sizeof(float), 64);
+                                        : std::max<size_t>(K * table_stride((int)M) * sizeof(float), 64);
     if (lds > 60 * 1024)
         return p;
     // The fused kernels write nothing, so they are LDS/VALU-bound and prefer long
@@ -243,14 +247,87 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
     FusedOut fo{};
     const C32Plan p = plan_c32(ctx, a, true);
     if (p.ok) {
-        ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_STORE, ctx->xcd_remap, a.pssm->wide);
-        if (ctx->quad_loads && !ctx->xcd_remap && !a.pssm->wide && score_c32_lookup_ql((int)a.pssm->m) &&
+        ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_STORE, ctx->xcd_remap);
+        if (ctx->quad_loads && !ctx->xcd_remap && score_c32_lookup_ql((int)a.pssm->m) &&
             reinterpret_cast<uintptr_t>(a.d_seq) % 4 == 0)
             fn = score_c32_lookup_ql((int)a.pssm->m);  // dword symbol loads (M % 4 == 0)
         ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_STORE);
         LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
                       a.row_begin, a.row_end, p.T, p.nstreams, a.d_out, fo));
         return LM_HIP_OK;
+    }
+    // motifs longer than kMaxFastM at C = 32: slices of <= kMaxFastM rows.  The first slice is an ordinary
+    // store pass; every further slice continues IN PLACE from the partial sums (MODE_CONTINUE: same add
+    // order, bit-identical), over whole streams only -- a cell must be read and rewritten exactly once,
+    // so no shifted or repeated stream -- and the few rows left over go cell by cell.
+    if (!a.pssm->parts.empty() && a.cols == 32 && a.seq_stride == 32 && a.out_stride == 32 &&
+        reinterpret_cast<uintptr_t>(a.d_seq) % 4 == 0 && a.row_end - a.row_begin > (size_t)kMaxFastM) {
+        const unsigned long long n = a.row_end - a.row_begin;
+        bool ok = true;
+        for (size_t i = 0; i < a.pssm->parts.size() && ok; ++i) {
+            const lm_hip_pssm::Part &part = a.pssm->parts[i];
+            const MotifShape ms{part.m, a.pssm->k, false};
+            ScoreArgs sa = a;
+            sa.d_seq = a.d_seq + part.off * a.seq_stride;  // slice row j reads sequence row r + off + j
+            const C32Plan p = plan_c32(ctx, ms, sa, true);
+            if (!p.ok) {
+                ok = false;
+                break;
+            }
+            if (i == 0) {
+                ScoreC32Launcher fn = score_c32_lookup_ql((int)part.m);
+                if (!fn)
+                    fn = score_c32_lookup((int)part.m, MODE_STORE, false);
+                LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, sa.d_seq, part.d_table, (int)a.pssm->k, a.row_begin, a.row_end,
+                              p.T, p.nstreams, a.d_out, fo));
+                continue;
+            }
+            const unsigned long long nfull = n / p.T;
+            if (nfull) {
+                const dim3 grid((unsigned)((nfull + kStreamsPerBlock - 1) / kStreamsPerBlock));
+                LM_HIP_TRY(score_c32_lookup_continue((int)part.m)(grid, p.lds, ctx->stream, sa.d_seq, part.d_table,
+                                                                  (int)a.pssm->k, a.row_begin, a.row_begin + nfull * p.T,
+                                                                  p.T, nfull, a.d_out, fo));
+            }
+            if (nfull * p.T < n) {
+                const unsigned long long r0 = a.row_begin + nfull * p.T;
+                const unsigned long long cells = (a.row_end - r0) * a.cols;
+                hipLaunchKernelGGL(score_continue_cells<0>, dim3((unsigned)((cells + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                                   ctx->stream, sa.d_seq, (unsigned long long)a.seq_stride, (int)a.cols,
+                                   a.pssm->d_dense + part.off * a.pssm->k, (int)part.m, (int)a.pssm->k, r0,
+                                   (unsigned long long)a.row_end, a.d_out + (r0 - a.row_begin) * a.out_stride,
+                                   (unsigned long long)a.out_stride);
+                LM_HIP_TRY(hipGetLastError());
+            }
+        }
+        if (ok) {
+            ctx->last_kernel = "score_c32_sliced";
+            return LM_HIP_OK;
+        }
+    }
+    // any other geometry: the tiled kernel when its LDS tile fits (the dense table + TR + M - 1 rows of
+    // `cols` symbols), else one thread per cell
+    {
+        const size_t tab_bytes = (a.pssm->m * a.pssm->k * 4 + 15) / 16 * 16;
+        const size_t budget = 40 * 1024;
+        const unsigned long long n = a.row_end - a.row_begin;
+        if (a.pssm->m >= 1 && tab_bytes + (a.pssm->m + 8) * a.cols <= budget && a.cols <= 4096) {
+            unsigned long long tr = (budget - tab_bytes) / a.cols - (a.pssm->m - 1);
+            tr = std::min<unsigned long long>(tr / kTiledStrip * kTiledStrip, 2048);
+            // enough workgroups to fill the chip
+            while (tr > kTiledStrip * 4 && (n + tr - 1) / tr < (unsigned long long)ctx->num_cus * 4)
+                tr = (tr / 2 + kTiledStrip - 1) / kTiledStrip * kTiledStrip;
+            if (tr >= (unsigned long long)kTiledStrip) {
+                const size_t lds = tab_bytes + (tr + a.pssm->m - 1) * a.cols + 16;
+                ctx->last_kernel = "score_tiled";
+                hipLaunchKernelGGL(score_tiled<kTiledStrip>, dim3((unsigned)((n + tr - 1) / tr)), dim3(kBlock), lds, ctx->stream, a.d_seq,
+                                   (unsigned long long)a.seq_stride, (int)a.cols, a.pssm->d_dense, (int)a.pssm->m,
+                                   (int)a.pssm->k, (unsigned long long)a.row_begin, (unsigned long long)a.row_end, (int)tr,
+                                   a.d_out, (unsigned long long)a.out_stride);
+                LM_HIP_TRY(hipGetLastError());
+                return LM_HIP_OK;
+            }
+        }
     }
     ctx->last_kernel = "score_generic<0>";
     const unsigned long long ncells = (unsigned long long)(a.row_end - a.row_begin) * a.cols;
@@ -285,7 +362,7 @@ int launch_score_u8(lm_hip_ctx *ctx, const DiscreteArgs &a)
     const unsigned wrap_mask = a.saturate ? 0u : 0xffu;
     // plan with the f32 planner: same stream geometry as the packed prefilter scans.  DNA takes
     // the pair-symbol scan (two rows per lookup) when the matrix allows dword symbol loads.
-    const MotifShape ms{a.m, a.k, false, true};
+    const MotifShape ms{a.m, a.k, true};
     ScoreArgs sa{nullptr, a.d_seq, a.seq_stride, a.cols, a.row_begin, a.row_end, nullptr, a.out_stride};
     // (both fast kernels write dwords: the score matrix must be 4-byte aligned)
     const bool out_aligned = reinterpret_cast<uintptr_t>(a.d_out) % 4 == 0;
@@ -442,7 +519,7 @@ int launch_score_store_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord 
 {
     *tracked = false;
     const C32Plan p = plan_c32(ctx, a, true);
-    ScoreC32Launcher fn = p.ok && !a.pssm->wide ? score_c32_lookup_store_argmax((int)a.pssm->m) : nullptr;
+    ScoreC32Launcher fn = p.ok ? score_c32_lookup_store_argmax((int)a.pssm->m) : nullptr;
     if (!fn || reinterpret_cast<uintptr_t>(a.d_seq) % 4 != 0)
         return launch_score_store(ctx, a);
     if (a.out_stride != 32)
@@ -696,7 +773,7 @@ static int launch_score_argmax_exact(lm_hip_ctx *ctx, const ScoreArgs *jobs, siz
         fo.block_best = blocks + block_pos[g.idx[0]];
         if (g.kind == KIND_EXACT) {
             fo.batch = n > 1 ? d_bparams + bp_pos : nullptr;
-            ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_ARGMAX, false, a.pssm->wide);
+            ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_ARGMAX, false);
             ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_ARGMAX);
             LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
                           a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, nullptr, fo));
@@ -1050,7 +1127,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
                               (int)a.pssm->k, a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, tds[i], fo));
                 any_candidates = true;
             } else if (g.kind == KIND_EXACT) {
-                ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_THRESHOLD, false, a.pssm->wide);
+                ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_THRESHOLD, false);
                 ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_THRESHOLD);
                 LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
                               a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, nullptr, fo));

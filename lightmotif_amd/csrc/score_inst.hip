@@ -30,14 +30,9 @@ struct RegisterRange {
         tab[MODE_THRESHOLD] = &score_c32_launch<M, MODE_THRESHOLD>;
         tab[3] = &score_c32_launch<M, MODE_STORE, 1>;
         if constexpr (M % 4 == 0)
-            tab[7] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 0, 1>;
-        tab[8] = &score_c32_launch<M, MODE_STORE_ARGMAX, LM_SCORE_XCD_REMAP, 0, 1>;
-#if defined(LM_SCORE_BUILD_WIDE)
-        // 8-byte-read variant for K > 16; not built by default, see api.hip (pssm_create)
-        tab[4 + MODE_STORE] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1>;
-        tab[4 + MODE_ARGMAX] = &score_c32_launch<M, MODE_ARGMAX, LM_SCORE_XCD_REMAP, 1>;
-        tab[4 + MODE_THRESHOLD] = &score_c32_launch<M, MODE_THRESHOLD, LM_SCORE_XCD_REMAP, 1>;
-#endif
+            tab[7] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1>;
+        tab[8] = &score_c32_launch<M, MODE_STORE_ARGMAX, LM_SCORE_XCD_REMAP, 1>;
+        tab[9] = &score_c32_launch<M, MODE_CONTINUE, LM_SCORE_XCD_REMAP, 1>;
         if constexpr (M < LM_M_HI)
             RegisterRange<M + 1>::run(r);
     }

@@ -50,18 +50,25 @@ constexpr int kMaxFastM = 36;        // largest motif the unrolled kernel is bui
 
 // Floats per symbol row of the transposed LDS table used by score_c32<M>:
 // 4 * (smallest odd number >= ceil(M/4)).
-// Alphabets with more than 16 symbols (protein, K = 21) cannot be conflict-free with
-// 16-byte reads (16 slots per 16-lane group), so they use 8-byte reads (32 slots per
-// 32-lane group) and a row stride of 2 * odd floats (`wide`).
-constexpr int table_stride(int m, bool wide = false)
-{
-    return wide ? 2 * (((m + 1) / 2) | 1) : 4 * (((m + 3) / 4) | 1);
-}
+// Alphabets with more than 16 symbols (protein, K = 21) cannot be conflict-free with 16-byte reads
+// (16 four-bank slots per 16-lane group: five pairs of symbols share a slot -- 44 % of the LDS
+// cycles of score_c32<12, 0> at K = 21 are bank-conflict cycles, profiles/r02_stalls_protein.txt).
+// The 8-byte-read layout that would be conflict-free (32 slots per 32-lane group) was built and
+// measured in round 1 and removed in round 2: an LDS read instruction occupies the pipeline ~4
+// cycles whatever its width (SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS, profiles/r02_stalls_store_kernel.txt),
+// so twice as many 8-byte reads cost more than the conflicts they avoid (0.254 vs 0.197 ms on the
+// 200 Mres configuration).
+constexpr int table_stride(int m) { return 4 * (((m + 3) / 4) | 1); }
 
-// MODE_STORE_ARGMAX: writes the scores AND tracks the running best, so that the argmax of a
-// freshly scored matrix (the reference's score_into + argmax flow) needs no second pass
-enum : int { MODE_STORE = 0, MODE_ARGMAX = 1, MODE_THRESHOLD = 2, MODE_STORE_ARGMAX = 3 };
-constexpr bool mode_stores(int mode) { return mode == MODE_STORE || mode == MODE_STORE_ARGMAX; }
+// MODE_CONTINUE: like MODE_STORE, but every output starts from the partial sum already stored in
+// its cell instead of +0.0 -- the later passes of a motif longer than kMaxFastM, which is scored
+// in slices of <= kMaxFastM rows with the SAME sequential add order (pass 1 stores
+// ((0 + P[0]) + ... + P[M1-1]), pass 2 continues with + P[M1] ...), hence bit-identical.
+enum : int { MODE_STORE = 0, MODE_ARGMAX = 1, MODE_THRESHOLD = 2, MODE_STORE_ARGMAX = 3, MODE_CONTINUE = 4 };
+constexpr bool mode_stores(int mode)
+{
+    return mode == MODE_STORE || mode == MODE_STORE_ARGMAX || mode == MODE_CONTINUE;
+}
 constexpr bool mode_tracks_best(int mode) { return mode == MODE_ARGMAX || mode == MODE_STORE_ARGMAX; }
 
 // One above-threshold cell: key = (job << 40) | flat index (row * cols + col).  Flat
@@ -193,43 +200,29 @@ __device__ __forceinline__ void record_hit(const FusedOut &fo, unsigned long lon
 #define LM_SCORE_NT_STORE 1
 #endif
 
-template <int M, int WIDE>
+template <int M>
 __device__ __forceinline__ void lds_fetch_column(float (&w)[4 * ((M + 3) / 4)],
                                                  const char *__restrict__ tab, const unsigned s)
 {
-    constexpr unsigned TSB = table_stride(M, WIDE) * 4;  // bytes per symbol row
-    if (WIDE) {
-        // ds_read_b64: bank = (addr/4) mod 64, 32 two-dword slots per 32-lane group;
-        // rows at s * (2*odd) dwords -> up to 32 symbols in distinct slots
-        constexpr int NV = (M + 1) / 2;
-        const char *row =
-            static_cast<const char *>(__builtin_assume_aligned(tab + __umul24(s, TSB), 8));
+    constexpr unsigned TSB = table_stride(M) * 4;  // bytes per symbol row
+    // M floats: whole 16-byte reads, then an 8- and/or 4-byte read for the rest
+    const char *row =
+        static_cast<const char *>(__builtin_assume_aligned(tab + __umul24(s, TSB), 16));
 #pragma unroll
-        for (int q = 0; q < NV; ++q) {
-            const float2 v = *reinterpret_cast<const float2 *>(row + 8 * q);
-            w[2 * q + 0] = v.x;
-            w[2 * q + 1] = v.y;
-        }
-    } else {
-        // M floats: whole 16-byte reads, then an 8- and/or 4-byte read for the rest
-        const char *row =
-            static_cast<const char *>(__builtin_assume_aligned(tab + __umul24(s, TSB), 16));
-#pragma unroll
-        for (int q = 0; q < M / 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4 *>(row + 16 * q);
-            w[4 * q + 0] = v.x;
-            w[4 * q + 1] = v.y;
-            w[4 * q + 2] = v.z;
-            w[4 * q + 3] = v.w;
-        }
-        if (M % 4 >= 2) {
-            const float2 v = *reinterpret_cast<const float2 *>(row + 16 * (M / 4));
-            w[4 * (M / 4) + 0] = v.x;
-            w[4 * (M / 4) + 1] = v.y;
-        }
-        if (M % 2 == 1)
-            w[M - 1] = *reinterpret_cast<const float *>(row + 4 * (M - 1));
+    for (int q = 0; q < M / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(row + 16 * q);
+        w[4 * q + 0] = v.x;
+        w[4 * q + 1] = v.y;
+        w[4 * q + 2] = v.z;
+        w[4 * q + 3] = v.w;
     }
+    if (M % 4 >= 2) {
+        const float2 v = *reinterpret_cast<const float2 *>(row + 16 * (M / 4));
+        w[4 * (M / 4) + 0] = v.x;
+        w[4 * (M / 4) + 1] = v.y;
+    }
+    if (M % 2 == 1)
+        w[M - 1] = *reinterpret_cast<const float *>(row + 4 * (M - 1));
 }
 
 // Edge groups (FIRST / LAST) need only part of the column: floats [4*C0, 4*C1).  Left to itself the
@@ -249,7 +242,7 @@ template <int M>
 __device__ __forceinline__ void lds_fetch_chunks(float (&w)[4 * ((M + 3) / 4)], const char *__restrict__ tab,
                                                  const unsigned s, const int c0, const int c1)
 {
-    constexpr unsigned TSB = table_stride(M, false) * 4;
+    constexpr unsigned TSB = table_stride(M) * 4;
     const char *row = static_cast<const char *>(__builtin_assume_aligned(tab + __umul24(s, TSB), 16));
 #pragma unroll
     for (int q = 0; q < (M + 3) / 4; ++q) {
@@ -284,14 +277,14 @@ enum : int { PHASE_FIRST = 0, PHASE_MAIN = 1, PHASE_LAST = 2 };
 // the group's first step (in the FIRST group only step M-1 completes a row).
 // `sym` is a ring of symbol bytes indexed by step mod M (only ~PF are live),
 // `wc` carries the prefetched LDS column across steps when LP = 1.
-template <int M, int MODE, int PF, int LP, int PHASE, int WIDE, int QL = 0>
+template <int M, int MODE, int PF, int LP, int PHASE, int QL = 0>
 __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
                                             float (&wc)[4 * ((M + 3) / 4)],
                                             const uint8_t *__restrict__ sp,
                                             const char *__restrict__ tab,
                                             float *__restrict__ op, const unsigned tbase,
                                             const int col, float &best_v, unsigned &best_t,
-                                            const FusedOut &fo, const unsigned shq = 0)
+                                            const FusedOut &fo, const unsigned shq, float &init_next)
 {
     constexpr int NW = 4 * ((M + 3) / 4);
     constexpr int NB = M / 4;                  // QL: 4-row symbol blocks per group (M % 4 == 0)
@@ -318,7 +311,7 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
         }
         // (2) the PSSM column of this step's symbol
         float w[NW];
-        if (LM_SCORE_EDGE_B128(M) && !WIDE && !LP && PHASE != PHASE_MAIN) {
+        if (LM_SCORE_EDGE_B128(M) && !LP && PHASE != PHASE_MAIN) {
             // FIRST: outputs started at steps 0..k -> weights 0..k.  LAST: the stream's last output
             // starts at the group's step 0, so step k still needs weights k..M-1
             const unsigned sy = QL ? s_now : sym[k];
@@ -330,22 +323,32 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
             else
                 lds_fetch_chunks<M>(w, tab, sy, k / 4, (M + 3) / 4);
         } else if (QL) {
-            lds_fetch_column<M, WIDE>(w, tab, s_now);
+            lds_fetch_column<M>(w, tab, s_now);
         } else if (LP) {
 #pragma unroll
             for (int i = 0; i < NW; ++i)
                 w[i] = wc[i];
             if (PHASE != PHASE_LAST || k + 1 < M)
-                lds_fetch_column<M, WIDE>(wc, tab, sym[(k + 1) % M]);
+                lds_fetch_column<M>(wc, tab, sym[(k + 1) % M]);
         } else {
-            lds_fetch_column<M, WIDE>(w, tab, sym[k]);
+            lds_fetch_column<M>(w, tab, sym[k]);
+        }
+        // MODE_CONTINUE: the output started at this step resumes from the partial sum in its cell
+        // (requested one step ago); request the next step's.  The row started at step k is stored
+        // at op + (k + M - 1) * 32.  Only rows of the stream are ever requested: in the LAST group
+        // step 0 starts the stream's last row, later starts are dead.
+        float init = 0.0f;
+        if (MODE == MODE_CONTINUE) {
+            init = init_next;
+            if (PHASE != PHASE_LAST)
+                init_next = op[(k + 1 + M - 1) * 32];
         }
         // (3) P[j][s] goes to the output row started j steps ago: slot (k - j) mod M.
 #pragma unroll
         for (int j = 0; j < M; ++j) {
             const int slot = (k - j + M) % M;
             if (j == 0)
-                acc[slot] = 0.0f + w[0];  // T::default() + P[0][s]   (pli/mod.rs:98,101)
+                acc[slot] = init + w[0];  // T::default() + P[0][s]   (pli/mod.rs:98,101), or the partial sum
             else
                 acc[slot] = acc[slot] + w[j];
         }
@@ -451,7 +454,7 @@ __device__ __forceinline__ void emit_candidates(const unsigned long long hit_gro
 #define LM_SCORE_XCD_REMAP 0
 #endif
 template <int M, int MODE, int PF = LM_SCORE_PF, int LP = LM_SCORE_LP, int BLK = LM_BLOCK,
-          int XCD = LM_SCORE_XCD_REMAP, int MINW = LM_SCORE_MIN_WAVES(M), int WIDE = 0, int QLREQ = 0>
+          int XCD = LM_SCORE_XCD_REMAP, int MINW = LM_SCORE_MIN_WAVES(M), int QLREQ = 0>
 __global__ __launch_bounds__(BLK, MINW) void score_c32(
     const uint8_t *__restrict__ seq, const float *__restrict__ table, const int K,
     const unsigned long long row_begin, const unsigned long long row_end,
@@ -467,12 +470,7 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         fo.threshold = bp.threshold;
         fo.job_key = bp.job_key;
     }
-    if (WIDE) {
-        float *dst = reinterpret_cast<float *>(lds_raw);
-        const int nf = K * table_stride(M, true);
-        for (int i = threadIdx.x; i < nf; i += BLK)
-            dst[i] = table[i];
-    } else {
+    {
         float4 *dst = reinterpret_cast<float4 *>(lds_raw);
         const float4 *src = reinterpret_cast<const float4 *>(table);
         const int n4 = K * table_stride(M) / 4;
@@ -493,6 +491,8 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
     }
     unsigned long long stream = (bid * (BLK / 64) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
     const bool idle = stream >= nstreams;  // re-does the last stream, reports nothing
+    if (MODE == MODE_CONTINUE && idle)
+        return;  // in-place continuation: every cell may be read and rewritten exactly once
     if (idle)
         stream = nstreams - 1;
     unsigned long long o0 = row_begin + stream * T;
@@ -532,12 +532,14 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         wc[i] = 0.0f;
     constexpr int LPE = (PFE >= 1) ? LP : 0;
     if (LPE)
-        lds_fetch_column<M, WIDE>(wc, lds_raw, sym[0]);
+        lds_fetch_column<M>(wc, lds_raw, sym[0]);
     float best_v = (MODE == MODE_STORE_ARGMAX) ? __builtin_nanf("") : -INFINITY;
     // argmax mode: step index of the lane's best score (0xffffffff = none);
     // threshold mode: "this group saw a hit" flag
     unsigned best_t = (MODE == MODE_THRESHOLD) ? 0u : 0xffffffffu;
     unsigned tbase = 0;
+    // MODE_CONTINUE: partial sum of the row started at step 0 (= the stream's first row)
+    float init_next = MODE == MODE_CONTINUE ? op[(M - 1) * 32] : 0.0f;
 
     const unsigned long long ngroups = (T + M - 1) / M;  // exact: T = q*M + 1, >= 2
 
@@ -559,24 +561,24 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         }
     };
 
-    score_group<M, MODE, PFE, LPE, PHASE_FIRST, WIDE, QL>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
-                                                best_t, fo, shq);
+    score_group<M, MODE, PFE, LPE, PHASE_FIRST, QL>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
+                                                best_t, fo, shq, init_next);
     note_group();
     for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
         sp += M * 32;
         tbase += M;
         if (mode_stores(MODE))
             op += M * 32;
-        score_group<M, MODE, PFE, LPE, PHASE_MAIN, WIDE, QL>(acc, sym, wc, sp, lds_raw, op, tbase, col,
-                                                   best_v, best_t, fo, shq);
+        score_group<M, MODE, PFE, LPE, PHASE_MAIN, QL>(acc, sym, wc, sp, lds_raw, op, tbase, col,
+                                                   best_v, best_t, fo, shq, init_next);
         note_group();
     }
     sp += M * 32;
     tbase += M;
     if (mode_stores(MODE))
         op += M * 32;
-    score_group<M, MODE, PFE, LPE, PHASE_LAST, WIDE, QL>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
-                                               best_t, fo, shq);
+    score_group<M, MODE, PFE, LPE, PHASE_LAST, QL>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
+                                               best_t, fo, shq, init_next);
     note_group();
 
     if (MODE == MODE_THRESHOLD) {
@@ -684,6 +686,101 @@ __global__ __launch_bounds__(kBlock) void score_generic(
     }
 }
 
+// Any column count / stride / motif length / alphabet, materialising, tiled: the fallback that
+// is more than a correctness path (C = 16 geometries of the reference's 16-lane back-ends,
+// M > 64, unaligned matrices).  A workgroup stages the symbols of TR + M - 1 rows x `cols` live
+// columns (padding bytes skipped) and the dense PSSM in LDS; a thread then owns a strip of
+// kTiledStrip vertically adjacent outputs of one column and slides down its M + strip - 1
+// input rows: ONE symbol read feeds up to `strip` outputs (weights P[rho - i][s] for the
+// outputs i = rho - j), so the LDS traffic is ~1.1 reads per add instead of the 2 global byte
+// loads + 1 table read per add of score_generic.  Each output still receives P[0], P[1], ...
+// in order from +0.0: the reference's add sequence (pli/mod.rs:98-102), bit-identical.
+constexpr int kTiledStrip = 8;
+
+template <int STRIP>
+__global__ __launch_bounds__(kBlock) void score_tiled(
+    const uint8_t *__restrict__ seq, const unsigned long long seq_stride, const int cols,
+    const float *__restrict__ pssm, const int M, const int K, const unsigned long long row_begin,
+    const unsigned long long row_end, const int TR, float *__restrict__ out,
+    const unsigned long long out_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    float *tab = reinterpret_cast<float *>(lds_raw);                       // M x K
+    uint8_t *tile = reinterpret_cast<uint8_t *>(lds_raw) + (((size_t)M * K * 4 + 15) / 16) * 16;
+    for (int i = threadIdx.x; i < M * K; i += kBlock)
+        tab[i] = pssm[i];
+    const unsigned long long r0 = row_begin + (unsigned long long)blockIdx.x * TR;
+    const unsigned long long nout = row_end - r0 < (unsigned long long)TR ? row_end - r0 : (unsigned long long)TR;
+    const unsigned long long nin = nout + M - 1;  // input rows r0 .. r0 + nin - 1 (wrap rows exist)
+    if (seq_stride == (unsigned long long)cols && (reinterpret_cast<uintptr_t>(seq + r0 * seq_stride) & 3) == 0) {
+        // contiguous tile: dword copies
+        const unsigned *src = reinterpret_cast<const unsigned *>(seq + r0 * seq_stride);
+        unsigned *dst = reinterpret_cast<unsigned *>(tile);
+        const unsigned long long nbytes = nin * cols, ndw = nbytes / 4;
+        for (unsigned long long i = threadIdx.x; i < ndw; i += kBlock)
+            dst[i] = src[i];
+        for (unsigned long long i = ndw * 4 + threadIdx.x; i < nbytes; i += kBlock)
+            tile[i] = seq[r0 * seq_stride + i];
+    } else {
+        const unsigned long long n = nin * cols;
+        for (unsigned long long i = threadIdx.x; i < n; i += kBlock) {
+            const unsigned long long r = i / cols;
+            tile[i] = seq[(r0 + r) * seq_stride + (i - r * cols)];
+        }
+    }
+    __syncthreads();
+    // strips: strip index -> (strip row block, column); consecutive threads take consecutive
+    // columns of one strip row block, so their tile reads are consecutive bytes
+    const unsigned long long nsr = (nout + STRIP - 1) / STRIP;
+    for (unsigned long long sidx = threadIdx.x; sidx < nsr * cols; sidx += kBlock) {
+        const unsigned long long sr = sidx / cols;
+        const int c = (int)(sidx - sr * cols);
+        const unsigned long long o = sr * STRIP;  // first output row of the strip (tile-relative)
+        const int n = (int)(nout - o < (unsigned long long)STRIP ? nout - o : (unsigned long long)STRIP);
+        float acc[STRIP];
+#pragma unroll
+        for (int i = 0; i < STRIP; ++i)
+            acc[i] = 0.0f;  // T::default() (pli/mod.rs:98)
+        const uint8_t *tp = tile + o * cols + c;
+        for (int rho = 0; rho < M + n - 1; ++rho) {  // input row o + rho feeds outputs i with j = rho - i in [0, M)
+            const unsigned s = tp[(size_t)rho * cols];
+            const float *trow = tab + s;
+#pragma unroll
+            for (int i = 0; i < STRIP; ++i) {
+                const int j = rho - i;
+                if (i < n && j >= 0 && j < M)  // uniform across the wavefront except for `n` at the tile's end
+                    acc[i] = acc[i] + trow[j * K];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < STRIP; ++i)
+            if (i < n)
+                out[(r0 - row_begin + o + i) * out_stride + c] = acc[i];
+    }
+}
+
+// The few rows a continuation pass (MODE_CONTINUE) cannot cover with whole streams: one thread
+// per cell, `out` holds the partial sum, `pssm` the slice's rows (M x K), `seq` row 0 = the
+// slice's first input row of output row 0.
+template <int UNUSED>
+__global__ __launch_bounds__(kBlock) void score_continue_cells(
+    const uint8_t *__restrict__ seq, const unsigned long long seq_stride, const int cols,
+    const float *__restrict__ pssm, const int M, const int K, const unsigned long long row_begin,
+    const unsigned long long row_end, float *__restrict__ out, const unsigned long long out_stride)
+{
+    const unsigned long long ncells = (row_end - row_begin) * (unsigned long long)cols;
+    for (unsigned long long cell = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; cell < ncells;
+         cell += (unsigned long long)gridDim.x * kBlock) {
+        const unsigned long long r = cell / cols;
+        const int c = (int)(cell - r * cols);
+        const uint8_t *sp = seq + (row_begin + r) * seq_stride + c;
+        float score = out[r * out_stride + c];
+        for (int j = 0; j < M; ++j)
+            score = score + pssm[j * K + sp[j * seq_stride]];
+        out[r * out_stride + c] = score;
+    }
+}
+
 // Host-side launch shim, one per (M, MODE), defined in score_inst_*.hip.
 using ScoreC32Launcher = hipError_t (*)(dim3 grid, size_t lds_bytes, hipStream_t stream,
                                         const uint8_t *seq, const float *table, int K,
@@ -691,14 +788,14 @@ using ScoreC32Launcher = hipError_t (*)(dim3 grid, size_t lds_bytes, hipStream_t
                                         unsigned long long T, unsigned long long nstreams,
                                         float *out, FusedOut fo);
 
-template <int M, int MODE, int XCD = LM_SCORE_XCD_REMAP, int WIDE = 0, int QL = 0>
+template <int M, int MODE, int XCD = LM_SCORE_XCD_REMAP, int QL = 0>
 hipError_t score_c32_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, const uint8_t *seq,
                             const float *table, int K, unsigned long long row_begin,
                             unsigned long long row_end, unsigned long long T,
                             unsigned long long nstreams, float *out, FusedOut fo)
 {
     hipLaunchKernelGGL((score_c32<M, MODE, LM_SCORE_PF, LM_SCORE_LP, LM_BLOCK, XCD,
-                                  LM_SCORE_MIN_WAVES(M), WIDE, QL>), grid,
+                                  LM_SCORE_MIN_WAVES(M), QL>), grid,
                        dim3(kBlock), lds_bytes, stream, seq, table, K, row_begin, row_end, T,
                        nstreams, out, fo);
     return hipGetLastError();
@@ -706,12 +803,13 @@ hipError_t score_c32_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, con
 
 // Filled by the score_inst_*.hip translation units; [M][MODE], nullptr if absent.
 // Registry row: [0..2] = modes, [3] = store kernel WITH the XCD remap (A/B knob),
-// [4..6] = modes for wide alphabets (K > 16), [7] = store kernel with quad-gathered symbol
+// [4..6] = unused, [7] = store kernel with quad-gathered symbol
 // loads (M % 4 == 0), [8] = store + running maximum (score_into on handles).
-constexpr int kRegistrySlots = 9;
-ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap = false, bool wide = false);
+constexpr int kRegistrySlots = 10;  // [9] = MODE_CONTINUE (later passes of motifs longer than kMaxFastM)
+ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap = false);
 ScoreC32Launcher score_c32_lookup_ql(int M);
 ScoreC32Launcher score_c32_lookup_store_argmax(int M);
+ScoreC32Launcher score_c32_lookup_continue(int M);
 const char *score_c32_name(int M, int mode);
 
 }  // namespace lm

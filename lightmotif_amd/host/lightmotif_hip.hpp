@@ -19,6 +19,7 @@
 #pragma once
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -446,6 +447,12 @@ public:
         return out;
     }
     lm_hip_scores *handle() const { return h_; }
+    // This StripedScores is one row shard of a larger matrix: `holds_first_row == false` skips
+    // Maximum::argmax's "scores[0][0] is NaN -> (0,0)" rule (pli/mod.rs:142-146) on it.
+    void set_first_cell_rule(bool holds_first_row) const
+    {
+        check(lm_hip_scores_set_first_cell_rule(h_, holds_first_row ? 1 : 0));
+    }
 
 private:
     struct Info { size_t rows, stride, cols, max_index; };
@@ -706,6 +713,22 @@ public:
         return out;
     }
 
+    // ---- row-sharded jobs across the GPUs of a node -----------------------------------
+    // Score::score_rows_into takes a row range so that a sequence can be cut (pli/mod.rs:72-78):
+    // one process per GPU scores rows [a_g, b_g) + an M-1-row halo; `ShardComm` (below) carries the
+    // halo hand-over and the argmax / threshold merge over RCCL, bound directly by the C library.
+    lm_hip_ctx *raw() const { return ctx_->ctx; }
+    // A StripedSequence over a device matrix that stays the caller's (one row shard, a buffer of
+    // the host application): nothing is copied.
+    StripedSequence<A> adopt(uint8_t *d_data, size_t rows, size_t wrap, size_t capacity_rows, size_t stride,
+                             size_t columns, size_t length) const
+    {
+        lm_hip_seq *h = nullptr;
+        check(lm_hip_seq_adopt_dptr(ctx_->ctx, d_data, rows + wrap, capacity_rows, stride, columns, wrap, length,
+                                    A::K, &h));
+        return StripedSequence<A>(ctx_, h);
+    }
+
 private:
     struct SeqView {
         const uint8_t *data = nullptr;
@@ -719,6 +742,90 @@ private:
     }
     explicit Pipeline(std::shared_ptr<CtxHandle> c) : ctx_(std::move(c)) {}
     std::shared_ptr<CtxHandle> ctx_;
+};
+
+// The merge rule on host arrays (any transport): per-shard results in ascending row order, rows
+// global, first-cell rule applied on the shard holding row 0 only -> Maximum::argmax of the whole
+// matrix (pli/mod.rs:135-155).
+struct ShardBest {
+    bool found = false;
+    MatrixCoordinates cell{};
+    float score = 0.0f;
+};
+inline ShardBest combine_argmax(const std::vector<ShardBest> &shards)
+{
+    const size_t n = shards.size();
+    std::vector<int> f(n);
+    std::vector<lm_hip_coords> b(n);
+    std::vector<float> v(n);
+    for (size_t i = 0; i < n; ++i) {
+        f[i] = shards[i].found ? 1 : 0;
+        b[i] = {shards[i].cell.row, shards[i].cell.col};
+        v[i] = shards[i].score;
+    }
+    ShardBest out;
+    int fo = 0;
+    lm_hip_coords bo{};
+    check(lm_hip_combine_argmax(f.data(), b.data(), v.data(), n, &fo, &bo, &out.score));
+    out.found = fo != 0;
+    out.cell = {bo.row, bo.col};
+    return out;
+}
+
+// RCCL communicator of a row-sharded job: rank g holds rows [row_offset, row_offset + rows).
+// One rank draws `unique_id()` and hands the 128 bytes to the others (MPI_Bcast, a file ...).
+template <class A>
+class ShardComm {
+public:
+    static std::array<uint8_t, LM_HIP_COMM_ID_BYTES> unique_id()
+    {
+        std::array<uint8_t, LM_HIP_COMM_ID_BYTES> id{};
+        check(lm_hip_comm_unique_id(id.data()));
+        return id;
+    }
+    ShardComm(const Pipeline<A> &pli, const std::array<uint8_t, LM_HIP_COMM_ID_BYTES> &id, int nranks, int rank)
+        : ctx_(pli.raw())
+    {
+        check(lm_hip_comm_create(ctx_, id.data(), nranks, rank, &h_));
+    }
+    ~ShardComm() { lm_hip_comm_destroy(h_); }
+    ShardComm(const ShardComm &) = delete;
+    // rows [rows, rows + halo) of this rank's shard <- the first rows of rank + 1's (the last rank
+    // gets rank 0's turned into wrap rows, seq.rs:373-378)
+    void exchange_halo(uint8_t *d_shard, size_t rows, size_t stride, size_t columns, size_t halo_rows) const
+    {
+        check(lm_hip_exchange_halo_dptr(ctx_, h_, d_shard, rows, stride, columns, halo_rows, (uint8_t)(A::K - 1)));
+    }
+    // StripedScores::argmax of the WHOLE matrix from this rank's resident shard
+    ShardBest argmax(const StripedScores &shard, size_t row_offset) const
+    {
+        ShardBest out;
+        int found = 0;
+        lm_hip_coords best{};
+        check(lm_hip_argmax_sharded(ctx_, h_, shard.handle(), row_offset, &found, &best, &out.score));
+        out.found = found != 0;
+        out.cell = {best.row, best.col};
+        return out;
+    }
+    // StripedScores::threshold of the whole matrix: (row, col) in the reference's row-major order
+    std::vector<MatrixCoordinates> threshold(const StripedScores &shard, float t, size_t row_offset) const
+    {
+        lm_hip_coords *mine = nullptr, *all = nullptr;
+        size_t n = 0, n_all = 0;
+        check(lm_hip_threshold(ctx_, shard.handle(), t, &mine, &n));
+        const int st = lm_hip_merge_threshold(ctx_, h_, mine, n, row_offset, &all, &n_all);
+        lm_hip_free(mine);
+        check(st);
+        std::vector<MatrixCoordinates> out(n_all);
+        for (size_t i = 0; i < n_all; ++i)
+            out[i] = {all[i].row, all[i].col};
+        lm_hip_free(all);
+        return out;
+    }
+
+private:
+    lm_hip_ctx *ctx_;
+    lm_hip_comm *h_ = nullptr;
 };
 
 }  // namespace lightmotif

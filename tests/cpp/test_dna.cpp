@@ -353,6 +353,41 @@ static void test_edge_cases(const Pipeline<Dna> &pli)
     CHECK(threw);
 }
 
+// The row-sharded path through the C++ mirror: a world of one rank (two ranks cannot share the
+// box's single GPU under RCCL) and the merge rule on explicit per-shard records.
+static void test_sharded(const Pipeline<Dna> &pli)
+{
+    // (1) combine rule: ties go to the later (row, col); NaN only as shard 0's first cell
+    {
+        std::vector<ShardBest> s = {{true, {5, 3}, 2.0f}, {false, {}, 0.0f}, {true, {9, 0}, 2.0f}, {true, {12, 31}, 1.5f}};
+        const ShardBest b = combine_argmax(s);
+        CHECK(b.found && b.cell.row == 9 && b.cell.col == 0 && b.score == 2.0f);
+        s[0] = {true, {0, 0}, std::nanf("")};
+        const ShardBest n = combine_argmax(s);
+        CHECK(n.found && n.cell.row == 0 && n.cell.col == 0 && n.score != n.score);
+        s[0] = {true, {4, 4}, std::nanf("")};          // a NaN that is not the first cell never wins
+        CHECK(combine_argmax(s).cell.row == 9);
+        CHECK(!combine_argmax({{false, {}, 0.0f}}).found);
+    }
+    // (2) one rank: score_into + argmax / threshold through the communicator == the plain calls
+    const auto pssm = golden_pssm();
+    auto striped = pli.stripe(EncodedSequence<Dna>::encode(SEQUENCE));
+    striped.configure(pssm);
+    auto scores = pli.score(pssm, striped);
+    ShardComm<Dna> comm(pli, ShardComm<Dna>::unique_id(), 1, 0);
+    scores.set_first_cell_rule(true);
+    const ShardBest best = comm.argmax(scores, 0);
+    CHECK(best.found && scores.offset(best.cell) == 18);             // tests/dna.rs:138
+    const auto hits = comm.threshold(scores, -10.0f, 0);
+    std::vector<size_t> pos;
+    for (const auto &h : hits)
+        pos.push_back(scores.offset(h));
+    std::sort(pos.begin(), pos.end());
+    CHECK((pos == std::vector<size_t>{18, 27, 32}));                 // tests/dna.rs:158-165
+    const auto shifted = comm.threshold(scores, -10.0f, 1000);       // rows become global
+    CHECK(shifted.size() == 3 && shifted[0].row == hits[0].row + 1000);
+}
+
 int main()
 {
     Pipeline<Dna> pli = Pipeline<Dna>::hip();
@@ -376,6 +411,7 @@ int main()
     test_batch(pli);
     test_encode(pli);
     test_edge_cases(pli);
+    test_sharded(pli);
     if (failures) {
         std::fprintf(stderr, "%d check(s) failed\n", failures);
         return 1;

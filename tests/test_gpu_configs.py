@@ -368,3 +368,69 @@ def test_adopted_sequence_borrows_the_callers_matrix(gpu_pli):
     del seq
     torch.cuda.synchronize()
     assert int(t[0, 0]) == int(ref.data[0, 0])           # still the caller's, not freed
+
+
+# ---- beyond the unrolled C = 32 kernels: long motifs and other column counts ------------------
+
+
+@pytest.mark.parametrize("m", [37, 38, 40, 47, 48, 63, 64, 72, 73, 100, 150])
+def test_long_motifs_are_scored_in_slices(pli, m):
+    """M > 36 at C = 32 (round 1: one thread per cell, 78 Gpos/s): slices of <= 36 motif rows, the
+    first through the store kernel, the others continuing in place from the partial sums
+    (score_c32<M', MODE_CONTINUE>) -- the same sequential adds, so bit-exact against the oracle on
+    ragged lengths, row ranges, -inf / NaN weights, N runs.  The reference's AVX2 loop takes any
+    M (avx2.rs:146-193)."""
+    rng = np.random.default_rng(m)
+    length = 3_000_000 + 17 * m
+    enc = rng.integers(0, 5, length, dtype=np.uint8)
+    enc[rng.random(length) < 0.97] %= 4
+    p = np.zeros((m, 8), np.float32)
+    p[:, :4] = rng.normal(0, 2, (m, 4))
+    p[:, 4] = -np.inf
+    if m % 2:
+        p[rng.integers(0, m), 4] = 1.5
+        p[rng.integers(0, m), rng.integers(0, 4)] = np.nan if m == 47 else -np.inf
+    ref = co.stripe(enc, COLS, 5)
+    co.configure_wrap(ref, m - 1)
+    seq = pli.stripe(lm.EncodedSequence(enc), COLS)
+    seq.configure_wrap(m - 1)
+    pssm = lm.ScoringMatrix(p)
+    scores = lm.StripedScores.empty(pli, COLS)
+    for a, b in ((0, ref.rows), (1234, ref.rows - 5), (ref.rows - 3 * m, ref.rows)):
+        want, _ = co.score_rows(ref, p, a, b)
+        pli.score_rows_into(pssm, seq, range(a, b), scores)
+        assert pli.last_kernel == "score_c32_sliced", pli.last_kernel
+        assert np.array_equal(bits(scores.matrix()[:, :COLS]), bits(want[:, :COLS])), (m, a, b)
+    want, _ = co.score_rows(ref, p)
+    pli.score_into(pssm, seq, scores)
+    assert pli.argmax(scores) == co.argmax(want, COLS)
+    assert pli.score_argmax(pssm, seq)[0] == co.argmax(want, COLS)
+    # a range shorter than one group falls back, same values
+    want, _ = co.score_rows(ref, p, 10, 10 + m // 2)
+    pli.score_rows_into(pssm, seq, range(10, 10 + m // 2), scores)
+    assert np.array_equal(bits(scores.matrix()[:, :COLS]), bits(want[:, :COLS]))
+
+
+@pytest.mark.parametrize("cols,m,k", [(16, 20, 5), (16, 33, 5), (1, 15, 5), (2, 7, 5), (33, 12, 5), (16, 70, 5),
+                                      (4, 100, 5), (16, 12, 21), (8, 40, 21)])
+def test_other_geometries_take_the_tiled_kernel(pli, cols, m, k):
+    """Column counts other than 32 (the 16-lane back-ends' geometry, the Generic bench's C = 1,
+    dna.rs:113-116) and motifs beyond 64: score_tiled, bit-exact against the oracle."""
+    rng = np.random.default_rng(cols * 1000 + m)
+    length = 400_003 if cols > 1 else 100_003
+    enc = rng.integers(0, k - 1, length, dtype=np.uint8)
+    p = np.zeros((m, co.stride(k, 4)), np.float32)
+    p[:, :k] = rng.normal(0, 2, (m, k))
+    p[:, k - 1] = -np.inf
+    ref = co.stripe(enc, cols, k)
+    co.configure_wrap(ref, m - 1)
+    seq = pli.stripe(lm.EncodedSequence(enc, protein=k == 21), cols)
+    seq.configure_wrap(m - 1)
+    pssm = lm.ScoringMatrix(p, protein=k == 21)
+    scores = lm.StripedScores.empty(pli, cols)
+    for a, b in ((0, ref.rows), (7, ref.rows - 11), (ref.rows - 3, ref.rows)):
+        want, _ = co.score_rows(ref, p, a, b)
+        pli.score_rows_into(pssm, seq, range(a, b), scores)
+        assert pli.last_kernel == "score_tiled", pli.last_kernel
+        assert np.array_equal(bits(scores.matrix()[:, :cols]), bits(want[:, :cols])), (cols, m, a, b)
+    assert pli.argmax(scores) == co.argmax(want, cols)

@@ -631,7 +631,8 @@ def test_scanner_max_strict_reference_mode(pli, kind):
         p[:6, 4] = -20.0
         p[6:, 4] = 4.0
         length = 30_000 - 7                             # tail cells exist (rows * 32 > L)
-        enc = enc[:length]
+        enc = enc[:length].copy()
+        enc[length - 6:] = p[:6, :4].argmax(axis=1)     # the best start of such a window: 6 real symbols + 3 N
     if kind == "overestimate_skip":
         p[:, :4] = rng.integers(-3, 4, (m, 4)) + rng.random((m, 4)).astype(np.float32) * 0.3
     ref = co.stripe(enc, 32, 5)

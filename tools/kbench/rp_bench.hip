@@ -109,7 +109,7 @@ int main(int argc, char **argv)
             const dim3 grid((unsigned)((ns + 7) / 8));
             const size_t lds = std::max<size_t>((size_t)K * table_stride(M) * 4, 64);
             if constexpr (M <= kMaxFastM)
-                hipLaunchKernelGGL((score_c32<M, MODE_STORE, LM_SCORE_PF, 0, 256, 0, LM_SCORE_MIN_WAVES(M), 0, 1>), grid, dim3(256),
+                hipLaunchKernelGGL((score_c32<M, MODE_STORE, LM_SCORE_PF, 0, 256, 0, LM_SCORE_MIN_WAVES(M), 1>), grid, dim3(256),
                                    lds, 0, d_seq, d_table, K, 0ull, rows, c.T, ns, d_out, fo);
         } else {
             const unsigned long long nr = (rows + c.T - 1) / c.T;
