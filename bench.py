@@ -137,8 +137,163 @@ def cpu_baseline(seq_sample: np.ndarray, length: int, pssm: np.ndarray, gpu_scor
     }
 
 
+def main_c3(args) -> None:
+    """BASELINE.json configs[2]: the 2 346 DNA matrices of JASPAR 2024 CORE (the reference's own
+    bench fixture, tests/golden/JASPAR2024.pwm.gz; converted like the CLI, main.rs:469-498) over a
+    100 Mbp resident sequence.  The reference fans (motif, sequence) jobs out to worker threads
+    (lightmotif-cli main.rs:502-561); across GPUs the motif list is sharded (balanced on sum M),
+    every rank holds the whole sequence, and the per-motif results are gathered in motif order.
+    Step = one batched fused threshold scan at p = 1e-5 per motif of this rank's share + the
+    gather.  Value = (motif, position) cells per second over all ranks; scaling is STRONG (the
+    total work is fixed)."""
+    from lightmotif_amd import io as lmio
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    coll_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    pssms = [r.matrix.normalize(0.1).log_odds() for r in lmio.read(ROOT / "tests" / "golden" / "JASPAR2024.pwm.gz")]
+    if args.motifs:
+        pssms = pssms[:args.motifs]
+    lengths = [len(p) for p in pssms]
+    max_m = max(lengths)
+    length = args.length if args.length != 1_000_000_000 else 100_000_000
+    rows = -(-length // COLS)
+    shard = synth_shard(rows, 0, rows, length, max_m - 1, dev, seed=0x5EED0003)   # the WHOLE sequence on every rank
+    stream = torch.cuda.current_stream()
+    pli = lm.Pipeline.hip(local_rank, stream=stream.cuda_stream)
+    pli.configure_wrap_dptr(shard.data_ptr(), rows, COLS, COLS, max_m - 1, 4)
+    torch.cuda.synchronize()
+    seq = pli.adopt_sequence(shard.data_ptr(), rows, max_m - 1, COLS, COLS, length, keepalive=shard)
+    ts = [p.score_for_pvalue(1e-5) for p in pssms]
+    parts = D.shard_motifs(lengths, world)
+    for i in parts[rank]:
+        pssms[i]._device(pli)
+
+    def step():
+        return D.scan_threshold_batch_sharded(pli, pssms, ts, seq, device=coll_dev, parts=parts)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    am = D.scan_argmax_batch_sharded(pli, pssms, seq, device=coll_dev, parts=parts)
+    t1 = time.perf_counter()
+    for _ in range(max(args.steps // 2, 1)):
+        am = D.scan_argmax_batch_sharded(pli, pssms, seq, device=coll_dev, parts=parts)
+    barrier()
+    am_s = (time.perf_counter() - t1) / max(args.steps // 2, 1)
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    cells = sum(length + 1 - m for m in lengths)
+    value = cells * args.steps / elapsed / 1e9
+    out = {
+        "metric": "scored (motif, position) cells/sec, fused threshold scan", "value": round(value, 1), "unit": "Gcell/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u16 prefilter + f32 re-scoring",
+        "data": "synthetic sequence (SplitMix64), JASPAR 2024 CORE matrices (reference fixture)",
+        "config": {"workload": f"configs[2]: {len(pssms)} JASPAR DNA PSSMs (sum M = {sum(lengths)}) x {length} bp resident, "
+                               "fused threshold at p = 1e-5 per motif, hits in the reference's order",
+                   "parallelism": f"motif-shard x{world} (LPT on sum M), sequence replicated",
+                   "motifs_per_rank": [len(p) for p in parts]},
+        "extras": {"hits_total": int(sum(len(c) for c, _ in res)), "fused_argmax_ms": round(am_s * 1e3, 3),
+                   "fused_argmax_Gcell_s": round(cells / am_s / 1e9, 1),
+                   "argmax_found": int(sum(a is not None for a in am))},
+        "roofline": None,
+        "roofline_note": "issue-bound scans over a cache-resident sequence: the PMC-based fraction of the VALU issue "
+                         "rate is in profiles/r02_c3_record.md; no HBM fraction applies",
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_c3(shard, rows, length, max_m, pssms, res, am, args.cpu_seconds)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline_c3(shard, rows, length, max_m, pssms, gpu_thr, gpu_am, seconds: float) -> dict:
+    """The AVX2 port on all host threads over a stratified subset of the motifs (every length once
+    if time allows) and the first 20 Mbp-equivalent rows of the sequence: score_rows + argmax per
+    motif (what one reference worker does per job, main.rs:554-561), GPU results of the same
+    motifs checked on that sample beforehand."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import c_oracle as co
+    srows = min(rows, 625_000)                      # 20 Mbp worth of striped rows
+    lengths = [len(p) for p in pssms]
+    subset = [lengths.index(m) for m in sorted(set(lengths))]
+    threads = os.cpu_count() or 1
+    workers = min(threads, 128)
+    data = co.aligned_empty((srows + max_m - 1, COLS), np.uint8)
+    data[:] = shard[:srows + max_m - 1].cpu().numpy()
+    block = 8192                                    # rows per call: the f32 block (1 MB) stays in cache, like the
+                                                    # reference Scanner's 256-row blocks (scan.rs:174-178)
+    tpv = {i: np.float32(pssms[i].score_for_pvalue(1e-5)) for i in subset}
+
+    def job(i):
+        """One (motif, sequence) job of a CLI worker (main.rs:554-561): score block by block, keep the
+        best cell and count the hits; single-threaded, the fan-out is over jobs like rayon's."""
+        m = lengths[i]
+        s = co.Striped(data[:srows + m - 1], length, m - 1, COLS, 5)
+        p = co.aligned_empty(pssms[i].data.shape, np.float32)
+        p[:] = pssms[i].data
+        out = co.aligned_empty((block, COLS), np.float32)
+        hits = []
+        for a in range(0, srows, block):
+            b = min(a + block, srows)
+            co.avx2_score_rows(s, p, out=out[:b - a], row_begin=a, row_end=b, threads=1)
+            co.avx2_argmax(out[:b - a], (b - a) * COLS)
+            rc = np.argwhere(out[:b - a, :COLS] >= tpv[i])
+            if rc.size:
+                rc[:, 0] += a
+                hits.append(rc)
+        return i, (np.concatenate(hits) if hits else np.zeros((0, 2), np.int64))
+
+    ok, cells, n, t0 = True, 0, 0, time.perf_counter()
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        while time.perf_counter() - t0 < seconds:
+            jobs = [subset[k % len(subset)] for k in range(workers)]
+            for i, rc in ex.map(job, jobs):
+                cells += srows * COLS
+                if n == 0:                              # the GPU's hits of this motif inside the sample == the CPU's
+                    g = gpu_thr[i][0]
+                    ok = ok and np.array_equal(g[g[:, 0] < srows], rc)
+            n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(cells / dt / 1e9, 2), "unit": "Gcell/s", "cores": workers, "kind": "port",
+            "sample": f"{len(subset)} motifs (one per length) x first {srows * COLS} positions; one single-threaded job per "
+                      f"(motif, sequence) like the CLI's workers, {workers} jobs in flight: AVX2 port (oracle/lm_avx2.c) "
+                      f"score_rows in cache-resident {block}-row blocks + argmax + threshold, {n} rounds, ~{seconds:.0f} s",
+            "gpu_hits_match_on_sample": bool(ok)}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="c2", choices=["c2", "c3"],
+                    help="c2 (default): the headline score() of configs[1] / configs[3]; c3: the JASPAR batch of configs[2]")
+    ap.add_argument("--motifs", type=int, default=0, help="c3: use only the first N matrices (development)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
@@ -160,6 +315,10 @@ def main() -> None:
     ap.add_argument("--ab", action="store_true",
                     help="development: interleaved A/B of the store kernel's tuning knobs, then exit")
     args = ap.parse_args()
+    if args.config == "c3":
+        if args.steps == 200 and args.warmup == 50:
+            args.steps, args.warmup = 10, 3
+        return main_c3(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

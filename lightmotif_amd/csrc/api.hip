@@ -495,6 +495,25 @@ int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stri
                 e = hipStreamSynchronize(ctx->stream);  // `table` dies with this scope
             if (e != hipSuccess)
                 return cleanup(fail(LM_HIP_ERR_HIP, "table upload failed: %s", hipGetErrorString(e)));
+            // lengths that are no multiple of 4: a second table with leading all-zero rows (see
+            // lm_hip_pssm::d_table_pad); 33..35 stay as they are (36 rows cost more than the byte loads)
+            if (m % 4 != 0 && (m + 3) / 4 * 4 <= 32) {
+                const size_t mp = (m + 3) / 4 * 4, lead = mp - m, tsp = (size_t)table_stride((int)mp);
+                std::vector<float> padded(k * tsp, 0.0f);
+                for (size_t s = 0; s < k; ++s)
+                    for (size_t j = 0; j < m; ++j)
+                        padded[s * tsp + lead + j] = p->host[j * k + s];
+                e = hipMalloc(&p->d_table_pad, padded.size() * sizeof(float));
+                if (e != hipSuccess)
+                    return cleanup(fail(LM_HIP_ERR_OOM, "hipMalloc(table) failed: %s", hipGetErrorString(e)));
+                e = hipMemcpyAsync(p->d_table_pad, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice,
+                                   ctx->stream);
+                if (e == hipSuccess)
+                    e = hipStreamSynchronize(ctx->stream);  // `padded` dies with this scope
+                if (e != hipSuccess)
+                    return cleanup(fail(LM_HIP_ERR_HIP, "table upload failed: %s", hipGetErrorString(e)));
+                p->lead = lead;
+            }
             // discrete prefilter image (score_prefilter.hpp); absent when the matrix has
             // NaN / +inf entries or no spread -- the exact f32 fused kernel is used then
             std::vector<unsigned> image;
@@ -530,12 +549,14 @@ int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stri
             for (size_t off = 0; off < m; off += len) {
                 lm_hip_pssm::Part part;
                 part.off = off;
-                part.m = std::min(len, m - off);
+                const size_t real = std::min(len, m - off);
+                part.lead = (4 - real % 4) % 4;          // the last slice: leading zero rows up to a multiple of 4
+                part.m = real + part.lead;
                 part.ts = (size_t)table_stride((int)part.m);
                 std::vector<float> table(k * part.ts, 0.0f);
                 for (size_t s = 0; s < k; ++s)
-                    for (size_t j = 0; j < part.m; ++j)
-                        table[s * part.ts + j] = p->host[(off + j) * k + s];
+                    for (size_t j = 0; j < real; ++j)
+                        table[s * part.ts + part.lead + j] = p->host[(off + j) * k + s];
                 e = hipMalloc(&part.d_table, table.size() * sizeof(float));
                 if (e != hipSuccess)
                     return cleanup(fail(LM_HIP_ERR_OOM, "hipMalloc(table) failed: %s", hipGetErrorString(e)));
@@ -581,6 +602,8 @@ int lm_hip_pssm_destroy(lm_hip_pssm *p)
         (void)hipFree(p->d_dense);
     if (p->d_table)
         (void)hipFree(p->d_table);
+    if (p->d_table_pad)
+        (void)hipFree(p->d_table_pad);
     for (auto &part : p->parts)
         if (part.d_table)
             (void)hipFree(part.d_table);

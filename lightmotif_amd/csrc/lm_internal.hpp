@@ -117,10 +117,15 @@ struct lm_hip_pssm {
     // ts = floats per symbol row (multiple of 4, ts/4 odd), zero padded.
     float *d_table = nullptr;
     size_t ts = 0;
+    // M % 4 != 0 (and M + lead <= 32): the store kernels' table with `lead` leading all-zero rows, so that
+    // the padded length is a multiple of 4 and the dword symbol loads apply (0.0 + 0.0 + P[0] ... is the
+    // same f32 sequence as 0.0 + P[0] ...: bit-identical)
+    float *d_table_pad = nullptr;
+    size_t lead = 0;
     // M > kMaxFastM (C = 32): slices of <= kMaxFastM rows, each with its own transposed table; the
     // first is scored with the store kernel, the others continue from the stored partial sums
     struct Part {
-        size_t off = 0, m = 0, ts = 0;
+        size_t off = 0, m = 0, ts = 0, lead = 0;  // `m` includes `lead` leading zero rows (table only)
         float *d_table = nullptr;
     };
     std::vector<Part> parts;

@@ -245,11 +245,26 @@ static int launch_generic(lm_hip_ctx *ctx, const ScoreArgs &a, const FusedOut &f
 int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
 {
     FusedOut fo{};
+    const bool dwords = ctx->quad_loads && !ctx->xcd_remap && reinterpret_cast<uintptr_t>(a.d_seq) % 4 == 0;
+    if (dwords && a.pssm->d_table_pad) {
+        // M % 4 != 0: the table padded with leading zero rows to M' = 4 * ceil(M / 4) -- the same f32
+        // sums (0.0 + 0.0 + P[0] ... ), with the dword symbol loads and 4-row blocks of the M' kernel
+        const size_t mp = a.pssm->m + a.pssm->lead;
+        const MotifShape ms{mp, a.pssm->k, false};
+        const C32Plan pp = plan_c32(ctx, ms, a, true);
+        if (pp.ok && score_c32_lookup_ql((int)mp)) {
+            fo.lead_rows = (unsigned)a.pssm->lead;
+            ctx->last_kernel = score_c32_name((int)mp, MODE_STORE);
+            LM_HIP_TRY(score_c32_lookup_ql((int)mp)(pp.grid, pp.lds, ctx->stream, a.d_seq, a.pssm->d_table_pad,
+                                                    (int)a.pssm->k, a.row_begin, a.row_end, pp.T, pp.nstreams, a.d_out,
+                                                    fo));
+            return LM_HIP_OK;
+        }
+    }
     const C32Plan p = plan_c32(ctx, a, true);
     if (p.ok) {
         ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_STORE, ctx->xcd_remap);
-        if (ctx->quad_loads && !ctx->xcd_remap && score_c32_lookup_ql((int)a.pssm->m) &&
-            reinterpret_cast<uintptr_t>(a.d_seq) % 4 == 0)
+        if (dwords && score_c32_lookup_ql((int)a.pssm->m))
             fn = score_c32_lookup_ql((int)a.pssm->m);  // dword symbol loads (M % 4 == 0)
         ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_STORE);
         LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
@@ -274,12 +289,14 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
                 ok = false;
                 break;
             }
+            FusedOut pfo = fo;
+            pfo.lead_rows = (unsigned)part.lead;
             if (i == 0) {
                 ScoreC32Launcher fn = score_c32_lookup_ql((int)part.m);
                 if (!fn)
                     fn = score_c32_lookup((int)part.m, MODE_STORE, false);
                 LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, sa.d_seq, part.d_table, (int)a.pssm->k, a.row_begin, a.row_end,
-                              p.T, p.nstreams, a.d_out, fo));
+                              p.T, p.nstreams, a.d_out, pfo));
                 continue;
             }
             const unsigned long long nfull = n / p.T;
@@ -287,14 +304,14 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
                 const dim3 grid((unsigned)((nfull + kStreamsPerBlock - 1) / kStreamsPerBlock));
                 LM_HIP_TRY(score_c32_lookup_continue((int)part.m)(grid, p.lds, ctx->stream, sa.d_seq, part.d_table,
                                                                   (int)a.pssm->k, a.row_begin, a.row_begin + nfull * p.T,
-                                                                  p.T, nfull, a.d_out, fo));
+                                                                  p.T, nfull, a.d_out, pfo));
             }
             if (nfull * p.T < n) {
                 const unsigned long long r0 = a.row_begin + nfull * p.T;
                 const unsigned long long cells = (a.row_end - r0) * a.cols;
                 hipLaunchKernelGGL(score_continue_cells<0>, dim3((unsigned)((cells + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                                    ctx->stream, sa.d_seq, (unsigned long long)a.seq_stride, (int)a.cols,
-                                   a.pssm->d_dense + part.off * a.pssm->k, (int)part.m, (int)a.pssm->k, r0,
+                                   a.pssm->d_dense + part.off * a.pssm->k, (int)(part.m - part.lead), (int)a.pssm->k, r0,
                                    (unsigned long long)a.row_end, a.d_out + (r0 - a.row_begin) * a.out_stride,
                                    (unsigned long long)a.out_stride);
                 LM_HIP_TRY(hipGetLastError());
@@ -518,8 +535,12 @@ int launch_score_store_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord 
                               int first_cell_rule)
 {
     *tracked = false;
-    const C32Plan p = plan_c32(ctx, a, true);
-    ScoreC32Launcher fn = p.ok ? score_c32_lookup_store_argmax((int)a.pssm->m) : nullptr;
+    // (lengths that are no multiple of 4 run the padded table, see launch_score_store)
+    const bool pad = a.pssm->d_table_pad != nullptr && ctx->quad_loads;
+    const size_t mk = a.pssm->m + (pad ? a.pssm->lead : 0);
+    const MotifShape ms{mk, a.pssm->k, false};
+    const C32Plan p = a.pssm->m <= (size_t)kMaxFastM ? plan_c32(ctx, ms, a, true) : C32Plan{};
+    ScoreC32Launcher fn = p.ok ? score_c32_lookup_store_argmax((int)mk) : nullptr;
     if (!fn || reinterpret_cast<uintptr_t>(a.d_seq) % 4 != 0)
         return launch_score_store(ctx, a);
     if (a.out_stride != 32)
@@ -529,9 +550,10 @@ int launch_score_store_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord 
     FusedOut fo{};
     fo.block_best = static_cast<ArgmaxRecord *>(ctx->scratch.ptr);
     ArgmaxRecord *folded = fo.block_best + nrec;
-    ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_STORE);
-    LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, a.pssm->d_table, (int)a.pssm->k, a.row_begin,
-                  a.row_end, p.T, p.nstreams, a.d_out, fo));
+    fo.lead_rows = pad ? (unsigned)a.pssm->lead : 0u;
+    ctx->last_kernel = score_c32_name((int)mk, MODE_STORE);
+    LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, pad ? a.pssm->d_table_pad : a.pssm->d_table, (int)a.pssm->k,
+                  a.row_begin, a.row_end, p.T, p.nstreams, a.d_out, fo));
     const ArgmaxRecord *recs = fo.block_best;
     unsigned n = nrec;
     if (n > 4096) {  // ~256 K wavefront records per Gbp: fold them to 256 first

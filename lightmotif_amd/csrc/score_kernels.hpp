@@ -113,6 +113,9 @@ struct FusedOut {
     unsigned long long cand_capacity;
     // non-null: a multi-job launch, the fields above that differ per job come from batch[blockIdx.y]
     const BatchParams *batch;
+    // store kernels: leading all-zero motif rows the table was padded with (0..3) so that M is a
+    // multiple of 4 (dword symbol loads): step t then reads sequence row o0 - lead_rows + t
+    unsigned lead_rows;
 };
 
 // Ordering used by every argmax reduction: larger value wins; equal values ->
@@ -502,7 +505,10 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
     // quad-gathered symbol loads need whole 4-row blocks per group
     constexpr int QL = (QLREQ && M % 4 == 0 && LP == 0) ? 1 : 0;
     const unsigned shq = 8u * (col & 3);
-    const uint8_t *sp = QL ? seq + (o0 + (col & 3)) * 32 + (col >> 2) * 4 : seq + o0 * 32 + col;
+    // (padded motifs: the first `lead` rows of a window carry zero weights and may lie before the matrix)
+    const long long lead = mode_stores(MODE) ? (long long)fo_in.lead_rows : 0;
+    const long long in0 = (long long)o0 - lead;
+    const uint8_t *sp = QL ? seq + (in0 + (col & 3)) * 32 + (col >> 2) * 4 : seq + in0 * 32 + col;
     // output row completed by step t is o0 + t - (M-1); `op` tracks step 0 of the group
     const long long orow = (long long)(o0 - row_begin) - (M - 1);
     float *op = mode_stores(MODE) ? out + orow * 32 + col : nullptr;
@@ -521,7 +527,8 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         constexpr int NB = M / 4, PFB = NB > 3 ? 3 : NB;
 #pragma unroll
         for (int j = 0; j < PFB; ++j)
-            sym[j] = *reinterpret_cast<const unsigned *>(sp + j * 128);
+            if (j > 0 || in0 + (col & 3) >= 0)  // lead <= 3: only block 0 can start before row 0; its rows
+                sym[j] = *reinterpret_cast<const unsigned *>(sp + j * 128);  // meet zero weights whatever they hold
     } else {
 #pragma unroll
         for (int j = 0; j < PFE; ++j)

@@ -31,7 +31,16 @@
 
 namespace lm {
 
-constexpr int prefilter2_mo(int m) { return m | 3; }                    // padded length M' = 3 (mod 4)
+// padded length M' = 3 (mod 4) -- except 8 <= M <= 11, which go to M' = 15 instead of 11: a table row of
+// M' = 11 is 6 dwords, read as 16 + 8 bytes, and the 8-byte reads of 16-byte-aligned rows run into 2-way bank
+// conflicts (a third of the LDS cycles of a kernel whose LDS was 96 % busy, profiles/r02_c3_record.md); a row
+// of M' = 15 is two whole 16-byte reads.  Those four lengths are half of JASPAR: the 2 346-motif batch went
+// 37.2 -> 33.8 ms (same-box A/B, profiles/r02_pair_store_whole_rows_ab.txt).  Padding EVERY length to
+// 7 (mod 8) costs single-motif scans of M = 16..19 / 24..27 4-7 %, so only this band moves.
+#ifndef LM_PREFILTER2_MO8
+#define LM_PREFILTER2_MO8 0
+#endif
+constexpr int prefilter2_mo(int m) { return (LM_PREFILTER2_MO8 || (m >= 8 && m <= 11)) ? (m | 7) : (m | 3); }
 constexpr int prefilter2_ring(int m) { return prefilter2_mo(m) + 1; }   // input rows per group
 constexpr int prefilter2_npair(int m) { return prefilter2_ring(m) / 2; }
 // dwords per table row: 4 * odd >= NPAIR (rows 0..15 then sit in distinct 16-byte slots)
@@ -220,7 +229,8 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter2(
         blk[0] = *reinterpret_cast<const unsigned *>(spq);
 #pragma unroll
     for (int j = 1; j < PFB; ++j)
-        blk[j] = *reinterpret_cast<const unsigned *>(spq + j * 128);
+        if (4 * j >= SHIFT || in0 + 4 * j + (long long)(col & 3) >= 0)  // SHIFT > 3: block 1 may start before the matrix too
+            blk[j] = *reinterpret_cast<const unsigned *>(spq + j * 128);
 
     const unsigned long long ngroups = (T - 2) / RING + 1;  // exact: T = q*RING + 2
     unsigned long long hit_groups = 0;
@@ -387,7 +397,8 @@ __global__ __launch_bounds__(kBlock, 4) void score_c32_prefilter2_multi(
         blk[0] = *reinterpret_cast<const unsigned *>(spq);
 #pragma unroll
     for (int j = 1; j < PFB; ++j)
-        blk[j] = *reinterpret_cast<const unsigned *>(spq + j * 128);
+        if (4 * j >= SHIFT || in0 + 4 * j + (long long)(col & 3) >= 0)  // SHIFT > 3: block 1 may start before the matrix too
+            blk[j] = *reinterpret_cast<const unsigned *>(spq + j * 128);
 
     const unsigned long long ngroups = (T - 2) / RING + 1;
     const unsigned long long G = (ngroups + 63) / 64;

@@ -136,7 +136,8 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_u8_pairs(
         blk[0] = *reinterpret_cast<const unsigned *>(spq);
 #pragma unroll
     for (int j = 1; j < PFB; ++j)
-        blk[j] = *reinterpret_cast<const unsigned *>(spq + j * 128);
+        if (4 * j >= SHIFT || in0 + 4 * j + (long long)(col & 3) >= 0)  // SHIFT > 3: block 1 may start before the matrix too
+            blk[j] = *reinterpret_cast<const unsigned *>(spq + j * 128);
 
     // group 0 completes rows 0 and 1, group g >= 1 rows (g-1)*RING + 2 .. g*RING + 1
     const unsigned long long ngroups = (T - 2) / RING + 1;  // exact: T = q*RING + 2

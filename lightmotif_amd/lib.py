@@ -980,8 +980,8 @@ class Scanner:
 
     def __init__(self, pssm: ScoringMatrix, sequence: StripedSequence, threshold: float = 0.0,
                  block_size: int = 256):
-        if pssm.protein or sequence.protein:
-            raise ValueError("scanner only supports DNA")  # lib.rs scan()
+        if pssm.protein != sequence.protein:
+            raise ValueError("motif and sequence alphabets differ")
         if block_size < 1:
             raise ValueError("block_size must be positive")
         self.block_size = block_size
@@ -1179,5 +1179,9 @@ def stripe(sequence: str, *, protein: bool = False) -> StripedSequence:
 
 def scan(pssm: ScoringMatrix, sequence: StripedSequence, *, threshold: float = 0.0,
          block_size: int = 256) -> Scanner:
-    """lib.rs:1437-1451"""
+    """lib.rs:1437-1451.  The reference's Python ``scan()`` is DNA-only (its PyO3 class is
+    instantiated for ``Dna``); the Rust ``Scanner`` is alphabet-generic (scan.rs:96-136), and so
+    is the ``Scanner`` class here -- this module-level helper keeps the binding's restriction."""
+    if pssm.protein or sequence.protein:
+        raise ValueError("scanner only supports DNA")  # lib.rs scan()
     return Scanner(pssm, sequence, threshold, block_size)

@@ -174,19 +174,18 @@ def test_shard_entry_points_merge_to_the_whole_matrix_answer(gpu_pli, kind, shar
     rng = np.random.default_rng([len(kind), ord(kind[0]), ord(kind[-1]), shards])
     length, m = 3_000_017, 9
     enc, p = _planted("random" if kind == "nan_elsewhere" else kind, rng, length, m)
-    ref = co.stripe(enc, COLS, 5)
-    co.configure_wrap(ref, m - 1)
-    rows = ref.rows
+    rows = -(-length // COLS)
     spans = [D.shard_rows(rows, shards, g) for g in range(shards)]
     if kind == "nan_elsewhere":
-        # NaN cells only in a shard that does not hold row 0: its first cell is NaN, which must
-        # NOT trigger the first-cell rule there
+        # NaN cells only where the window starts with the first symbol of shard 1 (position a1 = cell
+        # (a1, 0)): that shard's first cell is NaN, which must NOT trigger the first-cell rule there;
+        # the matrix's own first cell starts with another symbol
         a1 = spans[1][0]
-        first_sym = int(ref.data[a1, 0])
-        p[0, first_sym] = np.nan
-        if np.isnan(co.score_rows(ref, p, 0, 1)[0][0, 0]):
-            p[0, first_sym] = 0.0
-            pytest.skip("row 0 starts with the same symbol")
+        enc[0] = (enc[a1] + 1) % 4
+        p[0, int(enc[a1])] = np.nan
+    ref = co.stripe(enc, COLS, 5)
+    co.configure_wrap(ref, m - 1)
+    assert ref.rows == rows
     pssm = lm.ScoringMatrix(p)
     want, _ = co.score_rows(ref, p)
     want_am = co.argmax(want, COLS)

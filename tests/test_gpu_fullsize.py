@@ -56,7 +56,8 @@ def test_full_size_properties(gpu_pli, length, m, k):
     pli = gpu_pli
     seq, rows, pssm = make_workload(pli, length, m, k, seed=1234 + m)
     scores = score_all(pli, pssm, seq, rows, m, length)
-    assert pli.last_kernel == f"score_c32<{m},0>"
+    mp = m if m % 4 == 0 or (m + 3) // 4 * 4 > 32 else (m + 3) // 4 * 4   # padded with leading zero rows to 4 | M
+    assert pli.last_kernel == f"score_c32<{mp},0>"
 
     # (1) windows against the oracle, bit for bit (start, middle, the wrap-touching end)
     for a in (0, rows // 2 - 777, rows - 4096):

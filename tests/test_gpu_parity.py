@@ -690,3 +690,39 @@ def test_scanner_max_strict_reference_mode(pli, kind):
         hot = lm.ScoringMatrix(p2)
         with pytest.raises(IndexError):
             lm.Scanner(hot, seq, threshold=t).max(strict_reference=True)
+
+
+def test_scanner_on_protein(pli):
+    """The Rust Scanner is alphabet-generic (scan.rs:96-136; `to_discrete` pwm/mod.rs:665-696 for any
+    K).  Protein sequences go through the one-symbol u16 prefilter (21 table rows) + exact
+    re-scoring: the hits, their yield order and max() against the oracle's restatement."""
+    rng = np.random.default_rng(21)
+    length, m = 500_011, 12
+    enc = rng.integers(0, 21, length, dtype=np.uint8)
+    enc[rng.random(length) < 0.99] %= 20                      # a sprinkle of X
+    sites = ["".join(lm.lib.PROTEIN_SYMBOLS[i] for i in rng.integers(0, 20, m)) for _ in range(6)]
+    pssm = lm.create(sites, protein=True).counts.normalize(0.1).log_odds()
+    ref = co.stripe(enc, 32, 21)
+    co.configure_wrap(ref, m - 1)
+    want, _ = co.score_rows(ref, pssm.data)
+    seq = pli.stripe(lm.EncodedSequence(enc, protein=True), 32)
+    seq.configure(pssm)
+    finite = want[:, :32][np.isfinite(want[:, :32])]
+    for q, bs in ((0.9999, 256), (0.999, 64)):
+        t = float(np.quantile(finite, q))
+        order = no.scanner_collect(want, 32, length, m, t, bs)
+        sc = lm.Scanner(pssm, seq, threshold=t, block_size=bs)
+        got = [(h.position, np.float32(h.score)) for h in sc]
+        assert len(got) > 20 and got == [(i, s) for i, s in order]
+        best = no.scanner_max(want, 32, length, m, t)
+        top = lm.Scanner(pssm, seq, threshold=t, block_size=bs).max()
+        assert (top.position, np.float32(top.score)) == best
+    for on in (True, False):                                  # prefilter on / off: same hits
+        pli.set_prefilter(on)
+        try:
+            pos = lm.Scanner(pssm, seq, threshold=t).positions
+        finally:
+            pli.set_prefilter(True)
+        assert pos.tolist() == sorted(i for i, _ in order)
+    with pytest.raises(ValueError):
+        lm.scan(pssm, seq)                                    # the Python binding's helper stays DNA-only (lib.rs)

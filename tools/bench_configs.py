@@ -146,7 +146,19 @@ def config5(pli):
 
     assert fused() == pli.argmax_dptr(out.data_ptr(), rows, COLS, COLS)
     tf = timeit(fused, 30)
+    sample = out[: 1 << 18].flatten()
+    thr = float(torch.quantile(sample[torch.isfinite(sample)].float(), 1 - 1e-5))
+    th = {}
+    for on in (True, False):   # one-symbol u16 prefilter (21 table rows) vs the exact f32 kernel
+        pli.set_prefilter(on)
+        call = lambda: pli.score_threshold_dptr(pssm, seq.data_ptr(), rows + m - 1, COLS, COLS, m - 1, length, 0, rows, thr)  # noqa: E731
+        call()
+        th[on] = (timeit(call, 20), pli.last_kernel, len(call()[0]))
+    pli.set_prefilter(True)
+    assert th[True][2] == th[False][2]
     return {"config": "c5: protein (K=21) len-12 PSSM x 200 Mres, score() materialised", "kernel": store_kernel,
+            "fused_threshold_prefilter_ms": round(th[True][0] * 1e3, 4), "fused_threshold_prefilter_kernel": th[True][1],
+            "fused_threshold_exact_ms": round(th[False][0] * 1e3, 4), "fused_threshold_hits": th[True][2],
             "ms": round(t * 1e3, 4), "Gpos_per_s": round(rows * COLS / t / 1e9, 1),
             "GBps": round(5 * rows * COLS / t / 1e9, 1), "hbm_frac": round(5 * rows * COLS / t / 8e12, 4),
             "fused_argmax_ms": round(tf * 1e3, 4), "fused_argmax_Gpos_per_s": round(rows * COLS / tf / 1e9, 1),
@@ -209,9 +221,32 @@ def config_u8(pli):
             "note": "score_kernel_ms from HIP events on the launch stream, the other times are wall time per call incl. launch + synchronisation; algorithmic traffic 2 B / 1 B per cell"}
 
 
+def config_shapes(pli):
+    """Beyond the unrolled C = 32 kernels: long motifs (sliced in place) and other column counts
+    (score_tiled).  100 Mbp each; C = 1 is the Generic bench geometry of dna.rs:113-116, bound by 32-byte
+    rows (64 B of traffic per position)."""
+    out = {"config": "shapes: score() beyond C = 32 / M <= 36, 100 Mbp each", "rows": []}
+    rng = np.random.default_rng(9)
+    for cols, m, length in ((32, 40, 100_000_000), (32, 64, 100_000_000), (32, 100, 100_000_000), (16, 20, 100_000_000),
+                            (16, 33, 100_000_000), (1, 15, 20_000_000)):
+        enc = rng.integers(0, 4, length, dtype=np.uint8)
+        seq = pli.stripe(lm.EncodedSequence(enc), cols)
+        pssm = motif(rng, m)
+        seq.configure(pssm)
+        scores = lm.StripedScores.empty(pli, cols)
+        for _ in range(3):
+            pli.score_into(pssm, seq, scores)
+        t = timeit(lambda: pli.score_into(pssm, seq, scores), 10)
+        out["rows"].append({"C": cols, "M": m, "kernel": pli.last_kernel, "ms": round(t * 1e3, 3),
+                            "Gpos_per_s": round(length / t / 1e9, 1)})
+        del seq, scores
+    return out
+
+
 if __name__ == "__main__":
     torch.cuda.set_device(0)
     pli = lm.Pipeline.hip(0, stream=torch.cuda.current_stream().cuda_stream)
-    which = sys.argv[1:] or ["c1", "c5", "layout", "u8", "c3"]
+    which = sys.argv[1:] or ["c1", "c5", "layout", "u8", "shapes", "c3"]
     for name in which:
-        print(json.dumps({"c1": config1, "c3": config3, "c5": config5, "layout": config_layout, "u8": config_u8}[name](pli)), flush=True)
+        print(json.dumps({"c1": config1, "c3": config3, "c5": config5, "layout": config_layout, "u8": config_u8,
+                          "shapes": config_shapes}[name](pli)), flush=True)

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Builds a variant of the library with extra compiler flags next to the shipped one, for A/B runs on
+one box:   python tools/build_variant.py e0 -DLM_LDS_WHOLE_ROWS=0
+-> lightmotif_amd/csrc/liblightmotif_hip_e0.so (git-ignored); select it with LM_HIP_LIBRARY=<path>."""
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from lightmotif_amd import build as B  # noqa: E402
+
+tag, extra = sys.argv[1], sys.argv[2:]
+obj = B.CSRC / f"_obj_{tag}"
+obj.mkdir(exist_ok=True)
+hipcc = B._hipcc()
+cmds, objs = [], []
+for unit in B.UNITS:
+    o = obj / (unit + ".o")
+    objs.append(o)
+    cmds.append([hipcc, *B.FLAGS, *extra, "-c", str(B.CSRC / unit), "-o", str(o)])
+for inst, lo, hi in B.INST:
+    o = obj / f"score_inst_{inst}.o"
+    objs.append(o)
+    cmds.append([hipcc, *B.FLAGS, *extra, f"-DLM_M_LO={lo}", f"-DLM_M_HI={hi}", f"-DLM_INST_ID={inst}", "-c",
+                 str(B.CSRC / "score_inst.hip"), "-o", str(o)])
+with ThreadPoolExecutor(max_workers=8) as ex:
+    list(ex.map(B._run, cmds))
+lib = B.CSRC / f"liblightmotif_hip_{tag}.so"
+B._run([hipcc, f"--offload-arch={B.ARCH}", "-shared", "-fPIC", "-o", str(lib), *map(str, objs), "-ldl"])
+print(lib)

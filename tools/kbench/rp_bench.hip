@@ -11,7 +11,7 @@
 #include <string>
 #include <vector>
 
-#include "score_rowpair.hpp"
+#include "score_rowpair.hpp"  // tools/kbench/ (experiment)
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 #ifndef KB_M
