@@ -85,6 +85,27 @@ def synth_shard(rows: int, row0: int, total_rows: int, total_length: int, halo: 
     return shard
 
 
+_JSON_OUT = None
+
+
+def claim_stdout() -> None:
+    """Rank 0 owes the driver ONE JSON line on stdout, but RCCL prints a version banner there when a
+    communicator comes up (torch's and the library's alike), buffered until the process exits.  So the
+    real stdout is set aside for the JSON line and file descriptor 1 is pointed at stderr for everything
+    else this process or its libraries print."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(obj: dict) -> None:
+    out = _JSON_OUT or sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 def synth_pssm(m: int, seed: int = 0x5EED0002) -> lm.ScoringMatrix:
     """counts of 10 pseudo-random m-mers -> to_freq(0.1) -> to_scoring(uniform)."""
     rng = np.random.default_rng(seed)
@@ -228,7 +249,7 @@ def main_c3(args) -> None:
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_c3(shard, rows, length, max_m, pssms, res, am, args.cpu_seconds)
-    print(json.dumps(out), flush=True)
+    emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -315,6 +336,7 @@ def main() -> None:
     ap.add_argument("--ab", action="store_true",
                     help="development: interleaved A/B of the store kernel's tuning knobs, then exit")
     args = ap.parse_args()
+    claim_stdout()
     if args.config == "c3":
         if args.steps == 200 and args.warmup == 50:
             args.steps, args.warmup = 10, 3
@@ -359,20 +381,24 @@ def main() -> None:
     pli.score_into(pssm, seq, scores_h)                  # allocates the resident StripedScores
     torch.cuda.synchronize()
 
-    use_cabi = world > 1 and (args.merge == "cabi" or (args.merge == "auto" and args.dist_backend == "nccl"))
+    # (--merge cabi on ONE rank runs the sharded step through a communicator of one: a functional check of
+    #  the C-ABI merge path on a single-GPU box, not the headline configuration)
+    use_cabi = args.merge == "cabi" or (world > 1 and args.merge == "auto" and args.dist_backend == "nccl")
     comm, comm_note = None, None
     if use_cabi:
         try:
             comm = D.CabiComm.from_torch(pli, device=coll_dev)
         except lm.LightmotifHipError as e:      # e.g. no librccl next to a non-torch host: say so, use torch's
             comm_note = f"C-ABI communicator unavailable ({e}); merge carried by torch.distributed"
-        flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=coll_dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # all ranks or none
-        if int(flag.item()) == 0 and comm is not None:
-            comm.close()
-            comm = None
+        if world > 1:
+            flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=coll_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # all ranks or none
+            if int(flag.item()) == 0 and comm is not None:
+                comm.close()
+                comm = None
+    sharded = world > 1 or comm is not None
     scores_h.set_first_cell_rule(rank == 0)
-    pli.set_track_argmax(world > 1)            # N = 1 times the plain store kernel (configs[1])
+    pli.set_track_argmax(sharded)              # N = 1 times the plain store kernel (configs[1])
 
     def step():
         """N = 1: one score_into (pli/mod.rs:109-117) into the resident StripedScores.
@@ -380,7 +406,7 @@ def main() -> None:
         (tracked by the store kernel, first-cell rule on rank 0 only) and its merge over RCCL --
         SURVEY 8(d): "wall time of the slowest rank incl. the RCCL merge"."""
         pli.score_into(pssm, seq, scores_h)
-        if world == 1:
+        if not sharded:
             return None
         if comm is not None:
             return comm.argmax_sharded(scores_h, row0)   # device-side all_gather + combine, one 16-B read-back
@@ -435,7 +461,7 @@ def main() -> None:
         a.record(stream)
         pli.score_into(pssm, seq, scores_h)
         b.record(stream)
-        if world > 1:
+        if sharded:
             merged = (comm.argmax_sharded(scores_h, row0) if comm is not None else
                       D.merge_argmax(pli.argmax_handle_shard(scores_h, first_cell_rule=rank == 0), row0,
                                      device=coll_dev))
@@ -509,7 +535,7 @@ def main() -> None:
                                  "command (profiles/pmc_traffic.json), not measured by this run"
         except (OSError, ValueError):
             traffic = None
-    step_desc = ("score_into" if world == 1 else
+    step_desc = ("score_into" if not sharded else
                  "score_into of the rank's row shard + tracked shard argmax + RCCL merge of the argmax records "
                  f"({'C-ABI communicator' if comm is not None else 'torch.distributed ' + args.dist_backend})")
     out = {
@@ -555,7 +581,7 @@ def main() -> None:
                                            args.cpu_seconds)
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out), flush=True)
+    emit(out)
     if comm is not None:
         comm.close()
     if world > 1:

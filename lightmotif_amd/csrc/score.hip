@@ -323,8 +323,9 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
         }
     }
     // any other geometry: the tiled kernel when its LDS tile fits (the dense table + TR + M - 1 rows of
-    // `cols` symbols), else one thread per cell
-    {
+    // `cols` symbols), else one thread per cell (LM_HIP_TILED=0: always, for A/B runs)
+    static const bool tiled_on = [] { const char *e = getenv("LM_HIP_TILED"); return !e || atoi(e) != 0; }();
+    if (tiled_on) {
         const size_t tab_bytes = (a.pssm->m * a.pssm->k * 4 + 15) / 16 * 16;
         const size_t budget = 40 * 1024;
         const unsigned long long n = a.row_end - a.row_begin;
@@ -337,10 +338,19 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
             if (tr >= (unsigned long long)kTiledStrip) {
                 const size_t lds = tab_bytes + (tr + a.pssm->m - 1) * a.cols + 16;
                 ctx->last_kernel = "score_tiled";
-                hipLaunchKernelGGL(score_tiled<kTiledStrip>, dim3((unsigned)((n + tr - 1) / tr)), dim3(kBlock), lds, ctx->stream, a.d_seq,
-                                   (unsigned long long)a.seq_stride, (int)a.cols, a.pssm->d_dense, (int)a.pssm->m,
-                                   (int)a.pssm->k, (unsigned long long)a.row_begin, (unsigned long long)a.row_end, (int)tr,
-                                   a.d_out, (unsigned long long)a.out_stride);
+                const dim3 grid((unsigned)((n + tr - 1) / tr));
+                auto launch = [&](auto kernel) {
+                    hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, ctx->stream, a.d_seq, (unsigned long long)a.seq_stride,
+                                       (int)a.cols, a.pssm->d_dense, (int)a.pssm->m, (int)a.pssm->k,
+                                       (unsigned long long)a.row_begin, (unsigned long long)a.row_end, (int)tr, a.d_out,
+                                       (unsigned long long)a.out_stride);
+                };
+                if (a.pssm->k == 5)
+                    launch(score_tiled<kTiledStrip, 5>);
+                else if (a.pssm->k == 21)
+                    launch(score_tiled<kTiledStrip, 21>);
+                else
+                    launch(score_tiled<kTiledStrip, 0>);
                 LM_HIP_TRY(hipGetLastError());
                 return LM_HIP_OK;
             }

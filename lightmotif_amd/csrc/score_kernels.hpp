@@ -704,14 +704,15 @@ __global__ __launch_bounds__(kBlock) void score_generic(
 // in order from +0.0: the reference's add sequence (pli/mod.rs:98-102), bit-identical.
 constexpr int kTiledStrip = 8;
 
-template <int STRIP>
+template <int STRIP, int KT>  // KT: the alphabet size at compile time (5, 21), 0 = read it at run time
 __global__ __launch_bounds__(kBlock) void score_tiled(
     const uint8_t *__restrict__ seq, const unsigned long long seq_stride, const int cols,
-    const float *__restrict__ pssm, const int M, const int K, const unsigned long long row_begin,
+    const float *__restrict__ pssm, const int M, const int K_rt, const unsigned long long row_begin,
     const unsigned long long row_end, const int TR, float *__restrict__ out,
     const unsigned long long out_stride)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int K = KT ? KT : K_rt;
     float *tab = reinterpret_cast<float *>(lds_raw);                       // M x K
     uint8_t *tile = reinterpret_cast<uint8_t *>(lds_raw) + (((size_t)M * K * 4 + 15) / 16) * 16;
     for (int i = threadIdx.x; i < M * K; i += kBlock)
@@ -749,14 +750,38 @@ __global__ __launch_bounds__(kBlock) void score_tiled(
         for (int i = 0; i < STRIP; ++i)
             acc[i] = 0.0f;  // T::default() (pli/mod.rs:98)
         const uint8_t *tp = tile + o * cols + c;
-        for (int rho = 0; rho < M + n - 1; ++rho) {  // input row o + rho feeds outputs i with j = rho - i in [0, M)
-            const unsigned s = tp[(size_t)rho * cols];
-            const float *trow = tab + s;
+        // input row o + rho feeds the outputs i with j = rho - i in [0, M): weight tab[(rho - i) * K + s]
+        if (n == STRIP && M >= STRIP) {
+            // full strip: ramp-up (outputs 0..rho), steady state (all STRIP outputs, no tests), ramp-down
 #pragma unroll
-            for (int i = 0; i < STRIP; ++i) {
-                const int j = rho - i;
-                if (i < n && j >= 0 && j < M)  // uniform across the wavefront except for `n` at the tile's end
-                    acc[i] = acc[i] + trow[j * K];
+            for (int rho = 0; rho < STRIP - 1; ++rho) {
+                const float *base = tab + tp[(size_t)rho * cols] + rho * K;
+#pragma unroll
+                for (int i = 0; i <= rho; ++i)
+                    acc[i] = acc[i] + base[-i * K];
+            }
+            for (int rho = STRIP - 1; rho < M; ++rho) {
+                const float *base = tab + tp[(size_t)rho * cols] + rho * K;
+#pragma unroll
+                for (int i = 0; i < STRIP; ++i)
+                    acc[i] = acc[i] + base[-i * K];
+            }
+#pragma unroll
+            for (int d = 1; d < STRIP; ++d) {
+                const float *base = tab + tp[(size_t)(M - 1 + d) * cols] + (M - 1 + d) * K;
+#pragma unroll
+                for (int i = d; i < STRIP; ++i)
+                    acc[i] = acc[i] + base[-i * K];
+            }
+        } else {
+            for (int rho = 0; rho < M + n - 1; ++rho) {
+                const float *trow = tab + tp[(size_t)rho * cols];
+#pragma unroll
+                for (int i = 0; i < STRIP; ++i) {
+                    const int j = rho - i;
+                    if (i < n && j >= 0 && j < M)
+                        acc[i] = acc[i] + trow[j * K];
+                }
             }
         }
 #pragma unroll

@@ -1,22 +1,29 @@
 #!/bin/bash
 # Collects the measurements committed under profiles/ (run on a GPU box via gpurun):
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01'
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r02'
 # Everything lands in gpurun_out/<tag>/; copy what should be judged into profiles/.
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd "$ROOT"
 timeout 400 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-timeout 300 python tools/bench_configs.py > "$OUT/bench_configs.json" 2> "$OUT/bench_configs.err"
+timeout 300 python bench.py --config c3 > "$OUT/bench_c3.json" 2> "$OUT/bench_c3.err"
+timeout 400 python tools/bench_configs.py > "$OUT/bench_configs.json" 2> "$OUT/bench_configs.err"
 timeout 200 python tools/api_overhead.py > "$OUT/api_overhead.json" 2> "$OUT/api_overhead.err"
-timeout 100 tools/kbench/stripe_bench > "$OUT/stripe_bench.txt" 2>&1
-# the same box's ceiling for the store kernel: trivial kernels moving its 1 B read : 4 B written mix
+timeout 400 python tools/msweep.py > "$OUT/msweep.json" 2> "$OUT/msweep.err"
+timeout 200 python tools/msweep.py 1000000000 40,48,64,100 > "$OUT/msweep_long.json" 2> "$OUT/msweep_long.err"
 timeout 100 tools/kbench/mix_bench > "$OUT/mix_bench.txt" 2>&1
 timeout 200 python tools/handle_flow.py > "$OUT/handle_flow.json" 2> "$OUT/handle_flow.err"
+# the N > 1 control flow of bench.py on the box's one GPU: 2 ranks over gloo (torch merge), and the C-ABI merge path
+# through a communicator of one rank -- functional checks, NOT scaling numbers
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
     --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 5 --dist-backend gloo --single-device \
-    --length 400000000 --no-cpu-baseline 2> "$OUT/bench_2rank.err" | grep '^{' > "$OUT/bench_2rank_gloo_single_device.json"  # (gloo prints a banner on stdout)
+    --length 400000000 --no-cpu-baseline 2> "$OUT/bench_2rank.err" | grep '^{' > "$OUT/bench_2rank_gloo_single_device.json"
+timeout 200 python bench.py --merge cabi --steps 50 --warmup 10 --no-cpu-baseline > "$OUT/bench_cabi_merge_one_rank.json" 2> "$OUT/bench_cabi.err"
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+    --master-port 29518 bench.py --config c3 --gpus 2 --steps 4 --warmup 1 --dist-backend gloo --single-device \
+    --no-cpu-baseline 2> "$OUT/bench_c3_2rank.err" | grep '^{' > "$OUT/bench_c3_2rank_gloo_single_device.json"
 ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv \
     -d "$OUT/prof" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/prof_bench.json" 2> "$OUT/prof.err" )
 python - "$OUT" <<'PY'
@@ -32,8 +39,7 @@ for p in glob.glob(out + "/prof/**/*kernel_trace.csv", recursive=True):
         w = csv.DictWriter(f, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(rows)
 PY
 rm -rf "$OUT/prof"
-for pv in 1e-5 1e-3; do
-  GRAFT_REPO_ROOT=$ROOT bash "$ROOT/tools/timeline_threshold.sh" $pv 2>/dev/null | grep -v simple_timer > "$OUT/timeline_fused_p$pv.txt"
-done
+GRAFT_REPO_ROOT=$ROOT bash "$ROOT/tools/collect_pmc.sh" > "$OUT/pmc.log" 2>&1
+cp "$ROOT/gpurun_out/pmc/summary.json" "$OUT/pmc_summary.json" 2>/dev/null
 cd "$ROOT"
-tail -c 600 "$OUT/bench_default.json"; echo; head -5 "$OUT/bench_kernel_stats.csv" | cut -c1-200
+tail -c 700 "$OUT/bench_default.json"; echo; head -4 "$OUT/bench_kernel_stats.csv" | cut -c1-200; cat "$OUT/pmc_summary.json"
