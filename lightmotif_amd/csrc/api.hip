@@ -122,9 +122,9 @@ static bool build_prefilter(lm_hip_pssm &p, std::vector<unsigned> *image, std::v
     // E[e] = d[e-1][a] + d[e][b] over the motif padded to an ODD length M' by a leading
     // zero row; dword m = (lo E[2m+1], hi E[2m]).  Same weights, same sums, same bound.
     image2->clear();
-    if (k == 5) {
-        image2->assign((size_t)prefilter2_image_dw(m), 0u);
-        prefilter2_pack_image(d.data() + (size_t)shift * k, m, image2->data());
+    if (k == 5 || k == 21) {  // DNA: 25 pair rows; protein: 441
+        image2->assign((size_t)prefilter2_image_dw(m, k), 0u);
+        prefilter2_pack_image(d.data() + (size_t)shift * k, m, image2->data(), k);
     }
     p.pre_offset = offset;
     p.pre_factor = factor;
@@ -341,6 +341,8 @@ static int ctx_create(int device, void *stream, bool borrow, lm_hip_ctx **out)
         ctx->quad_loads = atoi(e) != 0;
     if (const char *e = getenv("LM_HIP_PAIR_PREFILTER"))  // A/B switch: 0 = one symbol per lookup
         ctx->pair_prefilter = atoi(e) != 0;
+    if (const char *e = getenv("LM_HIP_PAIR_PREFILTER_PROTEIN"))  // A/B switch: 1 = 441-row pair scan for K = 21
+        ctx->pair_prefilter_protein = atoi(e) != 0;
     if (borrow) {
         ctx->stream = static_cast<hipStream_t>(stream);
         ctx->owns_stream = false;

@@ -94,6 +94,7 @@ struct lm_hip_ctx {
     bool use_prefilter = true;  // fused threshold: packed 16-bit discrete prefilter (A/B knob)
     bool xcd_remap = false;      // A/B knob of the store kernel (lm_hip_ctx_set_xcd_remap)
     bool pair_prefilter = true;  // DNA prefilter scans look up two symbols at a time
+    bool pair_prefilter_protein = false;  // the 441-row protein pair scan: correct, measured 4 % slower
     bool quad_loads = true;      // store kernel: quad-gathered dword symbol loads (M % 4 == 0; +1 %)
     bool track_argmax = true;    // score_into on handles also tracks the best cell (cached argmax)
     bool speculate_order = true; // fused threshold: order the hit list before the host knows its length
@@ -135,7 +136,7 @@ struct lm_hip_pssm {
     // (u16 layout EVEN | u16 layout ODD) and the affine map
     // discrete = (score - pre_offset) / pre_factor, pre_emax = f32 rounding-error bound.
     unsigned *d_image = nullptr;
-    unsigned *d_image2 = nullptr;  // DNA only: pair-symbol table of score_prefilter2.hpp
+    unsigned *d_image2 = nullptr;  // DNA / protein: pair-symbol table of score_prefilter2.hpp (25 / 441 rows)
     bool has_prefilter = false;
     double pre_offset = 0, pre_factor = 0, pre_emax = 0;
 };

@@ -29,6 +29,7 @@ void register_score_c32_8(const KernelRegistry &r);
 static ScoreC32Launcher g_c32[kMaxFastM + 1][kRegistrySlots];
 static PrefilterLauncher g_pre[kMaxFastM + 1];
 static PrefilterLauncher g_pre2[kMaxFastM + 1];
+static PrefilterLauncher g_pre2_protein[kMaxFastM + 1];
 static ScoreU8Launcher g_u8[kMaxFastM + 1];
 static ScoreU8Launcher g_u8_pairs[kMaxFastM + 1];
 static PrefilterMultiLauncher g_pre2_multi[kMaxFastM + 1];
@@ -37,7 +38,7 @@ static std::once_flag g_c32_once;
 
 static void init_registry()
 {
-    const KernelRegistry r{g_c32, g_pre, g_pre2, g_u8, g_u8_pairs, g_pre2_multi};
+    const KernelRegistry r{g_c32, g_pre, g_pre2, g_pre2_protein, g_u8, g_u8_pairs, g_pre2_multi};
     register_score_c32_0(r);
     register_score_c32_1(r);
     register_score_c32_2(r);
@@ -68,10 +69,12 @@ PrefilterLauncher score_c32_prefilter_lookup(int M)
     return (M >= 1 && M <= kMaxFastM) ? g_pre[M] : nullptr;
 }
 
-PrefilterLauncher score_c32_prefilter2_lookup(int M)
+PrefilterLauncher score_c32_prefilter2_lookup(int M, int K)
 {
     std::call_once(g_c32_once, init_registry);
-    return (M >= 1 && M <= kMaxFastM) ? g_pre2[M] : nullptr;
+    if (M < 1 || M > kMaxFastM)
+        return nullptr;
+    return K == 5 ? g_pre2[M] : K == 21 ? g_pre2_protein[M] : nullptr;
 }
 
 PrefilterMultiLauncher score_c32_prefilter2_multi_lookup(int M)
@@ -164,10 +167,10 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const Score
     if (ms.m < 1 || ms.m > (size_t)kMaxFastM || n < M + extra)
         return p;
     // (the pair-symbol kernel fetches symbols with dword loads: 4-byte aligned matrix)
-    if (prefilter == 2 && (K != 5 || !ms.pair_table || ms.m < 2 ||
+    if (prefilter == 2 && ((K != 5 && !(K == 21 && ctx->pair_prefilter_protein)) || !ms.pair_table || ms.m < 2 ||
                            reinterpret_cast<uintptr_t>(a.d_seq) % 4 != 0))
         return p;
-    const size_t lds = prefilter == 2   ? (size_t)prefilter2_image_dw((int)ms.m) * 4
+    const size_t lds = prefilter == 2   ? (size_t)prefilter2_image_dw((int)ms.m, (int)K) * 4
                        : prefilter == 1 ? (size_t)prefilter_image_dw((int)ms.m, (int)K) * 4
                                         : std::max<size_t>(K * table_stride((int)M) * sizeof(float), 64);
     if (lds > 60 * 1024)
@@ -396,7 +399,8 @@ int launch_score_u8(lm_hip_ctx *ctx, const DiscreteArgs &a)
     // streams of ~128 rows: 1 B + 1 B per cell leaves the kernel between the f32 store kernel
     // (HBM-bound, short streams) and the scans (issue-bound, long streams); measured at 1 Gbp
     // x M = 20: T = 64 0.449 ms, 128 0.426, 256 0.434, 1024 0.456, 4096 0.486
-    C32Plan p = (out_aligned && ctx->pair_prefilter) ? plan_c32(ctx, ms, sa, true, 2, 1, 128) : C32Plan();
+    // (the u8 pair kernel exists for DNA only)
+    C32Plan p = (out_aligned && ctx->pair_prefilter && a.k == 5) ? plan_c32(ctx, ms, sa, true, 2, 1, 128) : C32Plan();
     const bool pairs = p.ok;
     if (!pairs && out_aligned)
         p = plan_c32(ctx, ms, sa, true, 1, 1, 128);
@@ -1082,7 +1086,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
         }
         const int m = (int)jobs[g.idx[0]].pssm->m;
         if (g.kind == KIND_PREFILTER2 && ctx->multi_motif && n > 1 && g.idx.size() >= 2 &&
-            score_c32_prefilter2_multi_lookup(m)) {
+            jobs[g.idx[0]].pssm->k == 5 && score_c32_prefilter2_multi_lookup(m)) {
             per_pass[gi] = prefilter2_multi(m);
             while ((bparams.size() - group_pos[gi]) % per_pass[gi]) {
                 BatchParams pad = bparams.back();
@@ -1152,7 +1156,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
                 any_candidates = true;
             } else if (g.kind == KIND_PREFILTER || g.kind == KIND_PREFILTER2) {
                 const bool pairs = g.kind == KIND_PREFILTER2;
-                PrefilterLauncher fn = pairs ? score_c32_prefilter2_lookup((int)a.pssm->m)
+                PrefilterLauncher fn = pairs ? score_c32_prefilter2_lookup((int)a.pssm->m, (int)a.pssm->k)
                                              : score_c32_prefilter_lookup((int)a.pssm->m);
                 ctx->last_kernel = pairs ? "score_c32_prefilter2" : "score_c32_prefilter";
                 LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, pairs ? a.pssm->d_image2 : a.pssm->d_image,
@@ -1532,7 +1536,7 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
         }
         const int m = (int)qjobs[g.idx[0]].pssm->m;
         if (g.kind == KIND_PREFILTER2 && ctx->multi_motif && g.idx.size() >= 2 &&
-            score_c32_prefilter2_multi_lookup(m)) {
+            qjobs[g.idx[0]].pssm->k == 5 && score_c32_prefilter2_multi_lookup(m)) {
             per_pass[gi] = prefilter2_multi(m);
             while ((order.size() - group_pos[gi]) % per_pass[gi]) {
                 order.push_back(g.idx.back());
@@ -1627,7 +1631,7 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
             continue;
         }
         const bool pairs = g.kind == KIND_PREFILTER2;
-        PrefilterLauncher fn = pairs ? score_c32_prefilter2_lookup((int)a.pssm->m)
+        PrefilterLauncher fn = pairs ? score_c32_prefilter2_lookup((int)a.pssm->m, (int)a.pssm->k)
                                      : score_c32_prefilter_lookup((int)a.pssm->m);
         ctx->last_kernel = pairs ? "score_c32_prefilter2" : "score_c32_prefilter";
         LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, ls, a.d_seq, pairs ? a.pssm->d_image2 : a.pssm->d_image,

@@ -20,6 +20,7 @@ struct RegisterRange {
         r.u8[M] = &score_c32_u8_launch<M>;  // DiscreteMatrix scores (score_u8.hpp)
         if constexpr (M >= 2) {
             r.pre2[M] = &score_c32_prefilter2_launch<M>;
+            r.pre2_protein[M] = &score_c32_prefilter2_launch<M, 21>;
             r.u8_pairs[M] = &score_c32_u8_pairs_launch<M>;
             if constexpr (prefilter2_multi(M) > 1)
                 r.pre2_multi[M] = &score_c32_prefilter2_multi_launch<M>;

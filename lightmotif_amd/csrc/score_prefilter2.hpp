@@ -45,8 +45,11 @@ constexpr int prefilter2_ring(int m) { return prefilter2_mo(m) + 1; }   // input
 constexpr int prefilter2_npair(int m) { return prefilter2_ring(m) / 2; }
 // dwords per table row: 4 * odd >= NPAIR (rows 0..15 then sit in distinct 16-byte slots)
 constexpr int prefilter2_stride_dw(int m) { return 4 * (((prefilter2_npair(m) + 3) / 4) | 1); }
-constexpr int kPairRows = 25;  // DNA symbol pairs
-constexpr int prefilter2_image_dw(int m) { return kPairRows * prefilter2_stride_dw(m); }
+// table rows = symbol pairs: 25 for DNA (K = 5), 441 for protein (K = 21).  Protein rows cannot be
+// conflict-free (441 rows, 16 slots): tools/kbench/lds_rows_bench measures 5.5 ns per wavefront read
+// against 3.5 ns for the 21 rows of the one-symbol prefilter -- but the pair scan needs half the reads.
+constexpr int prefilter2_rows(int ka) { return ka * ka; }
+constexpr int prefilter2_image_dw(int m, int ka = 5) { return prefilter2_rows(ka) * prefilter2_stride_dw(m); }
 
 // table row of the pair (a, b): the 16 pairs of A, C, T, G first
 __host__ __device__ __forceinline__ unsigned dna_pair_row(unsigned a, unsigned b)
@@ -56,20 +59,25 @@ __host__ __device__ __forceinline__ unsigned dna_pair_row(unsigned a, unsigned b
         idx = 21u + a;          // (a, N), a < 4: 21..24
     return idx;
 }
+template <int KA>
+__host__ __device__ __forceinline__ unsigned pair_row(unsigned a, unsigned b)
+{
+    return KA == 5 ? dna_pair_row(a, b) : a * (unsigned)KA + b;
+}
 
-// Host side: the pair table from the unpadded discrete weights d[j * 5 + s], j < m.
-inline void prefilter2_pack_image(const unsigned *d, int m, unsigned *image2)
+// Host side: the pair table from the unpadded discrete weights d[j * ka + s], j < m.
+inline void prefilter2_pack_image(const unsigned *d, int m, unsigned *image2, int ka = 5)
 {
     const int mo = prefilter2_mo(m), shift2 = mo - m, np2 = prefilter2_npair(m);
     const int dsd2 = prefilter2_stride_dw(m);
     auto dq = [&](int j, int s) -> unsigned {  // padded weight, 0 outside shift2 .. mo-1
-        return (j < shift2 || j >= mo) ? 0u : d[(size_t)(j - shift2) * 5 + s];
+        return (j < shift2 || j >= mo) ? 0u : d[(size_t)(j - shift2) * ka + s];
     };
-    for (int i = 0; i < prefilter2_image_dw(m); ++i)
+    for (int i = 0; i < prefilter2_image_dw(m, ka); ++i)
         image2[i] = 0u;
-    for (int a = 0; a < 5; ++a)
-        for (int b = 0; b < 5; ++b) {
-            unsigned *row = image2 + (size_t)dna_pair_row((unsigned)a, (unsigned)b) * dsd2;
+    for (int a = 0; a < ka; ++a)
+        for (int b = 0; b < ka; ++b) {
+            unsigned *row = image2 + (size_t)(ka == 5 ? dna_pair_row((unsigned)a, (unsigned)b) : (unsigned)(a * ka + b)) * dsd2;
             auto entry = [&](int e) -> unsigned { return e > mo ? 0u : dq(e - 1, a) + dq(e, b); };
             for (int w = 0; w < np2; ++w)
                 row[w] = entry(2 * w + 1) | (entry(2 * w) << 16);
@@ -90,7 +98,7 @@ inline void prefilter2_pack_image(const unsigned *d, int m, unsigned *image2)
 // the quad of lanes and written with one dword store per lane (128 contiguous bytes per
 // half-wave instruction).  `op` = the lane's cell of the group's first completed row; the
 // FIRST group completes rows 0 and 1 only (byte stores).  `wrap_mask` as in prefilter_group.
-template <int M, int PFB, int PHASE, int STORE = 0>
+template <int M, int PFB, int PHASE, int STORE = 0, int KA = 5>
 __device__ __forceinline__ void prefilter2_group(unsigned (&acc)[prefilter2_npair(M)],
                                                  unsigned (&blk)[prefilter2_ring(M) / 4],
                                                  const uint8_t *__restrict__ spq, const unsigned shq,
@@ -117,7 +125,7 @@ __device__ __forceinline__ void prefilter2_group(unsigned (&acc)[prefilter2_npai
         // a block is free once its second pair is taken: request the block PFB ahead
         if ((k & 1) && (PHASE != PHASE_LAST || k / 2 + PFB < NB))
             blk[(k / 2 + PFB) % NB] = *reinterpret_cast<const unsigned *>(spq + (k / 2 + PFB) * 128);
-        const unsigned idx = dna_pair_row(a, b);
+        const unsigned idx = pair_row<KA>(a, b);
         const char *row = static_cast<const char *>(__builtin_assume_aligned(tab + __umul24(idx, DSB), 16));
         unsigned w[NV * 4];
 #pragma unroll
@@ -166,8 +174,8 @@ __device__ __forceinline__ void prefilter2_group(unsigned (&acc)[prefilter2_npai
     }
 }
 
-template <int M>
-__global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter2(
+template <int M, int KA = 5>
+__global__ __launch_bounds__(kBlock, KA == 5 ? 6 : 4) void score_c32_prefilter2(
     const uint8_t *__restrict__ seq, const unsigned *__restrict__ image, const int K,
     const unsigned long long row_begin, const unsigned long long row_end,
     const unsigned long long T, const unsigned long long nstreams, unsigned td,
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter2(
     {
         uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
         const uint4 *src = reinterpret_cast<const uint4 *>(image);
-        constexpr int n4 = prefilter2_image_dw(M) / 4;
+        constexpr int n4 = prefilter2_image_dw(M, KA) / 4;
         for (int i = threadIdx.x; i < n4; i += kBlock)
             dst[i] = src[i];
     }
@@ -247,16 +255,16 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter2(
         }
     };
 
-    prefilter2_group<M, PFB, PHASE_FIRST>(acc, blk, spq, shq, lds_raw, mx);
+    prefilter2_group<M, PFB, PHASE_FIRST, 0, KA>(acc, blk, spq, shq, lds_raw, mx);
     note_group();
     for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
         spq += RING * 32;
-        prefilter2_group<M, PFB, PHASE_MAIN>(acc, blk, spq, shq, lds_raw, mx);
+        prefilter2_group<M, PFB, PHASE_MAIN, 0, KA>(acc, blk, spq, shq, lds_raw, mx);
         note_group();
     }
     if (ngroups > 1) {
         spq += RING * 32;
-        prefilter2_group<M, PFB, PHASE_LAST>(acc, blk, spq, shq, lds_raw, mx);
+        prefilter2_group<M, PFB, PHASE_LAST, 0, KA>(acc, blk, spq, shq, lds_raw, mx);
         note_group();
     }
 
@@ -476,18 +484,18 @@ hipError_t score_c32_prefilter2_multi_launch(dim3 grid, hipStream_t stream, cons
     return hipGetLastError();
 }
 
-template <int M>
+template <int M, int KA = 5>
 hipError_t score_c32_prefilter2_launch(dim3 grid, size_t lds_bytes, hipStream_t stream,
                                        const uint8_t *seq, const unsigned *image, int K,
                                        unsigned long long row_begin, unsigned long long row_end,
                                        unsigned long long T, unsigned long long nstreams,
                                        unsigned td, FusedOut fo)
 {
-    hipLaunchKernelGGL((score_c32_prefilter2<M>), grid, dim3(kBlock), lds_bytes, stream, seq, image,
+    hipLaunchKernelGGL((score_c32_prefilter2<M, KA>), grid, dim3(kBlock), lds_bytes, stream, seq, image,
                        K, row_begin, row_end, T, nstreams, td, fo);
     return hipGetLastError();
 }
 
-PrefilterLauncher score_c32_prefilter2_lookup(int M);
+PrefilterLauncher score_c32_prefilter2_lookup(int M, int K = 5);
 
 }  // namespace lm

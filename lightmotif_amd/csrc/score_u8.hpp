@@ -190,6 +190,7 @@ hipError_t score_c32_u8_pairs_launch(dim3 grid, size_t lds_bytes, hipStream_t st
 struct KernelRegistry {
     ScoreC32Launcher (*c32)[kRegistrySlots];
     PrefilterLauncher *pre, *pre2;
+    PrefilterLauncher *pre2_protein;  // the pair scan over the 441 residue pairs (K = 21)
     ScoreU8Launcher *u8, *u8_pairs;
     PrefilterMultiLauncher *pre2_multi;  // several motifs per pass (prefilter2_multi(M) > 1)
 };

@@ -376,6 +376,24 @@ def test_protein(pli, m):
     check_against_oracle(pli, enc, random_pssm(rng, m, 21), 32, 21, thresholds=[4.0])
 
 
+@pytest.mark.parametrize("m", [5, 12, 20, 31])
+def test_protein_pair_prefilter_opt_in(monkeypatch, m):
+    """The 441-row pair scan (score_c32_prefilter2<M, 21>) is off by default (measured 4 % slower)
+    but stays bit-exact: a pipeline created with LM_HIP_PAIR_PREFILTER_PROTEIN=1 must use it and agree."""
+    monkeypatch.setenv("LM_HIP_PAIR_PREFILTER_PROTEIN", "1")
+    pair = lm.Pipeline.hip(0)
+    rng = np.random.default_rng(100 + m)
+    enc = rng.integers(0, 21, 40_009, dtype=np.uint8)
+    p = random_pssm(rng, m, 21)
+    _, want = check_against_oracle(pair, enc, p, 32, 21, thresholds=[4.0])
+    seq = pair.stripe(lm.EncodedSequence(enc, protein=True), 32)
+    seq.configure_wrap(m - 1)
+    t = float(np.sort(want[:, :32][np.isfinite(want[:, :32])])[-20])
+    frc, _ = pair.score_threshold(lm.ScoringMatrix(p, protein=True), seq, t)
+    assert pair.last_kernel == "score_c32_prefilter2"
+    assert frc == [tuple(map(int, rc)) for rc in co.threshold(want, 32, t)]
+
+
 def test_million_positions_bitwise(pli):
     rng = np.random.default_rng(99)
     enc = rng.integers(0, 4, 1_000_003, dtype=np.uint8)

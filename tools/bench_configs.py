@@ -149,7 +149,7 @@ def config5(pli):
     sample = out[: 1 << 18].flatten()
     thr = float(torch.quantile(sample[torch.isfinite(sample)].float(), 1 - 1e-5))
     th = {}
-    for on in (True, False):   # one-symbol u16 prefilter (21 table rows) vs the exact f32 kernel
+    for on in (True, False):   # u16 prefilter (pair scan over 441 rows, or LM_HIP_PAIR_PREFILTER=0: 21 rows) vs exact f32
         pli.set_prefilter(on)
         call = lambda: pli.score_threshold_dptr(pssm, seq.data_ptr(), rows + m - 1, COLS, COLS, m - 1, length, 0, rows, thr)  # noqa: E731
         call()
