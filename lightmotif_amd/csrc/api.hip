@@ -343,6 +343,11 @@ static int ctx_create(int device, void *stream, bool borrow, lm_hip_ctx **out)
         ctx->pair_prefilter = atoi(e) != 0;
     if (const char *e = getenv("LM_HIP_PAIR_PREFILTER_PROTEIN"))  // A/B switch: 1 = 441-row pair scan for K = 21
         ctx->pair_prefilter_protein = atoi(e) != 0;
+    if (const char *e = getenv("LM_HIP_CHUNKED_FUSED"))  // A/B switch: 0 = fused scans of M > 36 go cell by cell
+        ctx->chunked_fused = atoi(e) != 0;
+    if (const char *e = getenv("LM_HIP_CHUNK_ROWS"))  // rows per chunk of those scans
+        if (atoll(e) >= 64)
+            ctx->chunk_rows = (size_t)atoll(e);
     if (borrow) {
         ctx->stream = static_cast<hipStream_t>(stream);
         ctx->owns_stream = false;
@@ -380,6 +385,7 @@ int lm_hip_ctx_destroy(lm_hip_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     ctx->scratch.release();
     ctx->scratch2.release();
+    ctx->chunk_scores.release();
     ctx->u8_tables.release();
     if (ctx->pinned)
         (void)hipHostFree(ctx->pinned);

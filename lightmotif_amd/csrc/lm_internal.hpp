@@ -89,6 +89,9 @@ struct lm_hip_ctx {
     std::mutex mu;
     lm::Scratch scratch;        // block partials, chunk counts, hit lists
     lm::Scratch scratch2;
+    lm::Scratch chunk_scores;   // fused reductions of sliced (M > 36) motifs: one chunk of f32 scores (score.hip)
+    size_t chunk_rows = 1u << 22; // rows of that chunk (512 MB at C = 32; LM_HIP_CHUNK_ROWS)
+    bool chunked_fused = true;  // A/B knob: 0 = such motifs go cell by cell (LM_HIP_CHUNKED_FUSED)
     void *pinned = nullptr;     // kPinnedBytes of host-pinned memory for read-backs
     size_t rows_per_stream = 0; // 0 = default
     bool use_prefilter = true;  // fused threshold: packed 16-bit discrete prefilter (A/B knob)
@@ -248,6 +251,10 @@ int launch_scan_u32(lm_hip_ctx *ctx, const unsigned *counts, unsigned long long 
 
 int launch_argmax(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride,
                   size_t cols, int first_cell_rule, ArgmaxRecord *out);
+// Block records of one contiguous (stride == cols, 16-byte aligned) piece of a larger matrix: `grid`
+// records at `d_blocks`, indices offset by `index_base`.  No synchronisation.
+int launch_argmax_blocks_flat(lm_hip_ctx *ctx, hipStream_t stream, const float *d_scores, unsigned long long ncells,
+                              long long index_base, unsigned grid, ArgmaxRecord *d_blocks);
 int launch_argmax_device(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride,
                          size_t cols, int first_cell_rule, ArgmaxRecord *d_out);
 int launch_threshold(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride,

@@ -27,6 +27,7 @@ int finalize_argmax_materialised(lm_hip_ctx *ctx, const ArgmaxRecord *d_blocks, 
 // floats whose index IS the row-major rank.  16-byte loads, grid-stride.
 __global__ __launch_bounds__(kBlock) void argmax_flat(const float *__restrict__ s,
                                                       const unsigned long long ncells,
+                                                      const long long index_base,
                                                       ArgmaxRecord *__restrict__ blocks)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -60,9 +61,18 @@ __global__ __launch_bounds__(kBlock) void argmax_flat(const float *__restrict__ 
     best_block_reduce(v, bi, sm_v, sm_i);
     if (threadIdx.x == 0) {
         blocks[blockIdx.x].value = v;
-        blocks[blockIdx.x].index = bi;
+        blocks[blockIdx.x].index = bi >= 0 ? bi + index_base : bi;
         blocks[blockIdx.x].found = bi >= 0;
     }
+}
+
+int launch_argmax_blocks_flat(lm_hip_ctx *ctx, hipStream_t stream, const float *d_scores, unsigned long long ncells,
+                              long long index_base, unsigned grid, ArgmaxRecord *d_blocks)
+{
+    (void)ctx;
+    hipLaunchKernelGGL(argmax_flat, dim3(grid), dim3(kBlock), 64, stream, d_scores, ncells, index_base, d_blocks);
+    LM_HIP_TRY(hipGetLastError());
+    return LM_HIP_OK;
 }
 
 // Padded rows (stride > cols): index = row * cols + col.
@@ -109,7 +119,7 @@ int launch_argmax_device(lm_hip_ctx *ctx, const float *d_scores, size_t rows, si
     const bool flat = stride == cols && (reinterpret_cast<uintptr_t>(d_scores) % 16 == 0);
     if (flat)
         hipLaunchKernelGGL(argmax_flat, dim3(grid), dim3(kBlock), 64, ctx->stream, d_scores, ncells,
-                           recs + 1);
+                           0ll, recs + 1);
     else
         hipLaunchKernelGGL(argmax_strided, dim3(grid), dim3(kBlock), 64, ctx->stream, d_scores,
                            (unsigned long long)rows, (unsigned long long)stride, (unsigned)cols,

@@ -692,7 +692,8 @@ __global__ __launch_bounds__(kBlock) void argmax_finalize_batch(const FinalizeJo
 // alphabet and sequence rows.  Many short per-motif launches lose ~15 % to their ramps
 // and to the short streams a small grid needs; a launch per motif LENGTH keeps streams
 // long and the chip full (2 346 JASPAR motifs -> ~50 launches).
-enum : int { KIND_GENERIC = 0, KIND_EXACT = 1, KIND_PREFILTER = 2, KIND_PREFILTER2 = 3 };
+enum : int { KIND_GENERIC = 0, KIND_EXACT = 1, KIND_PREFILTER = 2, KIND_PREFILTER2 = 3, KIND_CHUNKED = 4 };
+static inline bool kind_solo(int kind) { return kind == KIND_GENERIC || kind == KIND_CHUNKED; }
 struct JobGroup {
     int kind = KIND_GENERIC;
     std::vector<size_t> idx;  // job indices, ascending
@@ -709,7 +710,7 @@ static std::vector<JobGroup> group_jobs(const lm_hip_ctx *ctx, const ScoreArgs *
     for (size_t i = 0; i < n; ++i) {
         const ScoreArgs &a = jobs[i];
         const int kind = kind_of(i);
-        if (kind == KIND_GENERIC) {  // one launch each
+        if (kind_solo(kind)) {  // one launch (or chain of launches) each
             groups.push_back(JobGroup{kind, {i}, C32Plan{}});
             continue;
         }
@@ -723,12 +724,84 @@ static std::vector<JobGroup> group_jobs(const lm_hip_ctx *ctx, const ScoreArgs *
         }
     }
     for (JobGroup &g : groups)
-        if (g.kind != KIND_GENERIC) {
+        if (!kind_solo(g.kind)) {
             g.plan = plan_c32(ctx, jobs[g.idx[0]], false,
                               g.kind == KIND_PREFILTER2 ? 2 : (g.kind == KIND_PREFILTER ? 1 : 0), g.idx.size());
             g.plan.grid.y = (unsigned)g.idx.size();
         }
     return groups;
+}
+
+// ---- fused reductions of sliced motifs (M > kMaxFastM at C = 32) -----------------------------------
+//
+// No fused kernel holds more than kMaxFastM accumulators, and one thread per cell costs 23-50 ms per
+// Gbp.  Such a job is scored in CHUNKS of ctx->chunk_rows rows through the sliced store path
+// (launch_score_store: first slice stored, further slices continued in place) into one reusable
+// buffer, and each chunk is reduced right behind its last slice: block maxima with
+// global indices (argmax) or direct appends to the hit list (threshold).  Same values as the
+// materialised matrix, hence the same results; the buffer never exceeds 512 MB however long the
+// sequence.
+static bool chunked_ok(const lm_hip_ctx *ctx, const ScoreArgs &a)
+{
+    return ctx->chunked_fused && !a.pssm->parts.empty() && a.cols == 32 && a.seq_stride == 32 &&
+           reinterpret_cast<uintptr_t>(a.d_seq) % 4 == 0 && a.row_end - a.row_begin > (size_t)kMaxFastM;
+}
+
+static unsigned long long chunk_count(const lm_hip_ctx *ctx, const ScoreArgs &a)
+{
+    const unsigned long long n = a.row_end - a.row_begin;
+    return (n + ctx->chunk_rows - 1) / ctx->chunk_rows;
+}
+
+// Workgroups of the per-chunk argmax (a full chunk is 2^25 cells)
+static unsigned chunk_argmax_grid(const lm_hip_ctx *ctx)
+{
+    return (unsigned)ctx->num_cus * 8;
+}
+
+// f(buffer, first row of the chunk relative to a.row_begin, rows of the chunk) after each chunk's scores
+// are enqueued on ctx->stream
+template <typename PerChunk>
+static int for_each_scored_chunk(lm_hip_ctx *ctx, const ScoreArgs &a, PerChunk f)
+{
+    const unsigned long long n = a.row_end - a.row_begin;
+    const unsigned long long chunk = std::min<unsigned long long>(n, ctx->chunk_rows);
+    LM_TRY(ctx->chunk_scores.reserve(chunk * 32 * sizeof(float)));
+    float *buf = static_cast<float *>(ctx->chunk_scores.ptr);
+    for (unsigned long long c0 = 0; c0 < n; c0 += chunk) {
+        const unsigned long long c1 = std::min(n, c0 + chunk);
+        ScoreArgs b = a;
+        b.row_begin = a.row_begin + c0;
+        b.row_end = a.row_begin + c1;
+        b.d_out = buf;
+        b.out_stride = 32;
+        LM_TRY(launch_score_store(ctx, b));
+        LM_TRY(f(buf, c0, c1 - c0));
+    }
+    ctx->last_kernel = "score_c32_sliced+reduce";
+    return LM_HIP_OK;
+}
+
+// Appends every cell >= t of a contiguous C = 32 chunk to the hit list (rows relative to the job).
+__global__ __launch_bounds__(kBlock) void chunk_emit_hits(const float *__restrict__ s, const unsigned long long ncells,
+                                                          const unsigned long long row_base, const FusedOut fo)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 *s4 = reinterpret_cast<const f32x4 *>(s);
+    const unsigned long long n4 = ncells / 4;
+    const float t = fo.threshold;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < n4;
+         i += (unsigned long long)gridDim.x * kBlock) {
+        const f32x4 x = __builtin_nontemporal_load(&s4[i]);
+        if (!(x.x >= t || x.y >= t || x.z >= t || x.w >= t))
+            continue;
+        const unsigned long long row = row_base + i / 8;
+        const unsigned col = (unsigned)(i % 8) * 4;
+        if (x.x >= t) record_hit(fo, row, col, 32u, x.x);
+        if (x.y >= t) record_hit(fo, row, col + 1, 32u, x.y);
+        if (x.z >= t) record_hit(fo, row, col + 2, 32u, x.z);
+        if (x.w >= t) record_hit(fo, row, col + 3, 32u, x.w);
+    }
 }
 
 // Fused score+argmax of `n` independent jobs (one motif each): the n scoring kernels
@@ -740,7 +813,7 @@ static int launch_score_argmax_exact(lm_hip_ctx *ctx, const ScoreArgs *jobs, siz
     if (n == 0)
         return LM_HIP_OK;
     const std::vector<JobGroup> groups = group_jobs(ctx, jobs, n, [&](size_t i) {
-        return plan_c32(ctx, jobs[i], false).ok ? KIND_EXACT : KIND_GENERIC;
+        return plan_c32(ctx, jobs[i], false).ok ? KIND_EXACT : chunked_ok(ctx, jobs[i]) ? KIND_CHUNKED : KIND_GENERIC;
     });
     std::vector<unsigned> grids(n);
     size_t total_blocks = 0;
@@ -748,7 +821,9 @@ static int launch_score_argmax_exact(lm_hip_ctx *ctx, const ScoreArgs *jobs, siz
         for (size_t i : g.idx) {
             const unsigned long long ncells =
                 (unsigned long long)(jobs[i].row_end - jobs[i].row_begin) * jobs[i].cols;
-            grids[i] = g.kind == KIND_GENERIC ? generic_grid(ctx, ncells).x : g.plan.grid.x;
+            grids[i] = g.kind == KIND_GENERIC   ? generic_grid(ctx, ncells).x
+                       : g.kind == KIND_CHUNKED ? (unsigned)(chunk_count(ctx, jobs[i]) * chunk_argmax_grid(ctx))
+                                                : g.plan.grid.x;
             total_blocks += grids[i];
         }
     const size_t off_blocks = sizeof(ArgmaxRecord) * n;
@@ -813,6 +888,15 @@ static int launch_score_argmax_exact(lm_hip_ctx *ctx, const ScoreArgs *jobs, siz
             ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_ARGMAX);
             LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
                           a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, nullptr, fo));
+        } else if (g.kind == KIND_CHUNKED) {
+            // (always on ctx->stream: the chunk buffer is shared)
+            const unsigned cg = chunk_argmax_grid(ctx);
+            ArgmaxRecord *recs = fo.block_best;
+            const unsigned long long per = ctx->chunk_rows;
+            LM_TRY(for_each_scored_chunk(ctx, a, [&](const float *buf, unsigned long long c0, unsigned long long rows) {
+                return launch_argmax_blocks_flat(ctx, ctx->stream, buf, rows * 32, (long long)(c0 * 32), cg,
+                                                 recs + (c0 / per) * cg);
+            }));
         } else {
             ctx->last_kernel = "score_generic<1>";
             LM_TRY(launch_generic<MODE_ARGMAX>(ctx, a, fo, dim3(grids[g.idx[0]]), st));
@@ -1059,7 +1143,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
                     return (int)KIND_PREFILTER;
             }
         }
-        return plan_c32(ctx, a, false).ok ? (int)KIND_EXACT : (int)KIND_GENERIC;
+        return plan_c32(ctx, a, false).ok ? (int)KIND_EXACT : chunked_ok(ctx, a) ? (int)KIND_CHUNKED : (int)KIND_GENERIC;
     });
     const unsigned long long key_rows =
         keys == HitKeys::Position ? (unsigned long long)(jobs[0].row_end - jobs[0].row_begin) : 0;
@@ -1146,7 +1230,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
             hipStream_t st = (two_streams && (launch++ & 1)) ? ctx->aux_stream : ctx->stream;
             fo.threshold = ts[i];
             fo.job_key = (unsigned long long)i << 40;
-            fo.batch = (n > 1 && g.kind != KIND_GENERIC) ? d_bparams + bp_pos : nullptr;
+            fo.batch = (n > 1 && !kind_solo(g.kind)) ? d_bparams + bp_pos : nullptr;
             if (per_pass[gi] > 1) {  // several motifs of this length per pass over the sequence
                 dim3 grid = g.plan.grid;
                 grid.y = (unsigned)((g.idx.size() + per_pass[gi] - 1) / per_pass[gi]);
@@ -1168,6 +1252,16 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
                 LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
                               a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, nullptr, fo));
                 any_candidates = true;
+            } else if (g.kind == KIND_CHUNKED) {  // appends hits directly, chunk by chunk, on ctx->stream
+                const FusedOut cfo = fo;
+                LM_TRY(for_each_scored_chunk(ctx, a, [&](const float *buf, unsigned long long c0, unsigned long long rows) {
+                    const unsigned long long ncells = rows * 32;
+                    const unsigned grid = (unsigned)std::max<unsigned long long>(
+                        std::min<unsigned long long>((ncells / 4 + kBlock - 1) / kBlock, (unsigned long long)ctx->num_cus * 16), 1);
+                    hipLaunchKernelGGL(chunk_emit_hits, dim3(grid), dim3(kBlock), 0, ctx->stream, buf, ncells, c0, cfo);
+                    LM_HIP_TRY(hipGetLastError());
+                    return (int)LM_HIP_OK;
+                }));
             } else {
                 ctx->last_kernel = "score_generic<2>";  // appends hits directly
                 const unsigned long long ncells =

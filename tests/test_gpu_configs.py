@@ -410,6 +410,51 @@ def test_long_motifs_are_scored_in_slices(pli, m):
     assert np.array_equal(bits(scores.matrix()[:, :COLS]), bits(want[:, :COLS]))
 
 
+@pytest.mark.parametrize("m,chunk_rows", [(37, 5000), (40, 4096), (64, 1 << 20), (73, 7777), (100, 20_000), (150, 64)])
+def test_long_motifs_fused_reductions_go_chunk_by_chunk(monkeypatch, m, chunk_rows):
+    """score_argmax / score_threshold / Scanner-style hits of M > 36: the sliced store path into a
+    reusable chunk buffer + a reduction per chunk (score.hip, KIND_CHUNKED) instead of one thread per
+    cell.  Same cells, same values: bit-exact against the oracle's materialised matrix, row-major hit
+    order, last-maximal-cell ties across chunk borders, first-cell NaN rule, row sub-ranges."""
+    monkeypatch.setenv("LM_HIP_CHUNK_ROWS", str(chunk_rows))
+    pli = lm.Pipeline.hip(0)
+    rng = np.random.default_rng(7000 + m)
+    length = 1_500_000 + 13 * m
+    enc = rng.integers(0, 5, length, dtype=np.uint8)
+    enc[rng.random(length) < 0.98] %= 4
+    p = np.zeros((m, 8), np.float32)
+    if m in (40, 150):      # few distinct values -> many tied maxima, in several chunks
+        p[:, :4] = rng.integers(0, 2, (m, 4))
+    else:
+        p[:, :4] = rng.normal(0, 2, (m, 4))
+    p[:, 4] = -np.inf if m != 73 else -3.0
+    ref = co.stripe(enc, COLS, 5)
+    co.configure_wrap(ref, m - 1)
+    seq = pli.stripe(lm.EncodedSequence(enc), COLS)
+    seq.configure_wrap(m - 1)
+    pssm = lm.ScoringMatrix(p)
+    for a, b in ((0, ref.rows), (123, ref.rows - 77)):
+        want, _ = co.score_rows(ref, p, a, b)
+        got = pli.score_argmax(pssm, seq, range(a, b))
+        assert pli.last_kernel == "score_c32_sliced+reduce", pli.last_kernel
+        assert got[0] == co.argmax(want, COLS)
+        assert bits(np.float32(got[1])) == bits(co.max_(want, COLS))
+        finite = np.sort(want[:, :COLS][np.isfinite(want[:, :COLS])])
+        for t in (float(finite[-50]), float(finite[-5000])):
+            wrc = [tuple(map(int, rc)) for rc in co.threshold(want, COLS, t)]
+            frc, fval = pli.score_threshold(pssm, seq, t, range(a, b))
+            assert pli.last_kernel == "score_c32_sliced+reduce", pli.last_kernel
+            assert frc == wrc
+            assert np.array_equal(bits(fval), bits([want[r, c] for r, c in wrc]))
+    # first-cell NaN rule (pli/mod.rs:142-146) through the chunked path
+    q = p.copy()
+    q[0, int(enc[0])] = np.nan
+    want, _ = co.score_rows(ref, q)
+    assert np.isnan(want[0, 0])
+    got = pli.score_argmax(lm.ScoringMatrix(q), seq)
+    assert got[0] == co.argmax(want, COLS) == (0, 0) and np.isnan(got[1])
+
+
 @pytest.mark.parametrize("cols,m,k", [(16, 20, 5), (16, 33, 5), (1, 15, 5), (2, 7, 5), (33, 12, 5), (16, 70, 5),
                                       (4, 100, 5), (16, 12, 21), (8, 40, 21)])
 def test_other_geometries_take_the_tiled_kernel(pli, cols, m, k):
