@@ -186,6 +186,9 @@ __device__ __forceinline__ void record_hit(const FusedOut &fo, unsigned long lon
 //   PF  global prefetch distance in steps: the symbol byte of step k+PF is
 //       requested while step k is processed (0 = load at use);
 //   LP  1 = the LDS reads of step k+1 are issued before the adds of step k.
+#ifndef LM_SCORE_STORE_BATCH
+#define LM_SCORE_STORE_BATCH 1
+#endif
 #ifndef LM_SCORE_PF
 #define LM_SCORE_PF 12
 #endif
@@ -292,6 +295,11 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
     constexpr int NW = 4 * ((M + 3) / 4);
     constexpr int NB = M / 4;                  // QL: 4-row symbol blocks per group (M % 4 == 0)
     constexpr int PFB = NB > 3 ? 3 : NB;       // QL: blocks requested ahead of use
+    // experiment (LM_SCORE_STORE_BATCH = 2 / 4): completed rows wait in registers and leave as SB
+    // back-to-back row stores, i.e. SB * 128 contiguous bytes per half-wave within a few cycles
+    constexpr int SB = (mode_stores(MODE) && MODE != MODE_CONTINUE && PHASE != PHASE_FIRST &&
+                        M % LM_SCORE_STORE_BATCH == 0) ? LM_SCORE_STORE_BATCH : 1;
+    float pend[SB];
 #pragma unroll
     for (int k = 0; k < M; ++k) {
         // (1) request the symbol byte PF steps ahead (stays inside the stream's
@@ -358,7 +366,18 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
         // (4) the slot started at step k-(M-1) is complete.
         if (PHASE != PHASE_FIRST || k == M - 1) {
             const float score = acc[(k + 1) % M];
-            if (mode_stores(MODE)) {
+            if (mode_stores(MODE) && SB > 1) {
+                pend[k % SB] = score;
+                if (k % SB == SB - 1) {
+#pragma unroll
+                    for (int i = 0; i < SB; ++i) {
+                        if (LM_SCORE_NT_STORE)
+                            __builtin_nontemporal_store(pend[i], op + (k - SB + 1 + i) * 32);
+                        else
+                            op[(k - SB + 1 + i) * 32] = pend[i];
+                    }
+                }
+            } else if (mode_stores(MODE)) {
                 if (LM_SCORE_NT_STORE)
                     __builtin_nontemporal_store(score, op + k * 32);
                 else
