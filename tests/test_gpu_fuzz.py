@@ -25,6 +25,8 @@ def test_random_configuration(pli, seed):
     protein = seed % 7 == 3
     k = 21 if protein else 5
     m = int(rng.integers(1, 41))
+    if seed % 11 == 5:                      # sliced motifs: store, continuation and chunked reductions
+        m = int(rng.integers(37, 130))
     length = int(rng.choice([m, m + 1, 33, 1000, 4097, 20_000, 131_072, 250_001]))
     length = max(length, 1)
     cols = 32 if seed % 5 else int(rng.choice([1, 3, 16, 33]))
