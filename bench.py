@@ -330,6 +330,9 @@ def main() -> None:
     ap.add_argument("--dist-backend", default="nccl",
                     help="development: 'gloo' + --single-device exercises the N>1 control flow on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="development: every rank uses cuda:0")
+    ap.add_argument("--sync-merge", action="store_true",
+                    help="N > 1 through the C ABI: wait for every step's merge before the next score_into "
+                         "(default: pipelined, lm_hip_argmax_sharded_begin / _end)")
     ap.add_argument("--merge", default="auto", choices=["auto", "cabi", "torch"],
                     help="transport of the per-step argmax merge at N > 1: the C ABI's own RCCL communicator "
                          "(lm_hip_comm_*, default on nccl) or torch.distributed (gloo runs)")
@@ -400,18 +403,39 @@ def main() -> None:
     scores_h.set_first_cell_rule(rank == 0)
     pli.set_track_argmax(sharded)              # N = 1 times the plain store kernel (configs[1])
 
-    def step():
-        """N = 1: one score_into (pli/mod.rs:109-117) into the resident StripedScores.
+    pipelined = comm is not None and not args.sync_merge
+
+    def run_steps(n, events=None):
+        """N = 1: one score_into (pli/mod.rs:109-117) into the resident StripedScores per step.
         N > 1 (configs[3]): the same on this rank's row shard, plus the argmax of the shard
         (tracked by the store kernel, first-cell rule on rank 0 only) and its merge over RCCL --
-        SURVEY 8(d): "wall time of the slowest rank incl. the RCCL merge"."""
-        pli.score_into(pssm, seq, scores_h)
-        if not sharded:
-            return None
-        if comm is not None:
-            return comm.argmax_sharded(scores_h, row0)   # device-side all_gather + combine, one 16-B read-back
-        loc = pli.argmax_handle_shard(scores_h, first_cell_rule=rank == 0)
-        return D.merge_argmax(loc, row0, device=coll_dev)
+        SURVEY 8(d): "wall time of the slowest rank incl. the RCCL merge".  Through the C ABI's
+        communicator the merge is pipelined: lm_hip_argmax_sharded_begin enqueues record +
+        all_gather + read-back (the last two on the communicator's own stream) and the host
+        collects step i's result after enqueueing step i + 1, so the all_gather and the host's
+        wait overlap the next store kernel; every step's result is collected before this returns."""
+        merged, pending = None, None
+        for i in range(n):
+            if events is not None:
+                events[i][0].record(stream)
+            pli.score_into(pssm, seq, scores_h)
+            if events is not None:
+                events[i][1].record(stream)
+            if not sharded:
+                continue
+            if pipelined:
+                ticket = comm.argmax_sharded_begin(scores_h, row0)
+                if pending is not None:
+                    merged = comm.argmax_sharded_end(pending)
+                pending = ticket
+            elif comm is not None:
+                merged = comm.argmax_sharded(scores_h, row0)   # device-side all_gather + combine, one read-back
+            else:
+                loc = pli.argmax_handle_shard(scores_h, first_cell_rule=rank == 0)
+                merged = D.merge_argmax(loc, row0, device=coll_dev)
+        if pending is not None:
+            merged = comm.argmax_sharded_end(pending)
+        return merged
 
     def barrier() -> None:
         if world > 1:
@@ -427,8 +451,7 @@ def main() -> None:
         torch.cuda.synchronize()
         n_pre += 8
     preheat_ms = (time.perf_counter() - t_pre) * 1e3
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     barrier()
     kernel_name = pli.last_kernel
 
@@ -456,15 +479,7 @@ def main() -> None:
           for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
-    merged = None
-    for a, b in ev:
-        a.record(stream)
-        pli.score_into(pssm, seq, scores_h)
-        b.record(stream)
-        if sharded:
-            merged = (comm.argmax_sharded(scores_h, row0) if comm is not None else
-                      D.merge_argmax(pli.argmax_handle_shard(scores_h, first_cell_rule=rank == 0), row0,
-                                     device=coll_dev))
+    merged = run_steps(args.steps, ev)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -537,7 +552,9 @@ def main() -> None:
             traffic = None
     step_desc = ("score_into" if not sharded else
                  "score_into of the rank's row shard + tracked shard argmax + RCCL merge of the argmax records "
-                 f"({'C-ABI communicator' if comm is not None else 'torch.distributed ' + args.dist_backend})")
+                 f"({'C-ABI communicator' if comm is not None else 'torch.distributed ' + args.dist_backend}"
+                 + ("; pipelined: the merge of step i overlaps the scoring of step i+1, every step's result is "
+                    "collected on the host inside the timed region" if pipelined else "") + ")")
     out = {
         "metric": "scored positions/sec", "value": round(value, 2), "unit": "Gpos/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -430,6 +430,17 @@ int lm_hip_merge_argmax(lm_hip_ctx *ctx, lm_hip_comm *comm, int found_local,
  * the all_gather. */
 int lm_hip_argmax_sharded(lm_hip_ctx *ctx, lm_hip_comm *comm, const lm_hip_scores *scores,
                           size_t row_offset, int *found, lm_hip_coords *best, float *value);
+/* The same in two halves, for a host that scores shard after shard (Scanner-style block loops,
+ * scan.rs:174-178; the CLI's job loop, main.rs:502-561): _begin enqueues the shard record, its
+ * all_gather and the read-back (the last two on a stream of the communicator's own) and returns at
+ * once with a ticket; `scores` may be overwritten by the next lm_hip_score_into right away.  _end
+ * waits for that merge only and applies lm_hip_combine_argmax.  At most two merges in flight per
+ * communicator; every rank must issue the same sequence of collectives; one host thread per
+ * communicator. */
+int lm_hip_argmax_sharded_begin(lm_hip_ctx *ctx, lm_hip_comm *comm, const lm_hip_scores *scores,
+                                size_t row_offset, int *ticket);
+int lm_hip_argmax_sharded_end(lm_hip_ctx *ctx, lm_hip_comm *comm, int ticket, int *found,
+                              lm_hip_coords *best, float *value);
 /* Maximum::max (pli/mod.rs:158-160) when no NaN can occur (NaN contributions are dropped). */
 int lm_hip_merge_max(lm_hip_ctx *ctx, lm_hip_comm *comm, int found_local, float value_local,
                      int *found, float *value);

@@ -117,6 +117,8 @@ SIGNATURES = {
     "lm_hip_exchange_halo_dptr": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint8]),
     "lm_hip_merge_argmax": (C.c_int, [_vp, _vp, C.c_int, _cp, C.c_float, _sz, _ip, _cp, _fp]),
     "lm_hip_argmax_sharded": (C.c_int, [_vp, _vp, _vp, _sz, _ip, _cp, _fp]),
+    "lm_hip_argmax_sharded_begin": (C.c_int, [_vp, _vp, _vp, _sz, _ip]),
+    "lm_hip_argmax_sharded_end": (C.c_int, [_vp, _vp, C.c_int, _ip, _cp, _fp]),
     "lm_hip_merge_max": (C.c_int, [_vp, _vp, C.c_int, C.c_float, _ip, _fp]),
     "lm_hip_merge_threshold": (C.c_int, [_vp, _vp, _cp, _sz, _sz, C.POINTER(_cp), _szp]),
     "lm_hip_score_f32": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _sz, _vp, _sz, _sz, _sz, _sz, _sz, _vp,

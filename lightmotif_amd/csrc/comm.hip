@@ -31,6 +31,15 @@
 
 namespace lm {
 
+// What one rank contributes to a merged argmax: 32 bytes, rows in GLOBAL coordinates.
+struct MergeRecord {
+    long long row, col;
+    float value;
+    int found;
+    long long pad;
+};
+static_assert(sizeof(MergeRecord) == 32, "MergeRecord is the 32-byte all_gather payload");
+
 namespace {
 
 struct Rccl {
@@ -100,15 +109,6 @@ int need_rccl()
             return ::lm::fail(LM_HIP_ERR_COMM, "%s failed: %s", #expr, rccl().GetErrorString(_r)); \
     } while (0)
 
-// What one rank contributes to a merged argmax: 32 bytes, rows in GLOBAL coordinates.
-struct MergeRecord {
-    long long row, col;
-    float value;
-    int found;
-    long long pad;
-};
-static_assert(sizeof(MergeRecord) == 32, "MergeRecord is the 32-byte all_gather payload");
-
 // ArgmaxRecord of a shard (flat index row * cols + col, rows relative to the shard) -> MergeRecord
 __global__ void globalize_record(const ArgmaxRecord *__restrict__ local, const unsigned long long cols,
                                  const unsigned long long row_offset, MergeRecord *__restrict__ out)
@@ -147,6 +147,17 @@ struct lm_hip_comm {
     ncclComm_t nccl = nullptr;
     int rank = 0, nranks = 1, device = 0;
     lm::Scratch buf;  // device staging of the collectives
+    // pipelined argmax merges (lm_hip_argmax_sharded_begin / _end): two slots, each with its own device
+    // records and its own pinned read-back area; the all_gather and the read-back run on `side`
+    struct Slot {
+        hipEvent_t ready = nullptr, done = nullptr;
+        bool pending = false;
+    } slot[2];
+    hipStream_t side = nullptr;
+    lm::Scratch abuf;                  // per slot: ArgmaxRecord | MergeRecord mine | MergeRecord all[nranks]
+    lm::MergeRecord *h_slots = nullptr;  // pinned, 2 x nranks
+    int next = 0;
+    size_t slot_bytes() const { return 32 + sizeof(lm::MergeRecord) * ((size_t)nranks + 1); }
 };
 
 using namespace lm;
@@ -240,6 +251,17 @@ int lm_hip_comm_destroy(lm_hip_comm *comm)
         return LM_HIP_OK;
     DeviceGuard guard(comm->device);
     comm->buf.release();
+    if (comm->side) {
+        (void)hipStreamSynchronize(comm->side);
+        (void)hipStreamDestroy(comm->side);
+    }
+    for (auto &sl : comm->slot) {
+        if (sl.ready) (void)hipEventDestroy(sl.ready);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    comm->abuf.release();
+    if (comm->h_slots)
+        (void)hipHostFree(comm->h_slots);
     if (comm->nccl && rccl().ok)
         (void)rccl().CommDestroy(comm->nccl);
     delete comm;
@@ -348,15 +370,97 @@ int lm_hip_argmax_sharded(lm_hip_ctx *ctx, lm_hip_comm *comm, const lm_hip_score
     if (s->rows == 0) {
         LM_HIP_TRY(hipMemsetAsync(d_local, 0, sizeof(ArgmaxRecord), ctx->stream));  // found = 0
     } else if (s->best_valid && (int)s->first_cell_rule == rule) {
-        // tracked by the store kernel that wrote the shard (score_into on a handle)
-        LM_HIP_TRY(hipMemcpyAsync(d_local, s->d_best, sizeof(ArgmaxRecord), hipMemcpyDeviceToDevice, ctx->stream));
+        // tracked by the store kernel that wrote the shard (score_into on a handle): read in place
+        d_local = s->d_best;
     } else {
         LM_TRY(launch_argmax_device(ctx, s->d_data, s->rows, s->stride, s->cols, rule, d_local));
     }
-    hipLaunchKernelGGL(globalize_record, dim3(1), dim3(1), 0, ctx->stream, d_local, (unsigned long long)s->cols,
-                       (unsigned long long)row_offset, d);
+    hipLaunchKernelGGL(globalize_record, dim3(1), dim3(1), 0, ctx->stream, (const ArgmaxRecord *)d_local,
+                       (unsigned long long)s->cols, (unsigned long long)row_offset, d);
     LM_HIP_TRY(hipGetLastError());
     return gather_and_combine(ctx, comm, d, d + 1, found, best, value);
+}
+
+// ---- pipelined form: the merge of step i overlaps the scoring of step i+1 --------------------
+
+static int async_init(lm_hip_comm *comm)
+{
+    if (comm->side)
+        return LM_HIP_OK;
+    LM_TRY(comm->abuf.reserve(2 * comm->slot_bytes()));
+    LM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&comm->h_slots), 2 * sizeof(MergeRecord) * comm->nranks,
+                             hipHostMallocDefault));
+    for (auto &sl : comm->slot) {
+        LM_HIP_TRY(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
+        LM_HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
+    LM_HIP_TRY(hipStreamCreateWithFlags(&comm->side, hipStreamNonBlocking));
+    return LM_HIP_OK;
+}
+
+int lm_hip_argmax_sharded_begin(lm_hip_ctx *ctx, lm_hip_comm *comm, const lm_hip_scores *s, size_t row_offset,
+                                int *ticket)
+{
+    if (!ctx || !comm || !s || !ticket)
+        return fail(LM_HIP_ERR_BAD_ARGS, "argmax_sharded_begin: null argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    LM_TRY(async_init(comm));
+    const int k = comm->next;
+    lm_hip_comm::Slot &sl = comm->slot[k];
+    if (sl.pending)
+        return fail(LM_HIP_ERR_BAD_ARGS, "argmax_sharded_begin: two merges are in flight, collect one with _end first");
+    char *base = static_cast<char *>(comm->abuf.ptr) + (size_t)k * comm->slot_bytes();
+    ArgmaxRecord *d_local = reinterpret_cast<ArgmaxRecord *>(base);
+    MergeRecord *d_mine = reinterpret_cast<MergeRecord *>(base + 32);
+    MergeRecord *d_all = d_mine + 1;
+    const int rule = row_offset == 0 ? 1 : 0;  // only the shard holding row 0 holds scores[0][0]
+    if (s->rows == 0) {
+        LM_HIP_TRY(hipMemsetAsync(d_local, 0, sizeof(ArgmaxRecord), ctx->stream));  // found = 0
+    } else if (s->best_valid && (int)s->first_cell_rule == rule) {
+        d_local = s->d_best;  // tracked by the store kernel: read in place, on the stream that wrote it
+    } else {
+        LM_TRY(launch_argmax_device(ctx, s->d_data, s->rows, s->stride, s->cols, rule, d_local));
+    }
+    hipLaunchKernelGGL(globalize_record, dim3(1), dim3(1), 0, ctx->stream, (const ArgmaxRecord *)d_local,
+                       (unsigned long long)s->cols, (unsigned long long)row_offset, d_mine);
+    LM_HIP_TRY(hipGetLastError());
+    // from here on the scores (and the tracked record) may be overwritten: the side stream only
+    // needs the 32-byte record
+    LM_HIP_TRY(hipEventRecord(sl.ready, ctx->stream));
+    LM_HIP_TRY(hipStreamWaitEvent(comm->side, sl.ready, 0));
+    LM_NCCL_TRY(rccl().AllGather(d_mine, d_all, sizeof(MergeRecord), ncclUint8, comm->nccl, comm->side));
+    LM_HIP_TRY(hipMemcpyAsync(comm->h_slots + (size_t)k * comm->nranks, d_all, sizeof(MergeRecord) * comm->nranks,
+                              hipMemcpyDeviceToHost, comm->side));
+    LM_HIP_TRY(hipEventRecord(sl.done, comm->side));
+    sl.pending = true;
+    comm->next ^= 1;
+    *ticket = k;
+    return LM_HIP_OK;
+}
+
+int lm_hip_argmax_sharded_end(lm_hip_ctx *ctx, lm_hip_comm *comm, int ticket, int *found, lm_hip_coords *best,
+                              float *value)
+{
+    if (!ctx || !comm || !found || ticket < 0 || ticket > 1 || !comm->slot[ticket].pending)
+        return fail(LM_HIP_ERR_BAD_ARGS, "argmax_sharded_end: no merge in flight under this ticket");
+    {
+        DeviceGuard guard(ctx->device);
+        LM_HIP_TRY(hipEventSynchronize(comm->slot[ticket].done));  // (the context stays free for other threads)
+    }
+    comm->slot[ticket].pending = false;
+    const int n = comm->nranks;
+    const MergeRecord *h = comm->h_slots + (size_t)ticket * n;
+    std::vector<int> f(n);
+    std::vector<lm_hip_coords> b(n);
+    std::vector<float> v(n);
+    for (int i = 0; i < n; ++i) {
+        f[i] = h[i].found;
+        b[i].row = (size_t)h[i].row;
+        b[i].col = (size_t)h[i].col;
+        v[i] = h[i].value;
+    }
+    return lm_hip_combine_argmax(f.data(), b.data(), v.data(), (size_t)n, found, best, value);
 }
 
 int lm_hip_merge_max(lm_hip_ctx *ctx, lm_hip_comm *comm, int found_local, float value_local, int *found,

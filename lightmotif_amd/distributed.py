@@ -376,6 +376,24 @@ class CabiComm:
                                                  C.byref(best), C.byref(value)))
         return ((best.row, best.col), float(value.value)) if found.value else None
 
+    def argmax_sharded_begin(self, scores, row_offset: int) -> int:
+        """Enqueues the merge of ``scores``' argmax and returns a ticket at once; the shard may be
+        overwritten by the next ``score_into`` (the merge overlaps it).  At most two in flight."""
+        from . import _ffi
+        ticket = self._C.c_int(-1)
+        _ffi.check(self._L.lm_hip_argmax_sharded_begin(self._pli._h, self._h, scores._h, row_offset,
+                                                       self._C.byref(ticket)))
+        return ticket.value
+
+    def argmax_sharded_end(self, ticket: int):
+        """Result of the merge enqueued under ``ticket``: same value as ``argmax_sharded``."""
+        from . import _ffi
+        C = self._C
+        found, best, value = C.c_int(0), _ffi.Coords(), C.c_float(0)
+        _ffi.check(self._L.lm_hip_argmax_sharded_end(self._pli._h, self._h, ticket, C.byref(found), C.byref(best),
+                                                     C.byref(value)))
+        return ((best.row, best.col), float(value.value)) if found.value else None
+
     def merge_max(self, local: Optional[float]) -> Optional[float]:
         from . import _ffi
         C = self._C

@@ -807,6 +807,24 @@ public:
         out.cell = {best.row, best.col};
         return out;
     }
+    // The same in two halves: `argmax_begin` returns at once and the shard may be scored over right
+    // away; `argmax_end(ticket)` waits for that merge only (at most two in flight)
+    int argmax_begin(const StripedScores &shard, size_t row_offset) const
+    {
+        int ticket = -1;
+        check(lm_hip_argmax_sharded_begin(ctx_, h_, shard.handle(), row_offset, &ticket));
+        return ticket;
+    }
+    ShardBest argmax_end(int ticket) const
+    {
+        ShardBest out;
+        int found = 0;
+        lm_hip_coords best{};
+        check(lm_hip_argmax_sharded_end(ctx_, h_, ticket, &found, &best, &out.score));
+        out.found = found != 0;
+        out.cell = {best.row, best.col};
+        return out;
+    }
     // StripedScores::threshold of the whole matrix: (row, col) in the reference's row-major order
     std::vector<MatrixCoordinates> threshold(const StripedScores &shard, float t, size_t row_offset) const
     {

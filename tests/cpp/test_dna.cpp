@@ -386,6 +386,13 @@ static void test_sharded(const Pipeline<Dna> &pli)
     CHECK((pos == std::vector<size_t>{18, 27, 32}));                 // tests/dna.rs:158-165
     const auto shifted = comm.threshold(scores, -10.0f, 1000);       // rows become global
     CHECK(shifted.size() == 3 && shifted[0].row == hits[0].row + 1000);
+    // (3) the two-halves form: the merge is collected after the shard was scored over
+    const int t0 = comm.argmax_begin(scores, 0);
+    pli.score_into(pssm, striped, scores);
+    const int t1 = comm.argmax_begin(scores, 0);
+    const ShardBest b0 = comm.argmax_end(t0), b1 = comm.argmax_end(t1);
+    CHECK(b0.found && scores.offset(b0.cell) == 18 && b0.score == best.score);
+    CHECK(b1.found && scores.offset(b1.cell) == 18 && b1.score == best.score);
 }
 
 int main()

@@ -349,6 +349,60 @@ def test_c_abi_communicator_single_rank(gpu_pli):
     comm.close()
 
 
+def test_pipelined_sharded_argmax_merge(gpu_pli):
+    """lm_hip_argmax_sharded_begin / _end: the shard is scored over while the previous merge is in
+    flight (its record, all_gather and read-back live in the communicator's own slots and stream);
+    every ticket must return what the synchronous call returns for ITS step's matrix -- tracked
+    records and materialised ones, first-cell NaN, two in flight at most."""
+    pli = gpu_pli
+    comm = D.CabiComm.from_torch(pli)
+    rng = np.random.default_rng(31)
+    length = 3_000_017
+    enc = rng.integers(0, 4, length, dtype=np.uint8)
+    ref = co.stripe(enc, COLS, 5)
+    co.configure_wrap(ref, 24)
+    seq = pli.stripe(lm.EncodedSequence(enc), COLS)
+    seq.configure_wrap(24)
+    scores = lm.StripedScores.empty(pli, COLS)
+    motifs = []
+    for i, m in enumerate((20, 7, 25, 12, 20, 16)):
+        p = np.zeros((m, 8), np.float32)
+        p[:, :4] = rng.integers(-2, 3, (m, 4)) if i % 2 else rng.normal(0, 2, (m, 4))
+        p[:, 4] = -np.inf
+        if i == 3:
+            p[0, int(enc[0])] = np.nan                   # first-cell rule through the pipelined form
+        want, _ = co.score_rows(ref, p)
+        am = co.argmax(want, COLS)
+        motifs.append((lm.ScoringMatrix(p), (am, float(want[am]))))
+    for track in (True, False):
+        pli.set_track_argmax(track)
+        pending, got = None, []
+        for pssm, _ in motifs:
+            pli.score_into(pssm, seq, scores)
+            ticket = comm.argmax_sharded_begin(scores, 0)
+            if pending is not None:
+                got.append(comm.argmax_sharded_end(pending))
+            pending = ticket
+        got.append(comm.argmax_sharded_end(pending))
+        for g, (_, w) in zip(got, motifs):
+            assert g[0] == w[0] and (g[1] == w[1] or (g[1] != g[1] and w[1] != w[1])), (track, g, w)
+    pli.set_track_argmax(True)
+    # misuse: a third merge while two are in flight; a ticket that is not in flight
+    t0 = comm.argmax_sharded_begin(scores, 0)
+    t1 = comm.argmax_sharded_begin(scores, 0)
+    with pytest.raises(lm.LightmotifHipError):
+        comm.argmax_sharded_begin(scores, 0)
+    a, b = comm.argmax_sharded_end(t0), comm.argmax_sharded_end(t1)
+    assert a == b == comm.argmax_sharded(scores, 0)
+    with pytest.raises(lm.LightmotifHipError):
+        comm.argmax_sharded_end(t0)
+    # a shard that does not start at row 0 never applies the first-cell rule; rows come back global
+    t = comm.argmax_sharded_begin(scores, 1000)
+    r = comm.argmax_sharded_end(t)
+    assert r[0][0] >= 1000
+    comm.close()
+
+
 def test_adopted_sequence_borrows_the_callers_matrix(gpu_pli):
     pli = gpu_pli
     dev = torch.device("cuda", 0)
