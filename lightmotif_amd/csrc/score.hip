@@ -95,6 +95,12 @@ ScoreC32Launcher score_c32_lookup_continue(int M)
     return (M >= 1 && M <= kMaxFastM) ? g_c32[M][9] : nullptr;
 }
 
+ScoreC32Launcher score_c32_lookup_c16(int M)
+{
+    std::call_once(g_c32_once, init_registry);
+    return (M >= 1 && M <= kMaxFastM) ? g_c32[M][10] : nullptr;
+}
+
 ScoreC32Launcher score_c32_lookup_ql(int M)
 {
     std::call_once(g_c32_once, init_registry);
@@ -142,7 +148,8 @@ struct MotifShape {
 };
 
 static C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const ScoreArgs &a, bool store,
-                        int prefilter = 0, size_t batch = 1, unsigned long long default_rows = 0);
+                        int prefilter = 0, size_t batch = 1, unsigned long long default_rows = 0,
+                        bool allow16 = false);
 
 static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store, int prefilter = 0,
                         size_t batch = 1)
@@ -151,8 +158,10 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store, i
     return plan_c32(ctx, ms, a, store, prefilter, batch);
 }
 
+// `allow16`: the caller also has a kernel for C = 16 (plain store, score rows of 16 floats; a
+// wavefront then carries four streams)
 static C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const ScoreArgs &a, bool store,
-                        int prefilter, size_t batch, unsigned long long default_rows)
+                        int prefilter, size_t batch, unsigned long long default_rows, bool allow16)
 {
     C32Plan p;
     const size_t K = ms.k;
@@ -162,7 +171,8 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const Score
                                       : ms.m;
     const size_t extra = prefilter == 2 ? 2 : 1;  // rows of a stream beyond q groups
     const unsigned long long n = a.row_end - a.row_begin;
-    if (a.cols != 32 || a.seq_stride != 32 || (store && a.out_stride != 32))
+    const bool c16 = allow16 && store && prefilter == 0 && a.cols == 16;
+    if ((a.cols != 32 && !c16) || a.seq_stride != 32 || (store && a.out_stride != a.cols))
         return p;
     if (ms.m < 1 || ms.m > (size_t)kMaxFastM || n < M + extra)
         return p;
@@ -206,7 +216,8 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const Score
         return p;
     p.T = q * M + extra;
     p.nstreams = (n + p.T - 1) / p.T;
-    p.grid = dim3((unsigned)((p.nstreams + kStreamsPerBlock - 1) / kStreamsPerBlock));
+    const unsigned long long per_block = c16 ? 2 * kStreamsPerBlock : kStreamsPerBlock;
+    p.grid = dim3((unsigned)((p.nstreams + per_block - 1) / per_block));
     p.lds = lds;
     p.ok = true;
     return p;
@@ -254,21 +265,25 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
         // sums (0.0 + 0.0 + P[0] ... ), with the dword symbol loads and 4-row blocks of the M' kernel
         const size_t mp = a.pssm->m + a.pssm->lead;
         const MotifShape ms{mp, a.pssm->k, false};
-        const C32Plan pp = plan_c32(ctx, ms, a, true);
-        if (pp.ok && score_c32_lookup_ql((int)mp)) {
+        const C32Plan pp = plan_c32(ctx, ms, a, true, 0, 1, 0, true);
+        const ScoreC32Launcher pfn = a.cols == 16 ? score_c32_lookup_c16((int)mp) : score_c32_lookup_ql((int)mp);
+        if (pp.ok && pfn) {
             fo.lead_rows = (unsigned)a.pssm->lead;
             ctx->last_kernel = score_c32_name((int)mp, MODE_STORE);
-            LM_HIP_TRY(score_c32_lookup_ql((int)mp)(pp.grid, pp.lds, ctx->stream, a.d_seq, a.pssm->d_table_pad,
+            LM_HIP_TRY(pfn(pp.grid, pp.lds, ctx->stream, a.d_seq, a.pssm->d_table_pad,
                                                     (int)a.pssm->k, a.row_begin, a.row_end, pp.T, pp.nstreams, a.d_out,
                                                     fo));
             return LM_HIP_OK;
         }
     }
-    const C32Plan p = plan_c32(ctx, a, true);
+    const bool c16 = a.cols == 16 && dwords && score_c32_lookup_c16((int)a.pssm->m);
+    const C32Plan p = plan_c32(ctx, MotifShape{a.pssm->m, a.pssm->k, false}, a, true, 0, 1, 0, c16);
     if (p.ok) {
         ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_STORE, ctx->xcd_remap);
         if (dwords && score_c32_lookup_ql((int)a.pssm->m))
             fn = score_c32_lookup_ql((int)a.pssm->m);  // dword symbol loads (M % 4 == 0)
+        if (c16)
+            fn = score_c32_lookup_c16((int)a.pssm->m);  // four streams of 16 columns per wavefront
         ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_STORE);
         LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
                       a.row_begin, a.row_end, p.T, p.nstreams, a.d_out, fo));

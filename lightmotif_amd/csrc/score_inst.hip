@@ -30,8 +30,10 @@ struct RegisterRange {
         tab[MODE_ARGMAX] = &score_c32_launch<M, MODE_ARGMAX>;
         tab[MODE_THRESHOLD] = &score_c32_launch<M, MODE_THRESHOLD>;
         tab[3] = &score_c32_launch<M, MODE_STORE, 1>;
-        if constexpr (M % 4 == 0)
+        if constexpr (M % 4 == 0) {
             tab[7] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1>;
+            tab[10] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1, 16>;
+        }
         tab[8] = &score_c32_launch<M, MODE_STORE_ARGMAX, LM_SCORE_XCD_REMAP, 1>;
         tab[9] = &score_c32_launch<M, MODE_CONTINUE, LM_SCORE_XCD_REMAP, 1>;
         if constexpr (M < LM_M_HI)

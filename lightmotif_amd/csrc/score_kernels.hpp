@@ -283,7 +283,7 @@ enum : int { PHASE_FIRST = 0, PHASE_MAIN = 1, PHASE_LAST = 2 };
 // the group's first step (in the FIRST group only step M-1 completes a row).
 // `sym` is a ring of symbol bytes indexed by step mod M (only ~PF are live),
 // `wc` carries the prefetched LDS column across steps when LP = 1.
-template <int M, int MODE, int PF, int LP, int PHASE, int QL = 0>
+template <int M, int MODE, int PF, int LP, int PHASE, int QL = 0, int OC = 32>
 __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
                                             float (&wc)[4 * ((M + 3) / 4)],
                                             const uint8_t *__restrict__ sp,
@@ -352,7 +352,7 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
         if (MODE == MODE_CONTINUE) {
             init = init_next;
             if (PHASE != PHASE_LAST)
-                init_next = op[(k + 1 + M - 1) * 32];
+                init_next = op[(k + 1 + M - 1) * OC];
         }
         // (3) P[j][s] goes to the output row started j steps ago: slot (k - j) mod M.
 #pragma unroll
@@ -372,16 +372,16 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
 #pragma unroll
                     for (int i = 0; i < SB; ++i) {
                         if (LM_SCORE_NT_STORE)
-                            __builtin_nontemporal_store(pend[i], op + (k - SB + 1 + i) * 32);
+                            __builtin_nontemporal_store(pend[i], op + (k - SB + 1 + i) * OC);
                         else
-                            op[(k - SB + 1 + i) * 32] = pend[i];
+                            op[(k - SB + 1 + i) * OC] = pend[i];
                     }
                 }
             } else if (mode_stores(MODE)) {
                 if (LM_SCORE_NT_STORE)
-                    __builtin_nontemporal_store(score, op + k * 32);
+                    __builtin_nontemporal_store(score, op + k * OC);
                 else
-                    op[k * 32] = score;
+                    op[k * OC] = score;
             }
             if (MODE == MODE_STORE_ARGMAX) {
                 // value only (one v_max_f32; NaN operands are ignored, the NaN start value
@@ -476,7 +476,7 @@ __device__ __forceinline__ void emit_candidates(const unsigned long long hit_gro
 #define LM_SCORE_XCD_REMAP 0
 #endif
 template <int M, int MODE, int PF = LM_SCORE_PF, int LP = LM_SCORE_LP, int BLK = LM_BLOCK,
-          int XCD = LM_SCORE_XCD_REMAP, int MINW = LM_SCORE_MIN_WAVES(M), int QLREQ = 0>
+          int XCD = LM_SCORE_XCD_REMAP, int MINW = LM_SCORE_MIN_WAVES(M), int QLREQ = 0, int OC = 32>
 __global__ __launch_bounds__(BLK, MINW) void score_c32(
     const uint8_t *__restrict__ seq, const float *__restrict__ table, const int K,
     const unsigned long long row_begin, const unsigned long long row_end,
@@ -501,8 +501,11 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
     }
     __syncthreads();
 
+    // OC = 16 (the 16-lane back-ends' column count; plain store only): a wavefront carries four streams
+    // of 16 columns, score rows are 16 floats; the sequence rows keep their 32-byte stride (dense.rs:43-48)
+    static_assert(OC == 32 || (OC == 16 && MODE == MODE_STORE), "C = 16 is built for the plain store kernel");
     const int lane = threadIdx.x & 63;
-    const int col = lane & 31;
+    const int col = lane & (OC - 1);
     unsigned long long bid = blockIdx.x;
     if (XCD) {
         // Workgroup b runs on XCD b % 8 (observed dispatch order; speed only, never
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         const unsigned long long nb = gridDim.x, xcd = bid % 8, q = nb / 8, r = nb % 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
     }
-    unsigned long long stream = (bid * (BLK / 64) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    unsigned long long stream = (bid * (BLK / 64) + (threadIdx.x >> 6)) * (64 / OC) + lane / OC;
     const bool idle = stream >= nstreams;  // re-does the last stream, reports nothing
     if (MODE == MODE_CONTINUE && idle)
         return;  // in-place continuation: every cell may be read and rewritten exactly once
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
     const uint8_t *sp = QL ? seq + (in0 + (col & 3)) * 32 + (col >> 2) * 4 : seq + in0 * 32 + col;
     // output row completed by step t is o0 + t - (M-1); `op` tracks step 0 of the group
     const long long orow = (long long)(o0 - row_begin) - (M - 1);
-    float *op = mode_stores(MODE) ? out + orow * 32 + col : nullptr;
+    float *op = mode_stores(MODE) ? out + orow * OC + col : nullptr;
 
     constexpr int NW = 4 * ((M + 3) / 4);
     constexpr int PFE = PF < M ? PF : M - 1;  // look-ahead stays inside one group
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
     unsigned best_t = (MODE == MODE_THRESHOLD) ? 0u : 0xffffffffu;
     unsigned tbase = 0;
     // MODE_CONTINUE: partial sum of the row started at step 0 (= the stream's first row)
-    float init_next = MODE == MODE_CONTINUE ? op[(M - 1) * 32] : 0.0f;
+    float init_next = MODE == MODE_CONTINUE ? op[(M - 1) * OC] : 0.0f;
 
     const unsigned long long ngroups = (T + M - 1) / M;  // exact: T = q*M + 1, >= 2
 
@@ -587,23 +590,23 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         }
     };
 
-    score_group<M, MODE, PFE, LPE, PHASE_FIRST, QL>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
+    score_group<M, MODE, PFE, LPE, PHASE_FIRST, QL, OC>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
                                                 best_t, fo, shq, init_next);
     note_group();
     for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
         sp += M * 32;
         tbase += M;
         if (mode_stores(MODE))
-            op += M * 32;
-        score_group<M, MODE, PFE, LPE, PHASE_MAIN, QL>(acc, sym, wc, sp, lds_raw, op, tbase, col,
+            op += M * OC;
+        score_group<M, MODE, PFE, LPE, PHASE_MAIN, QL, OC>(acc, sym, wc, sp, lds_raw, op, tbase, col,
                                                    best_v, best_t, fo, shq, init_next);
         note_group();
     }
     sp += M * 32;
     tbase += M;
     if (mode_stores(MODE))
-        op += M * 32;
-    score_group<M, MODE, PFE, LPE, PHASE_LAST, QL>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
+        op += M * OC;
+    score_group<M, MODE, PFE, LPE, PHASE_LAST, QL, OC>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
                                                best_t, fo, shq, init_next);
     note_group();
 
@@ -839,14 +842,14 @@ using ScoreC32Launcher = hipError_t (*)(dim3 grid, size_t lds_bytes, hipStream_t
                                         unsigned long long T, unsigned long long nstreams,
                                         float *out, FusedOut fo);
 
-template <int M, int MODE, int XCD = LM_SCORE_XCD_REMAP, int QL = 0>
+template <int M, int MODE, int XCD = LM_SCORE_XCD_REMAP, int QL = 0, int OC = 32>
 hipError_t score_c32_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, const uint8_t *seq,
                             const float *table, int K, unsigned long long row_begin,
                             unsigned long long row_end, unsigned long long T,
                             unsigned long long nstreams, float *out, FusedOut fo)
 {
     hipLaunchKernelGGL((score_c32<M, MODE, LM_SCORE_PF, LM_SCORE_LP, LM_BLOCK, XCD,
-                                  LM_SCORE_MIN_WAVES(M), QL>), grid,
+                                  LM_SCORE_MIN_WAVES(M), QL, OC>), grid,
                        dim3(kBlock), lds_bytes, stream, seq, table, K, row_begin, row_end, T,
                        nstreams, out, fo);
     return hipGetLastError();
@@ -856,11 +859,13 @@ hipError_t score_c32_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, con
 // Registry row: [0..2] = modes, [3] = store kernel WITH the XCD remap (A/B knob),
 // [4..6] = unused, [7] = store kernel with quad-gathered symbol
 // loads (M % 4 == 0), [8] = store + running maximum (score_into on handles).
-constexpr int kRegistrySlots = 10;  // [9] = MODE_CONTINUE (later passes of motifs longer than kMaxFastM)
+constexpr int kRegistrySlots = 11;  // [9] = MODE_CONTINUE (later passes of motifs longer than kMaxFastM),
+                                    // [10] = store kernel for C = 16 (M % 4 == 0, quad loads)
 ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap = false);
 ScoreC32Launcher score_c32_lookup_ql(int M);
 ScoreC32Launcher score_c32_lookup_store_argmax(int M);
 ScoreC32Launcher score_c32_lookup_continue(int M);
+ScoreC32Launcher score_c32_lookup_c16(int M);
 const char *score_c32_name(int M, int mode);
 
 }  // namespace lm

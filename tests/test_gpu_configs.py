@@ -509,8 +509,40 @@ def test_long_motifs_fused_reductions_go_chunk_by_chunk(monkeypatch, m, chunk_ro
     assert got[0] == co.argmax(want, COLS) == (0, 0) and np.isnan(got[1])
 
 
-@pytest.mark.parametrize("cols,m,k", [(16, 20, 5), (16, 33, 5), (1, 15, 5), (2, 7, 5), (33, 12, 5), (16, 70, 5),
-                                      (4, 100, 5), (16, 12, 21), (8, 40, 21)])
+@pytest.mark.parametrize("m,k", [(4, 5), (7, 5), (8, 5), (15, 5), (20, 5), (21, 5), (28, 5), (32, 5), (36, 5), (12, 21),
+                                 (5, 21)])
+def test_sixteen_columns_take_the_unrolled_store_kernel(pli, m, k):
+    """C = 16 is the column count of the reference's 16-lane back-ends (sse2.rs / neon.rs: U16): the
+    rotating-accumulator store kernel with four 16-column streams per wavefront (score_c32<M', 0, ..., 16>,
+    M padded to a multiple of 4 with leading zero rows like at C = 32), bit-exact against the oracle on
+    ragged lengths and row ranges; the sequence rows keep their 32-byte stride (dense.rs:43-48)."""
+    rng = np.random.default_rng(1600 + m)
+    length = 2_000_003
+    enc = rng.integers(0, k, length, dtype=np.uint8)
+    enc[rng.random(length) < 0.95] %= (k - 1)
+    p = np.zeros((m, co.stride(k, 4)), np.float32)
+    p[:, :k] = rng.normal(0, 2, (m, k))
+    p[:, k - 1] = -np.inf
+    ref = co.stripe(enc, 16, k)
+    co.configure_wrap(ref, m - 1)
+    seq = pli.stripe(lm.EncodedSequence(enc, protein=k == 21), 16)
+    seq.configure_wrap(m - 1)
+    pssm = lm.ScoringMatrix(p, protein=k == 21)
+    scores = lm.StripedScores.empty(pli, 16)
+    for a, b in ((0, ref.rows), (7, ref.rows - 11), (ref.rows - 3 * m - 2, ref.rows), (1000, 1000 + m + 1)):
+        want, _ = co.score_rows(ref, p, a, b)
+        pli.score_rows_into(pssm, seq, range(a, b), scores)
+        if b - a > m + 4:                       # (a range shorter than one padded group falls back, same values)
+            assert pli.last_kernel.startswith("score_c32<"), pli.last_kernel
+        assert np.array_equal(bits(scores.matrix()[:, :16]), bits(want[:, :16])), (m, a, b)
+    want, _ = co.score_rows(ref, p)
+    pli.score_into(pssm, seq, scores)
+    assert pli.argmax(scores) == co.argmax(want, 16)
+    assert pli.score_argmax(pssm, seq)[0] == co.argmax(want, 16)
+
+
+@pytest.mark.parametrize("cols,m,k", [(16, 33, 5), (1, 15, 5), (2, 7, 5), (33, 12, 5), (16, 70, 5),
+                                      (4, 100, 5), (8, 40, 21)])
 def test_other_geometries_take_the_tiled_kernel(pli, cols, m, k):
     """Column counts other than 32 (the 16-lane back-ends' geometry, the Generic bench's C = 1,
     dna.rs:113-116) and motifs beyond 64: score_tiled, bit-exact against the oracle."""
