@@ -14,6 +14,8 @@ timeout 200 python tools/api_overhead.py > "$OUT/api_overhead.json" 2> "$OUT/api
 timeout 400 python tools/msweep.py > "$OUT/msweep.json" 2> "$OUT/msweep.err"
 timeout 200 python tools/msweep.py 1000000000 40,48,64,100 > "$OUT/msweep_long.json" 2> "$OUT/msweep_long.err"
 timeout 100 tools/kbench/mix_bench > "$OUT/mix_bench.txt" 2>&1
+timeout 200 python tools/track_ab.py 20 > "$OUT/track_ab.txt" 2>/dev/null
+timeout 200 python tools/track_ab.py 12 >> "$OUT/track_ab.txt" 2>/dev/null
 timeout 200 python tools/handle_flow.py > "$OUT/handle_flow.json" 2> "$OUT/handle_flow.err"
 # the N > 1 control flow of bench.py on the box's one GPU: 2 ranks over gloo (torch merge), and the C-ABI merge path
 # through a communicator of one rank -- functional checks, NOT scaling numbers
