@@ -31,6 +31,7 @@
 //
 // Generic kernel (`score_generic`): one thread per cell, any C / stride / M / K.
 #pragma once
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 
@@ -139,6 +140,28 @@ __device__ __forceinline__ void best_wave_reduce(float &v, long long &i)
     }
 }
 
+// Maximum of a float over the wavefront, NaN operands ignored (NaN only if every lane holds NaN),
+// with DPP moves only: `__shfl_xor` is a ds_bpermute, i.e. an LDS-pipeline instruction, and the store
+// kernel's epilogue is paid by every short-lived wavefront while the LDS pipeline is its bottleneck
+// (18 bpermutes per ~400 table reads).  Result in every lane.
+__device__ __forceinline__ float wave_max_dpp(float v)
+{
+    auto step = [](float x, auto ctrl) {
+        const int moved = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x),
+                                                      decltype(ctrl)::value, 0xf, 0xf, false);
+        return __builtin_fmaxf(x, __builtin_bit_cast(float, moved));
+    };
+    v = step(v, std::integral_constant<int, 0xb1>{});   // quad_perm [1, 0, 3, 2]
+    v = step(v, std::integral_constant<int, 0x4e>{});   // quad_perm [2, 3, 0, 1]
+    v = step(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
+    v = step(v, std::integral_constant<int, 0x140>{});  // row_mirror: every lane holds its row-of-16 maximum
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return __builtin_fmaxf(__builtin_fmaxf(r0, r1), __builtin_fmaxf(r2, r3));
+}
+
 // Block-level reduce of (v, i); result valid in thread 0.  `sm` has room for
 // kBlock/64 entries of each type.
 template <int BLK = kBlock>
@@ -186,6 +209,9 @@ __device__ __forceinline__ void record_hit(const FusedOut &fo, unsigned long lon
 //   PF  global prefetch distance in steps: the symbol byte of step k+PF is
 //       requested while step k is processed (0 = load at use);
 //   LP  1 = the LDS reads of step k+1 are issued before the adds of step k.
+#ifndef LM_EMIT_FAST_PATH
+#define LM_EMIT_FAST_PATH 1  // A/B: 0 = the candidate epilogue always runs its prefix sum
+#endif
 #ifndef LM_SCORE_STORE_BATCH
 #define LM_SCORE_STORE_BATCH 1
 #endif
@@ -432,12 +458,17 @@ __device__ __forceinline__ void emit_candidates(const unsigned long long hit_gro
         if (r1 > r0)
             mine += (unsigned)((r1 - r0 + 31) / 32);
     }
+    // Hits are rare (p ~ 1e-5 per cell): almost every wavefront has nothing to report, and the prefix
+    // sum below is six ds_bpermute -- LDS-pipeline instructions, which the scans that end here are bound
+    // by (one epilogue per ~64-row stream and motif: ~8 % of the pair scan's LDS instructions).
     unsigned incl = mine;
+    if (!LM_EMIT_FAST_PATH || __ballot(mine != 0)) {  // wavefront-uniform
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned y = __shfl_up(incl, off);
-        if (lane >= off)
-            incl += y;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned y = __shfl_up(incl, off);
+            if (lane >= off)
+                incl += y;
+        }
     }
     if (lane == 63)
         wave_total[wave] = incl;
@@ -635,8 +666,9 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         // one record per WAVEFRONT (no workgroup barrier at the end of a short-lived
         // workgroup: with ~80 steps per stream the barrier + LDS reduce cost 15 %);
         // "index" = the workgroup, ties go to the later rows
-        long long idx = best_v != best_v ? -1 : (long long)bid;
-        best_wave_reduce(best_v, idx);
+        // (every lane of the wavefront would report the same workgroup: only the value needs reducing)
+        best_v = wave_max_dpp(best_v);
+        const long long idx = best_v != best_v ? -1 : (long long)bid;
         if ((threadIdx.x & 63) == 0) {
             ArgmaxRecord *rec = fo.block_best + (size_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
             rec->value = best_v;
