@@ -256,6 +256,15 @@ static int launch_generic(lm_hip_ctx *ctx, const ScoreArgs &a, const FusedOut &f
 
 // ---- Store --------------------------------------------------------------------------
 
+// Plain store kernel only: (padded) length 12 at C = 32 runs fastest with ONE group per stream, T = 13
+// (0.916 vs 0.954 ms per Gbp at T = 37, reproduced on three runs and for M = 10, 11 padded to 12;
+// profiles/r02_tsweep_short_streams.txt).  The same choice is wrong for every other length (M' = 8: 0.998,
+// 16: 1.02, 20: 1.06), so it is a table entry, not a rule.  0 = the planner's default.
+static unsigned long long store_rows_hint(size_t m_kernel, size_t cols)
+{
+    return (cols == 32 && m_kernel == 12) ? 12 : 0;
+}
+
 int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
 {
     FusedOut fo{};
@@ -265,7 +274,7 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
         // sums (0.0 + 0.0 + P[0] ... ), with the dword symbol loads and 4-row blocks of the M' kernel
         const size_t mp = a.pssm->m + a.pssm->lead;
         const MotifShape ms{mp, a.pssm->k, false};
-        const C32Plan pp = plan_c32(ctx, ms, a, true, 0, 1, 0, true);
+        const C32Plan pp = plan_c32(ctx, ms, a, true, 0, 1, store_rows_hint(mp, a.cols), true);
         const ScoreC32Launcher pfn = a.cols == 16 ? score_c32_lookup_c16((int)mp) : score_c32_lookup_ql((int)mp);
         if (pp.ok && pfn) {
             fo.lead_rows = (unsigned)a.pssm->lead;
@@ -277,7 +286,8 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
         }
     }
     const bool c16 = a.cols == 16 && dwords && score_c32_lookup_c16((int)a.pssm->m);
-    const C32Plan p = plan_c32(ctx, MotifShape{a.pssm->m, a.pssm->k, false}, a, true, 0, 1, 0, c16);
+    const C32Plan p = plan_c32(ctx, MotifShape{a.pssm->m, a.pssm->k, false}, a, true, 0, 1,
+                               store_rows_hint(a.pssm->m, a.cols), c16);
     if (p.ok) {
         ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_STORE, ctx->xcd_remap);
         if (dwords && score_c32_lookup_ql((int)a.pssm->m))
