@@ -440,3 +440,86 @@ def test_candidate_route_argmax_batches_share_passes(gpu_pli):
         assert pli.last_kernel in ("score_c32_prefilter2_multi", "argmax_collect", "score_c32_prefilter2",
                                    "score_c32_prefilter")
         assert batch == singles
+
+
+@pytest.mark.parametrize("m", [20, 40], ids=["m20", "m40_sliced"])
+def test_more_than_2_32_cells_on_one_gpu(gpu_pli, m):
+    """4.5 Gbp on one GPU (4.5 GB of symbols, 18 GB of scores): row-major cell indices and sequence
+    positions pass 2^32, which `configs[3]`'s per-GPU shards never do.  The consensus k-mer of the PSSM
+    is planted at a low cell and at cells / positions beyond 2^32, so the maximum value occurs there
+    (and wherever chance put an equally good k-mer): argmax (materialised, tracked, fused) must return the LAST planted cell, threshold
+    (materialised, fused, Scanner positions) exactly the planted ones in order, and sampled windows
+    must equal the oracle bit for bit."""
+    pli = gpu_pli
+    dev = torch.device("cuda", 0)
+    length, k = 4_500_000_000, 5
+    rows = -(-length // COLS)
+    assert rows * COLS > 2 ** 32
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4242)
+    seq = torch.empty((rows + m - 1, COLS), dtype=torch.uint8, device=dev)
+    step = 1 << 24
+    for a in range(0, rows, step):
+        b = min(a + step, rows)
+        seq[a:b] = torch.randint(0, 4, (b - a, COLS), dtype=torch.uint8, device=dev, generator=gen)
+    rng = np.random.default_rng(4242)
+    sites = ["".join("ACTG"[i] for i in rng.integers(0, 4, m)) for _ in range(10)]
+    pssm = lm.create(sites).counts.normalize(0.1).log_odds()
+    consensus = torch.from_numpy(np.argmax(pssm.data[:, :4], axis=1).astype(np.uint8)).to(dev)
+    planted = [(1000, 3), (139_000_000, 17), (139_000_007, 31)]          # (row, col), ascending row-major order
+    for r, c in planted:
+        seq[r:r + m, c] = consensus
+    pli.configure_wrap_dptr(seq.data_ptr(), rows, COLS, COLS, m - 1, 4)
+    assert planted[1][0] * COLS + planted[1][1] > 2 ** 32
+    assert planted[2][1] * rows + planted[2][0] > 2 ** 32              # sequence position of the last one
+    best = float(np.float32(0.0))
+    acc = np.float32(0.0)
+    for j in range(m):
+        acc = np.float32(acc + pssm.data[j, int(consensus[j])])
+    best = float(acc)
+
+    scores = score_all(pli, pssm, seq, rows, m, length)
+    for a in (0, planted[1][0] - 100, rows - 4096):
+        b = min(a + 4096, rows)
+        win = co.Striped(seq[a:b + m - 1].cpu().numpy(), length, m - 1, COLS, k)
+        want, _ = co.score_rows(win, pssm.data, 0, b - a)
+        assert np.array_equal(scores[a:b].cpu().numpy().view(np.uint32), want.view(np.uint32)), f"window at row {a}"
+    for r, c in planted:
+        assert float(scores[r, c]) == best
+    # argmax: the last maximal cell in row-major order (pli/mod.rs:146 `>=`)
+    want_am = (planted[-1], best)
+    assert pli.argmax_dptr(scores.data_ptr(), rows, COLS, COLS) == want_am
+    assert pli.score_argmax_dptr(pssm, seq.data_ptr(), rows + m - 1, COLS, COLS, m - 1, length, 0, rows) == want_am
+    # threshold at the maximum: the planted cells (+ any natural occurrence of an equally good k-mer), row-major
+    parts = []                                   # (torch.nonzero itself fails beyond 2^32 elements: go by pieces)
+    for a in range(0, rows, 1 << 25):
+        nz = torch.nonzero(scores[a:a + (1 << 25)] >= best)
+        nz[:, 0] += a
+        parts.append(nz.cpu().numpy())
+    want_hits = np.concatenate(parts)
+    assert set(planted) <= set(map(tuple, want_hits.tolist())) and len(want_hits) < 100
+    assert np.array_equal(pli.threshold_dptr(scores.data_ptr(), rows, COLS, COLS, best), want_hits)
+    f_hits, f_vals = pli.score_threshold_dptr(pssm, seq.data_ptr(), rows + m - 1, COLS, COLS, m - 1, length, 0, rows,
+                                              best)
+    assert np.array_equal(f_hits, want_hits) and (f_vals == np.float32(best)).all()
+    # a p ~ 1e-5 tail over 4.5e9 cells: ~45 000 hits whose keys pass 2^32; fused == materialised
+    sample = scores[:1 << 18].flatten()
+    t = float(torch.quantile(sample[torch.isfinite(sample)], 1 - 1e-5))
+    mat_hits = pli.threshold_dptr(scores.data_ptr(), rows, COLS, COLS, t)
+    f_hits, f_vals = pli.score_threshold_dptr(pssm, seq.data_ptr(), rows + m - 1, COLS, COLS, m - 1, length, 0, rows, t)
+    assert mat_hits.shape[0] > 10_000 and np.array_equal(f_hits, mat_hits)
+    flat = mat_hits[:, 0] * COLS + mat_hits[:, 1]
+    assert (np.diff(flat) > 0).all() and flat[-1] > 2 ** 32
+    idx = torch.from_numpy(mat_hits).to(dev)
+    assert np.array_equal(f_vals, scores[idx[:, 0], idx[:, 1]].cpu().numpy())
+    del scores, idx
+    # the reference's own flow on handles: score_into (tracked maximum) + argmax; Scanner positions
+    sseq = pli.adopt_sequence(seq.data_ptr(), rows, m - 1, COLS, COLS, length, keepalive=seq)
+    sc = lm.StripedScores.empty(pli, COLS)
+    pli.score_into(pssm, sseq, sc)
+    assert pli.argmax(sc) == planted[-1] and sc.max_index == length - m + 1
+    del sc
+    scanner = lm.Scanner(pssm, sseq, threshold=best)
+    want_pos = sorted(int(c) * rows + int(r) for r, c in want_hits.tolist())
+    assert scanner.positions.tolist() == want_pos and want_pos[-1] > 2 ** 32
+    assert (scanner.scores == np.float32(best)).all()
