@@ -472,6 +472,22 @@ class EncodedSequence:
     def __len__(self) -> int:
         return int(self.data.size)
 
+    def __getitem__(self, index: int) -> int:
+        """Symbol index at ``index`` (lightmotif-py lib.rs ``EncodedSequence.__getitem__``: negative
+        indices count from the end, out of range raises IndexError)."""
+        n = int(self.data.size)
+        i = index + n if index < 0 else index
+        if not 0 <= i < n:
+            raise IndexError("sequence index out of range")
+        return int(self.data[i])
+
+    def __iter__(self):
+        return (int(x) for x in self.data)
+
+    def __array__(self, dtype=None, copy=None):
+        """The buffer the reference exposes through ``memoryview`` (1-D, one byte per symbol)."""
+        return self.data if dtype is None else self.data.astype(dtype)
+
     def __str__(self) -> str:
         sym = _symbols(self.protein)
         return "".join(sym[i] for i in self.data)
@@ -542,6 +558,12 @@ class StripedSequence:
         out = np.empty((rows + wrap, st), dtype=np.uint8)
         check(self._pli._L.lm_hip_seq_download(self._pli._h, self._h, out.ctypes.data))
         return out
+
+    def __array__(self, dtype=None, copy=None):
+        """What the reference exposes through ``memoryview(striped)``: the 2-D matrix, ``[row, column]``
+        (a host copy here -- the matrix lives on the device)."""
+        m = self.matrix()[:, :self.columns]
+        return m if dtype is None else m.astype(dtype)
 
 
 # --- matrices ------------------------------------------------------------------------

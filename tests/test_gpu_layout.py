@@ -71,3 +71,15 @@ def test_encode_on_device(pli):
     bad[7000] = ord("Z")
     with pytest.raises(lm.InvalidSymbol, match="'B'"):    # first invalid symbol wins
         pli.stripe_ascii(bytes(bad), protein=True)
+
+
+def test_striped_sequence_buffer_like_test_sequence_py(pli):
+    """lightmotif-py tests/test_sequence.py:60-75 (TestStripedSequence.test_memoryview): the striped matrix
+    as a 2-D ``[row, column]`` byte buffer."""
+    A, C, T, G, N = range(5)
+    s1 = pli.stripe(lm.EncodedSequence("ATGC"))
+    mem = np.asarray(s1)
+    assert (mem[0, 0], mem[1, 0], mem[2, 0], mem[3, 0]) == (A, T, G, C)
+    s2 = pli.stripe(lm.EncodedSequence("ATGTCCCAACAACGATACCCCGAGCCCATCGCCGTCATCGGCTCGGCATGCAGATTCCCAGGCG"))
+    mem = np.asarray(s2)
+    assert mem.shape == (2, 32) and (mem[0, 0], mem[1, 0], mem[0, 1]) == (A, T, G)

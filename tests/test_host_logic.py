@@ -28,6 +28,23 @@ def test_encode_matches_reference_alphabets():
         lm.EncodedSequence("PILFFRLK")  # lib.rs module doc example: protein text as DNA
 
 
+def test_encoded_sequence_protocol_like_test_sequence_py():
+    """lightmotif-py tests/test_sequence.py:10-57 (TestEncodedSequence): len, index, IndexError, iteration,
+    and the 1-D byte buffer (``memoryview`` there, ``np.asarray`` here -- a pure-Python class on 3.10)."""
+    A, C, T, G, N = range(5)
+    s1, s2 = lm.EncodedSequence("ATGC"), lm.EncodedSequence("ATGCTTAGATAC")
+    assert (len(s1), len(s2)) == (4, 12)                                        # test_len
+    assert [s1[i] for i in range(4)] == [A, T, G, C]                             # test_index
+    assert [s2[i] for i in range(7)] == [A, T, G, C, T, T, A]
+    assert s1[-1] == C
+    with pytest.raises(IndexError):                                             # test_index_error
+        _ = s1[10]
+    mem = np.asarray(s1)                                                        # test_memoryview
+    assert mem.shape == (4,) and mem.dtype == np.uint8 and list(mem) == [A, T, G, C]
+    assert list(s1) == [A, T, G, C]                                             # test_iter
+    assert str(s1.copy()) == "ATGC"
+
+
 def test_create_normalize_log_odds_equals_oracle_pssm():
     g = GOLD["G1_scores"]
     motif = lm.create(g["patterns"])
