@@ -495,6 +495,8 @@ class EncodedSequence:
     def copy(self) -> "EncodedSequence":
         return EncodedSequence(self.data.copy(), protein=self.protein)
 
+    __copy__ = copy
+
     def stripe(self, columns: int = DEFAULT_COLUMNS) -> "StripedSequence":
         return default_pipeline().stripe(self, columns)
 
@@ -558,6 +560,13 @@ class StripedSequence:
         out = np.empty((rows + wrap, st), dtype=np.uint8)
         check(self._pli._L.lm_hip_seq_download(self._pli._h, self._h, out.ctypes.data))
         return out
+
+    def copy(self) -> "StripedSequence":
+        """lib.rs ``StripedSequence.copy``: an independent sequence with the same rows and wrap rows."""
+        length, wrap, _, _, cols, _ = self._info()
+        return self._pli.upload(self.matrix(), length, wrap, cols, protein=self.protein)
+
+    __copy__ = copy
 
     def __array__(self, dtype=None, copy=None):
         """What the reference exposes through ``memoryview(striped)``: the 2-D matrix, ``[row, column]``
@@ -661,6 +670,10 @@ class WeightMatrix:
     def __getitem__(self, i: int) -> List[float]:
         return [float(x) for x in self.data[i]]
 
+    def __eq__(self, other) -> bool:
+        return (isinstance(other, WeightMatrix) and self.protein == other.protein
+                and np.array_equal(self.data, other.data, equal_nan=True))
+
     def log_odds(self, background: Optional[Dict[str, float]] = None, base: float = 2.0) -> "ScoringMatrix":
         """lib.rs WeightMatrix.log_odds -> rescale + to_scoring_with_base (pwm/mod.rs:505-526)."""
         data, bg = self.data, self.background
@@ -710,6 +723,14 @@ class ScoringMatrix:
 
     def __len__(self) -> int:
         return self.data.shape[0]
+
+    def __getitem__(self, i: int) -> List[float]:
+        """Row ``i``: the K scores of motif position ``i`` (lib.rs ``ScoringMatrix.__getitem__``)."""
+        n = self.data.shape[0]
+        j = i + n if i < 0 else i
+        if not 0 <= j < n:
+            raise IndexError("list index out of range")
+        return [float(x) for x in self.data[j, :self.k]]
 
     def __eq__(self, other) -> bool:
         return (isinstance(other, ScoringMatrix) and self.protein == other.protein

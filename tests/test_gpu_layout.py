@@ -83,3 +83,9 @@ def test_striped_sequence_buffer_like_test_sequence_py(pli):
     s2 = pli.stripe(lm.EncodedSequence("ATGTCCCAACAACGATACCCCGAGCCCATCGCCGTCATCGGCTCGGCATGCAGATTCCCAGGCG"))
     mem = np.asarray(s2)
     assert mem.shape == (2, 32) and (mem[0, 0], mem[1, 0], mem[0, 1]) == (A, T, G)
+    # StripedSequence.copy (lib.rs:367): independent of the original, wrap rows included
+    s2.configure_wrap(3)
+    c = s2.copy()
+    assert (len(c), c.wrap, c.rows, c.columns) == (len(s2), 3, 2, 32) and np.array_equal(c.matrix(), s2.matrix())
+    c.configure_wrap(7)
+    assert s2.wrap == 3 and c.wrap == 7

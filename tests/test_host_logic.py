@@ -45,6 +45,23 @@ def test_encoded_sequence_protocol_like_test_sequence_py():
     assert str(s1.copy()) == "ATGC"
 
 
+def test_matrix_protocols_of_the_python_module():
+    """lightmotif-py lib.rs: CountMatrix / WeightMatrix / ScoringMatrix are sized, indexable by motif
+    position (a row of K values), comparable, and carry `protein` (lib.rs:450-480, 568-598, 764-841)."""
+    motif = lm.create(["GTTGACCTTATCAAC", "GTTGATCCAGTCAAC"])
+    w = motif.counts.normalize(0.1)
+    assert w == motif.counts.normalize(0.1) and w != motif.counts.normalize(0.2)
+    p = w.log_odds()
+    assert len(p) == 15 and len(p[0]) == 5 and p[-1] == p[14] and p[0][4] == float("-inf")
+    assert p[0][3] == float(np.float32(p.data[0, 3])) and not p.protein and not w.protein
+    with pytest.raises(IndexError):
+        _ = p[15]
+    assert p == lm.ScoringMatrix({a: [row[i] for row in (p[j] for j in range(15))] for i, a in enumerate("ACTGN")})
+    import copy
+    e = lm.EncodedSequence("ATGC")
+    assert str(copy.copy(e)) == "ATGC" and copy.copy(e).data is not e.data
+
+
 def test_create_normalize_log_odds_equals_oracle_pssm():
     g = GOLD["G1_scores"]
     motif = lm.create(g["patterns"])
