@@ -569,9 +569,11 @@ class StripedSequence:
     __copy__ = copy
 
     def __array__(self, dtype=None, copy=None):
-        """What the reference exposes through ``memoryview(striped)``: the 2-D matrix, ``[row, column]``
-        (a host copy here -- the matrix lives on the device)."""
-        m = self.matrix()[:, :self.columns]
+        """What the reference exposes through ``memoryview(striped)``: shape ``(columns, rows)`` with
+        strides ``(1, stride)`` (lib.rs:303-317), i.e. indexed ``[column, row]``; a host copy here, the
+        matrix lives on the device."""
+        _, _, rows, _, cols, _ = self._info()
+        m = self.matrix()[:rows, :cols].T
         return m if dtype is None else m.astype(dtype)
 
 

@@ -75,14 +75,15 @@ def test_encode_on_device(pli):
 
 def test_striped_sequence_buffer_like_test_sequence_py(pli):
     """lightmotif-py tests/test_sequence.py:60-75 (TestStripedSequence.test_memoryview): the striped matrix
-    as a 2-D ``[row, column]`` byte buffer."""
+    as the reference's 2-D byte buffer, shape (columns, rows), strides (1, stride): ``[column, row]``
+    (lib.rs:303-317)."""
     A, C, T, G, N = range(5)
     s1 = pli.stripe(lm.EncodedSequence("ATGC"))
     mem = np.asarray(s1)
     assert (mem[0, 0], mem[1, 0], mem[2, 0], mem[3, 0]) == (A, T, G, C)
     s2 = pli.stripe(lm.EncodedSequence("ATGTCCCAACAACGATACCCCGAGCCCATCGCCGTCATCGGCTCGGCATGCAGATTCCCAGGCG"))
     mem = np.asarray(s2)
-    assert mem.shape == (2, 32) and (mem[0, 0], mem[1, 0], mem[0, 1]) == (A, T, G)
+    assert mem.shape == (32, 2) and (mem[0, 0], mem[0, 1], mem[1, 0]) == (A, T, G)   # position i at [i // 2, i % 2]
     # StripedSequence.copy (lib.rs:367): independent of the original, wrap rows included
     s2.configure_wrap(3)
     c = s2.copy()
