@@ -577,6 +577,7 @@ def main() -> None:
             "frac_at_median": round(BYTES_PER_POS * rows * COLS / (kernel_med_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "algorithmic_bytes_per_launch": BYTES_PER_POS * rows * COLS,
             "read_gbs": round(achieved / 5, 1), "write_gbs": round(achieved * 4 / 5, 1),
+            "frac_of_measured_copy": round(achieved / 6290.0, 4),   # MI355X_MICROARCH.md: best measured copy 6.29 TB/s
             "lds_frac": round(lds_bytes_per_s / LDS_PEAK_BYTES_PER_S, 4),
             "lds_note": f"secondary ceiling: {4 * m} B of LDS gathers per position against 256 B/clk/CU x 256 CUs x 2.4 GHz",
         },
