@@ -56,6 +56,7 @@ def test_score_rows_into_writes_only_its_cells(pli, cols, m, k, length, ostride)
         n = b - a
         buf = torch.full(((n + 2 * PAD_ROWS) * ostride + 8,), CANARY_F32, dtype=torch.int32, device=dev)
         out = buf[PAD_ROWS * ostride: (PAD_ROWS + n) * ostride]
+        torch.cuda.synchronize()        # the canary fill runs on torch's stream, the kernels on the context's own
         orow, _ = pli.score_dptr(pssm, seq.data_ptr(), seq.shape[0], seq.shape[1], cols, m - 1, length, a, b,
                                  out.data_ptr(), ostride)
         torch.cuda.synchronize()
@@ -83,6 +84,7 @@ def test_score_u8_writes_only_its_cells(pli, cols, m, k, length, saturate):
     dev = seq.device
     buf = torch.full(((n + 2 * PAD_ROWS) * ostride + 32,), CANARY_U8, dtype=torch.uint8, device=dev)
     out = buf[PAD_ROWS * ostride: (PAD_ROWS + n) * ostride]
+    torch.cuda.synchronize()
     orow, _ = pli.score_u8_dptr(dm, seq.data_ptr(), seq.shape[0], seq.shape[1], cols, m - 1, length, a, b,
                                 out.data_ptr(), ostride, saturate=saturate)
     torch.cuda.synchronize()
@@ -109,6 +111,7 @@ def test_stripe_and_wrap_write_only_their_rows(pli, cols, length, wrap):
     buf = torch.full(((rows_total + 2 * PAD_ROWS) * stride_,), CANARY_U8, dtype=torch.uint8, device=dev)
     data = buf[PAD_ROWS * stride_: (PAD_ROWS + rows_total) * stride_]
     d_enc = torch.from_numpy(enc).to(dev)
+    torch.cuda.synchronize()
     pli.stripe_dptr(d_enc.data_ptr(), length, cols, 4, wrap, data.data_ptr(), stride_)
     torch.cuda.synchronize()
     host = buf.cpu().numpy()
