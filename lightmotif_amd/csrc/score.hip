@@ -101,6 +101,12 @@ ScoreC32Launcher score_c32_lookup_c16(int M)
     return (M >= 1 && M <= kMaxFastM) ? g_c32[M][10] : nullptr;
 }
 
+ScoreC32Launcher score_c32_lookup_unrolled2(int M)
+{
+    std::call_once(g_c32_once, init_registry);
+    return (M >= 1 && M <= kMaxFastM) ? g_c32[M][11] : nullptr;
+}
+
 ScoreC32Launcher score_c32_lookup_ql(int M)
 {
     std::call_once(g_c32_once, init_registry);
@@ -275,7 +281,9 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
         const size_t mp = a.pssm->m + a.pssm->lead;
         const MotifShape ms{mp, a.pssm->k, false};
         const C32Plan pp = plan_c32(ctx, ms, a, true, 0, 1, store_rows_hint(mp, a.cols), true);
-        const ScoreC32Launcher pfn = a.cols == 16 ? score_c32_lookup_c16((int)mp) : score_c32_lookup_ql((int)mp);
+        ScoreC32Launcher pfn = a.cols == 16 ? score_c32_lookup_c16((int)mp) : score_c32_lookup_ql((int)mp);
+        if (pp.ok && a.cols == 32 && ctx->unroll_main && pp.T == 3 * mp + 1 && score_c32_lookup_unrolled2((int)mp))
+            pfn = score_c32_lookup_unrolled2((int)mp);
         if (pp.ok && pfn) {
             fo.lead_rows = (unsigned)a.pssm->lead;
             ctx->last_kernel = score_c32_name((int)mp, MODE_STORE);
@@ -294,6 +302,8 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
             fn = score_c32_lookup_ql((int)a.pssm->m);  // dword symbol loads (M % 4 == 0)
         if (c16)
             fn = score_c32_lookup_c16((int)a.pssm->m);  // four streams of 16 columns per wavefront
+        else if (dwords && ctx->unroll_main && p.T == 3 * a.pssm->m + 1 && score_c32_lookup_unrolled2((int)a.pssm->m))
+            fn = score_c32_lookup_unrolled2((int)a.pssm->m);  // both MAIN groups unrolled: exact s_waitcnt
         ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_STORE);
         LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
                       a.row_begin, a.row_end, p.T, p.nstreams, a.d_out, fo));
