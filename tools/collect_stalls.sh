@@ -24,6 +24,13 @@ GROUPS_=(
  "TCC_HIT_sum TCC_MISS_sum TCC_TAG_STALL_sum TCC_BUSY_sum"
  "GRBM_GUI_ACTIVE GRBM_COUNT"
 )
+if [ "$3" = tlb ]; then   # third argument "tlb": address-translation counters only
+GROUPS_=(
+ "TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS_sum"
+ "TCP_UTCL1_STALL_INFLIGHT_MAX_sum TCP_UTCL1_STALL_MULTI_MISS_sum TCP_UTCL1_THRASHING_STALL_sum TCP_UTCL1_STALL_LFIFO_NO_RES_sum"
+ "TCP_TCC_WRITE_REQ_sum TCP_TCC_WRITE_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum"
+)
+fi
 i=0
 for G in "${GROUPS_[@]}"; do
   i=$((i+1))
@@ -38,17 +45,17 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for p in glob.glob(out + "/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(p)):
         n = r["Kernel_Name"]
-        if "lm::" not in n and "kb::" not in n:
+        if "lm::" not in n and "kb::" not in n and "mix_" not in n and not n.startswith("fill"):
             continue
-        k = n[n.index("::") - 2:].split("(")[0][:48]
+        k = (n[n.index("::") - 2:] if "::" in n.split("(")[0] else n.replace("void ", "")).split("(")[0][:48]
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 # kernel durations of the same passes (ns), to turn GRBM_GUI_ACTIVE into a clock
 for p in glob.glob(out + "/g*/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(p)):
         n = r["Kernel_Name"]
-        if "lm::" not in n and "kb::" not in n:
+        if "lm::" not in n and "kb::" not in n and "mix_" not in n and not n.startswith("fill"):
             continue
-        k = n[n.index("::") - 2:].split("(")[0][:48]
+        k = (n[n.index("::") - 2:] if "::" in n.split("(")[0] else n.replace("void ", "")).split("(")[0][:48]
         acc[k]["duration_ns(all passes)"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
 with open(out + "/summary.txt", "w") as f:
     for k in sorted(acc):
