@@ -776,16 +776,31 @@ static std::vector<JobGroup> group_jobs(const lm_hip_ctx *ctx, const ScoreArgs *
 // global indices (argmax) or direct appends to the hit list (threshold).  Same values as the
 // materialised matrix, hence the same results; the buffer never exceeds 512 MB however long the
 // sequence.
+// The same detour pays for column counts other than 32 whose rows are whole 16-byte pieces (C = 16: the
+// unrolled four-stream store kernel, 690 Gpos/s; C = 4, 8, ...: score_tiled) once the input is large
+// enough for two more launches not to matter: their fused forms otherwise run one thread per cell
+// (45-70 Gpos/s).
 static bool chunked_ok(const lm_hip_ctx *ctx, const ScoreArgs &a)
 {
-    return ctx->chunked_fused && !a.pssm->parts.empty() && a.cols == 32 && a.seq_stride == 32 &&
-           reinterpret_cast<uintptr_t>(a.d_seq) % 4 == 0 && a.row_end - a.row_begin > (size_t)kMaxFastM;
+    if (!ctx->chunked_fused)
+        return false;
+    const unsigned long long n = a.row_end - a.row_begin;
+    if (a.cols == 32)
+        return !a.pssm->parts.empty() && a.seq_stride == 32 && reinterpret_cast<uintptr_t>(a.d_seq) % 4 == 0 &&
+               n > (unsigned long long)kMaxFastM;
+    return a.cols >= 4 && a.cols % 4 == 0 && a.cols <= 4096 && n * a.cols >= (1ull << 16) && n > a.pssm->m;
+}
+
+// rows per chunk: ctx->chunk_rows is quoted for C = 32; other column counts keep the chunk's cell count
+static unsigned long long chunk_rows_for(const lm_hip_ctx *ctx, const ScoreArgs &a)
+{
+    return std::max<unsigned long long>((unsigned long long)ctx->chunk_rows * 32 / a.cols, 1);
 }
 
 static unsigned long long chunk_count(const lm_hip_ctx *ctx, const ScoreArgs &a)
 {
-    const unsigned long long n = a.row_end - a.row_begin;
-    return (n + ctx->chunk_rows - 1) / ctx->chunk_rows;
+    const unsigned long long n = a.row_end - a.row_begin, per = chunk_rows_for(ctx, a);
+    return (n + per - 1) / per;
 }
 
 // Workgroups of the per-chunk argmax (a full chunk is 2^25 cells)
@@ -800,8 +815,8 @@ template <typename PerChunk>
 static int for_each_scored_chunk(lm_hip_ctx *ctx, const ScoreArgs &a, PerChunk f)
 {
     const unsigned long long n = a.row_end - a.row_begin;
-    const unsigned long long chunk = std::min<unsigned long long>(n, ctx->chunk_rows);
-    LM_TRY(ctx->chunk_scores.reserve(chunk * 32 * sizeof(float)));
+    const unsigned long long chunk = std::min<unsigned long long>(n, chunk_rows_for(ctx, a));
+    LM_TRY(ctx->chunk_scores.reserve(chunk * a.cols * sizeof(float)));
     float *buf = static_cast<float *>(ctx->chunk_scores.ptr);
     for (unsigned long long c0 = 0; c0 < n; c0 += chunk) {
         const unsigned long long c1 = std::min(n, c0 + chunk);
@@ -809,17 +824,19 @@ static int for_each_scored_chunk(lm_hip_ctx *ctx, const ScoreArgs &a, PerChunk f
         b.row_begin = a.row_begin + c0;
         b.row_end = a.row_begin + c1;
         b.d_out = buf;
-        b.out_stride = 32;
+        b.out_stride = a.cols;  // contiguous rows: the flat reductions apply
         LM_TRY(launch_score_store(ctx, b));
         LM_TRY(f(buf, c0, c1 - c0));
     }
-    ctx->last_kernel = "score_c32_sliced+reduce";
+    ctx->last_kernel = a.cols == 32 ? "score_c32_sliced+reduce" : "score_store+reduce";
     return LM_HIP_OK;
 }
 
-// Appends every cell >= t of a contiguous C = 32 chunk to the hit list (rows relative to the job).
+// Appends every cell >= t of a contiguous chunk (stride == cols, cols % 4 == 0) to the hit list (rows relative to
+// the job).
 __global__ __launch_bounds__(kBlock) void chunk_emit_hits(const float *__restrict__ s, const unsigned long long ncells,
-                                                          const unsigned long long row_base, const FusedOut fo)
+                                                          const unsigned long long row_base, const unsigned cols,
+                                                          const FusedOut fo)
 {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const f32x4 *s4 = reinterpret_cast<const f32x4 *>(s);
@@ -830,12 +847,13 @@ __global__ __launch_bounds__(kBlock) void chunk_emit_hits(const float *__restric
         const f32x4 x = __builtin_nontemporal_load(&s4[i]);
         if (!(x.x >= t || x.y >= t || x.z >= t || x.w >= t))
             continue;
-        const unsigned long long row = row_base + i / 8;
-        const unsigned col = (unsigned)(i % 8) * 4;
-        if (x.x >= t) record_hit(fo, row, col, 32u, x.x);
-        if (x.y >= t) record_hit(fo, row, col + 1, 32u, x.y);
-        if (x.z >= t) record_hit(fo, row, col + 2, 32u, x.z);
-        if (x.w >= t) record_hit(fo, row, col + 3, 32u, x.w);
+        const unsigned per_row = cols / 4;
+        const unsigned long long row = row_base + i / per_row;
+        const unsigned col = (unsigned)(i % per_row) * 4;
+        if (x.x >= t) record_hit(fo, row, col, cols, x.x);
+        if (x.y >= t) record_hit(fo, row, col + 1, cols, x.y);
+        if (x.z >= t) record_hit(fo, row, col + 2, cols, x.z);
+        if (x.w >= t) record_hit(fo, row, col + 3, cols, x.w);
     }
 }
 
@@ -927,9 +945,9 @@ static int launch_score_argmax_exact(lm_hip_ctx *ctx, const ScoreArgs *jobs, siz
             // (always on ctx->stream: the chunk buffer is shared)
             const unsigned cg = chunk_argmax_grid(ctx);
             ArgmaxRecord *recs = fo.block_best;
-            const unsigned long long per = ctx->chunk_rows;
+            const unsigned long long per = chunk_rows_for(ctx, a);
             LM_TRY(for_each_scored_chunk(ctx, a, [&](const float *buf, unsigned long long c0, unsigned long long rows) {
-                return launch_argmax_blocks_flat(ctx, ctx->stream, buf, rows * 32, (long long)(c0 * 32), cg,
+                return launch_argmax_blocks_flat(ctx, ctx->stream, buf, rows * a.cols, (long long)(c0 * a.cols), cg,
                                                  recs + (c0 / per) * cg);
             }));
         } else {
@@ -1290,10 +1308,11 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
             } else if (g.kind == KIND_CHUNKED) {  // appends hits directly, chunk by chunk, on ctx->stream
                 const FusedOut cfo = fo;
                 LM_TRY(for_each_scored_chunk(ctx, a, [&](const float *buf, unsigned long long c0, unsigned long long rows) {
-                    const unsigned long long ncells = rows * 32;
+                    const unsigned long long ncells = rows * a.cols;
                     const unsigned grid = (unsigned)std::max<unsigned long long>(
                         std::min<unsigned long long>((ncells / 4 + kBlock - 1) / kBlock, (unsigned long long)ctx->num_cus * 16), 1);
-                    hipLaunchKernelGGL(chunk_emit_hits, dim3(grid), dim3(kBlock), 0, ctx->stream, buf, ncells, c0, cfo);
+                    hipLaunchKernelGGL(chunk_emit_hits, dim3(grid), dim3(kBlock), 0, ctx->stream, buf, ncells, c0,
+                                       (unsigned)a.cols, cfo);
                     LM_HIP_TRY(hipGetLastError());
                     return (int)LM_HIP_OK;
                 }));

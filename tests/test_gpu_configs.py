@@ -538,7 +538,16 @@ def test_sixteen_columns_take_the_unrolled_store_kernel(pli, m, k):
     want, _ = co.score_rows(ref, p)
     pli.score_into(pssm, seq, scores)
     assert pli.argmax(scores) == co.argmax(want, 16)
-    assert pli.score_argmax(pssm, seq)[0] == co.argmax(want, 16)
+    # the fused forms: the same store kernel into a chunk buffer + a reduction per chunk
+    got = pli.score_argmax(pssm, seq)
+    assert pli.last_kernel == "score_store+reduce", pli.last_kernel
+    assert got[0] == co.argmax(want, 16) and bits(np.float32(got[1])) == bits(co.max_(want, 16))
+    finite = np.sort(want[:, :16][np.isfinite(want[:, :16])])
+    for t in (float(finite[-30]), float(finite[-3000])):
+        wrc = [tuple(map(int, rc)) for rc in co.threshold(want, 16, t)]
+        frc, fval = pli.score_threshold(pssm, seq, t)
+        assert pli.last_kernel == "score_store+reduce", pli.last_kernel
+        assert frc == wrc and np.array_equal(bits(fval), bits([want[r, c] for r, c in wrc]))
 
 
 @pytest.mark.parametrize("cols,m,k", [(16, 33, 5), (1, 15, 5), (2, 7, 5), (33, 12, 5), (16, 70, 5),
@@ -564,3 +573,14 @@ def test_other_geometries_take_the_tiled_kernel(pli, cols, m, k):
         assert pli.last_kernel == "score_tiled", pli.last_kernel
         assert np.array_equal(bits(scores.matrix()[:, :cols]), bits(want[:, :cols])), (cols, m, a, b)
     assert pli.argmax(scores) == co.argmax(want, cols)
+    # fused forms on the last range: chunked store + reduction where the rows are whole 16-byte pieces, else cell by cell
+    a, b = ref.rows - 3, ref.rows
+    big = pli.score_argmax(pssm, seq)
+    assert pli.last_kernel == ("score_store+reduce" if cols % 4 == 0 else "score_generic<1>"), pli.last_kernel
+    full, _ = co.score_rows(ref, p)
+    assert big[0] == co.argmax(full, cols)
+    finite = np.sort(full[:, :cols][np.isfinite(full[:, :cols])])
+    t = float(finite[-200])
+    wrc = [tuple(map(int, rc)) for rc in co.threshold(full, cols, t)]
+    frc, fval = pli.score_threshold(pssm, seq, t)
+    assert frc == wrc and np.array_equal(bits(fval), bits([full[r, c] for r, c in wrc]))
