@@ -237,8 +237,13 @@ def config_shapes(pli):
         for _ in range(3):
             pli.score_into(pssm, seq, scores)
         t = timeit(lambda: pli.score_into(pssm, seq, scores), 10)
-        out["rows"].append({"C": cols, "M": m, "kernel": pli.last_kernel, "ms": round(t * 1e3, 3),
-                            "Gpos_per_s": round(length / t / 1e9, 1)})
+        row = {"C": cols, "M": m, "kernel": pli.last_kernel, "ms": round(t * 1e3, 3),
+               "Gpos_per_s": round(length / t / 1e9, 1)}
+        pli.score_argmax(pssm, seq)
+        tf = timeit(lambda: pli.score_argmax(pssm, seq), 5)      # fused argmax, call wall incl. read-back
+        row.update({"fused_argmax_kernel": pli.last_kernel, "fused_argmax_ms": round(tf * 1e3, 3),
+                    "fused_argmax_Gpos_per_s": round(length / tf / 1e9, 1)})
+        out["rows"].append(row)
         del seq, scores
     return out
 
