@@ -1836,7 +1836,21 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
 // argmax is the answer: no later cell exists, and no earlier cell can beat B.  Otherwise (the
 // best k-mer is absent from the suffix) the job takes the usual routes.  On the JASPAR batch
 // the motifs up to length 9 (61 % of them) are settled from ~5 % of the rows or less.
-constexpr double kSuffixExpectedOccurrences = 24.0;
+// How many best k-mers the suffix should hold on average.  With lambda = cells / (K-1)^M expected in the whole
+// range, scanning a fraction f costs f + exp(-lambda * f) of a full scan (the miss falls back to the usual
+// routes), minimal at f = ln(lambda) / lambda: the suffix holds ln(lambda) occurrences, between 1.5 (a miss
+// every fifth motif, still a net gain) and 8.  Round 1 used a flat 24: never a miss, four times the rows
+// (JASPAR batch 14.0-14.7 -> 11.0 ms; LM_HIP_SUFFIX_OCCURRENCES=<x> pins the value for A/B runs).
+static double suffix_occurrences(double lambda)
+{
+    static const double pinned = [] {
+        const char *e = getenv("LM_HIP_SUFFIX_OCCURRENCES");
+        return e && atof(e) > 0 ? atof(e) : 0.0;
+    }();
+    if (pinned > 0)
+        return pinned;
+    return std::min(8.0, std::max(1.5, std::log(std::max(lambda, 1.0))));
+}
 constexpr unsigned long long kSuffixMinRows = 1ull << 15;  // keeps the streams long enough
 
 static int argmax_by_suffix(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n, ArgmaxRecord *out,
@@ -1857,9 +1871,12 @@ static int argmax_by_suffix(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n, Ar
             continue;
         const unsigned long long rows = a.row_end - a.row_begin;
         const double kmers = std::pow((double)(p->k - 1), (double)p->m);
-        const double need_cells = kSuffixExpectedOccurrences * kmers;
-        if (!(need_cells < 1e15))
+        if (!(kmers < 1e15))
             continue;
+        const double lambda = (double)rows * (double)a.cols / kmers;
+        if (lambda < 2.0)
+            continue;  // a best k-mer is not expected in the range at all
+        const double need_cells = suffix_occurrences(lambda) * kmers;
         const unsigned long long need_rows =
             std::max<unsigned long long>((unsigned long long)(need_cells / (double)a.cols) + 1, kSuffixMinRows);
         const bool dense = (double)need_rows * (double)a.cols / kmers > 256.0;  // expected hits at t = B
