@@ -231,21 +231,36 @@ def main_c3(args) -> None:
         return
     cells = sum(length + 1 - m for m in lengths)
     value = cells * args.steps / elapsed / 1e9
+
+    def best_kmer(p):      # the sequential f32 sum of the row maxima: no score exceeds it (score.hip best_kmer_score)
+        b = np.float32(0)
+        for row in p.data[:, :4]:
+            b = np.float32(b + row.max())
+        return b
+    unreachable = [i for i, (p, t) in enumerate(zip(pssms, ts)) if np.float32(t) > best_kmer(p)]
+    scanned_cells = cells - sum(length + 1 - lengths[i] for i in unreachable)
     out = {
         "metric": "scored (motif, position) cells/sec, fused threshold scan", "value": round(value, 1), "unit": "Gcell/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u16 prefilter + f32 re-scoring",
         "data": "synthetic sequence (SplitMix64), JASPAR 2024 CORE matrices (reference fixture)",
         "config": {"workload": f"configs[2]: {len(pssms)} JASPAR DNA PSSMs (sum M = {sum(lengths)}) x {length} bp resident, "
-                               "fused threshold at p = 1e-5 per motif, hits in the reference's order",
+                               "fused threshold at p = 1e-5 per motif, hits in the reference's order; "
+                               f"{len(unreachable)} motifs (all of length <= {max([lengths[i] for i in unreachable] or [0])}) "
+                               "cannot reach p = 1e-5 -- their threshold exceeds the score of their best k-mer -- and "
+                               "are answered (no hits) without a scan unless LM_HIP_SKIP_UNREACHABLE=0; `value` counts "
+                               "their cells as done, `extras.scanned_Gcell_s` does not",
                    "parallelism": f"motif-shard x{world} (LPT on sum M), sequence replicated",
                    "motifs_per_rank": [len(p) for p in parts]},
-        "extras": {"hits_total": int(sum(len(c) for c, _ in res)), "fused_argmax_ms": round(am_s * 1e3, 3),
+        "extras": {"hits_total": int(sum(len(c) for c, _ in res)),
+                   "motifs_unreachable_at_p": len(unreachable),
+                   "scanned_Gcell_s": round(scanned_cells * args.steps / elapsed / 1e9, 1),
+                   "fused_argmax_ms": round(am_s * 1e3, 3),
                    "fused_argmax_Gcell_s": round(cells / am_s / 1e9, 1),
                    "argmax_found": int(sum(a is not None for a in am))},
         "roofline": None,
-        "roofline_note": "issue-bound scans over a cache-resident sequence: the PMC-based fraction of the VALU issue "
-                         "rate is in profiles/r02_c3_record.md; no HBM fraction applies",
+        "roofline_note": "LDS-gather-bound scans over a cache-resident sequence: the PMC-based LDS / VALU utilisation "
+                         "per kernel is in profiles/r02_c3_record.md; no HBM fraction applies",
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_c3(shard, rows, length, max_m, pssms, res, am, args.cpu_seconds)

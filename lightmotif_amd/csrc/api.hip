@@ -339,6 +339,8 @@ static int ctx_create(int device, void *stream, bool borrow, lm_hip_ctx **out)
         ctx->multi_motif = atoi(e) != 0;
     if (const char *e = getenv("LM_HIP_QUAD_LOADS"))  // A/B switch of the store kernel's symbol loads
         ctx->quad_loads = atoi(e) != 0;
+    if (const char *e = getenv("LM_HIP_SKIP_UNREACHABLE"))  // A/B switch: 0 = scan even when no cell can reach the threshold
+        ctx->skip_unreachable = atoi(e) != 0;
     if (const char *e = getenv("LM_HIP_UNROLL_MAIN"))  // A/B switch of the store kernel: 0 = MAIN groups as a loop
         ctx->unroll_main = atoi(e) != 0;
     if (const char *e = getenv("LM_HIP_PAIR_PREFILTER"))  // A/B switch: 0 = one symbol per lookup

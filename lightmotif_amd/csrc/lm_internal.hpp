@@ -104,6 +104,7 @@ struct lm_hip_ctx {
     bool speculate_order = true; // fused threshold: order the hit list before the host knows its length
     bool suffix_argmax = true;   // fused argmax of short motifs: try the last rows first (score.hip)
     bool multi_motif = true;     // many-motif threshold batches: several motifs of one length per pass
+    bool skip_unreachable = true; // fused threshold: no scan when the threshold exceeds the best k-mer's score
     int num_cus = 256;
     unsigned long long last_hit_count = 0;  // sizes the next fused-threshold hit list
     unsigned long long last_cand_count = 0; // ... and its candidate list

@@ -727,8 +727,23 @@ __global__ __launch_bounds__(kBlock) void argmax_finalize_batch(const FinalizeJo
 // alphabet and sequence rows.  Many short per-motif launches lose ~15 % to their ramps
 // and to the short streams a small grid needs; a launch per motif LENGTH keeps streams
 // long and the chip full (2 346 JASPAR motifs -> ~50 launches).
-enum : int { KIND_GENERIC = 0, KIND_EXACT = 1, KIND_PREFILTER = 2, KIND_PREFILTER2 = 3, KIND_CHUNKED = 4 };
+enum : int { KIND_GENERIC = 0, KIND_EXACT = 1, KIND_PREFILTER = 2, KIND_PREFILTER2 = 3, KIND_CHUNKED = 4, KIND_SKIP = 5 };
 static inline bool kind_solo(int kind) { return kind == KIND_GENERIC || kind == KIND_CHUNKED; }
+// B = the score of a best k-mer: the row maxima added in motif order.  It bounds every score of the matrix from
+// above -- f32 rounding is monotone, so termwise larger weights added in the same order cannot give a smaller
+// sum -- provided the weights hold no NaN / +inf (lm_hip_pssm::has_prefilter).
+static float best_kmer_score(const lm_hip_pssm *p)
+{
+    float b = 0.0f;
+    for (size_t j = 0; j < p->m; ++j) {
+        float best = p->host[j * p->k];
+        for (size_t s = 1; s < p->k; ++s)
+            best = p->host[j * p->k + s] > best ? p->host[j * p->k + s] : best;
+        b = b + best;
+    }
+    return b;
+}
+
 struct JobGroup {
     int kind = KIND_GENERIC;
     std::vector<size_t> idx;  // job indices, ascending
@@ -745,6 +760,8 @@ static std::vector<JobGroup> group_jobs(const lm_hip_ctx *ctx, const ScoreArgs *
     for (size_t i = 0; i < n; ++i) {
         const ScoreArgs &a = jobs[i];
         const int kind = kind_of(i);
+        if (kind == KIND_SKIP)
+            continue;  // provably nothing to report: no launch
         if (kind_solo(kind)) {  // one launch (or chain of launches) each
             groups.push_back(JobGroup{kind, {i}, C32Plan{}});
             continue;
@@ -1185,6 +1202,11 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
     std::vector<unsigned> tds(n, 0);
     const std::vector<JobGroup> groups = group_jobs(ctx, jobs, n, [&](size_t i) {
         const ScoreArgs &a = jobs[i];
+        // A threshold above the best k-mer's score selects nothing, whatever the sequence: such a job is not
+        // scanned at all.  (At the CLI's p = 1e-5 that is every motif too short to reach the p-value -- 1 042 of
+        // the 2 346 JASPAR matrices, all of length <= 8 -- which the reference scans like any other.)
+        if (ctx->skip_unreachable && a.pssm->has_prefilter && a.pssm->m >= 1 && ts[i] > best_kmer_score(a.pssm))
+            return (int)KIND_SKIP;
         if (a.pssm->has_prefilter && ctx->use_prefilter && std::isfinite(ts[i])) {
             const double scaled = std::floor(((double)ts[i] - a.pssm->pre_offset) / a.pssm->pre_factor) -
                                   std::ceil(a.pssm->pre_emax / a.pssm->pre_factor) - 1.0;
@@ -1882,13 +1904,7 @@ static int argmax_by_suffix(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n, Ar
         const bool dense = (double)need_rows * (double)a.cols / kmers > 256.0;  // expected hits at t = B
         if (need_rows > (dense ? rows / 4 : rows / 2))
             continue;
-        float b = 0.0f;  // the score of a best k-mer: row maxima added in motif order
-        for (size_t j = 0; j < p->m; ++j) {
-            float best = p->host[j * p->k];
-            for (size_t s = 1; s < p->k; ++s)
-                best = p->host[j * p->k + s] > best ? p->host[j * p->k + s] : best;
-            b = b + best;
-        }
+        const float b = best_kmer_score(p);
         if (!std::isfinite(b))
             continue;
         ScoreArgs sub = a;

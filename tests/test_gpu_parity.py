@@ -394,6 +394,57 @@ def test_protein_pair_prefilter_opt_in(monkeypatch, m):
     assert frc == [tuple(map(int, rc)) for rc in co.threshold(want, 32, t)]
 
 
+def test_thresholds_above_the_best_kmer_are_not_scanned(pli, monkeypatch):
+    """A threshold above B = the sequential f32 sum of the PSSM's row maxima selects nothing whatever the
+    sequence (rounding is monotone), so the fused threshold skips the scan; at t == B the planted best k-mer
+    must still be found, and the batch form must keep its per-motif layout when some motifs are skipped."""
+    rng = np.random.default_rng(77)
+    length = 300_007
+    enc = rng.integers(0, 4, length, dtype=np.uint8)
+    motifs = []
+    for m in (6, 9, 14):
+        p = np.zeros((m, 8), np.float32)
+        p[:, :4] = rng.normal(0, 2, (m, 4))
+        p[:, 4] = -np.inf
+        motifs.append(p)
+    p = motifs[1]
+    cons = np.argmax(p[:, :4], axis=1).astype(np.uint8)
+    enc[200_000:200_000 + len(cons)] = cons
+    b = np.float32(0)
+    for j in range(len(cons)):
+        b = np.float32(b + p[j, cons[j]])
+    ref = co.stripe(enc, 32, 5)
+    co.configure_wrap(ref, 13)
+    seq = pli.stripe(lm.EncodedSequence(enc), 32)
+    seq.configure_wrap(13)
+    pssm = lm.ScoringMatrix(p)
+    want, _ = co.score_rows(ref, p)
+    above = float(np.nextafter(b, np.float32(np.inf)))
+    pli.score_argmax(pssm, seq)                               # (sets last_kernel to something else)
+    before = pli.last_kernel
+    assert pli.score_threshold(pssm, seq, above) == ([], [])
+    assert pli.last_kernel == before                          # nothing was launched
+    frc, fval = pli.score_threshold(pssm, seq, float(b))
+    wrc = [tuple(map(int, rc)) for rc in co.threshold(want, 32, float(b))]
+    assert frc == wrc and len(frc) >= 1 and all(v == float(b) for v in fval)
+    # batch: the middle motif's threshold is unreachable, the others' are not
+    pssms = [lm.ScoringMatrix(q) for q in motifs]
+    wants = [co.score_rows(ref, q)[0] for q in motifs]
+    ts = [float(np.sort(wants[0][:, :32][np.isfinite(wants[0][:, :32])])[-40]), above,
+          float(np.sort(wants[2][:, :32][np.isfinite(wants[2][:, :32])])[-40])]
+    res = pli.scan_threshold_batch(pssms, ts, seq)
+    for (coords, vals), w, t in zip(res, wants, ts):
+        wrc = [tuple(map(int, rc)) for rc in co.threshold(w, 32, t)]
+        assert [tuple(map(int, rc)) for rc in coords] == wrc
+    assert len(res[1][0]) == 0 and len(res[0][0]) >= 40
+    monkeypatch.setenv("LM_HIP_SKIP_UNREACHABLE", "0")
+    full = lm.Pipeline.hip(0)
+    seq2 = full.stripe(lm.EncodedSequence(enc), 32)
+    seq2.configure_wrap(13)
+    assert full.score_threshold(lm.ScoringMatrix(p), seq2, above) == ([], [])
+    assert full.last_kernel.startswith("score_c32")          # ... which the switch turns back into a scan
+
+
 def test_million_positions_bitwise(pli):
     rng = np.random.default_rng(99)
     enc = rng.integers(0, 4, 1_000_003, dtype=np.uint8)
