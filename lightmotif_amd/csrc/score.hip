@@ -421,8 +421,50 @@ __global__ __launch_bounds__(kBlock) void score_generic_u8(
     }
 }
 
+// out[i] = out[i] + add[i] per byte, saturating at 255 or wrapping mod 256, four cells per lane-word.
+__global__ __launch_bounds__(kBlock) void u8_combine(unsigned *__restrict__ out, const unsigned *__restrict__ add,
+                                                     const unsigned long long nwords, const int saturate)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < nwords;
+         i += (unsigned long long)gridDim.x * kBlock) {
+        const unsigned a = out[i], b = add[i];
+        const unsigned sum = ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u);  // bytewise, no carries across
+        const unsigned carry = ((a & b) | ((a | b) & ~sum)) & 0x80808080u;                      // bytes that overflowed
+        out[i] = saturate ? (sum | ((carry >> 7) * 0xffu)) : sum;
+    }
+}
+
 int launch_score_u8(lm_hip_ctx *ctx, const DiscreteArgs &a)
 {
+    // Motifs beyond kMaxFastM at C = 32: slices of <= kMaxFastM rows through the fast kernels, the first into the
+    // score matrix, the others into a temporary, added bytewise.  Exact for both flavours: u8 weights are
+    // non-negative, so saturating partial sums combine to min(255, total); wrapping sums are sums mod 256.
+    if (a.m > (size_t)kMaxFastM && a.cols == 32 && a.seq_stride == 32 && a.out_stride == 32 &&
+        reinterpret_cast<uintptr_t>(a.d_out) % 4 == 0 && a.row_end > a.row_begin + (size_t)kMaxFastM) {
+        const size_t nslices = (a.m + kMaxFastM - 1) / kMaxFastM, len = (a.m + nslices - 1) / nslices;
+        const unsigned long long n = a.row_end - a.row_begin;
+        LM_TRY(ctx->chunk_scores.reserve(n * 32));
+        uint8_t *tmp = static_cast<uint8_t *>(ctx->chunk_scores.ptr);
+        for (size_t off = 0; off < a.m; off += len) {
+            DiscreteArgs part = a;
+            part.weights = a.weights + off * a.wstride;
+            part.m = std::min(len, a.m - off);
+            part.d_seq = a.d_seq + off * a.seq_stride;  // slice row j reads sequence row r + off + j
+            part.d_out = off == 0 ? a.d_out : tmp;
+            LM_TRY(launch_score_u8(ctx, part));
+            if (off) {
+                const unsigned long long nwords = n * 32 / 4;
+                const unsigned grid = (unsigned)std::min<unsigned long long>((nwords + kBlock - 1) / kBlock,
+                                                                             (unsigned long long)ctx->num_cus * 16);
+                hipLaunchKernelGGL(u8_combine, dim3(grid), dim3(kBlock), 0, ctx->stream,
+                                   reinterpret_cast<unsigned *>(a.d_out), reinterpret_cast<const unsigned *>(tmp), nwords,
+                                   a.saturate ? 1 : 0);
+                LM_HIP_TRY(hipGetLastError());
+            }
+        }
+        ctx->last_kernel = "score_c32_u8_sliced";
+        return LM_HIP_OK;
+    }
     const int m = (int)a.m, k = (int)a.k;
     const unsigned wrap_mask = a.saturate ? 0u : 0xffu;
     // plan with the f32 planner: same stream geometry as the packed prefilter scans.  DNA takes

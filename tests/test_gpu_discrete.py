@@ -57,6 +57,7 @@ CASES = [  # (length, m, protein, weight ceiling, columns)
     (65_000, 33, False, 7, 32), (65_000, 36, False, 255, 32), (30_000, 12, True, 21, 32),
     (30_000, 12, True, 255, 32), (3000, 9, False, 28, 16), (3000, 9, False, 255, 1),
     (20_000, 40, False, 255, 32), (64, 15, False, 17, 32), (40, 36, False, 255, 32),
+    (300_007, 37, False, 6, 32), (300_007, 73, False, 255, 32), (100_003, 100, False, 3, 32), (50_000, 64, True, 4, 32),
 ]
 
 
@@ -86,7 +87,9 @@ def test_u8_scores_reductions_and_row_ranges(pli, length, m, protein, top, cols)
                 assert np.array_equal(part[:, :cols], want[a:b, :cols])
     if cols == 32 and 1 <= m <= 36 and rows >= (m | 3) + 3:
         assert pli.last_kernel == ("score_c32_u8_pairs" if PAIRS and not protein and m >= 2 else "score_c32_u8")
-    elif cols != 32 or m > 36:
+    elif cols == 32 and m > 36 and rows // 2 > 40:
+        assert pli.last_kernel == "score_c32_u8_sliced"     # slices of <= 36 rows through the fast kernels, added bytewise
+    elif cols != 32:
         assert pli.last_kernel == "score_generic_u8"
     if want_sat.shape[0] == 0:
         return
