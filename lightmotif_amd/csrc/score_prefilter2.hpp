@@ -29,6 +29,10 @@
 
 #include "score_prefilter.hpp"
 
+#ifndef LM_PREFILTER2_PFB
+#define LM_PREFILTER2_PFB 3  // 4-row symbol blocks requested ahead of use in the pair scans
+#endif
+
 namespace lm {
 
 // padded length M' = 3 (mod 4) -- except 8 <= M <= 11, which go to M' = 15 instead of 11: a table row of
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(kBlock, KA == 5 ? 6 : 4) void score_c32_prefilter2(
     const unsigned shq = 8u * (col & 3);
     const uint8_t *spq = seq + (in0 + (col & 3)) * 32 + (col >> 2) * 4;  // this lane's row of a block
     constexpr int NB = RING / 4;
-    constexpr int PFB = NB > 3 ? 3 : NB;                       // blocks requested ahead of use (<= NB:
+    constexpr int PFB = NB > LM_PREFILTER2_PFB ? LM_PREFILTER2_PFB : NB;                       // blocks requested ahead of use (<= NB:
                                                                // a request reuses a slot only after its last read)
     unsigned acc[NP];
     unsigned blk[NB];
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(kBlock, 4) void score_c32_prefilter2_multi(
     const unsigned shq = 8u * (col & 3);
     const uint8_t *spq = seq + (in0 + (col & 3)) * 32 + (col >> 2) * 4;
     constexpr int NB = RING / 4;
-    constexpr int PFB = NB > 3 ? 3 : NB;
+    constexpr int PFB = NB > LM_PREFILTER2_PFB ? LM_PREFILTER2_PFB : NB;
     unsigned acc[NM][NP];
     unsigned blk[NB];
 #pragma unroll

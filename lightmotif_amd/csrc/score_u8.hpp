@@ -14,6 +14,10 @@
 
 #include "score_prefilter2.hpp"
 
+#ifndef LM_PREFILTER2_PFB
+#define LM_PREFILTER2_PFB 3  // 4-row symbol blocks requested ahead of use in the pair scans
+#endif
+
 namespace lm {
 
 // `image` = prefilter image built from the u8 weights (api.hip: pack_prefilter_image);
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_u8_pairs(
     const unsigned shq = 8u * (col & 3);
     const uint8_t *spq = seq + (in0 + (col & 3)) * 32 + (col >> 2) * 4;  // this lane's row of a block
     constexpr int NB = RING / 4;
-    constexpr int PFB = NB > 3 ? 3 : NB;
+    constexpr int PFB = NB > LM_PREFILTER2_PFB ? LM_PREFILTER2_PFB : NB;
     unsigned acc[NP];
     unsigned blk[NB];
 #pragma unroll
