@@ -424,6 +424,10 @@ def test_thresholds_above_the_best_kmer_are_not_scanned(pli, monkeypatch):
     before = pli.last_kernel
     assert pli.score_threshold(pssm, seq, above) == ([], [])
     assert pli.last_kernel == before                          # nothing was launched
+    sc = lm.Scanner(pssm, seq, threshold=above)               # the Scanner's hit list through the same shortcut
+    assert len(sc.positions) == 0 and list(sc) == []
+    sc = lm.Scanner(pssm, seq, threshold=float(b))
+    assert 200_000 in sc.positions.tolist() and all(h.score == float(b) for h in sc)
     frc, fval = pli.score_threshold(pssm, seq, float(b))
     wrc = [tuple(map(int, rc)) for rc in co.threshold(want, 32, float(b))]
     assert frc == wrc and len(frc) >= 1 and all(v == float(b) for v in fval)
