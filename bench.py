@@ -194,7 +194,18 @@ def main_c3(args) -> None:
     torch.cuda.synchronize()
     seq = pli.adopt_sequence(shard.data_ptr(), rows, max_m - 1, COLS, COLS, length, keepalive=shard)
     ts = [p.score_for_pvalue(1e-5) for p in pssms]
-    parts = D.shard_motifs(lengths, world)
+
+    def best_kmer(p):      # the sequential f32 sum of the row maxima: no score exceeds it (score.hip best_kmer_score)
+        b = np.float32(0)
+        for row in p.data[:, :4]:
+            b = np.float32(b + row.max())
+        return b
+    unreachable = [i for i, (p, t) in enumerate(zip(pssms, ts)) if np.float32(t) > best_kmer(p)]
+    # shard on the expected cost of a motif's scan (profiles/r02_c3_per_length.txt: ~16-byte table reads per pair of
+    # positions), not on its bare length: a motif that cannot reach the threshold costs (almost) nothing
+    skip = set(unreachable)
+    cost = [0.02 if i in skip else (1 + (m | 3) // 8) for i, m in enumerate(lengths)]
+    parts = D.shard_motifs(cost, world)
     for i in parts[rank]:
         pssms[i]._device(pli)
 
@@ -232,12 +243,6 @@ def main_c3(args) -> None:
     cells = sum(length + 1 - m for m in lengths)
     value = cells * args.steps / elapsed / 1e9
 
-    def best_kmer(p):      # the sequential f32 sum of the row maxima: no score exceeds it (score.hip best_kmer_score)
-        b = np.float32(0)
-        for row in p.data[:, :4]:
-            b = np.float32(b + row.max())
-        return b
-    unreachable = [i for i, (p, t) in enumerate(zip(pssms, ts)) if np.float32(t) > best_kmer(p)]
     scanned_cells = cells - sum(length + 1 - lengths[i] for i in unreachable)
     out = {
         "metric": "scored (motif, position) cells/sec, fused threshold scan", "value": round(value, 1), "unit": "Gcell/s",
@@ -250,7 +255,7 @@ def main_c3(args) -> None:
                                "cannot reach p = 1e-5 -- their threshold exceeds the score of their best k-mer -- and "
                                "are answered (no hits) without a scan unless LM_HIP_SKIP_UNREACHABLE=0; `value` counts "
                                "their cells as done, `extras.scanned_Gcell_s` does not",
-                   "parallelism": f"motif-shard x{world} (LPT on sum M), sequence replicated",
+                   "parallelism": f"motif-shard x{world} (LPT on the expected scan cost per motif), sequence replicated",
                    "motifs_per_rank": [len(p) for p in parts]},
         "extras": {"hits_total": int(sum(len(c) for c, _ in res)),
                    "motifs_unreachable_at_p": len(unreachable),

@@ -49,9 +49,11 @@ def shard_rows(total_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
     return a, b
 
 
-def shard_motifs(lengths: Sequence[int], world_size: int) -> List[List[int]]:
-    """Partition a motif list over ranks balancing sum(M) (cost is proportional to
-    the motif length): longest-processing-time greedy.  Returns motif indices per rank."""
+def shard_motifs(lengths: Sequence[float], world_size: int) -> List[List[int]]:
+    """Partition a motif list over ranks balancing the sum of per-motif weights -- the motif
+    lengths, or any better cost estimate (``bench.py --config c3`` passes the expected scan cost:
+    table reads per position, ~0 for a motif whose threshold no cell can reach):
+    longest-processing-time greedy.  Returns motif indices per rank."""
     order = sorted(range(len(lengths)), key=lambda i: -lengths[i])
     load = [0] * world_size
     out: List[List[int]] = [[] for _ in range(world_size)]
