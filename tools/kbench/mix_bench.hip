@@ -98,6 +98,46 @@ __global__ __launch_bounds__(256) void mix_rows(const uint8_t *in, float *out, u
     }
 }
 
+// mix_rows with the store's cache-policy bits chosen by hand (gfx940-family syntax: sc0 / sc1 = coherence scope,
+// nt = non-temporal): does any policy change what the row pattern costs the memory side?
+template <int POL>
+__device__ __forceinline__ void store_policy(float *p, float v)
+{
+    if (POL == 0) asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    if (POL == 1) asm volatile("global_store_dword %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+    if (POL == 2) asm volatile("global_store_dword %0, %1, off sc0" ::"v"(p), "v"(v) : "memory");
+    if (POL == 3) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    if (POL == 4) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    if (POL == 5) asm volatile("global_store_dword %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+    if (POL == 6) asm volatile("global_store_dword %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+}
+template <int PFD, int POL>
+__global__ __launch_bounds__(256) void mix_rows_pol(const uint8_t *in, float *out, unsigned long long rows,
+                                                    unsigned long long T)
+{
+    const unsigned long long stream = ((unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + ((threadIdx.x & 63) >> 5);
+    const unsigned col = threadIdx.x & 31;
+    unsigned long long r0 = stream * T;
+    if (r0 >= rows) return;
+    unsigned long long r1 = r0 + T < rows ? r0 + T : rows;
+    const uint8_t *ip = in + r0 * 32 + col;
+    float *op = out + r0 * 32 + col;
+    unsigned ring[PFD];
+#pragma unroll
+    for (int k = 0; k < PFD; ++k) ring[k] = ip[k * 32];
+    for (unsigned long long r = r0; r < r1; r += PFD) {
+#pragma unroll
+        for (int k = 0; k < PFD; ++k) {
+            const unsigned s = ring[k];
+            ring[k] = ip[(k + PFD) * 32];
+            if (r + k < r1)
+                store_policy<POL>(op + k * 32, (float)s);
+        }
+        ip += PFD * 32;
+        op += PFD * 32;
+    }
+}
+
 // the score kernel's pattern with 4 rows gathered per store: lane (c) writes 16 bytes of row
 // r + (c & 3), columns 4*(c >> 2).. -- what a 4x4 quad transpose (DPP, no LDS) would allow:
 // a half-wave store covers 512 contiguous bytes
@@ -293,6 +333,26 @@ int main(int argc, char **argv)
             snprintf(nm, sizeof nm, "mix_rows_lds T=%llu", T);
             const unsigned long long rows8 = rows / T * T;
             rep(nm, timeit([&] { hipLaunchKernelGGL(mix_rows_lds, dim3((unsigned)(rows8 / T / 8)), dim3(256), 0, 0, in, (f32x4 *)out, rows8, T); }, 20));
+        }
+    }
+    {   // the row pattern under every store cache policy (two rounds, interleaved)
+        const unsigned long long rows = n / 32, T = 61;
+        const unsigned grid = (unsigned)(((rows + T - 1) / T + 7) / 8);
+        const char *names[7] = {"(none)", "nt", "sc0", "sc1", "sc0 sc1", "sc0 sc1 nt", "sc1 nt"};
+        for (int round = 0; round < 2; ++round) {
+            float ms[7];
+            ms[0] = timeit([&] { hipLaunchKernelGGL((mix_rows_pol<12, 0>), dim3(grid), dim3(256), 0, 0, in, out, rows, T); }, 20);
+            ms[1] = timeit([&] { hipLaunchKernelGGL((mix_rows_pol<12, 1>), dim3(grid), dim3(256), 0, 0, in, out, rows, T); }, 20);
+            ms[2] = timeit([&] { hipLaunchKernelGGL((mix_rows_pol<12, 2>), dim3(grid), dim3(256), 0, 0, in, out, rows, T); }, 20);
+            ms[3] = timeit([&] { hipLaunchKernelGGL((mix_rows_pol<12, 3>), dim3(grid), dim3(256), 0, 0, in, out, rows, T); }, 20);
+            ms[4] = timeit([&] { hipLaunchKernelGGL((mix_rows_pol<12, 4>), dim3(grid), dim3(256), 0, 0, in, out, rows, T); }, 20);
+            ms[5] = timeit([&] { hipLaunchKernelGGL((mix_rows_pol<12, 5>), dim3(grid), dim3(256), 0, 0, in, out, rows, T); }, 20);
+            ms[6] = timeit([&] { hipLaunchKernelGGL((mix_rows_pol<12, 6>), dim3(grid), dim3(256), 0, 0, in, out, rows, T); }, 20);
+            for (int p = 0; p < 7; ++p) {
+                char nm[64];
+                snprintf(nm, sizeof nm, "mix_rows T=61 store %s", names[p]);
+                rep(nm, ms[p]);
+            }
         }
     }
     return 0;
