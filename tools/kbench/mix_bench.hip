@@ -355,5 +355,15 @@ int main(int argc, char **argv)
             }
         }
     }
+    {   // the row pattern at reduced occupancy (unused dynamic LDS as ballast): fewer streams open at once
+        const unsigned long long rows = n / 32, T = 61;
+        const unsigned grid = (unsigned)(((rows + T - 1) / T + 7) / 8);
+        for (unsigned lds : {0u, 20u << 10, 40u << 10, 53u << 10, 80u << 10, 160u << 10}) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mix_rows<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+            char nm[64];
+            snprintf(nm, sizeof nm, "mix_rows T=61 lds=%uK", lds >> 10);
+            rep(nm, timeit([&] { hipLaunchKernelGGL(mix_rows<12>, dim3(grid), dim3(256), lds, 0, in, out, rows, T); }, 20));
+        }
+    }
     return 0;
 }
