@@ -304,7 +304,11 @@ __global__ __launch_bounds__(kBlock, KA == 5 ? 6 : 4) void score_c32_prefilter2(
 // whose td = 0xffffffff flags nothing).
 constexpr int prefilter2_multi(int m)  // motifs per pass: bounded by the accumulator registers
 {
+#ifdef LM_PREFILTER2_NM3  // experiment: three motifs per pass for M' = 19, 23
+    return prefilter2_npair(m) <= 8 ? 4 : prefilter2_npair(m) <= 12 ? 3 : prefilter2_npair(m) <= 16 ? 2 : 1;
+#else
     return prefilter2_npair(m) <= 8 ? 4 : prefilter2_npair(m) <= 16 ? 2 : 1;
+#endif
 }
 
 template <int M, int NM, int PFB, int PHASE>
