@@ -225,6 +225,14 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const Score
     const unsigned long long per_block = c16 ? 2 * kStreamsPerBlock : kStreamsPerBlock;
     p.grid = dim3((unsigned)((p.nstreams + per_block - 1) / per_block));
     p.lds = lds;
+    if (store && prefilter == 0) {  // experiment: unused LDS as ballast = fewer wavefronts per CU = a smaller
+        static const size_t ballast = [] {  // window of rows being written at once (<= 64 KB per workgroup without opt-in)
+            const char *e = getenv("LM_HIP_LDS_BALLAST_KB");
+            return e ? (size_t)atoi(e) * 1024 : (size_t)0;
+        }();
+        if (ballast && p.lds < ballast && ballast <= 64 * 1024)
+            p.lds = ballast;
+    }
     p.ok = true;
     return p;
 }

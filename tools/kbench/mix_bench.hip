@@ -98,6 +98,21 @@ __global__ __launch_bounds__(256) void mix_rows(const uint8_t *in, float *out, u
     }
 }
 
+// XCD <-> memory affinity test: workgroup b (dispatched to XCD b % 8) writes the contiguous chunk of `chunk16` float4
+// number c, where c = b (mode 0), b ^ 1 (mode 1), b rotated by 3 inside its group of eight (mode 2) or bit-reversed
+// inside its group of 256 (mode 3).  If a workgroup's XCD had "near" and "far" addresses, the modes would differ.
+__global__ __launch_bounds__(256) void fill_chunks(f32x4 *out, unsigned long long chunk16, int mode)
+{
+    unsigned long long b = blockIdx.x, c = b;
+    if (mode == 1) c = b ^ 1ull;
+    if (mode == 2) c = (b & ~7ull) | ((b + 3) & 7ull);
+    if (mode == 3) c = (b & ~255ull) | (__brev((unsigned)(b & 255)) >> 24);
+    f32x4 *p = out + c * chunk16;
+    const f32x4 v = {1.0f, 2.0f, 3.0f, 4.0f};
+    for (unsigned long long i = threadIdx.x; i < chunk16; i += 256)
+        __builtin_nontemporal_store(v, &p[i]);
+}
+
 // mix_rows with the store's cache-policy bits chosen by hand (gfx940-family syntax: sc0 / sc1 = coherence scope,
 // nt = non-temporal): does any policy change what the row pattern costs the memory side?
 template <int POL>
@@ -333,6 +348,17 @@ int main(int argc, char **argv)
             snprintf(nm, sizeof nm, "mix_rows_lds T=%llu", T);
             const unsigned long long rows8 = rows / T * T;
             rep(nm, timeit([&] { hipLaunchKernelGGL(mix_rows_lds, dim3((unsigned)(rows8 / T / 8)), dim3(256), 0, 0, in, (f32x4 *)out, rows8, T); }, 20));
+        }
+    }
+    {   // XCD <-> address affinity: 4 GB written in chunks of 4 KB ... 1 MB per workgroup under four chunk permutations
+        for (unsigned long long chunk_bytes : {4096ull, 16384ull, 65536ull, 1048576ull}) {
+            const unsigned long long chunk16 = chunk_bytes / 16, nchunks = (n * 4) / chunk_bytes / 256 * 256;
+            for (int mode = 0; mode < 4; ++mode) {
+                char nm[64];
+                snprintf(nm, sizeof nm, "fill_chunks %lluK mode %d", chunk_bytes >> 10, mode);
+                float ms = timeit([&] { hipLaunchKernelGGL(fill_chunks, dim3((unsigned)nchunks), dim3(256), 0, 0, (f32x4 *)out, chunk16, mode); }, 20);
+                printf("%-28s %8.3f ms  %7.1f GB/s\n", nm, ms, (double)nchunks * chunk_bytes / ms / 1e6);
+            }
         }
     }
     {   // the row pattern under every store cache policy (two rounds, interleaved)
