@@ -843,10 +843,10 @@ static std::vector<JobGroup> group_jobs(const lm_hip_ctx *ctx, const ScoreArgs *
 // global indices (argmax) or direct appends to the hit list (threshold).  Same values as the
 // materialised matrix, hence the same results; the buffer never exceeds 512 MB however long the
 // sequence.
-// The same detour pays for column counts other than 32 whose rows are whole 16-byte pieces (C = 16: the
-// unrolled four-stream store kernel, 690 Gpos/s; C = 4, 8, ...: score_tiled) once the input is large
-// enough for two more launches not to matter: their fused forms otherwise run one thread per cell
-// (45-70 Gpos/s).
+// The same detour pays for every column count other than 32 (C = 16: the unrolled four-stream store kernel,
+// 690 Gpos/s; the others: score_tiled into DENSE rows -- at C = 1 that is 4 instead of 32 bytes written per
+// position) once the input is large enough for two more launches not to matter: their fused forms
+// otherwise run one thread per cell (30-70 Gpos/s).
 static bool chunked_ok(const lm_hip_ctx *ctx, const ScoreArgs &a)
 {
     if (!ctx->chunked_fused)
@@ -855,7 +855,7 @@ static bool chunked_ok(const lm_hip_ctx *ctx, const ScoreArgs &a)
     if (a.cols == 32)
         return !a.pssm->parts.empty() && a.seq_stride == 32 && reinterpret_cast<uintptr_t>(a.d_seq) % 4 == 0 &&
                n > (unsigned long long)kMaxFastM;
-    return a.cols >= 4 && a.cols % 4 == 0 && a.cols <= 4096 && n * a.cols >= (1ull << 16) && n > a.pssm->m;
+    return a.cols >= 1 && a.cols <= 4096 && n * a.cols >= (1ull << 16) && n > a.pssm->m;
 }
 
 // rows per chunk: ctx->chunk_rows is quoted for C = 32; other column counts keep the chunk's cell count
@@ -899,8 +899,8 @@ static int for_each_scored_chunk(lm_hip_ctx *ctx, const ScoreArgs &a, PerChunk f
     return LM_HIP_OK;
 }
 
-// Appends every cell >= t of a contiguous chunk (stride == cols, cols % 4 == 0) to the hit list (rows relative to
-// the job).
+// Appends every cell >= t of a contiguous chunk (stride == cols) to the hit list (rows relative to the job): float4
+// reads when the rows are whole 16-byte pieces (cols % 4 == 0), one cell per thread otherwise.
 __global__ __launch_bounds__(kBlock) void chunk_emit_hits(const float *__restrict__ s, const unsigned long long ncells,
                                                           const unsigned long long row_base, const unsigned cols,
                                                           const FusedOut fo)
@@ -909,6 +909,15 @@ __global__ __launch_bounds__(kBlock) void chunk_emit_hits(const float *__restric
     const f32x4 *s4 = reinterpret_cast<const f32x4 *>(s);
     const unsigned long long n4 = ncells / 4;
     const float t = fo.threshold;
+    if (cols % 4 != 0) {
+        for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < ncells;
+             i += (unsigned long long)gridDim.x * kBlock) {
+            const float x = s[i];
+            if (x >= t)
+                record_hit(fo, row_base + i / cols, (unsigned)(i % cols), cols, x);
+        }
+        return;
+    }
     for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < n4;
          i += (unsigned long long)gridDim.x * kBlock) {
         const f32x4 x = __builtin_nontemporal_load(&s4[i]);
