@@ -423,7 +423,9 @@ def main() -> None:
     scores_h.set_first_cell_rule(rank == 0)
     pli.set_track_argmax(sharded)              # N = 1 times the plain store kernel (configs[1])
 
-    pipelined = comm is not None and not args.sync_merge
+    # merge transport of the sharded step: 2 = C ABI, pipelined; 1 = C ABI, one wait per step; 0 = torch.distributed.
+    # Chosen by a probe of three steps before the preheat: a transport that raises on any rank is dropped on all.
+    mode = {"v": 2 if (comm is not None and not args.sync_merge) else 1 if comm is not None else 0}
 
     def run_steps(n, events=None):
         """N = 1: one score_into (pli/mod.rs:109-117) into the resident StripedScores per step.
@@ -443,12 +445,12 @@ def main() -> None:
                 events[i][1].record(stream)
             if not sharded:
                 continue
-            if pipelined:
+            if mode["v"] == 2:
                 ticket = comm.argmax_sharded_begin(scores_h, row0)
                 if pending is not None:
                     merged = comm.argmax_sharded_end(pending)
                 pending = ticket
-            elif comm is not None:
+            elif mode["v"] == 1:
                 merged = comm.argmax_sharded(scores_h, row0)   # device-side all_gather + combine, one read-back
             else:
                 loc = pli.argmax_handle_shard(scores_h, first_cell_rule=rank == 0)
@@ -461,6 +463,22 @@ def main() -> None:
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    while sharded and mode["v"] > 0:            # probe the transport (identical failures on every rank are the expected kind)
+        try:
+            run_steps(3)
+            ok = 1
+        except lm.LightmotifHipError as e:
+            ok = 0
+            comm_note = f"C-ABI merge (mode {mode['v']}) failed in the probe ({e}); degraded"
+        if world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device=coll_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            break
+        mode["v"] -= 1
+    pipelined = mode["v"] == 2
 
     # time-based preheat (outside the counted warm-up), then the W counted warm-up steps
     t_pre = time.perf_counter()
@@ -572,7 +590,7 @@ def main() -> None:
             traffic = None
     step_desc = ("score_into" if not sharded else
                  "score_into of the rank's row shard + tracked shard argmax + RCCL merge of the argmax records "
-                 f"({'C-ABI communicator' if comm is not None else 'torch.distributed ' + args.dist_backend}"
+                 f"({'C-ABI communicator' if mode['v'] > 0 else 'torch.distributed ' + args.dist_backend}"
                  + ("; pipelined: the merge of step i overlaps the scoring of step i+1, every step's result is "
                     "collected on the host inside the timed region" if pipelined else "") + ")")
     out = {
