@@ -6,6 +6,7 @@ row-sharded with an M-1-row halo, configs[3]).
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...      (no launcher: re-executes itself under torch.distributed.run)
 
 A *step* is one full ``score_into`` (pli/mod.rs:109-117) of the rank's shard into a
 resident StripedScores matrix: 1 B read + 4 B written per position.  At N > 1 every step
@@ -113,6 +114,66 @@ def synth_pssm(m: int, seed: int = 0x5EED0002) -> lm.ScoringMatrix:
     return lm.create(sites).counts.normalize(0.1).log_odds()
 
 
+def cpu_topology() -> dict:
+    """{sockets, cores, threads, model} of the host from /proc/cpuinfo: `cores` are physical cores
+    (distinct (physical id, core id) pairs), `threads` the hardware threads the OS schedules on."""
+    sockets, cores, threads, model = set(), set(), 0, ""
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            key, _, val = line.partition(":")
+            key, val = key.strip(), val.strip()
+            if key == "processor":
+                threads += 1
+                phys = core = None
+            elif key == "model name" and not model:
+                model = val
+            elif key == "physical id":
+                phys = val
+                sockets.add(val)
+            elif key == "core id":
+                core = val
+                cores.add((phys, core))
+    except OSError:
+        pass
+    threads = threads or (os.cpu_count() or 1)
+    return {"sockets": len(sockets) or 1, "cores": len(cores) or threads, "threads": threads, "model": model}
+
+
+def self_launch(n: int) -> None:
+    """`python bench.py --gpus N` without a launcher: run the same command line as N ranks of one
+    node under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and leave with
+    its exit status.  Rank 0's JSON line reaches this process's stdout through the inherited
+    descriptor."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on these hosts
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["LM_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    print(f"bench.py: --gpus {n} without WORLD_SIZE: launching {n} ranks under torch.distributed.run "
+          f"(port {port})", file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def device_identity(dev: torch.device) -> str:
+    """PCI bus id (or uuid / name) of the GPU a rank runs on: gathered into `config.devices` so the
+    line shows N DISTINCT devices, not N ranks on one."""
+    p = torch.cuda.get_device_properties(dev)
+    for attr in ("pci_bus_id", "uuid"):
+        v = getattr(p, attr, None)
+        if v not in (None, ""):
+            if attr == "pci_bus_id":
+                return f"{getattr(p, 'pci_domain_id', 0):04x}:{int(v):02x}:{int(getattr(p, 'pci_device_id', 0)):02x}"
+            return str(v)
+    return f"{p.name}#{dev.index}"
+
+
 def cpu_baseline(seq_sample: np.ndarray, length: int, pssm: np.ndarray, gpu_scores: np.ndarray,
                  seconds: float) -> dict:
     """Times the AVX2 port of the reference back-end (oracle/lm_avx2.c follows
@@ -142,20 +203,51 @@ def cpu_baseline(seq_sample: np.ndarray, length: int, pssm: np.ndarray, gpu_scor
 
     one = run(1, seconds / 2)
     allc = run(threads, seconds / 2)
-    model = ""
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
+    topo = cpu_topology()
     return {
-        "value": round(allc, 3), "unit": "Gpos/s", "cores": threads, "kind": "port",
+        "value": round(allc, 3), "unit": "Gpos/s", "cores": topo["cores"], "threads": threads,
+        "sockets": topo["sockets"], "kind": "port",
         "sample": f"first {rows * COLS} positions of rank 0's shard, AVX2 port of avx2.rs:104-199 "
-                  f"(oracle/lm_avx2.c), rows split over {threads} threads, ~{seconds:.0f} s of CPU work",
-        "single_thread_gpos": round(one, 3), "cpu_model": model, "gpu_matches_cpu_bitwise": verified,
+                  f"(oracle/lm_avx2.c), rows split over {threads} software threads = every hardware thread of "
+                  f"{topo['sockets']} socket(s) x {topo['cores'] // max(topo['sockets'], 1)} cores "
+                  f"({topo['cores']} physical cores, SMT {threads // max(topo['cores'], 1)}), ~{seconds:.0f} s of CPU work",
+        "single_thread_gpos": round(one, 3), "cpu_model": topo["model"], "gpu_matches_cpu_bitwise": verified,
     }
+
+
+def init_ranks(args):
+    """World of this run.  Under a launcher (torch.distributed.run: WORLD_SIZE / RANK / LOCAL_RANK in
+    the environment) the environment is authoritative -- `--gpus` that disagrees is noted in the
+    line, not fatal.  Without one, `--gpus N > 1` launches the N ranks itself (self_launch).  The
+    process group gets a bounded timeout so that a rank that died raises on the others instead of
+    hanging them."""
+    import datetime
+    note = None
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if not args.single_device and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus}: this node shows {torch.cuda.device_count()} GPU(s)")
+        self_launch(args.gpus)                          # does not return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        note = f"--gpus {args.gpus} but the launcher started {world} rank(s): the launcher's world is used"
+    if not args.single_device and local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    coll_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where collectives run
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        timeout = datetime.timedelta(seconds=args.comm_timeout_s)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=timeout)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world, timeout=timeout)
+    # the C ABI's collectives wait this long at most (csrc/comm.hip: bounded waits)
+    os.environ.setdefault("LM_HIP_COMM_TIMEOUT_MS", str(int(args.comm_timeout_s * 1000)))
+    return world, rank, local_rank, dev, coll_dev, note
 
 
 def main_c3(args) -> None:
@@ -168,18 +260,7 @@ def main_c3(args) -> None:
     gather.  Value = (motif, position) cells per second over all ranks; scaling is STRONG (the
     total work is fixed)."""
     from lightmotif_amd import io as lmio
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    coll_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    world, rank, local_rank, dev, coll_dev, launch_note = init_ranks(args)
     pssms = [r.matrix.normalize(0.1).log_odds() for r in lmio.read(ROOT / "tests" / "golden" / "JASPAR2024.pwm.gz")]
     if args.motifs:
         pssms = pssms[:args.motifs]
@@ -330,6 +411,141 @@ def cpu_baseline_c3(shard, rows, length, max_m, pssms, gpu_thr, gpu_am, seconds:
             "gpu_hits_match_on_sample": bool(ok)}
 
 
+def secondary_configs(pli, dev) -> dict:
+    """BASELINE.json configs[0], [2], [4] on this box, after the timed region of the headline run (a
+    few seconds in all): the driver's line then carries every single-GPU configuration, not only
+    configs[1].  Times are wall time per call from this process (launch + synchronisation included)
+    unless marked `kernel_ms` (HIP events on the launch stream)."""
+    out = {}
+    stream = torch.cuda.current_stream()
+
+    def wall(fn, reps, warm=3):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    def events(fn, reps, warm=5):
+        for _ in range(warm):
+            fn()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:
+            a.record(stream)
+            fn()
+            b.record(stream)
+        torch.cuda.synchronize()
+        return float(np.median([a.elapsed_time(b) for a, b in ev]))
+
+    # --- configs[0]: lightmotif-bench/dna.rs:81-109 as is -- MX000001 (M = 15) over the first tenth of
+    # E. coli K12 (464 165 bp; a seeded random stand-in with the site planted at 391 677: the genome file is
+    # absent from the reference mount), one StripedScores re-used, timed body = score_into + argmax
+    length = 464_165
+    rng = np.random.default_rng(0xEC011)
+    enc = rng.integers(0, 4, length, dtype=np.uint8)
+    enc[391_677:391_677 + 15] = lm.EncodedSequence("GTTGACCTTATCAAC").data
+    pssm = lm.create(["GTTGACCTTATCAAC", "GTTGATCCAGTCAAC"]).counts.normalize(0.1).log_odds()
+    c1 = {"workload": "configs[0]: MX000001 (M = 15) x 464165 bp stand-in for E. coli/10 (site planted at 391677), "
+                      "score_into + argmax per iteration into one re-used StripedScores (dna.rs:104-107)"}
+    for cols, tag in ((32, "C32_dispatch_geometry"), (1, "C1_generic_bench_geometry")):
+        seq = pli.stripe(lm.EncodedSequence(enc), cols)
+        seq.configure(pssm)
+        scores = lm.StripedScores.empty(pli, cols)
+        best = [None]
+
+        def it():
+            pli.score_into(pssm, seq, scores)
+            best[0] = pli.argmax(scores)
+        t = wall(it, 300, warm=20)
+        k_store = pli.last_kernel
+        tf = wall(lambda: pli.score_argmax(pssm, seq), 300, warm=20)
+        c1[tag] = {"us_per_iter": round(t * 1e6, 2), "Mpos_per_s": round(length / t / 1e6, 1),
+                   "best_position": int(scores.offset(*best[0])), "kernel": k_store,
+                   "fused_score_argmax_us": round(tf * 1e6, 2), "fused_kernel": pli.last_kernel}
+        del seq, scores
+    out["c1"] = c1
+
+    # --- configs[4]: protein (K = 21) len-12 PSSM x 200 Mres: score() materialised + fused threshold
+    length, m = 200_000_000, 12
+    rows = -(-length // COLS)
+    prng = np.random.default_rng(5)
+    sym = lm.lib.PROTEIN_SYMBOLS[:-1]
+    sites = ["".join(sym[i] for i in prng.integers(0, len(sym), m)) for _ in range(6)]
+    ppssm = lm.create(sites, protein=True).counts.normalize(0.1).log_odds()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(55)
+    pseq = torch.empty((rows + m - 1, COLS), dtype=torch.uint8, device=dev)
+    pseq[:rows] = torch.randint(0, 20, (rows, COLS), dtype=torch.uint8, device=dev, generator=gen)
+    pli.configure_wrap_dptr(pseq.data_ptr(), rows, COLS, COLS, m - 1, 20)
+    pout = torch.empty((rows, COLS), dtype=torch.float32, device=dev)
+
+    def pscore():
+        pli.score_dptr(ppssm, pseq.data_ptr(), rows + m - 1, COLS, COLS, m - 1, length, 0, rows, pout.data_ptr(), COLS)
+    for _ in range(30):
+        pscore()
+    kms = events(pscore, 50)
+    k_store = pli.last_kernel
+    sample = pout[: 1 << 18].flatten()
+    thr = float(torch.quantile(sample[torch.isfinite(sample)].float(), 1 - 1e-5))
+    fth = lambda: pli.score_threshold_dptr(ppssm, pseq.data_ptr(), rows + m - 1, COLS, COLS, m - 1, length, 0, rows, thr)  # noqa: E731
+    t_th = wall(fth, 20)
+    k_th = pli.last_kernel
+    n_hits = len(fth()[0])
+    fam = lambda: pli.score_argmax_dptr(ppssm, pseq.data_ptr(), rows + m - 1, COLS, COLS, m - 1, length, 0, rows)  # noqa: E731
+    t_am = wall(fam, 20)
+    out["c5"] = {"workload": "configs[4]: protein (K = 21) len-12 PSSM x 200 Mres, score() materialised",
+                 "kernel": k_store, "kernel_ms": round(kms, 4), "Gpos_per_s": round(rows * COLS / kms / 1e6, 1),
+                 "hbm_frac": round(BYTES_PER_POS * rows * COLS / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "fused_threshold_ms": round(t_th * 1e3, 4), "fused_threshold_kernel": k_th, "fused_threshold_hits": n_hits,
+                 "fused_argmax_ms": round(t_am * 1e3, 4), "fused_argmax_kernel": pli.last_kernel}
+    del pseq, pout
+
+    # --- configs[2]: the 2 346 JASPAR 2024 CORE matrices x 100 Mbp, fused threshold at p = 1e-5 per motif
+    from lightmotif_amd import io as lmio
+    fixture = ROOT / "tests" / "golden" / "JASPAR2024.pwm.gz"
+    if fixture.exists():
+        pssms = [r.matrix.normalize(0.1).log_odds() for r in lmio.read(fixture)]
+        lengths = [len(p) for p in pssms]
+        max_m = max(lengths)
+        length = 100_000_000
+        rows = -(-length // COLS)
+        shard = synth_shard(rows, 0, rows, length, max_m - 1, dev, seed=0x5EED0003)
+        pli.configure_wrap_dptr(shard.data_ptr(), rows, COLS, COLS, max_m - 1, 4)
+        torch.cuda.synchronize()
+        seq = pli.adopt_sequence(shard.data_ptr(), rows, max_m - 1, COLS, COLS, length, keepalive=shard)
+        ts = [p.score_for_pvalue(1e-5) for p in pssms]
+        for p in pssms:
+            p._device(pli)
+        res = [None]
+
+        def scan():
+            res[0] = pli.scan_threshold_batch(pssms, ts, seq)
+        t_th = wall(scan, 5, warm=2)
+        k_th = pli.last_kernel
+        t_am = wall(lambda: pli.scan_argmax_batch(pssms, seq), 5, warm=2)
+        cells = sum(length + 1 - mm for mm in lengths)
+
+        def best_kmer(p):
+            b = np.float32(0)
+            for row in p.data[:, :4]:
+                b = np.float32(b + row.max())
+            return b
+        unreachable = [i for i, (p, t) in enumerate(zip(pssms, ts)) if np.float32(t) > best_kmer(p)]
+        scanned = cells - sum(length + 1 - lengths[i] for i in unreachable)
+        out["c3"] = {"workload": f"configs[2]: {len(pssms)} JASPAR 2024 CORE DNA PSSMs (sum M = {sum(lengths)}) x "
+                                 f"{length} bp resident, one batched fused threshold scan at p = 1e-5 per motif",
+                     "fused_threshold_ms": round(t_th * 1e3, 3), "Gcell_per_s": round(cells / t_th / 1e9, 1),
+                     "scanned_Gcell_per_s": round(scanned / t_th / 1e9, 1), "motifs_skipped_unreachable": len(unreachable),
+                     "hits_total": int(sum(len(c) for c, _ in res[0])), "kernel": k_th,
+                     "fused_argmax_ms": round(t_am * 1e3, 3), "fused_argmax_kernel": pli.last_kernel}
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="c2", choices=["c2", "c3"],
@@ -356,6 +572,10 @@ def main() -> None:
     ap.add_argument("--merge", default="auto", choices=["auto", "cabi", "torch"],
                     help="transport of the per-step argmax merge at N > 1: the C ABI's own RCCL communicator "
                          "(lm_hip_comm_*, default on nccl) or torch.distributed (gloo runs)")
+    ap.add_argument("--comm-timeout-s", type=float, default=120.0,
+                    help="N > 1: bound on every collective's wait (process group and the C ABI's communicator)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip extras.configs (configs[0], [2], [4] of BASELINE.json after the timed region)")
     ap.add_argument("--ab", action="store_true",
                     help="development: interleaved A/B of the store kernel's tuning knobs, then exit")
     args = ap.parse_args()
@@ -365,23 +585,7 @@ def main() -> None:
             args.steps, args.warmup = 10, 3
         return main_c3(args)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes "
-                         f"(WORLD_SIZE={world})")
-    if args.single_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    coll_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where collectives run
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    world, rank, local_rank, dev, coll_dev, launch_note = init_ranks(args)
 
     m = args.motif_len
     rows = -(-args.length // COLS)            # striped rows owned by this rank
@@ -394,6 +598,24 @@ def main() -> None:
     shard = synth_shard(rows, row0, total_rows, total_length, m - 1, dev)
     D.exchange_halo(shard, m - 1, COLS, 4)              # RCCL all_gather of (M-1) x 32 bytes per rank
     torch.cuda.synchronize()
+    # self-check of the hand-over: the halo the exchange delivered == the same rows drawn straight from the
+    # generator (the successor's first M-1 rows; on the last rank rank 0's rows as wrap rows, seq.rs:373-378)
+    if rank < world - 1:
+        want_halo = synth_shard(m - 1, row0 + rows, total_rows, total_length, 0, dev)
+    else:
+        head = synth_shard(m - 1, 0, total_rows, total_length, 0, dev)
+        want_halo = torch.full_like(head, 4)
+        want_halo[:, :COLS - 1] = head[:, 1:]
+    halo_ok = bool(torch.equal(shard[rows:], want_halo)) if m > 1 else True
+    ident = device_identity(dev)
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (ident, halo_ok))
+        devices, halo_ok = [g[0] for g in gathered], all(g[1] for g in gathered)
+    else:
+        devices = [ident]
+    if not halo_ok:
+        raise SystemExit("halo exchange delivered rows that differ from the generator's: refusing to time a wrong job")
 
     stream = torch.cuda.current_stream()
     pli = lm.Pipeline.hip(local_rank, stream=stream.cuda_stream)
@@ -420,6 +642,7 @@ def main() -> None:
                 comm.close()
                 comm = None
     sharded = world > 1 or comm is not None
+    rccl_ranks = comm.info()[1] if comm is not None else None     # what RCCL itself was initialised with
     scores_h.set_first_cell_rule(rank == 0)
     pli.set_track_argmax(sharded)              # N = 1 times the plain store kernel (configs[1])
 
@@ -603,6 +826,13 @@ def main() -> None:
                         f"(C=32, K=5, {rows} rows + {m - 1} halo rows), scores materialised in HBM; "
                         f"step = {step_desc}",
             "positions_per_gpu": rows * COLS, "motif_len": m, "parallelism": f"row-shard x{world}",
+            "devices": devices, "distinct_devices": len(set(devices)), "halo_verified": halo_ok,
+            "merge_transport": (None if not sharded else
+                                ["torch.distributed:" + args.dist_backend, "C-ABI communicator (lm_hip_argmax_sharded)",
+                                 "C-ABI communicator, pipelined (lm_hip_argmax_sharded_begin/_end)"][mode["v"]]),
+            "rccl_ranks": rccl_ranks if mode["v"] > 0 else (world if world > 1 and args.dist_backend == "nccl" else None),
+            "process_group": None if world == 1 else f"{dist.get_backend()} x{dist.get_world_size()}",
+            **({"launch_note": launch_note} if launch_note else {}),
             "inputs": "SplitMix64 stream seed 0x5EED0001, 2 bits/base (SURVEY 8d), PSSM seed 0x5EED0002",
             "preheat_ms": round(preheat_ms, 1), "preheat_launches": n_pre,
             **({"merge_note": comm_note} if comm_note else {}),
@@ -629,6 +859,8 @@ def main() -> None:
             "kernel_ms_min": round(min(kernel_ms), 4), "kernel_ms_max": round(max(kernel_ms), 4),
         },
     }
+    if world == 1 and not args.no_extras:
+        out["extras"]["configs"] = secondary_configs(pli, dev)
     if world == 1 and not args.no_cpu_baseline:
         srows = min(rows, max(args.cpu_sample // COLS, 1))
         seq_sample = shard[:srows + m - 1].cpu().numpy()

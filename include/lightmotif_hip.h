@@ -181,6 +181,11 @@ int lm_hip_score_f32_dptr(lm_hip_ctx *ctx, const lm_hip_pssm *pssm,
 int lm_hip_argmax_f32_dptr(lm_hip_ctx *ctx, const float *d_scores, size_t rows,
                            size_t stride, size_t cols, int *found,
                            lm_hip_coords *best, float *value);
+/* Maximum::max (pli/mod.rs:158-160) on its own: the value AT that argmax -- NaN when
+ * scores[0][0] is NaN, -inf for an all -inf matrix; *found = 0 (None) when rows == 0.
+ * (NOT Avx2::max_f32, which seeds with 0.0: avx2.rs:438-441.) */
+int lm_hip_max_f32_dptr(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride,
+                        size_t cols, int *found, float *value);
 
 /* Same for one SHARD of a row-partitioned score matrix (multi-GPU):
  * with first_cell_rule = 0 the "scores[0][0] is NaN -> (0,0)" rule is not applied,
@@ -372,6 +377,7 @@ int lm_hip_score_into(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq
 /* Maximum::argmax / max, Threshold::threshold on a resident StripedScores. */
 int lm_hip_argmax(lm_hip_ctx *ctx, const lm_hip_scores *scores, int *found,
                   lm_hip_coords *best, float *value);
+int lm_hip_max(lm_hip_ctx *ctx, const lm_hip_scores *scores, int *found, float *value);
 int lm_hip_threshold(lm_hip_ctx *ctx, const lm_hip_scores *scores, float t,
                      lm_hip_coords **coords, size_t *n);
 
@@ -385,7 +391,15 @@ int lm_hip_threshold(lm_hip_ctx *ctx, const lm_hip_scores *scores, float t,
  * StripedScores::{argmax, max, threshold} return for the WHOLE matrix (scores.rs:181-213);
  * the functions below produce it over RCCL (bound directly by this library: librccl.so.1 is
  * opened on first use; LM_HIP_ERR_COMM when it is absent).  Collectives: every rank of the
- * communicator must make the same call.
+ * communicator must make the same call, with arguments that are valid on every rank or on none
+ * (argument errors are reported before the collective is entered; the one per-shard condition,
+ * a shard shorter than the halo, is exchanged WITH the collective and reported on every rank).
+ * Waits are bounded: a collective that does not complete within LM_HIP_COMM_TIMEOUT_MS
+ * (environment, read by lm_hip_comm_create; default 120000, 0 = wait for ever) -- a peer died or
+ * never made the call -- aborts the communicator (ncclCommAbort) and returns LM_HIP_ERR_COMM,
+ * as does every later call on it; destroy it and make a new one.  Synchronous collectives
+ * (context stream) and pipelined ones (the communicator's side stream) are ordered against each
+ * other on the device, so they may be mixed freely from one host thread.
  */
 
 /* A StripedScores that is one row shard: enabled = 0 when it does NOT hold the matrix's first
@@ -464,6 +478,9 @@ int lm_hip_score_f32(const uint8_t *seq, size_t seq_rows_total, size_t seq_strid
                      float *out, size_t out_stride, size_t *out_rows, size_t *max_index);
 int lm_hip_argmax_f32(const float *scores, size_t rows, size_t stride, size_t cols,
                       int *found, lm_hip_coords *best, float *value);
+/* Maximum::max on a host matrix (pli/mod.rs:158-160; SURVEY 8b export list). */
+int lm_hip_max_f32(const float *scores, size_t rows, size_t stride, size_t cols,
+                   int *found, float *value);
 int lm_hip_threshold_f32(const float *scores, size_t rows, size_t stride, size_t cols, float t,
                          lm_hip_coords **coords, size_t *n);
 

@@ -70,6 +70,7 @@ SIGNATURES = {
     "lm_hip_score_f32_dptr": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz, _vp, _sz,
                                        _szp, _szp]),
     "lm_hip_argmax_f32_dptr": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _ip, _cp, _fp]),
+    "lm_hip_max_f32_dptr": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _ip, _fp]),
     "lm_hip_argmax_shard_f32_dptr": (C.c_int, [_vp, _vp, _sz, _sz, _sz, C.c_int, _ip, _cp, _fp]),
     "lm_hip_threshold_f32_dptr": (C.c_int, [_vp, _vp, _sz, _sz, _sz, C.c_float, C.POINTER(_cp), _szp]),
     "lm_hip_score_u8_dptr": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz,
@@ -105,6 +106,7 @@ SIGNATURES = {
     "lm_hip_score_rows_into": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _vp]),
     "lm_hip_score_into": (C.c_int, [_vp, _vp, _vp, _vp]),
     "lm_hip_argmax": (C.c_int, [_vp, _vp, _ip, _cp, _fp]),
+    "lm_hip_max": (C.c_int, [_vp, _vp, _ip, _fp]),
     "lm_hip_threshold": (C.c_int, [_vp, _vp, C.c_float, C.POINTER(_cp), _szp]),
     # row-sharded jobs
     "lm_hip_seq_adopt_dptr": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz, C.POINTER(_vp)]),
@@ -124,6 +126,7 @@ SIGNATURES = {
     "lm_hip_score_f32": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _sz, _vp, _sz, _sz, _sz, _sz, _sz, _vp,
                                   _sz, _szp, _szp]),
     "lm_hip_argmax_f32": (C.c_int, [_vp, _sz, _sz, _sz, _ip, _cp, _fp]),
+    "lm_hip_max_f32": (C.c_int, [_vp, _sz, _sz, _sz, _ip, _fp]),
     "lm_hip_threshold_f32": (C.c_int, [_vp, _sz, _sz, _sz, C.c_float, C.POINTER(_cp), _szp]),
 }
 

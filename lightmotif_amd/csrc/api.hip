@@ -341,8 +341,6 @@ static int ctx_create(int device, void *stream, bool borrow, lm_hip_ctx **out)
         ctx->quad_loads = atoi(e) != 0;
     if (const char *e = getenv("LM_HIP_SKIP_UNREACHABLE"))  // A/B switch: 0 = scan even when no cell can reach the threshold
         ctx->skip_unreachable = atoi(e) != 0;
-    if (const char *e = getenv("LM_HIP_UNROLL_MAIN"))  // A/B switch of the store kernel: 0 = MAIN groups as a loop
-        ctx->unroll_main = atoi(e) != 0;
     if (const char *e = getenv("LM_HIP_PAIR_PREFILTER"))  // A/B switch: 0 = one symbol per lookup
         ctx->pair_prefilter = atoi(e) != 0;
     if (const char *e = getenv("LM_HIP_PAIR_PREFILTER_PROTEIN"))  // A/B switch: 1 = 441-row pair scan for K = 21
@@ -1430,6 +1428,21 @@ int lm_hip_argmax(lm_hip_ctx *ctx, const lm_hip_scores *s, int *found, lm_hip_co
                                         found, best, value);
 }
 
+// Maximum::max (pli/mod.rs:158-160): `self.argmax(scores).map(|c| scores.matrix()[c])` -- the value AT
+// the Generic argmax (so a NaN first cell gives NaN, an all -inf matrix -inf), None when empty.
+int lm_hip_max(lm_hip_ctx *ctx, const lm_hip_scores *s, int *found, float *value)
+{
+    lm_hip_coords c{0, 0};
+    return lm_hip_argmax(ctx, s, found, &c, value);
+}
+
+int lm_hip_max_f32_dptr(lm_hip_ctx *ctx, const float *d_scores, size_t rows, size_t stride, size_t cols,
+                        int *found, float *value)
+{
+    lm_hip_coords c{0, 0};
+    return lm_hip_argmax_f32_dptr(ctx, d_scores, rows, stride, cols, found, &c, value);
+}
+
 int lm_hip_scores_set_first_cell_rule(lm_hip_scores *s, int enabled)
 {
     if (!s)
@@ -1548,6 +1561,12 @@ int lm_hip_argmax_f32(const float *scores, size_t rows, size_t stride, size_t co
     DeviceGuard guard(ctx->device);
     (void)hipFree(d);
     return st;
+}
+
+int lm_hip_max_f32(const float *scores, size_t rows, size_t stride, size_t cols, int *found, float *value)
+{
+    lm_hip_coords c{0, 0};
+    return lm_hip_argmax_f32(scores, rows, stride, cols, found, &c, value);
 }
 
 int lm_hip_threshold_f32(const float *scores, size_t rows, size_t stride, size_t cols, float t,

@@ -25,7 +25,33 @@
 #include <new>
 #include <vector>
 
+#include <chrono>
+#include <thread>
+
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// A ROCm install without the RCCL development headers: the handful of types the dlopen'ed entry points
+// take, as nccl.h has declared them since NCCL 2.x (the ABI RCCL keeps).
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct {
+    char internal[NCCL_UNIQUE_ID_BYTES];
+} ncclUniqueId;
+typedef enum {
+    ncclSuccess = 0,
+    ncclUnhandledCudaError = 1,
+    ncclSystemError = 2,
+    ncclInternalError = 3,
+    ncclInvalidArgument = 4,
+    ncclInvalidUsage = 5,
+    ncclRemoteError = 6,
+    ncclInProgress = 7
+} ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1 } ncclDataType_t;
+}
+#endif
 
 #include "lm_internal.hpp"
 
@@ -44,14 +70,15 @@ namespace {
 
 struct Rccl {
     void *handle = nullptr;
-    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
-    decltype(&ncclCommInitRank) CommInitRank = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclAllGather) AllGather = nullptr;
-    decltype(&ncclBroadcast) Broadcast = nullptr;
-    decltype(&ncclGroupStart) GroupStart = nullptr;
-    decltype(&ncclGroupEnd) GroupEnd = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
     char why[256] = "";
 };
@@ -84,6 +111,7 @@ Rccl &rccl()
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.handle, "ncclCommAbort"));  // optional
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
         r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
@@ -146,6 +174,8 @@ __global__ void halo_fill(uint8_t *__restrict__ dst, const uint8_t *__restrict__
 struct lm_hip_comm {
     ncclComm_t nccl = nullptr;
     int rank = 0, nranks = 1, device = 0;
+    bool broken = false;  // a collective timed out or failed: the communicator was aborted, every later call fails
+    long long timeout_ms = 120000;  // LM_HIP_COMM_TIMEOUT_MS when the communicator was made; 0 = wait for ever
     lm::Scratch buf;  // device staging of the collectives
     // pipelined argmax merges (lm_hip_argmax_sharded_begin / _end): two slots, each with its own device
     // records and its own pinned read-back area; the all_gather and the read-back run on `side`
@@ -154,6 +184,7 @@ struct lm_hip_comm {
         bool pending = false;
     } slot[2];
     hipStream_t side = nullptr;
+    hipEvent_t side_tail = nullptr;     // the `done` event of the collective enqueued last on `side`
     lm::Scratch abuf;                  // per slot: ArgmaxRecord | MergeRecord mine | MergeRecord all[nranks]
     lm::MergeRecord *h_slots = nullptr;  // pinned, 2 x nranks
     int next = 0;
@@ -161,6 +192,74 @@ struct lm_hip_comm {
 };
 
 using namespace lm;
+
+namespace {
+
+int comm_usable(const lm_hip_comm *comm)
+{
+    if (comm->broken || !comm->nccl)
+        return fail(LM_HIP_ERR_COMM, "the communicator was aborted after a failed or timed-out collective; "
+                                     "destroy it and make a new one on every rank");
+    return LM_HIP_OK;
+}
+
+// A collective that a peer never enters would block its stream for ever.  Every wait on one is a poll
+// with a deadline; past it the communicator is aborted (ncclCommAbort ends the kernel that spins on the
+// missing peer) and the call -- and every later one on this communicator -- returns LM_HIP_ERR_COMM.
+void abort_comm(lm_hip_comm *comm)
+{
+    comm->broken = true;
+    if (comm->nccl && rccl().CommAbort) {
+        (void)rccl().CommAbort(comm->nccl);
+        comm->nccl = nullptr;
+    }
+    for (auto &sl : comm->slot)
+        sl.pending = false;
+}
+
+template <class Query>
+int wait_bounded(lm_hip_comm *comm, Query query, const char *what)
+{
+    using clock = std::chrono::steady_clock;
+    const auto t0 = clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t e = query();
+        if (e == hipSuccess)
+            return LM_HIP_OK;
+        if (e != hipErrorNotReady) {
+            abort_comm(comm);
+            return fail(LM_HIP_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+        }
+        if (spins >= 4096) {  // ~a few hundred microseconds of tight polling cover every healthy merge
+            const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(clock::now() - t0).count();
+            if (comm->timeout_ms > 0 && ms > comm->timeout_ms) {
+                abort_comm(comm);
+                return fail(LM_HIP_ERR_COMM, "%s: no completion after %lld ms (rank %d of %d): a peer rank did not "
+                                             "enter the collective; communicator aborted (LM_HIP_COMM_TIMEOUT_MS)",
+                            what, ms, comm->rank, comm->nranks);
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(ms > 50 ? 200 : 20));
+        }
+    }
+}
+
+int wait_stream(lm_hip_comm *comm, hipStream_t st, const char *what)
+{
+    return wait_bounded(comm, [st] { return hipStreamQuery(st); }, what);
+}
+
+// Collectives of one communicator must not run concurrently: the synchronous entry points use the
+// context's stream, the pipelined merges the communicator's side stream.  A synchronous collective
+// therefore waits (on the device) for the side stream's last one; the side stream already waits for
+// the context stream through each slot's `ready` event.
+int order_after_side(lm_hip_ctx *ctx, lm_hip_comm *comm)
+{
+    if (comm->side_tail)
+        LM_HIP_TRY(hipStreamWaitEvent(ctx->stream, comm->side_tail, 0));
+    return LM_HIP_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -234,6 +333,10 @@ int lm_hip_comm_create(lm_hip_ctx *ctx, const uint8_t *id, int nranks, int rank,
     c->rank = rank;
     c->nranks = nranks;
     c->device = ctx->device;
+    if (const char *t = getenv("LM_HIP_COMM_TIMEOUT_MS")) {
+        const long long v = atoll(t);
+        c->timeout_ms = v < 0 ? 0 : v;
+    }
     ncclUniqueId u;
     memcpy(u.internal, id, LM_HIP_COMM_ID_BYTES);
     ncclResult_t r = rccl().CommInitRank(&c->nccl, nranks, u, rank);
@@ -252,7 +355,8 @@ int lm_hip_comm_destroy(lm_hip_comm *comm)
     DeviceGuard guard(comm->device);
     comm->buf.release();
     if (comm->side) {
-        (void)hipStreamSynchronize(comm->side);
+        if (!comm->broken)
+            (void)hipStreamSynchronize(comm->side);
         (void)hipStreamDestroy(comm->side);
     }
     for (auto &sl : comm->slot) {
@@ -284,22 +388,42 @@ int lm_hip_comm_info(const lm_hip_comm *comm, int *rank, int *nranks)
 int lm_hip_exchange_halo_dptr(lm_hip_ctx *ctx, lm_hip_comm *comm, uint8_t *d_shard, size_t rows,
                               size_t stride, size_t cols, size_t halo_rows, uint8_t default_symbol)
 {
+    // (argument errors of this block must be the same on every rank -- they are properties of the job,
+    //  not of a shard; the one per-shard condition, a shard shorter than the halo, travels WITH the
+    //  collective below so that every rank learns of it and none is left waiting)
     if (!ctx || !comm || cols == 0 || stride < cols || (halo_rows && !d_shard))
         return fail(LM_HIP_ERR_BAD_ARGS, "exchange_halo: bad argument");
     if (halo_rows == 0)
         return LM_HIP_OK;
-    if (rows < halo_rows)
-        return fail(LM_HIP_ERR_BAD_ARGS, "exchange_halo: a shard of %zu rows cannot give %zu halo rows", rows,
-                    halo_rows);
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard guard(ctx->device);
+    LM_TRY(comm_usable(comm));
     const size_t nbytes = halo_rows * stride;
-    LM_TRY(comm->buf.reserve(nbytes * comm->nranks));
-    uint8_t *all = static_cast<uint8_t *>(comm->buf.ptr);
+    const size_t rec = nbytes + 16;  // head rows + a status word (16 bytes keep the records aligned)
+    const int nr = comm->nranks;
+    if ((size_t)nr * 16 > kPinnedBytes)
+        return fail(LM_HIP_ERR_BAD_ARGS, "exchange_halo: too many ranks");
+    LM_TRY(comm->buf.reserve(rec * ((size_t)nr + 1)));
+    uint8_t *mine = static_cast<uint8_t *>(comm->buf.ptr);
+    uint8_t *all = mine + rec;
+    const bool short_shard = rows < halo_rows;
+    LM_TRY(order_after_side(ctx, comm));
+    if (short_shard)
+        LM_HIP_TRY(hipMemsetAsync(mine, default_symbol, nbytes, ctx->stream));
+    else
+        LM_HIP_TRY(hipMemcpyAsync(mine, d_shard, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+    LM_HIP_TRY(hipMemsetAsync(mine + nbytes, short_shard ? 1 : 0, 16, ctx->stream));
     // every rank's head rows to every rank (a few KB in total): no point-to-point pairing to get wrong
-    LM_NCCL_TRY(rccl().AllGather(d_shard, all, nbytes, ncclUint8, comm->nccl, ctx->stream));
-    const uint8_t *succ = all + (size_t)((comm->rank + 1) % comm->nranks) * nbytes;
-    const int as_wrap = comm->rank == comm->nranks - 1;
+    LM_NCCL_TRY(rccl().AllGather(mine, all, rec, ncclUint8, comm->nccl, ctx->stream));
+    uint8_t *h_status = static_cast<uint8_t *>(ctx->pinned);
+    LM_HIP_TRY(hipMemcpy2DAsync(h_status, 16, all + nbytes, rec, 16, (size_t)nr, hipMemcpyDeviceToHost, ctx->stream));
+    LM_TRY(wait_stream(comm, ctx->stream, "exchange_halo (ncclAllGather)"));
+    for (int r = 0; r < nr; ++r)
+        if (h_status[(size_t)r * 16])
+            return fail(LM_HIP_ERR_BAD_ARGS, "exchange_halo: the shard of rank %d has fewer than %zu rows and cannot "
+                                             "give its predecessor a halo (reported on every rank)", r, halo_rows);
+    const uint8_t *succ = all + (size_t)((comm->rank + 1) % nr) * rec;
+    const int as_wrap = comm->rank == nr - 1;
     hipLaunchKernelGGL(halo_fill, dim3((unsigned)std::min<size_t>((nbytes + 255) / 256, 1024)), dim3(256), 0,
                        ctx->stream, d_shard + rows * stride, succ, (unsigned long long)nbytes, (unsigned)stride,
                        (unsigned)cols, default_symbol, as_wrap);
@@ -310,17 +434,8 @@ int lm_hip_exchange_halo_dptr(lm_hip_ctx *ctx, lm_hip_comm *comm, uint8_t *d_sha
 
 // ---- argmax / max ---------------------------------------------------------------------------
 
-// all_gather of this rank's record (already on the device at `d_mine`) + the combine rule
-static int gather_and_combine(lm_hip_ctx *ctx, lm_hip_comm *comm, const MergeRecord *d_mine, MergeRecord *d_all,
-                              int *found, lm_hip_coords *best, float *value)
+static int combine_records(const MergeRecord *h, int n, int *found, lm_hip_coords *best, float *value)
 {
-    const int n = comm->nranks;
-    LM_NCCL_TRY(rccl().AllGather(d_mine, d_all, sizeof(MergeRecord), ncclUint8, comm->nccl, ctx->stream));
-    MergeRecord *h = static_cast<MergeRecord *>(ctx->pinned);
-    if (sizeof(MergeRecord) * (size_t)n > kPinnedBytes)
-        return fail(LM_HIP_ERR_BAD_ARGS, "merge: too many ranks");
-    LM_HIP_TRY(hipMemcpyAsync(h, d_all, sizeof(MergeRecord) * n, hipMemcpyDeviceToHost, ctx->stream));
-    LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     std::vector<int> f(n);
     std::vector<lm_hip_coords> b(n);
     std::vector<float> v(n);
@@ -333,6 +448,21 @@ static int gather_and_combine(lm_hip_ctx *ctx, lm_hip_comm *comm, const MergeRec
     return lm_hip_combine_argmax(f.data(), b.data(), v.data(), (size_t)n, found, best, value);
 }
 
+// all_gather of this rank's record (already on the device at `d_mine`) + the combine rule
+static int gather_and_combine(lm_hip_ctx *ctx, lm_hip_comm *comm, const MergeRecord *d_mine, MergeRecord *d_all,
+                              int *found, lm_hip_coords *best, float *value)
+{
+    const int n = comm->nranks;
+    if (sizeof(MergeRecord) * (size_t)n > kPinnedBytes / 2)
+        return fail(LM_HIP_ERR_BAD_ARGS, "merge: too many ranks");
+    LM_TRY(order_after_side(ctx, comm));
+    LM_NCCL_TRY(rccl().AllGather(d_mine, d_all, sizeof(MergeRecord), ncclUint8, comm->nccl, ctx->stream));
+    MergeRecord *h = static_cast<MergeRecord *>(ctx->pinned);
+    LM_HIP_TRY(hipMemcpyAsync(h, d_all, sizeof(MergeRecord) * n, hipMemcpyDeviceToHost, ctx->stream));
+    LM_TRY(wait_stream(comm, ctx->stream, "argmax merge (ncclAllGather)"));
+    return combine_records(h, n, found, best, value);
+}
+
 int lm_hip_merge_argmax(lm_hip_ctx *ctx, lm_hip_comm *comm, int found_local, const lm_hip_coords *best_local,
                         float value_local, size_t row_offset, int *found, lm_hip_coords *best, float *value)
 {
@@ -340,6 +470,7 @@ int lm_hip_merge_argmax(lm_hip_ctx *ctx, lm_hip_comm *comm, int found_local, con
         return fail(LM_HIP_ERR_BAD_ARGS, "merge_argmax: null argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard guard(ctx->device);
+    LM_TRY(comm_usable(comm));
     LM_TRY(comm->buf.reserve(sizeof(MergeRecord) * (comm->nranks + 1)));
     MergeRecord *d = static_cast<MergeRecord *>(comm->buf.ptr);
     MergeRecord mine{};
@@ -356,16 +487,10 @@ int lm_hip_merge_argmax(lm_hip_ctx *ctx, lm_hip_comm *comm, int found_local, con
     return gather_and_combine(ctx, comm, d, d + 1, found, best, value);
 }
 
-int lm_hip_argmax_sharded(lm_hip_ctx *ctx, lm_hip_comm *comm, const lm_hip_scores *s, size_t row_offset,
-                          int *found, lm_hip_coords *best, float *value)
+// the shard's ArgmaxRecord on the device (tracked by the store kernel, or reduced now) -> MergeRecord at d_mine
+static int local_record(lm_hip_ctx *ctx, const lm_hip_scores *s, size_t row_offset, ArgmaxRecord *d_local,
+                        MergeRecord *d_mine)
 {
-    if (!ctx || !comm || !s || !found)
-        return fail(LM_HIP_ERR_BAD_ARGS, "argmax_sharded: null argument");
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    DeviceGuard guard(ctx->device);
-    LM_TRY(comm->buf.reserve(sizeof(MergeRecord) * (comm->nranks + 1) + sizeof(ArgmaxRecord)));
-    MergeRecord *d = static_cast<MergeRecord *>(comm->buf.ptr);
-    ArgmaxRecord *d_local = reinterpret_cast<ArgmaxRecord *>(d + comm->nranks + 1);
     const int rule = row_offset == 0 ? 1 : 0;  // only the shard holding row 0 holds scores[0][0]
     if (s->rows == 0) {
         LM_HIP_TRY(hipMemsetAsync(d_local, 0, sizeof(ArgmaxRecord), ctx->stream));  // found = 0
@@ -376,8 +501,23 @@ int lm_hip_argmax_sharded(lm_hip_ctx *ctx, lm_hip_comm *comm, const lm_hip_score
         LM_TRY(launch_argmax_device(ctx, s->d_data, s->rows, s->stride, s->cols, rule, d_local));
     }
     hipLaunchKernelGGL(globalize_record, dim3(1), dim3(1), 0, ctx->stream, (const ArgmaxRecord *)d_local,
-                       (unsigned long long)s->cols, (unsigned long long)row_offset, d);
+                       (unsigned long long)s->cols, (unsigned long long)row_offset, d_mine);
     LM_HIP_TRY(hipGetLastError());
+    return LM_HIP_OK;
+}
+
+int lm_hip_argmax_sharded(lm_hip_ctx *ctx, lm_hip_comm *comm, const lm_hip_scores *s, size_t row_offset,
+                          int *found, lm_hip_coords *best, float *value)
+{
+    if (!ctx || !comm || !s || !found)
+        return fail(LM_HIP_ERR_BAD_ARGS, "argmax_sharded: null argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    LM_TRY(comm_usable(comm));
+    LM_TRY(comm->buf.reserve(sizeof(MergeRecord) * (comm->nranks + 1) + sizeof(ArgmaxRecord)));
+    MergeRecord *d = static_cast<MergeRecord *>(comm->buf.ptr);
+    ArgmaxRecord *d_local = reinterpret_cast<ArgmaxRecord *>(d + comm->nranks + 1);
+    LM_TRY(local_record(ctx, s, row_offset, d_local, d));
     return gather_and_combine(ctx, comm, d, d + 1, found, best, value);
 }
 
@@ -405,34 +545,28 @@ int lm_hip_argmax_sharded_begin(lm_hip_ctx *ctx, lm_hip_comm *comm, const lm_hip
         return fail(LM_HIP_ERR_BAD_ARGS, "argmax_sharded_begin: null argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard guard(ctx->device);
+    LM_TRY(comm_usable(comm));
     LM_TRY(async_init(comm));
     const int k = comm->next;
     lm_hip_comm::Slot &sl = comm->slot[k];
+    // (a property of the calling sequence, which every rank of an SPMD host runs alike: all ranks fail here, or none)
     if (sl.pending)
         return fail(LM_HIP_ERR_BAD_ARGS, "argmax_sharded_begin: two merges are in flight, collect one with _end first");
     char *base = static_cast<char *>(comm->abuf.ptr) + (size_t)k * comm->slot_bytes();
     ArgmaxRecord *d_local = reinterpret_cast<ArgmaxRecord *>(base);
     MergeRecord *d_mine = reinterpret_cast<MergeRecord *>(base + 32);
     MergeRecord *d_all = d_mine + 1;
-    const int rule = row_offset == 0 ? 1 : 0;  // only the shard holding row 0 holds scores[0][0]
-    if (s->rows == 0) {
-        LM_HIP_TRY(hipMemsetAsync(d_local, 0, sizeof(ArgmaxRecord), ctx->stream));  // found = 0
-    } else if (s->best_valid && (int)s->first_cell_rule == rule) {
-        d_local = s->d_best;  // tracked by the store kernel: read in place, on the stream that wrote it
-    } else {
-        LM_TRY(launch_argmax_device(ctx, s->d_data, s->rows, s->stride, s->cols, rule, d_local));
-    }
-    hipLaunchKernelGGL(globalize_record, dim3(1), dim3(1), 0, ctx->stream, (const ArgmaxRecord *)d_local,
-                       (unsigned long long)s->cols, (unsigned long long)row_offset, d_mine);
-    LM_HIP_TRY(hipGetLastError());
+    LM_TRY(local_record(ctx, s, row_offset, d_local, d_mine));
     // from here on the scores (and the tracked record) may be overwritten: the side stream only
-    // needs the 32-byte record
+    // needs the 32-byte record.  `ready` also orders this collective after every synchronous one
+    // enqueued on the context's stream before it.
     LM_HIP_TRY(hipEventRecord(sl.ready, ctx->stream));
     LM_HIP_TRY(hipStreamWaitEvent(comm->side, sl.ready, 0));
     LM_NCCL_TRY(rccl().AllGather(d_mine, d_all, sizeof(MergeRecord), ncclUint8, comm->nccl, comm->side));
     LM_HIP_TRY(hipMemcpyAsync(comm->h_slots + (size_t)k * comm->nranks, d_all, sizeof(MergeRecord) * comm->nranks,
                               hipMemcpyDeviceToHost, comm->side));
     LM_HIP_TRY(hipEventRecord(sl.done, comm->side));
+    comm->side_tail = sl.done;
     sl.pending = true;
     comm->next ^= 1;
     *ticket = k;
@@ -442,25 +576,23 @@ int lm_hip_argmax_sharded_begin(lm_hip_ctx *ctx, lm_hip_comm *comm, const lm_hip
 int lm_hip_argmax_sharded_end(lm_hip_ctx *ctx, lm_hip_comm *comm, int ticket, int *found, lm_hip_coords *best,
                               float *value)
 {
-    if (!ctx || !comm || !found || ticket < 0 || ticket > 1 || !comm->slot[ticket].pending)
-        return fail(LM_HIP_ERR_BAD_ARGS, "argmax_sharded_end: no merge in flight under this ticket");
+    if (!ctx || !comm || !found || ticket < 0 || ticket > 1)
+        return fail(LM_HIP_ERR_BAD_ARGS, "argmax_sharded_end: bad argument");
+    hipEvent_t done;
     {
-        DeviceGuard guard(ctx->device);
-        LM_HIP_TRY(hipEventSynchronize(comm->slot[ticket].done));  // (the context stays free for other threads)
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        LM_TRY(comm_usable(comm));
+        if (!comm->slot[ticket].pending)
+            return fail(LM_HIP_ERR_BAD_ARGS, "argmax_sharded_end: no merge in flight under this ticket");
+        done = comm->slot[ticket].done;
     }
+    {
+        DeviceGuard guard(ctx->device);  // (the wait itself leaves the context free for other threads)
+        LM_TRY(wait_bounded(comm, [done] { return hipEventQuery(done); }, "pipelined argmax merge (ncclAllGather)"));
+    }
+    std::lock_guard<std::mutex> lock(ctx->mu);
     comm->slot[ticket].pending = false;
-    const int n = comm->nranks;
-    const MergeRecord *h = comm->h_slots + (size_t)ticket * n;
-    std::vector<int> f(n);
-    std::vector<lm_hip_coords> b(n);
-    std::vector<float> v(n);
-    for (int i = 0; i < n; ++i) {
-        f[i] = h[i].found;
-        b[i].row = (size_t)h[i].row;
-        b[i].col = (size_t)h[i].col;
-        v[i] = h[i].value;
-    }
-    return lm_hip_combine_argmax(f.data(), b.data(), v.data(), (size_t)n, found, best, value);
+    return combine_records(comm->h_slots + (size_t)ticket * comm->nranks, comm->nranks, found, best, value);
 }
 
 int lm_hip_merge_max(lm_hip_ctx *ctx, lm_hip_comm *comm, int found_local, float value_local, int *found,
@@ -485,6 +617,8 @@ int lm_hip_merge_threshold(lm_hip_ctx *ctx, lm_hip_comm *comm, const lm_hip_coor
     *n_all = 0;
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard guard(ctx->device);
+    LM_TRY(comm_usable(comm));
+    LM_TRY(order_after_side(ctx, comm));
     const int nr = comm->nranks;
     // (1) hit counts
     LM_TRY(comm->buf.reserve(sizeof(unsigned long long) * (nr + 1)));
@@ -494,7 +628,7 @@ int lm_hip_merge_threshold(lm_hip_ctx *ctx, lm_hip_comm *comm, const lm_hip_coor
     LM_HIP_TRY(hipMemcpyAsync(d_cnt + nr, h + nr, 8, hipMemcpyHostToDevice, ctx->stream));
     LM_NCCL_TRY(rccl().AllGather(d_cnt + nr, d_cnt, 8, ncclUint8, comm->nccl, ctx->stream));
     LM_HIP_TRY(hipMemcpyAsync(h, d_cnt, 8 * nr, hipMemcpyDeviceToHost, ctx->stream));
-    LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    LM_TRY(wait_stream(comm, ctx->stream, "threshold merge, hit counts (ncclAllGather)"));
     std::vector<unsigned long long> cnt(h, h + nr), off(nr + 1, 0);
     for (int r = 0; r < nr; ++r)
         off[r + 1] = off[r] + cnt[r];
@@ -541,8 +675,13 @@ int lm_hip_merge_threshold(lm_hip_ctx *ctx, lm_hip_comm *comm, const lm_hip_coor
             e = hipMemcpyAsync(res + after, d_all + after, (total - after) * sizeof(lm_hip_coords),
                                hipMemcpyDeviceToHost, ctx->stream);
     }
-    if (e == hipSuccess)
-        e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && nr_ == ncclSuccess) {
+        const int st2 = wait_stream(comm, ctx->stream, "threshold merge, hit lists (ncclBroadcast group)");
+        if (st2 != LM_HIP_OK) {
+            result_free(res);
+            return st2;
+        }
+    }
     if (e != hipSuccess || nr_ != ncclSuccess) {
         result_free(res);
         if (nr_ != ncclSuccess)

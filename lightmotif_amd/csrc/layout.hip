@@ -115,22 +115,32 @@ int launch_encode(lm_hip_ctx *ctx, char alphabet, const uint8_t *d_ascii, size_t
 __global__ __launch_bounds__(kBlock) void max_symbol_kernel(const uint8_t *__restrict__ data,
                                                             const unsigned long long rows,
                                                             const unsigned long long stride,
-                                                            const unsigned cols,
+                                                            const unsigned long long cols,
                                                             unsigned *__restrict__ out)
 {
     unsigned m = 0;
-    if (stride == cols && cols % 4 == 0 && reinterpret_cast<uintptr_t>(data) % 4 == 0) {
-        const unsigned long long n4 = rows * cols / 4;
-        const unsigned *d4 = reinterpret_cast<const unsigned *>(data);
-        for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < n4;
-             i += (unsigned long long)gridDim.x * kBlock) {
+    const unsigned long long tid = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+    const unsigned long long step = (unsigned long long)gridDim.x * kBlock;
+    if (stride == cols) {
+        // one flat run of rows * cols bytes (an encoded sequence arrives as rows = 1, cols = len,
+        // and len may exceed 2^32): bytes up to the first 4-byte boundary, whole dwords, byte tail
+        const unsigned long long n = rows * cols;
+        const unsigned long long head = min(n, (unsigned long long)((4 - reinterpret_cast<uintptr_t>(data) % 4) % 4));
+        const unsigned long long n4 = (n - head) / 4;
+        const unsigned *d4 = reinterpret_cast<const unsigned *>(data + head);
+        for (unsigned long long i = tid; i < n4; i += step) {
             const unsigned w = d4[i];
             m = max(max(m, w & 0xff), max((w >> 8) & 0xff, max((w >> 16) & 0xff, w >> 24)));
         }
+        if (tid < head)
+            m = max(m, (unsigned)data[tid]);
+        const unsigned long long tail0 = head + n4 * 4;
+        if (tid < n - tail0)
+            m = max(m, (unsigned)data[tail0 + tid]);
     } else {
+        // padded rows: only the `cols` live bytes of each row are symbols
         const unsigned long long n = rows * cols;
-        for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < n;
-             i += (unsigned long long)gridDim.x * kBlock)
+        for (unsigned long long i = tid; i < n; i += step)
             m = max(m, (unsigned)data[(i / cols) * stride + i % cols]);
     }
 #pragma unroll
@@ -153,7 +163,7 @@ int launch_max_symbol(lm_hip_ctx *ctx, const uint8_t *d_data, size_t rows, size_
     const unsigned grid = (unsigned)std::min<unsigned long long>((work + kBlock - 1) / kBlock,
                                                                  (unsigned long long)ctx->num_cus * 32);
     hipLaunchKernelGGL(max_symbol_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, d_data,
-                       (unsigned long long)rows, (unsigned long long)stride, (unsigned)cols, d_max);
+                       (unsigned long long)rows, (unsigned long long)stride, (unsigned long long)cols, d_max);
     LM_HIP_TRY(hipGetLastError());
     LM_HIP_TRY(hipMemcpyAsync(ctx->pinned, d_max, 4, hipMemcpyDeviceToHost, ctx->stream));
     LM_HIP_TRY(hipStreamSynchronize(ctx->stream));

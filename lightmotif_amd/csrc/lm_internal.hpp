@@ -99,7 +99,6 @@ struct lm_hip_ctx {
     bool pair_prefilter = true;  // DNA prefilter scans look up two symbols at a time
     bool pair_prefilter_protein = false;  // the 441-row protein pair scan: correct, measured 4 % slower
     bool quad_loads = true;      // store kernel: quad-gathered dword symbol loads (M % 4 == 0; +1 %)
-    bool unroll_main = true;     // store kernel, T = 3M + 1: MAIN groups unrolled (LM_HIP_UNROLL_MAIN=0: the loop form)
     bool track_argmax = true;    // score_into on handles also tracks the best cell (cached argmax)
     bool speculate_order = true; // fused threshold: order the hit list before the host knows its length
     bool suffix_argmax = true;   // fused argmax of short motifs: try the last rows first (score.hip)

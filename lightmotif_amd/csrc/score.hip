@@ -101,12 +101,6 @@ ScoreC32Launcher score_c32_lookup_c16(int M)
     return (M >= 1 && M <= kMaxFastM) ? g_c32[M][10] : nullptr;
 }
 
-ScoreC32Launcher score_c32_lookup_unrolled2(int M)
-{
-    std::call_once(g_c32_once, init_registry);
-    return (M >= 1 && M <= kMaxFastM) ? g_c32[M][11] : nullptr;
-}
-
 ScoreC32Launcher score_c32_lookup_ql(int M)
 {
     std::call_once(g_c32_once, init_registry);
@@ -225,14 +219,6 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const Score
     const unsigned long long per_block = c16 ? 2 * kStreamsPerBlock : kStreamsPerBlock;
     p.grid = dim3((unsigned)((p.nstreams + per_block - 1) / per_block));
     p.lds = lds;
-    if (store && prefilter == 0) {  // experiment: unused LDS as ballast = fewer wavefronts per CU = a smaller
-        static const size_t ballast = [] {  // window of rows being written at once (<= 64 KB per workgroup without opt-in)
-            const char *e = getenv("LM_HIP_LDS_BALLAST_KB");
-            return e ? (size_t)atoi(e) * 1024 : (size_t)0;
-        }();
-        if (ballast && p.lds < ballast && ballast <= 64 * 1024)
-            p.lds = ballast;
-    }
     p.ok = true;
     return p;
 }
@@ -290,8 +276,6 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
         const MotifShape ms{mp, a.pssm->k, false};
         const C32Plan pp = plan_c32(ctx, ms, a, true, 0, 1, store_rows_hint(mp, a.cols), true);
         ScoreC32Launcher pfn = a.cols == 16 ? score_c32_lookup_c16((int)mp) : score_c32_lookup_ql((int)mp);
-        if (pp.ok && a.cols == 32 && ctx->unroll_main && pp.T == 3 * mp + 1 && score_c32_lookup_unrolled2((int)mp))
-            pfn = score_c32_lookup_unrolled2((int)mp);
         if (pp.ok && pfn) {
             fo.lead_rows = (unsigned)a.pssm->lead;
             ctx->last_kernel = score_c32_name((int)mp, MODE_STORE);
@@ -310,8 +294,6 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
             fn = score_c32_lookup_ql((int)a.pssm->m);  // dword symbol loads (M % 4 == 0)
         if (c16)
             fn = score_c32_lookup_c16((int)a.pssm->m);  // four streams of 16 columns per wavefront
-        else if (dwords && ctx->unroll_main && p.T == 3 * a.pssm->m + 1 && score_c32_lookup_unrolled2((int)a.pssm->m))
-            fn = score_c32_lookup_unrolled2((int)a.pssm->m);  // both MAIN groups unrolled: exact s_waitcnt
         ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_STORE);
         LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
                       a.row_begin, a.row_end, p.T, p.nstreams, a.d_out, fo));

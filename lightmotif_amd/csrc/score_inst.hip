@@ -33,10 +33,6 @@ struct RegisterRange {
         if constexpr (M % 4 == 0) {
             tab[7] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1>;
             tab[10] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1, 16>;
-#ifdef LM_SCORE_BUILD_UNROLLED  // experiment: exact s_waitcnt without the loop back-edge; measured neutral
-            if constexpr (M >= 8 && M <= 26)  // the lengths whose streams have three groups + 1 row (plan_c32)
-                tab[11] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1, 32, 2>;
-#endif
         }
         tab[8] = &score_c32_launch<M, MODE_STORE_ARGMAX, LM_SCORE_XCD_REMAP, 1>;
         tab[9] = &score_c32_launch<M, MODE_CONTINUE, LM_SCORE_XCD_REMAP, 1>;

@@ -507,7 +507,7 @@ __device__ __forceinline__ void emit_candidates(const unsigned long long hit_gro
 #define LM_SCORE_XCD_REMAP 0
 #endif
 template <int M, int MODE, int PF = LM_SCORE_PF, int LP = LM_SCORE_LP, int BLK = LM_BLOCK,
-          int XCD = LM_SCORE_XCD_REMAP, int MINW = LM_SCORE_MIN_WAVES(M), int QLREQ = 0, int OC = 32, int NMAIN = 0>
+          int XCD = LM_SCORE_XCD_REMAP, int MINW = LM_SCORE_MIN_WAVES(M), int QLREQ = 0, int OC = 32>
 __global__ __launch_bounds__(BLK, MINW) void score_c32(
     const uint8_t *__restrict__ seq, const float *__restrict__ table, const int K,
     const unsigned long long row_begin, const unsigned long long row_end,
@@ -624,32 +624,14 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
     score_group<M, MODE, PFE, LPE, PHASE_FIRST, QL, OC>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
                                                 best_t, fo, shq, init_next);
     note_group();
-    // NMAIN > 0: the stream has exactly NMAIN MAIN groups (T = (NMAIN + 1) * M + 1, checked by the launcher) and
-    // they are unrolled.  Without a loop back-edge the compiler's s_waitcnt pass knows how many vector-memory
-    // operations follow each symbol load: as a loop, every trip began with `s_waitcnt vmcnt(3)` / `vmcnt(1)` --
-    // the conservative merge of the entry and back-edge states -- i.e. with a wait for nearly all of the
-    // previous trip's 20 stores, the last 8 issued just before (profiles/r02_isa_store_kernel_main_group.txt).
-    if constexpr (NMAIN > 0) {
-#pragma unroll
-        for (int g = 0; g < NMAIN; ++g) {
-            sp += M * 32;
-            tbase += M;
-            if (mode_stores(MODE))
-                op += M * OC;
-            score_group<M, MODE, PFE, LPE, PHASE_MAIN, QL, OC>(acc, sym, wc, sp, lds_raw, op, tbase, col,
-                                                       best_v, best_t, fo, shq, init_next);
-            note_group();
-        }
-    } else {
-        for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
-            sp += M * 32;
-            tbase += M;
-            if (mode_stores(MODE))
-                op += M * OC;
-            score_group<M, MODE, PFE, LPE, PHASE_MAIN, QL, OC>(acc, sym, wc, sp, lds_raw, op, tbase, col,
-                                                       best_v, best_t, fo, shq, init_next);
-            note_group();
-        }
+    for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
+        sp += M * 32;
+        tbase += M;
+        if (mode_stores(MODE))
+            op += M * OC;
+        score_group<M, MODE, PFE, LPE, PHASE_MAIN, QL, OC>(acc, sym, wc, sp, lds_raw, op, tbase, col,
+                                                   best_v, best_t, fo, shq, init_next);
+        note_group();
     }
     sp += M * 32;
     tbase += M;
@@ -892,14 +874,14 @@ using ScoreC32Launcher = hipError_t (*)(dim3 grid, size_t lds_bytes, hipStream_t
                                         unsigned long long T, unsigned long long nstreams,
                                         float *out, FusedOut fo);
 
-template <int M, int MODE, int XCD = LM_SCORE_XCD_REMAP, int QL = 0, int OC = 32, int NMAIN = 0>
+template <int M, int MODE, int XCD = LM_SCORE_XCD_REMAP, int QL = 0, int OC = 32>
 hipError_t score_c32_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, const uint8_t *seq,
                             const float *table, int K, unsigned long long row_begin,
                             unsigned long long row_end, unsigned long long T,
                             unsigned long long nstreams, float *out, FusedOut fo)
 {
     hipLaunchKernelGGL((score_c32<M, MODE, LM_SCORE_PF, LM_SCORE_LP, LM_BLOCK, XCD,
-                                  LM_SCORE_MIN_WAVES(M), QL, OC, NMAIN>), grid,
+                                  LM_SCORE_MIN_WAVES(M), QL, OC>), grid,
                        dim3(kBlock), lds_bytes, stream, seq, table, K, row_begin, row_end, T,
                        nstreams, out, fo);
     return hipGetLastError();
@@ -910,14 +892,12 @@ hipError_t score_c32_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, con
 // [4..6] = unused, [7] = store kernel with quad-gathered symbol
 // loads (M % 4 == 0), [8] = store + running maximum (score_into on handles).
 constexpr int kRegistrySlots = 12;  // [9] = MODE_CONTINUE (later passes of motifs longer than kMaxFastM),
-                                    // [10] = store kernel for C = 16 (M % 4 == 0, quad loads),
-                                    // [11] = store kernel with its two MAIN groups unrolled (T = 3M + 1)
+                                    // [10] = store kernel for C = 16 (M % 4 == 0, quad loads), [11] = unused
 ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap = false);
 ScoreC32Launcher score_c32_lookup_ql(int M);
 ScoreC32Launcher score_c32_lookup_store_argmax(int M);
 ScoreC32Launcher score_c32_lookup_continue(int M);
 ScoreC32Launcher score_c32_lookup_c16(int M);
-ScoreC32Launcher score_c32_lookup_unrolled2(int M);
 const char *score_c32_name(int M, int mode);
 
 }  // namespace lm

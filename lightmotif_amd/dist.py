@@ -38,15 +38,15 @@ class ScoreDistribution:
                 if np.isfinite(s):                                       # `s != i32::MIN`
                     s = int(s)
                     pdf_new[s:s + mx + 1] += pdf_old[:mx + 1] * bg[a]
-        sf = pdf_new                                                     # :197-215
-        min_score = max_score = 0
-        for i in range(size - 2, -1, -1):
-            p_i1, p_i = sf[i + 1], sf[i]
-            sf[i] = min(p_i + p_i1, 1.0)
-            if max_score == 0 and p_i1 > 0.0:
-                max_score = i + 1
-            if p_i > 0.0:
-                min_score = i
+        # dist.rs:197-215: sf[i] = min(pdf[i] + sf[i+1], 1.0) from the top down.  The terms are >= 0, so the
+        # clamp only ever holds a saturated tail at 1.0: a sequential f64 running sum (np.cumsum adds in
+        # order) clipped afterwards is the same number at every index.  max_score = the highest index >= 1
+        # with mass, min_score = the lowest index <= size - 2 with mass (0 when there is none).
+        nz = np.nonzero(pdf_new > 0.0)[0]
+        hi, lo = nz[nz >= 1], nz[nz <= size - 2]
+        max_score = int(hi[-1]) if hi.size else 0
+        min_score = int(lo[0]) if lo.size else 0
+        sf = np.minimum(np.cumsum(pdf_new[::-1])[::-1], 1.0)
         self._scale, self._offset, self._rows = float(scale), int(offset), m
         self.sf, self.min_score, self.max_score = sf, min_score, max_score
 

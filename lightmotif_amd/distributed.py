@@ -340,6 +340,14 @@ class CabiComm:
             dist.broadcast(t, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
         return cls(pli, bytes(t.cpu().numpy().tobytes()), world, rank)
 
+    def info(self) -> Tuple[int, int]:
+        """``(rank, nranks)`` as the library's communicator holds them (``lm_hip_comm_info``): what RCCL was
+        initialised with, not what the launcher's environment says."""
+        from . import _ffi
+        r, n = self._C.c_int(-1), self._C.c_int(-1)
+        _ffi.check(self._L.lm_hip_comm_info(self._h, self._C.byref(r), self._C.byref(n)))
+        return r.value, n.value
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             self._L.lm_hip_comm_destroy(self._h)

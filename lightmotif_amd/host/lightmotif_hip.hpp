@@ -431,7 +431,7 @@ public:
     {
         int found = 0;
         float v = 0;
-        check(lm_hip_argmax(ctx_->ctx, h_, &found, nullptr, &v));
+        check(lm_hip_max(ctx_->ctx, h_, &found, &v));  // Maximum::max, pli/mod.rs:158-160
         return found ? std::optional<float>(v) : std::nullopt;
     }
     std::vector<size_t> threshold(float t) const

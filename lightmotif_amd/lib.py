@@ -214,8 +214,10 @@ class Pipeline:
         return (best.row, best.col) if found else None
 
     def max(self, scores: "StripedScores") -> Optional[float]:
-        found, _, value = self._argmax(scores)
-        return value if found else None
+        """``Maximum::max`` (pli/mod.rs:158-160) through its own export, ``lm_hip_max``."""
+        found, value = C.c_int(0), C.c_float(0)
+        check(self._L.lm_hip_max(self._h, scores._h, C.byref(found), C.byref(value)))
+        return float(value.value) if found.value else None
 
     def _argmax(self, scores: "StripedScores"):
         found, best, value = C.c_int(0), Coords(), C.c_float(0)
@@ -1097,28 +1099,28 @@ class Scanner:
         i = top[np.argmax(pos[top])]
         return Hit(int(pos[i]), float(sc[i]))
 
-    def max(self, strict_reference: bool = False, saturate: bool = True) -> Optional[Hit]:
-        """scan.rs:200-249: the best hit not yet yielded; greater score wins, equal scores
-        go to the greater position (scan.rs:237).  Consumes the scanner.
+    def max(self, saturate: bool = True) -> Optional[Hit]:
+        """``Scanner::max`` exactly as the reference computes it (scan.rs:200-249); consumes the scanner.
 
-        Default: the best VALID hit -- ``score >= threshold`` and ``position + M <= L`` like
-        every hit ``__next__`` yields (scan.rs:186-189).  On a fresh scanner the hit list is
-        never built (a low threshold would select most of the sequence): the fused argmax
-        gives the greatest score S of the matrix, and one scan at max(threshold, S) returns
-        the few valid positions that reach it.
+        The u8 DiscreteMatrix scores steer which cells are looked at: starting from the best pending hit
+        (or none) and the level ``dm.scale(threshold)``, cells are visited block by block in row-major
+        order; a cell whose u8 score reaches the current level is re-scored in f32 and replaces the best
+        hit when its score is greater, or equal at a greater position (scan.rs:237) -- and the level
+        becomes ITS u8 score.  Consequences the reference has and this keeps: (a) positions are not
+        tested against ``position + M <= L``; (b) while no hit is held the first candidate is accepted
+        even if its f32 score is below the threshold; (c) a better cell whose u8 score lies under the
+        level (the u8 score of the current best, an over-estimate) is skipped (scan.rs:227-243).
+        ``saturate``: the u8 adds of the x86-64 ``dispatch`` pipeline (avx2.rs:336); ``False`` =
+        Generic's wrapping adds.  :meth:`max_valid` is the variant without those corner cases."""
+        return self._max_strict(saturate)
 
-        This deviates from the reference's ``max()`` in corner cases, on purpose: there the
-        u8 DiscreteMatrix scores steer which cells are looked at, and (a) positions are not
-        tested against ``position + M <= L``, (b) while no hit is held the first candidate is
-        accepted even if its f32 score is below the threshold, (c) cells are filtered by the
-        u8 score of the current best hit, an over-estimate, so a better cell with a smaller
-        u8 score is skipped (scan.rs:227-243).  ``strict_reference=True`` reproduces all of
-        that literally from the device-computed u8 and f32 score matrices (``saturate``:
-        the u8 adds of the x86-64 ``dispatch`` pipeline, avx2.rs:336; ``False`` = Generic's
-        wrapping adds); it materialises both matrices and walks the candidates on the host,
-        so it is a parity tool, not the fast path."""
-        if strict_reference:
-            return self._max_strict(saturate)
+    def max_valid(self) -> Optional[Hit]:
+        """NOT the reference's ``max()``: the best VALID hit not yet yielded -- ``score >= threshold``
+        and ``position + M <= L`` like every hit ``__next__`` yields (scan.rs:186-189); greater score
+        wins, equal scores go to the greater position.  Consumes the scanner.  On a fresh scanner the
+        hit list is never built (a low threshold would select most of the sequence): the fused argmax
+        gives the greatest score S of the matrix, and one scan at max(threshold, S) returns the few
+        valid positions that reach it.  Differs from :meth:`max` exactly in that method's (a)-(c)."""
         if self._order is None:
             pli = self._seq._pli
             top = pli.score_argmax(self._pssm, self._seq)

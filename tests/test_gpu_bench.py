@@ -1,0 +1,74 @@
+"""bench.py as the driver runs it: the N = 1 line, and the N > 1 launch path rehearsed on ONE GPU.
+
+An 8-GPU node is the driver's to use, not the builder's, so the multi-rank control flow of
+``bench.py`` (self-launch under torch.distributed.run, halo hand-over checked against the
+generator, per-step argmax merge, the JSON fields that say what actually ran) is exercised here
+with two ranks that share ``cuda:0`` and merge over gloo -- RCCL refuses two ranks on one
+device, everything around the transport is the code the 8-GPU run takes."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def run_bench(*args, timeout=900):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)                                   # no launcher: bench.py must cope on its own
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                       # ONE JSON line on stdout, nothing else
+    return json.loads(lines[0])
+
+
+def test_two_ranks_without_a_launcher():
+    """`python bench.py --gpus 2 ...` with no WORLD_SIZE in the environment re-executes itself under
+    torch.distributed.run and prints one line for a 2-rank job."""
+    out = run_bench("--gpus", "2", "--single-device", "--dist-backend", "gloo", "--steps", "3", "--warmup", "1",
+                    "--length", "20000000", "--preheat-ms", "20")
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
+    cfg = out["config"]
+    assert cfg["parallelism"] == "row-shard x2" and cfg["halo_verified"] is True
+    assert cfg["process_group"] == "gloo x2" and cfg["merge_transport"].startswith("torch.distributed:gloo")
+    assert len(cfg["devices"]) == 2 and cfg["distinct_devices"] == 1     # both ranks on cuda:0 in this rehearsal
+    assert out["value"] > 0 and out["roofline"]["kernel"].startswith("score_c32<20")
+    # the merged argmax of the 40 Mbp job is the same cell a single process finds on the whole sequence
+    whole = run_bench("--gpus", "1", "--steps", "2", "--warmup", "1", "--length", "40000000", "--preheat-ms", "20",
+                      "--no-cpu-baseline", "--no-extras")
+    assert out["extras"]["argmax_global"] == whole["extras"]["argmax_global"]
+    assert out["extras"]["threshold_hits"] > 0
+
+
+def test_single_gpu_line_has_every_contract_field():
+    out = run_bench("--steps", "5", "--warmup", "2", "--length", "50000000", "--preheat-ms", "20", "--cpu-seconds", "2",
+                    "--cpu-sample", "16000000")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["dtype"] == "f32" and out["config"]["merge_transport"] is None
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = out["cpu_baseline"]
+    assert cb["gpu_matches_cpu_bitwise"] is True and cb["kind"] == "port"
+    assert cb["sockets"] >= 1 and cb["cores"] >= 1 and cb["threads"] >= cb["cores"]
+    ex = out["extras"]["configs"]                           # configs[0], [2], [4] ride along on the driver's line
+    assert ex["c1"]["C32_dispatch_geometry"]["best_position"] == 391_677
+    assert ex["c1"]["C1_generic_bench_geometry"]["best_position"] == 391_677
+    assert ex["c5"]["kernel"].startswith("score_c32<12") and 0 < ex["c5"]["hbm_frac"] < 1
+    assert ex["c3"]["hits_total"] > 0 and ex["c3"]["motifs_skipped_unreachable"] >= 0
+
+
+def test_one_rank_through_the_c_abi_communicator():
+    """`--merge cabi` on one rank: the sharded step through the library's own RCCL communicator (a world of one);
+    the line reports what RCCL was initialised with."""
+    out = run_bench("--merge", "cabi", "--steps", "5", "--warmup", "2", "--length", "50000000", "--preheat-ms", "20",
+                    "--no-cpu-baseline", "--no-extras")
+    assert out["config"]["rccl_ranks"] == 1 and "C-ABI communicator" in out["config"]["merge_transport"]

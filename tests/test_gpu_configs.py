@@ -586,3 +586,19 @@ def test_other_geometries_take_the_tiled_kernel(pli, cols, m, k):
     wrc = [tuple(map(int, rc)) for rc in co.threshold(full, cols, t)]
     frc, fval = pli.score_threshold(pssm, seq, t)
     assert frc == wrc and np.array_equal(bits(fval), bits([full[r, c] for r, c in wrc]))
+
+
+def test_symbol_validation_covers_sequences_of_2_32_symbols_and_more(gpu_pli):
+    """An encoded sequence of >= 2^32 symbols is validated to its last byte (the column count
+    used to be narrowed to 32 bits, so only len mod 2^32 bytes were looked at)."""
+    length = 2 ** 32 + 4096 + 3
+    enc = np.zeros(length, np.uint8)
+    enc[1::7] = 3
+    seq = gpu_pli.stripe(lm.EncodedSequence(enc), COLS)              # all valid
+    assert len(seq) == length
+    del seq
+    for bad in (2 ** 32 + 1000, length - 1, 2 ** 32 - 1):
+        enc[bad] = 5                                                 # not a Nucleotide
+        with pytest.raises(lm.InvalidSymbol):
+            gpu_pli.stripe(lm.EncodedSequence(enc), COLS)
+        enc[bad] = 0

@@ -183,22 +183,22 @@ def test_scanner_dense_hit_lists(pli, length, frac):
         assert [h.position for h in got_seq] == [i for i, _ in want_seq]
         assert np.array_equal(bits([h.score for h in got_seq]), bits([x for _, x in want_seq]))
     best = no.scanner_max(want, 32, length, m, t)                    # scan.rs:200-249
-    got = lm.Scanner(lm.ScoringMatrix(p), seq, threshold=t).max()
+    got = lm.Scanner(lm.ScoringMatrix(p), seq, threshold=t).max_valid()
     assert (got.position, np.float32(got.score)) == (best[0], best[1])
     it = lm.Scanner(lm.ScoringMatrix(p), seq, threshold=t)
     first = next(it)                                                  # max() sees what is left
     rest = [h for h in no.scanner_collect(want, 32, length, m, t, 256)][1:]
     if rest:
         bi, bs = max(rest, key=lambda h: (h[1], h[0]))
-        after = it.max()
+        after = it.max_valid()
         assert (after.position, np.float32(after.score)) == (bi, bs) and len(it) == 0
     else:
-        assert it.max() is None
+        assert it.max_valid() is None
     assert first.position == no.scanner_collect(want, 32, length, m, t, 256)[0][0]
 
 
-def test_scanner_max_does_not_build_the_hit_list(pli):
-    """`Scanner::max` on a fresh scanner (scan.rs:200-249) with a threshold that selects every
+def test_scanner_max_valid_does_not_build_the_hit_list(pli):
+    """`Scanner.max_valid` on a fresh scanner with a threshold that selects every
     position: the best hit comes from the fused argmax + one scan at its score, the full hit
     list is never materialised; ties go to the greater POSITION, not the later (row, col) cell."""
     rng = np.random.default_rng(12)
@@ -210,7 +210,7 @@ def test_scanner_max_does_not_build_the_hit_list(pli):
     seq = pli.stripe(lm.EncodedSequence(enc), 32)
     seq.configure_wrap(m - 1)
     sc = lm.Scanner(lm.ScoringMatrix(p), seq, threshold=-1e30)
-    best = sc.max()
+    best = sc.max_valid()
     assert sc._positions is None or sc._positions.size == 0      # nothing was collected
     ref = co.stripe(enc, 32, 5)
     co.configure_wrap(ref, m - 1)
@@ -218,8 +218,8 @@ def test_scanner_max_does_not_build_the_hit_list(pli):
     by_pos = want[:, :32].T.reshape(-1)[: length - m + 1]
     top = np.nonzero(by_pos == by_pos.max())[0]
     assert top.size > 1 and (best.position, best.score) == (int(top[-1]), float(by_pos.max()))
-    assert lm.Scanner(lm.ScoringMatrix(p), seq, threshold=float(by_pos.max()) + 0.5).max() is None
-    assert len(sc) == 0 and sc.max() is None                      # consumed
+    assert lm.Scanner(lm.ScoringMatrix(p), seq, threshold=float(by_pos.max()) + 0.5).max_valid() is None
+    assert len(sc) == 0 and sc.max_valid() is None                # consumed
 
 
 def test_reverse_complement_on_the_device(pli):
@@ -533,6 +533,17 @@ def test_host_pointer_entry_points(pli):
     found, best, val = C.c_int(0), _ffi.Coords(), C.c_float(0)
     assert L.lm_hip_argmax_f32(out.ctypes.data, 890, 32, 32, C.byref(found), C.byref(best), C.byref(val)) == 0
     assert found.value == 1 and (best.row, best.col) == co.argmax(want, 32)
+    # Maximum::max (pli/mod.rs:158-160) = the value at the Generic argmax, through its own exports
+    mfound, mval = C.c_int(0), C.c_float(0)
+    assert L.lm_hip_max_f32(out.ctypes.data, 890, 32, 32, C.byref(mfound), C.byref(mval)) == 0
+    assert mfound.value == 1 and np.float32(mval.value) == want[co.argmax(want, 32)] == np.float32(val.value)
+    neg = np.full((7, 32), -np.inf, np.float32)            # all -inf -> -inf (Avx2::max_f32 would say 0.0)
+    assert L.lm_hip_max_f32(neg.ctypes.data, 7, 32, 32, C.byref(mfound), C.byref(mval)) == 0
+    assert mfound.value == 1 and mval.value == -np.inf
+    neg[0, 0] = np.nan                                      # NaN first cell -> argmax (0, 0) -> NaN
+    assert L.lm_hip_max_f32(neg.ctypes.data, 7, 32, 32, C.byref(mfound), C.byref(mval)) == 0
+    assert mfound.value == 1 and np.isnan(mval.value)
+    assert L.lm_hip_max_f32(neg.ctypes.data, 0, 32, 32, C.byref(mfound), C.byref(mval)) == 0 and mfound.value == 0
     ptr, n = C.POINTER(_ffi.Coords)(), C.c_size_t(0)
     assert L.lm_hip_threshold_f32(out.ctypes.data, 890, 32, 32, 9.0, C.byref(ptr), C.byref(n)) == 0
     got = [(ptr[i].row, ptr[i].col) for i in range(n.value)]
@@ -687,11 +698,11 @@ def test_entry_points_are_thread_safe(pli):
 @pytest.mark.parametrize("kind", ["random", "below_threshold_first_candidate", "finite_n_tail", "overestimate_skip",
                                   "partially_consumed"])
 def test_scanner_max_strict_reference_mode(pli, kind):
-    """`Scanner.max(strict_reference=True)` walks scan.rs:200-249 as written -- u8 DiscreteMatrix
+    """`Scanner.max()` (the default call) walks scan.rs:200-249 as written -- u8 DiscreteMatrix
     scores steer the candidates, no `position + M <= L` test, first candidate accepted without
     the f32 threshold test, level = u8 score of the current best -- and must equal the oracle's
-    literal restatement (np_oracle.scanner_max_strict) on inputs built to hit each quirk; the
-    default mode must stay the best VALID hit."""
+    literal restatement (np_oracle.scanner_max_strict) on inputs built to hit each quirk;
+    `max_valid()` is the opt-in best VALID hit."""
     rng = np.random.default_rng(sum(map(ord, kind)))
     length, m = 30_011, 9
     enc = rng.integers(0, 4, length, dtype=np.uint8)
@@ -739,22 +750,22 @@ def test_scanner_max_strict_reference_mode(pli, kind):
                 want = (col * ref.rows + first_row + r, want[1])
         else:
             want = no.scanner_max_strict(scores, d, 32, t, scale, bs)
-        got = sc.max(strict_reference=True)
+        got = sc.max()
         if want is None:
             assert got is None, (kind, bs)
         else:
             assert got is not None and got.position == want[0] and np.float32(got.score) == want[1], (kind, bs, got, want)
-    # the default mode: the best valid hit, whatever the u8 scores say
+    # the opt-in variant: the best valid hit, whatever the u8 scores say
     best = no.scanner_max(scores, 32, length, m, t)
-    got = lm.Scanner(pssm, seq, threshold=t).max()
+    got = lm.Scanner(pssm, seq, threshold=t).max_valid()
     assert (got is None) == (best is None)
     if best is not None:
         assert got.position == best[0] and np.float32(got.score) == best[1]
     if kind == "below_threshold_first_candidate":
-        strict = lm.Scanner(pssm, seq, threshold=t).max(strict_reference=True)
+        strict = lm.Scanner(pssm, seq, threshold=t).max()
         assert best is None and (strict is None or strict.score < t)
     if kind == "finite_n_tail":
-        strict = lm.Scanner(pssm, seq, threshold=t).max(strict_reference=True)
+        strict = lm.Scanner(pssm, seq, threshold=t).max()
         assert strict.position + m > length             # the reference reports a position in the padded tail
         # ... and where a candidate's window leaves the striped matrix, `seq[pos + j]` panics in the
         # reference (seq.rs:433-442 indexes column C): the strict mode raises likewise
@@ -762,7 +773,7 @@ def test_scanner_max_strict_reference_mode(pli, kind):
         p2[:, 4] = 3.0
         hot = lm.ScoringMatrix(p2)
         with pytest.raises(IndexError):
-            lm.Scanner(hot, seq, threshold=t).max(strict_reference=True)
+            lm.Scanner(hot, seq, threshold=t).max()
 
 
 def test_scanner_on_protein(pli):
@@ -788,7 +799,7 @@ def test_scanner_on_protein(pli):
         got = [(h.position, np.float32(h.score)) for h in sc]
         assert len(got) > 20 and got == [(i, s) for i, s in order]
         best = no.scanner_max(want, 32, length, m, t)
-        top = lm.Scanner(pssm, seq, threshold=t, block_size=bs).max()
+        top = lm.Scanner(pssm, seq, threshold=t, block_size=bs).max_valid()
         assert (top.position, np.float32(top.score)) == best
     for on in (True, False):                                  # prefilter on / off: same hits
         pli.set_prefilter(on)

@@ -120,3 +120,34 @@ def test_to_discrete_equals_the_oracle_restatement():
         for q in (0, 1, 100, 255):
             assert np.float32(dm.unscale(q)) == no.discrete_unscale(q, factor, offset)
         assert dm.scale(pssm.max_score()) <= 255
+
+
+def test_bench_helpers_without_a_gpu(monkeypatch):
+    """bench.py's launch plumbing: the host topology the cpu_baseline object states, and the command line a
+    launcher-less `--gpus N` run re-executes itself with."""
+    import importlib.util
+    import subprocess
+    import sys
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("lm_bench", Path(__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    topo = bench.cpu_topology()
+    assert topo["sockets"] >= 1 and 1 <= topo["cores"] <= topo["threads"]
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 0
+        return R()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7"])
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(4)
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
