@@ -218,15 +218,11 @@ def cpu_baseline(seq_sample: np.ndarray, length: int, pssm: np.ndarray, gpu_scor
 def init_ranks(args):
     """World of this run.  Under a launcher (torch.distributed.run: WORLD_SIZE / RANK / LOCAL_RANK in
     the environment) the environment is authoritative -- `--gpus` that disagrees is noted in the
-    line, not fatal.  Without one, `--gpus N > 1` launches the N ranks itself (self_launch).  The
+    line, not fatal.  Without one, `--gpus N > 1` has already launched the N ranks itself (main -> self_launch).  The
     process group gets a bounded timeout so that a rank that died raises on the others instead of
     hanging them."""
     import datetime
     note = None
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        if not args.single_device and torch.cuda.device_count() < args.gpus:
-            raise SystemExit(f"--gpus {args.gpus}: this node shows {torch.cuda.device_count()} GPU(s)")
-        self_launch(args.gpus)                          # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
@@ -579,6 +575,10 @@ def main() -> None:
     ap.add_argument("--ab", action="store_true",
                     help="development: interleaved A/B of the store kernel's tuning knobs, then exit")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:    # no launcher: become one (before stdout is set aside)
+        if not args.single_device and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus}: this node shows {torch.cuda.device_count()} GPU(s)")
+        self_launch(args.gpus)                              # does not return
     claim_stdout()
     if args.config == "c3":
         if args.steps == 200 and args.warmup == 50:
