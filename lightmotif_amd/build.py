@@ -28,6 +28,10 @@ FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
          f"-I{ROOT / 'include'}", f"-I{CSRC}"]
 # score_inst.hip is compiled 9 times: motif lengths 4*i+1 .. 4*i+4 (M = 1 .. 36)
 INST = [(i, 4 * i + 1, 4 * i + 4) for i in range(9)]
+# score_long_inst.hip is compiled once per padded long motif length M' = 40, 44 ... 64 (exact f32 kernels only);
+# the raised unroll budget is what keeps their accumulators in registers (see the file's header)
+LONG = list(range(40, 65, 4))
+LONG_FLAGS = ["-mllvm", "-pragma-unroll-threshold=10000000"]
 UNITS = ["score.hip", "reduce.hip", "hits.hip", "discrete.hip", "layout.hip", "api.hip", "comm.hip"]
 
 
@@ -69,6 +73,12 @@ def build(force: bool = False, jobs: int | None = None) -> Path:
         if force or _newer(obj, [CSRC / "score_inst.hip"] + headers):
             cmds.append([hipcc, *FLAGS, f"-DLM_M_LO={lo}", f"-DLM_M_HI={hi}", f"-DLM_INST_ID={inst}",
                          "-c", str(CSRC / "score_inst.hip"), "-o", str(obj)])
+    for m in LONG:
+        obj = OBJ / f"score_long_inst_{m}.o"
+        objs.append(obj)
+        if force or _newer(obj, [CSRC / "score_long_inst.hip"] + headers):
+            cmds.append([hipcc, *FLAGS, *LONG_FLAGS, f"-DLM_LONG_M={m}", "-c", str(CSRC / "score_long_inst.hip"),
+                         "-o", str(obj)])
     if cmds:
         with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
             list(ex.map(_run, cmds))

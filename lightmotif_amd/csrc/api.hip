@@ -553,9 +553,11 @@ int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stri
             }
         }
         if (m > (size_t)kMaxFastM && k <= 64) {
-            // long motifs: slices of <= kMaxFastM rows (multiples of 4 rows: dword symbol loads)
-            const size_t nparts = (m + kMaxFastM - 1) / kMaxFastM;
-            const size_t len = std::min<size_t>(((m + nparts - 1) / nparts + 3) / 4 * 4, (size_t)kMaxFastM);
+            // long motifs: slices of <= kMaxLongM rows (multiples of 4 rows: dword symbol loads).  Up to
+            // kMaxLongM that is ONE slice -- a single pass of the long kernel family (score_long_inst.hip);
+            // beyond, the first slice is stored and the others continue in place (MODE_CONTINUE)
+            const size_t nparts = (m + kMaxLongM - 1) / kMaxLongM;
+            const size_t len = std::min<size_t>(((m + nparts - 1) / nparts + 3) / 4 * 4, (size_t)kMaxLongM);
             for (size_t off = 0; off < m; off += len) {
                 lm_hip_pssm::Part part;
                 part.off = off;

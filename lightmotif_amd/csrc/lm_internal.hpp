@@ -127,8 +127,9 @@ struct lm_hip_pssm {
     // same f32 sequence as 0.0 + P[0] ...: bit-identical)
     float *d_table_pad = nullptr;
     size_t lead = 0;
-    // M > kMaxFastM (C = 32): slices of <= kMaxFastM rows, each with its own transposed table; the
-    // first is scored with the store kernel, the others continue from the stored partial sums
+    // M > kMaxFastM (C = 32): slices of <= kMaxLongM rows, each with its own transposed table; the
+    // first is scored with the store kernel, the others continue from the stored partial sums.
+    // M <= kMaxLongM is ONE slice: the single-pass long kernels (score.hip: exact_motif)
     struct Part {
         size_t off = 0, m = 0, ts = 0, lead = 0;  // `m` includes `lead` leading zero rows (table only)
         float *d_table = nullptr;

@@ -25,15 +25,22 @@ void register_score_c32_5(const KernelRegistry &r);
 void register_score_c32_6(const KernelRegistry &r);
 void register_score_c32_7(const KernelRegistry &r);
 void register_score_c32_8(const KernelRegistry &r);
+void register_score_c32_long_40(const KernelRegistry &r);
+void register_score_c32_long_44(const KernelRegistry &r);
+void register_score_c32_long_48(const KernelRegistry &r);
+void register_score_c32_long_52(const KernelRegistry &r);
+void register_score_c32_long_56(const KernelRegistry &r);
+void register_score_c32_long_60(const KernelRegistry &r);
+void register_score_c32_long_64(const KernelRegistry &r);
 
-static ScoreC32Launcher g_c32[kMaxFastM + 1][kRegistrySlots];
+static ScoreC32Launcher g_c32[kMaxLongM + 1][kRegistrySlots];  // rows kMaxFastM + 1 ..: the long family (M % 4 == 0)
 static PrefilterLauncher g_pre[kMaxFastM + 1];
 static PrefilterLauncher g_pre2[kMaxFastM + 1];
 static PrefilterLauncher g_pre2_protein[kMaxFastM + 1];
 static ScoreU8Launcher g_u8[kMaxFastM + 1];
 static ScoreU8Launcher g_u8_pairs[kMaxFastM + 1];
 static PrefilterMultiLauncher g_pre2_multi[kMaxFastM + 1];
-static char g_c32_names[kMaxFastM + 1][3][32];
+static char g_c32_names[kMaxLongM + 1][3][32];
 static std::once_flag g_c32_once;
 
 static void init_registry()
@@ -48,7 +55,14 @@ static void init_registry()
     register_score_c32_6(r);
     register_score_c32_7(r);
     register_score_c32_8(r);
-    for (int m = 0; m <= kMaxFastM; ++m)
+    register_score_c32_long_40(r);
+    register_score_c32_long_44(r);
+    register_score_c32_long_48(r);
+    register_score_c32_long_52(r);
+    register_score_c32_long_56(r);
+    register_score_c32_long_60(r);
+    register_score_c32_long_64(r);
+    for (int m = 0; m <= kMaxLongM; ++m)
         for (int mode = 0; mode < 3; ++mode)
             snprintf(g_c32_names[m][mode], sizeof g_c32_names[m][mode], "score_c32<%d,%d>", m, mode);
 }
@@ -56,7 +70,7 @@ static void init_registry()
 ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap)
 {
     std::call_once(g_c32_once, init_registry);
-    if (M < 1 || M > kMaxFastM || mode < 0 || mode > 2)
+    if (M < 1 || M > kMaxLongM || mode < 0 || mode > 2)
         return nullptr;
     if (mode == MODE_STORE && xcd_remap)
         return g_c32[M][3];
@@ -86,13 +100,13 @@ PrefilterMultiLauncher score_c32_prefilter2_multi_lookup(int M)
 ScoreC32Launcher score_c32_lookup_store_argmax(int M)
 {
     std::call_once(g_c32_once, init_registry);
-    return (M >= 1 && M <= kMaxFastM) ? g_c32[M][8] : nullptr;
+    return (M >= 1 && M <= kMaxLongM) ? g_c32[M][8] : nullptr;
 }
 
 ScoreC32Launcher score_c32_lookup_continue(int M)
 {
     std::call_once(g_c32_once, init_registry);
-    return (M >= 1 && M <= kMaxFastM) ? g_c32[M][9] : nullptr;
+    return (M >= 1 && M <= kMaxLongM) ? g_c32[M][9] : nullptr;
 }
 
 ScoreC32Launcher score_c32_lookup_c16(int M)
@@ -104,7 +118,7 @@ ScoreC32Launcher score_c32_lookup_c16(int M)
 ScoreC32Launcher score_c32_lookup_ql(int M)
 {
     std::call_once(g_c32_once, init_registry);
-    return (M >= 1 && M <= kMaxFastM) ? g_c32[M][7] : nullptr;
+    return (M >= 1 && M <= kMaxLongM) ? g_c32[M][7] : nullptr;
 }
 
 ScoreU8Launcher score_c32_lookup_u8(int M, bool pairs)
@@ -116,7 +130,7 @@ ScoreU8Launcher score_c32_lookup_u8(int M, bool pairs)
 const char *score_c32_name(int M, int mode)
 {
     std::call_once(g_c32_once, init_registry);
-    return g_c32_names[M][mode];
+    return (M >= 0 && M <= kMaxLongM && mode >= 0 && mode < 3) ? g_c32_names[M][mode] : "score_c32";
 }
 
 // ---- stream geometry ---------------------------------------------------------------
@@ -151,10 +165,28 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const Score
                         int prefilter = 0, size_t batch = 1, unsigned long long default_rows = 0,
                         bool allow16 = false);
 
+// How the exact C = 32 kernels see a motif: up to kMaxFastM rows as they are (byte symbol loads, any length);
+// kMaxFastM < M <= kMaxLongM as ONE slice padded with leading zero rows to a multiple of 4 (the long family:
+// dword symbol loads, so the matrix must be 4-byte aligned); longer motifs have no single-pass kernel.
+struct ExactMotif {
+    size_t m = 0;            // rows the kernel is instantiated for
+    const float *table = nullptr;
+    unsigned lead = 0;       // leading all-zero rows among them
+};
+static ExactMotif exact_motif(const lm_hip_pssm *p, const uint8_t *d_seq)
+{
+    if (p->m <= (size_t)kMaxFastM)
+        return ExactMotif{p->m, p->d_table, 0u};
+    if (p->parts.size() == 1 && p->parts[0].m <= (size_t)kMaxLongM && reinterpret_cast<uintptr_t>(d_seq) % 4 == 0)
+        return ExactMotif{p->parts[0].m, p->parts[0].d_table, (unsigned)p->parts[0].lead};
+    return ExactMotif{};
+}
+
 static C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store, int prefilter = 0,
                         size_t batch = 1)
 {
-    const MotifShape ms{a.pssm->m, a.pssm->k, a.pssm->d_image2 != nullptr};
+    const size_t m = prefilter == 0 ? exact_motif(a.pssm, a.d_seq).m : a.pssm->m;
+    const MotifShape ms{m, a.pssm->k, a.pssm->d_image2 != nullptr};
     return plan_c32(ctx, ms, a, store, prefilter, batch);
 }
 
@@ -174,8 +206,10 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const Score
     const bool c16 = allow16 && store && prefilter == 0 && a.cols == 16;
     if ((a.cols != 32 && !c16) || a.seq_stride != 32 || (store && a.out_stride != a.cols))
         return p;
-    if (ms.m < 1 || ms.m > (size_t)kMaxFastM || n < M + extra)
+    if (ms.m < 1 || ms.m > (size_t)(prefilter == 0 ? kMaxLongM : kMaxFastM) || n < M + extra)
         return p;
+    if (ms.m > (size_t)kMaxFastM && (ms.m % 4 != 0 || reinterpret_cast<uintptr_t>(a.d_seq) % 4 != 0))
+        return p;  // the long family: padded lengths, dword symbol loads
     // (the pair-symbol kernel fetches symbols with dword loads: 4-byte aligned matrix)
     if (prefilter == 2 && ((K != 5 && !(K == 21 && ctx->pair_prefilter_protein)) || !ms.pair_table || ms.m < 2 ||
                            reinterpret_cast<uintptr_t>(a.d_seq) % 4 != 0))
@@ -286,8 +320,9 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
         }
     }
     const bool c16 = a.cols == 16 && dwords && score_c32_lookup_c16((int)a.pssm->m);
-    const C32Plan p = plan_c32(ctx, MotifShape{a.pssm->m, a.pssm->k, false}, a, true, 0, 1,
-                               store_rows_hint(a.pssm->m, a.cols), c16);
+    const C32Plan p = a.pssm->m <= (size_t)kMaxFastM ? plan_c32(ctx, MotifShape{a.pssm->m, a.pssm->k, false}, a, true, 0, 1,
+                                                                  store_rows_hint(a.pssm->m, a.cols), c16)
+                                                      : C32Plan{};  // longer: the slices below
     if (p.ok) {
         ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_STORE, ctx->xcd_remap);
         if (dwords && score_c32_lookup_ql((int)a.pssm->m))
@@ -304,7 +339,7 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
     // order, bit-identical), over whole streams only -- a cell must be read and rewritten exactly once,
     // so no shifted or repeated stream -- and the few rows left over go cell by cell.
     if (!a.pssm->parts.empty() && a.cols == 32 && a.seq_stride == 32 && a.out_stride == 32 &&
-        reinterpret_cast<uintptr_t>(a.d_seq) % 4 == 0 && a.row_end - a.row_begin > (size_t)kMaxFastM) {
+        reinterpret_cast<uintptr_t>(a.d_seq) % 4 == 0 && a.row_end - a.row_begin > a.pssm->parts[0].m) {
         const unsigned long long n = a.row_end - a.row_begin;
         bool ok = true;
         for (size_t i = 0; i < a.pssm->parts.size() && ok; ++i) {
@@ -346,7 +381,8 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
             }
         }
         if (ok) {
-            ctx->last_kernel = "score_c32_sliced";
+            ctx->last_kernel = a.pssm->parts.size() == 1 ? score_c32_name((int)a.pssm->parts[0].m, MODE_STORE)
+                                                         : "score_c32_sliced";
             return LM_HIP_OK;
         }
     }
@@ -617,10 +653,14 @@ int launch_score_store_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord 
 {
     *tracked = false;
     // (lengths that are no multiple of 4 run the padded table, see launch_score_store)
-    const bool pad = a.pssm->d_table_pad != nullptr && ctx->quad_loads;
-    const size_t mk = a.pssm->m + (pad ? a.pssm->lead : 0);
+    const bool longm = a.pssm->m > (size_t)kMaxFastM;
+    const ExactMotif em = longm ? exact_motif(a.pssm, a.d_seq) : ExactMotif{};
+    const bool pad = longm ? em.m != 0 : (a.pssm->d_table_pad != nullptr && ctx->quad_loads);
+    const size_t mk = longm ? em.m : a.pssm->m + (pad ? a.pssm->lead : 0);
+    const unsigned lead = longm ? em.lead : (unsigned)a.pssm->lead;
+    const float *pad_table = longm ? em.table : a.pssm->d_table_pad;
     const MotifShape ms{mk, a.pssm->k, false};
-    const C32Plan p = a.pssm->m <= (size_t)kMaxFastM ? plan_c32(ctx, ms, a, true) : C32Plan{};
+    const C32Plan p = mk >= 1 ? plan_c32(ctx, ms, a, true) : C32Plan{};
     ScoreC32Launcher fn = p.ok ? score_c32_lookup_store_argmax((int)mk) : nullptr;
     if (!fn || reinterpret_cast<uintptr_t>(a.d_seq) % 4 != 0)
         return launch_score_store(ctx, a);
@@ -631,9 +671,9 @@ int launch_score_store_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord 
     FusedOut fo{};
     fo.block_best = static_cast<ArgmaxRecord *>(ctx->scratch.ptr);
     ArgmaxRecord *folded = fo.block_best + nrec;
-    fo.lead_rows = pad ? (unsigned)a.pssm->lead : 0u;
+    fo.lead_rows = pad ? lead : 0u;
     ctx->last_kernel = score_c32_name((int)mk, MODE_STORE);
-    LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, pad ? a.pssm->d_table_pad : a.pssm->d_table, (int)a.pssm->k,
+    LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, pad ? pad_table : a.pssm->d_table, (int)a.pssm->k,
                   a.row_begin, a.row_end, p.T, p.nstreams, a.d_out, fo));
     const ArgmaxRecord *recs = fo.block_best;
     unsigned n = nrec;
@@ -836,7 +876,7 @@ static bool chunked_ok(const lm_hip_ctx *ctx, const ScoreArgs &a)
     const unsigned long long n = a.row_end - a.row_begin;
     if (a.cols == 32)
         return !a.pssm->parts.empty() && a.seq_stride == 32 && reinterpret_cast<uintptr_t>(a.d_seq) % 4 == 0 &&
-               n > (unsigned long long)kMaxFastM;
+               n > (unsigned long long)a.pssm->parts[0].m;
     return a.cols >= 1 && a.cols <= 4096 && n * a.cols >= (1ull << 16) && n > a.pssm->m;
 }
 
@@ -972,7 +1012,7 @@ static int launch_score_argmax_exact(lm_hip_ctx *ctx, const ScoreArgs *jobs, siz
     BatchParams *d_bparams = nullptr;
     if (n > 1) {
         for (size_t i = 0; i < n; ++i)
-            bparams[i] = BatchParams{jobs[i].pssm->d_table, blocks + block_pos[i], 0.0f, 0u, 0ull};
+            bparams[i] = BatchParams{exact_motif(jobs[i].pssm, jobs[i].d_seq).table, blocks + block_pos[i], 0.0f, 0u, 0ull};
         LM_TRY(ctx->scratch2.reserve(sizeof(BatchParams) * n));
         d_bparams = static_cast<BatchParams *>(ctx->scratch2.ptr);
     }
@@ -995,9 +1035,11 @@ static int launch_score_argmax_exact(lm_hip_ctx *ctx, const ScoreArgs *jobs, siz
         fo.block_best = blocks + block_pos[g.idx[0]];
         if (g.kind == KIND_EXACT) {
             fo.batch = n > 1 ? d_bparams + bp_pos : nullptr;
-            ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_ARGMAX, false);
-            ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_ARGMAX);
-            LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
+            const ExactMotif em = exact_motif(a.pssm, a.d_seq);  // (a group shares length, hence padding)
+            fo.lead_rows = em.lead;
+            ScoreC32Launcher fn = score_c32_lookup((int)em.m, MODE_ARGMAX, false);
+            ctx->last_kernel = score_c32_name((int)em.m, MODE_ARGMAX);
+            LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, em.table, (int)a.pssm->k,
                           a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, nullptr, fo));
         } else if (g.kind == KIND_CHUNKED) {
             // (always on ctx->stream: the chunk buffer is shared)
@@ -1279,6 +1321,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
                 return fail(LM_HIP_ERR_BAD_ARGS, "fused threshold: position keys need equal row ranges");
             bparams.push_back(BatchParams{g.kind == KIND_PREFILTER2  ? (const void *)a.pssm->d_image2
                                           : g.kind == KIND_PREFILTER ? (const void *)a.pssm->d_image
+                                          : g.kind == KIND_EXACT     ? (const void *)exact_motif(a.pssm, a.d_seq).table
                                                                      : (const void *)a.pssm->d_table,
                                           nullptr, ts[i], tds[i], (unsigned long long)i << 40});
             rjobs[i] = RescoreJob{a.d_seq + a.row_begin * a.seq_stride, a.pssm->d_dense,
@@ -1363,10 +1406,13 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
                               (int)a.pssm->k, a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, tds[i], fo));
                 any_candidates = true;
             } else if (g.kind == KIND_EXACT) {
-                ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_THRESHOLD, false);
-                ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_THRESHOLD);
-                LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
-                              a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, nullptr, fo));
+                const ExactMotif em = exact_motif(a.pssm, a.d_seq);
+                FusedOut efo = fo;
+                efo.lead_rows = em.lead;
+                ScoreC32Launcher fn = score_c32_lookup((int)em.m, MODE_THRESHOLD, false);
+                ctx->last_kernel = score_c32_name((int)em.m, MODE_THRESHOLD);
+                LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, em.table, (int)a.pssm->k,
+                              a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, nullptr, efo));
                 any_candidates = true;
             } else if (g.kind == KIND_CHUNKED) {  // appends hits directly, chunk by chunk, on ctx->stream
                 const FusedOut cfo = fo;

@@ -47,7 +47,11 @@ namespace lm {
 #endif
 constexpr int kBlock = LM_BLOCK;                 // threads per workgroup (4 wavefronts)
 constexpr int kStreamsPerBlock = kBlock / 32;    // 2 per wavefront
-constexpr int kMaxFastM = 36;        // largest motif the unrolled kernel is built for
+constexpr int kMaxFastM = 36;        // largest motif the whole kernel family (every length, prefilters, u8) is built for
+// 36 < M <= 64: the exact f32 kernels only, for the padded lengths M' = 40, 44 ... 64 (leading zero rows, see
+// lm_hip_pssm::Part::lead): one pass over the sequence like the reference's AVX2 loop takes for any length
+// (avx2.rs:146-193).  M' = 64 needs 163 VGPRs, three wavefronts per SIMD, no scratch (score_long_inst.hip).
+constexpr int kMaxLongM = 64;
 
 // Floats per symbol row of the transposed LDS table used by score_c32<M>:
 // 4 * (smallest odd number >= ceil(M/4)).
@@ -225,12 +229,28 @@ __device__ __forceinline__ void record_hit(const FusedOut &fo, unsigned long lon
 // __launch_bounds__ argument).  Without it the fused-threshold variant is allocated
 // 228 VGPRs (2 waves/SIMD) although ~75 suffice.
 #ifndef LM_SCORE_MIN_WAVES
-#define LM_SCORE_MIN_WAVES(M) ((M) <= 20 ? 6 : 4)
+#define LM_SCORE_MIN_WAVES(M) ((M) <= 20 ? 6 : (M) <= 40 ? 4 : 3)
 #endif
 // 1 = score rows are written with non-temporal (streaming) stores
 #ifndef LM_SCORE_NT_STORE
 #define LM_SCORE_NT_STORE 1
 #endif
+
+// The long family (M' = 44 ... 64) is compiled against a budget of two wavefronts per SIMD (256 VGPRs).  Most of
+// its kernels need 130-170 registers and still run three wavefronts; where the tighter bound made the
+// scheduler serialise reads and adds it cost more than the wavefront (plain store, 1 Gbp: M' = 44 1.85 -> 1.50 ms,
+// M' = 64 2.24 -> 2.04 ms, the other lengths unchanged; profiles/r03_long_variants_ab.txt), and the fused forms
+// from M' = 56 on would spill at the bound of three (15-38 VGPRs at M' = 64).
+#ifndef LM_LONG_STORE_MINW
+#define LM_LONG_STORE_MINW 2
+#endif
+// The fused forms, measured per length (fused threshold / argmax call, 1 Gbp, bound 3 vs 2: M' = 44 1.66 / 1.88 vs
+// 1.41 / 1.28 ms, 48 1.95 / 1.42 vs 1.55 / 1.40, 52 1.86 / 1.56 vs 2.15 / 1.56; profiles/r03_long_variants_ab.txt):
+// two everywhere but at M' = 52.
+constexpr int score_min_waves(int m, int mode)
+{
+    return m <= 40 ? LM_SCORE_MIN_WAVES(m) : mode == 0 /* MODE_STORE */ ? LM_LONG_STORE_MINW : m == 52 ? 3 : 2;
+}
 
 template <int M>
 __device__ __forceinline__ void lds_fetch_column(float (&w)[4 * ((M + 3) / 4)],
@@ -559,7 +579,8 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
     constexpr int QL = (QLREQ && M % 4 == 0 && LP == 0) ? 1 : 0;
     const unsigned shq = 8u * (col & 3);
     // (padded motifs: the first `lead` rows of a window carry zero weights and may lie before the matrix)
-    const long long lead = mode_stores(MODE) ? (long long)fo_in.lead_rows : 0;
+    // (the fused modes of the short family are never launched on padded tables; the long family always is)
+    const long long lead = (mode_stores(MODE) || M > kMaxFastM) ? (long long)fo_in.lead_rows : 0;
     const long long in0 = (long long)o0 - lead;
     const uint8_t *sp = QL ? seq + (in0 + (col & 3)) * 32 + (col >> 2) * 4 : seq + in0 * 32 + col;
     // output row completed by step t is o0 + t - (M-1); `op` tracks step 0 of the group
@@ -881,7 +902,7 @@ hipError_t score_c32_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, con
                             unsigned long long nstreams, float *out, FusedOut fo)
 {
     hipLaunchKernelGGL((score_c32<M, MODE, LM_SCORE_PF, LM_SCORE_LP, LM_BLOCK, XCD,
-                                  LM_SCORE_MIN_WAVES(M), QL, OC>), grid,
+                                  score_min_waves(M, MODE), QL, OC>), grid,
                        dim3(kBlock), lds_bytes, stream, seq, table, K, row_begin, row_end, T,
                        nstreams, out, fo);
     return hipGetLastError();

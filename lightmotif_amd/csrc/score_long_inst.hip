@@ -1,0 +1,32 @@
+// score_long_inst.hip -- the exact f32 kernels for ONE padded motif length LM_LONG_M in {40, 44 ... 64}.
+// Compiled once per length (build.py) with -mllvm -pragma-unroll-threshold raised: the M x M step / weight loops
+// of a group only become register-indexed accumulators when they unroll completely, and LLVM's default
+// budget for `#pragma unroll` (16 K unrolled instructions) ends at M ~ 40 -- past it the accumulators fall into
+// scratch (2 564 scratch instructions at M = 40 without the flag, none with it).
+#include "score_u8.hpp"
+
+#ifndef LM_LONG_M
+#error "LM_LONG_M must be defined"
+#endif
+
+namespace lm {
+
+#define LM_CAT2(a, b) a##b
+#define LM_CAT(a, b) LM_CAT2(a, b)
+
+static_assert(LM_LONG_M > kMaxFastM && LM_LONG_M <= kMaxLongM && LM_LONG_M % 4 == 0, "padded long motif length");
+
+void LM_CAT(register_score_c32_long_, LM_LONG_M)(const KernelRegistry &r)
+{
+    constexpr int M = LM_LONG_M;
+    ScoreC32Launcher *tab = r.c32[M];
+    // every kernel of this family fetches symbols with dword loads (M % 4 == 0, 4-byte aligned matrix)
+    tab[MODE_STORE] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1>;
+    tab[MODE_ARGMAX] = &score_c32_launch<M, MODE_ARGMAX, LM_SCORE_XCD_REMAP, 1>;
+    tab[MODE_THRESHOLD] = &score_c32_launch<M, MODE_THRESHOLD, LM_SCORE_XCD_REMAP, 1>;
+    tab[7] = tab[MODE_STORE];
+    tab[8] = &score_c32_launch<M, MODE_STORE_ARGMAX, LM_SCORE_XCD_REMAP, 1>;
+    tab[9] = &score_c32_launch<M, MODE_CONTINUE, LM_SCORE_XCD_REMAP, 1>;
+}
+
+}  // namespace lm

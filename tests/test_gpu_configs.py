@@ -426,13 +426,21 @@ def test_adopted_sequence_borrows_the_callers_matrix(gpu_pli):
 # ---- beyond the unrolled C = 32 kernels: long motifs and other column counts ------------------
 
 
-@pytest.mark.parametrize("m", [37, 38, 40, 47, 48, 63, 64, 72, 73, 100, 150])
+def long_kernel(m, mode):
+    """36 < M <= 64: ONE pass of the long kernel family at the padded length M' = 4 * ceil(M / 4)
+    (score_long_inst.hip); beyond 64: slices of <= 64 rows (store + in-place continuation)."""
+    if m <= 64:
+        return f"score_c32<{-(-m // 4) * 4},{mode}>"
+    return "score_c32_sliced" if mode == 0 else "score_c32_sliced+reduce"
+
+
+@pytest.mark.parametrize("m", [37, 38, 40, 41, 44, 47, 48, 52, 55, 56, 60, 63, 64, 65, 72, 73, 100, 128, 129, 150])
 def test_long_motifs_are_scored_in_slices(pli, m):
-    """M > 36 at C = 32 (round 1: one thread per cell, 78 Gpos/s): slices of <= 36 motif rows, the
-    first through the store kernel, the others continuing in place from the partial sums
-    (score_c32<M', MODE_CONTINUE>) -- the same sequential adds, so bit-exact against the oracle on
-    ragged lengths, row ranges, -inf / NaN weights, N runs.  The reference's AVX2 loop takes any
-    M (avx2.rs:146-193)."""
+    """M > 36 at C = 32: up to 64 rows in ONE pass (score_c32<M', 0> of the long family, leading zero
+    rows up to a multiple of 4); longer motifs in slices of <= 64 motif rows, the first through the
+    store kernel, the others continuing in place from the partial sums (score_c32<M', MODE_CONTINUE>)
+    -- the same sequential adds, so bit-exact against the oracle on ragged lengths, row ranges,
+    -inf / NaN weights, N runs.  The reference's AVX2 loop takes any M (avx2.rs:146-193)."""
     rng = np.random.default_rng(m)
     length = 3_000_000 + 17 * m
     enc = rng.integers(0, 5, length, dtype=np.uint8)
@@ -452,7 +460,7 @@ def test_long_motifs_are_scored_in_slices(pli, m):
     for a, b in ((0, ref.rows), (1234, ref.rows - 5), (ref.rows - 3 * m, ref.rows)):
         want, _ = co.score_rows(ref, p, a, b)
         pli.score_rows_into(pssm, seq, range(a, b), scores)
-        assert pli.last_kernel == "score_c32_sliced", pli.last_kernel
+        assert pli.last_kernel == long_kernel(m, 0), pli.last_kernel
         assert np.array_equal(bits(scores.matrix()[:, :COLS]), bits(want[:, :COLS])), (m, a, b)
     want, _ = co.score_rows(ref, p)
     pli.score_into(pssm, seq, scores)
@@ -464,9 +472,11 @@ def test_long_motifs_are_scored_in_slices(pli, m):
     assert np.array_equal(bits(scores.matrix()[:, :COLS]), bits(want[:, :COLS]))
 
 
-@pytest.mark.parametrize("m,chunk_rows", [(37, 5000), (40, 4096), (64, 1 << 20), (73, 7777), (100, 20_000), (150, 64)])
+@pytest.mark.parametrize("m,chunk_rows", [(37, 5000), (40, 4096), (45, 4096), (53, 4096), (59, 4096), (64, 1 << 20),
+                                          (65, 5000), (73, 7777), (100, 20_000), (150, 128)])
 def test_long_motifs_fused_reductions_go_chunk_by_chunk(monkeypatch, m, chunk_rows):
-    """score_argmax / score_threshold / Scanner-style hits of M > 36: the sliced store path into a
+    """score_argmax / score_threshold / Scanner-style hits of M > 36.  Up to 64 rows: the fused kernels of
+    the long family (score_c32<M', 1 | 2>), no score matrix.  Beyond: the sliced store path into a
     reusable chunk buffer + a reduction per chunk (score.hip, KIND_CHUNKED) instead of one thread per
     cell.  Same cells, same values: bit-exact against the oracle's materialised matrix, row-major hit
     order, last-maximal-cell ties across chunk borders, first-cell NaN rule, row sub-ranges."""
@@ -490,14 +500,14 @@ def test_long_motifs_fused_reductions_go_chunk_by_chunk(monkeypatch, m, chunk_ro
     for a, b in ((0, ref.rows), (123, ref.rows - 77)):
         want, _ = co.score_rows(ref, p, a, b)
         got = pli.score_argmax(pssm, seq, range(a, b))
-        assert pli.last_kernel == "score_c32_sliced+reduce", pli.last_kernel
+        assert pli.last_kernel == long_kernel(m, 1), pli.last_kernel
         assert got[0] == co.argmax(want, COLS)
         assert bits(np.float32(got[1])) == bits(co.max_(want, COLS))
         finite = np.sort(want[:, :COLS][np.isfinite(want[:, :COLS])])
         for t in (float(finite[-50]), float(finite[-5000])):
             wrc = [tuple(map(int, rc)) for rc in co.threshold(want, COLS, t)]
             frc, fval = pli.score_threshold(pssm, seq, t, range(a, b))
-            assert pli.last_kernel == "score_c32_sliced+reduce", pli.last_kernel
+            assert pli.last_kernel == long_kernel(m, 2), pli.last_kernel
             assert frc == wrc
             assert np.array_equal(bits(fval), bits([want[r, c] for r, c in wrc]))
     # first-cell NaN rule (pli/mod.rs:142-146) through the chunked path

@@ -442,7 +442,7 @@ def test_candidate_route_argmax_batches_share_passes(gpu_pli):
         assert batch == singles
 
 
-@pytest.mark.parametrize("m", [20, 40], ids=["m20", "m40_sliced"])
+@pytest.mark.parametrize("m", [20, 40], ids=["m20", "m40_long"])
 def test_more_than_2_32_cells_on_one_gpu(gpu_pli, m):
     """4.5 Gbp on one GPU (4.5 GB of symbols, 18 GB of scores): row-major cell indices and sequence
     positions pass 2^32, which `configs[3]`'s per-GPU shards never do.  The consensus k-mer of the PSSM

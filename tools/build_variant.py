@@ -12,6 +12,10 @@ sys.path.insert(0, str(ROOT))
 from lightmotif_amd import build as B  # noqa: E402
 
 tag, extra = sys.argv[1], sys.argv[2:]
+long_extra = []
+if "--long" in extra:       # flags after --long go to the long-family units (score_long_inst.hip) only
+    i = extra.index("--long")
+    extra, long_extra = extra[:i], extra[i + 1:]
 obj = B.CSRC / f"_obj_{tag}"
 obj.mkdir(exist_ok=True)
 hipcc = B._hipcc()
@@ -25,6 +29,15 @@ for inst, lo, hi in B.INST:
     objs.append(o)
     cmds.append([hipcc, *B.FLAGS, *extra, f"-DLM_M_LO={lo}", f"-DLM_M_HI={hi}", f"-DLM_INST_ID={inst}", "-c",
                  str(B.CSRC / "score_inst.hip"), "-o", str(o)])
+for m in B.LONG:
+    o = obj / f"score_long_inst_{m}.o"
+    objs.append(o)
+    cmds.append([hipcc, *B.FLAGS, *B.LONG_FLAGS, *extra, *long_extra, f"-DLM_LONG_M={m}", "-c",
+                 str(B.CSRC / "score_long_inst.hip"), "-o", str(o)])
+if long_extra and not extra:   # only the long units differ: reuse the shipped objects for the rest
+    keep = [c for c in cmds if "score_long_inst.hip" in " ".join(c)]
+    objs = [B.OBJ / o.name if "score_long_inst" not in o.name else o for o in objs]
+    cmds = keep
 with ThreadPoolExecutor(max_workers=8) as ex:
     list(ex.map(B._run, cmds))
 lib = B.CSRC / f"liblightmotif_hip_{tag}.so"

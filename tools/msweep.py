@@ -67,6 +67,13 @@ def main():
         rec["store"] = {"kernel": pli.last_kernel, "ms": round(t, 4), "ms_min": round(tmin, 4),
                         "Gpos_s": round(pos / t / 1e6, 1), "hbm_frac": round(5 * pos / (t * 1e-3) / HBM, 4),
                         "lds_frac": round(4 * m * pos / (t * 1e-3) / LDS, 4)}
+        if len(sys.argv) > 3:      # stream-length sweep of the store kernel: rows per stream (0 = the planner's default)
+            rec["store_rows_per_stream"] = {}
+            for rps in [int(x) for x in sys.argv[3].split(",")]:
+                pli.set_rows_per_stream(rps)
+                t2, _ = events_ms(lambda: pli.score_dptr(*args, out.data_ptr(), COLS), stream, reps=15, warm=5)
+                rec["store_rows_per_stream"][str(rps)] = round(t2, 4)
+            pli.set_rows_per_stream(0)
         sample = out[: 1 << 18].flatten()
         thr = float(torch.quantile(sample[torch.isfinite(sample)].float(), 1 - 1e-5))
         for name, pre in (("fused_threshold_prefilter", True), ("fused_threshold_exact", False)):
