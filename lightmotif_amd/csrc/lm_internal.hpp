@@ -93,6 +93,8 @@ struct lm_hip_ctx {
     size_t chunk_rows = 1u << 22; // rows of that chunk (512 MB at C = 32; LM_HIP_CHUNK_ROWS)
     bool chunked_fused = true;  // A/B knob: 0 = such motifs go cell by cell (LM_HIP_CHUNKED_FUSED)
     void *pinned = nullptr;     // kPinnedBytes of host-pinned memory for read-backs
+    unsigned fold_generation = 0; // of the last single-job fused argmax whose kernel wrote its result into `pinned`
+    unsigned *d_ticket = nullptr; // "last workgroup folds the records" counter of the single-launch argmax forms (zero between launches)
     size_t rows_per_stream = 0; // 0 = default
     bool use_prefilter = true;  // fused threshold: packed 16-bit discrete prefilter (A/B knob)
     bool xcd_remap = false;      // A/B knob of the store kernel (lm_hip_ctx_set_xcd_remap)
@@ -165,6 +167,11 @@ struct lm_hip_scores {
     // valid until the next library write into this handle)
     lm::ArgmaxRecord *d_best = nullptr;
     bool best_valid = false;
+    // pinned, device-visible copy of *d_best written by the same kernel (small score_into: MODE_STORE_TRACK):
+    // lm_hip_argmax then needs a stream synchronisation and no copy command
+    lm::ArgmaxRecord *h_best = nullptr;   // 64 pinned bytes: the record, then the generation word of the launch that wrote it
+    bool best_on_host = false;
+    unsigned best_generation = 0;         // of the last tracked launch into this handle
     // 0: this StripedScores is a row shard that does NOT hold the matrix's first cell, so the
     // "scores[0][0] is NaN -> (0,0)" rule of Maximum::argmax is skipped (lm_hip_scores_set_first_cell_rule)
     bool first_cell_rule = true;
@@ -207,6 +214,10 @@ int launch_threshold_u8(lm_hip_ctx *ctx, const uint8_t *d_scores, size_t rows, s
 // when the shape falls back to a plain store
 int launch_score_store_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *d_result, bool *tracked,
                               int first_cell_rule = 1);
+// small inputs: store + (value, cell) tracking + the fold of the workgroup records in ONE launch
+// (MODE_STORE_TRACK); the record also lands in *h_result (pinned, optional)
+int launch_score_store_track(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *d_result, ArgmaxRecord *h_result,
+                             unsigned generation, bool *tracked, int first_cell_rule = 1);
 int finalize_argmax_materialised(lm_hip_ctx *ctx, const ArgmaxRecord *d_blocks, unsigned nblocks,
                                  const float *d_scores, int first_cell_rule, ArgmaxRecord *d_out);
 // Fused score+argmax: leaves one ArgmaxRecord at ctx->scratch (device) -> out.

@@ -115,6 +115,12 @@ ScoreC32Launcher score_c32_lookup_c16(int M)
     return (M >= 1 && M <= kMaxFastM) ? g_c32[M][10] : nullptr;
 }
 
+ScoreC32Launcher score_c32_lookup_store_track(int M)
+{
+    std::call_once(g_c32_once, init_registry);
+    return (M >= 1 && M <= kMaxLongM) ? g_c32[M][11] : nullptr;
+}
+
 ScoreC32Launcher score_c32_lookup_ql(int M)
 {
     std::call_once(g_c32_once, init_registry);
@@ -689,6 +695,52 @@ int launch_score_store_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord 
     return LM_HIP_OK;
 }
 
+static int ensure_ticket(lm_hip_ctx *ctx)
+{
+    if (ctx->d_ticket)
+        return LM_HIP_OK;
+    LM_HIP_TRY(hipMalloc(&ctx->d_ticket, 64));
+    LM_HIP_TRY(hipMemsetAsync(ctx->d_ticket, 0, 64, ctx->stream));
+    return LM_HIP_OK;
+}
+
+// Small inputs (the reference's own bench is 464 165 bp, lightmotif-bench dna.rs:81-109): `score_into` + `argmax`
+// are launch-latency bound, so the store kernel tracks (value, cell) per lane and its last workgroup folds the
+// workgroup records -- one launch, no copy command (the record is also written to *h_result, pinned).
+int launch_score_store_track(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *d_result, ArgmaxRecord *h_result,
+                             unsigned generation, bool *tracked, int first_cell_rule)
+{
+    *tracked = false;
+    const bool longm = a.pssm->m > (size_t)kMaxFastM;
+    const ExactMotif em = longm ? exact_motif(a.pssm, a.d_seq) : ExactMotif{};
+    const bool pad = longm ? em.m != 0 : (a.pssm->d_table_pad != nullptr && ctx->quad_loads);
+    const size_t mk = longm ? em.m : a.pssm->m + (pad ? a.pssm->lead : 0);
+    const unsigned lead = longm ? em.lead : (unsigned)a.pssm->lead;
+    const float *table = pad ? (longm ? em.table : a.pssm->d_table_pad) : a.pssm->d_table;
+    const C32Plan p = (mk >= 1 && mk % 4 == 0 && a.cols == 32 && a.out_stride == 32 && ctx->quad_loads && !ctx->xcd_remap &&
+                       reinterpret_cast<uintptr_t>(a.d_seq) % 4 == 0)
+                          ? plan_c32(ctx, MotifShape{mk, a.pssm->k, false}, a, true, 0, 1, store_rows_hint(mk, a.cols))
+                          : C32Plan{};
+    ScoreC32Launcher fn = p.ok ? score_c32_lookup_store_track((int)mk) : nullptr;
+    if (!fn || !table)
+        return launch_score_store(ctx, a);
+    LM_TRY(ensure_ticket(ctx));
+    LM_TRY(ctx->scratch.reserve(sizeof(ArgmaxRecord) * (size_t)p.grid.x));
+    FusedOut fo{};
+    fo.block_best = static_cast<ArgmaxRecord *>(ctx->scratch.ptr);
+    fo.lead_rows = pad ? lead : 0u;
+    fo.ticket = ctx->d_ticket;
+    fo.final_out = d_result;
+    fo.final_host = h_result;
+    fo.generation = generation;
+    fo.first_cell_rule = first_cell_rule;
+    ctx->last_kernel = score_c32_name((int)mk, MODE_STORE);
+    LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, table, (int)a.pssm->k, a.row_begin, a.row_end, p.T, p.nstreams,
+                  a.d_out, fo));
+    *tracked = true;
+    return LM_HIP_OK;
+}
+
 // ---- fused argmax ---------------------------------------------------------------------
 
 // Final reduction of per-block records; also applies the reference's "scores[0]
@@ -1027,12 +1079,25 @@ static int launch_score_argmax_exact(lm_hip_ctx *ctx, const ScoreArgs *jobs, siz
     const bool two_streams = groups.size() > 1;
     if (two_streams)
         LM_TRY(batch_fork(ctx));
+    // one job through the exact kernel: its last workgroup folds the records and writes the result straight
+    // into the pinned block -- one launch instead of two (a small scan is launch-latency bound)
+    const bool fold_in_kernel = n == 1 && groups.size() == 1 && groups[0].kind == KIND_EXACT && zero_copy;
+    if (fold_in_kernel)
+        LM_TRY(ensure_ticket(ctx));
     size_t launch = 0, bp_pos = 0;
     for (const JobGroup &g : groups) {
         const ScoreArgs &a = jobs[g.idx[0]];
         hipStream_t st = (two_streams && (launch++ & 1)) ? ctx->aux_stream : ctx->stream;
         FusedOut fo{};
         fo.block_best = blocks + block_pos[g.idx[0]];
+        if (fold_in_kernel) {
+            fo.ticket = ctx->d_ticket;
+            fo.final_out = reinterpret_cast<ArgmaxRecord *>(ctx->d_ticket + 4);  // device copy nobody reads: 16 spare bytes
+            fo.final_host = results;                                             // pinned: record, then the generation word
+            fo.generation = ++ctx->fold_generation ? ctx->fold_generation : ++ctx->fold_generation;
+            *reinterpret_cast<volatile unsigned *>(results + 1) = 0u;  // (the block is shared staging: no stale match)
+            fo.first_cell_rule = first_cell_rule;
+        }
         if (g.kind == KIND_EXACT) {
             fo.batch = n > 1 ? d_bparams + bp_pos : nullptr;
             const ExactMotif em = exact_motif(a.pssm, a.d_seq);  // (a group shares length, hence padding)
@@ -1067,12 +1132,30 @@ static int launch_score_argmax_exact(lm_hip_ctx *ctx, const ScoreArgs *jobs, siz
     if (!zero_copy)
         LM_HIP_TRY(hipMemcpyAsync(d_jobs, fj, sizeof(FinalizeJob) * n, hipMemcpyHostToDevice,
                                   ctx->stream));
-    hipLaunchKernelGGL(argmax_finalize_batch, dim3((unsigned)n), dim3(kBlock), 0, ctx->stream,
-                       d_jobs, first_cell_rule, results);
-    LM_HIP_TRY(hipGetLastError());
+    if (!fold_in_kernel) {
+        hipLaunchKernelGGL(argmax_finalize_batch, dim3((unsigned)n), dim3(kBlock), 0, ctx->stream,
+                           d_jobs, first_cell_rule, results);
+        LM_HIP_TRY(hipGetLastError());
+    }
     if (!zero_copy)
         LM_HIP_TRY(hipMemcpyAsync(out, results, sizeof(ArgmaxRecord) * n, hipMemcpyDeviceToHost,
                                   ctx->stream));
+    if (fold_in_kernel) {
+        // the kernel raises the generation word behind the pinned record once it is written: poll it (a PCIe write
+        // after the fold) instead of waiting for the kernel's completion signal; bounded, then synchronise
+        const volatile unsigned *gen = reinterpret_cast<const volatile unsigned *>(results + 1);
+        bool seen = false;
+        for (unsigned spin = 0; spin < (1u << 20) && !seen; ++spin) {
+            seen = __atomic_load_n(gen, __ATOMIC_ACQUIRE) == ctx->fold_generation;
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+            __builtin_ia32_pause();
+#endif
+        }
+        if (!seen)
+            LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        memcpy(out, results, sizeof(ArgmaxRecord));
+        return LM_HIP_OK;
+    }
     LM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // also keeps `fj` alive long enough
     if (zero_copy)
         memcpy(out, results, sizeof(ArgmaxRecord) * n);

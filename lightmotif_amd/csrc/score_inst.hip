@@ -33,6 +33,7 @@ struct RegisterRange {
         if constexpr (M % 4 == 0) {
             tab[7] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1>;
             tab[10] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1, 16>;
+            tab[11] = &score_c32_launch<M, MODE_STORE_TRACK, LM_SCORE_XCD_REMAP, 1>;
         }
         tab[8] = &score_c32_launch<M, MODE_STORE_ARGMAX, LM_SCORE_XCD_REMAP, 1>;
         tab[9] = &score_c32_launch<M, MODE_CONTINUE, LM_SCORE_XCD_REMAP, 1>;

@@ -69,12 +69,21 @@ constexpr int table_stride(int m) { return 4 * (((m + 3) / 4) | 1); }
 // its cell instead of +0.0 -- the later passes of a motif longer than kMaxFastM, which is scored
 // in slices of <= kMaxFastM rows with the SAME sequential add order (pass 1 stores
 // ((0 + P[0]) + ... + P[M1-1]), pass 2 continues with + P[M1] ...), hence bit-identical.
-enum : int { MODE_STORE = 0, MODE_ARGMAX = 1, MODE_THRESHOLD = 2, MODE_STORE_ARGMAX = 3, MODE_CONTINUE = 4 };
+// MODE_STORE_TRACK: MODE_STORE that also tracks (value, cell) of the best score per lane like MODE_ARGMAX -- the
+// small-input form of the reference's `score_into` + `argmax` pair (lightmotif-bench dna.rs:104-107): ONE launch,
+// the last workgroup to finish folds the workgroup records (FusedOut::final_out).  MODE_STORE_ARGMAX (value only,
+// cell located afterwards) stays the large-input form: index tracking costs the store kernel 15 %.
+enum : int { MODE_STORE = 0, MODE_ARGMAX = 1, MODE_THRESHOLD = 2, MODE_STORE_ARGMAX = 3, MODE_CONTINUE = 4,
+             MODE_STORE_TRACK = 5 };
 constexpr bool mode_stores(int mode)
 {
-    return mode == MODE_STORE || mode == MODE_STORE_ARGMAX || mode == MODE_CONTINUE;
+    return mode == MODE_STORE || mode == MODE_STORE_ARGMAX || mode == MODE_CONTINUE || mode == MODE_STORE_TRACK;
 }
-constexpr bool mode_tracks_best(int mode) { return mode == MODE_ARGMAX || mode == MODE_STORE_ARGMAX; }
+constexpr bool mode_tracks_best(int mode)
+{
+    return mode == MODE_ARGMAX || mode == MODE_STORE_ARGMAX || mode == MODE_STORE_TRACK;
+}
+constexpr bool mode_tracks_cell(int mode) { return mode == MODE_ARGMAX || mode == MODE_STORE_TRACK; }
 
 // One above-threshold cell: key = (job << 40) | flat index (row * cols + col).  Flat
 // indices stay below 2^40 for anything that fits in 288 GB of HBM.
@@ -121,6 +130,16 @@ struct FusedOut {
     // store kernels: leading all-zero motif rows the table was padded with (0..3) so that M is a
     // multiple of 4 (dword symbol loads): step t then reads sequence row o0 - lead_rows + t
     unsigned lead_rows;
+    // MODE_ARGMAX / MODE_STORE_TRACK, single job: non-null = the last workgroup to finish (ticket counter, left
+    // at zero again) folds the workgroup records and writes the job's result -- no second launch.  final_host
+    // (optional) is a device-visible pinned copy the host reads after synchronising the stream: no copy command
+    unsigned *ticket;
+    ArgmaxRecord *final_out;
+    ArgmaxRecord *final_host;
+    int first_cell_rule;
+    // written to the word behind *final_host AFTER the record (system-scope release): a host that polls it
+    // sees the result a PCIe write after the fold, without waiting for the kernel's completion signal
+    unsigned generation;
 };
 
 // Ordering used by every argmax reduction: larger value wins; equal values ->
@@ -434,7 +453,7 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
                 // survives only if every score was NaN): the cell is located afterwards in
                 // the stored matrix.  Tracking the index too cost the store kernel 15 %.
                 best_v = __builtin_fmaxf(best_v, score);
-            } else if (MODE == MODE_ARGMAX) {
+            } else if (mode_tracks_cell(MODE)) {
                 if (score >= best_v) {  // same `>=` as pli/mod.rs:146, NaN never passes
                     best_v = score;
                     best_t = tbase + k;  // scalar + constant: no per-lane arithmetic
@@ -711,6 +730,65 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
             fo.block_best[blockIdx.x].index = idx;
             fo.block_best[blockIdx.x].found = idx >= 0;
         }
+        if (fo.final_out) {
+            // The last workgroup to finish folds the records (Generic rule: best_merge) and applies the
+            // first-cell rule (pli/mod.rs:142-146) -- what argmax_finalize does in a launch of its own.
+            __shared__ int is_last;
+            if (threadIdx.x == 0) {
+                __threadfence();  // this workgroup's record (and score rows) before its ticket
+                is_last = atomicAdd(fo.ticket, 1u) == gridDim.x - 1;
+            }
+            __syncthreads();
+            if (is_last) {  // workgroup-uniform
+                __threadfence();
+                float v = -INFINITY;
+                long long i = -1;
+                // (requested before the records so that the two round trips overlap)
+                unsigned first_bits = 0;
+                if (mode_stores(MODE) && fo.first_cell_rule && threadIdx.x == 0)
+                    first_bits = __hip_atomic_load(reinterpret_cast<const unsigned *>(out), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                for (unsigned b = threadIdx.x; b < gridDim.x; b += BLK) {
+                    const unsigned long long vf = __hip_atomic_load(
+                        reinterpret_cast<const unsigned long long *>(&fo.block_best[b]), __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_AGENT);  // {value, found}
+                    const long long bi = __hip_atomic_load(&fo.block_best[b].index, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+                    if ((int)(vf >> 32))
+                        best_merge(v, i, __builtin_bit_cast(float, (unsigned)vf), bi);
+                }
+                __syncthreads();  // (sm_v / sm_i are reused)
+                best_block_reduce<BLK>(v, i, sm_v, sm_i);
+                if (threadIdx.x == 0) {
+                    if (fo.first_cell_rule) {
+                        float first;
+                        if (mode_stores(MODE)) {  // the stored cell itself (written by whichever workgroup owns row 0)
+                            first = __builtin_bit_cast(float, first_bits);
+                        } else {  // recomputed in the reference's add order from the transposed table
+                            first = 0.0f;
+                            const uint8_t *s00 = seq + row_begin * 32;
+                            for (int j = (int)lead; j < M; ++j)
+                                first = first + table[s00[(j - (int)lead) * 32] * table_stride(M) + j];
+                        }
+                        if (first != first) {  // NaN: nothing ever compares >= it
+                            v = first;
+                            i = 0;
+                        }
+                    }
+                    ArgmaxRecord o;
+                    o.value = v;
+                    o.index = i;
+                    o.found = i >= 0;
+                    *fo.final_out = o;
+                    *fo.ticket = 0u;
+                    if (fo.final_host) {
+                        *fo.final_host = o;
+                        __hip_atomic_store(reinterpret_cast<unsigned *>(fo.final_host + 1), fo.generation, __ATOMIC_RELEASE,
+                                           __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -913,12 +991,14 @@ hipError_t score_c32_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, con
 // [4..6] = unused, [7] = store kernel with quad-gathered symbol
 // loads (M % 4 == 0), [8] = store + running maximum (score_into on handles).
 constexpr int kRegistrySlots = 12;  // [9] = MODE_CONTINUE (later passes of motifs longer than kMaxFastM),
-                                    // [10] = store kernel for C = 16 (M % 4 == 0, quad loads), [11] = unused
+                                    // [10] = store kernel for C = 16 (M % 4 == 0, quad loads),
+                                    // [11] = MODE_STORE_TRACK (M % 4 == 0, quad loads): small score_into + argmax
 ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap = false);
 ScoreC32Launcher score_c32_lookup_ql(int M);
 ScoreC32Launcher score_c32_lookup_store_argmax(int M);
 ScoreC32Launcher score_c32_lookup_continue(int M);
 ScoreC32Launcher score_c32_lookup_c16(int M);
+ScoreC32Launcher score_c32_lookup_store_track(int M);
 const char *score_c32_name(int M, int mode);
 
 }  // namespace lm

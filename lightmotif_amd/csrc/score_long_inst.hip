@@ -27,6 +27,7 @@ void LM_CAT(register_score_c32_long_, LM_LONG_M)(const KernelRegistry &r)
     tab[7] = tab[MODE_STORE];
     tab[8] = &score_c32_launch<M, MODE_STORE_ARGMAX, LM_SCORE_XCD_REMAP, 1>;
     tab[9] = &score_c32_launch<M, MODE_CONTINUE, LM_SCORE_XCD_REMAP, 1>;
+    tab[11] = &score_c32_launch<M, MODE_STORE_TRACK, LM_SCORE_XCD_REMAP, 1>;
 }
 
 }  // namespace lm

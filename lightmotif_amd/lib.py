@@ -251,22 +251,24 @@ class Pipeline:
     def score_argmax(self, pssm: "ScoringMatrix", seq: "StripedSequence",
                      rows: Optional[range] = None):
         """score_rows_into + argmax without writing the scores: ((row, col), value) or None."""
-        rows = range(0, seq.rows) if rows is None else rows
+        length, wrap, nrows, stride_, columns, data_ptr = seq._info()    # one call: a small scan is latency-bound
+        rows = range(0, nrows) if rows is None else rows
         found, best, value = C.c_int(0), Coords(), C.c_float(0)
         check(self._L.lm_hip_score_argmax_f32_dptr(
-            self._h, pssm._device(self), seq.data_ptr, seq.rows + seq.wrap, seq.stride, seq.columns,
-            seq.wrap, len(seq), rows.start, max(rows.stop, rows.start), C.byref(found),
+            self._h, pssm._device(self), data_ptr, nrows + wrap, stride_, columns,
+            wrap, length, rows.start, max(rows.stop, rows.start), C.byref(found),
             C.byref(best), C.byref(value)))
         return ((best.row, best.col), float(value.value)) if found.value else None
 
     def score_threshold(self, pssm: "ScoringMatrix", seq: "StripedSequence", threshold: float,
                         rows: Optional[range] = None):
         """score_rows_into + threshold without writing the scores: ([(row, col)], [value])."""
-        rows = range(0, seq.rows) if rows is None else rows
+        length, wrap, nrows, stride_, columns, data_ptr = seq._info()
+        rows = range(0, nrows) if rows is None else rows
         ptr, vals, n = C.POINTER(Coords)(), C.POINTER(C.c_float)(), C.c_size_t(0)
         check(self._L.lm_hip_score_threshold_f32_dptr(
-            self._h, pssm._device(self), seq.data_ptr, seq.rows + seq.wrap, seq.stride, seq.columns,
-            seq.wrap, len(seq), rows.start, max(rows.stop, rows.start), threshold,
+            self._h, pssm._device(self), data_ptr, nrows + wrap, stride_, columns,
+            wrap, length, rows.start, max(rows.stop, rows.start), threshold,
             C.byref(ptr), C.byref(vals), C.byref(n)))
         try:
             values = [float(vals[i]) for i in range(n.value)]

@@ -810,3 +810,59 @@ def test_scanner_on_protein(pli):
         assert pos.tolist() == sorted(i for i, _ in order)
     with pytest.raises(ValueError):
         lm.scan(pssm, seq)                                    # the Python binding's helper stays DNA-only (lib.rs)
+
+
+@pytest.mark.parametrize("m", [1, 3, 4, 15, 16, 20, 31, 33, 36, 37, 50, 64])
+def test_small_score_into_tracks_its_argmax_in_the_same_launch(pli, m):
+    """`score_into` + `argmax` on handles below 8 Mi cells (lightmotif-bench dna.rs:104-107 at its own
+    size): the store kernel tracks (value, cell) and its last workgroup folds the records
+    (MODE_STORE_TRACK), `argmax` / `max` read the pinned record.  Same scores bit for bit, the Generic
+    argmax rule on ties / all -inf / NaN first cell / shards without the first-cell rule, over and over
+    on one handle (the ticket counter must come back to zero every time)."""
+    rng = np.random.default_rng(5000 + m)
+    scores = lm.StripedScores.empty(pli, 32)
+    for trial, (length, kind) in enumerate([(100_003, "normal"), (464_165, "ties"), (5_000, "normal"), (40 * 32 + m, "ties"),
+                                            (200_000, "neg_inf"), (150_001, "nan_first"), (150_001, "nan_elsewhere")]):
+        length = max(length, 2 * m + 64)
+        enc = rng.integers(0, 4, length, dtype=np.uint8)
+        p = random_pssm(rng, m, 5, "ties" if kind == "ties" else "normal")
+        if kind == "neg_inf":
+            p[:, :5] = -np.inf
+        if kind == "nan_first":
+            p[0, int(enc[0])] = np.nan
+        if kind == "nan_elsewhere":
+            enc[0], enc[1:50] = 0, 1
+            enc[1000] = 2
+            p[0, 2] = np.nan                       # NaN cells exist, but not the first cell (symbol 0)
+            enc[enc == 2] = 3
+            enc[1000] = 2
+        ref = co.stripe(enc, 32, 5)
+        co.configure_wrap(ref, m - 1)
+        seq = pli.stripe(lm.EncodedSequence(enc), 32)
+        seq.configure_wrap(m - 1)
+        pssm = lm.ScoringMatrix(p)
+        for a, b in ((0, ref.rows), (7, ref.rows - 3)):
+            if b - a < 1:
+                continue
+            want, _ = co.score_rows(ref, p, a, b)
+            for rule in (True, False):
+                scores.set_first_cell_rule(rule)
+                pli.score_rows_into(pssm, seq, range(a, b), scores)
+                got_am = pli.argmax(scores)
+                assert np.array_equal(bits(scores.matrix()[:, :32]), bits(want[:, :32])), (m, kind, a, b)
+                if rule or not np.isnan(want[0, 0]):
+                    assert got_am == co.argmax(want, 32), (m, kind, a, b, rule, pli.last_kernel)
+                    v = pli.max(scores)
+                    assert bits(np.float32(v)) == bits(co.max_(want, 32))
+                else:   # a shard that does not hold the matrix's first cell: NaN never wins
+                    flat = np.where(np.isnan(want[:, :32]), -np.inf, want[:, :32])
+                    r, c = np.argwhere(flat == flat.max())[-1]
+                    assert got_am == (int(r), int(c))
+                # ... and the separate pass over the stored matrix agrees with the tracked record
+                assert pli.argmax_dptr(scores.data_ptr, b - a, 32, 32, first_cell_rule=rule)[0] == got_am
+            scores.set_first_cell_rule(True)
+        # the fused form of one job folds its records in the kernel as well
+        want, _ = co.score_rows(ref, p)
+        got = pli.score_argmax(pssm, seq)
+        assert got[0] == co.argmax(want, 32)
+        assert bits(np.float32(got[1])) == bits(co.max_(want, 32))
