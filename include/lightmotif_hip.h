@@ -346,6 +346,16 @@ int lm_hip_seq_from_encoded(lm_hip_ctx *ctx, const uint8_t *encoded, size_t len,
 /* Same, from ASCII text: encode (strict or lossy) + stripe on the device. */
 int lm_hip_seq_from_ascii(lm_hip_ctx *ctx, char alphabet, const uint8_t *ascii, size_t len,
                           size_t cols, int lossy, lm_hip_seq **out, size_t *bad_index);
+/* DNA packed 4 bases per byte -- base i in bits 2*(i%4).. of byte i/4, values A0 C1 T2 G3 (the
+ * Nucleotide discriminants, abc.rs:115-135): a quarter of the bytes over PCIe, unpacked straight
+ * into the striped matrix (pli/mod.rs:178-200 layout).  N positions: n_runs = n_run_count pairs
+ * {start, size} (the .2bit container's nBlockStarts / nBlockSizes; a genome's N are few long runs)
+ * and / or n_mask, one bit per base (bit i%8 of byte i/8 set: position i is N); both may be NULL /
+ * 0.  What a host that keeps genomes in 2-bit form ("ship raw/2-bit sequence") hands
+ * over instead of an EncodedSequence. */
+int lm_hip_seq_from_2bit(lm_hip_ctx *ctx, const uint8_t *packed, const uint8_t *n_mask,
+                         const uint64_t *n_runs, size_t n_run_count, size_t len, size_t cols,
+                         lm_hip_seq **out);
 /* StripedSequence::configure_wrap (seq.rs:369-381); `m` = wrap rows wanted. */
 int lm_hip_seq_configure_wrap(lm_hip_ctx *ctx, lm_hip_seq *seq, size_t m);
 /* len(), wrap(), matrix().rows() - wrap(), stride, cols, device pointer. */

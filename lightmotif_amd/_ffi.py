@@ -94,6 +94,7 @@ SIGNATURES = {
     "lm_hip_seq_upload": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, C.POINTER(_vp)]),
     "lm_hip_seq_from_encoded": (C.c_int, [_vp, _vp, _sz, _sz, _sz, C.POINTER(_vp)]),
     "lm_hip_seq_from_ascii": (C.c_int, [_vp, C.c_char, _vp, _sz, _sz, C.c_int, C.POINTER(_vp), _szp]),
+    "lm_hip_seq_from_2bit": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, C.POINTER(_vp)]),
     "lm_hip_seq_configure_wrap": (C.c_int, [_vp, _vp, _sz]),
     "lm_hip_seq_info": (C.c_int, [_vp, _szp, _szp, _szp, _szp, _szp, C.POINTER(_vp)]),
     "lm_hip_seq_download": (C.c_int, [_vp, _vp, _vp]),

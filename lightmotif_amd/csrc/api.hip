@@ -393,6 +393,14 @@ int lm_hip_ctx_destroy(lm_hip_ctx *ctx)
         (void)hipHostFree(ctx->pinned);
     if (ctx->d_ticket)
         (void)hipFree(ctx->d_ticket);
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+        for (int b = 0; b < 2; ++b) {
+            (void)hipEventDestroy(ctx->tile_copied[b]);
+            (void)hipEventDestroy(ctx->tile_consumed[b]);
+        }
+    }
     if (ctx->aux_stream) {
         (void)hipStreamSynchronize(ctx->aux_stream);
         (void)hipStreamDestroy(ctx->aux_stream);
@@ -1150,21 +1158,124 @@ int lm_hip_seq_adopt_dptr(lm_hip_ctx *ctx, uint8_t *d_data, size_t rows_total, s
     return LM_HIP_OK;
 }
 
-static int seq_from_device_encoded(lm_hip_ctx *ctx, const uint8_t *d_enc, size_t len, size_t cols,
-                                   size_t k, lm_hip_seq **out, bool validate)
+// ---- host sequence -> resident StripedSequence (Encode + Stripe, pli/mod.rs:56-66, 178-200) ------------
+//
+// The caller's buffer (ASCII text or symbol bytes, pageable) goes to the device TILE by tile: tile t = rows
+// [t * TR, (t + 1) * TR) of the striped matrix needs, for every column c, the TR bytes at position c * R + t * TR
+// -- one strided 2-D copy (pitch R) into one of two staging tiles on the copy stream, while the stripe kernel of
+// the previous tile (conversion fused: layout.hip) runs on the context's stream.  Scratch = two tiles (64 MB)
+// whatever the genome's size, nothing is staged twice, and the H2D transfer -- the floor of this step: a
+// pageable 1 GB buffer moves at ~55 GB/s on this host, 18 ms -- hides the 0.8 ms/Gbp of kernels behind it.
+// (Round 2 copied the whole text into a 2 x len scratch with one hipMemcpyAsync, then encoded, then striped.)
+static int ingest_streams(lm_hip_ctx *ctx)
 {
-    const size_t rows = (len + cols - 1) / cols;
+    if (ctx->copy_stream)
+        return LM_HIP_OK;
+    hipStream_t st = nullptr;
+    LM_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+        LM_HIP_TRY(hipEventCreateWithFlags(&ctx->tile_copied[b], hipEventDisableTiming));
+        LM_HIP_TRY(hipEventCreateWithFlags(&ctx->tile_consumed[b], hipEventDisableTiming));
+    }
+    ctx->copy_stream = st;
+    return LM_HIP_OK;
+}
+
+constexpr size_t kIngestTileBytes = 32u << 20;
+
+static int ingest_tiled(lm_hip_ctx *ctx, const uint8_t *host, size_t len, size_t cols, size_t k,
+                        StripeTile::Transform transform, bool protein, bool lossy, lm_hip_seq **out, size_t *bad_index,
+                        const char *what)
+{
+    const size_t rows = (len + cols - 1) / cols;  // pli/mod.rs:182
     const size_t stride = lm_hip_stride(cols, 1);
-    if (validate)  // bytes from the caller: the encode kernel's own output needs no check
-        LM_TRY(check_symbols(ctx, d_enc, 1, len, len, k, "seq_from_encoded"));
     lm_hip_seq *s = nullptr;
     LM_TRY(seq_alloc(ctx, rows, stride, cols, len, k, &s));
-    int st = launch_stripe(ctx, d_enc, len, cols, (uint8_t)(k - 1), 0, s->d_data, stride);
-    if (st == LM_HIP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
-        st = fail(LM_HIP_ERR_HIP, "stripe failed");
-    if (st != LM_HIP_OK) {
+    auto give_up = [&](int st) {
+        if (ctx->copy_stream)
+            (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamSynchronize(ctx->stream);
         lm_hip_seq_destroy(s);
         return st;
+    };
+    if (rows == 0) {
+        *out = s;
+        return LM_HIP_OK;
+    }
+    {
+        const int sst = ingest_streams(ctx);
+        if (sst != LM_HIP_OK)
+            return give_up(sst);
+    }
+    // rows per tile: ~32 MB of input, a multiple of the stripe kernels' workgroup tile
+    size_t tr = std::max<size_t>(kIngestTileBytes / cols / 1024 * 1024, 1024);
+    tr = std::min(tr, (rows + 15) / 16 * 16);
+    const size_t tile_bytes = tr * cols;
+    int st = ctx->scratch2.reserve(2 * tile_bytes + 64);
+    if (st != LM_HIP_OK)
+        return give_up(st);
+    uint8_t *stage = static_cast<uint8_t *>(ctx->scratch2.ptr);
+    unsigned long long *d_bad = reinterpret_cast<unsigned long long *>(stage + 2 * tile_bytes);  // 8-byte aligned: tile_bytes % 16 == 0
+    hipError_t e = hipMemsetAsync(d_bad, 0xff, 8, ctx->stream);
+    // the staging tiles may still be read by kernels enqueued earlier on the context's stream
+    if (e == hipSuccess)
+        e = hipEventRecord(ctx->tile_consumed[0], ctx->stream);
+    if (e == hipSuccess)
+        e = hipEventRecord(ctx->tile_consumed[1], ctx->stream);
+    for (size_t t = 0, rbase = 0; rbase < rows && e == hipSuccess; ++t, rbase += tr) {
+        const int b = (int)(t & 1);
+        const size_t w = std::min(tr, rows - rbase);
+        uint8_t *dst = stage + (size_t)b * tile_bytes;
+        e = hipStreamWaitEvent(ctx->copy_stream, ctx->tile_consumed[b], 0);
+        // columns whose w bytes all exist: c * rows + rbase + w <= len; then at most one partial column
+        const size_t nfull = len >= rbase + w ? std::min(cols, (len - rbase - w) / rows + 1) : 0;
+        if (e == hipSuccess && nfull)
+            e = hipMemcpy2DAsync(dst, tr, host + rbase, rows, w, nfull, hipMemcpyHostToDevice, ctx->copy_stream);
+        if (e == hipSuccess && nfull < cols && nfull * rows + rbase < len)
+            e = hipMemcpyAsync(dst + nfull * tr, host + nfull * rows + rbase, len - (nfull * rows + rbase),
+                               hipMemcpyHostToDevice, ctx->copy_stream);
+        if (e == hipSuccess)
+            e = hipEventRecord(ctx->tile_copied[b], ctx->copy_stream);
+        if (e == hipSuccess)
+            e = hipStreamWaitEvent(ctx->stream, ctx->tile_copied[b], 0);
+        if (e != hipSuccess)
+            break;
+        StripeTile tile;
+        tile.d_src = dst;
+        tile.pitch = tr;
+        tile.len = len;
+        tile.rows = rows;
+        tile.rbase = rbase;
+        tile.nrows = w;
+        tile.cols = cols;
+        tile.stride = stride;
+        tile.def = (uint8_t)(k - 1);
+        tile.d_data = s->d_data;
+        tile.transform = transform;
+        tile.k = k;
+        tile.protein = protein;
+        tile.lossy = lossy;
+        tile.d_first_bad = d_bad;
+        st = launch_stripe_tile(ctx, tile);
+        if (st != LM_HIP_OK)
+            return give_up(st);
+        e = hipEventRecord(ctx->tile_consumed[b], ctx->stream);
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(ctx->pinned, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess)
+        return give_up(fail(LM_HIP_ERR_HIP, "%s: upload failed: %s", what, hipGetErrorString(e)));
+    const unsigned long long bad = *static_cast<unsigned long long *>(ctx->pinned);
+    if (bad != ~0ull) {
+        lm_hip_seq_destroy(s);
+        if (bad_index)
+            *bad_index = (size_t)bad;
+        if (transform == StripeTile::Check)
+            return fail(LM_HIP_ERR_INVALID_SYMBOL, "%s: symbol byte %u at position %llu is not below the alphabet size %zu",
+                        what, (unsigned)host[bad], bad, k);
+        return fail(LM_HIP_ERR_INVALID_SYMBOL, "invalid symbol at position %llu", bad);
     }
     *out = s;
     return LM_HIP_OK;
@@ -1178,11 +1289,8 @@ int lm_hip_seq_from_encoded(lm_hip_ctx *ctx, const uint8_t *encoded, size_t len,
     *out = nullptr;
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard guard(ctx->device);
-    LM_TRY(ctx->scratch2.reserve(len + 16));
-    uint8_t *d_enc = static_cast<uint8_t *>(ctx->scratch2.ptr);
-    if (len)
-        LM_HIP_TRY(hipMemcpyAsync(d_enc, encoded, len, hipMemcpyHostToDevice, ctx->stream));
-    return seq_from_device_encoded(ctx, d_enc, len, cols, k, out, true);
+    // bytes from the caller: validated against the alphabet size on the way (abc.rs:113-135: symbols are enums)
+    return ingest_tiled(ctx, encoded, len, cols, k, StripeTile::Check, false, false, out, nullptr, "seq_from_encoded");
 }
 
 int lm_hip_seq_from_ascii(lm_hip_ctx *ctx, char alphabet, const uint8_t *ascii, size_t len,
@@ -1195,13 +1303,73 @@ int lm_hip_seq_from_ascii(lm_hip_ctx *ctx, char alphabet, const uint8_t *ascii, 
     *out = nullptr;
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard guard(ctx->device);
-    LM_TRY(ctx->scratch2.reserve(2 * len + 32));
-    uint8_t *d_ascii = static_cast<uint8_t *>(ctx->scratch2.ptr);
-    uint8_t *d_enc = d_ascii + (len + 15) / 16 * 16;
-    if (len)
-        LM_HIP_TRY(hipMemcpyAsync(d_ascii, ascii, len, hipMemcpyHostToDevice, ctx->stream));
-    LM_TRY(launch_encode(ctx, alphabet, d_ascii, len, lossy, d_enc, bad_index));
-    return seq_from_device_encoded(ctx, d_enc, len, cols, alphabet == 'P' ? 21 : 5, out, false);
+    return ingest_tiled(ctx, ascii, len, cols, alphabet == 'P' ? 21 : 5, StripeTile::Ascii, alphabet == 'P', lossy != 0, out,
+                        bad_index, "seq_from_ascii");
+}
+
+// DNA packed 4 bases per byte (base i in bits 2 * (i % 4) .. of byte i / 4, values A0 C1 T2 G3 = the reference's
+// Nucleotide discriminants, abc.rs:115-135): a quarter of the bytes over PCIe.  N positions come as a list of runs
+// {start, size} (what a .2bit file stores: a genome's N are few long runs) and / or as a bit mask (bit i % 8 of byte
+// i / 8; half as many bytes again as the bases).  The packed text is uploaded whole (len / 4 bytes of scratch) and
+// unpacked straight into the striped matrix by the stripe kernel -- no intermediate symbol array.
+int lm_hip_seq_from_2bit(lm_hip_ctx *ctx, const uint8_t *packed, const uint8_t *n_mask, const uint64_t *n_runs,
+                         size_t n_run_count, size_t len, size_t cols, lm_hip_seq **out)
+{
+    if (!ctx || !out || (len && !packed) || cols == 0 || (n_run_count && !n_runs))
+        return fail(LM_HIP_ERR_BAD_ARGS, "seq_from_2bit: bad argument");
+    *out = nullptr;
+    unsigned long long longest = 0;
+    for (size_t r = 0; r < n_run_count; ++r) {
+        const uint64_t start = n_runs[2 * r], size = n_runs[2 * r + 1];
+        if (start > len || size > len - start)
+            return fail(LM_HIP_ERR_BAD_ARGS, "seq_from_2bit: N run %zu (%llu + %llu) leaves the sequence of %zu bases", r,
+                        (unsigned long long)start, (unsigned long long)size, len);
+        longest = std::max<unsigned long long>(longest, size);
+    }
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    const size_t rows = (len + cols - 1) / cols, stride = lm_hip_stride(cols, 1);
+    const size_t pbytes = (len + 3) / 4, mbytes = n_mask ? (len + 7) / 8 : 0;
+    const size_t moff = (pbytes + 16 + 15) / 16 * 16, roff = (moff + mbytes + 16 + 15) / 16 * 16;
+    LM_TRY(ctx->scratch2.reserve(roff + n_run_count * 16 + 16));
+    uint8_t *d_packed = static_cast<uint8_t *>(ctx->scratch2.ptr);
+    uint8_t *d_mask = n_mask ? d_packed + moff : nullptr;
+    unsigned long long *d_runs = reinterpret_cast<unsigned long long *>(d_packed + roff);
+    lm_hip_seq *s = nullptr;
+    LM_TRY(seq_alloc(ctx, rows, stride, cols, len, 5, &s));
+    hipError_t e = hipSuccess;
+    if (pbytes)
+        e = hipMemcpyAsync(d_packed, packed, pbytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && mbytes)
+        e = hipMemcpyAsync(d_mask, n_mask, mbytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && n_run_count)
+        e = hipMemcpyAsync(d_runs, n_runs, n_run_count * 16, hipMemcpyHostToDevice, ctx->stream);
+    int st = LM_HIP_OK;
+    if (e == hipSuccess && rows) {
+        StripeTile tile;
+        tile.d_src = d_packed;
+        tile.len = len;
+        tile.rows = tile.nrows = tile.pitch = rows;
+        tile.cols = cols;
+        tile.stride = stride;
+        tile.def = 4;
+        tile.d_data = s->d_data;
+        tile.transform = StripeTile::TwoBit;
+        tile.k = 5;
+        tile.d_mask = d_mask;
+        st = launch_stripe_tile(ctx, tile);
+        if (st == LM_HIP_OK && n_run_count && longest)
+            st = launch_n_runs(ctx, d_runs, n_run_count, longest, rows, stride, 4, s->d_data);
+    }
+    if (e == hipSuccess && st == LM_HIP_OK)
+        e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess || st != LM_HIP_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        lm_hip_seq_destroy(s);
+        return st != LM_HIP_OK ? st : fail(LM_HIP_ERR_HIP, "seq_from_2bit: upload failed: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return LM_HIP_OK;
 }
 
 int lm_hip_seq_configure_wrap(lm_hip_ctx *ctx, lm_hip_seq *seq, size_t m)

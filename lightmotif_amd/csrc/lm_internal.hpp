@@ -86,6 +86,10 @@ struct lm_hip_ctx {
     bool owns_stream = false;
     hipStream_t aux_stream = nullptr;  // second lane for independent jobs of a batch
     hipEvent_t fork_event = nullptr, join_event = nullptr;
+    // host -> device ingest (api.hip: ingest_tiled): tiles are uploaded on `copy_stream` two ahead of the
+    // stripe kernels that consume them on `stream`
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t tile_copied[2] = {nullptr, nullptr}, tile_consumed[2] = {nullptr, nullptr};
     std::mutex mu;
     lm::Scratch scratch;        // block partials, chunk counts, hit lists
     lm::Scratch scratch2;
@@ -280,6 +284,27 @@ int launch_max_symbol(lm_hip_ctx *ctx, const uint8_t *d_data, size_t rows, size_
                       unsigned *max_symbol);
 int launch_stripe(lm_hip_ctx *ctx, const uint8_t *d_encoded, size_t len, size_t cols,
                   uint8_t default_symbol, size_t wrap, uint8_t *d_data, size_t stride);
+// One tile of the striped matrix (layout.hip): output rows [rbase, rbase + nrows) of `rows`, from `cols` pieces of
+// `pitch` bytes (piece c = the symbols of column c for those rows), converted on the way.  Async on ctx->stream.
+struct StripeTile {
+    enum Transform { None, Check, Ascii, TwoBit };
+    const uint8_t *d_src = nullptr;   // pieces; TwoBit: the WHOLE packed sequence (4 bases per byte) + 16 spare bytes
+    size_t pitch = 0;
+    size_t len = 0, rows = 0;         // of the whole sequence
+    size_t rbase = 0, nrows = 0;
+    size_t cols = 0, stride = 0;
+    uint8_t def = 0;
+    uint8_t *d_data = nullptr;        // row 0 of the striped matrix
+    Transform transform = None;
+    size_t k = 0;                     // Check: alphabet size
+    bool protein = false, lossy = false;          // Ascii
+    const uint8_t *d_mask = nullptr;              // TwoBit: N mask (1 bit per base) or null, + 16 spare bytes
+    unsigned long long *d_first_bad = nullptr;    // Check / Ascii: atomicMin of the first offending position
+};
+int launch_stripe_tile(lm_hip_ctx *ctx, const StripeTile &t);
+// d_runs: nruns x {start, size} on the device; cells of those positions become `def` (async on ctx->stream)
+int launch_n_runs(lm_hip_ctx *ctx, const unsigned long long *d_runs, size_t nruns, unsigned long long longest, size_t rows,
+                  size_t stride, uint8_t def, uint8_t *d_data);
 int launch_wrap(lm_hip_ctx *ctx, uint8_t *d_data, size_t rows, size_t stride, size_t cols,
                 size_t new_wrap, uint8_t default_symbol);
 

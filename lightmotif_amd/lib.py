@@ -25,6 +25,7 @@ from . import _ffi
 from ._ffi import Coords, InvalidSymbol, LightmotifHipError, UnsupportedBackend, check
 
 __all__ = [
+    "pack_2bit",
     "Pipeline", "EncodedSequence", "StripedSequence", "CountMatrix", "WeightMatrix",
     "ScoringMatrix", "DiscreteMatrix", "StripedScores", "Scanner", "Hit", "Motif", "create", "stripe", "scan",
     "UnsupportedBackend", "InvalidSymbol", "LightmotifHipError", "DEFAULT_COLUMNS",
@@ -152,17 +153,42 @@ class Pipeline:
                                               _k(encoded.protein), C.byref(h)))
         return StripedSequence(self, h, encoded.protein)
 
-    def stripe_ascii(self, sequence: Union[str, bytes], protein: bool = False, lossy: bool = False,
+    def stripe_2bit(self, packed: np.ndarray, length: int, n_mask: Optional[np.ndarray] = None,
+                    columns: int = DEFAULT_COLUMNS, n_runs: Optional[np.ndarray] = None) -> "StripedSequence":
+        """A DNA sequence held 4 bases per byte (``pack_2bit``) -> resident StripedSequence: a quarter of the
+        bytes over PCIe, unpacked straight into the striped matrix (``lm_hip_seq_from_2bit``).  N positions as an
+        ``(n, 2)`` array of runs ``(start, size)`` -- the .2bit container's form -- and / or as a bit mask."""
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        if packed.size < (length + 3) // 4:
+            raise ValueError("packed buffer shorter than length / 4")
+        mptr = rptr = None
+        nruns = 0
+        if n_mask is not None:
+            n_mask = np.ascontiguousarray(n_mask, dtype=np.uint8)
+            if n_mask.size < (length + 7) // 8:
+                raise ValueError("N mask shorter than length / 8")
+            mptr = n_mask.ctypes.data
+        if n_runs is not None and len(n_runs):
+            n_runs = np.ascontiguousarray(np.asarray(n_runs, dtype=np.uint64).reshape(-1, 2))
+            rptr, nruns = n_runs.ctypes.data, n_runs.shape[0]
+        h = C.c_void_p()
+        check(self._L.lm_hip_seq_from_2bit(self._h, packed.ctypes.data, mptr, rptr, nruns, length, columns, C.byref(h)))
+        return StripedSequence(self, h, False)
+
+    def stripe_ascii(self, sequence: Union[str, bytes, np.ndarray], protein: bool = False, lossy: bool = False,
                      columns: int = DEFAULT_COLUMNS) -> "StripedSequence":
         """encode (+ encode_lossy) and stripe entirely on the device."""
-        raw = sequence.encode("ascii", "replace") if isinstance(sequence, str) else bytes(sequence)
-        buf = np.frombuffer(raw, dtype=np.uint8)
+        if isinstance(sequence, np.ndarray):     # a genome already in memory as bytes: no copy
+            raw = buf = np.ascontiguousarray(sequence, dtype=np.uint8)
+        else:
+            raw = sequence.encode("ascii", "replace") if isinstance(sequence, str) else bytes(sequence)
+            buf = np.frombuffer(raw, dtype=np.uint8)
         h = C.c_void_p()
         bad = C.c_size_t(0)
         st = self._L.lm_hip_seq_from_ascii(self._h, b"P" if protein else b"D", buf.ctypes.data,
                                            buf.size, columns, int(lossy), C.byref(h), C.byref(bad))
         if st == _ffi.ERR_INVALID_SYMBOL:
-            raise InvalidSymbol(f"Invalid symbol in sequence: {chr(raw[bad.value])!r}")
+            raise InvalidSymbol(f"Invalid symbol in sequence: {chr(int(raw[bad.value]))!r}")
         check(st)
         return StripedSequence(self, h, protein)
 
@@ -1219,6 +1245,28 @@ def create(sequences: Iterable[str], *, protein: bool = False, name: Optional[st
     counts = CountMatrix.from_sequences(encoded, protein=protein)
     pwm = counts.normalize(0.0)
     return Motif(counts, pwm, pwm.log_odds(), name)
+
+
+def pack_2bit(encoded: np.ndarray, runs: bool = False):
+    """Symbol bytes of a DNA sequence (A0 C1 T2 G3 N4, abc.rs:115-135) -> ``(packed, n)`` as
+    ``Pipeline.stripe_2bit`` takes them: base i in bits 2*(i%4).. of byte i//4; N positions are packed as A and
+    described by ``n`` -- a bit mask (bit i%8 of byte i//8; default) or, with ``runs=True``, an ``(k, 2)`` uint64
+    array of ``(start, size)`` runs like a .2bit file's N blocks; ``None`` when the sequence has no N."""
+    enc = np.ascontiguousarray(encoded, dtype=np.uint8)
+    n = enc.size
+    is_n = enc > 3
+    two = np.where(is_n, 0, enc).astype(np.uint8)
+    pad = (-n) % 4
+    if pad:
+        two = np.concatenate([two, np.zeros(pad, np.uint8)])
+    q = two.reshape(-1, 4)
+    packed = (q[:, 0] | (q[:, 1] << 2) | (q[:, 2] << 4) | (q[:, 3] << 6)).astype(np.uint8)
+    if not is_n.any():
+        return packed, None
+    if not runs:
+        return packed, np.packbits(is_n, bitorder="little")
+    edges = np.flatnonzero(np.diff(np.concatenate([[0], is_n.view(np.int8), [0]])))
+    return packed, np.stack([edges[0::2], edges[1::2] - edges[0::2]], axis=1).astype(np.uint64)
 
 
 def stripe(sequence: str, *, protein: bool = False) -> StripedSequence:
