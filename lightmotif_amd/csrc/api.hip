@@ -500,8 +500,8 @@ int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stri
             return cleanup(fail(LM_HIP_ERR_HIP, "pssm upload failed: %s", hipGetErrorString(e)));
         if (m <= (size_t)kMaxFastM) {
             // transposed, padded table of score_c32<M>: table[s * ts + j] = pssm[j][s]
-            // (K = 21 > 16 slots: bank conflicts remain, see table_stride in score_kernels.hpp)
-            p->ts = (size_t)table_stride((int)m);
+            // (K > 16: rows of 2 * odd dwords for the 8-byte reads of the WIDE kernels, see table_stride)
+            p->ts = (size_t)table_stride((int)m, lds_wide((int)k));
             std::vector<float> table(k * p->ts, 0.0f);
             for (size_t s = 0; s < k; ++s)
                 for (size_t j = 0; j < m; ++j)
@@ -518,7 +518,7 @@ int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stri
             // lengths that are no multiple of 4: a second table with leading all-zero rows (see
             // lm_hip_pssm::d_table_pad); 33..35 stay as they are (36 rows cost more than the byte loads)
             if (m % 4 != 0 && (m + 3) / 4 * 4 <= 32) {
-                const size_t mp = (m + 3) / 4 * 4, lead = mp - m, tsp = (size_t)table_stride((int)mp);
+                const size_t mp = (m + 3) / 4 * 4, lead = mp - m, tsp = (size_t)table_stride((int)mp, lds_wide((int)k));
                 std::vector<float> padded(k * tsp, 0.0f);
                 for (size_t s = 0; s < k; ++s)
                     for (size_t j = 0; j < m; ++j)
@@ -574,7 +574,7 @@ int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stri
                 const size_t real = std::min(len, m - off);
                 part.lead = (4 - real % 4) % 4;          // the last slice: leading zero rows up to a multiple of 4
                 part.m = real + part.lead;
-                part.ts = (size_t)table_stride((int)part.m);
+                part.ts = (size_t)table_stride((int)part.m, lds_wide((int)k));
                 std::vector<float> table(k * part.ts, 0.0f);
                 for (size_t s = 0; s < k; ++s)
                     for (size_t j = 0; j < real; ++j)

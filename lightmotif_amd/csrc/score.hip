@@ -34,6 +34,9 @@ void register_score_c32_long_60(const KernelRegistry &r);
 void register_score_c32_long_64(const KernelRegistry &r);
 
 static ScoreC32Launcher g_c32[kMaxLongM + 1][kRegistrySlots];  // rows kMaxFastM + 1 ..: the long family (M % 4 == 0)
+static ScoreC32Launcher g_c32w[kMaxLongM + 1][kRegistrySlots];  // wide alphabets (lds_wide(K))
+static PrefilterLauncher g_prew[kMaxFastM + 1];
+static ScoreU8Launcher g_u8w[kMaxFastM + 1];
 static PrefilterLauncher g_pre[kMaxFastM + 1];
 static PrefilterLauncher g_pre2[kMaxFastM + 1];
 static PrefilterLauncher g_pre2_protein[kMaxFastM + 1];
@@ -45,7 +48,7 @@ static std::once_flag g_c32_once;
 
 static void init_registry()
 {
-    const KernelRegistry r{g_c32, g_pre, g_pre2, g_pre2_protein, g_u8, g_u8_pairs, g_pre2_multi};
+    const KernelRegistry r{g_c32, g_pre, g_pre2, g_pre2_protein, g_u8, g_u8_pairs, g_pre2_multi, g_c32w, g_prew, g_u8w};
     register_score_c32_0(r);
     register_score_c32_1(r);
     register_score_c32_2(r);
@@ -67,20 +70,22 @@ static void init_registry()
             snprintf(g_c32_names[m][mode], sizeof g_c32_names[m][mode], "score_c32<%d,%d>", m, mode);
 }
 
-ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap)
+ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap, bool wide)
 {
     std::call_once(g_c32_once, init_registry);
     if (M < 1 || M > kMaxLongM || mode < 0 || mode > 2)
         return nullptr;
+    if (wide)
+        return g_c32w[M][mode];  // (no XCD-remap variant: an A/B knob of the DNA store kernel)
     if (mode == MODE_STORE && xcd_remap)
         return g_c32[M][3];
     return g_c32[M][mode];
 }
 
-PrefilterLauncher score_c32_prefilter_lookup(int M)
+PrefilterLauncher score_c32_prefilter_lookup(int M, bool wide)
 {
     std::call_once(g_c32_once, init_registry);
-    return (M >= 1 && M <= kMaxFastM) ? g_pre[M] : nullptr;
+    return (M >= 1 && M <= kMaxFastM) ? (wide ? g_prew[M] : g_pre[M]) : nullptr;
 }
 
 PrefilterLauncher score_c32_prefilter2_lookup(int M, int K)
@@ -97,40 +102,24 @@ PrefilterMultiLauncher score_c32_prefilter2_multi_lookup(int M)
     return (M >= 1 && M <= kMaxFastM) ? g_pre2_multi[M] : nullptr;
 }
 
-ScoreC32Launcher score_c32_lookup_store_argmax(int M)
+static ScoreC32Launcher c32_slot(int M, int slot, bool wide)
 {
     std::call_once(g_c32_once, init_registry);
-    return (M >= 1 && M <= kMaxLongM) ? g_c32[M][8] : nullptr;
+    return (M >= 1 && M <= kMaxLongM) ? (wide ? g_c32w : g_c32)[M][slot] : nullptr;
 }
 
-ScoreC32Launcher score_c32_lookup_continue(int M)
-{
-    std::call_once(g_c32_once, init_registry);
-    return (M >= 1 && M <= kMaxLongM) ? g_c32[M][9] : nullptr;
-}
+ScoreC32Launcher score_c32_lookup_store_argmax(int M, bool wide) { return c32_slot(M, 8, wide); }
+ScoreC32Launcher score_c32_lookup_continue(int M, bool wide) { return c32_slot(M, 9, wide); }
+ScoreC32Launcher score_c32_lookup_c16(int M, bool wide) { return c32_slot(M <= kMaxFastM ? M : 0, 10, wide); }
+ScoreC32Launcher score_c32_lookup_store_track(int M, bool wide) { return c32_slot(M, 11, wide); }
+ScoreC32Launcher score_c32_lookup_ql(int M, bool wide) { return c32_slot(M, 7, wide); }
 
-ScoreC32Launcher score_c32_lookup_c16(int M)
+ScoreU8Launcher score_c32_lookup_u8(int M, bool pairs, bool wide)
 {
     std::call_once(g_c32_once, init_registry);
-    return (M >= 1 && M <= kMaxFastM) ? g_c32[M][10] : nullptr;
-}
-
-ScoreC32Launcher score_c32_lookup_store_track(int M)
-{
-    std::call_once(g_c32_once, init_registry);
-    return (M >= 1 && M <= kMaxLongM) ? g_c32[M][11] : nullptr;
-}
-
-ScoreC32Launcher score_c32_lookup_ql(int M)
-{
-    std::call_once(g_c32_once, init_registry);
-    return (M >= 1 && M <= kMaxLongM) ? g_c32[M][7] : nullptr;
-}
-
-ScoreU8Launcher score_c32_lookup_u8(int M, bool pairs)
-{
-    std::call_once(g_c32_once, init_registry);
-    return (M >= 1 && M <= kMaxFastM) ? (pairs ? g_u8_pairs[M] : g_u8[M]) : nullptr;
+    if (M < 1 || M > kMaxFastM)
+        return nullptr;
+    return pairs ? g_u8_pairs[M] : wide ? g_u8w[M] : g_u8[M];
 }
 
 const char *score_c32_name(int M, int mode)
@@ -222,7 +211,7 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const Score
         return p;
     const size_t lds = prefilter == 2   ? (size_t)prefilter2_image_dw((int)ms.m, (int)K) * 4
                        : prefilter == 1 ? (size_t)prefilter_image_dw((int)ms.m, (int)K) * 4
-                                        : std::max<size_t>(K * table_stride((int)M) * sizeof(float), 64);
+                                        : std::max<size_t>(K * table_stride((int)M, lds_wide((int)K)) * sizeof(float), 64);
     if (lds > 60 * 1024)
         return p;
     // The fused kernels write nothing, so they are LDS/VALU-bound and prefer long
@@ -308,6 +297,7 @@ static unsigned long long store_rows_hint(size_t m_kernel, size_t cols)
 int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
 {
     FusedOut fo{};
+    const bool wide = lds_wide((int)a.pssm->k);
     const bool dwords = ctx->quad_loads && !ctx->xcd_remap && reinterpret_cast<uintptr_t>(a.d_seq) % 4 == 0;
     if (dwords && a.pssm->d_table_pad) {
         // M % 4 != 0: the table padded with leading zero rows to M' = 4 * ceil(M / 4) -- the same f32
@@ -315,7 +305,7 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
         const size_t mp = a.pssm->m + a.pssm->lead;
         const MotifShape ms{mp, a.pssm->k, false};
         const C32Plan pp = plan_c32(ctx, ms, a, true, 0, 1, store_rows_hint(mp, a.cols), true);
-        ScoreC32Launcher pfn = a.cols == 16 ? score_c32_lookup_c16((int)mp) : score_c32_lookup_ql((int)mp);
+        ScoreC32Launcher pfn = a.cols == 16 ? score_c32_lookup_c16((int)mp, wide) : score_c32_lookup_ql((int)mp, wide);
         if (pp.ok && pfn) {
             fo.lead_rows = (unsigned)a.pssm->lead;
             ctx->last_kernel = score_c32_name((int)mp, MODE_STORE);
@@ -325,16 +315,16 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
             return LM_HIP_OK;
         }
     }
-    const bool c16 = a.cols == 16 && dwords && score_c32_lookup_c16((int)a.pssm->m);
+    const bool c16 = a.cols == 16 && dwords && score_c32_lookup_c16((int)a.pssm->m, wide);
     const C32Plan p = a.pssm->m <= (size_t)kMaxFastM ? plan_c32(ctx, MotifShape{a.pssm->m, a.pssm->k, false}, a, true, 0, 1,
                                                                   store_rows_hint(a.pssm->m, a.cols), c16)
                                                       : C32Plan{};  // longer: the slices below
     if (p.ok) {
-        ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_STORE, ctx->xcd_remap);
-        if (dwords && score_c32_lookup_ql((int)a.pssm->m))
-            fn = score_c32_lookup_ql((int)a.pssm->m);  // dword symbol loads (M % 4 == 0)
+        ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_STORE, ctx->xcd_remap, wide);
+        if (dwords && score_c32_lookup_ql((int)a.pssm->m, wide))
+            fn = score_c32_lookup_ql((int)a.pssm->m, wide);  // dword symbol loads (M % 4 == 0)
         if (c16)
-            fn = score_c32_lookup_c16((int)a.pssm->m);  // four streams of 16 columns per wavefront
+            fn = score_c32_lookup_c16((int)a.pssm->m, wide);  // four streams of 16 columns per wavefront
         ctx->last_kernel = score_c32_name((int)a.pssm->m, MODE_STORE);
         LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, a.pssm->d_table, (int)a.pssm->k,
                       a.row_begin, a.row_end, p.T, p.nstreams, a.d_out, fo));
@@ -361,9 +351,9 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
             FusedOut pfo = fo;
             pfo.lead_rows = (unsigned)part.lead;
             if (i == 0) {
-                ScoreC32Launcher fn = score_c32_lookup_ql((int)part.m);
+                ScoreC32Launcher fn = score_c32_lookup_ql((int)part.m, wide);
                 if (!fn)
-                    fn = score_c32_lookup((int)part.m, MODE_STORE, false);
+                    fn = score_c32_lookup((int)part.m, MODE_STORE, false, wide);
                 LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, sa.d_seq, part.d_table, (int)a.pssm->k, a.row_begin, a.row_end,
                               p.T, p.nstreams, a.d_out, pfo));
                 continue;
@@ -371,7 +361,7 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
             const unsigned long long nfull = n / p.T;
             if (nfull) {
                 const dim3 grid((unsigned)((nfull + kStreamsPerBlock - 1) / kStreamsPerBlock));
-                LM_HIP_TRY(score_c32_lookup_continue((int)part.m)(grid, p.lds, ctx->stream, sa.d_seq, part.d_table,
+                LM_HIP_TRY(score_c32_lookup_continue((int)part.m, wide)(grid, p.lds, ctx->stream, sa.d_seq, part.d_table,
                                                                   (int)a.pssm->k, a.row_begin, a.row_begin + nfull * p.T,
                                                                   p.T, nfull, a.d_out, pfo));
             }
@@ -513,7 +503,7 @@ int launch_score_u8(lm_hip_ctx *ctx, const DiscreteArgs &a)
     const bool pairs = p.ok;
     if (!pairs && out_aligned)
         p = plan_c32(ctx, ms, sa, true, 1, 1, 128);
-    ScoreU8Launcher fn = p.ok ? score_c32_lookup_u8(m, pairs) : nullptr;
+    ScoreU8Launcher fn = p.ok ? score_c32_lookup_u8(m, pairs, lds_wide(k)) : nullptr;
     // device copies (scratch2): [packed image | dense table]
     const size_t image_bytes = !fn ? 0 : pairs ? (size_t)prefilter2_image_dw(m) * 4 : (size_t)prefilter_image_dw(m, k) * 4;
     const size_t dense_bytes = ((size_t)m * k + 15) / 16 * 16;
@@ -667,7 +657,7 @@ int launch_score_store_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord 
     const float *pad_table = longm ? em.table : a.pssm->d_table_pad;
     const MotifShape ms{mk, a.pssm->k, false};
     const C32Plan p = mk >= 1 ? plan_c32(ctx, ms, a, true) : C32Plan{};
-    ScoreC32Launcher fn = p.ok ? score_c32_lookup_store_argmax((int)mk) : nullptr;
+    ScoreC32Launcher fn = p.ok ? score_c32_lookup_store_argmax((int)mk, lds_wide((int)a.pssm->k)) : nullptr;
     if (!fn || reinterpret_cast<uintptr_t>(a.d_seq) % 4 != 0)
         return launch_score_store(ctx, a);
     if (a.out_stride != 32)
@@ -721,7 +711,7 @@ int launch_score_store_track(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *
                        reinterpret_cast<uintptr_t>(a.d_seq) % 4 == 0)
                           ? plan_c32(ctx, MotifShape{mk, a.pssm->k, false}, a, true, 0, 1, store_rows_hint(mk, a.cols))
                           : C32Plan{};
-    ScoreC32Launcher fn = p.ok ? score_c32_lookup_store_track((int)mk) : nullptr;
+    ScoreC32Launcher fn = p.ok ? score_c32_lookup_store_track((int)mk, lds_wide((int)a.pssm->k)) : nullptr;
     if (!fn || !table)
         return launch_score_store(ctx, a);
     LM_TRY(ensure_ticket(ctx));
@@ -1102,7 +1092,7 @@ static int launch_score_argmax_exact(lm_hip_ctx *ctx, const ScoreArgs *jobs, siz
             fo.batch = n > 1 ? d_bparams + bp_pos : nullptr;
             const ExactMotif em = exact_motif(a.pssm, a.d_seq);  // (a group shares length, hence padding)
             fo.lead_rows = em.lead;
-            ScoreC32Launcher fn = score_c32_lookup((int)em.m, MODE_ARGMAX, false);
+            ScoreC32Launcher fn = score_c32_lookup((int)em.m, MODE_ARGMAX, false, lds_wide((int)a.pssm->k));
             ctx->last_kernel = score_c32_name((int)em.m, MODE_ARGMAX);
             LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, em.table, (int)a.pssm->k,
                           a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, nullptr, fo));
@@ -1483,7 +1473,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
             } else if (g.kind == KIND_PREFILTER || g.kind == KIND_PREFILTER2) {
                 const bool pairs = g.kind == KIND_PREFILTER2;
                 PrefilterLauncher fn = pairs ? score_c32_prefilter2_lookup((int)a.pssm->m, (int)a.pssm->k)
-                                             : score_c32_prefilter_lookup((int)a.pssm->m);
+                                             : score_c32_prefilter_lookup((int)a.pssm->m, lds_wide((int)a.pssm->k));
                 ctx->last_kernel = pairs ? "score_c32_prefilter2" : "score_c32_prefilter";
                 LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, pairs ? a.pssm->d_image2 : a.pssm->d_image,
                               (int)a.pssm->k, a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, tds[i], fo));
@@ -1492,7 +1482,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
                 const ExactMotif em = exact_motif(a.pssm, a.d_seq);
                 FusedOut efo = fo;
                 efo.lead_rows = em.lead;
-                ScoreC32Launcher fn = score_c32_lookup((int)em.m, MODE_THRESHOLD, false);
+                ScoreC32Launcher fn = score_c32_lookup((int)em.m, MODE_THRESHOLD, false, lds_wide((int)a.pssm->k));
                 ctx->last_kernel = score_c32_name((int)em.m, MODE_THRESHOLD);
                 LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, em.table, (int)a.pssm->k,
                               a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, nullptr, efo));
@@ -1972,7 +1962,7 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
         }
         const bool pairs = g.kind == KIND_PREFILTER2;
         PrefilterLauncher fn = pairs ? score_c32_prefilter2_lookup((int)a.pssm->m, (int)a.pssm->k)
-                                     : score_c32_prefilter_lookup((int)a.pssm->m);
+                                     : score_c32_prefilter_lookup((int)a.pssm->m, lds_wide((int)a.pssm->k));
         ctx->last_kernel = pairs ? "score_c32_prefilter2" : "score_c32_prefilter";
         LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, ls, a.d_seq, pairs ? a.pssm->d_image2 : a.pssm->d_image,
                       (int)a.pssm->k, a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, 0xffffffffu, fo));

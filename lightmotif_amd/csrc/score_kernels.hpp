@@ -55,15 +55,22 @@ constexpr int kMaxLongM = 64;
 
 // Floats per symbol row of the transposed LDS table used by score_c32<M>:
 // 4 * (smallest odd number >= ceil(M/4)).
-// Alphabets with more than 16 symbols (protein, K = 21) cannot be conflict-free with 16-byte reads
-// (16 four-bank slots per 16-lane group: five pairs of symbols share a slot -- 44 % of the LDS
-// cycles of score_c32<12, 0> at K = 21 are bank-conflict cycles, profiles/r02_stalls_protein.txt).
-// The 8-byte-read layout that would be conflict-free (32 slots per 32-lane group) was built and
-// measured in round 1 and removed in round 2: an LDS read instruction occupies the pipeline ~4
-// cycles whatever its width (SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS, profiles/r02_stalls_store_kernel.txt),
-// so twice as many 8-byte reads cost more than the conflicts they avoid (0.254 vs 0.197 ms on the
-// 200 Mres configuration).
-constexpr int table_stride(int m) { return 4 * (((m + 3) / 4) | 1); }
+// WIDE alphabets (K > 16: protein, K = 21).  A 16-byte LDS read is served in four 16-lane groups over 16
+// four-bank slots: 21 symbol rows cannot all sit in different slots, and 44 % of the LDS cycles of the K = 21
+// kernels were bank-conflict cycles (7.2 LDS cycles per read instead of 4; profiles/r02_stalls_protein.txt).  An
+// 8-byte read is served in two 32-lane groups over 32 two-bank slots (MI355X_MICROARCH.md, LDS table: ds_read_b64
+// 2 cycles, 256 B/clk like b128): with rows of 2 * odd dwords up to 32 symbols are conflict-free.  So the WIDE
+// kernels read the same column with twice as many single `ds_read_b64` (volatile: two of them fused into a
+// ds_read2_b64 cost 8 cycles, which is what round 1's attempt measured and round 2 misread as "4 cycles per
+// read whatever its width").  Counters, round 3 (profiles/r03_protein_b64.txt): conflicts 44 % -> 0, 2.0 LDS cycles
+// per instruction, store kernel 0.214 -> 0.191 ms per 200 Mres, u16 prefilter scan 0.131 -> 0.111 ms.  DNA keeps
+// the 16-byte reads: the 8-byte form costs it 3-10 % (twice the LDS instructions for the same LDS cycles).
+constexpr bool lds_wide(int k) { return k > 16; }
+constexpr int table_stride(int m, int wide = 0) { return wide ? 4 * ((m + 3) / 4) + 2 : 4 * (((m + 3) / 4) | 1); }
+typedef float lm_f32x2_t __attribute__((ext_vector_type(2)));
+typedef const volatile __attribute__((address_space(3))) lm_f32x2_t *lm_lds_b64_ptr;  // volatile: never fused into ds_read2_b64
+typedef unsigned lm_u32x2_t __attribute__((ext_vector_type(2)));
+typedef const volatile __attribute__((address_space(3))) lm_u32x2_t *lm_lds_u64_ptr;
 
 // MODE_CONTINUE: like MODE_STORE, but every output starts from the partial sum already stored in
 // its cell instead of +0.0 -- the later passes of a motif longer than kMaxFastM, which is scored
@@ -271,11 +278,21 @@ constexpr int score_min_waves(int m, int mode)
     return m <= 40 ? LM_SCORE_MIN_WAVES(m) : mode == 0 /* MODE_STORE */ ? LM_LONG_STORE_MINW : m == 52 ? 3 : 2;
 }
 
-template <int M>
+template <int M, int WIDE = 0>
 __device__ __forceinline__ void lds_fetch_column(float (&w)[4 * ((M + 3) / 4)],
                                                  const char *__restrict__ tab, const unsigned s)
 {
-    constexpr unsigned TSB = table_stride(M) * 4;  // bytes per symbol row
+    constexpr unsigned TSB = table_stride(M, WIDE) * 4;  // bytes per symbol row
+    if constexpr (WIDE != 0) {
+        const char *row8 = static_cast<const char *>(__builtin_assume_aligned(tab + __umul24(s, TSB), 8));
+#pragma unroll
+        for (int q = 0; q < (M + 1) / 2; ++q) {
+            const lm_f32x2_t v = *(lm_lds_b64_ptr)(row8 + 8 * q);
+            w[2 * q + 0] = v.x;
+            w[2 * q + 1] = v.y;
+        }
+        return;
+    }
     // M floats: whole 16-byte reads, then an 8- and/or 4-byte read for the rest
     const char *row =
         static_cast<const char *>(__builtin_assume_aligned(tab + __umul24(s, TSB), 16));
@@ -309,16 +326,24 @@ __device__ __forceinline__ void lds_fetch_column(float (&w)[4 * ((M + 3) / 4)],
 #ifndef LM_SCORE_EDGE_B128
 #define LM_SCORE_EDGE_B128(M) ((M) <= 16 || (M) >= 24)
 #endif
-template <int M>
+template <int M, int WIDE = 0>
 __device__ __forceinline__ void lds_fetch_chunks(float (&w)[4 * ((M + 3) / 4)], const char *__restrict__ tab,
                                                  const unsigned s, const int c0, const int c1)
 {
-    constexpr unsigned TSB = table_stride(M) * 4;
-    const char *row = static_cast<const char *>(__builtin_assume_aligned(tab + __umul24(s, TSB), 16));
+    constexpr unsigned TSB = table_stride(M, WIDE) * 4;
+    const char *row = static_cast<const char *>(__builtin_assume_aligned(tab + __umul24(s, TSB), WIDE ? 8 : 16));
 #pragma unroll
     for (int q = 0; q < (M + 3) / 4; ++q) {
         if (q < c0 || q >= c1)  // folds: the bounds are constants of the unrolled step
             continue;
+        if constexpr (WIDE != 0) {
+            const lm_f32x2_t a = *(lm_lds_b64_ptr)(row + 16 * q), b = *(lm_lds_b64_ptr)(row + 16 * q + 8);
+            w[4 * q + 0] = a.x;
+            w[4 * q + 1] = a.y;
+            w[4 * q + 2] = b.x;
+            w[4 * q + 3] = b.y;
+            continue;
+        }
         typedef float f32x4_t __attribute__((ext_vector_type(4)));
         typedef const volatile __attribute__((address_space(3))) f32x4_t *lds_ptr;  // explicit LDS space:
         const f32x4_t v = *(lds_ptr)(row + 16 * q);  // a volatile generic pointer would become flat_load
@@ -348,7 +373,7 @@ enum : int { PHASE_FIRST = 0, PHASE_MAIN = 1, PHASE_LAST = 2 };
 // the group's first step (in the FIRST group only step M-1 completes a row).
 // `sym` is a ring of symbol bytes indexed by step mod M (only ~PF are live),
 // `wc` carries the prefetched LDS column across steps when LP = 1.
-template <int M, int MODE, int PF, int LP, int PHASE, int QL = 0, int OC = 32>
+template <int M, int MODE, int PF, int LP, int PHASE, int QL = 0, int OC = 32, int WIDE = 0>
 __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
                                             float (&wc)[4 * ((M + 3) / 4)],
                                             const uint8_t *__restrict__ sp,
@@ -395,19 +420,19 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
             for (int i = 0; i < NW; ++i)
                 w[i] = 0.0f;
             if (PHASE == PHASE_FIRST)
-                lds_fetch_chunks<M>(w, tab, sy, 0, k / 4 + 1);
+                lds_fetch_chunks<M, WIDE>(w, tab, sy, 0, k / 4 + 1);
             else
-                lds_fetch_chunks<M>(w, tab, sy, k / 4, (M + 3) / 4);
+                lds_fetch_chunks<M, WIDE>(w, tab, sy, k / 4, (M + 3) / 4);
         } else if (QL) {
-            lds_fetch_column<M>(w, tab, s_now);
+            lds_fetch_column<M, WIDE>(w, tab, s_now);
         } else if (LP) {
 #pragma unroll
             for (int i = 0; i < NW; ++i)
                 w[i] = wc[i];
             if (PHASE != PHASE_LAST || k + 1 < M)
-                lds_fetch_column<M>(wc, tab, sym[(k + 1) % M]);
+                lds_fetch_column<M, WIDE>(wc, tab, sym[(k + 1) % M]);
         } else {
-            lds_fetch_column<M>(w, tab, sym[k]);
+            lds_fetch_column<M, WIDE>(w, tab, sym[k]);
         }
         // MODE_CONTINUE: the output started at this step resumes from the partial sum in its cell
         // (requested one step ago); request the next step's.  The row started at step k is stored
@@ -546,7 +571,7 @@ __device__ __forceinline__ void emit_candidates(const unsigned long long hit_gro
 #define LM_SCORE_XCD_REMAP 0
 #endif
 template <int M, int MODE, int PF = LM_SCORE_PF, int LP = LM_SCORE_LP, int BLK = LM_BLOCK,
-          int XCD = LM_SCORE_XCD_REMAP, int MINW = LM_SCORE_MIN_WAVES(M), int QLREQ = 0, int OC = 32>
+          int XCD = LM_SCORE_XCD_REMAP, int MINW = LM_SCORE_MIN_WAVES(M), int QLREQ = 0, int OC = 32, int WIDE = 0>
 __global__ __launch_bounds__(BLK, MINW) void score_c32(
     const uint8_t *__restrict__ seq, const float *__restrict__ table, const int K,
     const unsigned long long row_begin, const unsigned long long row_end,
@@ -563,9 +588,11 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         fo.job_key = bp.job_key;
     }
     {
-        float4 *dst = reinterpret_cast<float4 *>(lds_raw);
-        const float4 *src = reinterpret_cast<const float4 *>(table);
-        const int n4 = K * table_stride(M) / 4;
+        // (WIDE rows are 2 * odd dwords: the table is no multiple of 16 bytes)
+        typedef std::conditional_t<WIDE != 0, float2, float4> vec_t;
+        vec_t *dst = reinterpret_cast<vec_t *>(lds_raw);
+        const vec_t *src = reinterpret_cast<const vec_t *>(table);
+        const int n4 = K * table_stride(M, WIDE) / (WIDE ? 2 : 4);
         for (int i = threadIdx.x; i < n4; i += BLK)
             dst[i] = src[i];
     }
@@ -632,7 +659,7 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         wc[i] = 0.0f;
     constexpr int LPE = (PFE >= 1) ? LP : 0;
     if (LPE)
-        lds_fetch_column<M>(wc, lds_raw, sym[0]);
+        lds_fetch_column<M, WIDE>(wc, lds_raw, sym[0]);
     float best_v = (MODE == MODE_STORE_ARGMAX) ? __builtin_nanf("") : -INFINITY;
     // argmax mode: step index of the lane's best score (0xffffffff = none);
     // threshold mode: "this group saw a hit" flag
@@ -661,7 +688,7 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         }
     };
 
-    score_group<M, MODE, PFE, LPE, PHASE_FIRST, QL, OC>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
+    score_group<M, MODE, PFE, LPE, PHASE_FIRST, QL, OC, WIDE>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
                                                 best_t, fo, shq, init_next);
     note_group();
     for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
@@ -669,7 +696,7 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         tbase += M;
         if (mode_stores(MODE))
             op += M * OC;
-        score_group<M, MODE, PFE, LPE, PHASE_MAIN, QL, OC>(acc, sym, wc, sp, lds_raw, op, tbase, col,
+        score_group<M, MODE, PFE, LPE, PHASE_MAIN, QL, OC, WIDE>(acc, sym, wc, sp, lds_raw, op, tbase, col,
                                                    best_v, best_t, fo, shq, init_next);
         note_group();
     }
@@ -677,7 +704,7 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
     tbase += M;
     if (mode_stores(MODE))
         op += M * OC;
-    score_group<M, MODE, PFE, LPE, PHASE_LAST, QL, OC>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
+    score_group<M, MODE, PFE, LPE, PHASE_LAST, QL, OC, WIDE>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
                                                best_t, fo, shq, init_next);
     note_group();
 
@@ -768,7 +795,7 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
                             first = 0.0f;
                             const uint8_t *s00 = seq + row_begin * 32;
                             for (int j = (int)lead; j < M; ++j)
-                                first = first + table[s00[(j - (int)lead) * 32] * table_stride(M) + j];
+                                first = first + table[s00[(j - (int)lead) * 32] * table_stride(M, WIDE) + j];
                         }
                         if (first != first) {  // NaN: nothing ever compares >= it
                             v = first;
@@ -973,14 +1000,14 @@ using ScoreC32Launcher = hipError_t (*)(dim3 grid, size_t lds_bytes, hipStream_t
                                         unsigned long long T, unsigned long long nstreams,
                                         float *out, FusedOut fo);
 
-template <int M, int MODE, int XCD = LM_SCORE_XCD_REMAP, int QL = 0, int OC = 32>
+template <int M, int MODE, int XCD = LM_SCORE_XCD_REMAP, int QL = 0, int OC = 32, int WIDE = 0>
 hipError_t score_c32_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, const uint8_t *seq,
                             const float *table, int K, unsigned long long row_begin,
                             unsigned long long row_end, unsigned long long T,
                             unsigned long long nstreams, float *out, FusedOut fo)
 {
     hipLaunchKernelGGL((score_c32<M, MODE, LM_SCORE_PF, LM_SCORE_LP, LM_BLOCK, XCD,
-                                  score_min_waves(M, MODE), QL, OC>), grid,
+                                  score_min_waves(M, MODE), QL, OC, WIDE>), grid,
                        dim3(kBlock), lds_bytes, stream, seq, table, K, row_begin, row_end, T,
                        nstreams, out, fo);
     return hipGetLastError();
@@ -993,12 +1020,13 @@ hipError_t score_c32_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, con
 constexpr int kRegistrySlots = 12;  // [9] = MODE_CONTINUE (later passes of motifs longer than kMaxFastM),
                                     // [10] = store kernel for C = 16 (M % 4 == 0, quad loads),
                                     // [11] = MODE_STORE_TRACK (M % 4 == 0, quad loads): small score_into + argmax
-ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap = false);
-ScoreC32Launcher score_c32_lookup_ql(int M);
-ScoreC32Launcher score_c32_lookup_store_argmax(int M);
-ScoreC32Launcher score_c32_lookup_continue(int M);
-ScoreC32Launcher score_c32_lookup_c16(int M);
-ScoreC32Launcher score_c32_lookup_store_track(int M);
+// `wide`: the kernels for alphabets of more than 16 symbols (lds_wide(K): 8-byte LDS reads)
+ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap = false, bool wide = false);
+ScoreC32Launcher score_c32_lookup_ql(int M, bool wide = false);
+ScoreC32Launcher score_c32_lookup_store_argmax(int M, bool wide = false);
+ScoreC32Launcher score_c32_lookup_continue(int M, bool wide = false);
+ScoreC32Launcher score_c32_lookup_c16(int M, bool wide = false);
+ScoreC32Launcher score_c32_lookup_store_track(int M, bool wide = false);
 const char *score_c32_name(int M, int mode);
 
 }  // namespace lm

@@ -28,6 +28,14 @@ void LM_CAT(register_score_c32_long_, LM_LONG_M)(const KernelRegistry &r)
     tab[8] = &score_c32_launch<M, MODE_STORE_ARGMAX, LM_SCORE_XCD_REMAP, 1>;
     tab[9] = &score_c32_launch<M, MODE_CONTINUE, LM_SCORE_XCD_REMAP, 1>;
     tab[11] = &score_c32_launch<M, MODE_STORE_TRACK, LM_SCORE_XCD_REMAP, 1>;
+    // the same for alphabets of more than 16 symbols (8-byte LDS reads)
+    ScoreC32Launcher *tw = r.c32w[M];
+    tw[MODE_STORE] = tw[7] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1, 32, 1>;
+    tw[MODE_ARGMAX] = &score_c32_launch<M, MODE_ARGMAX, LM_SCORE_XCD_REMAP, 1, 32, 1>;
+    tw[MODE_THRESHOLD] = &score_c32_launch<M, MODE_THRESHOLD, LM_SCORE_XCD_REMAP, 1, 32, 1>;
+    tw[8] = &score_c32_launch<M, MODE_STORE_ARGMAX, LM_SCORE_XCD_REMAP, 1, 32, 1>;
+    tw[9] = &score_c32_launch<M, MODE_CONTINUE, LM_SCORE_XCD_REMAP, 1, 32, 1>;
+    tw[11] = &score_c32_launch<M, MODE_STORE_TRACK, LM_SCORE_XCD_REMAP, 1, 32, 1>;
 }
 
 }  // namespace lm

@@ -38,18 +38,22 @@ namespace lm {
 
 constexpr int prefilter_mp(int m) { return (m + 1) / 2 * 2; }
 // dwords per symbol row of one discrete layout: 4 * odd >= MP / 2 (conflict-free b128)
-constexpr int prefilter_stride_dw(int m) { return 4 * (((prefilter_mp(m) / 2 + 3) / 4) | 1); }
+// (wide alphabets, lds_wide(k): 2 * odd, read with single ds_read_b64 -- see table_stride in score_kernels.hpp)
+constexpr int prefilter_stride_dw(int m, int wide = 0)
+{
+    return wide ? 2 * (((prefilter_mp(m) / 2 + 1) / 2) | 1) : 4 * (((prefilter_mp(m) / 2 + 3) / 4) | 1);
+}
 // total dwords of the LDS image: layout EVEN | layout ODD
 constexpr int prefilter_image_dw(int m, int k)
 {
-    return 2 * k * prefilter_stride_dw(m);
+    return 2 * k * prefilter_stride_dw(m, lds_wide(k));
 }
 
 // Host side: packs the padded discrete weights d[j * k + s], j < prefilter_mp(m) (row 0 = the
 // all-zero padding row when m is odd), into the LDS image [layout EVEN | layout ODD].
 inline void prefilter_pack_image(const unsigned *d, int m, int k, unsigned *image)
 {
-    const int mp = prefilter_mp(m), dsd = prefilter_stride_dw(m);
+    const int mp = prefilter_mp(m), dsd = prefilter_stride_dw(m, lds_wide(k));
     for (int i = 0; i < prefilter_image_dw(m, k); ++i)
         image[i] = 0u;
     unsigned *even = image;
@@ -98,7 +102,7 @@ __device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b)
 // written to `op[k * 32]` (`op` = the lane's cell of the group's first completed output;
 // the FIRST group completes one output only), clamped to 255 (`sat_mask` = 0: the
 // saturating adds of avx2.rs:336) or reduced mod 256 (`sat_mask` = 0xff: Generic's `+=`).
-template <int M, int PF, int PHASE, int STORE = 0>
+template <int M, int PF, int PHASE, int STORE = 0, int WIDE = 0>
 __device__ __forceinline__ void prefilter_group(unsigned (&acc2)[prefilter_mp(M) / 2],
                                                 unsigned (&sym)[prefilter_mp(M)],
                                                 const uint8_t *__restrict__ sp,
@@ -118,7 +122,7 @@ __device__ __forceinline__ void prefilter_group(unsigned (&acc2)[prefilter_mp(M)
     constexpr int MP = prefilter_mp(M);
     constexpr int NP = MP / 2;
     constexpr int NV = (NP + 3) / 4;
-    constexpr unsigned DSB = prefilter_stride_dw(M) * 4;
+    constexpr unsigned DSB = prefilter_stride_dw(M, WIDE) * 4;
 #pragma unroll
     for (int k = 0; k < MP; ++k) {
         if (PF > 0) {
@@ -128,24 +132,34 @@ __device__ __forceinline__ void prefilter_group(unsigned (&acc2)[prefilter_mp(M)
             sym[k] = sp[k * 32];
         }
         const char *row = static_cast<const char *>(__builtin_assume_aligned(
-            ((k & 1) ? tab_odd : tab_even) + __umul24(sym[k], DSB), 16));
+            ((k & 1) ? tab_odd : tab_even) + __umul24(sym[k], DSB), WIDE ? 8 : 16));
         // NP dwords: whole 16-byte reads, then an 8- and/or 4-byte read for the rest
         unsigned w2[NV * 4];
+        if constexpr (WIDE != 0) {
 #pragma unroll
-        for (int q = 0; q < NP / 4; ++q) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(row + 16 * q);
-            w2[4 * q + 0] = v.x;
-            w2[4 * q + 1] = v.y;
-            w2[4 * q + 2] = v.z;
-            w2[4 * q + 3] = v.w;
+            for (int q = 0; q < (NP + 1) / 2; ++q) {
+                // (an unsigned vector: `__builtin_bit_cast(unsigned, v.y)` on a float vector's element reads v.x, hipcc 7.0)
+                const lm_u32x2_t v = *(lm_lds_u64_ptr)(row + 8 * q);
+                w2[2 * q + 0] = v.x;
+                w2[2 * q + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NP / 4; ++q) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(row + 16 * q);
+                w2[4 * q + 0] = v.x;
+                w2[4 * q + 1] = v.y;
+                w2[4 * q + 2] = v.z;
+                w2[4 * q + 3] = v.w;
+            }
+            if (NP % 4 >= 2) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(row + 16 * (NP / 4));
+                w2[4 * (NP / 4) + 0] = v.x;
+                w2[4 * (NP / 4) + 1] = v.y;
+            }
+            if (NP % 2 == 1)
+                w2[NP - 1] = *reinterpret_cast<const unsigned *>(row + 4 * (NP - 1));
         }
-        if (NP % 4 >= 2) {
-            const uint2 v = *reinterpret_cast<const uint2 *>(row + 16 * (NP / 4));
-            w2[4 * (NP / 4) + 0] = v.x;
-            w2[4 * (NP / 4) + 1] = v.y;
-        }
-        if (NP % 2 == 1)
-            w2[NP - 1] = *reinterpret_cast<const unsigned *>(row + 4 * (NP - 1));
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int j_lo = (k - 2 * i + 2 * MP) % MP;  // weight row of slot 2i at this step
@@ -187,7 +201,7 @@ __device__ __forceinline__ void prefilter_group(unsigned (&acc2)[prefilter_mp(M)
 // Same geometry as score_c32<M, MODE_THRESHOLD> with M replaced by MP: every stream
 // sweeps T = q*MP + 1 outputs in (q+1) groups of MP steps.  `image` = the LDS image
 // described above; `td` = discrete threshold.
-template <int M, int PF = LM_SCORE_PF>
+template <int M, int PF = LM_SCORE_PF, int WIDE = 0>
 __global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter(
     const uint8_t *__restrict__ seq, const unsigned *__restrict__ image, const int K,
     const unsigned long long row_begin, const unsigned long long row_end,
@@ -214,7 +228,7 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter(
     }
     __syncthreads();
     const char *tab_even = lds_raw;
-    const char *tab_odd = tab_even + (size_t)K * prefilter_stride_dw(M) * 4;
+    const char *tab_odd = tab_even + (size_t)K * prefilter_stride_dw(M, WIDE) * 4;
 
     const int lane = threadIdx.x & 63;
     const int col = lane & 31;
@@ -265,15 +279,15 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter(
         }
     };
 
-    prefilter_group<M, PFE, PHASE_FIRST>(acc2, sym, sp, tab_even, tab_odd, mx);
+    prefilter_group<M, PFE, PHASE_FIRST, 0, WIDE>(acc2, sym, sp, tab_even, tab_odd, mx);
     note_group();
     for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
         sp += MP * 32;
-        prefilter_group<M, PFE, PHASE_MAIN>(acc2, sym, sp, tab_even, tab_odd, mx);
+        prefilter_group<M, PFE, PHASE_MAIN, 0, WIDE>(acc2, sym, sp, tab_even, tab_odd, mx);
         note_group();
     }
     sp += MP * 32;
-    prefilter_group<M, PFE, PHASE_LAST>(acc2, sym, sp, tab_even, tab_odd, mx);
+    prefilter_group<M, PFE, PHASE_LAST, 0, WIDE>(acc2, sym, sp, tab_even, tab_odd, mx);
     note_group();
 
     // the flagged groups become candidates for exact re-scoring (outputs are counted from the stream's
@@ -306,18 +320,18 @@ using PrefilterLauncher = hipError_t (*)(dim3 grid, size_t lds_bytes, hipStream_
                                          unsigned long long T, unsigned long long nstreams,
                                          unsigned td, FusedOut fo);
 
-template <int M>
+template <int M, int WIDE = 0>
 hipError_t score_c32_prefilter_launch(dim3 grid, size_t lds_bytes, hipStream_t stream,
                                       const uint8_t *seq, const unsigned *image, int K,
                                       unsigned long long row_begin, unsigned long long row_end,
                                       unsigned long long T, unsigned long long nstreams,
                                       unsigned td, FusedOut fo)
 {
-    hipLaunchKernelGGL((score_c32_prefilter<M>), grid, dim3(kBlock), lds_bytes, stream, seq, image,
+    hipLaunchKernelGGL((score_c32_prefilter<M, LM_SCORE_PF, WIDE>), grid, dim3(kBlock), lds_bytes, stream, seq, image,
                        K, row_begin, row_end, T, nstreams, td, fo);
     return hipGetLastError();
 }
 
-PrefilterLauncher score_c32_prefilter_lookup(int M);
+PrefilterLauncher score_c32_prefilter_lookup(int M, bool wide = false);
 
 }  // namespace lm

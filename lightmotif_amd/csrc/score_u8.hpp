@@ -22,7 +22,7 @@ namespace lm {
 
 // `image` = prefilter image built from the u8 weights (api.hip: pack_prefilter_image);
 // `out` = row `row_begin` of the u8 score matrix, row stride 32.
-template <int M, int PF = LM_SCORE_PF>
+template <int M, int PF = LM_SCORE_PF, int WIDE = 0>
 __global__ __launch_bounds__(kBlock, 6) void score_c32_u8(
     const uint8_t *__restrict__ seq, const unsigned *__restrict__ image, const int K,
     const unsigned long long row_begin, const unsigned long long row_end,
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_u8(
     }
     __syncthreads();
     const char *tab_even = lds_raw;
-    const char *tab_odd = tab_even + (size_t)K * prefilter_stride_dw(M) * 4;
+    const char *tab_odd = tab_even + (size_t)K * prefilter_stride_dw(M, WIDE) * 4;
 
     const int lane = threadIdx.x & 63;
     const int col = lane & 31;
@@ -78,15 +78,15 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_u8(
     const unsigned long long ngroups = (T + MP - 1) / MP;  // exact: T = q*MP + 1, >= 2
     uint8_t *op = out + (o0 - row_begin) * 32 + col;
     unsigned mx = 0;
-    prefilter_group<M, PFE, PHASE_FIRST, 1>(acc2, sym, sp, tab_even, tab_odd, mx, op, wrap_mask);
+    prefilter_group<M, PFE, PHASE_FIRST, 1, WIDE>(acc2, sym, sp, tab_even, tab_odd, mx, op, wrap_mask);
     op += 32;
     for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
         sp += MP * 32;
-        prefilter_group<M, PFE, PHASE_MAIN, 1>(acc2, sym, sp, tab_even, tab_odd, mx, op, wrap_mask);
+        prefilter_group<M, PFE, PHASE_MAIN, 1, WIDE>(acc2, sym, sp, tab_even, tab_odd, mx, op, wrap_mask);
         op += MP * 32;
     }
     sp += MP * 32;
-    prefilter_group<M, PFE, PHASE_LAST, 1>(acc2, sym, sp, tab_even, tab_odd, mx, op, wrap_mask);
+    prefilter_group<M, PFE, PHASE_LAST, 1, WIDE>(acc2, sym, sp, tab_even, tab_odd, mx, op, wrap_mask);
 }
 
 // DNA, M >= 2: the same sums from the pair-symbol scan of score_prefilter2.hpp (two input rows
@@ -166,13 +166,13 @@ using ScoreU8Launcher = hipError_t (*)(dim3 grid, size_t lds_bytes, hipStream_t 
                                        unsigned long long row_end, unsigned long long T,
                                        unsigned long long nstreams, uint8_t *out, unsigned wrap_mask);
 
-template <int M>
+template <int M, int WIDE = 0>
 hipError_t score_c32_u8_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, const uint8_t *seq,
                                const unsigned *image, int K, unsigned long long row_begin,
                                unsigned long long row_end, unsigned long long T, unsigned long long nstreams,
                                uint8_t *out, unsigned wrap_mask)
 {
-    hipLaunchKernelGGL((score_c32_u8<M>), grid, dim3(kBlock), lds_bytes, stream, seq, image, K, row_begin,
+    hipLaunchKernelGGL((score_c32_u8<M, LM_SCORE_PF, WIDE>), grid, dim3(kBlock), lds_bytes, stream, seq, image, K, row_begin,
                        row_end, T, nstreams, out, wrap_mask);
     return hipGetLastError();
 }
@@ -197,6 +197,10 @@ struct KernelRegistry {
     PrefilterLauncher *pre2_protein;  // the pair scan over the 441 residue pairs (K = 21)
     ScoreU8Launcher *u8, *u8_pairs;
     PrefilterMultiLauncher *pre2_multi;  // several motifs per pass (prefilter2_multi(M) > 1)
+    // the same kernels for alphabets of more than 16 symbols (WIDE: 8-byte LDS reads, score_kernels.hpp)
+    ScoreC32Launcher (*c32w)[kRegistrySlots];
+    PrefilterLauncher *prew;
+    ScoreU8Launcher *u8w;
 };
 
 }  // namespace lm
