@@ -448,6 +448,9 @@ def secondary_configs(pli, dev) -> dict:
     pssm = lm.create(["GTTGACCTTATCAAC", "GTTGATCCAGTCAAC"]).counts.normalize(0.1).log_odds()
     c1 = {"workload": "configs[0]: MX000001 (M = 15) x 464165 bp stand-in for E. coli/10 (site planted at 391677), "
                       "score_into + argmax per iteration into one re-used StripedScores (dna.rs:104-107)"}
+    # (a context of its own on a stream the library owns, like the reference-side shim's default context: launches on
+    #  torch's legacy default stream, which the headline run borrows, cost ~10 us more each)
+    pli_main, pli = pli, lm.Pipeline.hip(dev.index)
     for cols, tag in ((32, "C32_dispatch_geometry"), (1, "C1_generic_bench_geometry")):
         seq = pli.stripe(lm.EncodedSequence(enc), cols)
         seq.configure(pssm)
@@ -465,6 +468,7 @@ def secondary_configs(pli, dev) -> dict:
                    "fused_score_argmax_us": round(tf * 1e6, 2), "fused_kernel": pli.last_kernel}
         del seq, scores
     out["c1"] = c1
+    pli = pli_main
 
     # --- configs[4]: protein (K = 21) len-12 PSSM x 200 Mres: score() materialised + fused threshold
     length, m = 200_000_000, 12

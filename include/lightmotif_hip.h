@@ -298,6 +298,27 @@ int lm_hip_scan_threshold_batch(lm_hip_ctx *ctx, const lm_hip_pssm *const *pssms
 int lm_hip_scan_f32(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *seq,
                     float threshold, lm_hip_hit **hits, size_t *n);
 
+/* Scanner::max EXACTLY as the reference computes it (scan.rs:200-249) -- which is not "the best
+ * hit": the u8 scores of the DiscreteMatrix steer the walk.  Cells are visited in row-major
+ * order (blocks ascending, Threshold order inside a block); a cell whose u8 score reaches the
+ * current level is re-scored in f32 and replaces the best hit when its score is greater, or
+ * equal at a greater position, and the level becomes ITS u8 score; while no hit is held the
+ * first candidate is taken as it is (no `score >= threshold` test) and the level stays the
+ * scaled threshold; positions are not tested against position + M <= L, and a candidate whose
+ * window leaves the striped matrix makes the reference panic -- LM_HIP_ERR_BAD_ARGS here.
+ *   dweights  the DiscreteMatrix's u8 weights (HOST, M x dweights_stride; pwm/mod.rs:754-791)
+ *   saturate  1: the u8 adds of the SIMD back-ends (avx2.rs:336), 0: Generic's wrapping `+=`
+ *   level     dm.scale(threshold), or dm.scale(best pending score) when `have`
+ *   have / position / score   the best hit among those already collected and not yet yielded
+ *             (scan.rs:207-210; 0 on a fresh scanner)
+ *   first_row the row the scanner has reached (scan.rs `self.row`; 0 on a fresh scanner)
+ * Runs on the device window by window (u8 + f32 scores of a window, an ordered parallel search
+ * per update of the walk's state): ~5 ms per Gbp.  Synchronises. */
+int lm_hip_scan_max_f32(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *seq,
+                        const uint8_t *dweights, size_t dweights_stride, int saturate, unsigned level,
+                        int have, size_t position, float score, size_t first_row, int *found,
+                        lm_hip_hit *best);
+
 /* ---- Encode / Stripe (device pointers) ------------------------------------ */
 
 /* Encode::encode_into (pli/mod.rs:56-66): ASCII -> symbol index.  alphabet is

@@ -88,6 +88,8 @@ SIGNATURES = {
     "lm_hip_scan_threshold_batch": (C.c_int, [_vp, C.POINTER(_vp), _fp, _sz, _vp, _szp,
                                               C.POINTER(_cp), C.POINTER(_fp)]),
     "lm_hip_scan_f32": (C.c_int, [_vp, _vp, _vp, C.c_float, C.POINTER(C.POINTER(Hit)), _szp]),
+    "lm_hip_scan_max_f32": (C.c_int, [_vp, _vp, _vp, _vp, _sz, C.c_int, C.c_uint, C.c_int, _sz, C.c_float, _sz, _ip,
+                                      C.POINTER(Hit)]),
     "lm_hip_encode_dptr": (C.c_int, [_vp, C.c_char, _vp, _sz, C.c_int, _vp, _szp]),
     "lm_hip_stripe_dptr": (C.c_int, [_vp, _vp, _sz, _sz, C.c_uint8, _sz, _vp, _sz]),
     "lm_hip_configure_wrap_dptr": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _sz, C.c_uint8]),
@@ -153,6 +155,10 @@ def lib() -> C.CDLL:
             raise ImportError("lightmotif_hip ABI version mismatch")
         _lib = L
     return _lib
+
+
+def last_error() -> str:
+    return lib().lm_hip_last_error().decode("utf-8", "replace")
 
 
 def check(status: int) -> None:

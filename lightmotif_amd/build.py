@@ -32,7 +32,7 @@ INST = [(i, 4 * i + 1, 4 * i + 4) for i in range(9)]
 # the raised unroll budget is what keeps their accumulators in registers (see the file's header)
 LONG = list(range(40, 65, 4))
 LONG_FLAGS = ["-mllvm", "-pragma-unroll-threshold=10000000"]
-UNITS = ["score.hip", "reduce.hip", "hits.hip", "discrete.hip", "layout.hip", "api.hip", "comm.hip"]
+UNITS = ["score.hip", "reduce.hip", "hits.hip", "discrete.hip", "layout.hip", "scanmax.hip", "api.hip", "comm.hip"]
 
 
 def _hipcc() -> str:

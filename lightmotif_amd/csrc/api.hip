@@ -141,7 +141,10 @@ static bool build_prefilter(lm_hip_pssm &p, std::vector<unsigned> *image, std::v
 // (profiles/r01_timeline_fused_p1e-3.txt: 1.06 ms of device work in a 2.14 ms call).  Large blocks
 // therefore come from a small process-wide pool: 2 MB-aligned, page-locked (hipHostRegister, so the
 // read-back is one DMA at link rate) and REUSED when the caller frees them.  LM_HIP_RESULT_POOL_MB
-// bounds what the pool keeps when idle (default 256; 0 = no pooling, plain malloc).
+// bounds what the pool keeps when idle (default 256; 0 or negative = no pooling, plain malloc); blocks the
+// caller still holds count too: once pinned memory -- idle and handed out -- reaches four times that budget,
+// further results are plain (pageable, unpooled) allocations, so a caller that keeps many results alive
+// cannot lock an unbounded amount of host memory.
 namespace {
 struct ResultBlock {
     void *ptr;
@@ -158,7 +161,8 @@ size_t pool_budget()
 {
     static const size_t b = [] {
         const char *e = getenv("LM_HIP_RESULT_POOL_MB");
-        return (size_t)(e ? atoll(e) : 256) << 20;
+        const long long mb = e ? atoll(e) : 256;
+        return (size_t)(mb < 0 ? 0 : mb > (1ll << 20) ? (1ll << 20) : mb) << 20;
     }();
     return b;
 }
@@ -202,6 +206,14 @@ void *result_alloc(size_t bytes)
         }
     }
     const size_t cap = (bytes + bytes / 4 + kHuge - 1) / kHuge * kHuge;  // some headroom: counts vary call to call
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        size_t pinned_total = 0;
+        for (const ResultBlock &b : g_pool)
+            pinned_total += b.cap;
+        if (pinned_total + cap > 4 * pool_budget())
+            return malloc(bytes);  // the cap on page-locked memory is reached: a plain block, freed by free()
+    }
     void *p = nullptr;
     if (posix_memalign(&p, kHuge, cap) != 0)
         return malloc(bytes);
@@ -388,6 +400,7 @@ int lm_hip_ctx_destroy(lm_hip_ctx *ctx)
     ctx->scratch.release();
     ctx->scratch2.release();
     ctx->chunk_scores.release();
+    ctx->scan_buf.release();
     ctx->u8_tables.release();
     if (ctx->pinned)
         (void)hipHostFree(ctx->pinned);
@@ -1026,6 +1039,27 @@ int lm_hip_scan_f32(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *
     }
     *hits = ho.hits;
     *n = keep;
+    return LM_HIP_OK;
+}
+
+// Scanner::max with the reference's own walk (scan.rs:200-249): see scanmax.hip.
+int lm_hip_scan_max_f32(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *seq, const uint8_t *dweights,
+                        size_t dweights_stride, int saturate, unsigned level, int have, size_t position, float score,
+                        size_t first_row, int *found, lm_hip_hit *best)
+{
+    if (!ctx || !pssm || !seq || !dweights || !found || !best)
+        return fail(LM_HIP_ERR_BAD_ARGS, "scan_max: null argument");
+    if (dweights_stride < pssm->k)
+        return fail(LM_HIP_ERR_BAD_ARGS, "scan_max: discrete weights stride %zu < alphabet size %zu", dweights_stride, pssm->k);
+    LM_TRY(check_score_args(pssm, seq->rows + seq->wrap, seq->stride, seq->cols, seq->wrap, 0, seq->rows));
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    unsigned long long pos = position;
+    float sc = score;
+    LM_TRY(launch_scan_max(ctx, pssm, seq, dweights, dweights_stride, saturate != 0, level, have != 0, pos, sc, first_row, found,
+                           &pos, &sc));
+    best->position = (size_t)pos;
+    best->score = sc;
     return LM_HIP_OK;
 }
 

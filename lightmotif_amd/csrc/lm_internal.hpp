@@ -93,6 +93,7 @@ struct lm_hip_ctx {
     std::mutex mu;
     lm::Scratch scratch;        // block partials, chunk counts, hit lists
     lm::Scratch scratch2;
+    lm::Scratch scan_buf;       // Scanner::max walk (scanmax.hip): one window of u8 + f32 scores and the walk's state
     lm::Scratch chunk_scores;   // fused reductions of sliced (M > 36) motifs: one chunk of f32 scores (score.hip)
     size_t chunk_rows = 1u << 22; // rows of that chunk (512 MB at C = 32; LM_HIP_CHUNK_ROWS)
     bool chunked_fused = true;  // A/B knob: 0 = such motifs go cell by cell (LM_HIP_CHUNKED_FUSED)
@@ -210,6 +211,10 @@ struct DiscreteArgs {
     bool saturate;            // true: avx2.rs:336 saturating adds; false: Generic's wrapping `+=`
 };
 int launch_score_u8(lm_hip_ctx *ctx, const DiscreteArgs &a);
+// Scanner::max as the reference walks it (scan.rs:200-249), scanmax.hip; synchronises
+int launch_scan_max(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *seq, const uint8_t *weights, size_t wstride,
+                    bool saturate, unsigned level, bool have, unsigned long long position, float score, size_t first_row,
+                    int *found, unsigned long long *best_position, float *best_score);
 int launch_argmax_u8(lm_hip_ctx *ctx, const uint8_t *d_scores, size_t rows, size_t stride, size_t cols,
                      ArgmaxRecord *out);
 int launch_threshold_u8(lm_hip_ctx *ctx, const uint8_t *d_scores, size_t rows, size_t stride, size_t cols,

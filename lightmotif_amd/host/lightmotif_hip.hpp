@@ -603,8 +603,24 @@ public:
         return hits;
     }
 
-    // Scanner::max (scan.rs:200-249): greater score wins, equal scores go to the greater position
-    static std::optional<Hit> scan_max(const std::vector<Hit> &hits)
+    // Scanner::new(pssm, seq).threshold(t).max() EXACTLY as the reference computes it (scan.rs:200-249): the u8
+    // DiscreteMatrix scores steer the walk (level = u8 score of the current best, first candidate taken below the
+    // threshold, no position + M <= L test; see lm_hip_scan_max_f32).  The walk runs on the device.  `saturate`:
+    // the u8 adds of the x86-64 `dispatch` pipeline (avx2.rs:336); false = Generic's wrapping adds.
+    std::optional<Hit> scan_max(const ScoringMatrix<A> &pssm, const StripedSequence<A> &seq, float threshold,
+                                bool saturate = true) const
+    {
+        const DiscreteMatrix<A> dm = pssm.to_discrete();
+        int found = 0;
+        lm_hip_hit best{0, 0.0f};
+        check(lm_hip_scan_max_f32(ctx_->ctx, pssm.device(ctx_->ctx), seq.handle(), dm.data.ptr(), dm.data.stride(),
+                                  saturate ? 1 : 0, dm.scale(threshold), 0, 0, 0.0f, 0, &found, &best));
+        return found ? std::optional<Hit>(Hit{best.position, best.score}) : std::nullopt;
+    }
+
+    // NOT the reference's max(): the best of an already collected hit list -- greater score wins, equal scores go
+    // to the greater position (the comparison of scan.rs:237 without the u8 steering)
+    static std::optional<Hit> scan_max_valid(const std::vector<Hit> &hits)
     {
         std::optional<Hit> best;
         for (const Hit &h : hits)

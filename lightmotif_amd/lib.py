@@ -1140,7 +1140,47 @@ class Scanner:
         level (the u8 score of the current best, an over-estimate) is skipped (scan.rs:227-243).
         ``saturate``: the u8 adds of the x86-64 ``dispatch`` pipeline (avx2.rs:336); ``False`` =
         Generic's wrapping adds.  :meth:`max_valid` is the variant without those corner cases."""
-        return self._max_strict(saturate)
+        return self._max_device(saturate)
+
+    def _pending_state(self):
+        """The reference scanner's state after the ``next()`` calls made so far (scan.rs:169-198): ``row`` = the
+        block after the one the last yielded hit came from, ``hits`` = the not yet yielded hits of that block --
+        derived from the complete hit list: (best pending hit or None, first row of the walk)."""
+        thr = np.float32(self.threshold)
+        rows, bs = self._seq.rows, self.block_size
+        best: Optional[Tuple[int, np.float32]] = None
+        first_block = 0
+        if self._order is not None and self._next > 0:
+            last = self._order[self._next - 1]
+            blk = (int(self._positions[last]) % rows) // bs
+            first_block = blk + 1
+            rest = self._order[self._next:]
+            rest = rest[(self._positions[rest] % rows) // bs == blk]
+            for i in rest[::-1]:                       # the vector's order = reverse of the yield order
+                sc = np.float32(self._scores[i])       # scan.rs:207-210; max_by keeps the LAST of equals
+                if sc >= thr and (best is None or not (sc < best[1])):
+                    best = (int(self._positions[i]), sc)
+        self._order = np.zeros(0, np.int64)            # consumed (scan.rs:200 takes `self`)
+        self._positions, self._scores, self._next = np.zeros(0, np.int64), np.zeros(0, np.float32), 0
+        return best, first_block * bs
+
+    def _max_device(self, saturate: bool) -> Optional[Hit]:
+        """scan.rs:200-249 through ``lm_hip_scan_max_f32``: the walk itself runs on the device (csrc/scanmax.hip)."""
+        pli, seq, pssm = self._seq._pli, self._seq, self._pssm
+        best, first_row = self._pending_state()
+        if seq.rows == 0 or len(seq) < len(pssm):
+            return None if best is None else Hit(best[0], float(best[1]))
+        dm = pssm.to_discrete()
+        level = dm.scale(float(best[1])) if best is not None else dm.scale(float(np.float32(self.threshold)))
+        w = np.ascontiguousarray(dm.data, dtype=np.uint8)
+        found, hit = C.c_int(0), _ffi.Hit()
+        st = pli._L.lm_hip_scan_max_f32(pli._h, pssm._device(pli), seq._h, w.ctypes.data, w.shape[1], int(bool(saturate)),
+                                        int(level), int(best is not None), 0 if best is None else best[0],
+                                        0.0 if best is None else float(best[1]), first_row, C.byref(found), C.byref(hit))
+        if st == _ffi.ERR_BAD_ARGS and "leaves the striped matrix" in _ffi.last_error():
+            raise IndexError("Scanner.max: " + _ffi.last_error())   # seq[pos + j] past the matrix: the reference panics
+        check(st)
+        return Hit(int(hit.position), float(hit.score)) if found.value else None
 
     def max_valid(self) -> Optional[Hit]:
         """NOT the reference's ``max()``: the best VALID hit not yet yielded -- ``score >= threshold``
@@ -1172,8 +1212,9 @@ class Scanner:
         self._next = self._order.size
         return self._best(self._positions[rest], self._scores[rest])
 
-    def _max_strict(self, saturate: bool) -> Optional[Hit]:
-        """``Scanner::max`` of the reference as written (scan.rs:200-249).
+    def _max_strict(self, saturate: bool = True) -> Optional[Hit]:
+        """``Scanner::max`` of the reference as written (scan.rs:200-249), walked on the HOST from the downloaded u8
+        and f32 score matrices: the cross-check of the device walk (``_max_device``) in the tests.
 
         State of the reference scanner after some ``next()`` calls: ``row`` = the block after
         the one the last yielded hit came from, ``hits`` = the not yet yielded hits of that
@@ -1181,20 +1222,8 @@ class Scanner:
         pli, seq, pssm = self._seq._pli, self._seq, self._pssm
         thr = np.float32(self.threshold)
         rows, cols, m, bs = seq.rows, seq.columns, len(pssm), self.block_size
-        best: Optional[Tuple[int, np.float32]] = None
-        first_block = 0
-        if self._order is not None and self._next > 0:
-            last = self._order[self._next - 1]
-            blk = (int(self._positions[last]) % rows) // bs
-            first_block = blk + 1
-            rest = self._order[self._next:]
-            rest = rest[(self._positions[rest] % rows) // bs == blk]
-            for i in rest[::-1]:                       # the vector's order = reverse of the yield order
-                sc = np.float32(self._scores[i])       # scan.rs:207-210; max_by keeps the LAST of equals
-                if sc >= thr and (best is None or not (sc < best[1])):
-                    best = (int(self._positions[i]), sc)
-        self._order = np.zeros(0, np.int64)            # consumed (scan.rs:200 takes `self`)
-        self._positions, self._scores, self._next = np.zeros(0, np.int64), np.zeros(0, np.float32), 0
+        best, first_row = self._pending_state()
+        first_block = first_row // bs
         if rows == 0 or len(seq) < m:
             return None if best is None else Hit(best[0], float(best[1]))
         dm = pssm.to_discrete()

@@ -204,9 +204,12 @@ static void test_scanner(const Pipeline<Dna> &pli)
     const auto row_blocks = Pipeline<Dna>::scan_order(hits, striped.rows(), 1);
     CHECK(row_blocks.size() == 3 && row_blocks[0].position == 32 && row_blocks[1].position == 18 &&
           row_blocks[2].position == 27);
-    const auto best = Pipeline<Dna>::scan_max(hits);  // scan.rs:317-333
+    const auto best = Pipeline<Dna>::scan_max_valid(hits);
     CHECK(best && best->position == 18 && std::fabs(best->score - (-5.50167f)) < 1e-5f);
-    CHECK(!Pipeline<Dna>::scan_max({}));
+    CHECK(!Pipeline<Dna>::scan_max_valid({}));
+    // Scanner::max as the reference walks it, on the device (scan.rs:317-333: best = (18, -5.50167) at t = -10)
+    const auto walked = pli.scan_max(pssm, striped, -10.0f);
+    CHECK(walked && walked->position == 18 && std::fabs(walked->score - (-5.50167f)) < 1e-5f);
 }
 
 // Many motifs over one resident sequence (lightmotif-cli main.rs:554-561 fans the motifs

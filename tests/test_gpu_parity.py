@@ -750,11 +750,14 @@ def test_scanner_max_strict_reference_mode(pli, kind):
                 want = (col * ref.rows + first_row + r, want[1])
         else:
             want = no.scanner_max_strict(scores, d, 32, t, scale, bs)
-        got = sc.max()
+        got = sc.max()                                  # the walk on the device (lm_hip_scan_max_f32)
         if want is None:
             assert got is None, (kind, bs)
         else:
             assert got is not None and got.position == want[0] and np.float32(got.score) == want[1], (kind, bs, got, want)
+        if kind != "partially_consumed":                # ... and the same walk on the host from the downloaded matrices
+            host = lm.Scanner(pssm, seq, threshold=t, block_size=bs)._max_strict()
+            assert (host is None) == (got is None) and (host is None or (host.position, host.score) == (got.position, got.score))
     # the opt-in variant: the best valid hit, whatever the u8 scores say
     best = no.scanner_max(scores, 32, length, m, t)
     got = lm.Scanner(pssm, seq, threshold=t).max_valid()
@@ -866,3 +869,33 @@ def test_small_score_into_tracks_its_argmax_in_the_same_launch(pli, m):
         got = pli.score_argmax(pssm, seq)
         assert got[0] == co.argmax(want, 32)
         assert bits(np.float32(got[1])) == bits(co.max_(want, 32))
+
+
+@pytest.mark.parametrize("kind", ["normal", "ties", "low_threshold", "protein"])
+def test_scanner_max_walk_on_the_device_at_size(pli, kind):
+    """`Scanner.max()` = scan.rs:200-249 walked on the device window by window (csrc/scanmax.hip), against the
+    oracle's line-by-line restatement on 3 Mbp: many windows, updates inside and across windows, exact ties at
+    the maximum (equal scores go to the greater POSITION, not the later cell), a threshold every cell passes."""
+    rng = np.random.default_rng(sum(map(ord, kind)))
+    protein = kind == "protein"
+    k = 21 if protein else 5
+    length, m = 3_000_017, 11
+    enc = rng.integers(0, k - 1, length, dtype=np.uint8)
+    p = np.zeros((m, co.stride(k, 4)), np.float32)
+    p[:, :k] = rng.integers(-2, 3, (m, k)) if kind == "ties" else rng.normal(0, 2, (m, k))
+    p[:, k - 1] = -np.inf
+    ref = co.stripe(enc, 32, k)
+    co.configure_wrap(ref, m - 1)
+    scores, _ = co.score_rows(ref, p)
+    w, factor, offsets, offset = no.to_discrete(p, k)
+    d = no.score_rows_u8_saturating(ref.data, 32, length, w, 0, ref.rows)
+    scale = lambda x: no.discrete_scale(x, factor, offset)   # noqa: E731
+    finite = scores[:, :32][np.isfinite(scores[:, :32])]
+    t = -1e30 if kind == "low_threshold" else float(np.quantile(finite, 0.9999))
+    pssm = lm.ScoringMatrix(p, protein=protein)
+    seq = pli.stripe(lm.EncodedSequence(enc, protein=protein), 32)
+    seq.configure(pssm)
+    want = no.scanner_max_strict(scores, d, 32, t, scale, 256)
+    got = lm.Scanner(pssm, seq, threshold=t).max()
+    assert pli.last_kernel == "scanmax_find"
+    assert got is not None and (got.position, np.float32(got.score)) == (want[0], want[1]), (got, want)

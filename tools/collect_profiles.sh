@@ -2,7 +2,7 @@
 # Collects the measurements committed under profiles/ (run on a GPU box via gpurun):
 #   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r02'
 # Everything lands in gpurun_out/<tag>/; copy what should be judged into profiles/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -12,7 +12,9 @@ timeout 300 python bench.py --config c3 > "$OUT/bench_c3.json" 2> "$OUT/bench_c3
 timeout 400 python tools/bench_configs.py > "$OUT/bench_configs.json" 2> "$OUT/bench_configs.err"
 timeout 200 python tools/api_overhead.py > "$OUT/api_overhead.json" 2> "$OUT/api_overhead.err"
 timeout 400 python tools/msweep.py > "$OUT/msweep.json" 2> "$OUT/msweep.err"
-timeout 200 python tools/msweep.py 1000000000 40,48,64,100 > "$OUT/msweep_long.json" 2> "$OUT/msweep_long.err"
+timeout 300 python tools/msweep.py 1000000000 40,48,64,100,150 > "$OUT/msweep_long.json" 2> "$OUT/msweep_long.err"
+timeout 100 python tools/c1_latency.py > "$OUT/c1_latency.json" 2> "$OUT/c1_latency.err"
+timeout 200 python tools/ingest_bench.py > "$OUT/ingest.json" 2> "$OUT/ingest.err"
 timeout 100 tools/kbench/mix_bench > "$OUT/mix_bench.txt" 2>&1
 timeout 200 python tools/track_ab.py 20 > "$OUT/track_ab.txt" 2>/dev/null
 timeout 200 python tools/track_ab.py 12 >> "$OUT/track_ab.txt" 2>/dev/null
@@ -43,5 +45,6 @@ PY
 rm -rf "$OUT/prof"
 GRAFT_REPO_ROOT=$ROOT bash "$ROOT/tools/collect_pmc.sh" > "$OUT/pmc.log" 2>&1
 cp "$ROOT/gpurun_out/pmc/summary.json" "$OUT/pmc_summary.json" 2>/dev/null
+cp "$ROOT/gpurun_out/pmc/pmc_traffic.json" "$OUT/pmc_traffic.json" 2>/dev/null
 cd "$ROOT"
 tail -c 700 "$OUT/bench_default.json"; echo; head -4 "$OUT/bench_kernel_stats.csv" | cut -c1-200; cat "$OUT/pmc_summary.json"
