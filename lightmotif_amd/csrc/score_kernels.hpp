@@ -315,8 +315,9 @@ __device__ __forceinline__ void lds_fetch_column(float (&w)[4 * ((M + 3) / 4)],
 
 // Edge groups (FIRST / LAST) need only part of the column: floats [4*C0, 4*C1).  Left to itself the
 // compiler narrows those reads to the exact floats (ds_read_b32 / b64: 85 LDS instructions in the
-// LAST group of M = 20 instead of 55), and a narrow read occupies the LDS pipeline as long as a
-// 16-byte one (SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS = 4.0 cycles across the kernel).  `volatile`
+// LAST group of M = 20 instead of 55), and the pieces cost the LDS as much as the read they replace while fetching
+// less (a b64 + a b32 = 2 + 2 LDS cycles, a b128 = 4: MI355X_MICROARCH.md's LDS table, confirmed by round 3's
+// counters on the WIDE kernels).  `volatile`
 // keeps them whole: 9 % fewer LDS cycles.  Interleaved A/B per motif length on one box
 // (profiles/r02_edge_ab.txt, 1 Gbp, best stream length each): M = 12 0.872 vs 0.884 ms, M = 16
 // 0.915 vs 0.927, M = 24 1.001 vs 1.004, M = 28 1.077 vs 1.089, M = 33 1.223 vs 1.253, M = 36
