@@ -87,6 +87,7 @@ def synth_shard(rows: int, row0: int, total_rows: int, total_length: int, halo: 
 
 
 _JSON_OUT = None
+_HARD_EXIT = False   # a helper thread is stuck in a collective that will never complete: leave with os._exit
 
 
 def claim_stdout() -> None:
@@ -636,9 +637,12 @@ def main() -> None:
     comm, comm_note = None, None
     if use_cabi:
         try:
-            comm = D.CabiComm.from_torch(pli, device=coll_dev)
+            comm = D.CabiComm.from_torch(pli, device=coll_dev, deadline_s=args.comm_timeout_s)
         except lm.LightmotifHipError as e:      # e.g. no librccl next to a non-torch host: say so, use torch's
             comm_note = f"C-ABI communicator unavailable ({e}); merge carried by torch.distributed"
+        except TimeoutError as e:               # a rank never arrived in ncclCommInitRank: a helper thread is stuck there
+            comm_note = f"C-ABI communicator not created ({e}); merge carried by torch.distributed"
+            globals()["_HARD_EXIT"] = True
         if world > 1:
             flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=coll_dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # all ranks or none
@@ -883,3 +887,7 @@ def main() -> None:
 
 if __name__ == "__main__":
     main()
+    if _HARD_EXIT:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)

@@ -325,7 +325,8 @@ int lm_hip_comm_create(lm_hip_ctx *ctx, const uint8_t *id, int nranks, int rank,
         return fail(LM_HIP_ERR_BAD_ARGS, "comm_create: bad argument");
     *out = nullptr;
     LM_TRY(need_rccl());
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    // (the context is NOT locked: ncclCommInitRank blocks until every rank has arrived, and a host that gives up
+    //  on it must still be able to use the context from another thread)
     DeviceGuard guard(ctx->device);
     lm_hip_comm *c = new (std::nothrow) lm_hip_comm();
     if (!c)

@@ -328,8 +328,14 @@ class CabiComm:
         return bytes(buf)
 
     @classmethod
-    def from_torch(cls, pli, device: torch.device | str = "cpu", group=None) -> "CabiComm":
-        """Rank 0 draws the unique id, ``torch.distributed`` broadcasts its 128 bytes."""
+    def from_torch(cls, pli, device: torch.device | str = "cpu", group=None,
+                   deadline_s: Optional[float] = None) -> "CabiComm":
+        """Rank 0 draws the unique id, ``torch.distributed`` broadcasts its 128 bytes, every rank joins.
+
+        ``deadline_s``: ``ncclCommInitRank`` blocks until every rank has arrived and has no timeout of its own; with
+        a deadline it runs on a helper thread and a rank that waits longer raises ``TimeoutError`` (the thread
+        is left behind -- the caller is expected to fall back to another transport and to leave the process with
+        ``os._exit`` at the end)."""
         rank, world = _world(group)
         dev = _coll_device(device, group) if world > 1 else torch.device("cpu")
         t = torch.zeros(128, dtype=torch.uint8)
@@ -338,7 +344,25 @@ class CabiComm:
         if world > 1:
             t = t.to(dev)
             dist.broadcast(t, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
-        return cls(pli, bytes(t.cpu().numpy().tobytes()), world, rank)
+        uid = bytes(t.cpu().numpy().tobytes())
+        if deadline_s is None:
+            return cls(pli, uid, world, rank)
+        import threading
+        box: dict = {}
+
+        def join():
+            try:
+                box["comm"] = cls(pli, uid, world, rank)
+            except BaseException as e:     # noqa: BLE001 -- handed to the caller's thread
+                box["error"] = e
+        th = threading.Thread(target=join, daemon=True, name="lm-hip-comm-init")
+        th.start()
+        th.join(deadline_s)
+        if th.is_alive():
+            raise TimeoutError(f"ncclCommInitRank did not return within {deadline_s:.0f} s on rank {rank}")
+        if "error" in box:
+            raise box["error"]
+        return box["comm"]
 
     def info(self) -> Tuple[int, int]:
         """``(rank, nranks)`` as the library's communicator holds them (``lm_hip_comm_info``): what RCCL was

@@ -679,6 +679,42 @@ public:
         return StripedSequence<A>(ctx_, h);
     }
 
+    // A DNA sequence held 4 bases per byte (base i in bits 2 * (i % 4).. of byte i / 4, A0 C1 T2 G3) with its N runs
+    // {start, size} like a .2bit file's N blocks: a quarter of the bytes over PCIe, unpacked straight into the
+    // striped matrix (lm_hip_seq_from_2bit).  `pack_2bit` builds both from an EncodedSequence.
+    struct Packed2bit {
+        std::vector<uint8_t> packed;
+        std::vector<uint64_t> n_runs;  // pairs
+        size_t length = 0;
+    };
+    static Packed2bit pack_2bit(const EncodedSequence<A> &seq)
+    {
+        Packed2bit p;
+        p.length = seq.len();
+        p.packed.assign((p.length + 3) / 4, 0);
+        for (size_t i = 0; i < p.length; ++i) {
+            const uint8_t s = seq.data[i];
+            if (s > 3) {
+                if (!p.n_runs.empty() && p.n_runs[p.n_runs.size() - 2] + p.n_runs.back() == i)
+                    ++p.n_runs.back();
+                else {
+                    p.n_runs.push_back(i);
+                    p.n_runs.push_back(1);
+                }
+            } else {
+                p.packed[i / 4] |= (uint8_t)(s << (2 * (i % 4)));
+            }
+        }
+        return p;
+    }
+    StripedSequence<A> stripe_2bit(const Packed2bit &p, size_t columns = 32) const
+    {
+        lm_hip_seq *h = nullptr;
+        check(lm_hip_seq_from_2bit(ctx_->ctx, p.packed.data(), nullptr, p.n_runs.data(), p.n_runs.size() / 2, p.length,
+                                   columns, &h));
+        return StripedSequence<A>(ctx_, h);
+    }
+
     // Many motifs over one resident sequence (the CLI's fan-out, lightmotif-cli main.rs:554-561):
     // per motif the best cell and its score, or nullopt when the sequence is shorter than the motif.
     std::vector<std::optional<Best>> scan_argmax_batch(const std::vector<const ScoringMatrix<A> *> &pssms,

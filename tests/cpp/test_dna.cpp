@@ -398,6 +398,41 @@ static void test_sharded(const Pipeline<Dna> &pli)
     CHECK(b1.found && scores.offset(b1.cell) == 18 && b1.score == best.score);
 }
 
+// The residency flow a Rust caller takes to profit from the GPU: the genome goes up ONCE --
+// as text, as symbol bytes or as 2-bit -- and stays; matrices, scores and reductions work on the resident handles.
+static void test_resident_flow(const Pipeline<Dna> &pli)
+{
+    std::string genome;
+    for (int i = 0; i < 4000; ++i)
+        genome += SEQUENCE;
+    genome.replace(1000, 37, std::string(37, 'N'));                     // an N run
+    genome[200001] = 'N';
+    const auto enc = EncodedSequence<Dna>::encode(genome);
+    auto from_text = pli.stripe_text(genome);                             // lm_hip_seq_from_ascii: tiled, encode fused
+    auto from_bytes = pli.stripe(enc);                                    // lm_hip_seq_from_encoded: tiled, validated
+    auto from_2bit = pli.stripe_2bit(Pipeline<Dna>::pack_2bit(enc));      // lm_hip_seq_from_2bit
+    const auto a = from_text.matrix(), b = from_bytes.matrix(), c = from_2bit.matrix();
+    CHECK(a.rows() == b.rows() && a.rows() == c.rows());
+    bool same = true;
+    for (size_t r = 0; r < a.rows() && same; ++r)
+        for (size_t j = 0; j < 32; ++j)
+            same = same && a(r, j) == b(r, j) && a(r, j) == c(r, j);
+    CHECK(same);
+    const auto pssm = golden_pssm();
+    from_2bit.configure(pssm);
+    from_text.configure(pssm);
+    StripedScores s2 = pli.empty_scores(32), st = pli.empty_scores(32);
+    for (int rep = 0; rep < 3; ++rep) {                                   // dna.rs:104-107: one StripedScores re-used
+        pli.score_into(pssm, from_2bit, s2);
+        pli.score_into(pssm, from_text, st);
+        const auto b2 = s2.argmax(), bt = st.argmax();
+        CHECK(b2 && bt && *b2 == *bt);
+        const auto m2 = s2.max(), mt = st.max();
+        CHECK(m2 && mt && *m2 == *mt && *m2 == s2.at(*b2) && *m2 >= -5.50167f - 1e-5f);   // at least the golden best site
+    }
+    CHECK(s2.threshold(-5.6f) == st.threshold(-5.6f) && !s2.threshold(-5.6f).empty());
+}
+
 int main()
 {
     Pipeline<Dna> pli = Pipeline<Dna>::hip();
@@ -422,6 +457,7 @@ int main()
     test_encode(pli);
     test_edge_cases(pli);
     test_sharded(pli);
+    test_resident_flow(pli);
     if (failures) {
         std::fprintf(stderr, "%d check(s) failed\n", failures);
         return 1;
