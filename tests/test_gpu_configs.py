@@ -612,3 +612,35 @@ def test_symbol_validation_covers_sequences_of_2_32_symbols_and_more(gpu_pli):
         with pytest.raises(lm.InvalidSymbol):
             gpu_pli.stripe(lm.EncodedSequence(enc), COLS)
         enc[bad] = 0
+
+
+@pytest.mark.parametrize("m", [37, 44, 52, 64, 70])
+def test_long_protein_motifs_take_the_wide_long_kernels(pli, m):
+    """Protein (K = 21) motifs of 37..64 rows: the long family's WIDE instantiations (8-byte LDS reads over rows of
+    2 * odd dwords), store and fused; beyond 64 the sliced path.  Bit-exact against the oracle incl. X runs."""
+    rng = np.random.default_rng(2100 + m)
+    length = 400_000 + 7 * m
+    enc = rng.integers(0, 21, length, dtype=np.uint8)
+    enc[rng.random(length) < 0.98] %= 20
+    p = np.zeros((m, 24), np.float32)
+    p[:, :21] = rng.normal(0, 2, (m, 21))
+    p[:, 20] = -np.inf
+    ref = co.stripe(enc, COLS, 21)
+    co.configure_wrap(ref, m - 1)
+    seq = pli.stripe(lm.EncodedSequence(enc, protein=True), COLS)
+    seq.configure_wrap(m - 1)
+    pssm = lm.ScoringMatrix(p, protein=True)
+    scores = lm.StripedScores.empty(pli, COLS)
+    for a, b in ((0, ref.rows), (17, ref.rows - 9)):
+        want, _ = co.score_rows(ref, p, a, b)
+        pli.score_rows_into(pssm, seq, range(a, b), scores)
+        assert pli.last_kernel == long_kernel(m, 0), pli.last_kernel
+        assert np.array_equal(bits(scores.matrix()[:, :COLS]), bits(want[:, :COLS])), (m, a, b)
+        assert pli.argmax(scores) == co.argmax(want, COLS)
+        got = pli.score_argmax(pssm, seq, range(a, b))
+        assert got[0] == co.argmax(want, COLS) and pli.last_kernel == long_kernel(m, 1)
+        finite = np.sort(want[:, :COLS][np.isfinite(want[:, :COLS])])
+        t = float(finite[-300])
+        frc, fval = pli.score_threshold(pssm, seq, t, range(a, b))
+        assert frc == [tuple(map(int, rc)) for rc in co.threshold(want, COLS, t)]
+        assert np.array_equal(bits(fval), bits([want[r, c] for r, c in frc]))
