@@ -318,6 +318,35 @@ size_t lm_hip_stride(size_t cols, size_t elem_size)
 
 // ---- context ----------------------------------------------------------------------------
 
+// Development / test switches, read once per context: each selects an alternative path that gives the SAME results
+// (the GPU suite runs several of them to cover those paths; tools/README.md lists them).  None is part of the ABI.
+static void read_dev_switches(lm_hip_ctx *ctx)
+{
+    if (const char *e = getenv("LM_HIP_TRACK_ARGMAX"))  // A/B switch: 0 = plain store in score_into
+        ctx->track_argmax = atoi(e) != 0;
+    if (const char *e = getenv("LM_HIP_HOST_FOLD"))  // A/B switch: 0 = small score_into folds its records on the device
+        ctx->host_fold = atoi(e) != 0;
+    if (const char *e = getenv("LM_HIP_SPECULATE_ORDER"))  // A/B switch: 0 = read the counts first
+        ctx->speculate_order = atoi(e) != 0;
+    if (const char *e = getenv("LM_HIP_SUFFIX_ARGMAX"))  // A/B switch: 0 = always scan the whole range
+        ctx->suffix_argmax = atoi(e) != 0;
+    if (const char *e = getenv("LM_HIP_MULTI_MOTIF"))  // A/B switch: 0 = one motif per workgroup pass
+        ctx->multi_motif = atoi(e) != 0;
+    if (const char *e = getenv("LM_HIP_QUAD_LOADS"))  // A/B switch of the store kernel's symbol loads
+        ctx->quad_loads = atoi(e) != 0;
+    if (const char *e = getenv("LM_HIP_SKIP_UNREACHABLE"))  // A/B switch: 0 = scan even when no cell can reach the threshold
+        ctx->skip_unreachable = atoi(e) != 0;
+    if (const char *e = getenv("LM_HIP_PAIR_PREFILTER"))  // A/B switch: 0 = one symbol per lookup
+        ctx->pair_prefilter = atoi(e) != 0;
+    if (const char *e = getenv("LM_HIP_PAIR_PREFILTER_PROTEIN"))  // A/B switch: 1 = 441-row pair scan for K = 21
+        ctx->pair_prefilter_protein = atoi(e) != 0;
+    if (const char *e = getenv("LM_HIP_CHUNKED_FUSED"))  // A/B switch: 0 = fused scans of M > 36 go cell by cell
+        ctx->chunked_fused = atoi(e) != 0;
+    if (const char *e = getenv("LM_HIP_CHUNK_ROWS"))  // rows per chunk of those scans
+        if (atoll(e) >= 64)
+            ctx->chunk_rows = (size_t)atoll(e);
+}
+
 static int ctx_create(int device, void *stream, bool borrow, lm_hip_ctx **out)
 {
     if (!out)
@@ -341,27 +370,7 @@ static int ctx_create(int device, void *stream, bool borrow, lm_hip_ctx **out)
         return fail(LM_HIP_ERR_OOM, "out of host memory");
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
-    if (const char *e = getenv("LM_HIP_TRACK_ARGMAX"))  // A/B switch: 0 = plain store in score_into
-        ctx->track_argmax = atoi(e) != 0;
-    if (const char *e = getenv("LM_HIP_SPECULATE_ORDER"))  // A/B switch: 0 = read the counts first
-        ctx->speculate_order = atoi(e) != 0;
-    if (const char *e = getenv("LM_HIP_SUFFIX_ARGMAX"))  // A/B switch: 0 = always scan the whole range
-        ctx->suffix_argmax = atoi(e) != 0;
-    if (const char *e = getenv("LM_HIP_MULTI_MOTIF"))  // A/B switch: 0 = one motif per workgroup pass
-        ctx->multi_motif = atoi(e) != 0;
-    if (const char *e = getenv("LM_HIP_QUAD_LOADS"))  // A/B switch of the store kernel's symbol loads
-        ctx->quad_loads = atoi(e) != 0;
-    if (const char *e = getenv("LM_HIP_SKIP_UNREACHABLE"))  // A/B switch: 0 = scan even when no cell can reach the threshold
-        ctx->skip_unreachable = atoi(e) != 0;
-    if (const char *e = getenv("LM_HIP_PAIR_PREFILTER"))  // A/B switch: 0 = one symbol per lookup
-        ctx->pair_prefilter = atoi(e) != 0;
-    if (const char *e = getenv("LM_HIP_PAIR_PREFILTER_PROTEIN"))  // A/B switch: 1 = 441-row pair scan for K = 21
-        ctx->pair_prefilter_protein = atoi(e) != 0;
-    if (const char *e = getenv("LM_HIP_CHUNKED_FUSED"))  // A/B switch: 0 = fused scans of M > 36 go cell by cell
-        ctx->chunked_fused = atoi(e) != 0;
-    if (const char *e = getenv("LM_HIP_CHUNK_ROWS"))  // rows per chunk of those scans
-        if (atoll(e) >= 64)
-            ctx->chunk_rows = (size_t)atoll(e);
+    read_dev_switches(ctx);
     if (borrow) {
         ctx->stream = static_cast<hipStream_t>(stream);
         ctx->owns_stream = false;
@@ -1558,6 +1567,8 @@ int lm_hip_scores_destroy(lm_hip_scores *s)
         (void)hipFree(s->d_best);
     if (s->h_best)
         (void)hipHostFree(s->h_best);
+    if (s->h_records)
+        (void)hipHostFree(s->h_records);
     delete s;
     return LM_HIP_OK;
 }
@@ -1607,6 +1618,8 @@ int lm_hip_score_rows_into(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hi
     // (small inputs are launch-latency bound: the extra reduction launch costs more than the
     //  second pass it saves)
     scores->best_on_host = false;
+    scores->records_on_host = false;
+    scores->folded = false;
     if (!scores->d_best || !ctx->track_argmax)
         return launch_score_store(ctx, a);
     bool tracked = false;
@@ -1615,8 +1628,8 @@ int lm_hip_score_rows_into(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hi
         // workgroup records (MODE_STORE_TRACK), and leaves the record in pinned memory as well
         const unsigned gen = ++scores->best_generation ? scores->best_generation : ++scores->best_generation;  // never 0
         LM_TRY(launch_score_store_track(ctx, a, scores->d_best, scores->h_best, gen, &tracked,
-                                        scores->first_cell_rule ? 1 : 0));
-        scores->best_valid = tracked;
+                                        scores->first_cell_rule ? 1 : 0, ctx->host_fold ? scores : nullptr));
+        scores->best_valid = tracked;   // false when the records went to the host (scores->records_on_host)
         scores->best_on_host = tracked && scores->h_best != nullptr;
         return LM_HIP_OK;
     }
@@ -1633,11 +1646,27 @@ int lm_hip_score_into(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq
     return lm_hip_score_rows_into(ctx, pssm, seq, 0, seq->rows, scores);  // pli/mod.rs:115-116
 }
 
+static int host_fold(lm_hip_ctx *ctx, lm_hip_scores *s)
+{
+    if (s->folded)
+        return LM_HIP_OK;
+    LM_TRY(fold_host_records(ctx, s->h_records, s->n_records, s->best_generation, s->first_cell_rule, &s->folded_record));
+    s->folded = true;
+    return LM_HIP_OK;
+}
+
 int lm_hip_argmax(lm_hip_ctx *ctx, const lm_hip_scores *s, int *found, lm_hip_coords *best,
                   float *value)
 {
     if (!s)
         return fail(LM_HIP_ERR_BAD_ARGS, "argmax: null scores");
+    if (ctx && found && s->records_on_host && s->rows) {  // small matrix: the store kernel's records, folded here
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        DeviceGuard guard(ctx->device);
+        LM_TRY(host_fold(ctx, const_cast<lm_hip_scores *>(s)));
+        record_to_coords(s->folded_record, s->cols, found, best, value);
+        return LM_HIP_OK;
+    }
     if (ctx && found && s->best_valid && s->rows) {  // tracked by the kernel that wrote the scores
         std::lock_guard<std::mutex> lock(ctx->mu);
         DeviceGuard guard(ctx->device);
@@ -1691,8 +1720,11 @@ int lm_hip_scores_set_first_cell_rule(lm_hip_scores *s, int enabled)
 {
     if (!s)
         return fail(LM_HIP_ERR_BAD_ARGS, "scores_set_first_cell_rule: null scores");
-    if (s->first_cell_rule != (enabled != 0))
-        s->best_valid = false;
+    if (s->first_cell_rule != (enabled != 0)) {
+        s->best_valid = false;  // the device record was reduced under the other rule
+        s->best_on_host = false;
+        s->folded = false;      // (host-side records are folded again, under the new rule)
+    }
     s->first_cell_rule = enabled != 0;
     return LM_HIP_OK;
 }

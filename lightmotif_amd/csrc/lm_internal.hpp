@@ -107,6 +107,7 @@ struct lm_hip_ctx {
     bool pair_prefilter_protein = false;  // the 441-row protein pair scan: correct, measured 4 % slower
     bool quad_loads = true;      // store kernel: quad-gathered dword symbol loads (M % 4 == 0; +1 %)
     bool track_argmax = true;    // score_into on handles also tracks the best cell (cached argmax)
+    bool host_fold = true;       // ... small matrices: per-wavefront records folded by the host (LM_HIP_HOST_FOLD=0: on the device)
     bool speculate_order = true; // fused threshold: order the hit list before the host knows its length
     bool suffix_argmax = true;   // fused argmax of short motifs: try the last rows first (score.hip)
     bool multi_motif = true;     // many-motif threshold batches: several motifs of one length per pass
@@ -177,6 +178,13 @@ struct lm_hip_scores {
     lm::ArgmaxRecord *h_best = nullptr;   // 64 pinned bytes: the record, then the generation word of the launch that wrote it
     bool best_on_host = false;
     unsigned best_generation = 0;         // of the last tracked launch into this handle
+    // small inputs: the store kernel's per-wavefront records (16 bytes each, + the first-cell slot) in pinned memory,
+    // folded by the host in lm_hip_argmax (api.hip: host_fold); `folded` caches the fold of the current generation
+    void *h_records = nullptr;
+    size_t h_records_cap = 0;             // records the block has room for
+    unsigned n_records = 0;               // wavefront records of the last launch (the first-cell slot follows them)
+    bool records_on_host = false, folded = false;
+    lm::ArgmaxRecord folded_record{};
     // 0: this StripedScores is a row shard that does NOT hold the matrix's first cell, so the
     // "scores[0][0] is NaN -> (0,0)" rule of Maximum::argmax is skipped (lm_hip_scores_set_first_cell_rule)
     bool first_cell_rule = true;
@@ -211,6 +219,11 @@ struct DiscreteArgs {
     bool saturate;            // true: avx2.rs:336 saturating adds; false: Generic's wrapping `+=`
 };
 int launch_score_u8(lm_hip_ctx *ctx, const DiscreteArgs &a);
+// Folds the per-wavefront records a small tracking kernel left in pinned memory (FusedOut::host_records; n records +
+// the first-cell slot, both halves of each carrying `generation`) with the Generic argmax rule.  Polls for their
+// arrival; synchronises ctx->stream if they take too long.
+int fold_host_records(lm_hip_ctx *ctx, const void *records, unsigned n, unsigned generation, bool first_cell_rule,
+                      ArgmaxRecord *out);
 // Scanner::max as the reference walks it (scan.rs:200-249), scanmax.hip; synchronises
 int launch_scan_max(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *seq, const uint8_t *weights, size_t wstride,
                     bool saturate, unsigned level, bool have, unsigned long long position, float score, size_t first_row,
@@ -226,7 +239,7 @@ int launch_score_store_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord 
 // small inputs: store + (value, cell) tracking + the fold of the workgroup records in ONE launch
 // (MODE_STORE_TRACK); the record also lands in *h_result (pinned, optional)
 int launch_score_store_track(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *d_result, ArgmaxRecord *h_result,
-                             unsigned generation, bool *tracked, int first_cell_rule = 1);
+                             unsigned generation, bool *tracked, int first_cell_rule = 1, lm_hip_scores *host_fold = nullptr);
 int finalize_argmax_materialised(lm_hip_ctx *ctx, const ArgmaxRecord *d_blocks, unsigned nblocks,
                                  const float *d_scores, int first_cell_rule, ArgmaxRecord *d_out);
 // Fused score+argmax: leaves one ArgmaxRecord at ctx->scratch (device) -> out.

@@ -685,6 +685,55 @@ int launch_score_store_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord 
     return LM_HIP_OK;
 }
 
+// Folds the per-wavefront records a small tracking kernel left in pinned memory (score_kernels.hpp:
+// FusedOut::host_records) with the Generic rule -- greater value, ties to the later cell, NaN never, scores[0][0]
+// NaN -> (0, 0) (pli/mod.rs:135-155) -- as soon as they have all arrived: each 8-byte half of a record carries the
+// launch's generation, so a record is complete when both halves show it.  Arrival is polled (PCIe posted writes, a
+// microsecond behind the wavefronts); a bounded spin, then the stream is synchronised and the records re-read.
+int fold_host_records(lm_hip_ctx *ctx, const void *records, unsigned n, unsigned gen, bool first_cell_rule,
+                      ArgmaxRecord *out)
+{
+    const volatile unsigned long long *rec = static_cast<const volatile unsigned long long *>(records);
+    float v = -INFINITY;
+    long long cell = -1;
+    bool synced = false;
+    for (unsigned i = 0; i <= n; ++i) {  // record n = the first-cell slot
+        unsigned long long lo = 0, hi = 0;
+        for (unsigned spin = 0;; ++spin) {
+            lo = __atomic_load_n(&rec[2 * i], __ATOMIC_ACQUIRE);
+            hi = __atomic_load_n(&rec[2 * i + 1], __ATOMIC_ACQUIRE);
+            if ((unsigned)lo == gen && (unsigned)hi == gen)
+                break;
+            if (spin >= (1u << 20)) {
+                if (synced)
+                    return fail(LM_HIP_ERR_HIP, "argmax: the kernel's record %u of %u never arrived", i, n);
+                LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+                synced = true;
+                spin = 0;
+            }
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+            __builtin_ia32_pause();
+#endif
+        }
+        const unsigned vbits = (unsigned)(lo >> 32), c = (unsigned)(hi >> 32);
+        float x;
+        memcpy(&x, &vbits, 4);
+        if (i == n) {
+            if (first_cell_rule && x != x) {  // scores[0][0] is NaN: nothing ever compares >= it
+                v = x;
+                cell = 0;
+            }
+        } else if (c != 0xffffffffu && (cell < 0 || x > v || (x == v && (long long)c > cell))) {
+            v = x;
+            cell = (long long)c;
+        }
+    }
+    out->value = v;
+    out->index = cell;
+    out->found = cell >= 0;
+    return LM_HIP_OK;
+}
+
 static int ensure_ticket(lm_hip_ctx *ctx)
 {
     if (ctx->d_ticket)
@@ -697,8 +746,11 @@ static int ensure_ticket(lm_hip_ctx *ctx)
 // Small inputs (the reference's own bench is 464 165 bp, lightmotif-bench dna.rs:81-109): `score_into` + `argmax`
 // are launch-latency bound, so the store kernel tracks (value, cell) per lane and its last workgroup folds the
 // workgroup records -- one launch, no copy command (the record is also written to *h_result, pinned).
+// `host_fold` (the scores handle the rows go into): when its pinned record block can be had, the kernel folds
+// nothing -- every wavefront writes one record there and lm_hip_argmax folds them on the host (*tracked stays false:
+// there is no device record; host_fold->records_on_host says where the result is).
 int launch_score_store_track(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *d_result, ArgmaxRecord *h_result,
-                             unsigned generation, bool *tracked, int first_cell_rule)
+                             unsigned generation, bool *tracked, int first_cell_rule, lm_hip_scores *host_fold)
 {
     *tracked = false;
     const bool longm = a.pssm->m > (size_t)kMaxFastM;
@@ -714,10 +766,30 @@ int launch_score_store_track(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *
     ScoreC32Launcher fn = p.ok ? score_c32_lookup_store_track((int)mk, lds_wide((int)a.pssm->k)) : nullptr;
     if (!fn || !table)
         return launch_score_store(ctx, a);
-    LM_TRY(ensure_ticket(ctx));
-    LM_TRY(ctx->scratch.reserve(sizeof(ArgmaxRecord) * (size_t)p.grid.x));
+    const size_t nrec = (size_t)p.grid.x * (kBlock / 64);
+    if (host_fold && nrec + 1 > host_fold->h_records_cap) {  // (re)allocate the pinned record block
+        if (host_fold->h_records)
+            (void)hipHostFree(host_fold->h_records);
+        host_fold->h_records = nullptr;
+        host_fold->h_records_cap = 0;
+        const size_t cap = std::max<size_t>(2 * (nrec + 1), 1024);
+        void *blk = nullptr;
+        if (hipHostMalloc(&blk, cap * 16, hipHostMallocDefault) == hipSuccess) {
+            memset(blk, 0, cap * 16);
+            host_fold->h_records = blk;
+            host_fold->h_records_cap = cap;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    const bool on_host = host_fold && host_fold->h_records;
+    if (!on_host) {
+        LM_TRY(ensure_ticket(ctx));
+        LM_TRY(ctx->scratch.reserve(sizeof(ArgmaxRecord) * (size_t)p.grid.x));
+    }
     FusedOut fo{};
-    fo.block_best = static_cast<ArgmaxRecord *>(ctx->scratch.ptr);
+    fo.block_best = on_host ? nullptr : static_cast<ArgmaxRecord *>(ctx->scratch.ptr);
+    fo.host_records = on_host ? static_cast<uint4 *>(host_fold->h_records) : nullptr;
     fo.lead_rows = pad ? lead : 0u;
     fo.ticket = ctx->d_ticket;
     fo.final_out = d_result;
@@ -727,7 +799,13 @@ int launch_score_store_track(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *
     ctx->last_kernel = score_c32_name((int)mk, MODE_STORE);
     LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, a.d_seq, table, (int)a.pssm->k, a.row_begin, a.row_end, p.T, p.nstreams,
                   a.d_out, fo));
-    *tracked = true;
+    if (on_host) {
+        host_fold->n_records = (unsigned)nrec;
+        host_fold->records_on_host = true;
+        host_fold->folded = false;
+    } else {
+        *tracked = true;
+    }
     return LM_HIP_OK;
 }
 
@@ -1072,6 +1150,8 @@ static int launch_score_argmax_exact(lm_hip_ctx *ctx, const ScoreArgs *jobs, siz
     // one job through the exact kernel: its last workgroup folds the records and writes the result straight
     // into the pinned block -- one launch instead of two (a small scan is launch-latency bound)
     const bool fold_in_kernel = n == 1 && groups.size() == 1 && groups[0].kind == KIND_EXACT && zero_copy;
+    uint4 *host_records = nullptr;  // fold_in_kernel, small job: the wavefronts' records in the pinned block
+    unsigned host_nrec = 0;
     if (fold_in_kernel)
         LM_TRY(ensure_ticket(ctx));
     size_t launch = 0, bp_pos = 0;
@@ -1087,6 +1167,18 @@ static int launch_score_argmax_exact(lm_hip_ctx *ctx, const ScoreArgs *jobs, siz
             fo.generation = ++ctx->fold_generation ? ctx->fold_generation : ++ctx->fold_generation;
             *reinterpret_cast<volatile unsigned *>(results + 1) = 0u;  // (the block is shared staging: no stale match)
             fo.first_cell_rule = first_cell_rule;
+            // few wavefronts and 32-bit cell indices: no fold on the device, the wavefronts' records go straight
+            // into the pinned block (from byte 4096 on) and are folded below
+            const size_t nrec = (size_t)g.plan.grid.x * (kBlock / 64);
+            const unsigned long long ncells = (unsigned long long)(a.row_end - a.row_begin) * a.cols;
+            if (ctx->host_fold && ncells < (1ull << 32) && 4096 + (nrec + 1) * 16 <= kPinnedBytes) {
+                host_records = reinterpret_cast<uint4 *>(static_cast<char *>(ctx->pinned) + 4096);
+                host_nrec = (unsigned)nrec;
+                // the block is shared staging: stale bytes must not look like this launch's generation
+                for (size_t r = 0; r <= nrec; ++r)
+                    reinterpret_cast<volatile unsigned long long *>(host_records)[2 * r] = 0ull;
+                fo.host_records = host_records;
+            }
         }
         if (g.kind == KIND_EXACT) {
             fo.batch = n > 1 ? d_bparams + bp_pos : nullptr;
@@ -1130,6 +1222,8 @@ static int launch_score_argmax_exact(lm_hip_ctx *ctx, const ScoreArgs *jobs, siz
     if (!zero_copy)
         LM_HIP_TRY(hipMemcpyAsync(out, results, sizeof(ArgmaxRecord) * n, hipMemcpyDeviceToHost,
                                   ctx->stream));
+    if (fold_in_kernel && host_records)
+        return fold_host_records(ctx, host_records, host_nrec, ctx->fold_generation, first_cell_rule != 0, out);
     if (fold_in_kernel) {
         // the kernel raises the generation word behind the pinned record once it is written: poll it (a PCIe write
         // after the fold) instead of waiting for the kernel's completion signal; bounded, then synchronise

@@ -147,6 +147,12 @@ struct FusedOut {
     // written to the word behind *final_host AFTER the record (system-scope release): a host that polls it
     // sees the result a PCIe write after the fold, without waiting for the kernel's completion signal
     unsigned generation;
+    // MODE_STORE_TRACK / MODE_ARGMAX of one job, small inputs: non-null = NO fold on the device at all.  Every wavefront writes its
+    // (value, cell) with ONE 16-byte store into this pinned array -- {generation, value bits | generation, cell} --
+    // the lane that owns the matrix's first cell adds scores[0][0] in the slot behind the last wavefront's, and
+    // the HOST folds the few hundred records (api.hip: host_fold).  The three dependent L2 round trips of the
+    // device fold (publish, ticket, read) were 3.8 of the kernel's 10.3 us at the reference's bench size.
+    uint4 *host_records;
 };
 
 // Ordering used by every argmax reduction: larger value wins; equal values ->
@@ -273,9 +279,12 @@ __device__ __forceinline__ void record_hit(const FusedOut &fo, unsigned long lon
 // The fused forms, measured per length (fused threshold / argmax call, 1 Gbp, bound 3 vs 2: M' = 44 1.66 / 1.88 vs
 // 1.41 / 1.28 ms, 48 1.95 / 1.42 vs 1.55 / 1.40, 52 1.86 / 1.56 vs 2.15 / 1.56; profiles/r03_long_variants_ab.txt):
 // two everywhere but at M' = 52.
+// (short family: the exact fused threshold kernel of M = 29 ... 36 schedules better against a bound of three -- M = 32
+//  1.11 -> 0.99 ms, M = 33 1.48 -> 1.04 per Gbp, the other modes and lengths unchanged; tools/fused_ab.sh, round 3)
 constexpr int score_min_waves(int m, int mode)
 {
-    return m <= 40 ? LM_SCORE_MIN_WAVES(m) : mode == 0 /* MODE_STORE */ ? LM_LONG_STORE_MINW : m == 52 ? 3 : 2;
+    return m <= 40 ? ((mode == 2 /* MODE_THRESHOLD */ && m > 28 && m <= 36) ? 3 : LM_SCORE_MIN_WAVES(m))
+                   : mode == 0 /* MODE_STORE */ ? LM_LONG_STORE_MINW : m == 52 ? 3 : 2;
 }
 
 template <int M, int WIDE = 0>
@@ -457,6 +466,8 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
         // (4) the slot started at step k-(M-1) is complete.
         if (PHASE != PHASE_FIRST || k == M - 1) {
             const float score = acc[(k + 1) % M];
+            if (mode_tracks_cell(MODE) && PHASE == PHASE_FIRST)
+                init_next = score;  // (MODE_CONTINUE's carrier is free in these modes) the stream's first output
             if (mode_stores(MODE) && SB > 1) {
                 pend[k % SB] = score;
                 if (k % SB == SB - 1) {
@@ -691,6 +702,7 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
 
     score_group<M, MODE, PFE, LPE, PHASE_FIRST, QL, OC, WIDE>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
                                                 best_t, fo, shq, init_next);
+    const float first_out = init_next;  // MODE_STORE_TRACK: the stream's first output (scores[0][0] for stream 0, column 0)
     note_group();
     for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
         sp += M * 32;
@@ -743,6 +755,18 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
             rec->index = idx;
             rec->found = idx >= 0;
         }
+    } else if (mode_tracks_cell(MODE) && fo.host_records) {
+        // no device-side fold: one 16-byte record per wavefront straight into pinned host memory
+        long long idx = best_t != 0xffffffffu
+                            ? ((long long)(o0 - row_begin) + (long long)best_t - (M - 1)) * 32 + col
+                            : -1;
+        best_wave_reduce(best_v, idx);
+        const unsigned gen = fo.generation;
+        if ((threadIdx.x & 63) == 0)
+            fo.host_records[(size_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6)] =
+                make_uint4(gen, __builtin_bit_cast(unsigned, best_v), gen, idx >= 0 ? (unsigned)idx : 0xffffffffu);
+        if (!idle && stream == 0 && col == 0 && o0 == row_begin)
+            fo.host_records[(size_t)gridDim.x * (BLK / 64)] = make_uint4(gen, __builtin_bit_cast(unsigned, first_out), gen, 0u);
     } else if (mode_tracks_best(MODE)) {
         // the table is dead: reuse the dynamic LDS (>= 64 B) as reduction scratch
         __syncthreads();
