@@ -203,6 +203,12 @@ struct ScoreArgs {
     size_t row_begin, row_end;
     // Store
     float *d_out; size_t out_stride;
+    // Store, optional (small inputs off the C = 32 kernels: score_tiled): per-wavefront (value, cell) records into this
+    // pinned array of `track_cap` slots; *track_nrec receives the number of wavefront records written (0: none)
+    uint4 *track_records = nullptr;
+    unsigned track_generation = 0;
+    size_t track_cap = 0;
+    unsigned *track_nrec = nullptr;
 };
 
 // Materialising score kernels.

@@ -399,11 +399,16 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
                 const size_t lds = tab_bytes + (tr + a.pssm->m - 1) * a.cols + 16;
                 ctx->last_kernel = "score_tiled";
                 const dim3 grid((unsigned)((n + tr - 1) / tr));
+                const size_t nrec = grid.x;  // one record per workgroup
+                const bool track = a.track_records && nrec + 1 <= a.track_cap && n * a.cols < (1ull << 32);
+                if (a.track_nrec)
+                    *a.track_nrec = track ? (unsigned)nrec : 0u;
                 auto launch = [&](auto kernel) {
                     hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, ctx->stream, a.d_seq, (unsigned long long)a.seq_stride,
                                        (int)a.cols, a.pssm->d_dense, (int)a.pssm->m, (int)a.pssm->k,
                                        (unsigned long long)a.row_begin, (unsigned long long)a.row_end, (int)tr, a.d_out,
-                                       (unsigned long long)a.out_stride);
+                                       (unsigned long long)a.out_stride, track ? a.track_records : (uint4 *)nullptr,
+                                       a.track_generation);
                 };
                 if (a.pssm->k == 5)
                     launch(score_tiled<kTiledStrip, 5>);
@@ -764,15 +769,14 @@ int launch_score_store_track(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *
                           ? plan_c32(ctx, MotifShape{mk, a.pssm->k, false}, a, true, 0, 1, store_rows_hint(mk, a.cols))
                           : C32Plan{};
     ScoreC32Launcher fn = p.ok ? score_c32_lookup_store_track((int)mk, lds_wide((int)a.pssm->k)) : nullptr;
-    if (!fn || !table)
-        return launch_score_store(ctx, a);
-    const size_t nrec = (size_t)p.grid.x * (kBlock / 64);
-    if (host_fold && nrec + 1 > host_fold->h_records_cap) {  // (re)allocate the pinned record block
+    auto ensure_records = [&](size_t need) {  // (re)allocate the pinned record block of the handle
+        if (!host_fold || need <= host_fold->h_records_cap)
+            return;
         if (host_fold->h_records)
             (void)hipHostFree(host_fold->h_records);
         host_fold->h_records = nullptr;
         host_fold->h_records_cap = 0;
-        const size_t cap = std::max<size_t>(2 * (nrec + 1), 1024);
+        const size_t cap = std::max<size_t>(2 * need, 1024);
         void *blk = nullptr;
         if (hipHostMalloc(&blk, cap * 16, hipHostMallocDefault) == hipSuccess) {
             memset(blk, 0, cap * 16);
@@ -781,7 +785,29 @@ int launch_score_store_track(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *
         } else {
             (void)hipGetLastError();
         }
+    };
+    if (!fn || !table) {
+        // off the C = 32 kernels (C = 1: the Generic bench geometry of dna.rs:113-116, C = 16 shapes, odd strides): the
+        // tiled store kernel leaves the same per-wavefront records when the handle can take them
+        ensure_records(16384);
+        ScoreArgs t = a;
+        unsigned nrec_t = 0;
+        if (host_fold && host_fold->h_records) {
+            t.track_records = static_cast<uint4 *>(host_fold->h_records);
+            t.track_generation = generation;
+            t.track_cap = host_fold->h_records_cap;
+            t.track_nrec = &nrec_t;
+        }
+        LM_TRY(launch_score_store(ctx, t));
+        if (nrec_t) {
+            host_fold->n_records = nrec_t;
+            host_fold->records_on_host = true;
+            host_fold->folded = false;
+        }
+        return LM_HIP_OK;
     }
+    const size_t nrec = (size_t)p.grid.x * (kBlock / 64);
+    ensure_records(nrec + 1);
     const bool on_host = host_fold && host_fold->h_records;
     if (!on_host) {
         LM_TRY(ensure_ticket(ctx));

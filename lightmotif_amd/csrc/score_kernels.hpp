@@ -914,10 +914,14 @@ __global__ __launch_bounds__(kBlock) void score_tiled(
     const uint8_t *__restrict__ seq, const unsigned long long seq_stride, const int cols,
     const float *__restrict__ pssm, const int M, const int K_rt, const unsigned long long row_begin,
     const unsigned long long row_end, const int TR, float *__restrict__ out,
-    const unsigned long long out_stride)
+    const unsigned long long out_stride, uint4 *__restrict__ host_records, const unsigned generation)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int K = KT ? KT : K_rt;
+    // host_records (small inputs, see FusedOut::host_records): every wavefront also leaves its best (value, cell)
+    // in pinned memory -- Generic rule: greater value, ties to the greater row-major cell, NaN never
+    float best_v = -INFINITY;
+    long long best_c = -1;
     float *tab = reinterpret_cast<float *>(lds_raw);                       // M x K
     uint8_t *tile = reinterpret_cast<uint8_t *>(lds_raw) + (((size_t)M * K * 4 + 15) / 16) * 16;
     for (int i = threadIdx.x; i < M * K; i += kBlock)
@@ -991,8 +995,21 @@ __global__ __launch_bounds__(kBlock) void score_tiled(
         }
 #pragma unroll
         for (int i = 0; i < STRIP; ++i)
-            if (i < n)
+            if (i < n) {
                 out[(r0 - row_begin + o + i) * out_stride + c] = acc[i];
+                if (host_records && acc[i] == acc[i])
+                    best_merge(best_v, best_c, acc[i], (long long)((r0 - row_begin + o + i) * cols + c));
+            }
+        if (host_records && blockIdx.x == 0 && sidx == 0)  // scores[0][0], for the first-cell rule
+            host_records[gridDim.x] = make_uint4(generation, __builtin_bit_cast(unsigned, acc[0]), generation, 0u);
+    }
+    if (host_records) {  // ONE record per workgroup: the host reads every record's cache line from memory
+        __shared__ float sm_v[kBlock / 64];
+        __shared__ long long sm_i[kBlock / 64];
+        best_block_reduce(best_v, best_c, sm_v, sm_i);
+        if (threadIdx.x == 0)
+            host_records[blockIdx.x] =
+                make_uint4(generation, __builtin_bit_cast(unsigned, best_v), generation, best_c >= 0 ? (unsigned)best_c : 0xffffffffu);
     }
 }
 

@@ -899,3 +899,32 @@ def test_scanner_max_walk_on_the_device_at_size(pli, kind):
     got = lm.Scanner(pssm, seq, threshold=t).max()
     assert pli.last_kernel == "scanmax_find"
     assert got is not None and (got.position, np.float32(got.score)) == (want[0], want[1]), (got, want)
+
+
+@pytest.mark.parametrize("cols", [1, 16, 33])
+@pytest.mark.parametrize("m", [5, 15, 20, 33])
+def test_small_score_into_tracks_its_argmax_off_the_c32_kernels(pli, cols, m):
+    """The same one-launch flow where `score_tiled` writes the scores -- C = 1 is the Generic geometry of the
+    reference's bench (dna.rs:113-116), C = 16 / 33 odd layouts: per-wavefront records into pinned memory, folded
+    by the host; ties, all -inf, NaN first cell, row ranges, the handle re-used."""
+    rng = np.random.default_rng(7000 + 100 * cols + m)
+    scores = lm.StripedScores.empty(pli, cols)
+    for length, kind in ((60_011, "normal"), (120_000, "ties"), (30_000, "neg_inf"), (45_001, "nan_first")):
+        enc = rng.integers(0, 4, length, dtype=np.uint8)
+        p = random_pssm(rng, m, 5, "ties" if kind == "ties" else "normal")
+        if kind == "neg_inf":
+            p[:, :5] = -np.inf
+        if kind == "nan_first":
+            p[0, int(enc[0])] = np.nan
+        ref = co.stripe(enc, cols, 5)
+        co.configure_wrap(ref, m - 1)
+        seq = pli.stripe(lm.EncodedSequence(enc), cols)
+        seq.configure_wrap(m - 1)
+        pssm = lm.ScoringMatrix(p)
+        for a, b in ((0, ref.rows), (3, ref.rows - 2)):
+            want, _ = co.score_rows(ref, p, a, b)
+            pli.score_rows_into(pssm, seq, range(a, b), scores)
+            got = pli.argmax(scores)
+            assert np.array_equal(bits(scores.matrix()[:, :cols]), bits(want[:, :cols])), (cols, m, kind)
+            assert got == co.argmax(want, cols), (cols, m, kind, a, b, pli.last_kernel)
+            assert bits(np.float32(pli.max(scores))) == bits(co.max_(want, cols))
