@@ -80,6 +80,18 @@ def build(force: bool = False, jobs: int | None = None) -> Path:
             cmds.append([hipcc, *FLAGS, *LONG_FLAGS, f"-DLM_LONG_M={m}", "-c", str(CSRC / "score_long_inst.hip"),
                          "-o", str(obj)])
     if cmds:
+        # longest units first (the long family and the high motif lengths unroll into the largest kernels), so that
+        # the pool does not end on one straggler
+        def weight(cmd):
+            text = " ".join(cmd)
+            for m in LONG:
+                if f"-DLM_LONG_M={m}" in text:
+                    return 1000 + m
+            for inst, lo, hi in INST:
+                if f"-DLM_INST_ID={inst}" in text:
+                    return 100 + hi
+            return 50 if "score.hip" in text else 0
+        cmds.sort(key=weight, reverse=True)
         with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
             list(ex.map(_run, cmds))
     if cmds or force or not LIB.exists():
