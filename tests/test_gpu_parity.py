@@ -928,3 +928,16 @@ def test_small_score_into_tracks_its_argmax_off_the_c32_kernels(pli, cols, m):
             assert np.array_equal(bits(scores.matrix()[:, :cols]), bits(want[:, :cols])), (cols, m, kind)
             assert got == co.argmax(want, cols), (cols, m, kind, a, b, pli.last_kernel)
             assert bits(np.float32(pli.max(scores))) == bits(co.max_(want, cols))
+
+
+def test_polled_small_argmax_under_stress():
+    """`tools/stress_small_argmax.py` for a few seconds: the polled per-wavefront records (tracked `score_into` +
+    `argmax`, fused `score_argmax`) alternate between inputs with different answers on shared handles; a stale or
+    torn record would show as a wrong cell (2 M iterations clean on the builder's run)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tools" / "stress_small_argmax.py"), "4"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
