@@ -35,16 +35,26 @@
 
 namespace lm {
 
-// padded length M' = 3 (mod 4) -- except 8 <= M <= 11, which go to M' = 15 instead of 11: a table row of
-// M' = 11 is 6 dwords, read as 16 + 8 bytes, and the 8-byte reads of 16-byte-aligned rows run into 2-way bank
-// conflicts (a third of the LDS cycles of a kernel whose LDS was 96 % busy, profiles/r02_c3_record.md); a row
-// of M' = 15 is two whole 16-byte reads.  Those four lengths are half of JASPAR: the 2 346-motif batch went
-// 37.2 -> 33.8 ms (same-box A/B, profiles/r02_pair_store_whole_rows_ab.txt).  Padding EVERY length to
-// 7 (mod 8) costs single-motif scans of M = 16..19 / 24..27 4-7 %, so only this band moves.
+// padded length M' = 3 (mod 4).  A table row of NPAIR = (M' + 1) / 2 dwords is read as whole 16-byte pieces plus,
+// when NPAIR % 4 == 2 (M' = 11, 19, 27, 35), an 8-byte tail.  Left to itself the compiler fuses those tails (of
+// neighbouring steps, or of the motifs of a multi-motif pass) into ds_read2_b64 / ds_read_b96 -- 8 LDS cycles each and
+// conflict-prone (MI355X_MICROARCH.md, LDS table) -- which is where the "2-way bank conflicts of the 8-byte reads"
+// of round 2 came from (a third of the LDS cycles of multi<8..11, 4>, profiles/r02_c3_record.md; ISA of round 3:
+// 22 ds_read2_b64 + 4 ds_read_b96 in multi<16, 2>).  Round 2 worked around it by padding 8 <= M <= 11 to M' = 15
+// (two whole 16-byte reads, +33 % adds: the 2 346-motif batch 37.2 -> 33.8 ms).  Round 3 reads the tail through a
+// volatile LDS pointer instead -- a lone ds_read_b64 costs 2 cycles, as the protein counters showed -- and drops the
+// padding: the JASPAR batch 22.5 -> 20.6 ms (mean of six interleaved runs; with the padding kept: 22.0;
+// profiles/r03_pair_tail_ab.txt).  LM_PREFILTER2_PAD811 = 1 / LM_PREFILTER2_TAIL_VOLATILE = 0 restore round 2.
 #ifndef LM_PREFILTER2_MO8
 #define LM_PREFILTER2_MO8 0
 #endif
-constexpr int prefilter2_mo(int m) { return (LM_PREFILTER2_MO8 || (m >= 8 && m <= 11)) ? (m | 7) : (m | 3); }
+#ifndef LM_PREFILTER2_PAD811
+#define LM_PREFILTER2_PAD811 0
+#endif
+#ifndef LM_PREFILTER2_TAIL_VOLATILE
+#define LM_PREFILTER2_TAIL_VOLATILE 1
+#endif
+constexpr int prefilter2_mo(int m) { return (LM_PREFILTER2_MO8 || (LM_PREFILTER2_PAD811 && m >= 8 && m <= 11)) ? (m | 7) : (m | 3); }
 constexpr int prefilter2_ring(int m) { return prefilter2_mo(m) + 1; }   // input rows per group
 constexpr int prefilter2_npair(int m) { return prefilter2_ring(m) / 2; }
 // dwords per table row: 4 * odd >= NPAIR (rows 0..15 then sit in distinct 16-byte slots)
@@ -141,7 +151,11 @@ __device__ __forceinline__ void prefilter2_group(unsigned (&acc)[prefilter2_npai
             w[4 * q + 3] = v.w;
         }
         if (NP % 4 >= 2) {
+#if LM_PREFILTER2_TAIL_VOLATILE
+            const lm_u32x2_t v = *(lm_lds_u64_ptr)(row + 16 * (NP / 4));
+#else
             const uint2 v = *reinterpret_cast<const uint2 *>(row + 16 * (NP / 4));
+#endif
             w[4 * (NP / 4) + 0] = v.x;
             w[4 * (NP / 4) + 1] = v.y;
         }
@@ -344,7 +358,11 @@ __device__ __forceinline__ void prefilter2_group_multi(unsigned (&acc)[NM][prefi
                 w[4 * q + 3] = v.w;
             }
             if (NP % 4 >= 2) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(row + 16 * (NP / 4));
+    #if LM_PREFILTER2_TAIL_VOLATILE
+            const lm_u32x2_t v = *(lm_lds_u64_ptr)(row + 16 * (NP / 4));
+#else
+            const uint2 v = *reinterpret_cast<const uint2 *>(row + 16 * (NP / 4));
+#endif
                 w[4 * (NP / 4) + 0] = v.x;
                 w[4 * (NP / 4) + 1] = v.y;
             }
