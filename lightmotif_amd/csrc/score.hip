@@ -772,8 +772,10 @@ int launch_score_store_track(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *
     auto ensure_records = [&](size_t need) {  // (re)allocate the pinned record block of the handle
         if (!host_fold || need <= host_fold->h_records_cap)
             return;
-        if (host_fold->h_records)
+        if (host_fold->h_records) {
+            (void)hipStreamSynchronize(ctx->stream);  // an earlier launch may still be writing its records there
             (void)hipHostFree(host_fold->h_records);
+        }
         host_fold->h_records = nullptr;
         host_fold->h_records_cap = 0;
         const size_t cap = std::max<size_t>(2 * need, 1024);
