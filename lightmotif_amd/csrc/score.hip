@@ -38,7 +38,7 @@ static ScoreC32Launcher g_c32w[kMaxLongM + 1][kRegistrySlots];  // wide alphabet
 static PrefilterLauncher g_prew[kMaxFastM + 1];
 static ScoreU8Launcher g_u8w[kMaxFastM + 1];
 static PrefilterLauncher g_pre[kMaxFastM + 1];
-static PrefilterLauncher g_pre2[kMaxFastM + 1];
+static PrefilterLauncher g_pre2[kMaxLongM + 1];  // DNA pair scan: every length up to kMaxLongM
 static PrefilterLauncher g_pre2_protein[kMaxFastM + 1];
 static ScoreU8Launcher g_u8[kMaxFastM + 1];
 static ScoreU8Launcher g_u8_pairs[kMaxFastM + 1];
@@ -91,7 +91,7 @@ PrefilterLauncher score_c32_prefilter_lookup(int M, bool wide)
 PrefilterLauncher score_c32_prefilter2_lookup(int M, int K)
 {
     std::call_once(g_c32_once, init_registry);
-    if (M < 1 || M > kMaxFastM)
+    if (M < 1 || M > (K == 5 ? kMaxLongM : kMaxFastM))
         return nullptr;
     return K == 5 ? g_pre2[M] : K == 21 ? g_pre2_protein[M] : nullptr;
 }
@@ -201,9 +201,9 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const Score
     const bool c16 = allow16 && store && prefilter == 0 && a.cols == 16;
     if ((a.cols != 32 && !c16) || a.seq_stride != 32 || (store && a.out_stride != a.cols))
         return p;
-    if (ms.m < 1 || ms.m > (size_t)(prefilter == 0 ? kMaxLongM : kMaxFastM) || n < M + extra)
+    if (ms.m < 1 || ms.m > (size_t)(prefilter == 0 || (prefilter == 2 && K == 5) ? kMaxLongM : kMaxFastM) || n < M + extra)
         return p;
-    if (ms.m > (size_t)kMaxFastM && (ms.m % 4 != 0 || reinterpret_cast<uintptr_t>(a.d_seq) % 4 != 0))
+    if (prefilter == 0 && ms.m > (size_t)kMaxFastM && (ms.m % 4 != 0 || reinterpret_cast<uintptr_t>(a.d_seq) % 4 != 0))
         return p;  // the long family: padded lengths, dword symbol loads
     // (the pair-symbol kernel fetches symbols with dword loads: 4-byte aligned matrix)
     if (prefilter == 2 && ((K != 5 && !(K == 21 && ctx->pair_prefilter_protein)) || !ms.pair_table || ms.m < 2 ||
@@ -1732,7 +1732,7 @@ constexpr unsigned kOrderedNegInf = 0x007fffffu;  // ordered_bits(-inf)
 // over the job's rows.  Chunks, not single cells: a lone cell costs M cache sectors for M
 // bytes (3.9 M scattered cells = 1.3 ms), a chunk reads its rows once.
 constexpr unsigned kSampleRows = kBlock / 32;  // one row per half-wave: a chunk is one pass of the block
-constexpr unsigned kMaxSampleM = kMaxFastM;    // the candidate route needs a prefilter kernel: M <= kMaxFastM
+constexpr unsigned kMaxSampleM = kMaxLongM;    // the candidate route needs a prefilter kernel: the DNA pair scan goes up to kMaxLongM
 // exact score of the cell at `p` for a motif of at most MAXM rows: all symbol loads in flight at
 // once, then all weight loads, then the reference's add order -- one HBM latency + one L2 latency
 // per chunk instead of M / 4 of each (slots past the motif re-read its last row; the wrap rows
@@ -1767,6 +1767,7 @@ __global__ __launch_bounds__(kBlock) void argmax_sample(const SampleJob *__restr
         // (three unroll depths: most motifs of a batch are short, and every slot costs two loads)
         const float sc = jb.m <= 12   ? sample_cell<12>(jb, p)
                          : jb.m <= 24 ? sample_cell<24>(jb, p)
+                         : jb.m <= 36 ? sample_cell<36>(jb, p)
                                       : sample_cell<kMaxSampleM>(jb, p);
         const unsigned key = ordered_bits(sc);
         best = key > best ? key : best;

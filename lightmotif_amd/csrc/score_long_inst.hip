@@ -28,6 +28,12 @@ void LM_CAT(register_score_c32_long_, LM_LONG_M)(const KernelRegistry &r)
     tab[8] = &score_c32_launch<M, MODE_STORE_ARGMAX, LM_SCORE_XCD_REMAP, 1>;
     tab[9] = &score_c32_launch<M, MODE_CONTINUE, LM_SCORE_XCD_REMAP, 1>;
     tab[11] = &score_c32_launch<M, MODE_STORE_TRACK, LM_SCORE_XCD_REMAP, 1>;
+    // the pair-symbol prefilter scan (score_prefilter2.hpp) of the four exact lengths that pad to M: the fused
+    // threshold / argmax of 36 < M <= 64 flag candidates with it like the shorter motifs do (DNA)
+    r.pre2[M - 3] = &score_c32_prefilter2_launch<M - 3>;
+    r.pre2[M - 2] = &score_c32_prefilter2_launch<M - 2>;
+    r.pre2[M - 1] = &score_c32_prefilter2_launch<M - 1>;
+    r.pre2[M] = &score_c32_prefilter2_launch<M>;
     // the same for alphabets of more than 16 symbols (8-byte LDS reads)
     ScoreC32Launcher *tw = r.c32w[M];
     tw[MODE_STORE] = tw[7] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1, 32, 1>;

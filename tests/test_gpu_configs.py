@@ -507,7 +507,12 @@ def test_long_motifs_fused_reductions_go_chunk_by_chunk(monkeypatch, m, chunk_ro
         for t in (float(finite[-50]), float(finite[-5000])):
             wrc = [tuple(map(int, rc)) for rc in co.threshold(want, COLS, t)]
             frc, fval = pli.score_threshold(pssm, seq, t, range(a, b))
-            assert pli.last_kernel == long_kernel(m, 2), pli.last_kernel
+            # DNA up to 64 rows: the pair-symbol prefilter scan flags the candidates (exact re-scoring decides)
+            assert pli.last_kernel == ("score_c32_prefilter2" if m <= 64 else long_kernel(m, 2)), pli.last_kernel
+            pli.set_prefilter(False)                 # ... and the exact fused kernel of the long family gives the same list
+            frc2, fval2 = pli.score_threshold(pssm, seq, t, range(a, b))
+            pli.set_prefilter(True)
+            assert pli.last_kernel == long_kernel(m, 2) and frc2 == wrc and np.array_equal(bits(fval2), bits(fval))
             assert frc == wrc
             assert np.array_equal(bits(fval), bits([want[r, c] for r, c in wrc]))
     # first-cell NaN rule (pli/mod.rs:142-146) through the chunked path
