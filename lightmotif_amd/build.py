@@ -32,6 +32,8 @@ INST = [(i, 4 * i + 1, 4 * i + 4) for i in range(9)]
 # the raised unroll budget is what keeps their accumulators in registers (see the file's header)
 LONG = list(range(40, 65, 4))
 LONG_FLAGS = ["-mllvm", "-pragma-unroll-threshold=10000000"]
+# score_pair_inst.hip: the pair-symbol prefilter scan alone for the lengths beyond the exact kernels (65 ... 128)
+PAIR = [(65, 80), (81, 96), (97, 112), (113, 128)]
 UNITS = ["score.hip", "reduce.hip", "hits.hip", "discrete.hip", "layout.hip", "scanmax.hip", "api.hip", "comm.hip"]
 
 
@@ -79,6 +81,12 @@ def build(force: bool = False, jobs: int | None = None) -> Path:
         if force or _newer(obj, [CSRC / "score_long_inst.hip"] + headers):
             cmds.append([hipcc, *FLAGS, *LONG_FLAGS, f"-DLM_LONG_M={m}", "-c", str(CSRC / "score_long_inst.hip"),
                          "-o", str(obj)])
+    for lo, hi in PAIR:
+        obj = OBJ / f"score_pair_inst_{lo}.o"
+        objs.append(obj)
+        if force or _newer(obj, [CSRC / "score_pair_inst.hip"] + headers):
+            cmds.append([hipcc, *FLAGS, *LONG_FLAGS, f"-DLM_PAIR_LO={lo}", f"-DLM_PAIR_HI={hi}", "-c",
+                         str(CSRC / "score_pair_inst.hip"), "-o", str(obj)])
     if cmds:
         # longest units first (the long family and the high motif lengths unroll into the largest kernels), so that
         # the pool does not end on one straggler
@@ -90,6 +98,8 @@ def build(force: bool = False, jobs: int | None = None) -> Path:
             for inst, lo, hi in INST:
                 if f"-DLM_INST_ID={inst}" in text:
                     return 100 + hi
+            if "score_pair_inst.hip" in text:
+                return 90
             return 50 if "score.hip" in text else 0
         cmds.sort(key=weight, reverse=True)
         with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:

@@ -613,8 +613,8 @@ int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stri
                     return cleanup(fail(LM_HIP_ERR_HIP, "table upload failed: %s", hipGetErrorString(e)));
             }
         }
-        if (m > (size_t)kMaxFastM && m <= (size_t)kMaxLongM && k == 5) {
-            // 36 < M <= 64, DNA: the pair-symbol prefilter table, so that the fused threshold / argmax scans of these
+        if (m > (size_t)kMaxFastM && m <= (size_t)kMaxPairM && k == 5) {
+            // 36 < M <= 128, DNA: the pair-symbol prefilter table, so that the fused threshold / argmax scans of these
             // lengths flag candidates like the shorter ones do (the one-symbol u16 scan ends at kMaxFastM)
             std::vector<unsigned> image, image2;
             if (build_prefilter(*p, &image, &image2) && !image2.empty()) {

@@ -32,13 +32,17 @@ void register_score_c32_long_52(const KernelRegistry &r);
 void register_score_c32_long_56(const KernelRegistry &r);
 void register_score_c32_long_60(const KernelRegistry &r);
 void register_score_c32_long_64(const KernelRegistry &r);
+void register_score_pair_65(const KernelRegistry &r);
+void register_score_pair_81(const KernelRegistry &r);
+void register_score_pair_97(const KernelRegistry &r);
+void register_score_pair_113(const KernelRegistry &r);
 
 static ScoreC32Launcher g_c32[kMaxLongM + 1][kRegistrySlots];  // rows kMaxFastM + 1 ..: the long family (M % 4 == 0)
 static ScoreC32Launcher g_c32w[kMaxLongM + 1][kRegistrySlots];  // wide alphabets (lds_wide(K))
 static PrefilterLauncher g_prew[kMaxFastM + 1];
 static ScoreU8Launcher g_u8w[kMaxFastM + 1];
 static PrefilterLauncher g_pre[kMaxFastM + 1];
-static PrefilterLauncher g_pre2[kMaxLongM + 1];  // DNA pair scan: every length up to kMaxLongM
+static PrefilterLauncher g_pre2[kMaxPairM + 1];  // DNA pair scan: every length up to kMaxPairM
 static PrefilterLauncher g_pre2_protein[kMaxFastM + 1];
 static ScoreU8Launcher g_u8[kMaxFastM + 1];
 static ScoreU8Launcher g_u8_pairs[kMaxFastM + 1];
@@ -65,6 +69,10 @@ static void init_registry()
     register_score_c32_long_56(r);
     register_score_c32_long_60(r);
     register_score_c32_long_64(r);
+    register_score_pair_65(r);
+    register_score_pair_81(r);
+    register_score_pair_97(r);
+    register_score_pair_113(r);
     for (int m = 0; m <= kMaxLongM; ++m)
         for (int mode = 0; mode < 3; ++mode)
             snprintf(g_c32_names[m][mode], sizeof g_c32_names[m][mode], "score_c32<%d,%d>", m, mode);
@@ -91,7 +99,7 @@ PrefilterLauncher score_c32_prefilter_lookup(int M, bool wide)
 PrefilterLauncher score_c32_prefilter2_lookup(int M, int K)
 {
     std::call_once(g_c32_once, init_registry);
-    if (M < 1 || M > (K == 5 ? kMaxLongM : kMaxFastM))
+    if (M < 1 || M > (K == 5 ? kMaxPairM : kMaxFastM))
         return nullptr;
     return K == 5 ? g_pre2[M] : K == 21 ? g_pre2_protein[M] : nullptr;
 }
@@ -201,7 +209,7 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const Score
     const bool c16 = allow16 && store && prefilter == 0 && a.cols == 16;
     if ((a.cols != 32 && !c16) || a.seq_stride != 32 || (store && a.out_stride != a.cols))
         return p;
-    if (ms.m < 1 || ms.m > (size_t)(prefilter == 0 || (prefilter == 2 && K == 5) ? kMaxLongM : kMaxFastM) || n < M + extra)
+    if (ms.m < 1 || ms.m > (size_t)(prefilter == 0 ? kMaxLongM : (prefilter == 2 && K == 5) ? kMaxPairM : kMaxFastM) || n < M + extra)
         return p;
     if (prefilter == 0 && ms.m > (size_t)kMaxFastM && (ms.m % 4 != 0 || reinterpret_cast<uintptr_t>(a.d_seq) % 4 != 0))
         return p;  // the long family: padded lengths, dword symbol loads
@@ -1353,7 +1361,8 @@ __global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const Rescor
         __syncthreads();
     };
     // block-uniform trip count: one candidate piece per half-wave per round
-    __shared__ uint8_t window[kRescoreBlock / 32][96];  // symbols of rows r0 .. r0 + nrows + M - 2
+    constexpr unsigned kWin = (32 + kMaxPairM - 1 + 31) / 32 * 32;  // a piece of <= 32 rows of a motif of <= kMaxPairM rows
+    __shared__ uint8_t window[kRescoreBlock / 32][kWin];  // symbols of rows r0 .. r0 + nrows + M - 2
     unsigned round = 0;
     for (unsigned long long c0 = (unsigned long long)blockIdx.x * (kRescoreBlock / 32); c0 < n; c0 += stride) {
         const unsigned long long c = c0 + (threadIdx.x >> 5);
@@ -1364,7 +1373,7 @@ __global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const Rescor
             // every symbol of the piece's column window is loaded once (<= 3 loads per
             // lane, all in flight together) and shared through LDS
             uint8_t *win = window[threadIdx.x >> 5];
-            const unsigned nsym = cd.nrows + jb.m - 1;  // <= 32 + 35
+            const unsigned nsym = cd.nrows + jb.m - 1;  // <= 32 + kMaxPairM - 1 (longer motifs never come here)
             const uint8_t *p = jb.seq + r0 * 32 + cd.col;
             uint8_t s0 = 0, s1 = 0, s2 = 0;
             if (lane < nsym)
@@ -1376,6 +1385,8 @@ __global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const Rescor
             win[lane] = s0;
             win[lane + 32] = s1;
             win[lane + 64] = s2;
+            for (unsigned o = lane + 96; o < nsym; o += 32)  // motifs beyond 65 rows
+                win[o] = p[(unsigned long long)o * 32];
             // (a half-wave runs in lockstep inside its wavefront: no barrier needed
             // between the LDS writes above and the reads below)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1755,6 +1766,15 @@ __device__ __forceinline__ float sample_cell(const SampleJob &jb, const uint8_t 
     return sc;
 }
 
+// motifs beyond kMaxSampleM rows (the pair scan goes up to kMaxPairM): row by row, the same add order
+__device__ __forceinline__ float sample_cell_loop(const SampleJob &jb, const uint8_t *__restrict__ p)
+{
+    float sc = 0.0f;
+    for (unsigned j = 0; j < jb.m; ++j)
+        sc = sc + jb.dense[j * jb.k + p[j * 32]];
+    return sc;
+}
+
 __global__ __launch_bounds__(kBlock) void argmax_sample(const SampleJob *__restrict__ jobs,
                                                         unsigned *__restrict__ partial)
 {
@@ -1768,7 +1788,8 @@ __global__ __launch_bounds__(kBlock) void argmax_sample(const SampleJob *__restr
         const float sc = jb.m <= 12   ? sample_cell<12>(jb, p)
                          : jb.m <= 24 ? sample_cell<24>(jb, p)
                          : jb.m <= 36 ? sample_cell<36>(jb, p)
-                                      : sample_cell<kMaxSampleM>(jb, p);
+                         : jb.m <= kMaxSampleM ? sample_cell<kMaxSampleM>(jb, p)
+                                               : sample_cell_loop(jb, p);
         const unsigned key = ordered_bits(sc);
         best = key > best ? key : best;
     }

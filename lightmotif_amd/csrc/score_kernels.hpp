@@ -52,6 +52,10 @@ constexpr int kMaxFastM = 36;        // largest motif the whole kernel family (e
 // lm_hip_pssm::Part::lead): one pass over the sequence like the reference's AVX2 loop takes for any length
 // (avx2.rs:146-193).  M' = 64 needs 163 VGPRs, three wavefronts per SIMD, no scratch (score_long_inst.hip).
 constexpr int kMaxLongM = 64;
+// The DNA pair-symbol prefilter scan (score_prefilter2.hpp) is length-generic and cheap in registers (M / 2 packed
+// accumulators): it is instantiated for every length up to 128, so the FUSED threshold / argmax scans have no cliff
+// where the exact kernels end (candidates are re-scored exactly by rescore_candidates, any length).
+constexpr int kMaxPairM = 128;
 
 // Floats per symbol row of the transposed LDS table used by score_c32<M>:
 // 4 * (smallest odd number >= ceil(M/4)).

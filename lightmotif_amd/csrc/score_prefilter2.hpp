@@ -193,7 +193,7 @@ __device__ __forceinline__ void prefilter2_group(unsigned (&acc)[prefilter2_npai
 }
 
 template <int M, int KA = 5>
-__global__ __launch_bounds__(kBlock, (KA == 5 && M <= kMaxFastM) ? 6 : M <= 52 ? 4 : 3) void score_c32_prefilter2(
+__global__ __launch_bounds__(kBlock, (KA == 5 && M <= kMaxFastM) ? 6 : M <= 52 ? 4 : M <= 80 ? 3 : 2) void score_c32_prefilter2(
     const uint8_t *__restrict__ seq, const unsigned *__restrict__ image, const int K,
     const unsigned long long row_begin, const unsigned long long row_end,
     const unsigned long long T, const unsigned long long nstreams, unsigned td,

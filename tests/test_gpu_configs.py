@@ -473,7 +473,8 @@ def test_long_motifs_are_scored_in_slices(pli, m):
 
 
 @pytest.mark.parametrize("m,chunk_rows", [(37, 5000), (40, 4096), (45, 4096), (53, 4096), (59, 4096), (64, 1 << 20),
-                                          (65, 5000), (73, 7777), (100, 20_000), (150, 128)])
+                                          (65, 5000), (73, 7777), (100, 20_000), (127, 4096), (128, 4096), (129, 4096),
+                                          (150, 128)])
 def test_long_motifs_fused_reductions_go_chunk_by_chunk(monkeypatch, m, chunk_rows):
     """score_argmax / score_threshold / Scanner-style hits of M > 36.  Up to 64 rows: the fused kernels of
     the long family (score_c32<M', 1 | 2>), no score matrix.  Beyond: the sliced store path into a
@@ -507,8 +508,8 @@ def test_long_motifs_fused_reductions_go_chunk_by_chunk(monkeypatch, m, chunk_ro
         for t in (float(finite[-50]), float(finite[-5000])):
             wrc = [tuple(map(int, rc)) for rc in co.threshold(want, COLS, t)]
             frc, fval = pli.score_threshold(pssm, seq, t, range(a, b))
-            # DNA up to 64 rows: the pair-symbol prefilter scan flags the candidates (exact re-scoring decides)
-            assert pli.last_kernel == ("score_c32_prefilter2" if m <= 64 else long_kernel(m, 2)), pli.last_kernel
+            # DNA up to 128 rows: the pair-symbol prefilter scan flags the candidates (exact re-scoring decides)
+            assert pli.last_kernel == ("score_c32_prefilter2" if m <= 128 else long_kernel(m, 2)), pli.last_kernel
             pli.set_prefilter(False)                 # ... and the exact fused kernel of the long family gives the same list
             frc2, fval2 = pli.score_threshold(pssm, seq, t, range(a, b))
             pli.set_prefilter(True)

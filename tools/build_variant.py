@@ -34,6 +34,11 @@ for m in B.LONG:
     objs.append(o)
     cmds.append([hipcc, *B.FLAGS, *B.LONG_FLAGS, *extra, *long_extra, f"-DLM_LONG_M={m}", "-c",
                  str(B.CSRC / "score_long_inst.hip"), "-o", str(o)])
+for lo, hi in B.PAIR:
+    o = obj / f"score_pair_inst_{lo}.o"
+    objs.append(o)
+    cmds.append([hipcc, *B.FLAGS, *B.LONG_FLAGS, *extra, f"-DLM_PAIR_LO={lo}", f"-DLM_PAIR_HI={hi}", "-c",
+                 str(B.CSRC / "score_pair_inst.hip"), "-o", str(o)])
 if long_extra and not extra:   # only the long units differ: reuse the shipped objects for the rest
     keep = [c for c in cmds if "score_long_inst.hip" in " ".join(c)]
     objs = [B.OBJ / o.name if "score_long_inst" not in o.name else o for o in objs]
