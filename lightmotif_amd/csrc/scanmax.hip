@@ -149,10 +149,12 @@ int launch_scan_max(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *
     const size_t max_rows = std::max<size_t>(((size_t)64 << 20) / cols, 4096);
     const size_t wrows_cap = std::min(max_rows, rows - first_row);
     const size_t d_bytes = (wrows_cap * cols + 255) / 256 * 256;
-    LM_TRY(ctx->scan_buf.reserve(d_bytes + wrows_cap * cols * sizeof(float) + 256));
+    // (the state block holds 64-bit words the search updates atomically: both score buffers are rounded to 256 B)
+    const size_t s_bytes = (wrows_cap * cols * sizeof(float) + 255) / 256 * 256;
+    LM_TRY(ctx->scan_buf.reserve(d_bytes + s_bytes + 256));
     uint8_t *d_d = static_cast<uint8_t *>(ctx->scan_buf.ptr);
     float *d_s = reinterpret_cast<float *>(d_d + d_bytes);
-    ScanMaxState *d_st = reinterpret_cast<ScanMaxState *>(reinterpret_cast<char *>(d_s) + wrows_cap * cols * sizeof(float));
+    ScanMaxState *d_st = reinterpret_cast<ScanMaxState *>(reinterpret_cast<char *>(d_s) + s_bytes);
     ScanMaxState *h_st = static_cast<ScanMaxState *>(ctx->pinned);
     ScanMaxState init{};
     init.index = position;

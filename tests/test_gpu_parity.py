@@ -941,3 +941,23 @@ def test_polled_small_argmax_under_stress():
     r = subprocess.run([sys.executable, str(root / "tools" / "stress_small_argmax.py"), "4"], capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("cols", [16, 1, 33])
+def test_scanner_max_walk_on_other_column_counts(pli, cols):
+    """The device walk of `Scanner::max` on striped matrices of 16 / 1 / 33 columns (generic u8 and f32 store
+    kernels, dense window buffers) against the host walk of the downloaded matrices."""
+    rng = np.random.default_rng(300 + cols)
+    length, m = 40_003, 9
+    enc = rng.integers(0, 4, length, dtype=np.uint8)
+    p = random_pssm(rng, m, 5)
+    pssm = lm.ScoringMatrix(p)
+    seq = pli.stripe(lm.EncodedSequence(enc), cols)
+    seq.configure(pssm)
+    mat = pli.score(pssm, seq).matrix()[:, :cols]
+    for q in (0.999, 0.5):
+        t = float(np.quantile(mat[np.isfinite(mat)], q))
+        got = lm.Scanner(pssm, seq, threshold=t).max()
+        host = lm.Scanner(pssm, seq, threshold=t)._max_strict()
+        assert (got is None) == (host is None)
+        assert got is None or (got.position, got.score) == (host.position, host.score), (cols, q, got, host)
