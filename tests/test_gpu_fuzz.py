@@ -97,6 +97,20 @@ def test_random_configuration(pli, seed):
             wpos = np.nonzero(by_pos >= np.float32(t))[0]
             assert scanner.positions.tolist() == wpos.tolist()
             assert np.array_equal(bits(scanner.scores), bits(by_pos[wpos]))
+        if a == 0 and b == rows_total and length >= m and kind in ("normal", "ties", "finite_default"):
+            # Scanner::max: the walk on the device (scanmax.hip) against the host walk of the downloaded matrices,
+            # both overflow flavours of the u8 scores; a candidate window that leaves the matrix is an IndexError in both
+            def walk(fn):
+                try:
+                    hit = fn()
+                    return None if hit is None else (hit.position, bits([hit.score])[0])
+                except IndexError:
+                    return "IndexError"
+            for sat in (True, False):
+                for t in ts[1:3]:
+                    got = walk(lambda: lm.Scanner(pssm, seq, threshold=t).max(sat))
+                    host = walk(lambda: lm.Scanner(pssm, seq, threshold=t)._max_strict(sat))
+                    assert got == host, (t, sat, got, host)
     finally:
         pli.set_rows_per_stream(0)
         pli.set_prefilter(True)
