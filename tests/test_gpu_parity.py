@@ -671,11 +671,23 @@ def test_entry_points_are_thread_safe(pli):
     want_th = [[tuple(map(int, rc)) for rc in co.threshold(w, 32, t)] for w, t in zip(wants, ts)]
     other = lm.Pipeline.hip()
     errors = []
+    text = np.frombuffer(b"ACTG", np.uint8)[enc]
+    packed, _ = lm.pack_2bit(enc)
+    # Scanner::max walks (scanmax.hip), expected from the host walk of a scanner run before the threads start
+    want_walk = []
+    seq0 = pli.stripe(lm.EncodedSequence(enc), 32)
+    seq0.configure_wrap(26)
+    for p_, t_ in zip(motifs, ts):
+        h = lm.Scanner(lm.ScoringMatrix(p_), seq0, threshold=t_)._max_strict()
+        want_walk.append(None if h is None else (h.position, h.score))
 
     def worker(p, k):
         try:
-            seq = p.stripe(lm.EncodedSequence(enc), 32)
+            # the three ingest forms (symbol bytes, text tile by tile, 2 bits per base) give the same resident matrix
+            seq = (p.stripe(lm.EncodedSequence(enc), 32) if k % 3 == 0 else p.stripe_ascii(text) if k % 3 == 1
+                   else p.stripe_2bit(packed, enc.size))
             seq.configure_wrap(26)
+            assert np.array_equal(seq.matrix(), ref.data[:, :32])
             for it in range(6):
                 i = (k + it) % len(motifs)
                 pssm = lm.ScoringMatrix(motifs[i])
@@ -684,6 +696,8 @@ def test_entry_points_are_thread_safe(pli):
                 assert p.argmax(scores) == want_am[i]
                 assert p.score_argmax(pssm, seq)[0] == want_am[i]
                 assert p.score_threshold(pssm, seq, ts[i])[0] == want_th[i]
+                h = lm.Scanner(pssm, seq, threshold=ts[i]).max()
+                assert (None if h is None else (h.position, h.score)) == want_walk[i]
         except Exception as e:  # noqa: BLE001 - reported to the main thread
             errors.append(repr(e))
 
