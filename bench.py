@@ -28,9 +28,12 @@ import sys
 import time
 from pathlib import Path
 
-import numpy as np
-import torch
-import torch.distributed as dist
+# dmabuf IPC: RCCL / device-memory sharing between the ranks' processes needs it on these hosts (set before HIP loads)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
