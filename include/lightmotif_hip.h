@@ -22,6 +22,11 @@
  *    turns a non-zero status into `panic!`.  Degenerate inputs are NOT errors:
  *    L < M or an empty row range gives zero rows (pli/mod.rs:85-88), empty
  *    scores give found = 0 (pli/mod.rs:136-138);
+ *  - a NULL handle or a NULL required pointer is LM_HIP_ERR_BAD_ARGS (checked before any device
+ *    work: the context stays usable); `*_destroy(NULL)` and lm_hip_free(NULL) are no-ops.  Outputs
+ *    that may be NULL when the caller does not want them: `best` / `value` next to `found`
+ *    (argmax, max, the batch argmax), `values` next to `coords` (threshold batch), `out_rows` /
+ *    `max_index`, `bad_index` (tests/test_abi_exports.py, tests/test_gpu_abi_misuse.py);
  *  - memory layout is the reference's: striped sequence
  *    (rows+wrap) x stride bytes, PSSM M x stride f32 (stride 8 for DNA, 24 for
  *    protein), scores rows x stride f32, all row-major, `stride` in ELEMENTS

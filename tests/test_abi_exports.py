@@ -76,3 +76,38 @@ def test_product_never_touches_the_oracle():
     out = subprocess.run(["ldd", str(ROOT / "lightmotif_amd" / "csrc" / "liblightmotif_hip.so")],
                          capture_output=True, text=True).stdout
     assert "lm_oracle" not in out and "lm_avx2" not in out
+
+
+NULL_CALLS = r"""
+import ctypes as C, json, sys
+sys.path.insert(0, sys.argv[1])
+from lightmotif_amd import _ffi
+L = _ffi.lib()
+out = {}
+for name, (res, args) in _ffi.SIGNATURES.items():
+    if res is not C.c_int or not args:
+        continue
+    vals = [0.0 if a is C.c_float else b"D" if a is C.c_char else 0 if a in (C.c_int, C.c_size_t, C.c_uint, C.c_uint8)
+            else None for a in args]
+    print(name, file=sys.stderr, flush=True)          # the last name printed is the one that crashed, if any does
+    st = getattr(L, name)(*vals)
+    out[name] = [st, _ffi.last_error() if st else ""]
+print(json.dumps(out))
+"""
+
+
+def test_null_arguments_are_a_status_not_a_crash():
+    """SURVEY 8(b) error conventions: misuse comes back as a status with a message, never as a fault or an exception
+    across the ABI.  Every int-returning entry point is called with null handles / pointers and zero sizes (before
+    any device work, so this runs without a GPU); `*_destroy(NULL)` is a no-op like free(NULL)."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, "-c", NULL_CALLS, str(ROOT)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, "crashed in " + (r.stderr.strip().splitlines() or ["?"])[-1]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert len(got) >= 65
+    for name, (st, msg) in got.items():
+        if name.endswith("_destroy"):
+            assert st == 0, (name, st, msg)
+        else:
+            assert st != 0 and msg, (name, st, msg)
