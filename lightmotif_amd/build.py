@@ -32,6 +32,8 @@ INST = [(i, 4 * i + 1, 4 * i + 4) for i in range(9)]
 # the raised unroll budget is what keeps their accumulators in registers (see the file's header)
 LONG = list(range(40, 65, 4))
 LONG_FLAGS = ["-mllvm", "-pragma-unroll-threshold=10000000"]
+# score_xlong_inst.hip: the plain store kernel alone for padded lengths 72, 80, 88 (one pass for motifs of 65 ... 88 rows)
+XLONG = list(range(72, 89, 8))
 # score_pair_inst.hip: the pair-symbol prefilter scan alone for the lengths beyond the exact kernels (65 ... 128)
 PAIR = [(65, 80), (81, 96), (97, 112), (113, 128)]
 UNITS = ["score.hip", "reduce.hip", "hits.hip", "discrete.hip", "layout.hip", "scanmax.hip", "api.hip", "comm.hip"]
@@ -81,6 +83,12 @@ def build(force: bool = False, jobs: int | None = None) -> Path:
         if force or _newer(obj, [CSRC / "score_long_inst.hip"] + headers):
             cmds.append([hipcc, *FLAGS, *LONG_FLAGS, f"-DLM_LONG_M={m}", "-c", str(CSRC / "score_long_inst.hip"),
                          "-o", str(obj)])
+    for m in XLONG:
+        obj = OBJ / f"score_xlong_inst_{m}.o"
+        objs.append(obj)
+        if force or _newer(obj, [CSRC / "score_xlong_inst.hip"] + headers):
+            cmds.append([hipcc, *FLAGS, *LONG_FLAGS, f"-DLM_XLONG_M={m}", "-c", str(CSRC / "score_xlong_inst.hip"),
+                         "-o", str(obj)])
     for lo, hi in PAIR:
         obj = OBJ / f"score_pair_inst_{lo}.o"
         objs.append(obj)
@@ -95,6 +103,9 @@ def build(force: bool = False, jobs: int | None = None) -> Path:
             for m in LONG:
                 if f"-DLM_LONG_M={m}" in text:
                     return 1000 + m
+            for m in XLONG:
+                if f"-DLM_XLONG_M={m}" in text:
+                    return 900 + m
             for inst, lo, hi in INST:
                 if f"-DLM_INST_ID={inst}" in text:
                     return 100 + hi

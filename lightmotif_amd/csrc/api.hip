@@ -324,6 +324,8 @@ static void read_dev_switches(lm_hip_ctx *ctx)
 {
     if (const char *e = getenv("LM_HIP_TRACK_ARGMAX"))  // A/B switch: 0 = plain store in score_into
         ctx->track_argmax = atoi(e) != 0;
+    if (const char *e = getenv("LM_HIP_XLONG"))  // A/B switch: 0 = motifs beyond 64 rows stored in slices (round 2 / 3 form)
+        ctx->xlong_store = atoi(e) != 0;
     if (const char *e = getenv("LM_HIP_HOST_FOLD"))  // A/B switch: 0 = small score_into folds its records on the device
         ctx->host_fold = atoi(e) != 0;
     if (const char *e = getenv("LM_HIP_SPECULATE_ORDER"))  // A/B switch: 0 = read the counts first
@@ -588,13 +590,17 @@ int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stri
             // long motifs: slices of <= kMaxLongM rows (multiples of 4 rows: dword symbol loads).  Up to
             // kMaxLongM that is ONE slice -- a single pass of the long kernel family (score_long_inst.hip);
             // beyond, the first slice is stored and the others continue in place (MODE_CONTINUE)
-            const size_t nparts = (m + kMaxLongM - 1) / kMaxLongM;
-            const size_t len = std::min<size_t>(((m + nparts - 1) / nparts + 3) / 4 * 4, (size_t)kMaxLongM);
+            // (65 ... kMaxStoreM rows: ONE slice as well, padded to a multiple of 8 -- the store-only kernels of
+            //  score_xlong_inst.hip; LM_HIP_XLONG=0 keeps the slices for A/B runs)
+            const bool xlong = m > (size_t)kMaxLongM && m <= (size_t)kMaxStoreM && ctx->xlong_store;
+            const size_t nparts = xlong ? 1 : (m + kMaxLongM - 1) / kMaxLongM;
+            const size_t len = xlong ? m : std::min<size_t>(((m + nparts - 1) / nparts + 3) / 4 * 4, (size_t)kMaxLongM);
             for (size_t off = 0; off < m; off += len) {
                 lm_hip_pssm::Part part;
                 part.off = off;
                 const size_t real = std::min(len, m - off);
-                part.lead = (4 - real % 4) % 4;          // the last slice: leading zero rows up to a multiple of 4
+                const size_t unit = xlong ? 8 : 4;
+                part.lead = (unit - real % unit) % unit;  // the last slice: leading zero rows up to a multiple of 4 (8)
                 part.m = real + part.lead;
                 part.ts = (size_t)table_stride((int)part.m, lds_wide((int)k));
                 std::vector<float> table(k * part.ts, 0.0f);

@@ -107,6 +107,7 @@ struct lm_hip_ctx {
     bool pair_prefilter_protein = false;  // the 441-row protein pair scan: correct, measured 4 % slower
     bool quad_loads = true;      // store kernel: quad-gathered dword symbol loads (M % 4 == 0; +1 %)
     bool track_argmax = true;    // score_into on handles also tracks the best cell (cached argmax)
+    bool xlong_store = true;     // motifs of 65 ... kMaxStoreM rows are stored in one pass (LM_HIP_XLONG=0: slices of <= 64)
     bool host_fold = true;       // ... small matrices: per-wavefront records folded by the host (LM_HIP_HOST_FOLD=0: on the device)
     bool speculate_order = true; // fused threshold: order the hit list before the host knows its length
     bool suffix_argmax = true;   // fused argmax of short motifs: try the last rows first (score.hip)

@@ -34,11 +34,15 @@ void register_score_c32_long_60(const KernelRegistry &r);
 void register_score_c32_long_64(const KernelRegistry &r);
 void register_score_pair_65(const KernelRegistry &r);
 void register_score_pair_81(const KernelRegistry &r);
+void register_score_c32_xlong_72(const KernelRegistry &r);
+void register_score_c32_xlong_80(const KernelRegistry &r);
+void register_score_c32_xlong_88(const KernelRegistry &r);
+
 void register_score_pair_97(const KernelRegistry &r);
 void register_score_pair_113(const KernelRegistry &r);
 
-static ScoreC32Launcher g_c32[kMaxLongM + 1][kRegistrySlots];  // rows kMaxFastM + 1 ..: the long family (M % 4 == 0)
-static ScoreC32Launcher g_c32w[kMaxLongM + 1][kRegistrySlots];  // wide alphabets (lds_wide(K))
+static ScoreC32Launcher g_c32[kMaxStoreM + 1][kRegistrySlots];  // rows kMaxFastM + 1 ..: the long family (M % 4 == 0); beyond kMaxLongM: store only (M % 8 == 0)
+static ScoreC32Launcher g_c32w[kMaxStoreM + 1][kRegistrySlots];  // wide alphabets (lds_wide(K))
 static PrefilterLauncher g_prew[kMaxFastM + 1];
 static ScoreU8Launcher g_u8w[kMaxFastM + 1];
 static PrefilterLauncher g_pre[kMaxFastM + 1];
@@ -47,7 +51,7 @@ static PrefilterLauncher g_pre2_protein[kMaxFastM + 1];
 static ScoreU8Launcher g_u8[kMaxFastM + 1];
 static ScoreU8Launcher g_u8_pairs[kMaxFastM + 1];
 static PrefilterMultiLauncher g_pre2_multi[kMaxFastM + 1];
-static char g_c32_names[kMaxLongM + 1][3][32];
+static char g_c32_names[kMaxStoreM + 1][3][32];
 static std::once_flag g_c32_once;
 
 static void init_registry()
@@ -69,11 +73,14 @@ static void init_registry()
     register_score_c32_long_56(r);
     register_score_c32_long_60(r);
     register_score_c32_long_64(r);
+    register_score_c32_xlong_72(r);
+    register_score_c32_xlong_80(r);
+    register_score_c32_xlong_88(r);
     register_score_pair_65(r);
     register_score_pair_81(r);
     register_score_pair_97(r);
     register_score_pair_113(r);
-    for (int m = 0; m <= kMaxLongM; ++m)
+    for (int m = 0; m <= kMaxStoreM; ++m)
         for (int mode = 0; mode < 3; ++mode)
             snprintf(g_c32_names[m][mode], sizeof g_c32_names[m][mode], "score_c32<%d,%d>", m, mode);
 }
@@ -81,7 +88,7 @@ static void init_registry()
 ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap, bool wide)
 {
     std::call_once(g_c32_once, init_registry);
-    if (M < 1 || M > kMaxLongM || mode < 0 || mode > 2)
+    if (M < 1 || M > kMaxStoreM || mode < 0 || mode > 2)
         return nullptr;
     if (wide)
         return g_c32w[M][mode];  // (no XCD-remap variant: an A/B knob of the DNA store kernel)
@@ -113,7 +120,7 @@ PrefilterMultiLauncher score_c32_prefilter2_multi_lookup(int M)
 static ScoreC32Launcher c32_slot(int M, int slot, bool wide)
 {
     std::call_once(g_c32_once, init_registry);
-    return (M >= 1 && M <= kMaxLongM) ? (wide ? g_c32w : g_c32)[M][slot] : nullptr;
+    return (M >= 1 && M <= kMaxStoreM) ? (wide ? g_c32w : g_c32)[M][slot] : nullptr;
 }
 
 ScoreC32Launcher score_c32_lookup_store_argmax(int M, bool wide) { return c32_slot(M, 8, wide); }
@@ -133,7 +140,7 @@ ScoreU8Launcher score_c32_lookup_u8(int M, bool pairs, bool wide)
 const char *score_c32_name(int M, int mode)
 {
     std::call_once(g_c32_once, init_registry);
-    return (M >= 0 && M <= kMaxLongM && mode >= 0 && mode < 3) ? g_c32_names[M][mode] : "score_c32";
+    return (M >= 0 && M <= kMaxStoreM && mode >= 0 && mode < 3) ? g_c32_names[M][mode] : "score_c32";
 }
 
 // ---- stream geometry ---------------------------------------------------------------
@@ -209,7 +216,7 @@ static C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const Score
     const bool c16 = allow16 && store && prefilter == 0 && a.cols == 16;
     if ((a.cols != 32 && !c16) || a.seq_stride != 32 || (store && a.out_stride != a.cols))
         return p;
-    if (ms.m < 1 || ms.m > (size_t)(prefilter == 0 ? kMaxLongM : (prefilter == 2 && K == 5) ? kMaxPairM : kMaxFastM) || n < M + extra)
+    if (ms.m < 1 || ms.m > (size_t)(prefilter == 0 ? (store ? kMaxStoreM : kMaxLongM) : (prefilter == 2 && K == 5) ? kMaxPairM : kMaxFastM) || n < M + extra)
         return p;
     if (prefilter == 0 && ms.m > (size_t)kMaxFastM && (ms.m % 4 != 0 || reinterpret_cast<uintptr_t>(a.d_seq) % 4 != 0))
         return p;  // the long family: padded lengths, dword symbol loads

@@ -52,6 +52,9 @@ constexpr int kMaxFastM = 36;        // largest motif the whole kernel family (e
 // lm_hip_pssm::Part::lead): one pass over the sequence like the reference's AVX2 loop takes for any length
 // (avx2.rs:146-193).  M' = 64 needs 163 VGPRs, three wavefronts per SIMD, no scratch (score_long_inst.hip).
 constexpr int kMaxLongM = 64;
+// ... and the plain STORE kernel alone goes on in one pass to this length (score_xlong_inst.hip: lengths padded to a
+// multiple of 8, two wavefronts per SIMD); the other exact modes of such motifs take the pair scan or the chunked route
+constexpr int kMaxStoreM = 88;
 // The DNA pair-symbol prefilter scan (score_prefilter2.hpp) is length-generic and cheap in registers (M / 2 packed
 // accumulators): it is instantiated for every length up to 128, so the FUSED threshold / argmax scans have no cliff
 // where the exact kernels end (candidates are re-scored exactly by rescore_candidates, any length).
@@ -663,7 +666,8 @@ __global__ __launch_bounds__(BLK, MINW) void score_c32(
         constexpr int NB = M / 4, PFB = NB > 3 ? 3 : NB;
 #pragma unroll
         for (int j = 0; j < PFB; ++j)
-            if (j > 0 || in0 + (col & 3) >= 0)  // lead <= 3: only block 0 can start before row 0; its rows
+            if (M <= kMaxLongM ? (j > 0 || in0 + (col & 3) >= 0)  // lead <= 3: only block 0 can start before row 0; its rows
+                               : in0 + 4 * j + (long long)(col & 3) >= 0)  // (beyond kMaxLongM: lead <= 7, two blocks can)
                 sym[j] = *reinterpret_cast<const unsigned *>(sp + j * 128);  // meet zero weights whatever they hold
     } else {
 #pragma unroll

@@ -428,16 +428,21 @@ def test_adopted_sequence_borrows_the_callers_matrix(gpu_pli):
 
 def long_kernel(m, mode):
     """36 < M <= 64: ONE pass of the long kernel family at the padded length M' = 4 * ceil(M / 4)
-    (score_long_inst.hip); beyond 64: slices of <= 64 rows (store + in-place continuation)."""
+    (score_long_inst.hip); 65 ... 88: the plain STORE alone still in one pass at M' = 8 * ceil(M / 8)
+    (score_xlong_inst.hip); beyond: slices of <= 64 rows (store + in-place continuation)."""
     if m <= 64:
         return f"score_c32<{-(-m // 4) * 4},{mode}>"
+    if m <= 88 and mode == 0:
+        return f"score_c32<{-(-m // 8) * 8},0>"
     return "score_c32_sliced" if mode == 0 else "score_c32_sliced+reduce"
 
 
-@pytest.mark.parametrize("m", [37, 38, 40, 41, 44, 47, 48, 52, 55, 56, 60, 63, 64, 65, 72, 73, 100, 128, 129, 150])
+@pytest.mark.parametrize("m", [37, 38, 40, 41, 44, 47, 48, 52, 55, 56, 60, 63, 64, 65, 71, 72, 73, 80, 81, 88, 95, 96, 97, 100, 104, 105,
+                               128, 129, 150])
 def test_long_motifs_are_scored_in_slices(pli, m):
     """M > 36 at C = 32: up to 64 rows in ONE pass (score_c32<M', 0> of the long family, leading zero
-    rows up to a multiple of 4); longer motifs in slices of <= 64 motif rows, the first through the
+    rows up to a multiple of 4), up to 88 rows the plain store still in one pass (leading zero rows up to a multiple
+    of 8: up to seven of them, two symbol blocks that may lie before the matrix); longer motifs in slices of <= 64 motif rows, the first through the
     store kernel, the others continuing in place from the partial sums (score_c32<M', MODE_CONTINUE>)
     -- the same sequential adds, so bit-exact against the oracle on ragged lengths, row ranges,
     -inf / NaN weights, N runs.  The reference's AVX2 loop takes any M (avx2.rs:146-193)."""
@@ -620,10 +625,10 @@ def test_symbol_validation_covers_sequences_of_2_32_symbols_and_more(gpu_pli):
         enc[bad] = 0
 
 
-@pytest.mark.parametrize("m", [37, 44, 52, 64, 70])
+@pytest.mark.parametrize("m", [37, 44, 52, 64, 70, 88, 90])
 def test_long_protein_motifs_take_the_wide_long_kernels(pli, m):
     """Protein (K = 21) motifs of 37..64 rows: the long family's WIDE instantiations (8-byte LDS reads over rows of
-    2 * odd dwords), store and fused; beyond 64 the sliced path.  Bit-exact against the oracle incl. X runs."""
+    2 * odd dwords), store and fused; 65..88 the one-pass store, beyond that the sliced path.  Bit-exact against the oracle incl. X runs."""
     rng = np.random.default_rng(2100 + m)
     length = 400_000 + 7 * m
     enc = rng.integers(0, 21, length, dtype=np.uint8)

@@ -51,15 +51,17 @@ def gpu_pli():
 
 
 @pytest.mark.parametrize("length,m,k", [(1_000_000_000, 20, 5), (999_999_937, 15, 5), (200_000_000, 12, 21),
-                                        (200_000_000, 50, 5), (150_000_000, 100, 5)],
+                                        (200_000_000, 50, 5), (150_000_000, 100, 5), (150_000_000, 75, 5)],
                          ids=["dna_1Gbp_m20", "dna_ragged_m15", "protein_200M_m12", "dna_200M_m50_long_family",
-                              "dna_150M_m100_sliced_store_pair_scan"])
+                              "dna_150M_m100_sliced_store_pair_scan", "dna_150M_m75_one_pass_store_pair_scan"])
 def test_full_size_properties(gpu_pli, length, m, k):
     pli = gpu_pli
     seq, rows, pssm = make_workload(pli, length, m, k, seed=1234 + m)
     scores = score_all(pli, pssm, seq, rows, m, length)
-    if m > 64:
+    if m > 88:
         assert pli.last_kernel == "score_c32_sliced"
+    elif m > 64:
+        assert pli.last_kernel == f"score_c32<{(m + 7) // 8 * 8},0>"   # one pass, padded to 8 | M (score_xlong_inst.hip)
     else:
         # padded with leading zero rows to 4 | M (33 ... 35 run unpadded; 37 ... 64: the long family)
         mp = m if m % 4 == 0 or 32 < (m + 3) // 4 * 4 <= 36 else (m + 3) // 4 * 4
