@@ -111,3 +111,27 @@ def test_null_arguments_are_a_status_not_a_crash():
             assert st == 0, (name, st, msg)
         else:
             assert st != 0 and msg, (name, st, msg)
+
+
+def test_header_is_plain_c99_and_links_from_c(tmp_path):
+    """The boundary is a C ABI (bindgen / cgo / ctypes read the header as C, not C++): it must parse as strict C99,
+    and a C program linked against the library must resolve its symbols (no compute: only the version and the
+    no-device status are asked for)."""
+    src = tmp_path / "probe.c"
+    src.write_text('#include <stdio.h>\n#include "lightmotif_hip.h"\n'
+                   "int main(void) {\n"
+                   "    lm_hip_ctx *ctx = NULL;\n"
+                   "    int n = -1;\n"
+                   "    if (lm_hip_abi_version() != 1) return 2;\n"
+                   "    if (lm_hip_stride(32, 1) != 32 || lm_hip_stride(5, 4) != 8 || lm_hip_stride(21, 4) != 24) return 3;\n"
+                   "    (void)lm_hip_device_count(&n);\n"
+                   "    if (n <= 0 && lm_hip_ctx_create(0, &ctx) == LM_HIP_OK) return 4;  /* no device: never a fallback */\n"
+                   '    printf("devices %d\\n", n);\n'
+                   "    return 0;\n}\n")
+    from lightmotif_amd import _ffi
+    exe = tmp_path / "probe"
+    libdir = _ffi.LIB_PATH.parent
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{ROOT / 'include'}", str(src), "-o", str(exe),
+                    f"-L{libdir}", "-llightmotif_hip", f"-Wl,-rpath,{libdir}"], check=True, capture_output=True, text=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
