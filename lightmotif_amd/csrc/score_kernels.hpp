@@ -288,9 +288,15 @@ __device__ __forceinline__ void record_hit(const FusedOut &fo, unsigned long lon
 // two everywhere but at M' = 52.
 // (short family: the exact fused threshold kernel of M = 29 ... 36 schedules better against a bound of three -- M = 32
 //  1.11 -> 0.99 ms, M = 33 1.48 -> 1.04 per Gbp, the other modes and lengths unchanged; tools/fused_ab.sh, round 3)
+// (the tracked store of M <= 20 takes 74 VGPRs = six wavefronts where the plain store's 68 allow seven; compiled against a
+//  bound of seven it fits 72 + 2 spills and runs 2 % SLOWER at M = 20, equal at 12 / 16: profiles/r03_track_ab.txt)
+#ifndef LM_TRACK_MINW_LE20
+#define LM_TRACK_MINW_LE20 6
+#endif
 constexpr int score_min_waves(int m, int mode)
 {
-    return m <= 40 ? ((mode == 2 /* MODE_THRESHOLD */ && m > 28 && m <= 36) ? 3 : LM_SCORE_MIN_WAVES(m))
+    return m <= 40 ? ((mode == 2 /* MODE_THRESHOLD */ && m > 28 && m <= 36) ? 3
+                      : (mode == 3 /* MODE_STORE_ARGMAX */ && m <= 20) ? LM_TRACK_MINW_LE20 : LM_SCORE_MIN_WAVES(m))
                    : mode == 0 /* MODE_STORE */ ? LM_LONG_STORE_MINW : m == 52 ? 3 : 2;
 }
 

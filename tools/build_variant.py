@@ -34,6 +34,11 @@ for m in B.LONG:
     objs.append(o)
     cmds.append([hipcc, *B.FLAGS, *B.LONG_FLAGS, *extra, *long_extra, f"-DLM_LONG_M={m}", "-c",
                  str(B.CSRC / "score_long_inst.hip"), "-o", str(o)])
+for m in B.XLONG:
+    o = obj / f"score_xlong_inst_{m}.o"
+    objs.append(o)
+    cmds.append([hipcc, *B.FLAGS, *B.LONG_FLAGS, *extra, f"-DLM_XLONG_M={m}", "-c",
+                 str(B.CSRC / "score_xlong_inst.hip"), "-o", str(o)])
 for lo, hi in B.PAIR:
     o = obj / f"score_pair_inst_{lo}.o"
     objs.append(o)
