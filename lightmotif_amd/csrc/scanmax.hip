@@ -146,7 +146,8 @@ int launch_scan_max(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *
     if (first_row >= rows || seq->length < m)
         return LM_HIP_OK;
     // window buffers: u8 scores | f32 scores, dense rows (stride = cols)
-    const size_t max_rows = std::max<size_t>(((size_t)64 << 20) / cols, 4096);
+    // (~64 M cells per window = 320 MB of u8 + f32 scores; matrices of very many columns keep at least 64 rows)
+    const size_t max_rows = std::max<size_t>(((size_t)64 << 20) / cols, 64);
     const size_t wrows_cap = std::min(max_rows, rows - first_row);
     const size_t d_bytes = (wrows_cap * cols + 255) / 256 * 256;
     // (the state block holds 64-bit words the search updates atomically: both score buffers are rounded to 256 B)
