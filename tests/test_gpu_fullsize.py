@@ -531,3 +531,51 @@ def test_more_than_2_32_cells_on_one_gpu(gpu_pli, m):
     want_pos = sorted(int(c) * rows + int(r) for r, c in want_hits.tolist())
     assert scanner.positions.tolist() == want_pos and want_pos[-1] > 2 ** 32
     assert (scanner.scores == np.float32(best)).all()
+
+
+# cells per trip of one argmax_flat workgroup (reduce.hip kArgmaxSpan) and per threshold_count chunk
+_SPAN, _CHUNK = 8192, 4096
+
+
+@pytest.mark.parametrize("ncells", [1, 3, 4, 5, 1023, 1024, _CHUNK - 1, _CHUNK, _CHUNK + 1, _SPAN - 1, _SPAN, _SPAN + 1,
+                                    3 * _SPAN + 5, 17 * _SPAN + 1027, 4097 * _SPAN + 7, 65536 * _SPAN + 8 * 4096 + 3])
+def test_materialised_reductions_at_span_and_chunk_boundaries(gpu_pli, ncells):
+    """Maximum / Threshold over a stored matrix (pli/mod.rs:135-160, 210-221) on sizes around the
+    kernels' work units: argmax_flat gives every workgroup one contiguous span (one trip of 8 192 cells
+    up to 65 536 workgroups, records beyond 4 096 folded), threshold_count reads whole 4 096-cell chunks
+    lane-contiguously and the ragged last chunk cell by cell.  One column, so the matrix is flat for every
+    size; ties planted at the first and last cell and on both sides of a span boundary."""
+    pli, dev = gpu_pli, torch.device("cuda", 0)
+    rng = np.random.default_rng(ncells % 9973)
+    host = rng.standard_normal(ncells).astype(np.float32)
+    top = np.float32(host.max() + 1)
+    for at in {0, ncells - 1, min(_SPAN - 1, ncells - 1), min(_SPAN, ncells - 1), ncells // 2}:
+        host[at] = top
+    if ncells > 7:
+        host[5] = np.nan
+        host[ncells - 3] = -np.inf
+    scores = torch.from_numpy(host).to(dev)
+    want = co.argmax(host.reshape(-1, 1), 1)
+    got = pli.argmax_dptr(scores.data_ptr(), ncells, 1, 1)
+    assert got is not None and got[0] == want == (ncells - 1, 0) and got[1] == top
+    for t in (float(top), 2.5, -np.inf):
+        if int((host >= np.float32(t)).sum()) > 2_000_000:
+            continue
+        w = co.threshold(host.reshape(-1, 1), 1, t)
+        g = pli.threshold_dptr(scores.data_ptr(), ncells, 1, 1, t)
+        assert np.array_equal(g.astype(np.uint64), w.astype(np.uint64)), (ncells, t)
+    # the last maximal cell somewhere inside: every later cell is smaller
+    if ncells > 2 * _SPAN:
+        host2 = host.copy()
+        host2[host2 == top] = 0
+        for at in (_SPAN - 1, _SPAN, ncells - _SPAN - 1):
+            host2[at] = top
+        scores.copy_(torch.from_numpy(host2))
+        assert pli.argmax_dptr(scores.data_ptr(), ncells, 1, 1)[0] == co.argmax(host2.reshape(-1, 1), 1) \
+            == (ncells - _SPAN - 1, 0)
+    # a NaN first cell answers (0, 0) under the first-cell rule, and is ignored without it
+    host[0] = np.nan
+    scores.copy_(torch.from_numpy(host))
+    assert pli.argmax_dptr(scores.data_ptr(), ncells, 1, 1)[0] == co.argmax(host.reshape(-1, 1), 1) == (0, 0)
+    if ncells > 1:
+        assert pli.argmax_dptr(scores.data_ptr(), ncells, 1, 1, first_cell_rule=False)[0] == (ncells - 1, 0)
