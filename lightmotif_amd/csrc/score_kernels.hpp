@@ -271,6 +271,10 @@ __device__ __forceinline__ void record_hit(const FusedOut &fo, unsigned long lon
 #define LM_SCORE_MIN_WAVES(M) ((M) <= 20 ? 6 : (M) <= 40 ? 4 : 3)
 #endif
 // 1 = score rows are written with non-temporal (streaming) stores
+// A/B (tools/build_variant.py): 1 = the quad symbol loads of the store / fused kernels are non-temporal too
+#ifndef LM_SCORE_NT_LOAD
+#define LM_SCORE_NT_LOAD 0
+#endif
 #ifndef LM_SCORE_NT_STORE
 #define LM_SCORE_NT_STORE 1
 #endif
@@ -426,7 +430,9 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
                     : (k % 4 == 2) ? quad_symbol<2>(d, shq)
                                    : quad_symbol<3>(d, shq);
             if (k % 4 == 3 && (PHASE != PHASE_LAST || k / 4 + PFB < NB))
-                sym[(k / 4 + PFB) % NB] = *reinterpret_cast<const unsigned *>(sp + (k / 4 + PFB) * 128);
+                sym[(k / 4 + PFB) % NB] = LM_SCORE_NT_LOAD
+                                              ? __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(sp + (k / 4 + PFB) * 128))
+                                              : *reinterpret_cast<const unsigned *>(sp + (k / 4 + PFB) * 128);
         } else if (PF > 0) {
             if (PHASE != PHASE_LAST || k + PF < M)
                 sym[(k + PF) % M] = sp[(k + PF) * 32];

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Builds a variant of the library with extra compiler flags next to the shipped one, for A/B runs on
 one box:   python tools/build_variant.py e0 -DLM_LDS_WHOLE_ROWS=0
--> lightmotif_amd/csrc/liblightmotif_hip_e0.so (git-ignored); select it with LM_HIP_LIBRARY=<path>."""
+-> lightmotif_amd/csrc/liblightmotif_hip_e0.so (git-ignored); select it with LM_HIP_LIBRARY=<path>.
+`--short` anywhere among the flags: only the short family's units (score_inst.hip) are rebuilt with them."""
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -16,6 +17,9 @@ long_extra = []
 if "--long" in extra:       # flags after --long go to the long-family units (score_long_inst.hip) only
     i = extra.index("--long")
     extra, long_extra = extra[:i], extra[i + 1:]
+short_only = "--short" in extra   # the flags go to the short family (score_inst.hip, M = 1 ... 36) only: other objects are the shipped ones
+if short_only:
+    extra = [e for e in extra if e != "--short"]
 obj = B.CSRC / f"_obj_{tag}"
 obj.mkdir(exist_ok=True)
 hipcc = B._hipcc()
@@ -48,6 +52,9 @@ if long_extra and not extra:   # only the long units differ: reuse the shipped o
     keep = [c for c in cmds if "score_long_inst.hip" in " ".join(c)]
     objs = [B.OBJ / o.name if "score_long_inst" not in o.name else o for o in objs]
     cmds = keep
+if short_only:
+    cmds = [c for c in cmds if "score_inst.hip" in " ".join(c)]
+    objs = [o if o.name.startswith("score_inst_") else B.OBJ / o.name for o in objs]
 with ThreadPoolExecutor(max_workers=8) as ex:
     list(ex.map(B._run, cmds))
 lib = B.CSRC / f"liblightmotif_hip_{tag}.so"
