@@ -118,6 +118,17 @@ def synth_pssm(m: int, seed: int = 0x5EED0002) -> lm.ScoringMatrix:
     return lm.create(sites).counts.normalize(0.1).log_odds()
 
 
+def store_kernel_digest() -> str:
+    """sha256 over the sources the store kernel is compiled from: `profiles/pmc_traffic.json` records it at
+    collection time (tools/collect_pmc.sh), and a line printed from other sources says `traffic_current: false`
+    instead of quoting a stale counter figure silently."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("score_kernels.hpp", "score_inst.hip", "score.hip"):
+        h.update((ROOT / "lightmotif_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()[:16]
+
+
 def cpu_topology() -> dict:
     """{sockets, cores, threads, model} of the host from /proc/cpuinfo: `cores` are physical cores
     (distinct (physical id, core id) pairs), `threads` the hardware threads the OS schedules on."""
@@ -816,7 +827,7 @@ def main() -> None:
     value = positions / elapsed / 1e9
     achieved = BYTES_PER_POS * rows * COLS / (kernel_avg_ms * 1e-3) / 1e9
     lds_bytes_per_s = 4 * m * rows * COLS / (kernel_avg_ms * 1e-3)
-    traffic, traffic_source = None, None
+    traffic, traffic_source, traffic_current = None, None, None
     pmc = ROOT / "profiles" / "pmc_traffic.json"
     if pmc.exists():
         try:
@@ -826,6 +837,7 @@ def main() -> None:
             if (j.get("algorithmic_bytes_per_launch") == BYTES_PER_POS * rows * COLS and m == 20
                     and not args.rows_per_stream):
                 traffic = j.get("hbm_bytes_per_launch")
+                traffic_current = j.get("store_kernel_digest") == store_kernel_digest()
                 traffic_source = "offline PMC: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this " \
                                  "command (profiles/pmc_traffic.json), not measured by this run"
         except (OSError, ValueError):
@@ -858,7 +870,7 @@ def main() -> None:
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source, "traffic_current": traffic_current,
             "kernel": kernel_name, "kernel_avg_ms": round(kernel_avg_ms, 4),
             "kernel_median_ms": round(kernel_med_ms, 4),
             "frac_at_median": round(BYTES_PER_POS * rows * COLS / (kernel_med_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

@@ -134,6 +134,15 @@ def test_bench_helpers_without_a_gpu(monkeypatch):
     spec.loader.exec_module(bench)
     topo = bench.cpu_topology()
     assert topo["sockets"] >= 1 and 1 <= topo["cores"] <= topo["threads"]
+    # the committed PMC traffic figure names the store-kernel sources it was counted on (roofline.traffic_current)
+    import json
+    pmc = json.loads((Path(__file__).resolve().parent.parent / "profiles" / "pmc_traffic.json").read_text())
+    digest = bench.store_kernel_digest()
+    assert len(digest) == 16 and len(pmc["store_kernel_digest"]) == 16
+    if pmc["store_kernel_digest"] != digest:
+        import warnings
+        warnings.warn("profiles/pmc_traffic.json was counted on other store-kernel sources: bench.py reports "
+                      "roofline.traffic_current = false until tools/collect_pmc.sh is re-run")
     seen = {}
 
     def fake_run(cmd, env=None, **kw):

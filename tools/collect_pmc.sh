@@ -10,9 +10,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/$C" -o p -- \
       python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/$C.log" 2>&1
 done
-python - "$OUT" <<'PY'
+python - "$OUT" "$ROOT" <<'PY'
 import csv, glob, json, sys
 out = sys.argv[1]
+sys.path.insert(0, sys.argv[2])
 res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     vals = []
@@ -35,5 +36,7 @@ if res["FETCH_SIZE"]["launches"] and res["WRITE_SIZE"]["launches"]:
                "calibration": "WRITE_SIZE in KiB (factor 1.00); FETCH_SIZE under-reports by exactly 2x on gfx950 (MI355X_MICROARCH.md HBM "
                               "section; calibrated in round 2 on kernels of known traffic): read bytes = 2 * FETCH_SIZE * 1024",
                "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
-               "algorithmic_bytes_per_launch": 5000000000}, open(out + "/pmc_traffic.json", "w"), indent=1)
+               "algorithmic_bytes_per_launch": 5000000000,
+               # the sources these counters were taken on: bench.py says `traffic_current: false` when they have changed since
+               "store_kernel_digest": __import__("bench").store_kernel_digest()}, open(out + "/pmc_traffic.json", "w"), indent=1)
 PY
