@@ -93,7 +93,7 @@ struct lm_hip_ctx {
     std::mutex mu;
     lm::Scratch scratch;        // block partials, chunk counts, hit lists
     lm::Scratch scratch2;
-    lm::Scratch scan_buf;       // Scanner::max walk (scanmax.hip): one window of u8 + f32 scores and the walk's state
+    lm::Scratch scan_buf;       // Scanner::max walk (scanmax.hip): one window of u8 scores and the walk's state
     lm::Scratch chunk_scores;   // fused reductions of sliced (M > 36) motifs: one chunk of f32 scores (score.hip)
     size_t chunk_rows = 1u << 22; // rows of that chunk (512 MB at C = 32; LM_HIP_CHUNK_ROWS)
     bool chunked_fused = true;  // A/B knob: 0 = such motifs go cell by cell (LM_HIP_CHUNKED_FUSED)

@@ -9,12 +9,17 @@
 // column C).  The answer depends on the order of the walk, so it cannot be a plain reduction.
 //
 // Device form: the state (have, best score, best position, level) lives on the device; rows are scored window by
-// window (u8 scores + f32 scores into two reusable buffers; windows start small and double, the walk makes most of
-// its updates early), and inside a window the walk is a chain of "find the FIRST cell at or after the cursor that
-// the reference would act on" -- a parallel search with an ordered minimum -- followed by a one-thread state
-// update.  The expected number of updates over n cells of continuous scores is ~ln n, less than one per doubling
-// window, so the whole walk costs about two passes over the two score matrices: ~5 ms per Gbp instead of
-// downloading 5 GB of scores to walk them on the host.
+// window (the DiscreteMatrix's u8 scores into one reusable buffer; windows start small and double, the walk makes
+// most of its updates early), and inside a window the walk is a chain of "find the FIRST cell at or after the cursor
+// that the reference would act on" -- a parallel search with an ordered minimum -- followed by a one-thread state
+// update.  The f32 score of a candidate is computed where it is needed (`score_cell`: the M sequential adds of
+// `score_position`, pwm/mod.rs:651-662 -- the same f32 sequence as the store kernel's, so the same bits): candidates
+// are the cells whose u8 score reaches the current level, a vanishing fraction once the first windows are walked,
+// and the first version of this file spent a third of its time materialising 4 B per cell for them.  The expected
+// number of updates over n cells of continuous scores is ~ln n, less than one per doubling window, so beyond the
+// first windows the host does not wait per window either: it enqueues a batch of windows, each with a fixed number of
+// find / update rounds, and a window that would have needed more rounds raises a `stall` mark that turns the rest of
+// the batch into no-ops; the host then finishes that window round by round and carries on behind it.
 #include <algorithm>
 
 #include "score_kernels.hpp"
@@ -30,74 +35,46 @@ struct ScanMaxState {
     int have;
     int err;                    // 1: a candidate's window leaves the striped matrix (the reference panics)
     int more;                   // the last update consumed a cell: search again
-    int pad;
+    int stall;                  // window id + 1 of a pipelined window that ran out of rounds (the kernels behind it do nothing)
+    unsigned pad[2];
 };
 
 namespace {
 
-// The first cell at or after the cursor the reference's loop would ACT on: u8 score >= level and -- no hit held, or
-// a greater f32 score, or an equal one at a greater position (scan.rs:229-242) -- or a window that leaves the matrix.
-__global__ __launch_bounds__(kBlock) void scanmax_find(const uint8_t *__restrict__ d, const float *__restrict__ s,
-                                                       const unsigned long long ncells, const unsigned cols,
-                                                       const unsigned long long row0, const unsigned long long rows,
-                                                       const unsigned m, ScanMaxState *__restrict__ st)
+// Where the f32 score of a cell comes from: the striped sequence and the dense M x K weights.
+struct ScanMaxSource {
+    const uint8_t *seq;          // striped matrix, rows + wrap rows
+    unsigned long long stride;
+    const float *dense;          // dense[j * k + s] = pssm[j][s]
+    unsigned k;
+};
+
+// `score_position` (pwm/mod.rs:651-662): 0.0 + P[0][s0] + P[1][s1] + ... in motif order, f32, no contraction --
+// the add sequence of score_rows_into (pli/mod.rs:98-102), hence the value the store kernel would have written.
+__device__ __forceinline__ float score_cell(const ScanMaxSource &src, const unsigned long long row, const unsigned col,
+                                            const unsigned m)
 {
-    const unsigned long long cursor = st->cursor;
-    if (cursor >= ncells)
-        return;
-    const unsigned level = st->level;
-    const int have = st->have;
-    const float best = st->score;
-    const unsigned long long best_index = st->index;
-    const unsigned long long total = rows * cols;
-    constexpr unsigned long long CH = (unsigned long long)kBlock * 16;  // cells per workgroup chunk
-    const unsigned long long first_chunk = cursor / CH;
-    for (unsigned long long c = first_chunk + blockIdx.x;; c += gridDim.x) {
-        const unsigned long long c0 = c * CH;
-        // chunks are taken in ascending order: nothing at or beyond an already found cell can be the first
-        if (c0 >= ncells || c0 >= __hip_atomic_load(&st->found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            return;
-        const unsigned long long f0 = c0 + 16ull * threadIdx.x;
-        unsigned long long mine = ~0ull;
-        if (f0 < ncells) {
-            unsigned char b[16];
-            if (f0 + 16 <= ncells && (reinterpret_cast<uintptr_t>(d + f0) & 15) == 0) {
-                *reinterpret_cast<uint4 *>(b) = *reinterpret_cast<const uint4 *>(d + f0);
-            } else {
-                for (int i = 0; i < 16; ++i)
-                    b[i] = f0 + i < ncells ? d[f0 + i] : 0;
-            }
-            for (int i = 0; i < 16 && mine == ~0ull; ++i) {
-                const unsigned long long f = f0 + i;
-                if (f < cursor || f >= ncells || b[i] < level)
-                    continue;
-                const unsigned long long r = row0 + f / cols, col = f % cols;
-                const unsigned long long index = col * rows + r;  // scan.rs:231
-                bool act = index + m > total;                    // score_position would index column C
-                if (!act) {
-                    const float x = s[f];
-                    act = !have || x > best || (x == best && index > best_index);
-                }
-                if (act)
-                    mine = f;
-            }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_xor(mine, off);
-            mine = o < mine ? o : mine;
-        }
-        if ((threadIdx.x & 63) == 0 && mine != ~0ull)
-            atomicMin(&st->found, mine);
-    }
+    const uint8_t *p = src.seq + row * src.stride + col;
+    float acc = 0.0f;
+    for (unsigned j = 0; j < m; ++j)
+        acc = acc + src.dense[j * src.k + p[(unsigned long long)j * src.stride]];
+    return acc;
 }
 
-__global__ void scanmax_apply(const uint8_t *__restrict__ d, const float *__restrict__ s, const unsigned long long ncells,
+// The state update behind one search (one thread, a launch of its own: letting the search's last workgroup do it
+// was tried -- a ticket per workgroup means an agent-scope release per workgroup, an L2 write-back on this
+// multi-XCD part, and the search got 2.7 x slower): the found cell becomes the best hit (scan.rs:229-242), or the
+// window is walked.  `last_round` != 0 (pipelined windows): this was the window's last search; if its walk is not
+// finished, mark the window (`stall = window_id + 1`) -- every kernel enqueued behind it then leaves the state alone.
+__global__ void scanmax_apply(const uint8_t *__restrict__ d, const ScanMaxSource src, const unsigned long long ncells,
                               const unsigned cols, const unsigned long long row0, const unsigned long long rows,
-                              const unsigned m, ScanMaxState *__restrict__ st, ScanMaxState *__restrict__ host_copy)
+                              const unsigned m, const int last_round, const int window_id, ScanMaxState *__restrict__ st,
+                              ScanMaxState *__restrict__ host_copy)
 {
     ScanMaxState t = *st;
-    if (t.found != ~0ull && !t.err) {
+    if (t.err | t.stall)
+        return;
+    if (t.found != ~0ull) {
         const unsigned long long f = t.found;
         const unsigned long long r = row0 + f / cols, col = f % cols;
         const unsigned long long index = col * rows + r;
@@ -110,25 +87,122 @@ __global__ void scanmax_apply(const uint8_t *__restrict__ d, const float *__rest
             if (t.have)
                 t.level = d[f];  // scan.rs:238 best_discrete = dscore (the first hit keeps the scaled threshold, :241)
             t.have = 1;
-            t.score = s[f];      // = score_position (pwm/mod.rs:651-662): the same M sequential f32 adds
+            t.score = score_cell(src, r, (unsigned)col, m);  // = score_position (pwm/mod.rs:651-662)
             t.index = index;
             t.cursor = f + 1;
-            t.more = 1;
+            t.more = t.cursor < ncells;
         }
     } else {
         t.more = 0;
         t.cursor = ncells;
     }
     t.found = ~0ull;
+    if (last_round && t.more)
+        t.stall = window_id + 1;
     *st = t;
     *host_copy = t;
 }
 
-__global__ void scanmax_window(ScanMaxState *__restrict__ st)
+// One search of the walk over the window in `d`: the FIRST cell at or after the cursor the reference's loop would ACT
+// on -- u8 score >= level and (no hit held, or a greater f32 score, or an equal one at a greater position,
+// scan.rs:229-242), or a window that leaves the matrix -- found by all workgroups with an ordered minimum.
+// `new_window`: the cursor starts at the window's first cell.  Every workgroup owns ONE contiguous span of 4 096-cell
+// chunks, in ascending order; a lane turns its 16 cells into a bit mask of `u8 >= level` (all but never empty), and
+// only the set bits are looked at.  `found` is polled from L2 every fourth chunk: every wavefront asking for that one
+// address per chunk was 1 M same-address requests per Gbp; a late answer only delays the early exit.
+__global__ __launch_bounds__(kBlock) void scanmax_find(const uint8_t *__restrict__ d, const ScanMaxSource src,
+                                                       const unsigned long long ncells, const unsigned cols,
+                                                       const unsigned long long row0, const unsigned long long rows,
+                                                       const unsigned m, const int new_window, ScanMaxState *__restrict__ st)
 {
-    st->cursor = 0;
+    if (st->err | st->stall)
+        return;
+    const unsigned long long cursor = new_window ? 0ull : st->cursor;
+    if (cursor >= ncells)
+        return;
+    const unsigned level = st->level;
+    const int have = st->have;
+    const float best = st->score;
+    const unsigned long long best_index = st->index;
+    const unsigned long long total = rows * cols;
+    constexpr unsigned long long CH = (unsigned long long)kBlock * 16;  // cells per workgroup chunk
+    const unsigned long long first_chunk = cursor / CH, nchunks = (ncells + CH - 1) / CH;
+    const unsigned long long per = (nchunks - first_chunk + gridDim.x - 1) / gridDim.x;
+    unsigned long long c = first_chunk + (unsigned long long)blockIdx.x * per;
+    const unsigned long long c_end = c + per < nchunks ? c + per : nchunks;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // a lane's cells ascend from chunk to chunk, so its first find is its smallest; the wavefront leaves the span as
+    // soon as any lane has one (a ballot per chunk -- the 64-bit minimum over the lanes is taken once, afterwards)
+    unsigned long long mine = ~0ull;
+    // the lane's 16 cells of chunk `cc` as four dwords (zero past the window); the next chunk's are requested before
+    // this chunk's are looked at
+    auto load_cells = [&](const unsigned long long cc, unsigned (&w)[4]) {
+        const unsigned long long f0 = cc * CH + 16ull * threadIdx.x;
+        w[0] = w[1] = w[2] = w[3] = 0u;
+        if (f0 + 16 <= ncells && (reinterpret_cast<uintptr_t>(d + f0) & 15) == 0) {
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(d + f0));
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
+            for (int i = 0; i < 16; ++i)
+                if (f0 + i < ncells)
+                    w[i / 4] |= (unsigned)d[f0 + i] << (8 * (i % 4));
+        }
+    };
+    unsigned w[4], wn[4] = {0u, 0u, 0u, 0u};
+    if (c < c_end)
+        load_cells(c, w);
+    for (unsigned it = 0; c < c_end; ++c, ++it) {
+        const unsigned long long c0 = c * CH;
+        // chunks are taken in ascending order: nothing at or beyond an already found cell can be the first
+        if ((it & 3u) == 0 && c0 >= __hip_atomic_load(&st->found, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            break;
+        if (c + 1 < c_end)
+            load_cells(c + 1, wn);
+        const unsigned long long f0 = c0 + 16ull * threadIdx.x;
+        if (f0 < ncells) {
+            unsigned mask = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                mask |= (unsigned)(((w[i / 4] >> (8 * (i % 4))) & 0xffu) >= level) << i;
+            if (f0 + 16 > ncells)
+                mask &= (1u << (unsigned)(ncells - f0)) - 1u;   // cells past the window
+            if (f0 < cursor)
+                mask = cursor - f0 >= 16 ? 0u : mask & ~((1u << (unsigned)(cursor - f0)) - 1u);  // cells already walked
+            while (mask && mine == ~0ull) {
+                const int i = __ffs(mask) - 1;
+                mask &= mask - 1;
+                const unsigned long long f = f0 + i;
+                const unsigned long long r = row0 + f / cols, col = f % cols;
+                const unsigned long long index = col * rows + r;  // scan.rs:231
+                bool act = index + m > total;                    // score_position would index column C
+                if (!act) {
+                    const float x = score_cell(src, r, (unsigned)col, m);
+                    act = !have || x > best || (x == best && index > best_index);
+                }
+                if (act)
+                    mine = f;
+            }
+        }
+        if (__ballot(mine != ~0ull))  // later chunks of the span cannot hold the first cell
+            break;
+        w[0] = wn[0]; w[1] = wn[1]; w[2] = wn[2]; w[3] = wn[3];
+    }
+    if (__ballot(mine != ~0ull)) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(mine, off);
+            mine = o < mine ? o : mine;
+        }
+        if ((threadIdx.x & 63) == 0)
+            atomicMin(&st->found, mine);
+    }
+}
+
+// the host takes a stalled window over (its u8 scores are in the buffer again): cursor and level stay
+__global__ void scanmax_resume(ScanMaxState *__restrict__ st)
+{
+    st->stall = 0;
     st->found = ~0ull;
-    st->more = 0;
 }
 
 }  // namespace
@@ -145,17 +219,14 @@ int launch_scan_max(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *
     *best_score = score;
     if (first_row >= rows || seq->length < m)
         return LM_HIP_OK;
-    // window buffers: u8 scores | f32 scores, dense rows (stride = cols)
-    // (~64 M cells per window = 320 MB of u8 + f32 scores; matrices of very many columns keep at least 64 rows)
+    // window buffer: the u8 scores, dense rows (stride = cols); ~64 M cells per window, matrices of very many columns
+    // keep at least 64 rows.  (The state block holds 64-bit words the search updates atomically: 256-byte aligned.)
     const size_t max_rows = std::max<size_t>(((size_t)64 << 20) / cols, 64);
     const size_t wrows_cap = std::min(max_rows, rows - first_row);
     const size_t d_bytes = (wrows_cap * cols + 255) / 256 * 256;
-    // (the state block holds 64-bit words the search updates atomically: both score buffers are rounded to 256 B)
-    const size_t s_bytes = (wrows_cap * cols * sizeof(float) + 255) / 256 * 256;
-    LM_TRY(ctx->scan_buf.reserve(d_bytes + s_bytes + 256));
+    LM_TRY(ctx->scan_buf.reserve(d_bytes + 256));
     uint8_t *d_d = static_cast<uint8_t *>(ctx->scan_buf.ptr);
-    float *d_s = reinterpret_cast<float *>(d_d + d_bytes);
-    ScanMaxState *d_st = reinterpret_cast<ScanMaxState *>(reinterpret_cast<char *>(d_s) + s_bytes);
+    ScanMaxState *d_st = reinterpret_cast<ScanMaxState *>(d_d + d_bytes);
     ScanMaxState *h_st = static_cast<ScanMaxState *>(ctx->pinned);
     ScanMaxState init{};
     init.index = position;
@@ -165,35 +236,85 @@ int launch_scan_max(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *
     init.level = level;
     init.have = have ? 1 : 0;
     h_st[1] = init;  // staged through the pinned block ([0] receives the kernel's copies)
+    h_st[0] = init;
     LM_HIP_TRY(hipMemcpyAsync(d_st, &h_st[1], sizeof(ScanMaxState), hipMemcpyHostToDevice, ctx->stream));
+    const ScanMaxSource src{seq->d_data, (unsigned long long)seq->stride, pssm->d_dense, (unsigned)pssm->k};
     const unsigned grid = (unsigned)ctx->num_cus * 8;
-    size_t w = std::min<size_t>(4096, wrows_cap);
-    for (size_t r = first_row; r < rows;) {
-        const size_t rb = std::min(rows, r + w);
-        const unsigned long long ncells = (unsigned long long)(rb - r) * cols;
-        DiscreteArgs da{weights, m, wstride, pssm->k, seq->d_data, seq->stride, cols, r, rb, d_d, cols, saturate};
-        LM_TRY(launch_score_u8(ctx, da));
-        ScoreArgs sa{pssm, seq->d_data, seq->stride, cols, r, rb, d_s, cols};
-        LM_TRY(launch_score_store(ctx, sa));
-        hipLaunchKernelGGL(scanmax_window, dim3(1), dim3(1), 0, ctx->stream, d_st);
-        for (;;) {
-            for (int rep = 0; rep < 3; ++rep) {  // a few rounds per synchronisation: most windows hold 0-1 updates
-                hipLaunchKernelGGL(scanmax_find, dim3(grid), dim3(kBlock), 0, ctx->stream, d_d, d_s, ncells, (unsigned)cols,
-                                   (unsigned long long)r, (unsigned long long)rows, (unsigned)m, d_st);
-                hipLaunchKernelGGL(scanmax_apply, dim3(1), dim3(1), 0, ctx->stream, d_d, d_s, ncells, (unsigned)cols,
-                                   (unsigned long long)r, (unsigned long long)rows, (unsigned)m, d_st, h_st);
-            }
+    struct Window {
+        size_t r, rb;
+    };
+    auto score_window = [&](const Window &wd) {
+        DiscreteArgs da{weights, m, wstride, pssm->k, seq->d_data, seq->stride, cols, wd.r, wd.rb, d_d, cols, saturate};
+        return launch_score_u8(ctx, da);
+    };
+    // `rounds` searches (each followed by its update) over the window in the buffer; the last one closes a pipelined window
+    auto walk_rounds = [&](const Window &wd, int rounds, bool fresh, bool pipelined, int id) {
+        const unsigned long long ncells = (unsigned long long)(wd.rb - wd.r) * cols;
+        for (int rep = 0; rep < rounds; ++rep) {
+            hipLaunchKernelGGL(scanmax_find, dim3(grid), dim3(kBlock), 0, ctx->stream, d_d, src, ncells, (unsigned)cols,
+                               (unsigned long long)wd.r, (unsigned long long)rows, (unsigned)m, fresh && rep == 0 ? 1 : 0, d_st);
+            hipLaunchKernelGGL(scanmax_apply, dim3(1), dim3(1), 0, ctx->stream, d_d, src, ncells, (unsigned)cols,
+                               (unsigned long long)wd.r, (unsigned long long)rows, (unsigned)m,
+                               pipelined && rep == rounds - 1 ? 1 : 0, id, d_st, h_st);
+        }
+    };
+    auto panicked = [&]() {
+        return fail(LM_HIP_ERR_BAD_ARGS,
+                    "Scanner::max: the window of candidate position %llu (+ %zu rows) leaves the striped matrix; the "
+                    "reference panics here (seq.rs:433-442)", h_st[0].index, m);
+    };
+    // the window in the buffer, round by round under the host's eyes until its walk is complete
+    auto finish_window = [&](const Window &wd, bool fresh) -> int {
+        for (;; fresh = false) {
+            walk_rounds(wd, 3, fresh, false, 0);  // a few rounds per synchronisation
             LM_HIP_TRY(hipGetLastError());
             LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
             if (h_st[0].err)
-                return fail(LM_HIP_ERR_BAD_ARGS,
-                            "Scanner::max: the window of candidate position %llu (+ %zu rows) leaves the striped matrix; the "
-                            "reference panics here (seq.rs:433-442)", h_st[0].index, m);
+                return panicked();
             if (!h_st[0].more)
-                break;
+                return LM_HIP_OK;
         }
-        r = rb;
-        w = std::min(2 * w, wrows_cap);
+    };
+    constexpr size_t kWatchedRows = 1u << 16;  // the walk updates often at first: windows below this size are watched
+    constexpr int kBatch = 8, kRounds = 3;     // pipelined windows per synchronisation, searches per pipelined window
+    size_t w = std::min<size_t>(4096, wrows_cap);
+    size_t r = first_row;
+    while (r < rows) {
+        if (w < kWatchedRows) {
+            const Window wd{r, std::min(rows, r + w)};
+            LM_TRY(score_window(wd));
+            LM_TRY(finish_window(wd, true));
+            r = wd.rb;
+            w = std::min(2 * w, wrows_cap);
+            continue;
+        }
+        Window batch[kBatch];
+        size_t wsize[kBatch];
+        int nb = 0;
+        for (size_t q = r; q < rows && nb < kBatch; ++nb) {
+            batch[nb] = Window{q, std::min(rows, q + w)};
+            wsize[nb] = w;
+            LM_TRY(score_window(batch[nb]));
+            walk_rounds(batch[nb], kRounds, true, true, nb);
+            q = batch[nb].rb;
+            w = std::min(2 * w, wrows_cap);
+        }
+        LM_HIP_TRY(hipGetLastError());
+        LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (h_st[0].err)
+            return panicked();
+        if (h_st[0].stall) {
+            // window `id` ran out of rounds; what was enqueued behind it did nothing.  Its u8 scores again, then on
+            // from its cursor; the windows behind it are enqueued anew
+            const int id = h_st[0].stall - 1;
+            LM_TRY(score_window(batch[id]));
+            hipLaunchKernelGGL(scanmax_resume, dim3(1), dim3(1), 0, ctx->stream, d_st);
+            LM_TRY(finish_window(batch[id], false));
+            r = batch[id].rb;
+            w = std::min(2 * wsize[id], wrows_cap);
+        } else {
+            r = batch[nb - 1].rb;
+        }
     }
     ctx->last_kernel = "scanmax_find";
     *found = h_st[0].have;
