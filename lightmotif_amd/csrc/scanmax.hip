@@ -219,9 +219,9 @@ int launch_scan_max(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *
     *best_score = score;
     if (first_row >= rows || seq->length < m)
         return LM_HIP_OK;
-    // window buffer: the u8 scores, dense rows (stride = cols); ~64 M cells per window, matrices of very many columns
+    // window buffer: the u8 scores, dense rows (stride = cols); up to 256 M cells per window (64 M: 8 % slower per Gbp), matrices of very many columns
     // keep at least 64 rows.  (The state block holds 64-bit words the search updates atomically: 256-byte aligned.)
-    const size_t max_rows = std::max<size_t>(((size_t)64 << 20) / cols, 64);
+    const size_t max_rows = std::max<size_t>(((size_t)256 << 20) / cols, 64);
     const size_t wrows_cap = std::min(max_rows, rows - first_row);
     const size_t d_bytes = (wrows_cap * cols + 255) / 256 * 256;
     LM_TRY(ctx->scan_buf.reserve(d_bytes + 256));
