@@ -279,6 +279,7 @@ int launch_scan_max(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *
     constexpr int kBatch = 8, kRounds = 3;     // pipelined windows per synchronisation, searches per pipelined window
     size_t w = std::min<size_t>(4096, wrows_cap);
     size_t r = first_row;
+    bool resumed = false;
     while (r < rows) {
         if (w < kWatchedRows) {
             const Window wd{r, std::min(rows, r + w)};
@@ -307,6 +308,7 @@ int launch_scan_max(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *
             // window `id` ran out of rounds; what was enqueued behind it did nothing.  Its u8 scores again, then on
             // from its cursor; the windows behind it are enqueued anew
             const int id = h_st[0].stall - 1;
+            resumed = true;
             LM_TRY(score_window(batch[id]));
             hipLaunchKernelGGL(scanmax_resume, dim3(1), dim3(1), 0, ctx->stream, d_st);
             LM_TRY(finish_window(batch[id], false));
@@ -316,7 +318,7 @@ int launch_scan_max(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *
             r = batch[nb - 1].rb;
         }
     }
-    ctx->last_kernel = "scanmax_find";
+    ctx->last_kernel = resumed ? "scanmax_find (a batched window resumed)" : "scanmax_find";
     *found = h_st[0].have;
     *best_position = h_st[0].index;
     *best_score = h_st[0].score;

@@ -911,8 +911,62 @@ def test_scanner_max_walk_on_the_device_at_size(pli, kind):
     seq.configure(pssm)
     want = no.scanner_max_strict(scores, d, 32, t, scale, 256)
     got = lm.Scanner(pssm, seq, threshold=t).max()
-    assert pli.last_kernel == "scanmax_find"
+    assert pli.last_kernel.startswith("scanmax_find")
     assert got is not None and (got.position, np.float32(got.score)) == (want[0], want[1]), (got, want)
+
+
+@pytest.mark.parametrize("threshold", ["p1e-4", "every_cell"])
+def test_scanner_max_walk_batched_windows_stall_and_resume(pli, threshold):
+    """The walk beyond its first windows (csrc/scanmax.hip): windows of 65 536 rows and more are enqueued in batches
+    with three search / update rounds each and no wait in between; a window that needs more rounds stalls the batch
+    and is finished under the host's eyes.  8 Mbp with sites of rising strength planted inside ONE late window
+    (five records in a row: more than three rounds) and again in the next one, against the oracle's line-by-line
+    restatement of scan.rs:200-249."""
+    rng = np.random.default_rng(20_260_929)
+    length, m, k = 8_000_003, 20, 5
+    rows = -(-length // 32)
+    enc = rng.integers(0, 4, length, dtype=np.uint8)
+    p = np.zeros((m, co.stride(k, 4)), np.float32)
+    p[:, :4] = rng.normal(-1, 1, (m, 4))
+    p[np.arange(m), rng.integers(0, 4, m)] = 3.0       # a consensus far above anything random: every planted site is a record
+    p[:, k - 1] = -np.inf
+    order = np.argsort(p[:, :4], axis=1)
+    best_sym, second_sym, worst_sym = order[:, 3], order[:, 2], order[:, 0]
+
+    def plant(row, col, mismatches, sub):  # cell (row, col) <-> position col * rows + row (pli/mod.rs:191-193)
+        site = best_sym.copy()
+        site[:mismatches] = sub[:mismatches]
+        enc[col * rows + row: col * rows + row + m] = site
+    for i, mm in enumerate((6, 5, 4, 3)):              # window of rows 61 440 ... 126 975 (the first batched one): four records
+        plant(70_000 + 40 * i, 0, mm, worst_sym)
+    for i, mm in enumerate((3, 2, 1, 0)):              # the window behind it: four more, each above the last
+        plant(200_000 + 40 * i, 3, mm, second_sym)
+    ref = co.stripe(enc, 32, k)
+    co.configure_wrap(ref, m - 1)
+    scores, _ = co.score_rows(ref, p)
+    w, factor, offsets, offset = no.to_discrete(p, k)
+    d = no.score_rows_u8_saturating(ref.data, 32, length, w, 0, ref.rows)
+    scale = lambda x: no.discrete_scale(x, factor, offset)   # noqa: E731
+    finite = scores[:, :32][np.isfinite(scores[:, :32])]
+    t = -1e30 if threshold == "every_cell" else float(np.quantile(finite, 0.9999))
+    pssm = lm.ScoringMatrix(p)
+    seq = pli.stripe(lm.EncodedSequence(enc), 32)
+    seq.configure(pssm)
+    want = no.scanner_max_strict(scores, d, 32, t, scale, 256)
+    got = lm.Scanner(pssm, seq, threshold=t).max()
+    assert pli.last_kernel == "scanmax_find (a batched window resumed)"     # the stall path was taken
+    assert got is not None and (got.position, np.float32(got.score)) == (want[0], want[1]), (got, want)
+    # a scanner that has already yielded part of its hits walks on from where it stands (scan.rs:200-215)
+    sc = lm.Scanner(pssm, seq, threshold=float(np.quantile(finite, 0.99999)), block_size=4096)
+    it = iter(sc)
+    for _ in range(3):
+        next(it)
+    host = lm.Scanner(pssm, seq, threshold=float(np.quantile(finite, 0.99999)), block_size=4096)
+    ith = iter(host)
+    for _ in range(3):
+        next(ith)
+    a, b = sc.max(), host._max_strict()
+    assert (a is None) == (b is None) and (a is None or (a.position, a.score) == (b.position, b.score))
 
 
 @pytest.mark.parametrize("cols", [1, 16, 33])
