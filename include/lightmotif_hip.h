@@ -133,7 +133,10 @@ int lm_hip_ctx_set_prefilter(lm_hip_ctx *ctx, int enabled);
  * lm_hip_scores_info. */
 int lm_hip_ctx_set_track_argmax(lm_hip_ctx *ctx, int enabled);
 /* Name of the kernel the last score call on this context launched
- * (for profiling tools); valid until the next call. */
+ * (for profiling tools); valid until the next call.  "score_c32<M,MODE>" names
+ * the kernel family and the length it ran at (MODE 0 store, 1 fused argmax,
+ * 2 fused threshold); the store kernel's tracking forms (lm_hip_ctx_set_track_argmax:
+ * template modes 3 and 5 in a rocprofv3 trace) report as "score_c32<M,0>". */
 const char *lm_hip_ctx_last_kernel(lm_hip_ctx *ctx);
 
 /* ---- PSSM ---------------------------------------------------------------- */
