@@ -304,6 +304,18 @@ constexpr int score_min_waves(int m, int mode)
                    : mode == 0 /* MODE_STORE */ ? LM_LONG_STORE_MINW : m == 52 ? 3 : 2;
 }
 
+// Upper bound of the wavefronts per SIMD (second argument of amdgpu_waves_per_eu; 0 = none, i.e. plain
+// __launch_bounds__).  hipcc schedules two tracked store kernels of the long family badly when it is free to aim at
+// a higher occupancy than the bound asks for: M' = 56 with 1 424 `s_waitcnt` instead of the plain store's 823 (LDS
+// reads next to their uses) and M' = 40 alike -- 2.33 / 1.60 ms per Gbp against 1.87 / 1.41 for the plain store.
+// Capped at their lower bound the register allocator stops trading the schedule for a wavefront it does not get:
+// 484 waits, 2.00 / 1.43 ms.  The same cap on every other store kernel is a disaster (M' = 44 1.52 -> 3.11 ms,
+// M = 24 1.04 -> 1.88; profiles/r03_maxw_ab.txt), hence the two lengths by name.
+#ifndef LM_MAXW
+#define LM_MAXW(M, MODE, MINW) (((MODE) == 3 /* MODE_STORE_ARGMAX */ && ((M) == 40 || (M) == 56)) ? (MINW) : 0)
+#endif
+constexpr int score_max_waves(int m, int mode, int minw) { return LM_MAXW(m, mode, minw); }
+
 template <int M, int WIDE = 0>
 __device__ __forceinline__ void lds_fetch_column(float (&w)[4 * ((M + 3) / 4)],
                                                  const char *__restrict__ tab, const unsigned s)
@@ -603,7 +615,7 @@ __device__ __forceinline__ void emit_candidates(const unsigned long long hit_gro
 #endif
 template <int M, int MODE, int PF = LM_SCORE_PF, int LP = LM_SCORE_LP, int BLK = LM_BLOCK,
           int XCD = LM_SCORE_XCD_REMAP, int MINW = LM_SCORE_MIN_WAVES(M), int QLREQ = 0, int OC = 32, int WIDE = 0>
-__global__ __launch_bounds__(BLK, MINW) void score_c32(
+__global__ __attribute__((amdgpu_flat_work_group_size(1, BLK), amdgpu_waves_per_eu(MINW, score_max_waves(M, MODE, MINW)))) void score_c32(
     const uint8_t *__restrict__ seq, const float *__restrict__ table, const int K,
     const unsigned long long row_begin, const unsigned long long row_end,
     const unsigned long long T, const unsigned long long nstreams, float *__restrict__ out,

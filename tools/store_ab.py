@@ -3,7 +3,8 @@
 median / minimum kernel time of `score_into` on a resident DNA sequence per motif length, and a digest of the
 score matrix so that two libraries can be compared bit for bit.  GPU box only:
 
-    python tools/store_ab.py 1000000000 24,28,33,36
+    python tools/store_ab.py 1000000000 24,28,33,36 [track]     (track: the handle path's default, the store kernel
+                                                                  that tracks the best value on the way)
 """
 import hashlib
 import json
@@ -39,7 +40,8 @@ def main():
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream()
     pli = lm.Pipeline.hip(0, stream=stream.cuda_stream)
-    pli.set_track_argmax(False)                    # the plain store kernel (bench.py's N = 1 step), not the tracked one
+    track = len(sys.argv) > 3 and sys.argv[3] == "track"
+    pli.set_track_argmax(track)                    # off: the plain store kernel (bench.py's N = 1 step)
     rows = -(-length // B.COLS)
     for m in ms:
         pssm = B.synth_pssm(m)
@@ -59,7 +61,7 @@ def main():
         torch.cuda.synchronize()
         t = sorted(a.elapsed_time(b) for a, b in ev)
         digest = device_digest(scores.data_ptr, scores.rows * scores.stride, dev)
-        print(json.dumps({"M": m, "kernel": pli.last_kernel, "ms": round(t[len(t) // 2], 4), "ms_min": round(t[0], 4),
+        print(json.dumps({"M": m, "tracked": track, "kernel": pli.last_kernel, "ms": round(t[len(t) // 2], 4), "ms_min": round(t[0], 4),
                           "sha": digest}), flush=True)
         del scores, seq, shard
         torch.cuda.empty_cache()
