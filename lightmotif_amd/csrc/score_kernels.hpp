@@ -304,6 +304,13 @@ constexpr int score_min_waves(int m, int mode)
                    : mode == 0 /* MODE_STORE */ ? LM_LONG_STORE_MINW : m == 52 ? 3 : 2;
 }
 
+// MODE_CONTINUE: how many steps ahead a row's partial sum is requested (see score_group)
+#ifndef LM_CONTINUE_AHEAD
+#define LM_CONTINUE_AHEAD 4
+#endif
+// (M' = 52, the one continuation kernel on a bound of three wavefronts per SIMD, gets SLOWER with the ring: 2.28 -> ~3.1 ms
+//  per Gbp; it keeps the step-ahead form.  profiles/r03_continue_ahead_ab.txt)
+constexpr int continue_ahead(int m) { return (m % LM_CONTINUE_AHEAD == 0 && m != 52) ? LM_CONTINUE_AHEAD : 1; }
 // Upper bound of the wavefronts per SIMD (second argument of amdgpu_waves_per_eu; 0 = none, i.e. plain
 // __launch_bounds__).  hipcc schedules two tracked store kernels of the long family badly when it is free to aim at
 // a higher occupancy than the bound asks for: M' = 56 with 1 424 `s_waitcnt` instead of the plain store's 823 (LDS
@@ -419,7 +426,8 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
                                             const char *__restrict__ tab,
                                             float *__restrict__ op, const unsigned tbase,
                                             const int col, float &best_v, unsigned &best_t,
-                                            const FusedOut &fo, const unsigned shq, float &init_next)
+                                            const FusedOut &fo, const unsigned shq, float &init_next,
+                                            float (&initq)[LM_CONTINUE_AHEAD], const bool prelast)
 {
     constexpr int NW = 4 * ((M + 3) / 4);
     constexpr int NB = M / 4;                  // QL: 4-row symbol blocks per group (M % 4 == 0)
@@ -481,9 +489,20 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
         // step 0 starts the stream's last row, later starts are dead.
         float init = 0.0f;
         if (MODE == MODE_CONTINUE) {
-            init = init_next;
-            if (PHASE != PHASE_LAST)
-                init_next = op[(k + 1 + M - 1) * OC];
+            // a ring of CD partial sums in flight: the one requested CD steps ago is used, the row started CD steps
+            // from now is requested (M % CD == 0 keeps the ring's phase from group to group).  One step ahead the
+            // kernel waited out most of an HBM read latency per step at two or three wavefronts per SIMD:
+            // <48,4> 2.24 ms per Gbp against 1.59 for <48,0>, <64,4> 3.21 against 1.96.  Starts beyond step 0 of the
+            // LAST group are dead rows (possibly past the matrix): in the group before it those requests go to a
+            // row of this group instead (`prelast`, wave-uniform: two v_cndmask on CD - 1 steps per group).
+            constexpr int CD = continue_ahead(M);  // 1 (the step-ahead form) for lengths that are no multiple of the ring
+            init = initq[k % CD];
+            if (PHASE != PHASE_LAST) {
+                const float *src = op + (k + CD + M - 1) * OC;
+                if (k + CD > M)
+                    src = prelast ? op + (M - 1) * OC : src;
+                initq[k % CD] = *src;
+            }
         }
         // (3) P[j][s] goes to the output row started j steps ago: slot (k - j) mod M.
 #pragma unroll
@@ -710,7 +729,11 @@ __global__ __attribute__((amdgpu_flat_work_group_size(1, BLK), amdgpu_waves_per_
     unsigned best_t = (MODE == MODE_THRESHOLD) ? 0u : 0xffffffffu;
     unsigned tbase = 0;
     // MODE_CONTINUE: partial sum of the row started at step 0 (= the stream's first row)
-    float init_next = MODE == MODE_CONTINUE ? op[(M - 1) * OC] : 0.0f;
+    float init_next = 0.0f;
+    float initq[LM_CONTINUE_AHEAD];
+#pragma unroll
+    for (int d = 0; d < LM_CONTINUE_AHEAD; ++d)  // rows started at steps 0 .. CD-1 of the stream (T >= M + 1 rows: they exist)
+        initq[d] = (MODE == MODE_CONTINUE && d < continue_ahead(M)) ? op[(d + M - 1) * OC] : 0.0f;
 
     const unsigned long long ngroups = (T + M - 1) / M;  // exact: T = q*M + 1, >= 2
 
@@ -733,7 +756,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(1, BLK), amdgpu_waves_per_
     };
 
     score_group<M, MODE, PFE, LPE, PHASE_FIRST, QL, OC, WIDE>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
-                                                best_t, fo, shq, init_next);
+                                                best_t, fo, shq, init_next, initq, ngroups == 2);
     const float first_out = init_next;  // MODE_STORE_TRACK: the stream's first output (scores[0][0] for stream 0, column 0)
     note_group();
     for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
@@ -742,7 +765,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(1, BLK), amdgpu_waves_per_
         if (mode_stores(MODE))
             op += M * OC;
         score_group<M, MODE, PFE, LPE, PHASE_MAIN, QL, OC, WIDE>(acc, sym, wc, sp, lds_raw, op, tbase, col,
-                                                   best_v, best_t, fo, shq, init_next);
+                                                   best_v, best_t, fo, shq, init_next, initq, g + 2 == ngroups);
         note_group();
     }
     sp += M * 32;
@@ -750,7 +773,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(1, BLK), amdgpu_waves_per_
     if (mode_stores(MODE))
         op += M * OC;
     score_group<M, MODE, PFE, LPE, PHASE_LAST, QL, OC, WIDE>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
-                                               best_t, fo, shq, init_next);
+                                               best_t, fo, shq, init_next, initq, false);
     note_group();
 
     if (MODE == MODE_THRESHOLD) {
