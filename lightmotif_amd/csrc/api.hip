@@ -52,8 +52,8 @@ void Scratch::release()
     bytes = 0;
 }
 
-static int check_score_args(const lm_hip_pssm *pssm, size_t seq_rows_total, size_t seq_stride,
-                            size_t cols, size_t wrap, size_t row_begin, size_t row_end)
+int check_score_args(const lm_hip_pssm *pssm, size_t seq_rows_total, size_t seq_stride, size_t cols, size_t wrap,
+                     size_t row_begin, size_t row_end)
 {
     if (!pssm)
         return fail(LM_HIP_ERR_BAD_ARGS, "score: null pssm");
@@ -241,21 +241,6 @@ void result_free(void *p)
             }
     }
     free(p);
-}
-
-static int default_ctx(lm_hip_ctx **out)
-{
-    static std::mutex mu;
-    static lm_hip_ctx *ctx = nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!ctx) {
-        int dev = 0;
-        if (const char *e = getenv("LM_HIP_DEVICE"))
-            dev = atoi(e);
-        LM_TRY(lm_hip_ctx_create(dev, &ctx));
-    }
-    *out = ctx;
-    return LM_HIP_OK;
 }
 
 }  // namespace lm
@@ -769,6 +754,21 @@ int lm_hip_score_u8(lm_hip_ctx *ctx, const uint8_t *weights, size_t m, size_t we
     std::lock_guard<std::mutex> lock(ctx->mu);
     DeviceGuard guard(ctx->device);
     const size_t nrows = row_end - row_begin, cols = seq->cols;
+    if (nrows * cols + 4096 <= kPinnedBytes / 2 && nrows * cols <= (128u << 10)) {
+        // a Scanner block (scan.rs:174-178: 256 rows): the kernel writes the u8 scores straight into pinned host
+        // memory -- no copy command, one synchronisation (tools/kbench/hostpipe_bench.hip: 16 us against 28 us)
+        uint8_t *z_out = static_cast<uint8_t *>(ctx->pinned) + 4096;
+        DiscreteArgs a{weights, m, weights_stride, k, seq->d_data, seq->stride, cols, row_begin, row_end, z_out, cols,
+                       saturate != 0};
+        LM_TRY(launch_score_u8(ctx, a));
+        LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (out_stride == cols)
+            memcpy(out, z_out, nrows * cols);
+        else
+            for (size_t r = 0; r < nrows; ++r)
+                memcpy(out + r * out_stride, z_out + r * cols, cols);
+        return LM_HIP_OK;
+    }
     LM_TRY(ctx->scratch.reserve(nrows * cols));
     uint8_t *d_out = static_cast<uint8_t *>(ctx->scratch.ptr);
     DiscreteArgs a{weights, m, weights_stride, k, seq->d_data, seq->stride, cols, row_begin, row_end, d_out,
@@ -1757,139 +1757,6 @@ int lm_hip_threshold(lm_hip_ctx *ctx, const lm_hip_scores *s, float t, lm_hip_co
     if (!s)
         return fail(LM_HIP_ERR_BAD_ARGS, "threshold: null scores");
     return lm_hip_threshold_f32_dptr(ctx, s->d_data, s->rows, s->stride, s->cols, t, coords, n);
-}
-
-// ---- host-pointer convenience forms ----------------------------------------------------------------------
-
-int lm_hip_score_f32(const uint8_t *seq, size_t seq_rows_total, size_t seq_stride, size_t cols,
-                     size_t wrap, size_t length, const float *pssm, size_t m, size_t pssm_stride,
-                     size_t k, size_t row_begin, size_t row_end, float *out, size_t out_stride,
-                     size_t *out_rows, size_t *max_index)
-{
-    lm_hip_ctx *ctx = nullptr;
-    LM_TRY(default_ctx(&ctx));
-    lm_hip_pssm *p = nullptr;
-    LM_TRY(lm_hip_pssm_create(ctx, pssm, m, pssm_stride, k, &p));
-    int st = check_score_args(p, seq_rows_total, seq_stride, cols, wrap, row_begin, row_end);
-    size_t orow = 0, mi = 0;
-    if (st == LM_HIP_OK && !(length < m || row_begin >= row_end)) {
-        if (!seq || !out || out_stride < cols) {
-            st = fail(LM_HIP_ERR_BAD_ARGS, "score: null buffer or bad output stride");
-        } else {
-            // ship only the rows the range needs: [row_begin, row_end + m - 1)
-            const size_t nrows_in = (row_end - row_begin) + (m ? m - 1 : 0);
-            const size_t nrows_out = row_end - row_begin;
-            std::lock_guard<std::mutex> lock(ctx->mu);
-            DeviceGuard guard(ctx->device);
-            uint8_t *d_seq = nullptr;
-            float *d_out = nullptr;
-            hipError_t e = hipMalloc(&d_seq, nrows_in * seq_stride + 64);
-            if (e == hipSuccess)
-                e = hipMalloc(&d_out, nrows_out * out_stride * sizeof(float));
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(d_seq, seq + row_begin * seq_stride, nrows_in * seq_stride,
-                                   hipMemcpyHostToDevice, ctx->stream);
-            if (e != hipSuccess) {
-                st = fail(e == hipErrorOutOfMemory ? LM_HIP_ERR_OOM : LM_HIP_ERR_HIP,
-                          "score: staging failed: %s", hipGetErrorString(e));
-            } else {
-                ScoreArgs a{p, d_seq, seq_stride, cols, 0, nrows_out, d_out, out_stride};
-                st = launch_score_store(ctx, a);
-                if (st == LM_HIP_OK) {
-                    // only the `cols` scored cells of each row: the caller's alignment
-                    // padding is left as it was, like pli/mod.rs:103 does
-                    e = out_stride == cols
-                            ? hipMemcpyAsync(out, d_out, nrows_out * out_stride * sizeof(float),
-                                             hipMemcpyDeviceToHost, ctx->stream)
-                            : hipMemcpy2DAsync(out, out_stride * sizeof(float), d_out,
-                                               out_stride * sizeof(float), cols * sizeof(float),
-                                               nrows_out, hipMemcpyDeviceToHost, ctx->stream);
-                    if (e == hipSuccess)
-                        e = hipStreamSynchronize(ctx->stream);
-                    if (e != hipSuccess)
-                        st = fail(LM_HIP_ERR_HIP, "score: read-back failed: %s", hipGetErrorString(e));
-                }
-            }
-            if (d_seq) (void)hipFree(d_seq);
-            if (d_out) (void)hipFree(d_out);
-            orow = nrows_out;
-            mi = length + 1 - m;
-        }
-    }
-    lm_hip_pssm_destroy(p);
-    if (st == LM_HIP_OK) {
-        if (out_rows) *out_rows = orow;
-        if (max_index) *max_index = mi;
-    }
-    return st;
-}
-
-static int stage_scores(lm_hip_ctx *ctx, const float *scores, size_t rows, size_t stride,
-                        float **d_scores)
-{
-    LM_HIP_TRY(hipMalloc(d_scores, rows * stride * sizeof(float)));
-    hipError_t e = hipMemcpyAsync(*d_scores, scores, rows * stride * sizeof(float),
-                                  hipMemcpyHostToDevice, ctx->stream);
-    if (e != hipSuccess) {
-        (void)hipFree(*d_scores);
-        return fail(LM_HIP_ERR_HIP, "score upload failed: %s", hipGetErrorString(e));
-    }
-    return LM_HIP_OK;
-}
-
-int lm_hip_argmax_f32(const float *scores, size_t rows, size_t stride, size_t cols, int *found,
-                      lm_hip_coords *best, float *value)
-{
-    if (!found)
-        return fail(LM_HIP_ERR_BAD_ARGS, "argmax: null argument");
-    *found = 0;
-    if (rows == 0)
-        return LM_HIP_OK;
-    if (!scores || cols == 0 || stride < cols)
-        return fail(LM_HIP_ERR_BAD_ARGS, "argmax: bad matrix");
-    lm_hip_ctx *ctx = nullptr;
-    LM_TRY(default_ctx(&ctx));
-    float *d = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        DeviceGuard guard(ctx->device);
-        LM_TRY(stage_scores(ctx, scores, rows, stride, &d));
-    }
-    const int st = lm_hip_argmax_f32_dptr(ctx, d, rows, stride, cols, found, best, value);
-    DeviceGuard guard(ctx->device);
-    (void)hipFree(d);
-    return st;
-}
-
-int lm_hip_max_f32(const float *scores, size_t rows, size_t stride, size_t cols, int *found, float *value)
-{
-    lm_hip_coords c{0, 0};
-    return lm_hip_argmax_f32(scores, rows, stride, cols, found, &c, value);
-}
-
-int lm_hip_threshold_f32(const float *scores, size_t rows, size_t stride, size_t cols, float t,
-                         lm_hip_coords **coords, size_t *n)
-{
-    if (!coords || !n)
-        return fail(LM_HIP_ERR_BAD_ARGS, "threshold: null argument");
-    *coords = nullptr;
-    *n = 0;
-    if (rows == 0)
-        return LM_HIP_OK;
-    if (!scores || cols == 0 || stride < cols)
-        return fail(LM_HIP_ERR_BAD_ARGS, "threshold: bad matrix");
-    lm_hip_ctx *ctx = nullptr;
-    LM_TRY(default_ctx(&ctx));
-    float *d = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        DeviceGuard guard(ctx->device);
-        LM_TRY(stage_scores(ctx, scores, rows, stride, &d));
-    }
-    const int st = lm_hip_threshold_f32_dptr(ctx, d, rows, stride, cols, t, coords, n);
-    DeviceGuard guard(ctx->device);
-    (void)hipFree(d);
-    return st;
 }
 
 }  // extern "C"

@@ -1,0 +1,578 @@
+// hostptr.hip -- the host-pointer entry points: what the reference-side shim binds.
+//
+//   lm_hip_score_f32      Score::score_rows_into on host matrices   (pli/mod.rs:72-106, avx2.rs:889-904)
+//   lm_hip_argmax_f32     StripedScores::argmax                     (scores.rs:181-186, pli/mod.rs:135-155)
+//   lm_hip_max_f32        StripedScores::max                        (scores.rs:188-192, pli/mod.rs:158-160)
+//   lm_hip_threshold_f32  StripedScores::threshold                  (scores.rs:207-213, pli/mod.rs:210-221)
+//
+// The caller's matrices are pageable host memory (a Rust Vec); every call moves 1 B per position up and 4 B per
+// position down over PCIe, so the link is the floor.  What this file is about is paying nothing else:
+//
+//  * LANES.  Every host thread that calls in gets a lane of its own -- a context (its own stream), device staging
+//    buffers that persist between calls, and a small cache of device-side PSSM tables keyed on the weights -- so the
+//    CLI's worker threads (main.rs:270) and GIL-released Python threads (lightmotif-py lib.rs:865) overlap instead of
+//    queueing on one context, and a loop over one motif (lightmotif-bench dna.rs:104-107) builds its tables once.
+//    A lane whose thread has exited is handed to the next new thread.
+//  * SMALL calls (the reference's own bench: 464 165 positions; a Scanner block: 256 rows) are latency-bound:
+//    one pageable copy up, one kernel, one pageable copy down, one synchronisation; no allocation, no table build.
+//    The tiniest (<= 128 KB each way) skip the copy commands altogether: the kernel reads the symbols from and writes
+//    the scores to pinned host memory (tools/kbench/hostpipe_bench.hip: 15.9 us against 27.8 us per iteration).
+//  * LARGE calls are link-bound and run as a three-stage pipeline over row tiles: an uploader thread copies tile
+//    t + 1 .. t + 3 (pageable H2D, 56 GB/s) while the store kernel of tile t runs and tile t - 1 travels back.  The
+//    way back is the long one (4 B per position): the runtime's pageable D2H reaches 48 GB/s, a copy into pinned
+//    memory 56.6 GB/s -- so tiles land in a ring of four pinned 32 MB buffers and four copier threads move them into
+//    the caller's matrix while the next tiles are in flight (measured: hostpipe_bench, profiles/r04_hostpipe_bench.txt).
+//    The ring, its streams and the device tile buffers exist once per process; a large call that finds them taken by
+//    another thread runs chunk by chunk on its own lane instead.
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <thread>
+
+#include "lm_internal.hpp"
+
+namespace lm {
+namespace {
+
+constexpr size_t kZeroCopyBytes = 128u << 10;   // tiniest calls: symbols / scores straight from / to pinned memory
+constexpr size_t kKeepBytes = 256u << 20;       // staging buffers above this are released when the call ends
+constexpr size_t kPipeMinOutBytes = 48u << 20;  // score matrices from here on take the tile pipeline
+constexpr size_t kTileBytes = 32u << 20;        // one tile of scores (and one pinned ring slot)
+constexpr int kInSlots = 3, kOutSlots = 4, kCopiers = 4;
+constexpr size_t kPssmCache = 16;
+
+struct CachedPssm {
+    uint64_t hash = 0, stamp = 0;
+    lm_hip_pssm *p = nullptr;
+};
+
+struct HostLane {
+    lm_hip_ctx *ctx = nullptr;
+    Scratch d_in, d_out;
+    uint8_t *zc = nullptr;  // 2 x kZeroCopyBytes, pinned and device-visible
+    std::vector<CachedPssm> pssms;
+    uint64_t stamp = 0;
+};
+
+// process lifetime (never destroyed: host threads may still be inside the library when the process exits)
+std::mutex &lanes_mu()
+{
+    static std::mutex *mu = new std::mutex();
+    return *mu;
+}
+std::vector<HostLane *> &idle_lanes()
+{
+    static std::vector<HostLane *> *v = new std::vector<HostLane *>();
+    return *v;
+}
+
+struct LaneRef {
+    HostLane *lane = nullptr;
+    ~LaneRef()
+    {
+        if (lane) {  // the thread is gone; its lane (stream idle: every call synchronises) serves the next one
+            std::lock_guard<std::mutex> lock(lanes_mu());
+            idle_lanes().push_back(lane);
+        }
+    }
+};
+thread_local LaneRef t_lane;
+
+int acquire_lane(HostLane **out)
+{
+    if (!t_lane.lane) {
+        {
+            std::lock_guard<std::mutex> lock(lanes_mu());
+            if (!idle_lanes().empty()) {
+                t_lane.lane = idle_lanes().back();
+                idle_lanes().pop_back();
+            }
+        }
+        if (!t_lane.lane) {
+            int dev = 0;
+            if (const char *e = getenv("LM_HIP_DEVICE"))
+                dev = atoi(e);
+            lm_hip_ctx *ctx = nullptr;
+            LM_TRY(lm_hip_ctx_create(dev, &ctx));
+            HostLane *lane = new (std::nothrow) HostLane();
+            if (!lane) {
+                lm_hip_ctx_destroy(ctx);
+                return fail(LM_HIP_ERR_OOM, "out of host memory");
+            }
+            lane->ctx = ctx;
+            DeviceGuard guard(ctx->device);
+            if (hipHostMalloc(reinterpret_cast<void **>(&lane->zc), 2 * kZeroCopyBytes, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                lane->zc = nullptr;  // tiny calls take the copy path then
+            }
+            t_lane.lane = lane;
+        }
+    }
+    *out = t_lane.lane;
+    return LM_HIP_OK;
+}
+
+uint64_t hash_weights(const float *w, size_t m, size_t stride, size_t k)
+{
+    uint64_t h = 0xcbf29ce484222325ull ^ (m * 0x9E3779B97F4A7C15ull) ^ (k << 48);
+    for (size_t j = 0; j < m; ++j)
+        for (size_t s = 0; s < k; ++s) {
+            uint32_t bits;
+            memcpy(&bits, &w[j * stride + s], 4);
+            h = (h ^ bits) * 0x100000001b3ull;
+        }
+    return h;
+}
+
+// The lane's device tables for this matrix: built on first sight, found again by hash + full comparison.
+int lane_pssm(HostLane *lane, const float *w, size_t m, size_t stride, size_t k, lm_hip_pssm **out)
+{
+    if (!w && m)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score: null pssm");
+    if (k == 0 || k > 256 || stride < k)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score: bad alphabet size %zu / pssm stride %zu", k, stride);
+    const uint64_t h = hash_weights(w, m, stride, k);
+    for (CachedPssm &e : lane->pssms) {
+        if (e.hash != h || e.p->m != m || e.p->k != k)
+            continue;
+        bool same = true;
+        for (size_t j = 0; j < m && same; ++j)
+            same = memcmp(&e.p->host[j * k], &w[j * stride], k * sizeof(float)) == 0;
+        if (same) {
+            e.stamp = ++lane->stamp;
+            *out = e.p;
+            return LM_HIP_OK;
+        }
+    }
+    if (lane->pssms.size() >= kPssmCache) {  // the stream is idle between calls: safe to destroy
+        size_t oldest = 0;
+        for (size_t i = 1; i < lane->pssms.size(); ++i)
+            if (lane->pssms[i].stamp < lane->pssms[oldest].stamp)
+                oldest = i;
+        lm_hip_pssm_destroy(lane->pssms[oldest].p);
+        lane->pssms.erase(lane->pssms.begin() + (long)oldest);
+    }
+    lm_hip_pssm *p = nullptr;
+    LM_TRY(lm_hip_pssm_create(lane->ctx, w, m, stride, k, &p));
+    lane->pssms.push_back(CachedPssm{h, ++lane->stamp, p});
+    *out = p;
+    return LM_HIP_OK;
+}
+
+void trim(Scratch &s)
+{
+    if (s.bytes > kKeepBytes)
+        s.release();
+}
+
+void copy_rows(char *dst, size_t dst_pitch, const char *src, size_t src_pitch, size_t width, size_t nrows)
+{
+    if (dst_pitch == width && src_pitch == width) {
+        memcpy(dst, src, width * nrows);
+        return;
+    }
+    for (size_t r = 0; r < nrows; ++r)
+        memcpy(dst + r * dst_pitch, src + r * src_pitch, width);
+}
+
+// ---- the tile pipeline of large calls ---------------------------------------------------------------------------------
+
+struct BigPipe {
+    std::mutex mu;  // one large call at a time
+    int device = -1;
+    hipStream_t s_up = nullptr, s_dn = nullptr;
+    hipEvent_t kdone[kInSlots] = {}, landed[kOutSlots] = {};
+    Scratch d_in, d_out;
+    char *pinned = nullptr;  // kOutSlots x kTileBytes
+};
+
+BigPipe &big_pipe()
+{
+    static BigPipe *bp = new BigPipe();
+    return *bp;
+}
+
+int pipe_prepare(BigPipe &bp, int device)
+{
+    if (bp.device == device)
+        return LM_HIP_OK;
+    if (bp.device >= 0)
+        return fail(LM_HIP_ERR_BAD_ARGS, "host-pointer calls use one device per process");
+    hipStream_t up = nullptr, dn = nullptr;
+    hipEvent_t ev[kInSlots + kOutSlots] = {};
+    char *pin = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
+    if (e == hipSuccess)
+        e = hipStreamCreateWithFlags(&dn, hipStreamNonBlocking);
+    for (int i = 0; i < kInSlots + kOutSlots && e == hipSuccess; ++i)
+        e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+    if (e == hipSuccess)
+        e = hipHostMalloc(reinterpret_cast<void **>(&pin), kOutSlots * kTileBytes, hipHostMallocDefault);
+    if (e != hipSuccess) {  // nothing half-made is kept
+        for (hipEvent_t x : ev)
+            if (x)
+                (void)hipEventDestroy(x);
+        if (up)
+            (void)hipStreamDestroy(up);
+        if (dn)
+            (void)hipStreamDestroy(dn);
+        return fail(e == hipErrorOutOfMemory ? LM_HIP_ERR_OOM : LM_HIP_ERR_HIP, "host pipeline set-up failed: %s",
+                    hipGetErrorString(e));
+    }
+    bp.s_up = up;
+    bp.s_dn = dn;
+    for (int i = 0; i < kInSlots; ++i)
+        bp.kdone[i] = ev[i];
+    for (int i = 0; i < kOutSlots; ++i)
+        bp.landed[i] = ev[kInSlots + i];
+    bp.pinned = pin;
+    bp.device = device;
+    return LM_HIP_OK;
+}
+
+// One pipelined job: `upload` (uploader thread; blocks until tile t is in input slot `slot`), `compute` (calling
+// thread: enqueues tile t's kernels on the lane's stream), `download` (calling thread: enqueues the copy of output
+// slot `slot` into the pinned slot on bp.s_dn) and `copy_out` (copier j of n: its share of tile t, pinned -> caller).
+struct TileJob {
+    size_t ntiles = 0;
+    std::function<hipError_t(size_t t, int slot)> upload;
+    std::function<int(size_t t, int in_slot, int out_slot)> compute;
+    std::function<hipError_t(size_t t, int slot)> download;
+    std::function<void(size_t t, int slot, int j, int n)> copy_out;
+};
+
+int run_pipeline(lm_hip_ctx *ctx, BigPipe &bp, const TileJob &job)
+{
+    struct Shared {
+        std::mutex mu;
+        std::condition_variable cv;
+        size_t uploaded = 0, launched = 0, issued = 0, copied = 0;
+        unsigned done[kOutSlots] = {};
+        int status = LM_HIP_OK;
+        char err[256] = "";
+    } sh;
+    auto raise = [&](int status, const char *what, hipError_t e) {
+        std::lock_guard<std::mutex> lock(sh.mu);
+        if (sh.status == LM_HIP_OK) {
+            sh.status = status;
+            snprintf(sh.err, sizeof sh.err, "%s failed: %s", what, hipGetErrorString(e));
+        }
+        sh.cv.notify_all();
+    };
+    const int device = ctx->device;
+    const size_t n = job.ntiles;
+    std::thread uploader([&] {
+        if (hipSetDevice(device) != hipSuccess)
+            return raise(LM_HIP_ERR_HIP, "hipSetDevice", hipGetLastError());
+        for (size_t t = 0; t < n; ++t) {
+            {   // input slot t % kInSlots was read by tile t - kInSlots: its kernel must have been launched ...
+                std::unique_lock<std::mutex> lock(sh.mu);
+                sh.cv.wait(lock, [&] { return sh.launched + kInSlots > t || sh.status != LM_HIP_OK; });
+                if (sh.status != LM_HIP_OK)
+                    return;
+            }
+            hipError_t e = t >= (size_t)kInSlots ? hipEventSynchronize(bp.kdone[t % kInSlots]) : hipSuccess;  // ... and have finished
+            if (e == hipSuccess)
+                e = job.upload(t, (int)(t % kInSlots));
+            if (e != hipSuccess)
+                return raise(e == hipErrorOutOfMemory ? LM_HIP_ERR_OOM : LM_HIP_ERR_HIP, "tile upload", e);
+            std::lock_guard<std::mutex> lock(sh.mu);
+            sh.uploaded = t + 1;
+            sh.cv.notify_all();
+        }
+    });
+    std::vector<std::thread> copiers;
+    for (int j = 0; j < kCopiers; ++j)
+        copiers.emplace_back([&, j] {
+            if (hipSetDevice(device) != hipSuccess)
+                return raise(LM_HIP_ERR_HIP, "hipSetDevice", hipGetLastError());
+            for (size_t t = 0; t < n; ++t) {
+                {
+                    std::unique_lock<std::mutex> lock(sh.mu);
+                    sh.cv.wait(lock, [&] { return sh.issued > t || sh.status != LM_HIP_OK; });
+                    if (sh.status != LM_HIP_OK)
+                        return;
+                }
+                const int slot = (int)(t % kOutSlots);
+                const hipError_t e = hipEventSynchronize(bp.landed[slot]);
+                if (e != hipSuccess)
+                    return raise(LM_HIP_ERR_HIP, "tile read-back", e);
+                job.copy_out(t, slot, j, kCopiers);
+                std::lock_guard<std::mutex> lock(sh.mu);
+                if (++sh.done[slot] == (unsigned)kCopiers) {
+                    sh.done[slot] = 0;
+                    sh.copied = t + 1;
+                    sh.cv.notify_all();
+                }
+            }
+        });
+    for (size_t t = 0; t < n; ++t) {
+        {   // tile t is on the device, and output slot t % kOutSlots (device + pinned) has been emptied into the caller's matrix
+            std::unique_lock<std::mutex> lock(sh.mu);
+            sh.cv.wait(lock, [&] { return (sh.uploaded > t && sh.copied + kOutSlots > t) || sh.status != LM_HIP_OK; });
+            if (sh.status != LM_HIP_OK)
+                break;
+        }
+        const int is = (int)(t % kInSlots), os = (int)(t % kOutSlots);
+        const int st = job.compute(t, is, os);
+        if (st != LM_HIP_OK) {
+            std::lock_guard<std::mutex> lock(sh.mu);
+            if (sh.status == LM_HIP_OK) {
+                sh.status = st;
+                snprintf(sh.err, sizeof sh.err, "%s", lm_hip_last_error());
+            }
+            sh.cv.notify_all();
+            break;
+        }
+        hipError_t e = hipEventRecord(bp.kdone[is], ctx->stream);
+        if (e == hipSuccess) {
+            std::lock_guard<std::mutex> lock(sh.mu);
+            sh.launched = t + 1;
+            sh.cv.notify_all();
+        }
+        if (e == hipSuccess)
+            e = hipStreamWaitEvent(bp.s_dn, bp.kdone[is], 0);
+        if (e == hipSuccess)
+            e = job.download(t, os);
+        if (e == hipSuccess)
+            e = hipEventRecord(bp.landed[os], bp.s_dn);
+        if (e != hipSuccess) {
+            raise(LM_HIP_ERR_HIP, "tile launch", e);
+            break;
+        }
+        std::lock_guard<std::mutex> lock(sh.mu);
+        sh.issued = t + 1;
+        sh.cv.notify_all();
+    }
+    uploader.join();
+    for (std::thread &c : copiers)
+        c.join();
+    // whatever happened, nothing may still be in flight into the ring or out of the tile buffers when this returns
+    (void)hipStreamSynchronize(bp.s_up);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(bp.s_dn);
+    if (sh.status != LM_HIP_OK)
+        return fail(sh.status, "%s", sh.err);
+    return LM_HIP_OK;
+}
+
+struct ScoreCall {
+    const lm_hip_pssm *p;
+    const uint8_t *seq;  // row `row_begin` of the caller's striped matrix
+    size_t seq_stride, cols, nrows, halo;
+    float *out;
+    size_t out_stride;
+};
+
+// Rows [r0, r1) of the call on the lane's own buffers: copy up, score, copy down (the copies of pageable memory
+// return when they are done), or for the tiniest pieces no copy command at all.
+int score_piece(HostLane *lane, const ScoreCall &c, size_t r0, size_t r1)
+{
+    lm_hip_ctx *ctx = lane->ctx;
+    const size_t w = r1 - r0, in_bytes = (w + c.halo) * c.seq_stride, out_bytes = w * c.cols * sizeof(float);
+    const uint8_t *src = c.seq + r0 * c.seq_stride;
+    float *dst = c.out + r0 * c.out_stride;
+    if (lane->zc && in_bytes <= kZeroCopyBytes && out_bytes <= kZeroCopyBytes) {
+        uint8_t *zin = lane->zc;
+        float *zout = reinterpret_cast<float *>(lane->zc + kZeroCopyBytes);
+        memcpy(zin, src, in_bytes);
+        ScoreArgs a{c.p, zin, c.seq_stride, c.cols, 0, w, zout, c.cols};
+        LM_TRY(launch_score_store(ctx, a));
+        LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        copy_rows(reinterpret_cast<char *>(dst), c.out_stride * sizeof(float), reinterpret_cast<const char *>(zout),
+                  c.cols * sizeof(float), c.cols * sizeof(float), w);
+        return LM_HIP_OK;
+    }
+    LM_TRY(lane->d_in.reserve(in_bytes + 64));
+    LM_TRY(lane->d_out.reserve(out_bytes));
+    uint8_t *d_in = static_cast<uint8_t *>(lane->d_in.ptr);
+    float *d_out = static_cast<float *>(lane->d_out.ptr);
+    LM_HIP_TRY(hipMemcpyAsync(d_in, src, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    ScoreArgs a{c.p, d_in, c.seq_stride, c.cols, 0, w, d_out, c.cols};
+    LM_TRY(launch_score_store(ctx, a));
+    // only the `cols` scored cells of each row: the caller's alignment padding is left as it was (pli/mod.rs:103)
+    LM_HIP_TRY(c.out_stride == c.cols
+                   ? hipMemcpyAsync(dst, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream)
+                   : hipMemcpy2DAsync(dst, c.out_stride * sizeof(float), d_out, c.cols * sizeof(float),
+                                      c.cols * sizeof(float), w, hipMemcpyDeviceToHost, ctx->stream));
+    LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return LM_HIP_OK;
+}
+
+int score_pipelined(HostLane *lane, BigPipe &bp, const ScoreCall &c)
+{
+    lm_hip_ctx *ctx = lane->ctx;
+    LM_TRY(pipe_prepare(bp, ctx->device));
+    // rows per tile: 32 MB of scores, at most 64 MB of symbols
+    size_t tr = std::min(kTileBytes / (c.cols * sizeof(float)), (2 * kTileBytes) / c.seq_stride);
+    tr = std::max<size_t>(tr / 256 * 256, 256);
+    const size_t in_tile = ((tr + c.halo) * c.seq_stride + 255) / 256 * 256, out_tile = tr * c.cols * sizeof(float);
+    if (out_tile > kTileBytes)  // (more than 32 K columns: not a shape this path is for)
+        return LM_HIP_ERR_CAPACITY;
+    LM_TRY(bp.d_in.reserve(kInSlots * in_tile + 64));
+    LM_TRY(bp.d_out.reserve(kOutSlots * out_tile));
+    uint8_t *d_in = static_cast<uint8_t *>(bp.d_in.ptr);
+    char *d_out = static_cast<char *>(bp.d_out.ptr);
+    TileJob job;
+    job.ntiles = (c.nrows + tr - 1) / tr;
+    auto width = [&](size_t t) { return std::min(tr, c.nrows - t * tr); };
+    job.upload = [&](size_t t, int slot) {
+        hipError_t e = hipMemcpyAsync(d_in + (size_t)slot * in_tile, c.seq + t * tr * c.seq_stride,
+                                      (width(t) + c.halo) * c.seq_stride, hipMemcpyHostToDevice, bp.s_up);
+        return e == hipSuccess ? hipStreamSynchronize(bp.s_up) : e;
+    };
+    job.compute = [&](size_t t, int is, int os) {
+        ScoreArgs a{c.p, d_in + (size_t)is * in_tile, c.seq_stride, c.cols, 0, width(t),
+                    reinterpret_cast<float *>(d_out + (size_t)os * out_tile), c.cols};
+        return launch_score_store(ctx, a);
+    };
+    job.download = [&](size_t t, int slot) {
+        return hipMemcpyAsync(bp.pinned + (size_t)slot * kTileBytes, d_out + (size_t)slot * out_tile,
+                              width(t) * c.cols * sizeof(float), hipMemcpyDeviceToHost, bp.s_dn);
+    };
+    job.copy_out = [&](size_t t, int slot, int j, int n) {
+        const size_t w = width(t), a = w * (size_t)j / (size_t)n, b = w * (size_t)(j + 1) / (size_t)n;
+        copy_rows(reinterpret_cast<char *>(c.out + (t * tr + a) * c.out_stride), c.out_stride * sizeof(float),
+                  bp.pinned + (size_t)slot * kTileBytes + a * c.cols * sizeof(float), c.cols * sizeof(float),
+                  c.cols * sizeof(float), b - a);
+    };
+    const int st = run_pipeline(ctx, bp, job);
+    trim(bp.d_in);
+    return st;
+}
+
+// The caller's score matrix on the device, dense (stride == cols): `*d` points into the lane's staging buffer.
+int stage_scores(HostLane *lane, const float *scores, size_t rows, size_t stride, size_t cols, const float **d)
+{
+    lm_hip_ctx *ctx = lane->ctx;
+    LM_TRY(lane->d_in.reserve(rows * cols * sizeof(float)));
+    float *dev = static_cast<float *>(lane->d_in.ptr);
+    LM_HIP_TRY(stride == cols ? hipMemcpyAsync(dev, scores, rows * cols * sizeof(float), hipMemcpyHostToDevice, ctx->stream)
+                              : hipMemcpy2DAsync(dev, cols * sizeof(float), scores, stride * sizeof(float),
+                                                 cols * sizeof(float), rows, hipMemcpyHostToDevice, ctx->stream));
+    *d = dev;
+    return LM_HIP_OK;
+}
+
+}  // namespace
+}  // namespace lm
+
+using namespace lm;
+
+extern "C" {
+
+int lm_hip_score_f32(const uint8_t *seq, size_t seq_rows_total, size_t seq_stride, size_t cols,
+                     size_t wrap, size_t length, const float *pssm, size_t m, size_t pssm_stride,
+                     size_t k, size_t row_begin, size_t row_end, float *out, size_t out_stride,
+                     size_t *out_rows, size_t *max_index)
+{
+    HostLane *lane = nullptr;
+    LM_TRY(acquire_lane(&lane));
+    lm_hip_ctx *ctx = lane->ctx;  // the lane is this thread's alone: nothing to lock
+    DeviceGuard guard(ctx->device);
+    lm_hip_pssm *p = nullptr;
+    LM_TRY(lane_pssm(lane, pssm, m, pssm_stride, k, &p));
+    LM_TRY(check_score_args(p, seq_rows_total, seq_stride, cols, wrap, row_begin, row_end));
+    if (length < m || row_begin >= row_end) {  // pli/mod.rs:85-88
+        if (out_rows) *out_rows = 0;
+        if (max_index) *max_index = 0;
+        return LM_HIP_OK;
+    }
+    if (!seq || !out || out_stride < cols)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score: null buffer or out stride %zu < columns %zu", out_stride, cols);
+    // only the rows the range needs travel: [row_begin, row_end + m - 1)
+    ScoreCall c{p, seq + row_begin * seq_stride, seq_stride, cols, row_end - row_begin, m ? m - 1 : 0, out, out_stride};
+    int st = LM_HIP_ERR_CAPACITY;
+    if (c.nrows * cols * sizeof(float) >= kPipeMinOutBytes) {
+        BigPipe &bp = big_pipe();
+        std::unique_lock<std::mutex> pipe(bp.mu, std::try_to_lock);
+        if (pipe.owns_lock())
+            st = score_pipelined(lane, bp, c);
+    }
+    if (st == LM_HIP_ERR_CAPACITY) {  // small, or the pipeline is serving another thread: piece by piece on this lane
+        const size_t piece = std::max<size_t>((64u << 20) / (cols * sizeof(float)), 1);
+        st = LM_HIP_OK;
+        for (size_t r0 = 0; r0 < c.nrows && st == LM_HIP_OK; r0 += piece)
+            st = score_piece(lane, c, r0, std::min(c.nrows, r0 + piece));
+        if (st != LM_HIP_OK)
+            (void)hipStreamSynchronize(ctx->stream);
+        trim(lane->d_in);
+        trim(lane->d_out);
+    }
+    if (st != LM_HIP_OK)
+        return st;
+    if (out_rows) *out_rows = c.nrows;       // pli/mod.rs:91
+    if (max_index) *max_index = length + 1 - m;
+    return LM_HIP_OK;
+}
+
+int lm_hip_argmax_f32(const float *scores, size_t rows, size_t stride, size_t cols, int *found,
+                      lm_hip_coords *best, float *value)
+{
+    if (!found)
+        return fail(LM_HIP_ERR_BAD_ARGS, "argmax: null argument");
+    *found = 0;
+    if (rows == 0)  // pli/mod.rs:136-138
+        return LM_HIP_OK;
+    if (!scores || cols == 0 || stride < cols)
+        return fail(LM_HIP_ERR_BAD_ARGS, "argmax: bad matrix");
+    HostLane *lane = nullptr;
+    LM_TRY(acquire_lane(&lane));
+    lm_hip_ctx *ctx = lane->ctx;  // the lane is this thread's alone: nothing to lock
+    DeviceGuard guard(ctx->device);
+    const float *d = nullptr;
+    ArgmaxRecord rec{};
+    int st = stage_scores(lane, scores, rows, stride, cols, &d);
+    if (st == LM_HIP_OK)
+        st = launch_argmax(ctx, d, rows, cols, cols, 1, &rec);
+    if (st != LM_HIP_OK)
+        (void)hipStreamSynchronize(ctx->stream);
+    trim(lane->d_in);
+    if (st != LM_HIP_OK)
+        return st;
+    *found = rec.found;
+    if (rec.found) {
+        if (best) {
+            best->row = (size_t)(rec.index / (long long)cols);
+            best->col = (size_t)(rec.index % (long long)cols);
+        }
+        if (value)
+            *value = rec.value;
+    }
+    return LM_HIP_OK;
+}
+
+int lm_hip_max_f32(const float *scores, size_t rows, size_t stride, size_t cols, int *found, float *value)
+{
+    lm_hip_coords c{0, 0};
+    return lm_hip_argmax_f32(scores, rows, stride, cols, found, &c, value);
+}
+
+int lm_hip_threshold_f32(const float *scores, size_t rows, size_t stride, size_t cols, float t,
+                         lm_hip_coords **coords, size_t *n)
+{
+    if (!coords || !n)
+        return fail(LM_HIP_ERR_BAD_ARGS, "threshold: null argument");
+    *coords = nullptr;
+    *n = 0;
+    if (rows == 0)
+        return LM_HIP_OK;
+    if (!scores || cols == 0 || stride < cols)
+        return fail(LM_HIP_ERR_BAD_ARGS, "threshold: bad matrix");
+    HostLane *lane = nullptr;
+    LM_TRY(acquire_lane(&lane));
+    lm_hip_ctx *ctx = lane->ctx;  // the lane is this thread's alone: nothing to lock
+    DeviceGuard guard(ctx->device);
+    const float *d = nullptr;
+    int st = stage_scores(lane, scores, rows, stride, cols, &d);
+    if (st == LM_HIP_OK)
+        st = launch_threshold(ctx, d, rows, cols, cols, t, coords, n);
+    if (st != LM_HIP_OK)
+        (void)hipStreamSynchronize(ctx->stream);
+    trim(lane->d_in);
+    return st;
+}
+
+}  // extern "C"

@@ -212,6 +212,10 @@ struct ScoreArgs {
     unsigned *track_nrec = nullptr;
 };
 
+// Geometry checks shared by every score entry point (avx2.rs:832-837: the wrap check; row range inside the matrix)
+int check_score_args(const lm_hip_pssm *pssm, size_t seq_rows_total, size_t seq_stride, size_t cols, size_t wrap,
+                     size_t row_begin, size_t row_end);
+
 // Materialising score kernels.
 int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a);
 

@@ -1,0 +1,298 @@
+"""The literal drop-in path: the host-pointer entry points a reference-side shim binds --
+`lm_hip_score_f32`, `lm_hip_argmax_f32`, `lm_hip_max_f32`, `lm_hip_threshold_f32`, `lm_hip_score_u8` -- against
+the oracle, bit for bit, over every route inside `csrc/hostptr.hip`: zero-copy (tiny), copy (small), the tile
+pipeline (large, several tiles, ragged last tile), the piecewise fallback when the pipeline is taken, row ranges,
+`out_stride != cols`, column counts other than 32, protein, the per-thread PSSM cache and its eviction, and host
+threads calling in concurrently (pwm/mod.rs:640-648, scores.rs:181-213, avx2.rs:889-904, scan.rs:174-178)."""
+import ctypes as C
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import lightmotif_amd as lm
+from lightmotif_amd import _ffi
+from oracle import c_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def random_pssm(rng, m, k, kind="normal"):
+    p = np.zeros((m, co.stride(k, 4)), np.float32)
+    p[:, :k] = rng.integers(-2, 3, (m, k)) if kind == "ties" else rng.normal(0, 2, (m, k))
+    p[:, k - 1] = -np.inf
+    return p
+
+
+def aligned(p):
+    q = co.aligned_empty(p.shape, np.float32)
+    q[:] = p
+    return q
+
+
+def host_score(s, p, k, a, b, out_stride=None, sentinel=None):
+    """lm_hip_score_f32 on the oracle's own striped matrix; returns (out incl. padding columns, out_rows, max_index)"""
+    L = _ffi.lib()
+    cols = s.cols
+    ost = co.stride(cols, 4) if out_stride is None else out_stride
+    out = np.full((max(b - a, 0), ost), np.float32(777.0) if sentinel is None else sentinel, np.float32)
+    orow, omi = C.c_size_t(123), C.c_size_t(456)
+    st = L.lm_hip_score_f32(s.data.ctypes.data, s.data.shape[0], s.stride, cols, s.wrap, s.length, p.ctypes.data,
+                            p.shape[0], p.shape[1], k, a, b, out.ctypes.data, ost, C.byref(orow), C.byref(omi))
+    assert st == 0, _ffi.last_error()
+    return out, orow.value, omi.value
+
+
+def host_argmax(scores, rows, stride, cols):
+    L = _ffi.lib()
+    found, best, val = C.c_int(0), _ffi.Coords(), C.c_float(0)
+    assert L.lm_hip_argmax_f32(scores.ctypes.data, rows, stride, cols, C.byref(found), C.byref(best), C.byref(val)) == 0, \
+        _ffi.last_error()
+    return ((best.row, best.col), np.float32(val.value)) if found.value else None
+
+
+def host_threshold(scores, rows, stride, cols, t):
+    L = _ffi.lib()
+    ptr, n = C.POINTER(_ffi.Coords)(), C.c_size_t(0)
+    assert L.lm_hip_threshold_f32(scores.ctypes.data, rows, stride, cols, t, C.byref(ptr), C.byref(n)) == 0, _ffi.last_error()
+    got = np.array([(ptr[i].row, ptr[i].col) for i in range(n.value)], dtype=np.uintp).reshape(-1, 2)
+    L.lm_hip_free(ptr)
+    return got
+
+
+def striped(rng, length, cols, k, m):
+    enc = rng.integers(0, k - 1, length, dtype=np.uint8)
+    enc[rng.random(length) < 0.001] = k - 1
+    s = co.stripe(enc, cols, k)
+    co.configure_wrap(s, m - 1)
+    return s
+
+
+@pytest.mark.parametrize("length,cols,k,m,rows", [
+    (6_000, 32, 5, 15, None),            # tiny: 188 rows -- symbols and scores through pinned memory, no copy command
+    (32_768 - 40, 32, 5, 20, None),      # the largest zero-copy shape (1023 rows)
+    (32_768 + 64, 32, 5, 20, None),      # just beyond it: the copy path
+    (464_165, 32, 5, 15, None),          # the reference's own bench size (dna.rs:81-109)
+    (464_165, 32, 5, 15, (1000, 9000)),  # a row range (Score::score_rows_into)
+    (200_000, 32, 21, 12, None),         # protein, wide-alphabet kernels
+    (150_000, 20, 5, 9, (7, 4000)),      # 20 columns: stride 32 in, 24 out; generic / tiled kernels
+    (90_000, 1, 5, 15, None),            # C = 1 (lightmotif-bench's Generic geometry)
+    (500_000, 32, 5, 40, None),          # the long kernel family
+])
+def test_score_f32_matches_oracle(length, cols, k, m, rows):
+    rng = np.random.default_rng(length + cols + m)
+    s = striped(rng, length, cols, k, m)
+    p = random_pssm(rng, m, k)
+    a, b = (0, s.rows) if rows is None else rows
+    want, mi = co.score_rows(s, p, a, b)
+    got, orow, omi = host_score(s, p, k, a, b)
+    assert (orow, omi) == (b - a, mi)
+    assert np.array_equal(bits(got[:, :cols]), bits(want[:, :cols]))
+    assert np.all(got[:, cols:] == 777.0), "alignment padding of the caller's rows was written (pli/mod.rs:103 leaves it)"
+    am = host_argmax(got, b - a, got.shape[1], cols)
+    assert am[0] == co.argmax(want, cols) and bits(am[1]) == bits(co.max_(want, cols))
+    t = float(np.sort(want[:, :cols][np.isfinite(want[:, :cols])])[-50])
+    assert np.array_equal(host_threshold(got, b - a, got.shape[1], cols, t), co.threshold(want, cols, t))
+
+
+@pytest.mark.parametrize("out_stride", [32, 40])
+def test_pipeline_tiles_row_range_and_out_stride(out_stride):
+    """Large enough for the tile pipeline (3 full tiles of 262 144 rows + a ragged one), a row range that starts inside
+    the matrix, the caller's rows wider than the scored columns: every tile boundary must be seamless."""
+    rng = np.random.default_rng(out_stride)
+    m, rows_total = 20, 262_144 * 3 + 5_000
+    length = rows_total * 32 - 11
+    s = striped(rng, length, 32, 5, m)
+    p = random_pssm(rng, m, 5)
+    a, b = 1_234, rows_total - 321
+    want = co.aligned_empty((b - a, 32), np.float32)
+    co.avx2_score_rows(s, aligned(p), out=want, row_begin=a, row_end=b, threads=8)  # == Generic bitwise (test_oracle_golden)
+    chk, _ = co.score_rows(s, p, a, a + 2_000)
+    assert np.array_equal(bits(chk[:, :32]), bits(want[:2_000]))
+    got, orow, omi = host_score(s, p, 5, a, b, out_stride=out_stride)
+    assert (orow, omi) == (b - a, length + 1 - m)
+    assert np.array_equal(bits(got[:, :32]), bits(want))
+    if out_stride > 32:
+        assert np.all(got[:, 32:] == 777.0)
+    # the reductions on the same host matrix (4 B per cell up): dense or padded rows
+    am = host_argmax(got, b - a, out_stride, 32)
+    assert am[0] == co.argmax(want, 32)
+    t = float(np.partition(want[np.isfinite(want)], -300)[-300])
+    assert np.array_equal(host_threshold(got, b - a, out_stride, 32, t), co.threshold(want, 32, t))
+
+
+def test_pssm_cache_alternating_motifs_and_eviction():
+    """One thread, many matrices: the lane keeps the device tables of the last 16 -- alternating between matrices of the
+    same shape, more than 16 distinct ones, and a matrix that differs from a cached one in a single weight."""
+    rng = np.random.default_rng(4)
+    s = striped(rng, 70_000, 32, 5, 33)
+    motifs = [random_pssm(rng, m, 5) for m in (8, 8, 12, 15, 20, 20, 24, 33)] + [random_pssm(rng, 11, 5) for _ in range(14)]
+    twin = motifs[4].copy()
+    twin[7, 2] = np.nextafter(twin[7, 2], np.float32(np.inf))
+    motifs.append(twin)
+    wants = [co.score_rows(s, p)[0] for p in motifs]
+    order = list(range(len(motifs))) * 2 + [4, len(motifs) - 1, 4, 0, 1, 0, 1]
+    for i in order:
+        got, _, _ = host_score(s, motifs[i], 5, 0, s.rows)
+        assert np.array_equal(bits(got[:, :32]), bits(wants[i][:, :32])), i
+
+
+def test_threads_are_bit_exact_and_overlap():
+    """Eight host threads (the CLI's `-j`, main.rs:270; Python threads with the GIL released, lib.rs:865) call the
+    host-pointer functions at once: each gets a lane of its own, results stay bit-identical, and the wall time is well
+    under the same calls made one after the other."""
+    L = _ffi.lib()
+    rng = np.random.default_rng(8)
+    nthreads, m, iters = 8, 15, 60
+    jobs = []
+    for t in range(nthreads):
+        s = striped(rng, 464_165 + 1000 * t, 32, 5, m)
+        p = random_pssm(rng, m, 5)
+        want, _ = co.score_rows(s, p)
+        jobs.append((s, p, want, np.zeros((s.rows, 32), np.float32)))
+
+    def work(job, n):
+        s, p, want, out = job
+        orow, omi = C.c_size_t(0), C.c_size_t(0)
+        found, best, val = C.c_int(0), _ffi.Coords(), C.c_float(0)
+        for _ in range(n):
+            st = L.lm_hip_score_f32(s.data.ctypes.data, s.data.shape[0], 32, 32, s.wrap, s.length, p.ctypes.data, m, p.shape[1],
+                                    5, 0, s.rows, out.ctypes.data, 32, C.byref(orow), C.byref(omi))
+            assert st == 0
+            assert L.lm_hip_argmax_f32(out.ctypes.data, s.rows, 32, 32, C.byref(found), C.byref(best), C.byref(val)) == 0
+        job_best.append(((best.row, best.col), co.argmax(want, 32)))
+
+    job_best = []
+    for j in jobs:                                   # warm: lanes of the main thread, tables, clocks
+        work(j, 3)
+    t0 = time.perf_counter()
+    for j in jobs:
+        work(j, iters)
+    serial = time.perf_counter() - t0
+    for *_, out in jobs:
+        out[:] = 0
+    job_best.clear()
+    th = [threading.Thread(target=work, args=(j, 3)) for j in jobs]   # warm the threads' own lanes
+    [x.start() for x in th]
+    [x.join() for x in th]
+    job_best.clear()
+    th = [threading.Thread(target=work, args=(j, iters)) for j in jobs]
+    t0 = time.perf_counter()
+    [x.start() for x in th]
+    [x.join() for x in th]
+    parallel = time.perf_counter() - t0
+    assert len(job_best) == nthreads and all(g == w for g, w in job_best)
+    for s, p, want, out in jobs:
+        assert np.array_equal(bits(out), bits(want[:, :32]))
+    print(f"8 threads: serial {serial * 1e3:.1f} ms, parallel {parallel * 1e3:.1f} ms, ratio {parallel / serial:.2f}")
+    assert parallel < 0.6 * serial, (serial, parallel)
+
+
+def test_two_large_calls_at_once():
+    """Two threads enter with pipeline-sized matrices at the same moment: one takes the pinned ring, the other runs piece
+    by piece on its own lane -- both bit-exact."""
+    rng = np.random.default_rng(21)
+    m = 20
+    jobs = []
+    for t in range(2):
+        rows = 262_144 * 2 + 999 + t
+        s = striped(rng, rows * 32 - 5, 32, 5, m)
+        p = random_pssm(rng, m, 5)
+        want = co.aligned_empty((rows, 32), np.float32)
+        co.avx2_score_rows(s, aligned(p), out=want, row_end=rows, threads=8)
+        jobs.append((s, p, want))
+    res = [None, None]
+
+    def work(i):
+        s, p, _ = jobs[i]
+        res[i] = host_score(s, p, 5, 0, s.rows)[0]
+    for _ in range(2):
+        th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        [x.start() for x in th]
+        [x.join() for x in th]
+        for i in range(2):
+            assert np.array_equal(bits(res[i]), bits(jobs[i][2]))
+
+
+def test_errors_leave_the_lane_usable():
+    L = _ffi.lib()
+    rng = np.random.default_rng(2)
+    s = striped(rng, 40_000, 32, 5, 10)            # 9 wrap rows
+    p20, p10 = random_pssm(rng, 20, 5), random_pssm(rng, 10, 5)
+    out = np.zeros((s.rows, 32), np.float32)
+    orow, omi = C.c_size_t(0), C.c_size_t(0)
+
+    def call(p, a, b, seq_ptr=None, out_ptr=None, out_stride=32):
+        return L.lm_hip_score_f32(s.data.ctypes.data if seq_ptr is None else seq_ptr, s.data.shape[0], 32, 32, s.wrap, s.length,
+                                  p.ctypes.data, p.shape[0], p.shape[1], 5, a, b, out.ctypes.data if out_ptr is None else out_ptr,
+                                  out_stride, C.byref(orow), C.byref(omi))
+    assert call(p20, 0, s.rows) == _ffi.ERR_WRAP                       # avx2.rs:832-837
+    assert b"wrapping rows" in L.lm_hip_last_error()
+    assert call(p10, 0, s.rows + 1) == _ffi.ERR_BAD_ARGS               # rows past the sequence
+    assert call(p10, 0, s.rows, out_stride=16) == _ffi.ERR_BAD_ARGS    # rows narrower than the columns
+    assert call(p10, 0, s.rows, out_ptr=0) == _ffi.ERR_BAD_ARGS
+    assert call(p10, 5, 5) == 0 and (orow.value, omi.value) == (0, 0)  # empty range: Ok, resized to nothing (pli/mod.rs:85-88)
+    assert call(p10, 0, s.rows) == 0
+    want, mi = co.score_rows(s, p10)
+    assert (orow.value, omi.value) == (s.rows, mi) and np.array_equal(bits(out), bits(want[:, :32]))
+
+
+def test_reductions_on_special_values_and_padded_rows():
+    rng = np.random.default_rng(6)
+    sc = rng.normal(0, 3, (5_000, 40)).astype(np.float32)
+    sc[rng.random(sc.shape) < 0.01] = -np.inf
+    sc[17, 3] = sc[4_000, 31] = sc[:, :32].max() + 1                    # tie: the LAST maximal cell wins (pli/mod.rs:146)
+    sc[:, 32:] = np.inf                                                 # padding must never be looked at
+    dense = np.ascontiguousarray(sc[:, :32])
+    assert host_argmax(sc, 5_000, 40, 32)[0] == co.argmax(dense, 32) == (4_000, 31)
+    assert np.array_equal(host_threshold(sc, 5_000, 40, 32, 6.0), co.threshold(dense, 32, 6.0))
+    sc[0, 0] = np.nan                                                   # NaN first cell -> (0, 0) (pli/mod.rs:142-146)
+    got = host_argmax(sc, 5_000, 40, 32)
+    assert got[0] == (0, 0) and np.isnan(got[1])
+    sc[0, 0], sc[9, 9] = 0.0, np.nan                                    # NaN elsewhere never wins
+    assert host_argmax(sc, 5_000, 40, 32)[0] == (4_000, 31)
+    assert len(host_threshold(sc, 5_000, 40, 32, float("-inf"))) == 5_000 * 32 - 1   # all but the NaN cell
+
+
+def test_large_reduction_inputs_release_their_staging():
+    """A 320 MB host matrix (above the 256 MB a lane keeps): uploaded, reduced, staging released -- and again."""
+    rng = np.random.default_rng(12)
+    rows = 2_500_000
+    sc = rng.normal(0, 1, (rows, 32)).astype(np.float32)
+    sc[1_999_999, 7] = 50.0
+    sc[2_400_000, 1] = 50.0
+    for _ in range(2):
+        assert host_argmax(sc, rows, 32, 32)[0] == (2_400_000, 1)
+        got = host_threshold(sc, rows, 32, 32, 49.0)
+        assert [tuple(map(int, x)) for x in got] == [(1_999_999, 7), (2_400_000, 1)]
+
+
+@pytest.mark.parametrize("out_stride", [32, 48])
+def test_score_u8_scanner_blocks(pli, out_stride):
+    """Scanner::next's inner call (scan.rs:174-178): u8 scores of 256-row blocks into the caller's host matrix -- the
+    kernel writes pinned memory directly; also a last, shorter block and rows wider than the columns."""
+    L = _ffi.lib()
+    rng = np.random.default_rng(31)
+    m = 15
+    enc = rng.integers(0, 4, 100_000, dtype=np.uint8)
+    s = co.stripe(enc, 32, 5)
+    co.configure_wrap(s, m - 1)
+    seq = pli.stripe(lm.EncodedSequence(enc))
+    seq.configure_wrap(m - 1)
+    w = np.zeros((m, 32), np.uint8)
+    w[:, :5] = rng.integers(0, 14, (m, 5))
+    want, mi = co.score_rows_u8(s, w)
+    orow, omi = C.c_size_t(0), C.c_size_t(0)
+    for a in list(range(0, s.rows, 256)):
+        b = min(a + 256, s.rows)
+        out = np.full((b - a, out_stride), 99, np.uint8)
+        st = L.lm_hip_score_u8(pli._h, w.ctypes.data, m, 32, 5, seq._h, a, b, 0, out.ctypes.data, out_stride,
+                               C.byref(orow), C.byref(omi))
+        assert st == 0, _ffi.last_error()
+        assert (orow.value, omi.value) == (b - a, mi)
+        assert np.array_equal(out[:, :32], want[a:b, :32]) and np.all(out[:, 32:] == 99)

@@ -1,0 +1,221 @@
+"""The literal drop-in path, timed: the host-pointer entry points the Rust shim binds on
+pageable host buffers -- `lm_hip_score_f32`, `lm_hip_argmax_f32`, `lm_hip_threshold_f32`, `lm_hip_score_u8`.
+
+  c1        lightmotif-bench/dna.rs:104-107 as is: score + argmax per iteration on host matrices (464 165 bp, M = 15),
+            next to the 1-thread AVX2 port of the same loop
+  block     Scanner's 256-row block (scan.rs:174-178): lm_hip_score_u8 into a host StripedScores<u8>
+  big       1 Gbp x M = 20 through lm_hip_score_f32: ms, Gpos/s, link GB/s
+  threads   8 host threads, one 50 Mbp call each, against the same calls one after the other
+
+    python tools/host_pointer_bench.py [--json out.json] [--big 1000000000]
+"""
+import argparse
+import ctypes as C
+import json
+import sys
+import threading
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import lightmotif_amd as lm  # noqa: E402
+from lightmotif_amd import _ffi  # noqa: E402
+
+L = _ffi.lib()
+COLS = 32
+
+
+def striped(enc: np.ndarray, m: int, k: int = 5):
+    """host StripedSequence matrix (rows + m - 1, 32) of encoded symbols, wrap rows configured (seq.rs:369-381)"""
+    length = len(enc)
+    rows = -(-length // COLS)
+    pad = np.full(rows * COLS, k - 1, np.uint8)
+    pad[:length] = enc
+    mat = np.empty((rows + m - 1, COLS), np.uint8)
+    mat[:rows] = pad.reshape(COLS, rows).T
+    mat[rows:, :COLS - 1] = mat[:m - 1, 1:]
+    mat[rows:, COLS - 1] = k - 1
+    return mat, rows, length
+
+
+def score_f32(mat, rows, length, pssm, out, row_begin=0, row_end=None):
+    orow, mi = C.c_size_t(0), C.c_size_t(0)
+    m = pssm.shape[0]
+    st = L.lm_hip_score_f32(mat.ctypes.data, mat.shape[0], COLS, COLS, mat.shape[0] - rows, length, pssm.ctypes.data, m,
+                            pssm.shape[1], 5, row_begin, rows if row_end is None else row_end, out.ctypes.data, out.shape[1],
+                            C.byref(orow), C.byref(mi))
+    assert st == 0, _ffi.last_error()
+    return orow.value, mi.value
+
+
+def argmax_f32(scores, rows):
+    found, best, value = C.c_int(0), _ffi.Coords(), C.c_float(0)
+    st = L.lm_hip_argmax_f32(scores.ctypes.data, rows, scores.shape[1], COLS, C.byref(found), C.byref(best), C.byref(value))
+    assert st == 0, _ffi.last_error()
+    return (best.row, best.col) if found.value else None
+
+
+def loop_us(fn, reps, warm):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)) * 1e6, float(np.min(ts)) * 1e6
+
+
+def bench_c1():
+    from oracle import c_oracle as co
+    length = 464_165
+    rng = np.random.default_rng(0xEC011)
+    enc = rng.integers(0, 4, length, dtype=np.uint8)
+    enc[391_677:391_677 + 15] = lm.EncodedSequence("GTTGACCTTATCAAC").data
+    pssm = lm.create(["GTTGACCTTATCAAC", "GTTGATCCAGTCAAC"]).counts.normalize(0.1).log_odds().data
+    m = pssm.shape[0]
+    mat, rows, _ = striped(enc, m)
+    out = co.aligned_empty((rows, COLS), np.float32)
+    best = [None]
+
+    def it():
+        score_f32(mat, rows, length, pssm, out)
+        best[0] = argmax_f32(out, rows)
+    med, mn = loop_us(it, 300, 30)
+    s_med, _ = loop_us(lambda: score_f32(mat, rows, length, pssm, out), 300, 30)
+    a_med, _ = loop_us(lambda: argmax_f32(out, rows), 300, 30)
+    pos = best[0][1] * rows + best[0][0]
+    # the AVX2 port, one thread, same loop (avx2.rs:104-199 + 351-426)
+    data = co.aligned_empty(mat.shape, np.uint8)
+    data[:] = mat
+    s = co.Striped(data, length, m - 1, COLS, 5)
+    p = co.aligned_empty(pssm.shape, np.float32)
+    p[:] = pssm
+    cout = co.aligned_empty((rows, COLS), np.float32)
+
+    def cpu_it():
+        co.avx2_score_rows(s, p, out=cout, row_end=rows, threads=1)
+        co.avx2_argmax(cout, length + 1 - m)
+    c_med, c_min = loop_us(cpu_it, 100, 10)
+    same = bool(np.array_equal(cout.view(np.uint32), out.view(np.uint32)))
+    return {"host_pointer_us_per_iter": round(med, 1), "host_pointer_us_min": round(mn, 1), "score_f32_us": round(s_med, 1),
+            "argmax_f32_us": round(a_med, 1), "best_position": int(pos), "avx2_port_1_thread_us_per_iter": round(c_med, 1),
+            "avx2_port_1_thread_us_min": round(c_min, 1), "scores_match_avx2_port_bitwise": same,
+            "x_avx2_port": round(c_med / med, 2)}
+
+
+def bench_block():
+    """Scanner::next's inner step (scan.rs:174-178): pli.score_rows_into(&dm, seq, row..row+256, &mut dscores) -- u8 scores of
+    one 256-row block land in the caller's host matrix"""
+    length, m = 10_000_000, 15
+    rng = np.random.default_rng(3)
+    enc = rng.integers(0, 4, length, dtype=np.uint8)
+    pli = lm.Pipeline.hip(0)
+    seq = pli.stripe(lm.EncodedSequence(enc))
+    pssm = lm.create(["GTTGACCTTATCAAC", "GTTGATCCAGTCAAC"]).counts.normalize(0.1).log_odds()
+    seq.configure(pssm)
+    w = rng.integers(0, 12, (m, 32), dtype=np.uint8)     # a DenseMatrix<u8, K> with its 32-byte rows
+    out = np.zeros((256, COLS), np.uint8)
+    orow, mi = C.c_size_t(0), C.c_size_t(0)
+    row = [0]
+
+    def it():
+        st = L.lm_hip_score_u8(pli._h, w.ctypes.data, m, 32, 5, seq._h, row[0], row[0] + 256, 1, out.ctypes.data, COLS,
+                               C.byref(orow), C.byref(mi))
+        assert st == 0, _ffi.last_error()
+        row[0] = (row[0] + 256) % (seq.rows - 256)
+    med, mn = loop_us(it, 1000, 100)
+    return {"scanner_block_us": round(med, 2), "scanner_block_us_min": round(mn, 2), "rows": 256}
+
+
+def bench_big(length: int, m: int = 20):
+    rng = np.random.default_rng(0)
+    rows = -(-length // COLS)
+    mat = rng.integers(0, 4, (rows + m - 1, COLS), dtype=np.uint8)
+    mat[rows:, :31] = mat[:m - 1, 1:]
+    mat[rows:, 31] = 4
+    sites = ["".join("ACTG"[i] for i in rng.integers(0, 4, m)) for _ in range(10)]
+    pssm = lm.create(sites).counts.normalize(0.1).log_odds().data
+    out = np.zeros((rows, COLS), np.float32)
+    score_f32(mat, rows, length, pssm, out)
+    ts = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        score_f32(mat, rows, length, pssm, out)
+        ts.append(time.perf_counter() - t0)
+    t = min(ts)
+    # spot check against the resident path
+    pli = lm.Pipeline.hip(0)
+    chk = min(rows, 1 << 16)
+    from oracle import c_oracle as co
+    s = co.Striped(np.ascontiguousarray(mat[:chk + m - 1]), length, m - 1, COLS, 5)
+    want, _ = co.score_rows(s, pssm, 0, chk)
+    ok = bool(np.array_equal(want.view(np.uint32), out[:chk].view(np.uint32)))
+    tail = co.Striped(np.ascontiguousarray(mat[rows - chk:]), length, m - 1, COLS, 5)
+    want_t, _ = co.score_rows(tail, pssm, 0, chk)
+    ok = ok and bool(np.array_equal(want_t.view(np.uint32), out[rows - chk:].view(np.uint32)))
+    del pli
+    return {"length": length, "host_pointer_ms": round(t * 1e3, 2), "gpos": round(length / t / 1e9, 2),
+            "link_gbs": round(5 * rows * COLS / t / 1e9, 1), "d2h_gbs": round(4 * rows * COLS / t / 1e9, 1),
+            "head_and_tail_match_oracle": ok, "all_ms": [round(x * 1e3, 2) for x in ts]}, (mat, rows, pssm, out)
+
+
+def bench_threads(nthreads: int = 8, length: int = 50_000_000, m: int = 20):
+    rng = np.random.default_rng(9)
+    rows = -(-length // COLS)
+    sites = ["".join("ACTG"[i] for i in rng.integers(0, 4, m)) for _ in range(10)]
+    pssm = lm.create(sites).counts.normalize(0.1).log_odds().data
+    jobs = []
+    for t in range(nthreads):
+        mat = rng.integers(0, 4, (rows + m - 1, COLS), dtype=np.uint8)
+        mat[rows:, :31] = mat[:m - 1, 1:]
+        mat[rows:, 31] = 4
+        jobs.append((mat, np.zeros((rows, COLS), np.float32)))
+    for mat, out in jobs:
+        score_f32(mat, rows, length, pssm, out)
+    ref = [out.copy() for _, out in jobs[:2]]
+    t0 = time.perf_counter()
+    for mat, out in jobs:
+        score_f32(mat, rows, length, pssm, out)
+    serial = time.perf_counter() - t0
+    for _, out in jobs:
+        out[:] = 0
+    th = [threading.Thread(target=score_f32, args=(mat, rows, length, pssm, out)) for mat, out in jobs]
+    t0 = time.perf_counter()
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    par = time.perf_counter() - t0
+    same = all(np.array_equal(r.view(np.uint32), jobs[i][1].view(np.uint32)) for i, r in enumerate(ref))
+    return {"threads": nthreads, "length_each": length, "serial_ms": round(serial * 1e3, 1), "parallel_ms": round(par * 1e3, 1),
+            "parallel_over_serial": round(par / serial, 3), "bit_identical": bool(same)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--json", default="")
+    ap.add_argument("--big", type=int, default=1_000_000_000)
+    ap.add_argument("--skip", default="")
+    a = ap.parse_args()
+    res = {}
+    if "c1" not in a.skip:
+        res["c1"] = bench_c1()
+        print(json.dumps({"c1": res["c1"]}), flush=True)
+    if "block" not in a.skip:
+        res["scanner_block"] = bench_block()
+        print(json.dumps({"scanner_block": res["scanner_block"]}), flush=True)
+    if "threads" not in a.skip:
+        res["threads"] = bench_threads()
+        print(json.dumps({"threads": res["threads"]}), flush=True)
+    if "big" not in a.skip:
+        res["end_to_end"], _ = bench_big(a.big)
+        print(json.dumps({"end_to_end": res["end_to_end"]}), flush=True)
+    if a.json:
+        Path(a.json).write_text(json.dumps(res, indent=1) + "\n")
+
+
+if __name__ == "__main__":
+    main()
