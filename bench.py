@@ -218,6 +218,15 @@ def cpu_baseline(seq_sample: np.ndarray, length: int, pssm: np.ndarray, gpu_scor
 
     one = run(1, seconds / 2)
     allc = run(threads, seconds / 2)
+    # the Generic pipeline (pli/mod.rs:72-106; oracle/lm_oracle.c), one thread, on the head of the same sample: BASELINE.md
+    # section 3 lists it next to the AVX2 leg (it is what lightmotif-bench/dna.rs times)
+    grows = min(rows, 1 << 19)
+    gs = co.Striped(data[:grows + m - 1], length, m - 1, COLS, 5)
+    co.score_rows(gs, p, 0, min(grows, 4096))
+    t0 = time.perf_counter()
+    gout, _ = co.score_rows(gs, p, 0, grows)
+    generic = grows * COLS / (time.perf_counter() - t0) / 1e9
+    generic_ok = bool(np.array_equal(gout[:, :COLS].view(np.uint32), gpu_scores[:grows].view(np.uint32)))
     topo = cpu_topology()
     return {
         "value": round(allc, 3), "unit": "Gpos/s", "cores": topo["cores"], "threads": threads,
@@ -227,6 +236,9 @@ def cpu_baseline(seq_sample: np.ndarray, length: int, pssm: np.ndarray, gpu_scor
                   f"{topo['sockets']} socket(s) x {topo['cores'] // max(topo['sockets'], 1)} cores "
                   f"({topo['cores']} physical cores, SMT {threads // max(topo['cores'], 1)}), ~{seconds:.0f} s of CPU work",
         "single_thread_gpos": round(one, 3), "cpu_model": topo["model"], "gpu_matches_cpu_bitwise": verified,
+        "generic_single_thread_gpos": round(generic, 4),
+        "generic_sample": f"first {grows * COLS} positions, Generic restatement of pli/mod.rs:72-106 (oracle/lm_oracle.c), 1 thread",
+        "gpu_matches_generic_bitwise": generic_ok,
     }
 
 
@@ -261,6 +273,76 @@ def init_ranks(args):
     return world, rank, local_rank, dev, coll_dev, note
 
 
+def best_kmer_score(p) -> np.float32:
+    """the sequential f32 sum of the row maxima: no score of the matrix exceeds it (score.hip best_kmer_score)"""
+    b = np.float32(0)
+    for row in p.data[:, :4]:
+        b = np.float32(b + row.max())
+    return b
+
+
+def c3_setup(pli, dev, world: int, rank: int, length: int, motifs: int = 0) -> dict:
+    """BASELINE.json configs[2] on this rank: the JASPAR 2024 CORE matrices (the reference's bench fixture, converted like
+    the CLI, main.rs:469-498), thresholds at p = 1e-5, the WHOLE synthetic sequence resident on every rank, and the motif
+    list cut into `world` shares balanced on the expected scan cost (lightmotif-cli main.rs:502-561 fans (motif, sequence)
+    jobs out to threads; across GPUs the motif list is the unit)."""
+    from lightmotif_amd import io as lmio
+    pssms = [r.matrix.normalize(0.1).log_odds() for r in lmio.read(ROOT / "tests" / "golden" / "JASPAR2024.pwm.gz")]
+    if motifs:
+        pssms = pssms[:motifs]
+    lengths = [len(p) for p in pssms]
+    max_m = max(lengths)
+    rows = -(-length // COLS)
+    shard = synth_shard(rows, 0, rows, length, max_m - 1, dev, seed=0x5EED0003)
+    pli.configure_wrap_dptr(shard.data_ptr(), rows, COLS, COLS, max_m - 1, 4)
+    torch.cuda.synchronize()
+    seq = pli.adopt_sequence(shard.data_ptr(), rows, max_m - 1, COLS, COLS, length, keepalive=shard)
+    ts = [p.score_for_pvalue(1e-5) for p in pssms]
+    unreachable = [i for i, (p, t) in enumerate(zip(pssms, ts)) if np.float32(t) > best_kmer_score(p)]
+    # shard on the expected cost of a motif's scan (profiles/r02_c3_per_length.txt: ~16-byte table reads per pair of
+    # positions), not on its bare length: a motif that cannot reach the threshold costs (almost) nothing
+    skip = set(unreachable)
+    cost = [0.02 if i in skip else (1 + (m | 3) // 8) for i, m in enumerate(lengths)]
+    parts = D.shard_motifs(cost, world)
+    for i in parts[rank]:
+        pssms[i]._device(pli)
+    cells = sum(length + 1 - m for m in lengths)
+    scanned = cells - sum(length + 1 - lengths[i] for i in unreachable)
+    # LDS bytes the pair-prefilter scans gather (score_prefilter2.hpp: one table row of (M | 3) + 1 u16 per pair of input
+    # rows = (M | 3) + 1 bytes per position), summed over the motifs that are scanned
+    lds_bytes = sum(((m | 3) + 1) * (length + 1 - m) for i, m in enumerate(lengths) if i not in skip)
+    return {"pssms": pssms, "lengths": lengths, "ts": ts, "seq": seq, "shard": shard, "parts": parts,
+            "unreachable": unreachable, "rows": rows, "max_m": max_m, "length": length, "cells": cells,
+            "scanned_cells": scanned, "lds_bytes": lds_bytes}
+
+
+C3_LDS_MODEL = ("pair-prefilter scans (score_prefilter2.hpp): one LDS table row of (M | 3) + 1 u16 entries per pair of input "
+                "rows = (M | 3) + 1 bytes gathered per scanned (motif, position) cell, against 256 B/clk/CU x 256 CUs x 2.4 GHz; "
+                "whole call on the wall clock (re-scoring, ordering and read-back of the hits included)")
+
+
+def fused_roofline(ms: float, rows: int, m: int, kernel: str) -> dict:
+    """A fused score+argmax / score+threshold call over `rows` x 32 positions: wall time of the whole call (scan, re-scoring,
+    reductions, read-back) against the one byte per position it must read from HBM; `lds_frac` = the pair table's gather."""
+    ach = rows * COLS / (ms * 1e-3) / 1e9
+    lds = ((m | 3) + 1) * rows * COLS / (ms * 1e-3)
+    return {"ms": round(ms, 4), "kernel": kernel,
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_call": rows * COLS,
+                         "lds_frac": round(lds / LDS_PEAK_BYTES_PER_S, 4),
+                         "lds_note": f"{(m | 3) + 1} B of pair-table gathers per position (score_prefilter2.hpp) against "
+                                     "256 B/clk/CU x 256 CUs x 2.4 GHz"}}
+
+
+def lds_roofline(lds_bytes: float, seconds: float, note: str) -> dict:
+    """scans that never touch HBM per cell are priced against the LDS-gather ceiling."""
+    ach = lds_bytes / seconds / 1e12
+    peak = LDS_PEAK_BYTES_PER_S / 1e12
+    return {"bound": "lds", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TB/s", "frac": round(ach / peak, 4),
+            "model": note}
+
+
+
 def main_c3(args) -> None:
     """BASELINE.json configs[2]: the 2 346 DNA matrices of JASPAR 2024 CORE (the reference's own
     bench fixture, tests/golden/JASPAR2024.pwm.gz; converted like the CLI, main.rs:469-498) over a
@@ -270,36 +352,13 @@ def main_c3(args) -> None:
     Step = one batched fused threshold scan at p = 1e-5 per motif of this rank's share + the
     gather.  Value = (motif, position) cells per second over all ranks; scaling is STRONG (the
     total work is fixed)."""
-    from lightmotif_amd import io as lmio
     world, rank, local_rank, dev, coll_dev, launch_note = init_ranks(args)
-    pssms = [r.matrix.normalize(0.1).log_odds() for r in lmio.read(ROOT / "tests" / "golden" / "JASPAR2024.pwm.gz")]
-    if args.motifs:
-        pssms = pssms[:args.motifs]
-    lengths = [len(p) for p in pssms]
-    max_m = max(lengths)
-    length = args.length if args.length != 1_000_000_000 else 100_000_000
-    rows = -(-length // COLS)
-    shard = synth_shard(rows, 0, rows, length, max_m - 1, dev, seed=0x5EED0003)   # the WHOLE sequence on every rank
     stream = torch.cuda.current_stream()
     pli = lm.Pipeline.hip(local_rank, stream=stream.cuda_stream)
-    pli.configure_wrap_dptr(shard.data_ptr(), rows, COLS, COLS, max_m - 1, 4)
-    torch.cuda.synchronize()
-    seq = pli.adopt_sequence(shard.data_ptr(), rows, max_m - 1, COLS, COLS, length, keepalive=shard)
-    ts = [p.score_for_pvalue(1e-5) for p in pssms]
-
-    def best_kmer(p):      # the sequential f32 sum of the row maxima: no score exceeds it (score.hip best_kmer_score)
-        b = np.float32(0)
-        for row in p.data[:, :4]:
-            b = np.float32(b + row.max())
-        return b
-    unreachable = [i for i, (p, t) in enumerate(zip(pssms, ts)) if np.float32(t) > best_kmer(p)]
-    # shard on the expected cost of a motif's scan (profiles/r02_c3_per_length.txt: ~16-byte table reads per pair of
-    # positions), not on its bare length: a motif that cannot reach the threshold costs (almost) nothing
-    skip = set(unreachable)
-    cost = [0.02 if i in skip else (1 + (m | 3) // 8) for i, m in enumerate(lengths)]
-    parts = D.shard_motifs(cost, world)
-    for i in parts[rank]:
-        pssms[i]._device(pli)
+    length = args.length if args.length != 1_000_000_000 else 100_000_000
+    c3 = c3_setup(pli, dev, world, rank, length, args.motifs)
+    pssms, lengths, ts, seq, shard, parts, unreachable, rows, max_m = (c3[k] for k in (
+        "pssms", "lengths", "ts", "seq", "shard", "parts", "unreachable", "rows", "max_m"))
 
     def step():
         return D.scan_threshold_batch_sharded(pli, pssms, ts, seq, device=coll_dev, parts=parts)
@@ -332,10 +391,8 @@ def main_c3(args) -> None:
             dist.barrier()
             dist.destroy_process_group()
         return
-    cells = sum(length + 1 - m for m in lengths)
+    cells, scanned_cells = c3["cells"], c3["scanned_cells"]
     value = cells * args.steps / elapsed / 1e9
-
-    scanned_cells = cells - sum(length + 1 - lengths[i] for i in unreachable)
     out = {
         "metric": "scored (motif, position) cells/sec, fused threshold scan", "value": round(value, 1), "unit": "Gcell/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -345,7 +402,7 @@ def main_c3(args) -> None:
                                "fused threshold at p = 1e-5 per motif, hits in the reference's order; "
                                f"{len(unreachable)} motifs (all of length <= {max([lengths[i] for i in unreachable] or [0])}) "
                                "cannot reach p = 1e-5 -- their threshold exceeds the score of their best k-mer -- and "
-                               "are answered (no hits) without a scan unless LM_HIP_SKIP_UNREACHABLE=0; `value` counts "
+                               "are answered (no hits) without a scan; `value` counts "
                                "their cells as done, `extras.scanned_Gcell_s` does not",
                    "parallelism": f"motif-shard x{world} (LPT on the expected scan cost per motif), sequence replicated",
                    "motifs_per_rank": [len(p) for p in parts]},
@@ -355,7 +412,7 @@ def main_c3(args) -> None:
                    "fused_argmax_ms": round(am_s * 1e3, 3),
                    "fused_argmax_Gcell_s": round(cells / am_s / 1e9, 1),
                    "argmax_found": int(sum(a is not None for a in am))},
-        "roofline": None,
+        "roofline": lds_roofline(c3["lds_bytes"] * args.steps, elapsed, C3_LDS_MODEL),
         "roofline_note": "LDS-gather-bound scans over a cache-resident sequence: the PMC-based LDS / VALU utilisation "
                          "per kernel is in profiles/r02_c3_record.md; no HBM fraction applies",
     }
@@ -420,6 +477,105 @@ def cpu_baseline_c3(shard, rows, length, max_m, pssms, gpu_thr, gpu_am, seconds:
                       f"(motif, sequence) like the CLI's workers, {workers} jobs in flight: AVX2 port (oracle/lm_avx2.c) "
                       f"score_rows in cache-resident {block}-row blocks + argmax + threshold, {n} rounds, ~{seconds:.0f} s",
             "gpu_hits_match_on_sample": bool(ok)}
+
+
+def host_pointer_bench():
+    """tools/host_pointer_bench.py as a module: the measurements of the literal drop-in path are shared with that tool"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("host_pointer_bench", ROOT / "tools" / "host_pointer_bench.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def measured_d2h_gbs(dev, nbytes: int = 1 << 28) -> float:
+    """The floor of the host-pointer path: device -> pinned host memory, GB/s (what a copy command reaches on this box)."""
+    host = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    best = 0.0
+    for _ in range(4):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        host.copy_(src, non_blocking=True)
+        b.record()
+        torch.cuda.synchronize()
+        best = max(best, nbytes / (a.elapsed_time(b) * 1e-3) / 1e9)
+    return best
+
+
+def end_to_end(shard, rows: int, m: int, length: int, pssm, scores_h, dev) -> dict:
+    """SURVEY 8(d) "End-to-end ... reported separately and labelled": the same 1 Gbp job through the host-pointer entry
+    point the reference-side shim binds (`lm_hip_score_f32`: striped sequence and score matrix in pageable HOST memory,
+    1 B per position up + 4 B per position down over PCIe per call, pwm/mod.rs:640-648).  Never `value`."""
+    hpb = host_pointer_bench()
+    mat = shard.cpu().numpy()                       # rows + M - 1 wrap rows, as seq.rs:369-381 leaves them on the host
+
+    def check(out):                                 # against the resident scores of the timed region: head, tail, a middle window
+        ok = True
+        for a in (0, max(rows // 2 - 50_000, 0), max(rows - 100_000, 0)):
+            b = min(a + 100_000, rows)
+            ok = ok and np.array_equal(out[a:b].view(np.uint32), scores_h.rows_matrix(a, b)[:, :COLS].view(np.uint32))
+        return ok
+    res = hpb.bench_big(length, m, mat=mat, pssm=pssm.data, reps=4, check=check)
+    d2h = measured_d2h_gbs(dev)
+    floor_ms = 4 * rows * COLS / d2h / 1e6
+    return {"host_pointer_1gbp_ms": res["host_pointer_ms"], "host_pointer_median_ms": res["host_pointer_median_ms"],
+            "gpos": res["gpos"], "link_gbs": res["link_gbs"], "d2h_gbs": res["d2h_gbs"],
+            "measured_pinned_d2h_gbs": round(d2h, 1), "d2h_floor_ms": round(floor_ms, 2),
+            "frac_of_d2h_floor": round(floor_ms / res["host_pointer_ms"], 4), "matches_resident_scores": res["verified"],
+            "positions": rows * COLS,
+            "what": "lm_hip_score_f32 on pageable host matrices (what INTEGRATION.md 2 binds): tiles of 262144 rows, pageable "
+                    "H2D by an uploader thread | store kernel | D2H into a pinned ring + 4 copier threads; the floor is the 4 B "
+                    "per position that must come back over PCIe at the pinned D2H rate measured in this run"}
+
+
+def c3_leg(pli, dev, coll_dev, world: int, rank: int, reps: int = 5) -> dict:
+    """configs[2] after the headline run: ms per batched fused threshold scan (p = 1e-5 per motif) and per batched fused
+    argmax of the JASPAR matrices x 100 Mbp.  world > 1: the motif list sharded over the ranks (every rank holds the
+    sequence, results gathered in motif order: `scan_threshold_batch_sharded`), slowest rank counts; all ranks call this."""
+    length = 100_000_000
+    c3 = c3_setup(pli, dev, world, rank, length)
+    pssms, ts, seq, parts = c3["pssms"], c3["ts"], c3["seq"], c3["parts"]
+    res = [None]
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, n, warm=2):
+        for _ in range(warm):
+            fn()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        sync_all()
+        dt = (time.perf_counter() - t0) / n
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def scan():
+        res[0] = (pli.scan_threshold_batch(pssms, ts, seq) if world == 1 else
+                  D.scan_threshold_batch_sharded(pli, pssms, ts, seq, device=coll_dev, parts=parts))
+    t_th = timed(scan, reps)
+    k_th = pli.last_kernel
+    t_am = timed(lambda: (pli.scan_argmax_batch(pssms, seq) if world == 1 else
+                          D.scan_argmax_batch_sharded(pli, pssms, seq, device=coll_dev, parts=parts)), reps)
+    lengths = c3["lengths"]
+    return {"workload": f"configs[2]: {len(pssms)} JASPAR 2024 CORE DNA PSSMs (sum M = {sum(lengths)}) x "
+                        f"{length} bp resident, one batched fused threshold scan at p = 1e-5 per motif",
+            "parallelism": f"motif-shard x{world} (LPT on the expected scan cost per motif), sequence replicated",
+            "motifs_per_rank": [len(p) for p in parts],
+            "fused_threshold_ms": round(t_th * 1e3, 3), "Gcell_per_s": round(c3["cells"] / t_th / 1e9, 1),
+            "scanned_Gcell_per_s": round(c3["scanned_cells"] / t_th / 1e9, 1),
+            "motifs_skipped_unreachable": len(c3["unreachable"]),
+            "hits_total": int(sum(len(c) for c, _ in res[0])), "kernel": k_th,
+            "roofline": lds_roofline(c3["lds_bytes"], t_th, C3_LDS_MODEL),
+            "fused_argmax_ms": round(t_am * 1e3, 3), "fused_argmax_kernel": pli.last_kernel}
 
 
 def secondary_configs(pli, dev) -> dict:
@@ -490,6 +646,11 @@ def secondary_configs(pli, dev) -> dict:
                    "best_position": int(scores.offset(*best[0])), "kernel": k_store,
                    "fused_score_argmax_us": round(tf * 1e6, 2), "fused_kernel": pli.last_kernel}
         del seq, scores
+    # ... and the same loop as the reference-side shim runs it: `lm_hip_score_f32` + `lm_hip_argmax_f32` on
+    # HOST matrices, next to the 1-thread AVX2 port of that loop on this box; Scanner's 256-row u8 block (scan.rs:174-178)
+    hpb = host_pointer_bench()
+    c1.update(hpb.bench_c1())
+    c1.update(hpb.bench_block())
     out["c1"] = c1
     pli = pli_main
 
@@ -524,48 +685,18 @@ def secondary_configs(pli, dev) -> dict:
     out["c5"] = {"workload": "configs[4]: protein (K = 21) len-12 PSSM x 200 Mres, score() materialised",
                  "kernel": k_store, "kernel_ms": round(kms, 4), "Gpos_per_s": round(rows * COLS / kms / 1e6, 1),
                  "hbm_frac": round(BYTES_PER_POS * rows * COLS / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "roofline": {"bound": "hbm", "achieved": round(BYTES_PER_POS * rows * COLS / (kms * 1e-3) / 1e9, 1),
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(BYTES_PER_POS * rows * COLS / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "algorithmic_bytes_per_launch": BYTES_PER_POS * rows * COLS,
+                              "lds_frac": round(4 * m * rows * COLS / (kms * 1e-3) / LDS_PEAK_BYTES_PER_S, 4)},
                  "fused_threshold_ms": round(t_th * 1e3, 4), "fused_threshold_kernel": k_th, "fused_threshold_hits": n_hits,
                  "fused_argmax_ms": round(t_am * 1e3, 4), "fused_argmax_kernel": pli.last_kernel}
     del pseq, pout
 
     # --- configs[2]: the 2 346 JASPAR 2024 CORE matrices x 100 Mbp, fused threshold at p = 1e-5 per motif
-    from lightmotif_amd import io as lmio
-    fixture = ROOT / "tests" / "golden" / "JASPAR2024.pwm.gz"
-    if fixture.exists():
-        pssms = [r.matrix.normalize(0.1).log_odds() for r in lmio.read(fixture)]
-        lengths = [len(p) for p in pssms]
-        max_m = max(lengths)
-        length = 100_000_000
-        rows = -(-length // COLS)
-        shard = synth_shard(rows, 0, rows, length, max_m - 1, dev, seed=0x5EED0003)
-        pli.configure_wrap_dptr(shard.data_ptr(), rows, COLS, COLS, max_m - 1, 4)
-        torch.cuda.synchronize()
-        seq = pli.adopt_sequence(shard.data_ptr(), rows, max_m - 1, COLS, COLS, length, keepalive=shard)
-        ts = [p.score_for_pvalue(1e-5) for p in pssms]
-        for p in pssms:
-            p._device(pli)
-        res = [None]
-
-        def scan():
-            res[0] = pli.scan_threshold_batch(pssms, ts, seq)
-        t_th = wall(scan, 5, warm=2)
-        k_th = pli.last_kernel
-        t_am = wall(lambda: pli.scan_argmax_batch(pssms, seq), 5, warm=2)
-        cells = sum(length + 1 - mm for mm in lengths)
-
-        def best_kmer(p):
-            b = np.float32(0)
-            for row in p.data[:, :4]:
-                b = np.float32(b + row.max())
-            return b
-        unreachable = [i for i, (p, t) in enumerate(zip(pssms, ts)) if np.float32(t) > best_kmer(p)]
-        scanned = cells - sum(length + 1 - lengths[i] for i in unreachable)
-        out["c3"] = {"workload": f"configs[2]: {len(pssms)} JASPAR 2024 CORE DNA PSSMs (sum M = {sum(lengths)}) x "
-                                 f"{length} bp resident, one batched fused threshold scan at p = 1e-5 per motif",
-                     "fused_threshold_ms": round(t_th * 1e3, 3), "Gcell_per_s": round(cells / t_th / 1e9, 1),
-                     "scanned_Gcell_per_s": round(scanned / t_th / 1e9, 1), "motifs_skipped_unreachable": len(unreachable),
-                     "hits_total": int(sum(len(c) for c, _ in res[0])), "kernel": k_th,
-                     "fused_argmax_ms": round(t_am * 1e3, 3), "fused_argmax_kernel": pli.last_kernel}
+    if (ROOT / "tests" / "golden" / "JASPAR2024.pwm.gz").exists():
+        out["c3"] = c3_leg(pli, dev, torch.device("cpu"), 1, 0, reps=5)
     return out
 
 
@@ -589,6 +720,9 @@ def main() -> None:
     ap.add_argument("--dist-backend", default="nccl",
                     help="development: 'gloo' + --single-device exercises the N>1 control flow on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="development: every rank uses cuda:0")
+    ap.add_argument("--require-distinct-devices", action="store_true",
+                    help="development: with --single-device, keep the N-ranks-on-N-devices check (the line becomes `invalid`, "
+                         "exit status 3) -- the check is always on without --single-device")
     ap.add_argument("--sync-merge", action="store_true",
                     help="N > 1 through the C ABI: wait for every step's merge before the next score_into "
                          "(default: pipelined, lm_hip_argmax_sharded_begin / _end)")
@@ -680,7 +814,7 @@ def main() -> None:
     # Chosen by a probe of three steps before the preheat: a transport that raises on any rank is dropped on all.
     mode = {"v": 2 if (comm is not None and not args.sync_merge) else 1 if comm is not None else 0}
 
-    def run_steps(n, events=None):
+    def run_steps(n, events=None, lat=None):
         """N = 1: one score_into (pli/mod.rs:109-117) into the resident StripedScores per step.
         N > 1 (configs[3]): the same on this rank's row shard, plus the argmax of the shard
         (tracked by the store kernel, first-cell rule on rank 0 only) and its merge over RCCL --
@@ -698,18 +832,27 @@ def main() -> None:
                 events[i][1].record(stream)
             if not sharded:
                 continue
+            tm = time.perf_counter()
             if mode["v"] == 2:
                 ticket = comm.argmax_sharded_begin(scores_h, row0)
                 if pending is not None:
-                    merged = comm.argmax_sharded_end(pending)
-                pending = ticket
+                    merged = comm.argmax_sharded_end(pending[0])
+                    if lat is not None:     # from the merge's begin to its result on the host (the next step's enqueue lies inside)
+                        lat.append(time.perf_counter() - pending[1])
+                pending = (ticket, tm)
             elif mode["v"] == 1:
                 merged = comm.argmax_sharded(scores_h, row0)   # device-side all_gather + combine, one read-back
+                if lat is not None:
+                    lat.append(time.perf_counter() - tm)
             else:
                 loc = pli.argmax_handle_shard(scores_h, first_cell_rule=rank == 0)
                 merged = D.merge_argmax(loc, row0, device=coll_dev)
+                if lat is not None:
+                    lat.append(time.perf_counter() - tm)
         if pending is not None:
-            merged = comm.argmax_sharded_end(pending)
+            merged = comm.argmax_sharded_end(pending[0])
+            if lat is not None:
+                lat.append(time.perf_counter() - pending[1])
         return merged
 
     def barrier() -> None:
@@ -768,9 +911,10 @@ def main() -> None:
     # enqueues on torch's current stream, so torch.cuda.Event sees it)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
+    merge_lat = []
     barrier()
     t0 = time.perf_counter()
-    merged = run_steps(args.steps, ev)
+    merged = run_steps(args.steps, ev, merge_lat)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -780,6 +924,14 @@ def main() -> None:
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     kernel_avg_ms = float(np.mean(kernel_ms))
     kernel_med_ms = float(np.median(kernel_ms))
+    # every rank's own kernel time and merge latency (the line reports the spread, and the aggregate rate as a sum)
+    mine = {"kernel_avg_ms": kernel_avg_ms,
+            "merge_us": [float(np.median(merge_lat)) * 1e6, float(np.max(merge_lat)) * 1e6] if merge_lat else None}
+    if world > 1:
+        by_rank = [None] * world
+        dist.all_gather_object(by_rank, mine)
+    else:
+        by_rank = [mine]
 
     # --- reductions / merge on the last step's matrix (outside the timed region; "extras") --------
     def timed(fn, reps=5):
@@ -797,6 +949,7 @@ def main() -> None:
     am_ms, am = timed(lambda: pli.argmax_dptr(sc_ptr, rows, COLS, COLS, first_cell_rule=rank == 0))
     fam_ms, fam = timed(lambda: pli.score_argmax_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS,
                                                       m - 1, total_length, 0, rows, first_cell_rule=rank == 0))
+    fam_kernel = pli.last_kernel
     assert am == fam, (am, fam)
     mg_ms, best = timed(lambda: D.merge_argmax(am, row0, device=coll_dev))
     if merged is not None:
@@ -811,9 +964,17 @@ def main() -> None:
     th_ms, hits = timed(lambda: pli.threshold_dptr(sc_ptr, rows, COLS, COLS, thr_t), reps=5)
     fth_ms, fhits = timed(lambda: pli.score_threshold_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS,
                                                           m - 1, total_length, 0, rows, thr_t), reps=5)
+    fth_kernel = pli.last_kernel
     assert np.array_equal(hits, fhits[0]), "fused threshold differs from materialised threshold"
     mt_ms, all_hits = timed(lambda: (comm.merge_threshold(hits, row0) if comm is not None else
                                      D.merge_threshold(hits, row0, device=coll_dev)), reps=3)
+    # the same list through the other transport (one timed merge per variant of the step)
+    mt_torch_ms, all_hits_t = (timed(lambda: D.merge_threshold(hits, row0, device=coll_dev), reps=3)
+                               if comm is not None else (mt_ms, all_hits))
+    assert np.array_equal(np.asarray(all_hits), np.asarray(all_hits_t)), "merge_threshold: the two transports disagree"
+    # configs[2] with the motif list sharded over the ranks (every rank takes part)
+    c3_sharded = (c3_leg(pli, dev, coll_dev, world, rank, reps=3)
+                  if world > 1 and not args.no_extras and (ROOT / "tests" / "golden" / "JASPAR2024.pwm.gz").exists() else None)
 
     if rank != 0:
         if comm is not None:
@@ -826,6 +987,15 @@ def main() -> None:
     positions = rows * COLS * world * args.steps
     value = positions / elapsed / 1e9
     achieved = BYTES_PER_POS * rows * COLS / (kernel_avg_ms * 1e-3) / 1e9
+    rank_kernel_ms = [r["kernel_avg_ms"] for r in by_rank]
+    achieved_aggregate = sum(BYTES_PER_POS * rows * COLS / (k * 1e-3) / 1e9 for k in rank_kernel_ms)
+    rank_merge = [r["merge_us"] for r in by_rank if r["merge_us"]]
+    # a line that does not describe N ranks on N devices over RCCL must not pass for one (exit status 3 below)
+    invalid = []
+    if world > 1 and len(set(devices)) != world and (not args.single_device or args.require_distinct_devices):
+        invalid.append(f"{world} ranks on {len(set(devices))} distinct device(s)")
+    if world > 1 and args.dist_backend == "nccl" and mode["v"] > 0 and rccl_ranks != world:
+        invalid.append(f"the C-ABI communicator was initialised with {rccl_ranks} rank(s), world is {world}")
     lds_bytes_per_s = 4 * m * rows * COLS / (kernel_avg_ms * 1e-3)
     traffic, traffic_source, traffic_current = None, None, None
     pmc = ROOT / "profiles" / "pmc_traffic.json"
@@ -871,6 +1041,8 @@ def main() -> None:
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source, "traffic_current": traffic_current,
+            "achieved_aggregate": round(achieved_aggregate, 1), "peak_aggregate": HBM_PEAK_GBS * world,
+            "kernel_ms_by_rank": [round(min(rank_kernel_ms), 4), round(max(rank_kernel_ms), 4)],
             "kernel": kernel_name, "kernel_avg_ms": round(kernel_avg_ms, 4),
             "kernel_median_ms": round(kernel_med_ms, 4),
             "frac_at_median": round(BYTES_PER_POS * rows * COLS / (kernel_med_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -888,11 +1060,29 @@ def main() -> None:
             "merge_threshold_ms": round(mt_ms, 4),
             "threshold_hits": int(len(all_hits)), "argmax_global": [int(best[0][0]), int(best[0][1])],
             "kernel_ms_min": round(min(kernel_ms), 4), "kernel_ms_max": round(max(kernel_ms), 4),
+            # the fused forms never write the score matrix -- 1 B per position read from HBM is what is left,
+            # and the pair-prefilter scan gathers (M | 3) + 1 bytes of LDS per position (score_prefilter2.hpp)
+            "fused_score_argmax": fused_roofline(fam_ms, rows, m, fam_kernel),
+            "fused_score_threshold": fused_roofline(fth_ms, rows, m, fth_kernel),
+            "merge_threshold_ms_torch": round(mt_torch_ms, 4),
+            "merge_us": (None if not rank_merge else
+                         {"p50": round(float(np.median([x[0] for x in rank_merge])), 1),
+                          "max": round(max(x[1] for x in rank_merge), 1),
+                          "what": "per timed step, host clock: from the merge's begin to the merged argmax on the host; "
+                                  "median of the ranks' medians, maximum over ranks and steps"
+                                  + ("; pipelined -- the next step's enqueue lies inside" if pipelined else "")}),
         },
     }
+    if invalid:
+        out["invalid"] = invalid
     if world == 1 and not args.no_extras:
+        out["extras"]["end_to_end"] = end_to_end(shard, rows, m, total_length, pssm, scores_h, dev)
         out["extras"]["configs"] = secondary_configs(pli, dev)
-    if world == 1 and not args.no_cpu_baseline:
+    elif c3_sharded is not None:
+        out["extras"]["configs"] = {"c3": c3_sharded}
+    if not args.no_cpu_baseline:
+        # rank 0's host cores, whatever N (the other ranks wait at the closing barrier): the sample is the head of
+        # rank 0's shard; a window that reaches the shard's end needs the halo rows the exchange delivered
         srows = min(rows, max(args.cpu_sample // COLS, 1))
         seq_sample = shard[:srows + m - 1].cpu().numpy()
         gpu_sample = scores_h.rows_matrix(0, srows)
@@ -906,6 +1096,10 @@ def main() -> None:
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if invalid:
+        print("bench.py: " + "; ".join(invalid), file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(3)
 
 
 if __name__ == "__main__":

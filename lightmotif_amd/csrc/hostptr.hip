@@ -22,10 +22,11 @@
 //    way back is the long one (4 B per position): the runtime's pageable D2H reaches 48 GB/s, a copy into pinned
 //    memory 56.6 GB/s -- so tiles land in a ring of four pinned 32 MB buffers and four copier threads move them into
 //    the caller's matrix while the next tiles are in flight (measured: hostpipe_bench, profiles/r04_hostpipe_bench.txt).
-//    The ring, its streams and the device tile buffers exist once per process; a large call that finds them taken by
-//    another thread runs chunk by chunk on its own lane instead.
+//    The ring, its streams and the device tile buffers exist once per process: large calls of several threads take
+//    turns on it (the link is the bound; side by side they only get in each other's way).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <functional>
@@ -41,6 +42,30 @@ constexpr size_t kKeepBytes = 256u << 20;       // staging buffers above this ar
 constexpr size_t kPipeMinOutBytes = 48u << 20;  // score matrices from here on take the tile pipeline
 constexpr size_t kTileBytes = 32u << 20;        // one tile of scores (and one pinned ring slot)
 constexpr int kInSlots = 3, kOutSlots = 4, kCopiers = 4;
+constexpr int kMaxOutSlots = 8;
+
+// Shape of the pipeline.  Shipped: the constants above; a -DLM_HIP_DEV_SWITCHES build (tools/build_variant.py) reads
+// LM_HIP_PIPE_{TILE_MB,OUT_SLOTS,COPIERS} once, for sweeps (tools/hostpipe_sweep.sh).
+struct PipeShape {
+    size_t tile_bytes = kTileBytes;
+    int out_slots = kOutSlots, copiers = kCopiers;
+};
+const PipeShape &pipe_shape()
+{
+    static const PipeShape shape = [] {
+        PipeShape s;
+#ifdef LM_HIP_DEV_SWITCHES
+        if (const char *e = getenv("LM_HIP_PIPE_TILE_MB"))
+            s.tile_bytes = (size_t)std::max(1, std::min(atoi(e), 256)) << 20;
+        if (const char *e = getenv("LM_HIP_PIPE_OUT_SLOTS"))
+            s.out_slots = std::max(2, std::min(atoi(e), kMaxOutSlots));
+        if (const char *e = getenv("LM_HIP_PIPE_COPIERS"))
+            s.copiers = std::max(1, std::min(atoi(e), 32));
+#endif
+        return s;
+    }();
+    return shape;
+}
 constexpr size_t kPssmCache = 16;
 
 struct CachedPssm {
@@ -183,9 +208,9 @@ struct BigPipe {
     std::mutex mu;  // one large call at a time
     int device = -1;
     hipStream_t s_up = nullptr, s_dn = nullptr;
-    hipEvent_t kdone[kInSlots] = {}, landed[kOutSlots] = {};
+    hipEvent_t kdone[kInSlots] = {}, landed[kMaxOutSlots] = {};
     Scratch d_in, d_out;
-    char *pinned = nullptr;  // kOutSlots x kTileBytes
+    char *pinned = nullptr;  // out_slots x tile_bytes
 };
 
 BigPipe &big_pipe()
@@ -201,15 +226,15 @@ int pipe_prepare(BigPipe &bp, int device)
     if (bp.device >= 0)
         return fail(LM_HIP_ERR_BAD_ARGS, "host-pointer calls use one device per process");
     hipStream_t up = nullptr, dn = nullptr;
-    hipEvent_t ev[kInSlots + kOutSlots] = {};
+    hipEvent_t ev[kInSlots + kMaxOutSlots] = {};
     char *pin = nullptr;
     hipError_t e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
     if (e == hipSuccess)
         e = hipStreamCreateWithFlags(&dn, hipStreamNonBlocking);
-    for (int i = 0; i < kInSlots + kOutSlots && e == hipSuccess; ++i)
+    for (int i = 0; i < kInSlots + kMaxOutSlots && e == hipSuccess; ++i)
         e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
     if (e == hipSuccess)
-        e = hipHostMalloc(reinterpret_cast<void **>(&pin), kOutSlots * kTileBytes, hipHostMallocDefault);
+        e = hipHostMalloc(reinterpret_cast<void **>(&pin), (size_t)pipe_shape().out_slots * pipe_shape().tile_bytes, hipHostMallocDefault);
     if (e != hipSuccess) {  // nothing half-made is kept
         for (hipEvent_t x : ev)
             if (x)
@@ -225,7 +250,7 @@ int pipe_prepare(BigPipe &bp, int device)
     bp.s_dn = dn;
     for (int i = 0; i < kInSlots; ++i)
         bp.kdone[i] = ev[i];
-    for (int i = 0; i < kOutSlots; ++i)
+    for (int i = 0; i < kMaxOutSlots; ++i)
         bp.landed[i] = ev[kInSlots + i];
     bp.pinned = pin;
     bp.device = device;
@@ -249,7 +274,7 @@ int run_pipeline(lm_hip_ctx *ctx, BigPipe &bp, const TileJob &job)
         std::mutex mu;
         std::condition_variable cv;
         size_t uploaded = 0, launched = 0, issued = 0, copied = 0;
-        unsigned done[kOutSlots] = {};
+        unsigned done[kMaxOutSlots] = {};
         int status = LM_HIP_OK;
         char err[256] = "";
     } sh;
@@ -261,21 +286,41 @@ int run_pipeline(lm_hip_ctx *ctx, BigPipe &bp, const TileJob &job)
         }
         sh.cv.notify_all();
     };
-    const int device = ctx->device;
+    const int device = ctx->device, out_slots = pipe_shape().out_slots, ncopiers = pipe_shape().copiers;
     const size_t n = job.ntiles;
+#ifdef LM_HIP_DEV_SWITCHES  // where the wall time of a large call goes (LM_HIP_PIPE_TRACE=1)
+    std::atomic<long long> ns_up_wait{0}, ns_up_copy{0}, ns_main_wait{0}, ns_cp_wait{0}, ns_cp_copy{0};
+    auto tick = [] { return std::chrono::steady_clock::now(); };
+    auto since = [](std::chrono::steady_clock::time_point t0) {
+        return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    };
+    const auto t_start = tick();
+#define LM_PIPE_T0 const auto _t0 = tick()
+#define LM_PIPE_ADD(counter) counter += since(_t0)
+#else
+#define LM_PIPE_T0 (void)0
+#define LM_PIPE_ADD(counter) (void)0
+#endif
     std::thread uploader([&] {
         if (hipSetDevice(device) != hipSuccess)
             return raise(LM_HIP_ERR_HIP, "hipSetDevice", hipGetLastError());
         for (size_t t = 0; t < n; ++t) {
+            hipError_t e = hipSuccess;
             {   // input slot t % kInSlots was read by tile t - kInSlots: its kernel must have been launched ...
+                LM_PIPE_T0;
                 std::unique_lock<std::mutex> lock(sh.mu);
                 sh.cv.wait(lock, [&] { return sh.launched + kInSlots > t || sh.status != LM_HIP_OK; });
                 if (sh.status != LM_HIP_OK)
                     return;
+                lock.unlock();
+                e = t >= (size_t)kInSlots ? hipEventSynchronize(bp.kdone[t % kInSlots]) : hipSuccess;  // ... and have finished
+                LM_PIPE_ADD(ns_up_wait);
             }
-            hipError_t e = t >= (size_t)kInSlots ? hipEventSynchronize(bp.kdone[t % kInSlots]) : hipSuccess;  // ... and have finished
-            if (e == hipSuccess)
+            if (e == hipSuccess) {
+                LM_PIPE_T0;
                 e = job.upload(t, (int)(t % kInSlots));
+                LM_PIPE_ADD(ns_up_copy);
+            }
             if (e != hipSuccess)
                 return raise(e == hipErrorOutOfMemory ? LM_HIP_ERR_OOM : LM_HIP_ERR_HIP, "tile upload", e);
             std::lock_guard<std::mutex> lock(sh.mu);
@@ -284,24 +329,31 @@ int run_pipeline(lm_hip_ctx *ctx, BigPipe &bp, const TileJob &job)
         }
     });
     std::vector<std::thread> copiers;
-    for (int j = 0; j < kCopiers; ++j)
+    for (int j = 0; j < ncopiers; ++j)
         copiers.emplace_back([&, j] {
             if (hipSetDevice(device) != hipSuccess)
                 return raise(LM_HIP_ERR_HIP, "hipSetDevice", hipGetLastError());
             for (size_t t = 0; t < n; ++t) {
+                const int slot = (int)(t % (size_t)out_slots);
                 {
+                    LM_PIPE_T0;
                     std::unique_lock<std::mutex> lock(sh.mu);
                     sh.cv.wait(lock, [&] { return sh.issued > t || sh.status != LM_HIP_OK; });
                     if (sh.status != LM_HIP_OK)
                         return;
+                    lock.unlock();
+                    const hipError_t e = hipEventSynchronize(bp.landed[slot]);
+                    if (e != hipSuccess)
+                        return raise(LM_HIP_ERR_HIP, "tile read-back", e);
+                    LM_PIPE_ADD(ns_cp_wait);
                 }
-                const int slot = (int)(t % kOutSlots);
-                const hipError_t e = hipEventSynchronize(bp.landed[slot]);
-                if (e != hipSuccess)
-                    return raise(LM_HIP_ERR_HIP, "tile read-back", e);
-                job.copy_out(t, slot, j, kCopiers);
+                {
+                    LM_PIPE_T0;
+                    job.copy_out(t, slot, j, ncopiers);
+                    LM_PIPE_ADD(ns_cp_copy);
+                }
                 std::lock_guard<std::mutex> lock(sh.mu);
-                if (++sh.done[slot] == (unsigned)kCopiers) {
+                if (++sh.done[slot] == (unsigned)ncopiers) {
                     sh.done[slot] = 0;
                     sh.copied = t + 1;
                     sh.cv.notify_all();
@@ -309,13 +361,15 @@ int run_pipeline(lm_hip_ctx *ctx, BigPipe &bp, const TileJob &job)
             }
         });
     for (size_t t = 0; t < n; ++t) {
-        {   // tile t is on the device, and output slot t % kOutSlots (device + pinned) has been emptied into the caller's matrix
+        {   // tile t is on the device, and output slot t % out_slots (device + pinned) has been emptied into the caller's matrix
+            LM_PIPE_T0;
             std::unique_lock<std::mutex> lock(sh.mu);
-            sh.cv.wait(lock, [&] { return (sh.uploaded > t && sh.copied + kOutSlots > t) || sh.status != LM_HIP_OK; });
+            sh.cv.wait(lock, [&] { return (sh.uploaded > t && sh.copied + (size_t)out_slots > t) || sh.status != LM_HIP_OK; });
             if (sh.status != LM_HIP_OK)
                 break;
+            LM_PIPE_ADD(ns_main_wait);
         }
-        const int is = (int)(t % kInSlots), os = (int)(t % kOutSlots);
+        const int is = (int)(t % kInSlots), os = (int)(t % (size_t)out_slots);
         const int st = job.compute(t, is, os);
         if (st != LM_HIP_OK) {
             std::lock_guard<std::mutex> lock(sh.mu);
@@ -353,6 +407,14 @@ int run_pipeline(lm_hip_ctx *ctx, BigPipe &bp, const TileJob &job)
     (void)hipStreamSynchronize(bp.s_up);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(bp.s_dn);
+#ifdef LM_HIP_DEV_SWITCHES
+    if (getenv("LM_HIP_PIPE_TRACE"))
+        fprintf(stderr, "[lm_hip pipe] %zu tiles in %.2f ms: uploader waits %.2f copies %.2f | caller waits %.2f | copiers (each of %d) wait %.2f copy %.2f\n",
+                n, since(t_start) * 1e-6, ns_up_wait * 1e-6, ns_up_copy * 1e-6, ns_main_wait * 1e-6, ncopiers,
+                ns_cp_wait * 1e-6 / ncopiers, ns_cp_copy * 1e-6 / ncopiers);
+#endif
+#undef LM_PIPE_T0
+#undef LM_PIPE_ADD
     if (sh.status != LM_HIP_OK)
         return fail(sh.status, "%s", sh.err);
     return LM_HIP_OK;
@@ -406,13 +468,14 @@ int score_pipelined(HostLane *lane, BigPipe &bp, const ScoreCall &c)
     lm_hip_ctx *ctx = lane->ctx;
     LM_TRY(pipe_prepare(bp, ctx->device));
     // rows per tile: 32 MB of scores, at most 64 MB of symbols
-    size_t tr = std::min(kTileBytes / (c.cols * sizeof(float)), (2 * kTileBytes) / c.seq_stride);
+    const size_t tile_bytes = pipe_shape().tile_bytes;
+    size_t tr = std::min(tile_bytes / (c.cols * sizeof(float)), (2 * tile_bytes) / c.seq_stride);
     tr = std::max<size_t>(tr / 256 * 256, 256);
     const size_t in_tile = ((tr + c.halo) * c.seq_stride + 255) / 256 * 256, out_tile = tr * c.cols * sizeof(float);
-    if (out_tile > kTileBytes)  // (more than 32 K columns: not a shape this path is for)
+    if (out_tile > tile_bytes)  // (more than 32 K columns: not a shape this path is for)
         return LM_HIP_ERR_CAPACITY;
     LM_TRY(bp.d_in.reserve(kInSlots * in_tile + 64));
-    LM_TRY(bp.d_out.reserve(kOutSlots * out_tile));
+    LM_TRY(bp.d_out.reserve((size_t)pipe_shape().out_slots * out_tile));
     uint8_t *d_in = static_cast<uint8_t *>(bp.d_in.ptr);
     char *d_out = static_cast<char *>(bp.d_out.ptr);
     TileJob job;
@@ -429,13 +492,13 @@ int score_pipelined(HostLane *lane, BigPipe &bp, const ScoreCall &c)
         return launch_score_store(ctx, a);
     };
     job.download = [&](size_t t, int slot) {
-        return hipMemcpyAsync(bp.pinned + (size_t)slot * kTileBytes, d_out + (size_t)slot * out_tile,
+        return hipMemcpyAsync(bp.pinned + (size_t)slot * tile_bytes, d_out + (size_t)slot * out_tile,
                               width(t) * c.cols * sizeof(float), hipMemcpyDeviceToHost, bp.s_dn);
     };
     job.copy_out = [&](size_t t, int slot, int j, int n) {
         const size_t w = width(t), a = w * (size_t)j / (size_t)n, b = w * (size_t)(j + 1) / (size_t)n;
         copy_rows(reinterpret_cast<char *>(c.out + (t * tr + a) * c.out_stride), c.out_stride * sizeof(float),
-                  bp.pinned + (size_t)slot * kTileBytes + a * c.cols * sizeof(float), c.cols * sizeof(float),
+                  bp.pinned + (size_t)slot * tile_bytes + a * c.cols * sizeof(float), c.cols * sizeof(float),
                   c.cols * sizeof(float), b - a);
     };
     const int st = run_pipeline(ctx, bp, job);
@@ -486,12 +549,13 @@ int lm_hip_score_f32(const uint8_t *seq, size_t seq_rows_total, size_t seq_strid
     ScoreCall c{p, seq + row_begin * seq_stride, seq_stride, cols, row_end - row_begin, m ? m - 1 : 0, out, out_stride};
     int st = LM_HIP_ERR_CAPACITY;
     if (c.nrows * cols * sizeof(float) >= kPipeMinOutBytes) {
+        // link-bound: large calls of several threads take turns on the ring (run side by side through the runtime's
+        // pageable copies they were 2.2 x slower than one after the other -- profiles/r04_host_pointer.json)
         BigPipe &bp = big_pipe();
-        std::unique_lock<std::mutex> pipe(bp.mu, std::try_to_lock);
-        if (pipe.owns_lock())
-            st = score_pipelined(lane, bp, c);
+        std::lock_guard<std::mutex> pipe(bp.mu);
+        st = score_pipelined(lane, bp, c);
     }
-    if (st == LM_HIP_ERR_CAPACITY) {  // small, or the pipeline is serving another thread: piece by piece on this lane
+    if (st == LM_HIP_ERR_CAPACITY) {  // small (or a shape the tiles do not fit): piece by piece on this lane
         const size_t piece = std::max<size_t>((64u << 20) / (cols * sizeof(float)), 1);
         st = LM_HIP_OK;
         for (size_t r0 = 0; r0 < c.nrows && st == LM_HIP_OK; r0 += piece)

@@ -45,6 +45,40 @@ def test_two_ranks_without_a_launcher():
                       "--no-cpu-baseline", "--no-extras")
     assert out["extras"]["argmax_global"] == whole["extras"]["argmax_global"]
     assert out["extras"]["threshold_hits"] > 0
+    # what the first real N > 1 run will be read by: a CPU leg on rank 0, the per-rank kernel spread, the aggregate rate as
+    # a sum over ranks, the merge latency of the timed steps, both merge_threshold transports, the motif-sharded configs[2]
+    cb = out["cpu_baseline"]
+    assert cb is not None and cb["gpu_matches_cpu_bitwise"] is True and cb["gpu_matches_generic_bitwise"] is True
+    assert cb["value"] > 0 and cb["generic_single_thread_gpos"] > 0
+    rf = out["roofline"]
+    lo, hi = rf["kernel_ms_by_rank"]
+    assert 0 < lo <= hi and rf["peak_aggregate"] == 2 * rf["peak"]
+    assert abs(rf["achieved_aggregate"] - 2 * rf["achieved"]) < 0.35 * rf["achieved_aggregate"]   # two ranks share ONE device here
+    mu = out["extras"]["merge_us"]
+    assert mu["p50"] > 0 and mu["max"] >= mu["p50"]
+    assert out["extras"]["merge_threshold_ms"] > 0 and out["extras"]["merge_threshold_ms_torch"] > 0
+    for key in ("fused_score_argmax", "fused_score_threshold"):
+        fr = out["extras"][key]["roofline"]
+        assert fr["bound"] == "hbm" and 0 < fr["frac"] < 1 and 0 < fr["lds_frac"] < 1.2
+    c3 = out["extras"]["configs"]["c3"]
+    assert c3["parallelism"].startswith("motif-shard x2") and len(c3["motifs_per_rank"]) == 2
+    assert sum(c3["motifs_per_rank"]) == 2346 and c3["hits_total"] > 0 and c3["roofline"]["bound"] == "lds"
+    assert "invalid" not in out
+
+
+def test_a_line_that_is_not_n_ranks_on_n_devices_fails_loudly():
+    """Two ranks on one device WITHOUT the rehearsal flag's exemption cannot happen by accident (LOCAL_RANK picks the
+    device), but a launcher that maps both ranks to one GPU can: the line carries `invalid` and the exit status is 3."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--single-device", "--require-distinct-devices",
+                        "--dist-backend", "gloo",
+                        "--steps", "2", "--warmup", "1", "--length", "10000000", "--preheat-ms", "20", "--no-cpu-baseline",
+                        "--no-extras"], capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+    assert r.returncode != 0
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    assert line["invalid"] and "distinct device" in line["invalid"][0]
 
 
 def test_single_gpu_line_has_every_contract_field():
@@ -64,6 +98,17 @@ def test_single_gpu_line_has_every_contract_field():
     assert ex["c1"]["C1_generic_bench_geometry"]["best_position"] == 391_677
     assert ex["c5"]["kernel"].startswith("score_c32<12") and 0 < ex["c5"]["hbm_frac"] < 1
     assert ex["c3"]["hits_total"] > 0 and ex["c3"]["motifs_skipped_unreachable"] >= 0
+    # the literal drop-in path rides along: host-pointer loop of dna.rs, Scanner block, the labelled end-to-end figure
+    assert ex["c1"]["host_pointer_us_per_iter"] > 0 and ex["c1"]["avx2_port_1_thread_us_per_iter"] > 0
+    assert ex["c1"]["scores_match_avx2_port_bitwise"] is True and ex["c1"]["scanner_block_us"] > 0
+    e2e = out["extras"]["end_to_end"]
+    assert e2e["matches_resident_scores"] is True and 0 < e2e["frac_of_d2h_floor"] <= 1.05 and e2e["gpos"] > 0
+    assert cb["gpu_matches_generic_bitwise"] is True and cb["generic_single_thread_gpos"] > 0
+    for key in ("fused_score_argmax", "fused_score_threshold"):
+        fr = out["extras"][key]["roofline"]
+        assert fr["bound"] == "hbm" and 0 < fr["frac"] < 1
+    assert ex["c3"]["roofline"]["bound"] == "lds" and 0 < ex["c3"]["roofline"]["frac"] < 1.2
+    assert ex["c5"]["roofline"]["bound"] == "hbm" and ex["c5"]["roofline"]["frac"] == ex["c5"]["hbm_frac"]
 
 
 def test_one_rank_through_the_c_abi_communicator():
