@@ -92,6 +92,11 @@ int lm_hip_device_count(int *count);
 int lm_hip_device_ordinal(int index, int *ordinal);
 /* Frees buffers this library returned to the caller (threshold / hit lists). */
 void lm_hip_free(void *p);
+/* The pool behind large result arrays (threshold / hit lists): page-locked 2 MB-aligned blocks re-used between calls.
+ * Bytes it holds idle, bytes handed out and not yet freed, and the idle budget ($LM_HIP_RESULT_POOL_MB, default 256;
+ * blocks in use may reach four times that, results beyond come from plain malloc).  For hosts that watch their
+ * locked memory; a pointer may be NULL (not all three). */
+int lm_hip_result_pool_info(size_t *pinned_idle, size_t *pinned_in_use, size_t *budget);
 
 /* DenseMatrix::stride (dense.rs:126-128) for x86-64 hosts: elements per row. */
 size_t lm_hip_stride(size_t cols, size_t elem_size);
@@ -132,6 +137,13 @@ int lm_hip_ctx_set_prefilter(lm_hip_ctx *ctx, int enabled);
  * own writes to the handle -- not by external writes through the device pointer of
  * lm_hip_scores_info. */
 int lm_hip_ctx_set_track_argmax(lm_hip_ctx *ctx, int enabled);
+/* Selects an alternative path inside the library for this context.  Every option leaves the RESULTS unchanged (the
+ * test-suite runs both sides of each against the oracle); they exist for A/B measurements and to exercise paths that
+ * are otherwise taken only for some shapes.  Names: "track_argmax", "prefilter", "xcd_remap" (= the setters above),
+ * "pair_prefilter", "pair_prefilter_protein", "speculate_order", "suffix_argmax", "suffix_occurrences", "multi_motif",
+ * "skip_unreachable", "quad_loads", "xlong_store", "host_fold", "chunked_fused", "chunk_rows", "tiled".  Unknown names:
+ * LM_HIP_ERR_BAD_ARGS.  The shipped library reads none of them from the environment. */
+int lm_hip_ctx_set_option(lm_hip_ctx *ctx, const char *name, double value);
 /* Name of the kernel the last score call on this context launched
  * (for profiling tools); valid until the next call.  "score_c32<M,MODE>" names
  * the kernel family and the length it ran at (MODE 0 store, 1 fused argmax,

@@ -52,6 +52,7 @@ SIGNATURES = {
     "lm_hip_device_count": (C.c_int, [_ip]),
     "lm_hip_device_ordinal": (C.c_int, [C.c_int, _ip]),
     "lm_hip_free": (None, [_vp]),
+    "lm_hip_result_pool_info": (C.c_int, [_szp, _szp, _szp]),
     "lm_hip_stride": (_sz, [_sz, _sz]),
     "lm_hip_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "lm_hip_ctx_create_on_stream": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
@@ -62,6 +63,7 @@ SIGNATURES = {
     "lm_hip_ctx_set_xcd_remap": (C.c_int, [_vp, C.c_int]),
     "lm_hip_ctx_set_prefilter": (C.c_int, [_vp, C.c_int]),
     "lm_hip_ctx_set_track_argmax": (C.c_int, [_vp, C.c_int]),
+    "lm_hip_ctx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
     "lm_hip_ctx_last_kernel": (C.c_char_p, [_vp]),
     "lm_hip_pssm_create": (C.c_int, [_vp, _vp, _sz, _sz, _sz, C.POINTER(_vp)]),
     "lm_hip_pssm_reverse_complement": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),

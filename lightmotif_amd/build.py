@@ -36,7 +36,8 @@ LONG_FLAGS = ["-mllvm", "-pragma-unroll-threshold=10000000"]
 XLONG = list(range(72, 89, 8))
 # score_pair_inst.hip: the pair-symbol prefilter scan alone for the lengths beyond the exact kernels (65 ... 128)
 PAIR = [(65, 80), (81, 96), (97, 112), (113, 128)]
-UNITS = ["score.hip", "reduce.hip", "hits.hip", "discrete.hip", "layout.hip", "scanmax.hip", "api.hip", "hostptr.hip", "comm.hip"]
+UNITS = ["score.hip", "reduce.hip", "hits.hip", "discrete.hip", "layout.hip", "scanmax.hip", "context.hip", "pssm.hip", "score_api.hip", "handles.hip",
+         "hostptr.hip", "comm.hip"]
 
 
 def _hipcc() -> str:

@@ -111,7 +111,7 @@ Rccl &rccl()
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
-        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.handle, "ncclCommAbort"));  // optional
+        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(sym("ncclCommAbort"));  // required: every wait is bounded by it
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
         r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
@@ -206,19 +206,26 @@ int comm_usable(const lm_hip_comm *comm)
 // A collective that a peer never enters would block its stream for ever.  Every wait on one is a poll
 // with a deadline; past it the communicator is aborted (ncclCommAbort ends the kernel that spins on the
 // missing peer) and the call -- and every later one on this communicator -- returns LM_HIP_ERR_COMM.
-void abort_comm(lm_hip_comm *comm)
+// Work queued BEHIND the stuck collective (read-backs into pinned areas and into result blocks the caller is about to
+// free) would still land after the call has returned: ncclCommAbort has released the kernel, so the streams drain in
+// bounded time, and they are drained here before anything is handed back or freed.
+void abort_comm(lm_hip_comm *comm, hipStream_t waited_on = nullptr)
 {
     comm->broken = true;
-    if (comm->nccl && rccl().CommAbort) {
+    if (comm->nccl) {
         (void)rccl().CommAbort(comm->nccl);
         comm->nccl = nullptr;
     }
+    if (waited_on)
+        (void)hipStreamSynchronize(waited_on);
+    if (comm->side && comm->side != waited_on)
+        (void)hipStreamSynchronize(comm->side);
     for (auto &sl : comm->slot)
         sl.pending = false;
 }
 
 template <class Query>
-int wait_bounded(lm_hip_comm *comm, Query query, const char *what)
+int wait_bounded(lm_hip_comm *comm, Query query, const char *what, hipStream_t stream = nullptr)
 {
     using clock = std::chrono::steady_clock;
     const auto t0 = clock::now();
@@ -227,13 +234,13 @@ int wait_bounded(lm_hip_comm *comm, Query query, const char *what)
         if (e == hipSuccess)
             return LM_HIP_OK;
         if (e != hipErrorNotReady) {
-            abort_comm(comm);
+            abort_comm(comm, stream);
             return fail(LM_HIP_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
         }
         if (spins >= 4096) {  // ~a few hundred microseconds of tight polling cover every healthy merge
             const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(clock::now() - t0).count();
             if (comm->timeout_ms > 0 && ms > comm->timeout_ms) {
-                abort_comm(comm);
+                abort_comm(comm, stream);
                 return fail(LM_HIP_ERR_COMM, "%s: no completion after %lld ms (rank %d of %d): a peer rank did not "
                                              "enter the collective; communicator aborted (LM_HIP_COMM_TIMEOUT_MS)",
                             what, ms, comm->rank, comm->nranks);
@@ -245,7 +252,7 @@ int wait_bounded(lm_hip_comm *comm, Query query, const char *what)
 
 int wait_stream(lm_hip_comm *comm, hipStream_t st, const char *what)
 {
-    return wait_bounded(comm, [st] { return hipStreamQuery(st); }, what);
+    return wait_bounded(comm, [st] { return hipStreamQuery(st); }, what, st);
 }
 
 // Collectives of one communicator must not run concurrently: the synchronous entry points use the
@@ -354,21 +361,24 @@ int lm_hip_comm_destroy(lm_hip_comm *comm)
     if (!comm)
         return LM_HIP_OK;
     DeviceGuard guard(comm->device);
-    comm->buf.release();
-    if (comm->side) {
-        if (!comm->broken)
-            (void)hipStreamSynchronize(comm->side);
+    // first the collectives, then what they read and write: a merge still queued on the side stream is waited for with
+    // the usual bound (a peer that never came aborts the communicator, which drains the stream); only then do the
+    // communicator, its buffers and events go
+    if (comm->side && !comm->broken)
+        (void)wait_stream(comm, comm->side, "comm_destroy (pending merges)");
+    if (comm->nccl && rccl().ok)
+        (void)rccl().CommDestroy(comm->nccl);  // (an aborted communicator is gone already: never destroyed twice)
+    comm->nccl = nullptr;
+    if (comm->side)
         (void)hipStreamDestroy(comm->side);
-    }
     for (auto &sl : comm->slot) {
         if (sl.ready) (void)hipEventDestroy(sl.ready);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
+    comm->buf.release();
     comm->abuf.release();
     if (comm->h_slots)
         (void)hipHostFree(comm->h_slots);
-    if (comm->nccl && rccl().ok)
-        (void)rccl().CommDestroy(comm->nccl);
     delete comm;
     return LM_HIP_OK;
 }

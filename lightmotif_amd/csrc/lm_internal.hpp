@@ -95,8 +95,8 @@ struct lm_hip_ctx {
     lm::Scratch scratch2;
     lm::Scratch scan_buf;       // Scanner::max walk (scanmax.hip): one window of u8 scores and the walk's state
     lm::Scratch chunk_scores;   // fused reductions of sliced (M > 36) motifs: one chunk of f32 scores (score.hip)
-    size_t chunk_rows = 1u << 22; // rows of that chunk (512 MB at C = 32; LM_HIP_CHUNK_ROWS)
-    bool chunked_fused = true;  // A/B knob: 0 = such motifs go cell by cell (LM_HIP_CHUNKED_FUSED)
+    size_t chunk_rows = 1u << 22; // rows of that chunk (512 MB at C = 32; option "chunk_rows")
+    bool chunked_fused = true;  // A/B knob: 0 = such motifs go cell by cell (option "chunked_fused")
     void *pinned = nullptr;     // kPinnedBytes of host-pinned memory for read-backs
     unsigned fold_generation = 0; // of the last single-job fused argmax whose kernel wrote its result into `pinned`
     unsigned *d_ticket = nullptr; // "last workgroup folds the records" counter of the single-launch argmax forms (zero between launches)
@@ -107,12 +107,14 @@ struct lm_hip_ctx {
     bool pair_prefilter_protein = false;  // the 441-row protein pair scan: correct, measured 4 % slower
     bool quad_loads = true;      // store kernel: quad-gathered dword symbol loads (M % 4 == 0; +1 %)
     bool track_argmax = true;    // score_into on handles also tracks the best cell (cached argmax)
-    bool xlong_store = true;     // motifs of 65 ... kMaxStoreM rows are stored in one pass (LM_HIP_XLONG=0: slices of <= 64)
-    bool host_fold = true;       // ... small matrices: per-wavefront records folded by the host (LM_HIP_HOST_FOLD=0: on the device)
+    bool xlong_store = true;     // motifs of 65 ... kMaxStoreM rows are stored in one pass (option "xlong_store" = 0: slices of <= 64)
+    bool host_fold = true;       // ... small matrices: per-wavefront records folded by the host (option "host_fold" = 0: on the device)
     bool speculate_order = true; // fused threshold: order the hit list before the host knows its length
     bool suffix_argmax = true;   // fused argmax of short motifs: try the last rows first (score.hip)
     bool multi_motif = true;     // many-motif threshold batches: several motifs of one length per pass
     bool skip_unreachable = true; // fused threshold: no scan when the threshold exceeds the best k-mer's score
+    bool tiled = true;           // column counts off the C = 32 / 16 kernels: LDS-tiled kernel (0: one thread per cell)
+    double suffix_occurrences = 0; // fused argmax of short motifs: best k-mers the suffix should hold (0 = ln lambda, score.hip)
     int num_cus = 256;
     unsigned long long last_hit_count = 0;  // sizes the next fused-threshold hit list
     unsigned long long last_cand_count = 0; // ... and its candidate list
@@ -192,6 +194,40 @@ struct lm_hip_scores {
 };
 
 namespace lm {
+
+// A dense result (a threshold every cell passes: 16 B per cell on the device while it is ordered and copied) must not
+// leave the context holding tens of gigabytes for good: scratch above this is handed back when such a call ends.
+constexpr size_t kScratchKeepBytes = (size_t)2 << 30;
+struct ScratchTrim {
+    lm_hip_ctx *ctx;
+    explicit ScratchTrim(lm_hip_ctx *c) : ctx(c) {}
+    ~ScratchTrim()
+    {
+        for (Scratch *s : {&ctx->scratch, &ctx->scratch2})
+            if (s->bytes > kScratchKeepBytes) {
+                (void)hipStreamSynchronize(ctx->stream);
+                s->release();
+            }
+    }
+};
+
+
+// ArgmaxRecord -> the (found, coordinates, value) outputs of the ABI
+inline void record_to_coords(const ArgmaxRecord &rec, size_t cols, int *found, lm_hip_coords *best,
+                             float *value)
+{
+    if (found)
+        *found = rec.found;
+    if (rec.found) {
+        if (best) {
+            best->row = (size_t)(rec.index / (long long)cols);
+            best->col = (size_t)(rec.index % (long long)cols);
+        }
+        if (value)
+            *value = rec.value;
+    }
+}
+
 
 // ---- kernel launchers (score.hip, reduce.hip, layout.hip) ----------------------
 

@@ -61,24 +61,37 @@ __device__ __forceinline__ float score_cell(const ScanMaxSource &src, const unsi
     return acc;
 }
 
-// The state update behind one search (one thread, a launch of its own: letting the search's last workgroup do it
+// The state update behind one search (ONE wavefront, a launch of its own: letting the search's last workgroup do it
 // was tried -- a ticket per workgroup means an agent-scope release per workgroup, an L2 write-back on this
 // multi-XCD part, and the search got 2.7 x slower): the found cell becomes the best hit (scan.rs:229-242), or the
 // window is walked.  `last_round` != 0 (pipelined windows): this was the window's last search; if its walk is not
 // finished, mark the window (`stall = window_id + 1`) -- every kernel enqueued behind it then leaves the state alone.
-__global__ void scanmax_apply(const uint8_t *__restrict__ d, const ScanMaxSource src, const unsigned long long ncells,
-                              const unsigned cols, const unsigned long long row0, const unsigned long long rows,
-                              const unsigned m, const int last_round, const int window_id, ScanMaxState *__restrict__ st,
-                              ScanMaxState *__restrict__ host_copy)
+//
+// Behind the found cell the wavefront WALKS ON, 64 cells at a time, for as long as the cells keep updating the state:
+// on continuous scores the next update is ~n cells away and the first chunk ends the walk (a few microseconds), but
+// "equal score at a greater position replaces the best" (scan.rs:237) fires once per ROW across a run of equal
+// best-scoring cells -- homopolymers, low-complexity repeats, constant sequences -- and a search + update launch pair
+// per row made such inputs O(rows) launches (tens of seconds per 100 Mbp where the reference's single pass takes two).
+// Each lane scores its cell once; the updates inside a chunk are then resolved in cell order with ballots (the level
+// only rises, so the chunk's candidates at its first level contain all later ones).  Bounded per launch.
+constexpr unsigned long long kWalkCells = 1ull << 15;
+
+__global__ __launch_bounds__(64) void scanmax_apply(const uint8_t *__restrict__ d, const ScanMaxSource src,
+                                                    const unsigned long long ncells, const unsigned cols,
+                                                    const unsigned long long row0, const unsigned long long rows,
+                                                    const unsigned m, const int last_round, const int window_id,
+                                                    ScanMaxState *__restrict__ st, ScanMaxState *__restrict__ host_copy)
 {
-    ScanMaxState t = *st;
+    ScanMaxState t = *st;  // uniform over the wavefront
     if (t.err | t.stall)
         return;
+    const unsigned lane = threadIdx.x;
+    const unsigned long long total = rows * cols;
     if (t.found != ~0ull) {
         const unsigned long long f = t.found;
         const unsigned long long r = row0 + f / cols, col = f % cols;
         const unsigned long long index = col * rows + r;
-        if (index + m > rows * cols) {
+        if (index + m > total) {
             t.err = 1;
             t.index = index;
             t.cursor = ncells;
@@ -90,7 +103,42 @@ __global__ void scanmax_apply(const uint8_t *__restrict__ d, const ScanMaxSource
             t.score = score_cell(src, r, (unsigned)col, m);  // = score_position (pwm/mod.rs:651-662)
             t.index = index;
             t.cursor = f + 1;
-            t.more = t.cursor < ncells;
+            bool hot = true;
+            for (unsigned long long walked = 0; hot && !t.err && t.cursor < ncells && walked < kWalkCells; walked += 64) {
+                hot = false;
+                const unsigned long long g = t.cursor + lane;
+                const bool valid = g < ncells;
+                const unsigned dv = valid ? d[g] : 0u;
+                const unsigned long long gr = row0 + g / cols, gc = g % cols;
+                const unsigned long long gi = gc * rows + gr;  // scan.rs:231
+                const bool cand = valid && dv >= t.level;
+                const bool leaves = cand && gi + m > total;  // score_position would index column C: the reference panics
+                const float x = (cand && !leaves) ? score_cell(src, gr, (unsigned)gc, m) : 0.0f;
+                unsigned long long pending = __ballot(cand);
+                while (pending) {
+                    const bool act = ((pending >> lane) & 1ull) && dv >= t.level &&
+                                     (leaves || x > t.score || (x == t.score && gi > t.index));
+                    const unsigned long long am = __ballot(act);
+                    if (!am)
+                        break;
+                    const int fl = __ffsll((long long)am) - 1;
+                    const unsigned long long i_s = __shfl(gi, fl);
+                    if (__shfl((int)leaves, fl)) {
+                        t.err = 1;
+                        t.index = i_s;
+                        break;
+                    }
+                    t.level = __shfl(dv, fl);
+                    t.score = __shfl(x, fl);
+                    t.index = i_s;
+                    hot = true;
+                    pending &= ~((2ull << fl) - 1ull);  // the cells behind it, against the new state
+                }
+                t.cursor = t.cursor + 64 < ncells ? t.cursor + 64 : ncells;
+            }
+            if (t.err)
+                t.cursor = ncells;
+            t.more = !t.err && t.cursor < ncells;
         }
     } else {
         t.more = 0;
@@ -99,8 +147,10 @@ __global__ void scanmax_apply(const uint8_t *__restrict__ d, const ScanMaxSource
     t.found = ~0ull;
     if (last_round && t.more)
         t.stall = window_id + 1;
-    *st = t;
-    *host_copy = t;
+    if (lane == 0) {
+        *st = t;
+        *host_copy = t;
+    }
 }
 
 // One search of the walk over the window in `d`: the FIRST cell at or after the cursor the reference's loop would ACT
@@ -253,7 +303,7 @@ int launch_scan_max(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *
         for (int rep = 0; rep < rounds; ++rep) {
             hipLaunchKernelGGL(scanmax_find, dim3(grid), dim3(kBlock), 0, ctx->stream, d_d, src, ncells, (unsigned)cols,
                                (unsigned long long)wd.r, (unsigned long long)rows, (unsigned)m, fresh && rep == 0 ? 1 : 0, d_st);
-            hipLaunchKernelGGL(scanmax_apply, dim3(1), dim3(1), 0, ctx->stream, d_d, src, ncells, (unsigned)cols,
+            hipLaunchKernelGGL(scanmax_apply, dim3(1), dim3(64), 0, ctx->stream, d_d, src, ncells, (unsigned)cols,
                                (unsigned long long)wd.r, (unsigned long long)rows, (unsigned)m,
                                pipelined && rep == rounds - 1 ? 1 : 0, id, d_st, h_st);
         }

@@ -309,6 +309,29 @@ static unsigned long long store_rows_hint(size_t m_kernel, size_t cols)
     return (cols == 32 && m_kernel == 12) ? 12 : 0;
 }
 
+// Geometry of the LDS-tiled store kernel (any column count): workgroups of `*tr` rows whose tile -- the dense table +
+// tr + M - 1 rows of `cols` symbols -- fits 40 KB.  Returns the grid size, 0 when the shape goes cell by cell.
+static unsigned tiled_plan(const lm_hip_ctx *ctx, const ScoreArgs &a, unsigned long long *tr_out, size_t *lds_out)
+{
+    if (!ctx->tiled)
+        return 0;
+    const size_t tab_bytes = (a.pssm->m * a.pssm->k * 4 + 15) / 16 * 16;
+    const size_t budget = 40 * 1024;
+    const unsigned long long n = a.row_end - a.row_begin;
+    if (!(a.pssm->m >= 1 && tab_bytes + (a.pssm->m + 8) * a.cols <= budget && a.cols <= 4096))
+        return 0;
+    unsigned long long tr = (budget - tab_bytes) / a.cols - (a.pssm->m - 1);
+    tr = std::min<unsigned long long>(tr / kTiledStrip * kTiledStrip, 2048);
+    // enough workgroups to fill the chip
+    while (tr > kTiledStrip * 4 && (n + tr - 1) / tr < (unsigned long long)ctx->num_cus * 4)
+        tr = (tr / 2 + kTiledStrip - 1) / kTiledStrip * kTiledStrip;
+    if (tr < (unsigned long long)kTiledStrip)
+        return 0;
+    *tr_out = tr;
+    *lds_out = tab_bytes + (tr + a.pssm->m - 1) * a.cols + 16;
+    return (unsigned)((n + tr - 1) / tr);
+}
+
 int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
 {
     FusedOut fo{};
@@ -398,43 +421,33 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
         }
     }
     // any other geometry: the tiled kernel when its LDS tile fits (the dense table + TR + M - 1 rows of
-    // `cols` symbols), else one thread per cell (LM_HIP_TILED=0: always, for A/B runs)
-    static const bool tiled_on = [] { const char *e = getenv("LM_HIP_TILED"); return !e || atoi(e) != 0; }();
-    if (tiled_on) {
-        const size_t tab_bytes = (a.pssm->m * a.pssm->k * 4 + 15) / 16 * 16;
-        const size_t budget = 40 * 1024;
+    // `cols` symbols), else one thread per cell (context option "tiled" = 0: always, for A/B runs)
+    unsigned long long tr = 0;
+    size_t lds = 0;
+    const unsigned grid_x = tiled_plan(ctx, a, &tr, &lds);
+    if (grid_x) {
+        ctx->last_kernel = "score_tiled";
+        const dim3 grid(grid_x);
+        const size_t nrec = grid.x;  // one record per workgroup
         const unsigned long long n = a.row_end - a.row_begin;
-        if (a.pssm->m >= 1 && tab_bytes + (a.pssm->m + 8) * a.cols <= budget && a.cols <= 4096) {
-            unsigned long long tr = (budget - tab_bytes) / a.cols - (a.pssm->m - 1);
-            tr = std::min<unsigned long long>(tr / kTiledStrip * kTiledStrip, 2048);
-            // enough workgroups to fill the chip
-            while (tr > kTiledStrip * 4 && (n + tr - 1) / tr < (unsigned long long)ctx->num_cus * 4)
-                tr = (tr / 2 + kTiledStrip - 1) / kTiledStrip * kTiledStrip;
-            if (tr >= (unsigned long long)kTiledStrip) {
-                const size_t lds = tab_bytes + (tr + a.pssm->m - 1) * a.cols + 16;
-                ctx->last_kernel = "score_tiled";
-                const dim3 grid((unsigned)((n + tr - 1) / tr));
-                const size_t nrec = grid.x;  // one record per workgroup
-                const bool track = a.track_records && nrec + 1 <= a.track_cap && n * a.cols < (1ull << 32);
-                if (a.track_nrec)
-                    *a.track_nrec = track ? (unsigned)nrec : 0u;
-                auto launch = [&](auto kernel) {
-                    hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, ctx->stream, a.d_seq, (unsigned long long)a.seq_stride,
-                                       (int)a.cols, a.pssm->d_dense, (int)a.pssm->m, (int)a.pssm->k,
-                                       (unsigned long long)a.row_begin, (unsigned long long)a.row_end, (int)tr, a.d_out,
-                                       (unsigned long long)a.out_stride, track ? a.track_records : (uint4 *)nullptr,
-                                       a.track_generation);
-                };
-                if (a.pssm->k == 5)
-                    launch(score_tiled<kTiledStrip, 5>);
-                else if (a.pssm->k == 21)
-                    launch(score_tiled<kTiledStrip, 21>);
-                else
-                    launch(score_tiled<kTiledStrip, 0>);
-                LM_HIP_TRY(hipGetLastError());
-                return LM_HIP_OK;
-            }
-        }
+        const bool track = a.track_records && nrec + 1 <= a.track_cap && n * a.cols < (1ull << 32);
+        if (a.track_nrec)
+            *a.track_nrec = track ? (unsigned)nrec : 0u;
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, ctx->stream, a.d_seq, (unsigned long long)a.seq_stride,
+                               (int)a.cols, a.pssm->d_dense, (int)a.pssm->m, (int)a.pssm->k,
+                               (unsigned long long)a.row_begin, (unsigned long long)a.row_end, (int)tr, a.d_out,
+                               (unsigned long long)a.out_stride, track ? a.track_records : (uint4 *)nullptr,
+                               a.track_generation);
+        };
+        if (a.pssm->k == 5)
+            launch(score_tiled<kTiledStrip, 5>);
+        else if (a.pssm->k == 21)
+            launch(score_tiled<kTiledStrip, 21>);
+        else
+            launch(score_tiled<kTiledStrip, 0>);
+        LM_HIP_TRY(hipGetLastError());
+        return LM_HIP_OK;
     }
     ctx->last_kernel = "score_generic<0>";
     const unsigned long long ncells = (unsigned long long)(a.row_end - a.row_begin) * a.cols;
@@ -806,7 +819,13 @@ int launch_score_store_track(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *
     if (!fn || !table) {
         // off the C = 32 kernels (C = 1: the Generic bench geometry of dna.rs:113-116, C = 16 shapes, odd strides): the
         // tiled store kernel leaves the same per-wavefront records when the handle can take them
-        ensure_records(16384);
+        {   // the record block is sized from the grid the tiled kernel will actually run (one record per workgroup)
+            unsigned long long tr = 0;
+            size_t lds = 0;
+            const unsigned g = tiled_plan(ctx, a, &tr, &lds);
+            if (g && g < 16384)
+                ensure_records((size_t)g + 1);
+        }
         ScoreArgs t = a;
         unsigned nrec_t = 0;
         if (host_fold && host_fold->h_records) {
@@ -2173,15 +2192,11 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
 // range, scanning a fraction f costs f + exp(-lambda * f) of a full scan (the miss falls back to the usual
 // routes), minimal at f = ln(lambda) / lambda: the suffix holds ln(lambda) occurrences, between 1.5 (a miss
 // every fifth motif, still a net gain) and 8.  Round 1 used a flat 24: never a miss, four times the rows
-// (JASPAR batch 14.0-14.7 -> 11.0 ms; LM_HIP_SUFFIX_OCCURRENCES=<x> pins the value for A/B runs).
-static double suffix_occurrences(double lambda)
+// (JASPAR batch 14.0-14.7 -> 11.0 ms; the context option "suffix_occurrences" pins the value for A/B runs).
+static double suffix_occurrences(const lm_hip_ctx *ctx, double lambda)
 {
-    static const double pinned = [] {
-        const char *e = getenv("LM_HIP_SUFFIX_OCCURRENCES");
-        return e && atof(e) > 0 ? atof(e) : 0.0;
-    }();
-    if (pinned > 0)
-        return pinned;
+    if (ctx->suffix_occurrences > 0)
+        return ctx->suffix_occurrences;
     return std::min(8.0, std::max(1.5, std::log(std::max(lambda, 1.0))));
 }
 constexpr unsigned long long kSuffixMinRows = 1ull << 15;  // keeps the streams long enough
@@ -2209,7 +2224,7 @@ static int argmax_by_suffix(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n, Ar
         const double lambda = (double)rows * (double)a.cols / kmers;
         if (lambda < 2.0)
             continue;  // a best k-mer is not expected in the range at all
-        const double need_cells = suffix_occurrences(lambda) * kmers;
+        const double need_cells = suffix_occurrences(ctx, lambda) * kmers;
         const unsigned long long need_rows =
             std::max<unsigned long long>((unsigned long long)(need_cells / (double)a.cols) + 1, kSuffixMinRows);
         const bool dense = (double)need_rows * (double)a.cols / kmers > 256.0;  // expected hits at t = B

@@ -134,6 +134,10 @@ class Pipeline:
         same scores is free (default on)."""
         check(self._L.lm_hip_ctx_set_track_argmax(self._h, int(enabled)))
 
+    def set_option(self, name: str, value: float) -> None:
+        """An alternative path inside the library with identical results (``lm_hip_ctx_set_option``): for tests and A/B runs."""
+        check(self._L.lm_hip_ctx_set_option(self._h, name.encode(), float(value)))
+
     def set_xcd_remap(self, enabled: bool) -> None:
         check(self._L.lm_hip_ctx_set_xcd_remap(self._h, int(enabled)))
 
@@ -1127,8 +1131,12 @@ class Scanner:
         i = top[np.argmax(pos[top])]
         return Hit(int(pos[i]), float(sc[i]))
 
-    def max(self, saturate: bool = True) -> Optional[Hit]:
+    def max(self, saturate: bool = True, strict_reference: Optional[bool] = None) -> Optional[Hit]:
         """``Scanner::max`` exactly as the reference computes it (scan.rs:200-249); consumes the scanner.
+
+        ``strict_reference`` is accepted for callers written against the first rounds of this package (where the
+        reference's walk was opt-in) and ignored with a DeprecationWarning: the walk is the only behaviour of
+        ``max()`` now; ``strict_reference=False`` callers want :meth:`max_valid`.
 
         The u8 DiscreteMatrix scores steer which cells are looked at: starting from the best pending hit
         (or none) and the level ``dm.scale(threshold)``, cells are visited block by block in row-major
@@ -1140,6 +1148,10 @@ class Scanner:
         level (the u8 score of the current best, an over-estimate) is skipped (scan.rs:227-243).
         ``saturate``: the u8 adds of the x86-64 ``dispatch`` pipeline (avx2.rs:336); ``False`` =
         Generic's wrapping adds.  :meth:`max_valid` is the variant without those corner cases."""
+        if strict_reference is not None:
+            import warnings
+            warnings.warn("Scanner.max(strict_reference=...) is deprecated: max() always walks like the reference "
+                          "(scan.rs:200-249); use max_valid() for the greatest valid hit", DeprecationWarning, stacklevel=2)
         return self._max_device(saturate)
 
     def _pending_state(self):

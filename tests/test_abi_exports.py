@@ -87,7 +87,7 @@ out = {}
 for name, (res, args) in _ffi.SIGNATURES.items():
     if res is not C.c_int or not args:
         continue
-    vals = [0.0 if a is C.c_float else b"D" if a is C.c_char else 0 if a in (C.c_int, C.c_size_t, C.c_uint, C.c_uint8)
+    vals = [0.0 if a in (C.c_float, C.c_double) else b"D" if a is C.c_char else 0 if a in (C.c_int, C.c_size_t, C.c_uint, C.c_uint8)
             else None for a in args]
     print(name, file=sys.stderr, flush=True)          # the last name printed is the one that crashed, if any does
     st = getattr(L, name)(*vals)

@@ -28,7 +28,7 @@ out = {}
 for name, (res, args) in _ffi.SIGNATURES.items():
     if res is not C.c_int or name not in ctx_first or name == "lm_hip_ctx_destroy":
         continue
-    vals = [0.0 if a is C.c_float else b"D" if a is C.c_char else 0 if a in (C.c_int, C.c_size_t, C.c_uint, C.c_uint8)
+    vals = [0.0 if a in (C.c_float, C.c_double) else b"D" if a is C.c_char else 0 if a in (C.c_int, C.c_size_t, C.c_uint, C.c_uint8)
             else None for a in args]
     vals[0] = ctx
     print(name, file=sys.stderr, flush=True)
@@ -117,7 +117,7 @@ for name, good in calls.items():
     res[name + ":valid"] = [st, _ffi.last_error() if st else "", 0]
     args = _ffi.SIGNATURES[name][1]
     for i, a in enumerate(args):
-        if i == 0 or a in (C.c_float, C.c_char, C.c_int, C.c_size_t, C.c_uint, C.c_uint8) or good[i] is None:
+        if i == 0 or a in (C.c_float, C.c_double, C.c_char, C.c_int, C.c_size_t, C.c_uint, C.c_uint8) or good[i] is None:
             continue
         bad = list(good); bad[i] = None
         print(name, "arg", i, file=sys.stderr, flush=True)

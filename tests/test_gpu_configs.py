@@ -480,14 +480,14 @@ def test_long_motifs_are_scored_in_slices(pli, m):
 @pytest.mark.parametrize("m,chunk_rows", [(37, 5000), (40, 4096), (45, 4096), (53, 4096), (59, 4096), (64, 1 << 20),
                                           (65, 5000), (73, 7777), (100, 20_000), (127, 4096), (128, 4096), (129, 4096),
                                           (150, 128)])
-def test_long_motifs_fused_reductions_go_chunk_by_chunk(monkeypatch, m, chunk_rows):
+def test_long_motifs_fused_reductions_go_chunk_by_chunk(m, chunk_rows):
     """score_argmax / score_threshold / Scanner-style hits of M > 36.  Up to 64 rows: the fused kernels of
     the long family (score_c32<M', 1 | 2>), no score matrix.  Beyond: the sliced store path into a
     reusable chunk buffer + a reduction per chunk (score.hip, KIND_CHUNKED) instead of one thread per
     cell.  Same cells, same values: bit-exact against the oracle's materialised matrix, row-major hit
     order, last-maximal-cell ties across chunk borders, first-cell NaN rule, row sub-ranges."""
-    monkeypatch.setenv("LM_HIP_CHUNK_ROWS", str(chunk_rows))
     pli = lm.Pipeline.hip(0)
+    pli.set_option("chunk_rows", chunk_rows)
     rng = np.random.default_rng(7000 + m)
     length = 1_500_000 + 13 * m
     enc = rng.integers(0, 5, length, dtype=np.uint8)

@@ -14,7 +14,7 @@ from oracle import c_oracle as co
 from oracle import np_oracle as no
 
 pytestmark = pytest.mark.gpu
-PAIRS = os.environ.get("LM_HIP_PAIR_PREFILTER", "1") != "0"   # the A/B knob may be set for a whole run
+PAIRS = True   # the DNA pair-symbol scan is the shipped route (option "pair_prefilter" = 0: one symbol per lookup)
 GOLD_SEQ = "ATGTCCCAACAACGATACCCCGAGCCCATCGCCGTCATCGGCTCGGCATGCAGATTCCCAGGCG"
 PATTERNS = ["GTTGACCTTATCAAC", "GTTGATCCAGTCAAC"]
 
@@ -112,12 +112,11 @@ def test_u8_scores_reductions_and_row_ranges(pli, length, m, protein, top, cols)
 
 
 @pytest.mark.parametrize("m", [2, 3, 4, 9, 20, 23, 36])
-def test_one_symbol_scan_and_unaligned_buffers(monkeypatch, m):
-    """The DNA pair-symbol scan can be switched off (LM_HIP_PAIR_PREFILTER=0 -> one symbol per
+def test_one_symbol_scan_and_unaligned_buffers(m):
+    """The DNA pair-symbol scan can be switched off (option "pair_prefilter" = 0 -> one symbol per
     lookup) and needs 4-byte aligned matrices; every route gives the same bytes."""
-    monkeypatch.setenv("LM_HIP_PAIR_PREFILTER", "0")
     single = lm.Pipeline.hip(0)
-    monkeypatch.delenv("LM_HIP_PAIR_PREFILTER")
+    single.set_option("pair_prefilter", 0)
     paired = lm.Pipeline.hip(0)
     rng = np.random.default_rng(m)
     length = 70_001

@@ -314,23 +314,22 @@ def test_unaligned_sequence_pointer(gpu_pli, offset):
     assert am_a == am_u
     t = float(torch.quantile(out_a.view(-1)[:4_000_000], 1 - 1e-4))
     th_a = pli.score_threshold_dptr(pssm, ptr_a, rows + m - 1, COLS, COLS, m - 1, length, 0, rows, t)
-    pairs = os.environ.get("LM_HIP_PAIR_PREFILTER", "1") != "0"   # A/B knob of a whole run
-    assert pli.last_kernel == ("score_c32_prefilter2" if pairs else "score_c32_prefilter")
+    assert pli.last_kernel == "score_c32_prefilter2"
     th_u = pli.score_threshold_dptr(pssm, ptr_u, rows + m - 1, COLS, COLS, m - 1, length, 0, rows, t)
     assert pli.last_kernel == "score_c32_prefilter"
     assert np.array_equal(th_a[0], th_u[0]) and np.array_equal(th_a[1], th_u[1]) and len(th_a[0]) > 50
 
 
-def test_hit_ordering_with_and_without_known_count(monkeypatch):
+def test_hit_ordering_with_and_without_known_count():
     """The fused threshold orders its hit list either after reading the count
-    (LM_HIP_SPECULATE_ORDER=0) or before (default; sized from the previous call and redone
+    (option "speculate_order" = 0) or before (default; sized from the previous call and redone
     when that guess is off): both give the materialised result whatever the call history."""
     torch.cuda.set_device(0)
     stream = torch.cuda.current_stream().cuda_stream
     plis = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("LM_HIP_SPECULATE_ORDER", flag)
         plis[flag] = lm.Pipeline.hip(0, stream=stream)
+        plis[flag].set_option("speculate_order", int(flag))
     length, m = 40_000_003, 10
     seq, rows, pssm = make_workload(plis["1"], length, m, 5, seed=77)
     scores = score_all(plis["1"], pssm, seq, rows, m, length)
@@ -352,15 +351,14 @@ def test_hit_ordering_with_and_without_known_count(monkeypatch):
 
 @pytest.mark.parametrize("m,kind", [(1, "random"), (3, "random"), (5, "ties"), (6, "random"), (6, "absent_in_suffix"),
                                     (4, "only_at_the_end"), (7, "finite_n"), (9, "random"), (5, "range")])
-def test_fused_argmax_of_short_motifs_from_the_last_rows(monkeypatch, m, kind):
+def test_fused_argmax_of_short_motifs_from_the_last_rows(m, kind):
     """Short motifs are settled from the last rows of the range when those hold a best k-mer
     (score == sum of the row maxima); otherwise the usual routes run.  Both must give the
     Generic argmax (pli/mod.rs:135-155) -- also when the best k-mer is missing from the suffix,
     sits in the very last valid window only, ties abound, N has finite weights, or a row
     range is scored."""
-    monkeypatch.setenv("LM_HIP_SUFFIX_ARGMAX", "0")
     plain = lm.Pipeline.hip(0)
-    monkeypatch.delenv("LM_HIP_SUFFIX_ARGMAX")
+    plain.set_option("suffix_argmax", 0)
     suffix = lm.Pipeline.hip(0)
     rng = np.random.default_rng(1000 + m)
     length = 6_000_011
@@ -579,3 +577,76 @@ def test_materialised_reductions_at_span_and_chunk_boundaries(gpu_pli, ncells):
     assert pli.argmax_dptr(scores.data_ptr(), ncells, 1, 1)[0] == co.argmax(host.reshape(-1, 1), 1) == (0, 0)
     if ncells > 1:
         assert pli.argmax_dptr(scores.data_ptr(), ncells, 1, 1, first_cell_rule=False)[0] == (ncells - 1, 0)
+
+
+def test_dense_results_at_full_size(gpu_pli):
+    """A threshold EVERY cell passes, at BASELINE's full size: 10^9 (row, col) pairs = 16 GB of coordinates (pli/mod.rs:210-221
+    pushes them all).  A finite N weight makes the padded tail qualify too.  Each entry point either returns
+    the complete row-major list or a clean LM_HIP_ERR_OOM; afterwards the context works, holds no tens of gigabytes of
+    scratch, and the page-locked result pool is back under its cap."""
+    import ctypes as C
+    from lightmotif_amd import _ffi
+    L = _ffi.lib()
+    pli = gpu_pli
+    length, m = 1_000_000_000 - 5, 20
+    seq, rows, pssm = make_workload(pli, length, m, 5, seed=4242)
+    w = pssm.data.copy()
+    w[:, 4] = -1.0                                                      # N scores finitely: no -inf anywhere
+    pssm = lm.ScoringMatrix(w)
+    scores = score_all(pli, pssm, seq, rows, m, length)
+    ncells = rows * COLS
+    free0, _ = torch.cuda.mem_get_info()
+
+    def pool_ok():
+        idle, used, budget = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        assert L.lm_hip_result_pool_info(C.byref(idle), C.byref(used), C.byref(budget)) == 0
+        return idle.value <= budget.value and used.value == 0
+
+    def small_call_works():
+        t = float(scores[:4096].max())
+        got = pli.threshold_dptr(scores.data_ptr(), 4096, COLS, COLS, t)
+        want = torch.nonzero(scores[:4096] >= t).cpu().numpy()
+        return np.array_equal(got, want)
+
+    # 1. Threshold on the materialised matrix
+    ptr, n = C.POINTER(_ffi.Coords)(), C.c_size_t(0)
+    st = L.lm_hip_threshold_f32_dptr(pli._h, C.c_void_p(scores.data_ptr()), rows, COLS, COLS, C.c_float(float("-inf")),
+                                     C.byref(ptr), C.byref(n))
+    assert st in (_ffi.OK, _ffi.ERR_OOM), _ffi.last_error()
+    if st == _ffi.OK:
+        assert n.value == ncells
+        for i in (0, 1, 31, 32, 33, ncells // 2 + 7, ncells - 2, ncells - 1):
+            assert (ptr[i].row, ptr[i].col) == (i // COLS, i % COLS), i
+        L.lm_hip_free(ptr)
+    assert small_call_works() and pool_ok()
+
+    # 2. fused score + threshold (coordinates and values)
+    ptr, vals, n = C.POINTER(_ffi.Coords)(), C.POINTER(C.c_float)(), C.c_size_t(0)
+    st = L.lm_hip_score_threshold_f32_dptr(pli._h, pssm._device(pli), C.c_void_p(seq.data_ptr()), rows + m - 1, COLS, COLS,
+                                           m - 1, length, 0, rows, C.c_float(float("-inf")), C.byref(ptr), C.byref(vals),
+                                           C.byref(n))
+    assert st in (_ffi.OK, _ffi.ERR_OOM), _ffi.last_error()
+    if st == _ffi.OK:
+        assert n.value == ncells
+        idx = [0, 1, 33, ncells // 3, ncells - 1]
+        want = scores.flatten()[torch.tensor(idx, device=scores.device)].cpu().numpy()
+        for i, wv in zip(idx, want):
+            assert (ptr[i].row, ptr[i].col) == (i // COLS, i % COLS) and np.float32(vals[i]) == wv, i
+        L.lm_hip_free(ptr)
+        L.lm_hip_free(vals)
+    assert small_call_works() and pool_ok()
+
+    # 3. Scanner semantics: ascending position, only windows that fit (scan.rs:185-190)
+    h = pli.adopt_sequence(seq.data_ptr(), rows, m - 1, COLS, COLS, length, keepalive=seq)
+    hits, n = C.POINTER(_ffi.Hit)(), C.c_size_t(0)
+    st = L.lm_hip_scan_f32(pli._h, pssm._device(pli), h._h, C.c_float(float("-inf")), C.byref(hits), C.byref(n))
+    assert st in (_ffi.OK, _ffi.ERR_OOM), _ffi.last_error()
+    if st == _ffi.OK:
+        assert n.value == length - m + 1
+        for i in (0, 1, 12345, rows, rows + 1, n.value - 1):
+            assert hits[i].position == i and np.float32(hits[i].score) == np.float32(scores[i % rows, i // rows].item()), i
+        L.lm_hip_free(hits)
+    assert small_call_works() and pool_ok()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (6 << 30), f"the context kept {(free0 - free1) >> 30} GB of scratch after dense results"

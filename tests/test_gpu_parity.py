@@ -377,11 +377,11 @@ def test_protein(pli, m):
 
 
 @pytest.mark.parametrize("m", [5, 12, 20, 31])
-def test_protein_pair_prefilter_opt_in(monkeypatch, m):
+def test_protein_pair_prefilter_opt_in(m):
     """The 441-row pair scan (score_c32_prefilter2<M, 21>) is off by default (measured 4 % slower)
-    but stays bit-exact: a pipeline created with LM_HIP_PAIR_PREFILTER_PROTEIN=1 must use it and agree."""
-    monkeypatch.setenv("LM_HIP_PAIR_PREFILTER_PROTEIN", "1")
+    but stays bit-exact: a pipeline with the option "pair_prefilter_protein" set must use it and agree."""
     pair = lm.Pipeline.hip(0)
+    pair.set_option("pair_prefilter_protein", 1)
     rng = np.random.default_rng(100 + m)
     enc = rng.integers(0, 21, 40_009, dtype=np.uint8)
     p = random_pssm(rng, m, 21)
@@ -394,7 +394,7 @@ def test_protein_pair_prefilter_opt_in(monkeypatch, m):
     assert frc == [tuple(map(int, rc)) for rc in co.threshold(want, 32, t)]
 
 
-def test_thresholds_above_the_best_kmer_are_not_scanned(pli, monkeypatch):
+def test_thresholds_above_the_best_kmer_are_not_scanned(pli):
     """A threshold above B = the sequential f32 sum of the PSSM's row maxima selects nothing whatever the
     sequence (rounding is monotone), so the fused threshold skips the scan; at t == B the planted best k-mer
     must still be found, and the batch form must keep its per-motif layout when some motifs are skipped."""
@@ -441,8 +441,8 @@ def test_thresholds_above_the_best_kmer_are_not_scanned(pli, monkeypatch):
         wrc = [tuple(map(int, rc)) for rc in co.threshold(w, 32, t)]
         assert [tuple(map(int, rc)) for rc in coords] == wrc
     assert len(res[1][0]) == 0 and len(res[0][0]) >= 40
-    monkeypatch.setenv("LM_HIP_SKIP_UNREACHABLE", "0")
     full = lm.Pipeline.hip(0)
+    full.set_option("skip_unreachable", 0)
     seq2 = full.stripe(lm.EncodedSequence(enc), 32)
     seq2.configure_wrap(13)
     assert full.score_threshold(lm.ScoringMatrix(p), seq2, above) == ([], [])
@@ -829,6 +829,70 @@ def test_scanner_on_protein(pli):
         lm.scan(pssm, seq)                                    # the Python binding's helper stays DNA-only (lib.rs)
 
 
+ABYB1_SITES = ["SFKELGFDSLTAVELRNRLAAAT", "AFKELGFDSLAAIQLRNRLLADV", "PSRRLGFDSLTAVELRNQLAAST", "AFREIGFDSLTAVELRNRLGAAA",
+               "SLMEEGLDSLAAVELGGTLQRDT", "GFFDLGMDSLMAVELRRRIEQGV"]
+
+
+def test_real_protein_abyB1_text_to_hits(pli):
+    """The reference's own protein bench fixture (lightmotif/benches/abyB1.txt, 5 781 residues, with the six 23-residue
+    sites of lightmotif/benches/score.rs:179-189): real letters through the text ingest (strict, and lossy with foreign
+    bytes mixed in), then score / argmax / max / threshold / Scanner on the device against the oracle -- every other
+    protein test draws uniform random symbols."""
+    text = (Path(__file__).parent / "golden" / "abyB1.txt").read_bytes()
+    assert len(text) == 5781
+    enc = co.encode(text, "P")
+    m = len(ABYB1_SITES[0])
+    want_pssm = co.pssm_from_sites([co.encode(x, "P") for x in ABYB1_SITES], 21, 0.1)
+    pssm = lm.create(ABYB1_SITES, protein=True).counts.normalize(0.1).log_odds()
+    assert np.array_equal(bits(pssm.data[:, :21]), bits(want_pssm[:, :21]))
+    ref = co.stripe(enc, 32, 21)
+    co.configure_wrap(ref, m - 1)
+    want, mi = co.score_rows(ref, want_pssm)
+    seq = pli.stripe_ascii(text, protein=True)                         # Encode + Stripe on the device (strict)
+    assert np.array_equal(seq.matrix(), ref.data[:ref.rows])
+    seq.configure(pssm)
+    assert np.array_equal(seq.matrix(), ref.data)
+    scores = pli.score(pssm, seq)
+    assert scores.max_index == mi == 5781 - m + 1
+    assert np.array_equal(bits(scores.matrix()[:, :32]), bits(want[:, :32]))
+    assert pli.last_kernel.startswith("score_c32<24") or pli.last_kernel.startswith("score_c32<23")
+    assert pli.argmax(scores) == co.argmax(want, 32)
+    assert bits(np.float32(pli.max(scores))) == bits(co.max_(want, 32))
+    assert pli.score_argmax(pssm, seq)[0] == co.argmax(want, 32)
+    finite = want[:, :32][np.isfinite(want[:, :32])]
+    for t in (float(np.quantile(finite, 0.99)), 0.0, float(finite.max())):
+        wrc = [tuple(map(int, rc)) for rc in co.threshold(want, 32, t)]
+        assert [tuple(map(int, rc)) for rc in pli.threshold(scores, t)] == wrc
+        frc, fv = pli.score_threshold(pssm, seq, t)
+        assert [tuple(map(int, rc)) for rc in frc] == wrc
+        assert np.array_equal(bits(fv), bits(np.array([want[r, c] for r, c in wrc], np.float32)))
+    # the sites themselves are in the sequence's neighbourhood: the best window scores well above the background
+    best = co.argmax(want, 32)
+    assert want[best] > 20.0
+    # Scanner (scan.rs:150-250): hits in the reference's yield order, and max()
+    t = float(np.quantile(finite, 0.995))
+    order = no.scanner_collect(want, 32, len(enc), m, t, 256)
+    got = [(h.position, np.float32(h.score)) for h in lm.Scanner(pssm, seq, threshold=t)]
+    assert len(got) >= 10 and got == [(i, s) for i, s in order]
+    top = lm.Scanner(pssm, seq, threshold=t).max_valid()
+    assert (top.position, np.float32(top.score)) == no.scanner_max(want, 32, len(enc), m, t)
+    # lossy ingest: bytes outside the alphabet (lower case, digits, a newline) become X; strict ingest names the first one
+    dirty = bytearray(text)
+    for i in (0, 17, 1000, 5780):
+        dirty[i] = b"a1\n*"[i % 4]
+    with pytest.raises(lm.InvalidSymbol):
+        pli.stripe_ascii(bytes(dirty), protein=True)
+    lossy = pli.stripe_ascii(bytes(dirty), protein=True, lossy=True)
+    enc_l = co.encode(bytes(dirty), "P", lossy=True)
+    assert [int(enc_l[i]) for i in (0, 17, 1000, 5780)] == [20] * 4
+    ref_l = co.stripe(enc_l, 32, 21)
+    co.configure_wrap(ref_l, m - 1)
+    lossy.configure(pssm)
+    assert np.array_equal(lossy.matrix(), ref_l.data)
+    want_l, _ = co.score_rows(ref_l, want_pssm)
+    assert np.array_equal(bits(pli.score(pssm, lossy).matrix()[:, :32]), bits(want_l[:, :32]))
+
+
 @pytest.mark.parametrize("m", [1, 3, 4, 15, 16, 20, 31, 33, 36, 37, 50, 64])
 def test_small_score_into_tracks_its_argmax_in_the_same_launch(pli, m):
     """`score_into` + `argmax` on handles below 8 Mi cells (lightmotif-bench dna.rs:104-107 at its own
@@ -913,6 +977,52 @@ def test_scanner_max_walk_on_the_device_at_size(pli, kind):
     got = lm.Scanner(pssm, seq, threshold=t).max()
     assert pli.last_kernel.startswith("scanmax_find")
     assert got is not None and (got.position, np.float32(got.score)) == (want[0], want[1]), (got, want)
+
+
+@pytest.mark.parametrize("kind", ["poly_a", "repeat", "random_then_poly_a", "poly_a_2mbp"])
+def test_scanner_max_on_degenerate_sequences(pli, kind):
+    """Homopolymers and low-complexity repeats: "equal score at a greater position replaces the best" (scan.rs:237) then
+    fires once per ROW, not ~ln n times.  The device walk consumes such runs inside its update kernel (a wavefront walking
+    on behind every found cell) instead of one search + update launch pair per row; same answer as the reference's
+    single pass, in bounded time."""
+    import time
+    rng = np.random.default_rng(sum(map(ord, kind)))
+    k, m = 5, 12
+    length = 2_000_003 if kind == "poly_a_2mbp" else 600_011
+    if kind.startswith("poly_a"):
+        enc = np.zeros(length, np.uint8)
+    elif kind == "repeat":
+        enc = np.tile(np.array([0, 1, 3], np.uint8), length // 3 + 1)[:length]
+    else:
+        enc = rng.integers(0, 4, length, dtype=np.uint8)
+        enc[length // 3:] = 0
+    p = np.zeros((m, co.stride(k, 4)), np.float32)
+    p[:, :k] = rng.normal(0, 2, (m, k))
+    p[:, 0] += 1.0                                             # the repeated letter scores well: every cell is a candidate
+    p[:, k - 1] = -np.inf
+    ref = co.stripe(enc, 32, k)
+    co.configure_wrap(ref, m - 1)
+    scores, _ = co.score_rows(ref, p)
+    w, factor, offsets, offset = no.to_discrete(p, k)
+    d = no.score_rows_u8_saturating(ref.data, 32, length, w, 0, ref.rows)
+    scale = lambda x: no.discrete_scale(x, factor, offset)   # noqa: E731
+    t = float(np.quantile(scores[:, :32][np.isfinite(scores[:, :32])], 0.5))
+    pssm = lm.ScoringMatrix(p)
+    seq = pli.stripe(lm.EncodedSequence(enc), 32)
+    seq.configure(pssm)
+    lm.Scanner(pssm, seq, threshold=t).max()                   # warm (tables, buffers)
+    t0 = time.perf_counter()
+    got = lm.Scanner(pssm, seq, threshold=t).max()
+    dt = time.perf_counter() - t0
+    if kind != "poly_a_2mbp":                                  # (the oracle's walk is a Python loop over every candidate)
+        want = no.scanner_max_strict(scores, d, 32, t, scale, 256)
+        assert got is not None and (got.position, np.float32(got.score)) == (want[0], want[1]), (got, want)
+    else:                                                      # constant scores: the last valid-or-not cell in position order wins
+        flat_best = scores[:, :32].max()
+        pos = np.argwhere(scores[:, :32] == flat_best)
+        want_pos = int((pos[:, 1] * ref.rows + pos[:, 0]).max())
+        assert got.position == want_pos and np.float32(got.score) == flat_best
+    assert dt < 3.0, f"{dt:.2f} s for {length} positions"
 
 
 @pytest.mark.parametrize("threshold", ["p1e-4", "every_cell"])
