@@ -124,7 +124,7 @@ def store_kernel_digest() -> str:
     instead of quoting a stale counter figure silently."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("score_kernels.hpp", "score_inst.hip", "score.hip"):
+    for name in ("score_kernels.hpp", "score_inst.hip", "score_plan.hip", "score_store.hip"):
         h.update((ROOT / "lightmotif_amd" / "csrc" / name).read_bytes())
     return h.hexdigest()[:16]
 
@@ -274,7 +274,7 @@ def init_ranks(args):
 
 
 def best_kmer_score(p) -> np.float32:
-    """the sequential f32 sum of the row maxima: no score of the matrix exceeds it (score.hip best_kmer_score)"""
+    """the sequential f32 sum of the row maxima: no score of the matrix exceeds it (score_plan.hip best_kmer_score)"""
     b = np.float32(0)
     for row in p.data[:, :4]:
         b = np.float32(b + row.max())

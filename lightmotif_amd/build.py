@@ -36,7 +36,7 @@ LONG_FLAGS = ["-mllvm", "-pragma-unroll-threshold=10000000"]
 XLONG = list(range(72, 89, 8))
 # score_pair_inst.hip: the pair-symbol prefilter scan alone for the lengths beyond the exact kernels (65 ... 128)
 PAIR = [(65, 80), (81, 96), (97, 112), (113, 128)]
-UNITS = ["score.hip", "reduce.hip", "hits.hip", "discrete.hip", "layout.hip", "scanmax.hip", "context.hip", "pssm.hip", "score_api.hip", "handles.hip",
+UNITS = ["score_plan.hip", "score_store.hip", "score_argmax.hip", "score_threshold.hip", "reduce.hip", "hits.hip", "discrete.hip", "layout.hip", "scanmax.hip", "context.hip", "pssm.hip", "score_api.hip", "handles.hip",
          "hostptr.hip", "comm.hip"]
 
 
@@ -112,7 +112,7 @@ def build(force: bool = False, jobs: int | None = None) -> Path:
                     return 100 + hi
             if "score_pair_inst.hip" in text:
                 return 90
-            return 50 if "score.hip" in text else 0
+            return 50 if "score_" in text else 0
         cmds.sort(key=weight, reverse=True)
         with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
             list(ex.map(_run, cmds))

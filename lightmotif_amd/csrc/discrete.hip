@@ -15,7 +15,7 @@
 namespace lm {
 
 __global__ void argmax_fold(const ArgmaxRecord *__restrict__ blocks, const unsigned nblocks,
-                            ArgmaxRecord *__restrict__ out);  // score.hip
+                            ArgmaxRecord *__restrict__ out);  // score_store.hip
 
 namespace {
 

@@ -177,7 +177,7 @@ int launch_max_symbol(lm_hip_ctx *ctx, const uint8_t *d_data, size_t rows, size_
 // `rows` the whole sequence has, read from `cols` pieces of `pitch` bytes -- piece c holds the symbols of
 // column c for exactly those rows, src[c * pitch + rr] = symbol at position c * rows + rbase + rr
 // (pli/mod.rs:192).  The classic whole-sequence call is the tile rbase = 0, nrows = pitch = rows.  Tiles are
-// what the host-side ingest uploads, two in flight (api.hip: ingest_tiled), so that a genome needs two tiles
+// what the host-side ingest uploads, two in flight (handles.hip: ingest_tiled), so that a genome needs two tiles
 // of staging instead of a device copy of itself.
 //
 // The bytes of a piece are turned into symbols on the way (XF): as they are (device-side encode ran before, or

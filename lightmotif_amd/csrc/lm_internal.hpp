@@ -86,7 +86,7 @@ struct lm_hip_ctx {
     bool owns_stream = false;
     hipStream_t aux_stream = nullptr;  // second lane for independent jobs of a batch
     hipEvent_t fork_event = nullptr, join_event = nullptr;
-    // host -> device ingest (api.hip: ingest_tiled): tiles are uploaded on `copy_stream` two ahead of the
+    // host -> device ingest (handles.hip: ingest_tiled): tiles are uploaded on `copy_stream` two ahead of the
     // stripe kernels that consume them on `stream`
     hipStream_t copy_stream = nullptr;
     hipEvent_t tile_copied[2] = {nullptr, nullptr}, tile_consumed[2] = {nullptr, nullptr};
@@ -94,7 +94,7 @@ struct lm_hip_ctx {
     lm::Scratch scratch;        // block partials, chunk counts, hit lists
     lm::Scratch scratch2;
     lm::Scratch scan_buf;       // Scanner::max walk (scanmax.hip): one window of u8 scores and the walk's state
-    lm::Scratch chunk_scores;   // fused reductions of sliced (M > 36) motifs: one chunk of f32 scores (score.hip)
+    lm::Scratch chunk_scores;   // fused reductions of sliced (M > 36) motifs: one chunk of f32 scores (score_launch.hpp)
     size_t chunk_rows = 1u << 22; // rows of that chunk (512 MB at C = 32; option "chunk_rows")
     bool chunked_fused = true;  // A/B knob: 0 = such motifs go cell by cell (option "chunked_fused")
     void *pinned = nullptr;     // kPinnedBytes of host-pinned memory for read-backs
@@ -110,11 +110,11 @@ struct lm_hip_ctx {
     bool xlong_store = true;     // motifs of 65 ... kMaxStoreM rows are stored in one pass (option "xlong_store" = 0: slices of <= 64)
     bool host_fold = true;       // ... small matrices: per-wavefront records folded by the host (option "host_fold" = 0: on the device)
     bool speculate_order = true; // fused threshold: order the hit list before the host knows its length
-    bool suffix_argmax = true;   // fused argmax of short motifs: try the last rows first (score.hip)
+    bool suffix_argmax = true;   // fused argmax of short motifs: try the last rows first (score_argmax.hip)
     bool multi_motif = true;     // many-motif threshold batches: several motifs of one length per pass
     bool skip_unreachable = true; // fused threshold: no scan when the threshold exceeds the best k-mer's score
     bool tiled = true;           // column counts off the C = 32 / 16 kernels: LDS-tiled kernel (0: one thread per cell)
-    double suffix_occurrences = 0; // fused argmax of short motifs: best k-mers the suffix should hold (0 = ln lambda, score.hip)
+    double suffix_occurrences = 0; // fused argmax of short motifs: best k-mers the suffix should hold (0 = ln lambda, score_argmax.hip)
     int num_cus = 256;
     unsigned long long last_hit_count = 0;  // sizes the next fused-threshold hit list
     unsigned long long last_cand_count = 0; // ... and its candidate list
@@ -140,7 +140,7 @@ struct lm_hip_pssm {
     size_t lead = 0;
     // M > kMaxFastM (C = 32): slices of <= kMaxLongM rows, each with its own transposed table; the
     // first is scored with the store kernel, the others continue from the stored partial sums.
-    // M <= kMaxLongM is ONE slice: the single-pass long kernels (score.hip: exact_motif)
+    // M <= kMaxLongM is ONE slice: the single-pass long kernels (score_plan.hip: exact_motif)
     struct Part {
         size_t off = 0, m = 0, ts = 0, lead = 0;  // `m` includes `lead` leading zero rows (table only)
         float *d_table = nullptr;
@@ -182,7 +182,7 @@ struct lm_hip_scores {
     bool best_on_host = false;
     unsigned best_generation = 0;         // of the last tracked launch into this handle
     // small inputs: the store kernel's per-wavefront records (16 bytes each, + the first-cell slot) in pinned memory,
-    // folded by the host in lm_hip_argmax (api.hip: host_fold); `folded` caches the fold of the current generation
+    // folded by the host in lm_hip_argmax (handles.hip: host_fold); `folded` caches the fold of the current generation
     void *h_records = nullptr;
     size_t h_records_cap = 0;             // records the block has room for
     unsigned n_records = 0;               // wavefront records of the last launch (the first-cell slot follows them)
@@ -229,7 +229,7 @@ inline void record_to_coords(const ArgmaxRecord &rec, size_t cols, int *found, l
 }
 
 
-// ---- kernel launchers (score.hip, reduce.hip, layout.hip) ----------------------
+// ---- kernel launchers (score_*.hip, reduce.hip, layout.hip) ----------------------
 
 enum class ScoreMode { Store, Argmax, Threshold };
 
@@ -255,7 +255,7 @@ int check_score_args(const lm_hip_pssm *pssm, size_t seq_rows_total, size_t seq_
 // Materialising score kernels.
 int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a);
 
-// Score<u8, ..> with a DiscreteMatrix (score.hip; reductions in discrete.hip)
+// Score<u8, ..> with a DiscreteMatrix (score_store.hip; reductions in discrete.hip)
 struct DiscreteArgs {
     const uint8_t *weights;   // HOST: M x wstride u8 (DenseMatrix<u8, K>, pwm/mod.rs:757)
     size_t m, wstride, k;

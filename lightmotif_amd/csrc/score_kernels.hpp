@@ -157,7 +157,7 @@ struct FusedOut {
     // MODE_STORE_TRACK / MODE_ARGMAX of one job, small inputs: non-null = NO fold on the device at all.  Every wavefront writes its
     // (value, cell) with ONE 16-byte store into this pinned array -- {generation, value bits | generation, cell} --
     // the lane that owns the matrix's first cell adds scores[0][0] in the slot behind the last wavefront's, and
-    // the HOST folds the few hundred records (api.hip: host_fold).  The three dependent L2 round trips of the
+    // the HOST folds the few hundred records (handles.hip: host_fold).  The three dependent L2 round trips of the
     // device fold (publish, ticket, read) were 3.8 of the kernel's 10.3 us at the reference's bench size.
     uint4 *host_records;
 };
@@ -561,7 +561,7 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
 // Tail of the fused threshold kernels.  After its stream a lane only knows WHICH row
 // ranges of its column may hold a hit (one bit per range in `hit_groups`); it appends
 // them, cut into pieces of at most 32 rows, to the candidate list.  The pieces are
-// re-scored exactly by `rescore_candidates` (score.hip) -- like the reference Scanner,
+// re-scored exactly by `rescore_candidates` (score_threshold.hip) -- like the reference Scanner,
 // which collects candidate positions from the discrete scores and re-scores them with
 // `score_position` (scan.rs:179-190) -- with one half-wave per piece, so that the
 // symbol loads of neighbouring rows share cache lines.  `range(bit, r0, r1)` maps a

@@ -15,14 +15,14 @@
 //     symbol's whole column is M*2 bytes of LDS instead of M*4 -> half the LDS
 //     traffic and half the adds of the f32 kernel, which is LDS-bound;
 //   * flagged row ranges go to the candidate list and are re-scored with the exact
-//     f32 weights by `rescore_candidates` (score.hip), the same path the f32 fused
+//     f32 weights by `rescore_candidates` (score_threshold.hip), the same path the f32 fused
 //     kernel uses, so results are bit-identical to it.
 //
 // Soundness (no false negatives): with P' = P where finite and the row minimum where
 // P = -inf, off_j = min_s P'[j][s], O = sum off_j, factor = (sum_j max_s P'[j][s] - O)
 // / 65000, d[j][s] = ceil((P'[j][s] - off_j) / factor), an f32 score S >= t implies
 // sum d >= floor((t - O) / factor) - ceil(E / factor) where E bounds the rounding error
-// of the M sequential f32 adds (host side, api.hip: build_prefilter).
+// of the M sequential f32 adds (host side, pssm.hip: build_prefilter).
 //
 // Rotating accumulators as in score_c32, with the motif padded to an EVEN length MP by
 // a leading all-zero row (SHIFT = MP - M): slot pair i = outputs (2i, 2i+1) mod MP.

@@ -20,7 +20,7 @@
 
 namespace lm {
 
-// `image` = prefilter image built from the u8 weights (api.hip: pack_prefilter_image);
+// `image` = prefilter image built from the u8 weights (score_store.hip: launch_score_u8);
 // `out` = row `row_begin` of the u8 score matrix, row stride 32.
 template <int M, int PF = LM_SCORE_PF, int WIDE = 0>
 __global__ __launch_bounds__(kBlock, 6) void score_c32_u8(
@@ -190,7 +190,7 @@ hipError_t score_c32_u8_pairs_launch(dim3 grid, size_t lds_bytes, hipStream_t st
 }
 
 // What a score_inst_*.hip translation unit fills in for its range of motif lengths
-// (arrays indexed by M; see score.hip: init_registry).
+// (arrays indexed by M; see score_plan.hip: init_registry).
 struct KernelRegistry {
     ScoreC32Launcher (*c32)[kRegistrySlots];
     PrefilterLauncher *pre, *pre2;

@@ -483,7 +483,7 @@ def test_long_motifs_are_scored_in_slices(pli, m):
 def test_long_motifs_fused_reductions_go_chunk_by_chunk(m, chunk_rows):
     """score_argmax / score_threshold / Scanner-style hits of M > 36.  Up to 64 rows: the fused kernels of
     the long family (score_c32<M', 1 | 2>), no score matrix.  Beyond: the sliced store path into a
-    reusable chunk buffer + a reduction per chunk (score.hip, KIND_CHUNKED) instead of one thread per
+    reusable chunk buffer + a reduction per chunk (score_launch.hpp, KIND_CHUNKED) instead of one thread per
     cell.  Same cells, same values: bit-exact against the oracle's materialised matrix, row-major hit
     order, last-maximal-cell ties across chunk borders, first-cell NaN rule, row sub-ranges."""
     pli = lm.Pipeline.hip(0)

@@ -189,7 +189,7 @@ def test_more_positions_than_u32_max(gpu_pli):
 @pytest.mark.parametrize("kind", ["normal", "ties", "late_maximum", "mostly_n"])
 def test_fused_argmax_candidate_route_against_oracle(gpu_pli, kind):
     """From ~100 M cells per call the fused argmax takes the sample -> prefilter scan -> exact re-scoring
-    route (score.hip: argmax_by_prefilter).  It must return the Generic answer -- the LAST
+    route (score_argmax.hip: argmax_by_prefilter).  It must return the Generic answer -- the LAST
     maximal cell -- also when many cells tie (lists overflow -> exact kernel), when the sample
     misses the region holding the maximum, and when most of the sample is -inf."""
     import lightmotif_amd as lm

@@ -8,7 +8,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/$C" -o p -- \
-      python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/$C.log" 2>&1
+      python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/$C.log" 2>&1
 done
 python - "$OUT" "$ROOT" <<'PY'
 import csv, glob, json, sys

@@ -2,7 +2,7 @@
 # Collects the measurements committed under profiles/ (run on a GPU box via gpurun):
 #   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r02'
 # Everything lands in gpurun_out/<tag>/; copy what should be judged into profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -19,6 +19,8 @@ timeout 100 tools/kbench/mix_bench > "$OUT/mix_bench.txt" 2>&1
 timeout 200 python tools/track_ab.py 20 > "$OUT/track_ab.txt" 2>/dev/null
 timeout 200 python tools/track_ab.py 12 >> "$OUT/track_ab.txt" 2>/dev/null
 timeout 200 python tools/handle_flow.py > "$OUT/handle_flow.json" 2> "$OUT/handle_flow.err"
+# the literal drop-in path: host-pointer entry points on pageable host matrices (dna.rs loop, Scanner block, threads, 1 Gbp)
+timeout 300 python tools/host_pointer_bench.py --json "$OUT/host_pointer.json" > "$OUT/host_pointer.log" 2>&1
 # the N > 1 control flow of bench.py on the box's one GPU: 2 ranks over gloo (torch merge), and the C-ABI merge path
 # through a communicator of one rank -- functional checks, NOT scaling numbers
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
@@ -29,7 +31,9 @@ timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --mast
     --master-port 29518 bench.py --config c3 --gpus 2 --steps 4 --warmup 1 --dist-backend gloo --single-device \
     --no-cpu-baseline 2> "$OUT/bench_c3_2rank.err" | grep '^{' > "$OUT/bench_c3_2rank_gloo_single_device.json"
 ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv \
-    -d "$OUT/prof" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/prof_bench.json" 2> "$OUT/prof.err" )
+    -d "$OUT/prof" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline --no-extras > "$OUT/prof_bench.json" 2> "$OUT/prof.err" )
+# (--no-extras: the end-to-end extra launches the SAME store kernel on 262 144-row tiles through lm_hip_score_f32, which
+#  would be averaged into the headline kernel's row of the statistics)
 python - "$OUT" <<'PY'
 import csv, glob, sys
 out = sys.argv[1]

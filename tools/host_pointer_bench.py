@@ -199,6 +199,44 @@ def bench_threads(nthreads: int = 8, length: int = 50_000_000, m: int = 20):
             "parallel_over_serial": round(par / serial, 3), "bit_identical": bool(same)}
 
 
+def bench_threads_small(nthreads: int = 8, iters: int = 100):
+    """The CLI's `-j` workers (main.rs:270) / GIL-released Python threads (lib.rs:865) at the reference's own bench size:
+    every thread loops score + argmax on its own host matrices; each gets a lane (context, stream, staging) of its own."""
+    length, m = 464_165, 15
+    rng = np.random.default_rng(11)
+    pssm = lm.create(["GTTGACCTTATCAAC", "GTTGATCCAGTCAAC"]).counts.normalize(0.1).log_odds().data
+    jobs = []
+    for _ in range(nthreads):
+        mat, rows, _ = striped(rng.integers(0, 4, length, dtype=np.uint8), m)
+        jobs.append((mat, rows, np.zeros((rows, COLS), np.float32)))
+
+    def work(job, n):
+        mat, rows, out = job
+        for _ in range(n):
+            score_f32(mat, rows, length, pssm, out)
+            argmax_f32(out, rows)
+    for j in jobs:
+        work(j, 3)
+    t0 = time.perf_counter()
+    for j in jobs:
+        work(j, iters)
+    serial = time.perf_counter() - t0
+
+    def run(n):
+        th = [threading.Thread(target=work, args=(j, n)) for j in jobs]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        return time.perf_counter() - t0
+    run(3)
+    par = run(iters)
+    return {"threads": nthreads, "iterations_each": iters, "serial_ms": round(serial * 1e3, 1), "parallel_ms": round(par * 1e3, 1),
+            "parallel_over_serial": round(par / serial, 3),
+            "us_per_iteration_aggregate": round(par / (nthreads * iters) * 1e6, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--json", default="")
@@ -213,6 +251,8 @@ def main():
         res["scanner_block"] = bench_block()
         print(json.dumps({"scanner_block": res["scanner_block"]}), flush=True)
     if "threads" not in a.skip:
+        res["threads_small_calls"] = bench_threads_small()
+        print(json.dumps({"threads_small_calls": res["threads_small_calls"]}), flush=True)
         res["threads"] = bench_threads()
         print(json.dumps({"threads": res["threads"]}), flush=True)
     if "big" not in a.skip:
