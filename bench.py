@@ -1068,7 +1068,8 @@ def main() -> None:
             "merge_us": (None if not rank_merge else
                          {"p50": round(float(np.median([x[0] for x in rank_merge])), 1),
                           "max": round(max(x[1] for x in rank_merge), 1),
-                          "what": "per timed step, host clock: from the merge's begin to the merged argmax on the host; "
+                          "what": "per timed step, host clock: from the merge's begin to the merged argmax on the host (the wait for "
+                                  "the shard's own store kernel, whose tracked record is what gets merged, lies inside); "
                                   "median of the ranks' medians, maximum over ranks and steps"
                                   + ("; pipelined -- the next step's enqueue lies inside" if pipelined else "")}),
         },

@@ -127,7 +127,19 @@ def bench_block():
         assert st == 0, _ffi.last_error()
         row[0] = (row[0] + 256) % (seq.rows - 256)
     med, mn = loop_us(it, 1000, 100)
-    return {"scanner_block_us": round(med, 2), "scanner_block_us_min": round(mn, 2), "scanner_block_rows": 256}
+    # the same block on one CPU thread: the oracle's Generic u8 restatement (pli/mod.rs:72-106 with u8 weights; the
+    # reference's AVX2 u8 kernel, avx2.rs:294-347, has no port here -- this is the slower of the two CPU forms)
+    from oracle import c_oracle as co
+    ref = co.stripe(enc, 32, 5)
+    co.configure_wrap(ref, m - 1)
+    crow = [0]
+
+    def cpu_it():
+        co.score_rows_u8(ref, w, crow[0], crow[0] + 256)
+        crow[0] = (crow[0] + 256) % (ref.rows - 256)
+    c_med, _ = loop_us(cpu_it, 300, 30)
+    return {"scanner_block_us": round(med, 2), "scanner_block_us_min": round(mn, 2), "scanner_block_rows": 256,
+            "scanner_block_generic_cpu_1_thread_us": round(c_med, 2)}
 
 
 def bench_big(length: int, m: int = 20, mat=None, pssm=None, reps: int = 4, check=None):
