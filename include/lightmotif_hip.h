@@ -519,14 +519,24 @@ int lm_hip_merge_threshold(lm_hip_ctx *ctx, lm_hip_comm *comm, const lm_hip_coor
 
 /* ---- host-pointer convenience forms (synchronous, PCIe both ways) ---------- */
 
-/* Exactly what a Rust shim can obtain from &StripedSequence / &DenseMatrix /
- * &mut StripedScores; uses a lazily created per-process default context on
- * device 0 (or $LM_HIP_DEVICE). */
+/* Exactly what a Rust shim can obtain from &StripedSequence / &DenseMatrix / &mut StripedScores: pageable host
+ * matrices in, pageable host matrices out (csrc/hostptr.hip).  No context argument: every calling host thread is given
+ * a lane of its own (context + stream, persistent staging, a cache of device PSSM tables keyed on the weights) on device
+ * 0 or $LM_HIP_DEVICE, so threads overlap; large calls (>= 48 MB of scores) run as a tile pipeline over a process-wide
+ * ring of pinned buffers and take turns on it.  1 B per position travels up and 4 B down per lm_hip_score_f32 call. */
 int lm_hip_score_f32(const uint8_t *seq, size_t seq_rows_total, size_t seq_stride, size_t cols,
                      size_t wrap, size_t length,
                      const float *pssm, size_t m, size_t pssm_stride, size_t k,
                      size_t row_begin, size_t row_end,
                      float *out, size_t out_stride, size_t *out_rows, size_t *max_index);
+/* Score<u8, A, C>::score_rows_into with a DiscreteMatrix's weights on host matrices (pwm/mod.rs:754-791; the AVX2 impl is
+ * pli/mod.rs:437-476 over avx2.rs:294-347) -- what Scanner::next calls per block (scan.rs:174-178).  `saturate` != 0: the
+ * SIMD back-ends' saturating adds (avx2.rs:336), 0: Generic's wrapping `+=`.  Same conventions as lm_hip_score_f32. */
+int lm_hip_score_u8_host(const uint8_t *seq, size_t seq_rows_total, size_t seq_stride, size_t cols,
+                         size_t wrap, size_t length,
+                         const uint8_t *weights, size_t m, size_t weights_stride, size_t k,
+                         size_t row_begin, size_t row_end, int saturate,
+                         uint8_t *out, size_t out_stride, size_t *out_rows, size_t *max_index);
 int lm_hip_argmax_f32(const float *scores, size_t rows, size_t stride, size_t cols,
                       int *found, lm_hip_coords *best, float *value);
 /* Maximum::max on a host matrix (pli/mod.rs:158-160; SURVEY 8b export list). */

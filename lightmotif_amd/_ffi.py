@@ -130,6 +130,7 @@ SIGNATURES = {
     "lm_hip_merge_threshold": (C.c_int, [_vp, _vp, _cp, _sz, _sz, C.POINTER(_cp), _szp]),
     "lm_hip_score_f32": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _sz, _vp, _sz, _sz, _sz, _sz, _sz, _vp,
                                   _sz, _szp, _szp]),
+    "lm_hip_score_u8_host": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _sz, _vp, _sz, _sz, _sz, _sz, _sz, C.c_int, _vp, _sz, _szp, _szp]),
     "lm_hip_argmax_f32": (C.c_int, [_vp, _sz, _sz, _sz, _ip, _cp, _fp]),
     "lm_hip_max_f32": (C.c_int, [_vp, _sz, _sz, _sz, _ip, _fp]),
     "lm_hip_threshold_f32": (C.c_int, [_vp, _sz, _sz, _sz, C.c_float, C.POINTER(_cp), _szp]),

@@ -1,6 +1,7 @@
 // hostptr.hip -- the host-pointer entry points: what the reference-side shim binds.
 //
 //   lm_hip_score_f32      Score::score_rows_into on host matrices   (pli/mod.rs:72-106, avx2.rs:889-904)
+//   lm_hip_score_u8_host  the same with a DiscreteMatrix, u8 scores   (avx2.rs:294-347, 921-931; scan.rs:174-178)
 //   lm_hip_argmax_f32     StripedScores::argmax                     (scores.rs:181-186, pli/mod.rs:135-155)
 //   lm_hip_max_f32        StripedScores::max                        (scores.rs:188-192, pli/mod.rs:158-160)
 //   lm_hip_threshold_f32  StripedScores::threshold                  (scores.rs:207-213, pli/mod.rs:210-221)
@@ -420,12 +421,15 @@ int run_pipeline(lm_hip_ctx *ctx, BigPipe &bp, const TileJob &job)
     return LM_HIP_OK;
 }
 
+// One Score::score_rows_into call on host matrices, f32 (a PSSM) or u8 (a DiscreteMatrix): `launch` enqueues the store
+// kernels of `rows` rows whose first sequence row is at `d_seq`, dense output rows (stride = cols) at `d_out`.
 struct ScoreCall {
-    const lm_hip_pssm *p;
     const uint8_t *seq;  // row `row_begin` of the caller's striped matrix
     size_t seq_stride, cols, nrows, halo;
-    float *out;
-    size_t out_stride;
+    char *out;           // the caller's score matrix, row 0 of the range
+    size_t out_stride;   // in elements
+    size_t elem;         // bytes per score: 4 (f32) or 1 (u8)
+    std::function<int(lm_hip_ctx *ctx, const uint8_t *d_seq, size_t rows, void *d_out)> launch;
 };
 
 // Rows [r0, r1) of the call on the lane's own buffers: copy up, score, copy down (the copies of pageable memory
@@ -433,32 +437,29 @@ struct ScoreCall {
 int score_piece(HostLane *lane, const ScoreCall &c, size_t r0, size_t r1)
 {
     lm_hip_ctx *ctx = lane->ctx;
-    const size_t w = r1 - r0, in_bytes = (w + c.halo) * c.seq_stride, out_bytes = w * c.cols * sizeof(float);
+    const size_t w = r1 - r0, in_bytes = (w + c.halo) * c.seq_stride, row_bytes = c.cols * c.elem, out_bytes = w * row_bytes;
     const uint8_t *src = c.seq + r0 * c.seq_stride;
-    float *dst = c.out + r0 * c.out_stride;
+    char *dst = c.out + r0 * c.out_stride * c.elem;
     if (lane->zc && in_bytes <= kZeroCopyBytes && out_bytes <= kZeroCopyBytes) {
         uint8_t *zin = lane->zc;
-        float *zout = reinterpret_cast<float *>(lane->zc + kZeroCopyBytes);
+        char *zout = reinterpret_cast<char *>(lane->zc + kZeroCopyBytes);
         memcpy(zin, src, in_bytes);
-        ScoreArgs a{c.p, zin, c.seq_stride, c.cols, 0, w, zout, c.cols};
-        LM_TRY(launch_score_store(ctx, a));
+        LM_TRY(c.launch(ctx, zin, w, zout));
         LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-        copy_rows(reinterpret_cast<char *>(dst), c.out_stride * sizeof(float), reinterpret_cast<const char *>(zout),
-                  c.cols * sizeof(float), c.cols * sizeof(float), w);
+        copy_rows(dst, c.out_stride * c.elem, zout, row_bytes, row_bytes, w);
         return LM_HIP_OK;
     }
     LM_TRY(lane->d_in.reserve(in_bytes + 64));
     LM_TRY(lane->d_out.reserve(out_bytes));
     uint8_t *d_in = static_cast<uint8_t *>(lane->d_in.ptr);
-    float *d_out = static_cast<float *>(lane->d_out.ptr);
+    char *d_out = static_cast<char *>(lane->d_out.ptr);
     LM_HIP_TRY(hipMemcpyAsync(d_in, src, in_bytes, hipMemcpyHostToDevice, ctx->stream));
-    ScoreArgs a{c.p, d_in, c.seq_stride, c.cols, 0, w, d_out, c.cols};
-    LM_TRY(launch_score_store(ctx, a));
+    LM_TRY(c.launch(ctx, d_in, w, d_out));
     // only the `cols` scored cells of each row: the caller's alignment padding is left as it was (pli/mod.rs:103)
     LM_HIP_TRY(c.out_stride == c.cols
                    ? hipMemcpyAsync(dst, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream)
-                   : hipMemcpy2DAsync(dst, c.out_stride * sizeof(float), d_out, c.cols * sizeof(float),
-                                      c.cols * sizeof(float), w, hipMemcpyDeviceToHost, ctx->stream));
+                   : hipMemcpy2DAsync(dst, c.out_stride * c.elem, d_out, row_bytes, row_bytes, w, hipMemcpyDeviceToHost,
+                                      ctx->stream));
     LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     return LM_HIP_OK;
 }
@@ -468,11 +469,11 @@ int score_pipelined(HostLane *lane, BigPipe &bp, const ScoreCall &c)
     lm_hip_ctx *ctx = lane->ctx;
     LM_TRY(pipe_prepare(bp, ctx->device));
     // rows per tile: 32 MB of scores, at most 64 MB of symbols
-    const size_t tile_bytes = pipe_shape().tile_bytes;
-    size_t tr = std::min(tile_bytes / (c.cols * sizeof(float)), (2 * tile_bytes) / c.seq_stride);
+    const size_t tile_bytes = pipe_shape().tile_bytes, row_bytes = c.cols * c.elem;
+    size_t tr = std::min(tile_bytes / row_bytes, (2 * tile_bytes) / c.seq_stride);
     tr = std::max<size_t>(tr / 256 * 256, 256);
-    const size_t in_tile = ((tr + c.halo) * c.seq_stride + 255) / 256 * 256, out_tile = tr * c.cols * sizeof(float);
-    if (out_tile > tile_bytes)  // (more than 32 K columns: not a shape this path is for)
+    const size_t in_tile = ((tr + c.halo) * c.seq_stride + 255) / 256 * 256, out_tile = (tr * row_bytes + 255) / 256 * 256;
+    if (tr * row_bytes > tile_bytes)  // (more than 32 K columns: not a shape this path is for)
         return LM_HIP_ERR_CAPACITY;
     LM_TRY(bp.d_in.reserve(kInSlots * in_tile + 64));
     LM_TRY(bp.d_out.reserve((size_t)pipe_shape().out_slots * out_tile));
@@ -487,22 +488,44 @@ int score_pipelined(HostLane *lane, BigPipe &bp, const ScoreCall &c)
         return e == hipSuccess ? hipStreamSynchronize(bp.s_up) : e;
     };
     job.compute = [&](size_t t, int is, int os) {
-        ScoreArgs a{c.p, d_in + (size_t)is * in_tile, c.seq_stride, c.cols, 0, width(t),
-                    reinterpret_cast<float *>(d_out + (size_t)os * out_tile), c.cols};
-        return launch_score_store(ctx, a);
+        return c.launch(ctx, d_in + (size_t)is * in_tile, width(t), d_out + (size_t)os * out_tile);
     };
     job.download = [&](size_t t, int slot) {
-        return hipMemcpyAsync(bp.pinned + (size_t)slot * tile_bytes, d_out + (size_t)slot * out_tile,
-                              width(t) * c.cols * sizeof(float), hipMemcpyDeviceToHost, bp.s_dn);
+        return hipMemcpyAsync(bp.pinned + (size_t)slot * tile_bytes, d_out + (size_t)slot * out_tile, width(t) * row_bytes,
+                              hipMemcpyDeviceToHost, bp.s_dn);
     };
     job.copy_out = [&](size_t t, int slot, int j, int n) {
         const size_t w = width(t), a = w * (size_t)j / (size_t)n, b = w * (size_t)(j + 1) / (size_t)n;
-        copy_rows(reinterpret_cast<char *>(c.out + (t * tr + a) * c.out_stride), c.out_stride * sizeof(float),
-                  bp.pinned + (size_t)slot * tile_bytes + a * c.cols * sizeof(float), c.cols * sizeof(float),
-                  c.cols * sizeof(float), b - a);
+        copy_rows(c.out + (t * tr + a) * c.out_stride * c.elem, c.out_stride * c.elem,
+                  bp.pinned + (size_t)slot * tile_bytes + a * row_bytes, row_bytes, row_bytes, b - a);
     };
     const int st = run_pipeline(ctx, bp, job);
     trim(bp.d_in);
+    return st;
+}
+
+// The whole call: the tile pipeline for large score matrices, piece by piece on the lane otherwise.
+int score_call(HostLane *lane, const ScoreCall &c)
+{
+    lm_hip_ctx *ctx = lane->ctx;
+    int st = LM_HIP_ERR_CAPACITY;
+    if (c.nrows * c.cols * c.elem >= kPipeMinOutBytes) {
+        // link-bound: large calls of several threads take turns on the ring (run side by side through the runtime's
+        // pageable copies they were 2.2 x slower than one after the other -- profiles/r04_host_pointer.json)
+        BigPipe &bp = big_pipe();
+        std::lock_guard<std::mutex> pipe(bp.mu);
+        st = score_pipelined(lane, bp, c);
+    }
+    if (st == LM_HIP_ERR_CAPACITY) {  // small (or a shape the tiles do not fit): piece by piece on this lane
+        const size_t piece = std::max<size_t>((64u << 20) / (c.cols * c.elem), 1);
+        st = LM_HIP_OK;
+        for (size_t r0 = 0; r0 < c.nrows && st == LM_HIP_OK; r0 += piece)
+            st = score_piece(lane, c, r0, std::min(c.nrows, r0 + piece));
+        if (st != LM_HIP_OK)
+            (void)hipStreamSynchronize(ctx->stream);
+        trim(lane->d_in);
+        trim(lane->d_out);
+    }
     return st;
 }
 
@@ -546,28 +569,51 @@ int lm_hip_score_f32(const uint8_t *seq, size_t seq_rows_total, size_t seq_strid
     if (!seq || !out || out_stride < cols)
         return fail(LM_HIP_ERR_BAD_ARGS, "score: null buffer or out stride %zu < columns %zu", out_stride, cols);
     // only the rows the range needs travel: [row_begin, row_end + m - 1)
-    ScoreCall c{p, seq + row_begin * seq_stride, seq_stride, cols, row_end - row_begin, m ? m - 1 : 0, out, out_stride};
-    int st = LM_HIP_ERR_CAPACITY;
-    if (c.nrows * cols * sizeof(float) >= kPipeMinOutBytes) {
-        // link-bound: large calls of several threads take turns on the ring (run side by side through the runtime's
-        // pageable copies they were 2.2 x slower than one after the other -- profiles/r04_host_pointer.json)
-        BigPipe &bp = big_pipe();
-        std::lock_guard<std::mutex> pipe(bp.mu);
-        st = score_pipelined(lane, bp, c);
-    }
-    if (st == LM_HIP_ERR_CAPACITY) {  // small (or a shape the tiles do not fit): piece by piece on this lane
-        const size_t piece = std::max<size_t>((64u << 20) / (cols * sizeof(float)), 1);
-        st = LM_HIP_OK;
-        for (size_t r0 = 0; r0 < c.nrows && st == LM_HIP_OK; r0 += piece)
-            st = score_piece(lane, c, r0, std::min(c.nrows, r0 + piece));
-        if (st != LM_HIP_OK)
-            (void)hipStreamSynchronize(ctx->stream);
-        trim(lane->d_in);
-        trim(lane->d_out);
-    }
-    if (st != LM_HIP_OK)
-        return st;
+    ScoreCall c{seq + row_begin * seq_stride, seq_stride, cols, row_end - row_begin, m ? m - 1 : 0,
+                reinterpret_cast<char *>(out), out_stride, sizeof(float), nullptr};
+    c.launch = [p, seq_stride, cols](lm_hip_ctx *cx, const uint8_t *d_seq, size_t rows, void *d_out) {
+        ScoreArgs a{p, d_seq, seq_stride, cols, 0, rows, static_cast<float *>(d_out), cols};
+        return launch_score_store(cx, a);
+    };
+    LM_TRY(score_call(lane, c));
     if (out_rows) *out_rows = c.nrows;       // pli/mod.rs:91
+    if (max_index) *max_index = length + 1 - m;
+    return LM_HIP_OK;
+}
+
+// Score<u8, A, C>::score_rows_into with a DiscreteMatrix on host matrices (pli/mod.rs:437-476 is the AVX2 impl; what
+// Scanner::next calls per 256-row block, scan.rs:174-178).  `saturate`: avx2.rs:336 (adds_epu8) or Generic's wrapping `+=`.
+int lm_hip_score_u8_host(const uint8_t *seq, size_t seq_rows_total, size_t seq_stride, size_t cols, size_t wrap,
+                         size_t length, const uint8_t *weights, size_t m, size_t weights_stride, size_t k,
+                         size_t row_begin, size_t row_end, int saturate, uint8_t *out, size_t out_stride,
+                         size_t *out_rows, size_t *max_index)
+{
+    if (!weights || m == 0 || k == 0 || k > 256 || weights_stride < k)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score_u8: bad discrete matrix (%zu x %zu, stride %zu)", m, k, weights_stride);
+    lm_hip_pssm shape;  // the geometry checks only look at the motif length
+    shape.m = m;
+    shape.k = k;
+    LM_TRY(check_score_args(&shape, seq_rows_total, seq_stride, cols, wrap, row_begin, row_end));
+    if (length < m || row_begin >= row_end) {  // pli/mod.rs:85-88
+        if (out_rows) *out_rows = 0;
+        if (max_index) *max_index = 0;
+        return LM_HIP_OK;
+    }
+    if (!seq || !out || out_stride < cols)
+        return fail(LM_HIP_ERR_BAD_ARGS, "score_u8: null buffer or out stride %zu < columns %zu", out_stride, cols);
+    HostLane *lane = nullptr;
+    LM_TRY(acquire_lane(&lane));
+    DeviceGuard guard(lane->ctx->device);
+    ScoreCall c{seq + row_begin * seq_stride, seq_stride, cols, row_end - row_begin, m - 1, reinterpret_cast<char *>(out),
+                out_stride, 1, nullptr};
+    c.launch = [=](lm_hip_ctx *cx, const uint8_t *d_seq, size_t rows, void *d_out) {
+        // (the device tables of the matrix are kept by the lane's context until the weights change: launch_score_u8)
+        DiscreteArgs a{weights, m, weights_stride, k, d_seq, seq_stride, cols, 0, rows, static_cast<uint8_t *>(d_out), cols,
+                       saturate != 0};
+        return launch_score_u8(cx, a);
+    };
+    LM_TRY(score_call(lane, c));
+    if (out_rows) *out_rows = c.nrows;
     if (max_index) *max_index = length + 1 - m;
     return LM_HIP_OK;
 }

@@ -296,3 +296,56 @@ def test_score_u8_scanner_blocks(pli, out_stride):
         assert st == 0, _ffi.last_error()
         assert (orow.value, omi.value) == (b - a, mi)
         assert np.array_equal(out[:, :32], want[a:b, :32]) and np.all(out[:, 32:] == 99)
+
+
+def host_score_u8(s, w, k, a, b, saturate, out_stride=None):
+    L = _ffi.lib()
+    ost = co.stride(s.cols, 1) if out_stride is None else out_stride
+    out = np.full((max(b - a, 0), ost), 99, np.uint8)
+    orow, omi = C.c_size_t(0), C.c_size_t(0)
+    st = L.lm_hip_score_u8_host(s.data.ctypes.data, s.data.shape[0], s.stride, s.cols, s.wrap, s.length, w.ctypes.data, w.shape[0],
+                                w.shape[1], k, a, b, int(saturate), out.ctypes.data, ost, C.byref(orow), C.byref(omi))
+    assert st == 0, _ffi.last_error()
+    return out, orow.value, omi.value
+
+
+@pytest.mark.parametrize("length,cols,k,m,rows,out_stride", [
+    (10_000, 32, 5, 15, (0, 256), None),          # one Scanner block (scan.rs:174-178): zero-copy both ways
+    (10_000, 32, 5, 15, (256, 313), 48),          # the last, short block; the caller's rows wider than the columns
+    (700_000, 32, 5, 20, None, None),             # copy path
+    (300_000, 32, 21, 12, (5, 9000), None),       # protein
+    (120_000, 20, 5, 9, None, None),              # 20 columns
+    (400_000, 32, 5, 40, None, None),             # beyond 36 rows: slices added bytewise
+])
+def test_score_u8_host_matches_oracle(length, cols, k, m, rows, out_stride):
+    """`Score<u8, A, C>` with a DiscreteMatrix on HOST matrices (`lm_hip_score_u8_host`, what a shim's `impl Score<u8, ..> for
+    Pipeline<A, Hip>` binds): both overflow flavours -- Generic's wrapping `+=` against the C oracle, the SIMD back-ends'
+    saturating adds (avx2.rs:336) against the numpy restatement -- with weights large enough to overflow."""
+    from oracle import np_oracle as no
+    rng = np.random.default_rng(length + m + cols)
+    s = striped(rng, length, cols, k, m)
+    w = np.zeros((m, 32), np.uint8)
+    w[:, :k] = rng.integers(0, 40, (m, k))
+    a, b = (0, s.rows) if rows is None else rows
+    want, mi = co.score_rows_u8(s, w, a, b)
+    got, orow, omi = host_score_u8(s, w, k, a, b, saturate=False, out_stride=out_stride)
+    assert (orow, omi) == (b - a, mi)
+    assert np.array_equal(got[:, :cols], want[:, :cols])
+    assert np.all(got[:, cols:] == 99), "alignment padding of the caller's rows was written"
+    if b - a <= 30_000:
+        sat = no.score_rows_u8_saturating(s.data, cols, length, w[:, :k], a, b)
+        got_s, _, _ = host_score_u8(s, w, k, a, b, saturate=True, out_stride=out_stride)
+        assert np.array_equal(got_s[:, :cols], sat) and sat.max() == 255
+
+
+def test_score_u8_host_through_the_tile_pipeline():
+    """64 Mbp: 64 MB of u8 scores, two tiles of the pipeline and a ragged one; wrapping adds against the C oracle."""
+    rng = np.random.default_rng(64)
+    m, rows_total = 15, 2_000_000 + 77
+    s = striped(rng, rows_total * 32 - 3, 32, 5, m)
+    w = np.zeros((m, 32), np.uint8)
+    w[:, :5] = rng.integers(0, 17, (m, 5))
+    a, b = 11, rows_total - 5
+    want, mi = co.score_rows_u8(s, w, a, b)
+    got, orow, omi = host_score_u8(s, w, 5, a, b, saturate=False)
+    assert (orow, omi) == (b - a, mi) and np.array_equal(got[:, :32], want[:, :32])

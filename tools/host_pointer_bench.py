@@ -127,6 +127,16 @@ def bench_block():
         assert st == 0, _ffi.last_error()
         row[0] = (row[0] + 256) % (seq.rows - 256)
     med, mn = loop_us(it, 1000, 100)
+    # ... and with the sequence on the HOST as well (lm_hip_score_u8_host: 8.6 KB up, 8 KB down per block, zero-copy)
+    host_mat = seq.matrix()
+    hrow = [0]
+
+    def host_it():
+        st = L.lm_hip_score_u8_host(host_mat.ctypes.data, host_mat.shape[0], 32, COLS, m - 1, length, w.ctypes.data, m, 32, 5,
+                                    hrow[0], hrow[0] + 256, 1, out.ctypes.data, COLS, C.byref(orow), C.byref(mi))
+        assert st == 0, _ffi.last_error()
+        hrow[0] = (hrow[0] + 256) % (seq.rows - 256)
+    h_med, h_min = loop_us(host_it, 1000, 100)
     # the same block on one CPU thread: the oracle's Generic u8 restatement (pli/mod.rs:72-106 with u8 weights; the
     # reference's AVX2 u8 kernel, avx2.rs:294-347, has no port here -- this is the slower of the two CPU forms)
     from oracle import c_oracle as co
@@ -139,7 +149,7 @@ def bench_block():
         crow[0] = (crow[0] + 256) % (ref.rows - 256)
     c_med, _ = loop_us(cpu_it, 300, 30)
     return {"scanner_block_us": round(med, 2), "scanner_block_us_min": round(mn, 2), "scanner_block_rows": 256,
-            "scanner_block_generic_cpu_1_thread_us": round(c_med, 2)}
+            "scanner_block_host_sequence_us": round(h_med, 2), "scanner_block_generic_cpu_1_thread_us": round(c_med, 2)}
 
 
 def bench_big(length: int, m: int = 20, mat=None, pssm=None, reps: int = 4, check=None):
