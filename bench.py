@@ -322,16 +322,17 @@ C3_LDS_MODEL = ("pair-prefilter scans (score_prefilter2.hpp): one LDS table row 
 
 
 def fused_roofline(ms: float, rows: int, m: int, kernel: str) -> dict:
-    """A fused score+argmax / score+threshold call over `rows` x 32 positions: wall time of the whole call (scan, re-scoring,
-    reductions, read-back) against the one byte per position it must read from HBM; `lds_frac` = the pair table's gather."""
-    ach = rows * COLS / (ms * 1e-3) / 1e9
+    """A fused score+argmax / score+threshold call over `rows` x 32 positions, whole call on the wall clock (scan, re-scoring,
+    reductions, read-back).  SURVEY 8(d): no score matrix is written, so the binding ceiling is the LDS gather -- here the
+    pair table's (M | 3) + 1 bytes per position (score_prefilter2.hpp) against 256 B/clk/CU x 256 CUs x 2.4 GHz; the one
+    byte per position the scan must still read from HBM is reported beside it (`hbm_read_frac`), not as the bound."""
     lds = ((m | 3) + 1) * rows * COLS / (ms * 1e-3)
-    return {"ms": round(ms, 4), "kernel": kernel,
-            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_call": rows * COLS,
-                         "lds_frac": round(lds / LDS_PEAK_BYTES_PER_S, 4),
-                         "lds_note": f"{(m | 3) + 1} B of pair-table gathers per position (score_prefilter2.hpp) against "
-                                     "256 B/clk/CU x 256 CUs x 2.4 GHz"}}
+    ach = rows * COLS / (ms * 1e-3) / 1e9
+    return {"ms": round(ms, 4), "kernel": kernel, "Gpos_s": round(rows * COLS / ms / 1e6, 1),
+            "roofline": {"bound": "lds", "achieved": round(lds / 1e12, 2), "peak": round(LDS_PEAK_BYTES_PER_S / 1e12, 1),
+                         "unit": "TB/s", "frac": round(lds / LDS_PEAK_BYTES_PER_S, 4),
+                         "lds_bytes_per_position": (m | 3) + 1, "hbm_read_gbs": round(ach, 1),
+                         "hbm_read_frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_hbm_bytes_per_call": rows * COLS}}
 
 
 def lds_roofline(lds_bytes: float, seconds: float, note: str) -> dict:
@@ -1060,8 +1061,8 @@ def main() -> None:
             "merge_threshold_ms": round(mt_ms, 4),
             "threshold_hits": int(len(all_hits)), "argmax_global": [int(best[0][0]), int(best[0][1])],
             "kernel_ms_min": round(min(kernel_ms), 4), "kernel_ms_max": round(max(kernel_ms), 4),
-            # the fused forms never write the score matrix -- 1 B per position read from HBM is what is left,
-            # and the pair-prefilter scan gathers (M | 3) + 1 bytes of LDS per position (score_prefilter2.hpp)
+            # the fused forms never write the score matrix -- priced against the LDS-gather ceiling (the pair
+            # table's (M | 3) + 1 bytes per position), the 1 B per position of HBM reads beside it
             "fused_score_argmax": fused_roofline(fam_ms, rows, m, fam_kernel),
             "fused_score_threshold": fused_roofline(fth_ms, rows, m, fth_kernel),
             "merge_threshold_ms_torch": round(mt_torch_ms, 4),

@@ -59,7 +59,7 @@ def test_two_ranks_without_a_launcher():
     assert out["extras"]["merge_threshold_ms"] > 0 and out["extras"]["merge_threshold_ms_torch"] > 0
     for key in ("fused_score_argmax", "fused_score_threshold"):
         fr = out["extras"][key]["roofline"]
-        assert fr["bound"] == "hbm" and 0 < fr["frac"] < 1 and 0 < fr["lds_frac"] < 1.2
+        assert fr["bound"] == "lds" and 0 < fr["frac"] < 1.2 and 0 < fr["hbm_read_frac"] < 1
     c3 = out["extras"]["configs"]["c3"]
     assert c3["parallelism"].startswith("motif-shard x2") and len(c3["motifs_per_rank"]) == 2
     assert sum(c3["motifs_per_rank"]) == 2346 and c3["hits_total"] > 0 and c3["roofline"]["bound"] == "lds"
@@ -106,7 +106,7 @@ def test_single_gpu_line_has_every_contract_field():
     assert cb["gpu_matches_generic_bitwise"] is True and cb["generic_single_thread_gpos"] > 0
     for key in ("fused_score_argmax", "fused_score_threshold"):
         fr = out["extras"][key]["roofline"]
-        assert fr["bound"] == "hbm" and 0 < fr["frac"] < 1
+        assert fr["bound"] == "lds" and 0 < fr["frac"] < 1.2 and 0 < fr["hbm_read_frac"] < 1
     assert ex["c3"]["roofline"]["bound"] == "lds" and 0 < ex["c3"]["roofline"]["frac"] < 1.2
     assert ex["c5"]["roofline"]["bound"] == "hbm" and ex["c5"]["roofline"]["frac"] == ex["c5"]["hbm_frac"]
 
