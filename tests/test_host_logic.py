@@ -160,3 +160,29 @@ def test_bench_helpers_without_a_gpu(monkeypatch):
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_bench_roofline_blocks_without_a_gpu():
+    """The roofline arithmetic bench.py prints for the extras: the fused forms and configs[2] are priced against
+    the LDS-gather ceiling with (M | 3) + 1 bytes of pair table per scanned (motif, position) cell, the 1 B per position of
+    HBM reads beside it; the best-k-mer bound that decides which motifs cannot reach a threshold."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("lm_bench2", Path(__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rows, m = 31_250_000, 20
+    fr = bench.fused_roofline(0.25, rows, m, "score_c32_prefilter2")
+    rf = fr["roofline"]
+    assert rf["bound"] == "lds" and rf["lds_bytes_per_position"] == 24 and rf["peak"] == 157.3
+    assert abs(rf["achieved"] - 24 * 1e9 / 0.25e-3 / 1e12) < 0.01 and abs(rf["frac"] - rf["achieved"] / 157.2864) < 1e-3
+    assert abs(rf["hbm_read_frac"] - (1e9 / 0.25e-3 / 1e9) / 8000.0) < 1e-4 and fr["Gpos_s"] == 4000.0
+    lr = bench.lds_roofline(157.2864e12 * 0.5, 1.0, "model")
+    assert lr["bound"] == "lds" and lr["frac"] == 0.5 and lr["unit"] == "TB/s"
+    # (M | 3) + 1: the pair scan pads the motif to 3 (mod 4) rows and reads one u16 per padded row + 1, per PAIR of input rows
+    assert [(mm | 3) + 1 for mm in (4, 7, 8, 11, 12, 20, 33)] == [8, 8, 12, 12, 16, 24, 36]
+    pssm = lm.create(["ACGT", "ACGA", "ACCT"]).counts.normalize(0.1).log_odds()
+    want = np.float32(0)
+    for row in pssm.data[:, :4]:                     # the sequential f32 sum of the row maxima, in motif order
+        want = np.float32(want + row.max())
+    assert bench.best_kmer_score(pssm) == want
