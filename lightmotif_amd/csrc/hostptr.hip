@@ -302,7 +302,25 @@ int run_pipeline(lm_hip_ctx *ctx, BigPipe &bp, const TileJob &job)
 #define LM_PIPE_T0 (void)0
 #define LM_PIPE_ADD(counter) (void)0
 #endif
-    std::thread uploader([&] {
+    std::thread uploader;
+    std::vector<std::thread> copiers;
+    auto abandon = [&](const char *why) {  // a helper thread could not be started: stop the ones that were, report
+        {
+            std::lock_guard<std::mutex> lock(sh.mu);
+            if (sh.status == LM_HIP_OK) {
+                sh.status = LM_HIP_ERR_OOM;
+                snprintf(sh.err, sizeof sh.err, "host pipeline: %s", why);
+            }
+            sh.cv.notify_all();
+        }
+        if (uploader.joinable())
+            uploader.join();
+        for (std::thread &c : copiers)
+            if (c.joinable())
+                c.join();
+        return fail(LM_HIP_ERR_OOM, "%s", sh.err);
+    };
+    auto upload_loop = [&] {
         if (hipSetDevice(device) != hipSuccess)
             return raise(LM_HIP_ERR_HIP, "hipSetDevice", hipGetLastError());
         for (size_t t = 0; t < n; ++t) {
@@ -328,39 +346,44 @@ int run_pipeline(lm_hip_ctx *ctx, BigPipe &bp, const TileJob &job)
             sh.uploaded = t + 1;
             sh.cv.notify_all();
         }
-    });
-    std::vector<std::thread> copiers;
-    for (int j = 0; j < ncopiers; ++j)
-        copiers.emplace_back([&, j] {
-            if (hipSetDevice(device) != hipSuccess)
-                return raise(LM_HIP_ERR_HIP, "hipSetDevice", hipGetLastError());
-            for (size_t t = 0; t < n; ++t) {
-                const int slot = (int)(t % (size_t)out_slots);
-                {
-                    LM_PIPE_T0;
-                    std::unique_lock<std::mutex> lock(sh.mu);
-                    sh.cv.wait(lock, [&] { return sh.issued > t || sh.status != LM_HIP_OK; });
-                    if (sh.status != LM_HIP_OK)
-                        return;
-                    lock.unlock();
-                    const hipError_t e = hipEventSynchronize(bp.landed[slot]);
-                    if (e != hipSuccess)
-                        return raise(LM_HIP_ERR_HIP, "tile read-back", e);
-                    LM_PIPE_ADD(ns_cp_wait);
-                }
-                {
-                    LM_PIPE_T0;
-                    job.copy_out(t, slot, j, ncopiers);
-                    LM_PIPE_ADD(ns_cp_copy);
-                }
-                std::lock_guard<std::mutex> lock(sh.mu);
-                if (++sh.done[slot] == (unsigned)ncopiers) {
-                    sh.done[slot] = 0;
-                    sh.copied = t + 1;
-                    sh.cv.notify_all();
-                }
+    };
+    auto copy_loop = [&](int j) {
+        if (hipSetDevice(device) != hipSuccess)
+            return raise(LM_HIP_ERR_HIP, "hipSetDevice", hipGetLastError());
+        for (size_t t = 0; t < n; ++t) {
+            const int slot = (int)(t % (size_t)out_slots);
+            {
+                LM_PIPE_T0;
+                std::unique_lock<std::mutex> lock(sh.mu);
+                sh.cv.wait(lock, [&] { return sh.issued > t || sh.status != LM_HIP_OK; });
+                if (sh.status != LM_HIP_OK)
+                    return;
+                lock.unlock();
+                const hipError_t e = hipEventSynchronize(bp.landed[slot]);
+                if (e != hipSuccess)
+                    return raise(LM_HIP_ERR_HIP, "tile read-back", e);
+                LM_PIPE_ADD(ns_cp_wait);
             }
-        });
+            {
+                LM_PIPE_T0;
+                job.copy_out(t, slot, j, ncopiers);
+                LM_PIPE_ADD(ns_cp_copy);
+            }
+            std::lock_guard<std::mutex> lock(sh.mu);
+            if (++sh.done[slot] == (unsigned)ncopiers) {
+                sh.done[slot] = 0;
+                sh.copied = t + 1;
+                sh.cv.notify_all();
+            }
+        }
+    };
+    try {
+        uploader = std::thread(upload_loop);
+        for (int j = 0; j < ncopiers; ++j)
+            copiers.emplace_back(copy_loop, j);
+    } catch (const std::exception &ex) {  // std::system_error: no more threads
+        return abandon(ex.what());
+    }
     for (size_t t = 0; t < n; ++t) {
         {   // tile t is on the device, and output slot t % out_slots (device + pinned) has been emptied into the caller's matrix
             LM_PIPE_T0;
@@ -547,6 +570,19 @@ int stage_scores(HostLane *lane, const float *scores, size_t rows, size_t stride
 
 using namespace lm;
 
+// No C++ exception may cross the C ABI (std::bad_alloc from a table cache or a job closure, std::system_error from a thread).
+template <class Body>
+static int guarded(const char *what, Body body)
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(LM_HIP_ERR_OOM, "%s: out of host memory", what);
+    } catch (const std::exception &ex) {
+        return fail(LM_HIP_ERR_HIP, "%s: %s", what, ex.what());
+    }
+}
+
 extern "C" {
 
 int lm_hip_score_f32(const uint8_t *seq, size_t seq_rows_total, size_t seq_stride, size_t cols,
@@ -554,31 +590,33 @@ int lm_hip_score_f32(const uint8_t *seq, size_t seq_rows_total, size_t seq_strid
                      size_t k, size_t row_begin, size_t row_end, float *out, size_t out_stride,
                      size_t *out_rows, size_t *max_index)
 {
-    HostLane *lane = nullptr;
-    LM_TRY(acquire_lane(&lane));
-    lm_hip_ctx *ctx = lane->ctx;  // the lane is this thread's alone: nothing to lock
-    DeviceGuard guard(ctx->device);
-    lm_hip_pssm *p = nullptr;
-    LM_TRY(lane_pssm(lane, pssm, m, pssm_stride, k, &p));
-    LM_TRY(check_score_args(p, seq_rows_total, seq_stride, cols, wrap, row_begin, row_end));
-    if (length < m || row_begin >= row_end) {  // pli/mod.rs:85-88
-        if (out_rows) *out_rows = 0;
-        if (max_index) *max_index = 0;
+    return guarded("score", [&]() -> int {
+        HostLane *lane = nullptr;
+        LM_TRY(acquire_lane(&lane));
+        lm_hip_ctx *ctx = lane->ctx;  // the lane is this thread's alone: nothing to lock
+        DeviceGuard guard(ctx->device);
+        lm_hip_pssm *p = nullptr;
+        LM_TRY(lane_pssm(lane, pssm, m, pssm_stride, k, &p));
+        LM_TRY(check_score_args(p, seq_rows_total, seq_stride, cols, wrap, row_begin, row_end));
+        if (length < m || row_begin >= row_end) {  // pli/mod.rs:85-88
+            if (out_rows) *out_rows = 0;
+            if (max_index) *max_index = 0;
+            return LM_HIP_OK;
+        }
+        if (!seq || !out || out_stride < cols)
+            return fail(LM_HIP_ERR_BAD_ARGS, "score: null buffer or out stride %zu < columns %zu", out_stride, cols);
+        // only the rows the range needs travel: [row_begin, row_end + m - 1)
+        ScoreCall c{seq + row_begin * seq_stride, seq_stride, cols, row_end - row_begin, m ? m - 1 : 0,
+                    reinterpret_cast<char *>(out), out_stride, sizeof(float), nullptr};
+        c.launch = [p, seq_stride, cols](lm_hip_ctx *cx, const uint8_t *d_seq, size_t rows, void *d_out) {
+            ScoreArgs a{p, d_seq, seq_stride, cols, 0, rows, static_cast<float *>(d_out), cols};
+            return launch_score_store(cx, a);
+        };
+        LM_TRY(score_call(lane, c));
+        if (out_rows) *out_rows = c.nrows;       // pli/mod.rs:91
+        if (max_index) *max_index = length + 1 - m;
         return LM_HIP_OK;
-    }
-    if (!seq || !out || out_stride < cols)
-        return fail(LM_HIP_ERR_BAD_ARGS, "score: null buffer or out stride %zu < columns %zu", out_stride, cols);
-    // only the rows the range needs travel: [row_begin, row_end + m - 1)
-    ScoreCall c{seq + row_begin * seq_stride, seq_stride, cols, row_end - row_begin, m ? m - 1 : 0,
-                reinterpret_cast<char *>(out), out_stride, sizeof(float), nullptr};
-    c.launch = [p, seq_stride, cols](lm_hip_ctx *cx, const uint8_t *d_seq, size_t rows, void *d_out) {
-        ScoreArgs a{p, d_seq, seq_stride, cols, 0, rows, static_cast<float *>(d_out), cols};
-        return launch_score_store(cx, a);
-    };
-    LM_TRY(score_call(lane, c));
-    if (out_rows) *out_rows = c.nrows;       // pli/mod.rs:91
-    if (max_index) *max_index = length + 1 - m;
-    return LM_HIP_OK;
+    });
 }
 
 // Score<u8, A, C>::score_rows_into with a DiscreteMatrix on host matrices (pli/mod.rs:437-476 is the AVX2 impl; what
@@ -588,70 +626,74 @@ int lm_hip_score_u8_host(const uint8_t *seq, size_t seq_rows_total, size_t seq_s
                          size_t row_begin, size_t row_end, int saturate, uint8_t *out, size_t out_stride,
                          size_t *out_rows, size_t *max_index)
 {
-    if (!weights || m == 0 || k == 0 || k > 256 || weights_stride < k)
-        return fail(LM_HIP_ERR_BAD_ARGS, "score_u8: bad discrete matrix (%zu x %zu, stride %zu)", m, k, weights_stride);
-    lm_hip_pssm shape;  // the geometry checks only look at the motif length
-    shape.m = m;
-    shape.k = k;
-    LM_TRY(check_score_args(&shape, seq_rows_total, seq_stride, cols, wrap, row_begin, row_end));
-    if (length < m || row_begin >= row_end) {  // pli/mod.rs:85-88
-        if (out_rows) *out_rows = 0;
-        if (max_index) *max_index = 0;
+    return guarded("score_u8", [&]() -> int {
+        if (!weights || m == 0 || k == 0 || k > 256 || weights_stride < k)
+            return fail(LM_HIP_ERR_BAD_ARGS, "score_u8: bad discrete matrix (%zu x %zu, stride %zu)", m, k, weights_stride);
+        lm_hip_pssm shape;  // the geometry checks only look at the motif length
+        shape.m = m;
+        shape.k = k;
+        LM_TRY(check_score_args(&shape, seq_rows_total, seq_stride, cols, wrap, row_begin, row_end));
+        if (length < m || row_begin >= row_end) {  // pli/mod.rs:85-88
+            if (out_rows) *out_rows = 0;
+            if (max_index) *max_index = 0;
+            return LM_HIP_OK;
+        }
+        if (!seq || !out || out_stride < cols)
+            return fail(LM_HIP_ERR_BAD_ARGS, "score_u8: null buffer or out stride %zu < columns %zu", out_stride, cols);
+        HostLane *lane = nullptr;
+        LM_TRY(acquire_lane(&lane));
+        DeviceGuard guard(lane->ctx->device);
+        ScoreCall c{seq + row_begin * seq_stride, seq_stride, cols, row_end - row_begin, m - 1, reinterpret_cast<char *>(out),
+                    out_stride, 1, nullptr};
+        c.launch = [=](lm_hip_ctx *cx, const uint8_t *d_seq, size_t rows, void *d_out) {
+            // (the device tables of the matrix are kept by the lane's context until the weights change: launch_score_u8)
+            DiscreteArgs a{weights, m, weights_stride, k, d_seq, seq_stride, cols, 0, rows, static_cast<uint8_t *>(d_out), cols,
+                           saturate != 0};
+            return launch_score_u8(cx, a);
+        };
+        LM_TRY(score_call(lane, c));
+        if (out_rows) *out_rows = c.nrows;
+        if (max_index) *max_index = length + 1 - m;
         return LM_HIP_OK;
-    }
-    if (!seq || !out || out_stride < cols)
-        return fail(LM_HIP_ERR_BAD_ARGS, "score_u8: null buffer or out stride %zu < columns %zu", out_stride, cols);
-    HostLane *lane = nullptr;
-    LM_TRY(acquire_lane(&lane));
-    DeviceGuard guard(lane->ctx->device);
-    ScoreCall c{seq + row_begin * seq_stride, seq_stride, cols, row_end - row_begin, m - 1, reinterpret_cast<char *>(out),
-                out_stride, 1, nullptr};
-    c.launch = [=](lm_hip_ctx *cx, const uint8_t *d_seq, size_t rows, void *d_out) {
-        // (the device tables of the matrix are kept by the lane's context until the weights change: launch_score_u8)
-        DiscreteArgs a{weights, m, weights_stride, k, d_seq, seq_stride, cols, 0, rows, static_cast<uint8_t *>(d_out), cols,
-                       saturate != 0};
-        return launch_score_u8(cx, a);
-    };
-    LM_TRY(score_call(lane, c));
-    if (out_rows) *out_rows = c.nrows;
-    if (max_index) *max_index = length + 1 - m;
-    return LM_HIP_OK;
+    });
 }
 
 int lm_hip_argmax_f32(const float *scores, size_t rows, size_t stride, size_t cols, int *found,
                       lm_hip_coords *best, float *value)
 {
-    if (!found)
-        return fail(LM_HIP_ERR_BAD_ARGS, "argmax: null argument");
-    *found = 0;
-    if (rows == 0)  // pli/mod.rs:136-138
-        return LM_HIP_OK;
-    if (!scores || cols == 0 || stride < cols)
-        return fail(LM_HIP_ERR_BAD_ARGS, "argmax: bad matrix");
-    HostLane *lane = nullptr;
-    LM_TRY(acquire_lane(&lane));
-    lm_hip_ctx *ctx = lane->ctx;  // the lane is this thread's alone: nothing to lock
-    DeviceGuard guard(ctx->device);
-    const float *d = nullptr;
-    ArgmaxRecord rec{};
-    int st = stage_scores(lane, scores, rows, stride, cols, &d);
-    if (st == LM_HIP_OK)
-        st = launch_argmax(ctx, d, rows, cols, cols, 1, &rec);
-    if (st != LM_HIP_OK)
-        (void)hipStreamSynchronize(ctx->stream);
-    trim(lane->d_in);
-    if (st != LM_HIP_OK)
-        return st;
-    *found = rec.found;
-    if (rec.found) {
-        if (best) {
-            best->row = (size_t)(rec.index / (long long)cols);
-            best->col = (size_t)(rec.index % (long long)cols);
+    return guarded("argmax", [&]() -> int {
+        if (!found)
+            return fail(LM_HIP_ERR_BAD_ARGS, "argmax: null argument");
+        *found = 0;
+        if (rows == 0)  // pli/mod.rs:136-138
+            return LM_HIP_OK;
+        if (!scores || cols == 0 || stride < cols)
+            return fail(LM_HIP_ERR_BAD_ARGS, "argmax: bad matrix");
+        HostLane *lane = nullptr;
+        LM_TRY(acquire_lane(&lane));
+        lm_hip_ctx *ctx = lane->ctx;  // the lane is this thread's alone: nothing to lock
+        DeviceGuard guard(ctx->device);
+        const float *d = nullptr;
+        ArgmaxRecord rec{};
+        int st = stage_scores(lane, scores, rows, stride, cols, &d);
+        if (st == LM_HIP_OK)
+            st = launch_argmax(ctx, d, rows, cols, cols, 1, &rec);
+        if (st != LM_HIP_OK)
+            (void)hipStreamSynchronize(ctx->stream);
+        trim(lane->d_in);
+        if (st != LM_HIP_OK)
+            return st;
+        *found = rec.found;
+        if (rec.found) {
+            if (best) {
+                best->row = (size_t)(rec.index / (long long)cols);
+                best->col = (size_t)(rec.index % (long long)cols);
+            }
+            if (value)
+                *value = rec.value;
         }
-        if (value)
-            *value = rec.value;
-    }
-    return LM_HIP_OK;
+        return LM_HIP_OK;
+    });
 }
 
 int lm_hip_max_f32(const float *scores, size_t rows, size_t stride, size_t cols, int *found, float *value)
@@ -663,26 +705,28 @@ int lm_hip_max_f32(const float *scores, size_t rows, size_t stride, size_t cols,
 int lm_hip_threshold_f32(const float *scores, size_t rows, size_t stride, size_t cols, float t,
                          lm_hip_coords **coords, size_t *n)
 {
-    if (!coords || !n)
-        return fail(LM_HIP_ERR_BAD_ARGS, "threshold: null argument");
-    *coords = nullptr;
-    *n = 0;
-    if (rows == 0)
-        return LM_HIP_OK;
-    if (!scores || cols == 0 || stride < cols)
-        return fail(LM_HIP_ERR_BAD_ARGS, "threshold: bad matrix");
-    HostLane *lane = nullptr;
-    LM_TRY(acquire_lane(&lane));
-    lm_hip_ctx *ctx = lane->ctx;  // the lane is this thread's alone: nothing to lock
-    DeviceGuard guard(ctx->device);
-    const float *d = nullptr;
-    int st = stage_scores(lane, scores, rows, stride, cols, &d);
-    if (st == LM_HIP_OK)
-        st = launch_threshold(ctx, d, rows, cols, cols, t, coords, n);
-    if (st != LM_HIP_OK)
-        (void)hipStreamSynchronize(ctx->stream);
-    trim(lane->d_in);
-    return st;
+    return guarded("threshold", [&]() -> int {
+        if (!coords || !n)
+            return fail(LM_HIP_ERR_BAD_ARGS, "threshold: null argument");
+        *coords = nullptr;
+        *n = 0;
+        if (rows == 0)
+            return LM_HIP_OK;
+        if (!scores || cols == 0 || stride < cols)
+            return fail(LM_HIP_ERR_BAD_ARGS, "threshold: bad matrix");
+        HostLane *lane = nullptr;
+        LM_TRY(acquire_lane(&lane));
+        lm_hip_ctx *ctx = lane->ctx;  // the lane is this thread's alone: nothing to lock
+        DeviceGuard guard(ctx->device);
+        const float *d = nullptr;
+        int st = stage_scores(lane, scores, rows, stride, cols, &d);
+        if (st == LM_HIP_OK)
+            st = launch_threshold(ctx, d, rows, cols, cols, t, coords, n);
+        if (st != LM_HIP_OK)
+            (void)hipStreamSynchronize(ctx->stream);
+        trim(lane->d_in);
+        return st;
+    });
 }
 
 }  // extern "C"
