@@ -53,7 +53,7 @@ def test_two_ranks_without_a_launcher():
     rf = out["roofline"]
     lo, hi = rf["kernel_ms_by_rank"]
     assert 0 < lo <= hi and rf["peak_aggregate"] == 2 * rf["peak"]
-    assert abs(rf["achieved_aggregate"] - 2 * rf["achieved"]) < 0.35 * rf["achieved_aggregate"]   # two ranks share ONE device here
+    assert rf["achieved"] < rf["achieved_aggregate"] < 4 * rf["achieved"]     # the sum over both ranks (which share ONE device here)
     mu = out["extras"]["merge_us"]
     assert mu["p50"] > 0 and mu["max"] >= mu["p50"]
     assert out["extras"]["merge_threshold_ms"] > 0 and out["extras"]["merge_threshold_ms_torch"] > 0
