@@ -522,7 +522,7 @@ int lm_hip_merge_threshold(lm_hip_ctx *ctx, lm_hip_comm *comm, const lm_hip_coor
 /* Exactly what a Rust shim can obtain from &StripedSequence / &DenseMatrix / &mut StripedScores: pageable host
  * matrices in, pageable host matrices out (csrc/hostptr.hip).  No context argument: every calling host thread is given
  * a lane of its own (context + stream, persistent staging, a cache of device PSSM tables keyed on the weights) on device
- * 0 or $LM_HIP_DEVICE, so threads overlap; large calls (>= 48 MB of scores) run as a tile pipeline over a process-wide
+ * 0 or $LM_HIP_DEVICE, so threads overlap; large calls (>= 96 MB of scores) run as a tile pipeline over a process-wide
  * ring of pinned buffers and take turns on it.  1 B per position travels up and 4 B down per lm_hip_score_f32 call. */
 int lm_hip_score_f32(const uint8_t *seq, size_t seq_rows_total, size_t seq_stride, size_t cols,
                      size_t wrap, size_t length,

@@ -18,7 +18,7 @@
 //    one pageable copy up, one kernel, one pageable copy down, one synchronisation; no allocation, no table build.
 //    The tiniest (<= 128 KB each way) skip the copy commands altogether: the kernel reads the symbols from and writes
 //    the scores to pinned host memory (tools/kbench/hostpipe_bench.hip: 15.9 us against 27.8 us per iteration).
-//  * LARGE calls are link-bound and run as a three-stage pipeline over row tiles: an uploader thread copies tile
+//  * LARGE calls (>= 96 MB of scores) are link-bound and run as a three-stage pipeline over row tiles: an uploader thread copies tile
 //    t + 1 .. t + 3 (pageable H2D, 56 GB/s) while the store kernel of tile t runs and tile t - 1 travels back.  The
 //    way back is the long one (4 B per position): the runtime's pageable D2H reaches 48 GB/s, a copy into pinned
 //    memory 56.6 GB/s -- so tiles land in a ring of four pinned 32 MB buffers and four copier threads move them into
@@ -40,7 +40,10 @@ namespace {
 
 constexpr size_t kZeroCopyBytes = 128u << 10;   // tiniest calls: symbols / scores straight from / to pinned memory
 constexpr size_t kKeepBytes = 256u << 20;       // staging buffers above this are released when the call ends
-constexpr size_t kPipeMinOutBytes = 48u << 20;  // score matrices from here on take the tile pipeline
+constexpr size_t kPipeMinOutBytes = 96u << 20;  // score matrices from here on take the tile pipeline (below, its ramp --
+                                                // helper threads, one tile each of upload / read-back / copy-out latency --
+                                                // costs more than the 15 % the pinned read-back gains: r04_host_pointer.json)
+constexpr size_t kPipeMinTileBytes = 4u << 20;  // tiles: a twelfth of the score matrix, between this and a ring slot
 constexpr size_t kTileBytes = 32u << 20;        // one tile of scores (and one pinned ring slot)
 constexpr int kInSlots = 3, kOutSlots = 4, kCopiers = 4;
 constexpr int kMaxOutSlots = 8;
@@ -491,9 +494,12 @@ int score_pipelined(HostLane *lane, BigPipe &bp, const ScoreCall &c)
 {
     lm_hip_ctx *ctx = lane->ctx;
     LM_TRY(pipe_prepare(bp, ctx->device));
-    // rows per tile: 32 MB of scores, at most 64 MB of symbols
+    // rows per tile: a ring slot (32 MB) of scores for genome-sized calls, smaller tiles for smaller calls -- the
+    // pipeline's ramp is one tile each of upload, read-back and copy-out latency, a tile costs ~20 us of its own --
+    // and at most two slots' worth of symbols
     const size_t tile_bytes = pipe_shape().tile_bytes, row_bytes = c.cols * c.elem;
-    size_t tr = std::min(tile_bytes / row_bytes, (2 * tile_bytes) / c.seq_stride);
+    const size_t target = std::min(tile_bytes, std::max(kPipeMinTileBytes, c.nrows * row_bytes / 12));
+    size_t tr = std::min(target / row_bytes, (2 * tile_bytes) / c.seq_stride);
     tr = std::max<size_t>(tr / 256 * 256, 256);
     const size_t in_tile = ((tr + c.halo) * c.seq_stride + 255) / 256 * 256, out_tile = (tr * row_bytes + 255) / 256 * 256;
     if (tr * row_bytes > tile_bytes)  // (more than 32 K columns: not a shape this path is for)

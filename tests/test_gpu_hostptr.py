@@ -102,7 +102,7 @@ def test_score_f32_matches_oracle(length, cols, k, m, rows):
 
 @pytest.mark.parametrize("out_stride", [32, 40])
 def test_pipeline_tiles_row_range_and_out_stride(out_stride):
-    """Large enough for the tile pipeline (3 full tiles of 262 144 rows + a ragged one), a row range that starts inside
+    """Large enough for the tile pipeline (101 MB of scores: a dozen tiles and a ragged one), a row range that starts inside
     the matrix, the caller's rows wider than the scored columns: every tile boundary must be seamless."""
     rng = np.random.default_rng(out_stride)
     m, rows_total = 20, 262_144 * 3 + 5_000
@@ -200,13 +200,13 @@ def test_threads_are_bit_exact_and_overlap():
 
 
 def test_two_large_calls_at_once():
-    """Two threads enter with pipeline-sized matrices at the same moment: one takes the pinned ring, the other runs piece
-    by piece on its own lane -- both bit-exact."""
+    """Two threads enter with pipeline-sized matrices at the same moment: they take turns on the pinned ring (the link is
+    the bound) -- both bit-exact."""
     rng = np.random.default_rng(21)
     m = 20
     jobs = []
     for t in range(2):
-        rows = 262_144 * 2 + 999 + t
+        rows = 262_144 * 3 + 999 + t          # 100 MB of scores each: both take the tile pipeline
         s = striped(rng, rows * 32 - 5, 32, 5, m)
         p = random_pssm(rng, m, 5)
         want = co.aligned_empty((rows, 32), np.float32)
@@ -345,9 +345,9 @@ def test_score_u8_host_matches_oracle(length, cols, k, m, rows, out_stride):
 
 
 def test_score_u8_host_through_the_tile_pipeline():
-    """64 Mbp: 64 MB of u8 scores, two tiles of the pipeline and a ragged one; wrapping adds against the C oracle."""
+    """102 Mbp: 102 MB of u8 scores through the tile pipeline (twelve tiles and a ragged one); wrapping adds against the C oracle."""
     rng = np.random.default_rng(64)
-    m, rows_total = 15, 2_000_000 + 77
+    m, rows_total = 15, 3_200_000 + 77
     s = striped(rng, rows_total * 32 - 3, 32, 5, m)
     w = np.zeros((m, 32), np.uint8)
     w[:, :5] = rng.integers(0, 17, (m, 5))

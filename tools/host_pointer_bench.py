@@ -259,6 +259,24 @@ def bench_threads_small(nthreads: int = 8, iters: int = 100):
             "us_per_iteration_aggregate": round(par / (nthreads * iters) * 1e6, 1)}
 
 
+def bench_sizes(sizes=(1_000_000, 4_641_652, 10_000_000, 20_000_000, 50_000_000, 100_000_000, 200_000_000), m: int = 20):
+    """lm_hip_score_f32 by sequence length (4 641 652 = E. coli K12, the reference's README benchmark): where the copy path
+    ends and the tile pipeline begins (96 MB of scores = 25 Mbp)"""
+    rng = np.random.default_rng(5)
+    sites = ["".join("ACTG"[i] for i in rng.integers(0, 4, m)) for _ in range(10)]
+    pssm = lm.create(sites).counts.normalize(0.1).log_odds().data
+    out = {}
+    for length in sizes:
+        rows = -(-length // COLS)
+        mat = rng.integers(0, 4, (rows + m - 1, COLS), dtype=np.uint8)
+        mat[rows:, :31] = mat[:m - 1, 1:]
+        mat[rows:, 31] = 4
+        res = np.zeros((rows, COLS), np.float32)
+        med, mn = loop_us(lambda: score_f32(mat, rows, length, pssm, res), 12 if length > 20_000_000 else 40, 3)
+        out[str(length)] = {"ms": round(med / 1e3, 3), "ms_min": round(mn / 1e3, 3), "gpos": round(rows * COLS / med / 1e3, 2)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--json", default="")
@@ -277,6 +295,9 @@ def main():
         print(json.dumps({"threads_small_calls": res["threads_small_calls"]}), flush=True)
         res["threads"] = bench_threads()
         print(json.dumps({"threads": res["threads"]}), flush=True)
+    if "sizes" not in a.skip:
+        res["by_length"] = bench_sizes()
+        print(json.dumps({"by_length": res["by_length"]}), flush=True)
     if "big" not in a.skip:
         res["end_to_end"] = bench_big(a.big)
         print(json.dumps({"end_to_end": res["end_to_end"]}), flush=True)
