@@ -186,3 +186,21 @@ def test_bench_roofline_blocks_without_a_gpu():
     for row in pssm.data[:, :4]:                     # the sequential f32 sum of the row maxima, in motif order
         want = np.float32(want + row.max())
     assert bench.best_kmer_score(pssm) == want
+
+
+def test_no_built_artefact_is_tracked():
+    """History stays source-only: nothing git tracks is an ELF object / executable / shared library (built `.so` files and
+    the kbench tools travel to the GPU box untracked)."""
+    import subprocess
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run(["git", "ls-files", "-z"], cwd=root, capture_output=True)
+    if r.returncode != 0 or not r.stdout:
+        pytest.skip("not a git checkout")
+    bad = []
+    for name in r.stdout.decode().split("\0"):
+        p = root / name
+        if name and p.is_file():
+            with open(p, "rb") as f:
+                if f.read(4) == b"\x7fELF":
+                    bad.append(name)
+    assert not bad, bad
