@@ -466,6 +466,182 @@ private:
     lm_hip_scores *h_;
 };
 
+// ---- the literal drop-in: host matrices in, host matrices out ------------------------------------------------
+//
+// The C++ twin of the Rust shim in INTEGRATION.md 2-4b.  `host::StripedSequence` / `host::StripedScores` are the
+// reference's own structs (seq.rs:288-294, scores.rs:102-107) with their data in ordinary host memory, striped and wrapped
+// by the Generic loops (pli/mod.rs:178-200, seq.rs:362-381) -- what a Rust caller holds when `Dispatch::Hip` is asked to
+// score.  `HipDispatch` binds exactly the host-pointer entry points that shim binds, with the same resize-then-call
+// order (avx2.rs:839-844), so the functions behind a `Dispatch::Hip` arm are exercised from compiled host code.
+
+namespace host {
+
+template <class A>
+class StripedSequence {
+public:
+    StripedSequence(DenseMatrix<uint8_t> d, size_t length, size_t wrap, size_t cols)
+        : data(std::move(d)), length_(length), wrap_(wrap), cols_(cols) {}
+    // Stripe::stripe_into, Generic (pli/mod.rs:178-200): position i -> [i % R][i / R], the tail = default symbol
+    static StripedSequence stripe(const EncodedSequence<A> &seq, size_t cols = 32)
+    {
+        const size_t len = seq.len(), rows = (len + cols - 1) / cols;
+        DenseMatrix<uint8_t> m(rows, cols);
+        for (size_t r = 0; r < rows; ++r)
+            for (size_t c = 0; c < cols; ++c)
+                m(r, c) = (uint8_t)(A::K - 1);
+        for (size_t i = 0; i < len; ++i)
+            m(i % rows, i / rows) = seq.data[i];
+        return StripedSequence(std::move(m), len, 0, cols);
+    }
+    // seq.rs:362-381: rows() + motif_len - 1 rows; wrap row i = row i shifted one column left, last column = default
+    void configure_wrap(size_t motif_len)
+    {
+        if (motif_len <= wrap_)
+            return;
+        const size_t rows = data.rows() - wrap_;
+        DenseMatrix<uint8_t> m(rows + motif_len, cols_);
+        for (size_t r = 0; r < rows; ++r)
+            for (size_t c = 0; c < cols_; ++c)
+                m(r, c) = data(r, c);
+        for (size_t i = 0; i < motif_len; ++i) {
+            for (size_t c = 0; c + 1 < cols_; ++c)
+                m(rows + i, c) = m(i, c + 1);
+            m(rows + i, cols_ - 1) = (uint8_t)(A::K - 1);
+        }
+        data = std::move(m);
+        wrap_ = motif_len;
+    }
+    void configure(const ScoringMatrix<A> &pssm)
+    {
+        if (pssm.len() > 0)
+            configure_wrap(pssm.len() - 1);
+    }
+    size_t len() const { return length_; }
+    size_t wrap() const { return wrap_; }
+    size_t columns() const { return cols_; }
+    const DenseMatrix<uint8_t> &matrix() const { return data; }
+    DenseMatrix<uint8_t> data;
+
+private:
+    size_t length_, wrap_, cols_;
+};
+
+template <class T>
+class StripedScores {
+public:
+    explicit StripedScores(size_t cols = 32) : data(0, cols), cols_(cols) {}
+    void resize(size_t rows, size_t max_index)  // scores.rs:148-152
+    {
+        if (rows != data.rows())
+            data = DenseMatrix<T>(rows, cols_);
+        max_index_ = max_index;
+    }
+    size_t max_index() const { return max_index_; }
+    size_t len() const { return std::min(max_index_, data.rows() * cols_); }            // scores.rs:274-279
+    size_t offset(MatrixCoordinates mc) const { return mc.col * data.rows() + mc.row; }  // scores.rs:155-157
+    std::vector<T> unstripe() const                                                      // scores.rs:167-170
+    {
+        std::vector<T> out(len());
+        for (size_t i = 0; i < out.size(); ++i)
+            out[i] = data(i % data.rows(), i / data.rows());
+        return out;
+    }
+    const DenseMatrix<T> &matrix() const { return data; }
+    DenseMatrix<T> data;
+
+private:
+    size_t cols_, max_index_ = 0;
+};
+
+}  // namespace host
+
+struct HipDispatch {
+    // Hip::available(): `Pipeline::hip()` mirrors `Pipeline::avx2()` (pli/mod.rs:401-407)
+    static bool available()
+    {
+        int n = 0;
+        return lm_hip_device_count(&n) == LM_HIP_OK && n > 0;
+    }
+    // Score<f32, A, C>::score_rows_into for Dispatch::Hip (dispatch.rs:90-106; contract of avx2.rs:889-904)
+    template <class A>
+    static void score_rows_into(const ScoringMatrix<A> &pssm, const host::StripedSequence<A> &seq, size_t row_begin,
+                                size_t row_end, host::StripedScores<float> &scores)
+    {
+        const DenseMatrix<float> &w = pssm.matrix();
+        if (seq.len() < w.rows() || row_begin >= row_end) {  // avx2.rs:839-842
+            scores.resize(0, 0);
+            return;
+        }
+        scores.resize(row_end - row_begin, seq.len() + 1 - w.rows());
+        size_t out_rows = 0, max_index = 0;
+        const DenseMatrix<uint8_t> &m = seq.matrix();
+        check(lm_hip_score_f32(m.ptr(), m.rows(), m.stride(), seq.columns(), seq.wrap(), seq.len(), w.ptr(), w.rows(),
+                               w.stride(), A::K, row_begin, row_end, scores.data.ptr(), scores.data.stride(), &out_rows,
+                               &max_index));
+    }
+    template <class A>
+    static host::StripedScores<float> score(const ScoringMatrix<A> &pssm, const host::StripedSequence<A> &seq)
+    {
+        host::StripedScores<float> scores(seq.columns());
+        score_rows_into(pssm, seq, 0, seq.matrix().rows() - seq.wrap(), scores);  // pli/mod.rs:115-116
+        return scores;
+    }
+    // Score<u8, A, C> with a DiscreteMatrix (pli/mod.rs:437-476; avx2.rs:921-931)
+    template <class A>
+    static void score_rows_into(const DiscreteMatrix<A> &dm, const host::StripedSequence<A> &seq, size_t row_begin,
+                                size_t row_end, host::StripedScores<uint8_t> &scores, bool saturate = true)
+    {
+        const DenseMatrix<uint8_t> &w = dm.matrix();
+        if (seq.len() < w.rows() || row_begin >= row_end) {
+            scores.resize(0, 0);
+            return;
+        }
+        scores.resize(row_end - row_begin, seq.len() + 1 - w.rows());
+        size_t out_rows = 0, max_index = 0;
+        const DenseMatrix<uint8_t> &m = seq.matrix();
+        check(lm_hip_score_u8_host(m.ptr(), m.rows(), m.stride(), seq.columns(), seq.wrap(), seq.len(), w.ptr(), w.rows(),
+                                   w.stride(), A::K, row_begin, row_end, saturate ? 1 : 0, scores.data.ptr(),
+                                   scores.data.stride(), &out_rows, &max_index));
+    }
+    // Maximum<f32, C> (dispatch.rs:160-177): the Generic rule
+    static std::optional<MatrixCoordinates> argmax(const host::StripedScores<float> &scores)
+    {
+        const DenseMatrix<float> &d = scores.matrix();
+        if (d.rows() == 0)
+            return std::nullopt;
+        int found = 0;
+        lm_hip_coords best{};
+        check(lm_hip_argmax_f32(d.ptr(), d.rows(), d.stride(), d.columns(), &found, &best, nullptr));
+        return found ? std::optional<MatrixCoordinates>(MatrixCoordinates{best.row, best.col}) : std::nullopt;
+    }
+    static std::optional<float> max(const host::StripedScores<float> &scores)  // pli/mod.rs:158-160
+    {
+        const DenseMatrix<float> &d = scores.matrix();
+        if (d.rows() == 0)
+            return std::nullopt;
+        int found = 0;
+        float v = 0;
+        check(lm_hip_max_f32(d.ptr(), d.rows(), d.stride(), d.columns(), &found, &v));
+        return found ? std::optional<float>(v) : std::nullopt;
+    }
+    // Threshold<f32, C> (dispatch.rs:205; pli/mod.rs:210-221): row-major push order
+    static std::vector<MatrixCoordinates> threshold(const host::StripedScores<float> &scores, float t)
+    {
+        const DenseMatrix<float> &d = scores.matrix();
+        std::vector<MatrixCoordinates> out;
+        if (d.rows() == 0)
+            return out;
+        lm_hip_coords *c = nullptr;
+        size_t n = 0;
+        check(lm_hip_threshold_f32(d.ptr(), d.rows(), d.stride(), d.columns(), t, &c, &n));
+        out.reserve(n);
+        for (size_t i = 0; i < n; ++i)
+            out.push_back(MatrixCoordinates{c[i].row, c[i].col});
+        lm_hip_free(c);
+        return out;
+    }
+};
+
 // ---- Pipeline<A, Hip> --------------------------------------------------------------------------------
 
 template <class A>
