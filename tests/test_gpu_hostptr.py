@@ -355,3 +355,37 @@ def test_score_u8_host_through_the_tile_pipeline():
     want, mi = co.score_rows_u8(s, w, a, b)
     got, orow, omi = host_score_u8(s, w, 5, a, b, saturate=False)
     assert (orow, omi) == (b - a, mi) and np.array_equal(got[:, :32], want[:, :32])
+
+
+def test_host_pointer_fuzz():
+    """160 random shapes through the host-pointer entry points -- column counts 1 ... 40, motif lengths 1 ... 44, both alphabets,
+    row ranges, padded caller rows, -inf / tied weights -- f32 scores, argmax, max and threshold against the oracle, bit for bit."""
+    rng = np.random.default_rng(0xF0221)
+    for case in range(160):
+        k = 21 if rng.random() < 0.25 else 5
+        cols = int(rng.choice([32, 32, 32, 1, 2, 7, 16, 20, 33, 40]))
+        m = int(rng.integers(1, 45))
+        length = int(rng.integers(m, 60_000)) if rng.random() < 0.9 else int(rng.integers(1, m + 1))
+        s = striped(rng, length, cols, k, m)
+        p = random_pssm(rng, m, k, "ties" if rng.random() < 0.3 else "normal")
+        if rng.random() < 0.2:
+            p[rng.integers(0, m), rng.integers(0, k - 1)] = -np.inf
+        a = int(rng.integers(0, s.rows)) if rng.random() < 0.4 else 0
+        b = int(rng.integers(a, s.rows + 1)) if rng.random() < 0.4 else s.rows
+        ost = co.stride(cols, 4) + (8 if rng.random() < 0.3 else 0)
+        want, mi = co.score_rows(s, p, a, b)
+        got, orow, omi = host_score(s, p, k, a, b, out_stride=ost)
+        tag = (case, k, cols, m, length, a, b, ost)
+        assert (orow, omi) == (want.shape[0], mi), tag
+        if want.shape[0] == 0:
+            continue
+        assert np.array_equal(bits(got[:, :cols]), bits(want[:, :cols])), tag
+        assert np.all(got[:, cols:] == 777.0), tag
+        am = host_argmax(got, b - a, ost, cols)
+        wam = co.argmax(want, cols)
+        assert (am[0] if am else None) == wam, tag
+        if wam is not None:
+            assert bits(am[1]) == bits(co.max_(want, cols)), tag
+        finite = want[:, :cols][np.isfinite(want[:, :cols])]
+        t = float(np.quantile(finite, 0.98)) if finite.size else 0.0
+        assert np.array_equal(host_threshold(got, b - a, ost, cols, t), co.threshold(want, cols, t)), tag
