@@ -544,6 +544,11 @@ int lm_hip_max_f32(const float *scores, size_t rows, size_t stride, size_t cols,
                    int *found, float *value);
 int lm_hip_threshold_f32(const float *scores, size_t rows, size_t stride, size_t cols, float t,
                          lm_hip_coords **coords, size_t *n);
+/* Hands back what the host-pointer functions keep between calls: the pinned ring of the tile pipeline (128 MB of
+ * page-locked memory), its device tiles, and the device staging of this thread's lane and of lanes whose threads have
+ * exited.  Contexts and cached PSSM tables stay; the next call sets up again what it needs.  Safe at any time (waits for
+ * a large call in flight); for hosts that score a genome and then sit idle. */
+int lm_hip_host_trim(void);
 
 #ifdef __cplusplus
 }

@@ -134,6 +134,7 @@ SIGNATURES = {
     "lm_hip_argmax_f32": (C.c_int, [_vp, _sz, _sz, _sz, _ip, _cp, _fp]),
     "lm_hip_max_f32": (C.c_int, [_vp, _sz, _sz, _sz, _ip, _fp]),
     "lm_hip_threshold_f32": (C.c_int, [_vp, _sz, _sz, _sz, C.c_float, C.POINTER(_cp), _szp]),
+    "lm_hip_host_trim": (C.c_int, []),
 }
 
 _lib = None

@@ -664,6 +664,50 @@ int lm_hip_score_u8_host(const uint8_t *seq, size_t seq_rows_total, size_t seq_s
     });
 }
 
+// What the host-pointer path keeps between calls -- the pinned ring (128 MB), its device tiles, the staging buffers of
+// lanes whose threads have exited and of the calling thread's own lane -- handed back; the next call sets them up again.
+// Contexts, streams and cached PSSM tables stay.  Waits for a large call in flight on another thread.
+int lm_hip_host_trim(void)
+{
+    return guarded("host_trim", [&]() -> int {
+        {
+            BigPipe &bp = big_pipe();
+            std::lock_guard<std::mutex> pipe(bp.mu);
+            if (bp.device >= 0) {
+                DeviceGuard guard(bp.device);
+                (void)hipStreamSynchronize(bp.s_up);
+                (void)hipStreamSynchronize(bp.s_dn);
+                bp.d_in.release();
+                bp.d_out.release();
+                for (hipEvent_t e : bp.kdone)
+                    (void)hipEventDestroy(e);
+                for (hipEvent_t e : bp.landed)
+                    (void)hipEventDestroy(e);
+                (void)hipStreamDestroy(bp.s_up);
+                (void)hipStreamDestroy(bp.s_dn);
+                (void)hipHostFree(bp.pinned);
+                bp.s_up = bp.s_dn = nullptr;
+                bp.pinned = nullptr;
+                bp.device = -1;
+            }
+        }
+        std::vector<HostLane *> lanes;
+        {
+            std::lock_guard<std::mutex> lock(lanes_mu());
+            lanes = idle_lanes();  // idle: no thread owns them; they stay on the list
+            if (t_lane.lane)
+                lanes.push_back(t_lane.lane);
+            for (HostLane *lane : lanes) {
+                DeviceGuard guard(lane->ctx->device);
+                (void)hipStreamSynchronize(lane->ctx->stream);
+                lane->d_in.release();
+                lane->d_out.release();
+            }
+        }
+        return LM_HIP_OK;
+    });
+}
+
 int lm_hip_argmax_f32(const float *scores, size_t rows, size_t stride, size_t cols, int *found,
                       lm_hip_coords *best, float *value)
 {

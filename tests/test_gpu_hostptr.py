@@ -389,3 +389,34 @@ def test_host_pointer_fuzz():
         finite = want[:, :cols][np.isfinite(want[:, :cols])]
         t = float(np.quantile(finite, 0.98)) if finite.size else 0.0
         assert np.array_equal(host_threshold(got, b - a, ost, cols, t), co.threshold(want, cols, t)), tag
+
+
+def test_host_trim_gives_the_ring_back_and_the_path_still_works():
+    """`lm_hip_host_trim`: after a pipeline-sized call the process holds 128 MB of page-locked ring + device tiles; trimming
+    returns them (device memory visibly), and the next calls -- small and large -- set up again and stay bit-exact."""
+    L = _ffi.lib()
+
+    def device_free_bytes():
+        # hipMemGetInfo of the HIP runtime the library itself is linked to (torch must not be imported after the library
+        # in one process on this image -- README -- so the runtime is asked directly)
+        path = next(line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line)
+        free, total = C.c_size_t(0), C.c_size_t(0)
+        assert C.CDLL(path).hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
+    rng = np.random.default_rng(77)
+    m = 12
+    rows = 262_144 * 3 + 100
+    s = striped(rng, rows * 32 - 9, 32, 5, m)
+    p = random_pssm(rng, m, 5)
+    want = co.aligned_empty((rows, 32), np.float32)
+    co.avx2_score_rows(s, aligned(p), out=want, row_end=rows, threads=8)
+    assert np.array_equal(bits(host_score(s, p, 5, 0, rows)[0]), bits(want))
+    free_before = device_free_bytes()
+    assert L.lm_hip_host_trim() == 0, _ffi.last_error()
+    free_after = device_free_bytes()
+    assert free_after >= free_before + (32 << 20), (free_before, free_after)     # four 8.4 MB score tiles + three symbol tiles
+    assert L.lm_hip_host_trim() == 0                       # idempotent
+    small = striped(rng, 50_000, 32, 5, m)
+    w_small, _ = co.score_rows(small, p)
+    assert np.array_equal(bits(host_score(small, p, 5, 0, small.rows)[0][:, :32]), bits(w_small[:, :32]))
+    assert np.array_equal(bits(host_score(s, p, 5, 0, rows)[0]), bits(want))
