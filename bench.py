@@ -653,6 +653,36 @@ def secondary_configs(pli, dev) -> dict:
     c1.update(hpb.bench_c1())
     c1.update(hpb.bench_block())
     out["c1"] = c1
+
+    # --- the reference's own published benchmark (README.md:102-108): `score` of MX000001 (M = 15) over
+    # the WHOLE E. coli K12 genome, 4 641 652 bp -- AVX2 4.51 ms, Generic 317.7 ms on an i7-10710U, one thread.  The genome
+    # file is absent from the reference mount, so a seeded random stand-in of that length; the same-box AVX2 port beside it.
+    from oracle import c_oracle as co
+    glen = 4_641_652
+    genc = np.random.default_rng(0xEC012).integers(0, 4, glen, dtype=np.uint8)
+    gseq = pli.stripe(lm.EncodedSequence(genc))
+    gseq.configure(pssm)
+    gscores = lm.StripedScores.empty(pli, COLS)
+    pli.set_track_argmax(False)
+    t_res = loop(lambda: (pli.score_into(pssm, gseq, gscores), pli.sync()), reps=300, warm=30)
+    gmat = gseq.matrix()
+    grows = gseq.rows
+    gout = np.zeros((grows, COLS), np.float32)
+    t_host, _ = hpb.loop_us(lambda: hpb.score_f32(gmat, grows, glen, pssm.data, gout), 40, 5)
+    cs = co.Striped(co.aligned_empty(gmat.shape, np.uint8), glen, pssm.data.shape[0] - 1, COLS, 5)
+    cs.data[:] = gmat
+    cp = co.aligned_empty(pssm.data.shape, np.float32)
+    cp[:] = pssm.data
+    cout = co.aligned_empty((grows, COLS), np.float32)
+    t_cpu, _ = hpb.loop_us(lambda: co.avx2_score_rows(cs, cp, out=cout, row_end=grows, threads=1), 10, 2)
+    out["readme_benchmark"] = {
+        "workload": "README.md:102-108 `score` f32 of MX000001 (M = 15) over a whole-E.-coli-sized sequence (4641652 bp, random "
+                    "stand-in), one call",
+        "published_i7_10710U_avx2_ms": 4.511, "published_i7_10710U_generic_ms": 317.7,
+        "resident_score_into_ms": round(t_res * 1e3, 4), "host_pointer_score_f32_ms": round(t_host / 1e3, 4),
+        "same_box_avx2_port_1_thread_ms": round(t_cpu / 1e3, 3),
+        "host_pointer_matches_avx2_port_bitwise": bool(np.array_equal(gout.view(np.uint32), cout.view(np.uint32)))}
+    del gseq, gscores
     pli = pli_main
 
     # --- configs[4]: protein (K = 21) len-12 PSSM x 200 Mres: score() materialised + fused threshold

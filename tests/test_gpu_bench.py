@@ -101,6 +101,8 @@ def test_single_gpu_line_has_every_contract_field():
     # the literal drop-in path rides along: host-pointer loop of dna.rs, Scanner block, the labelled end-to-end figure
     assert ex["c1"]["host_pointer_us_per_iter"] > 0 and ex["c1"]["avx2_port_1_thread_us_per_iter"] > 0
     assert ex["c1"]["scores_match_avx2_port_bitwise"] is True and ex["c1"]["scanner_block_us"] > 0
+    rb = ex["readme_benchmark"]                             # the reference's published benchmark at its own size
+    assert rb["host_pointer_matches_avx2_port_bitwise"] is True and 0 < rb["resident_score_into_ms"] < rb["host_pointer_score_f32_ms"]
     e2e = out["extras"]["end_to_end"]
     assert e2e["matches_resident_scores"] is True and 0 < e2e["frac_of_d2h_floor"] <= 1.05 and e2e["gpos"] > 0
     assert cb["gpu_matches_generic_bitwise"] is True and cb["generic_single_thread_gpos"] > 0
