@@ -511,10 +511,42 @@ static void test_dispatch_hip_on_host_matrices(size_t columns)
     CHECK(threw);
 }
 
+// lightmotif/tests/argmax.rs:23-52 with `Dispatch::Hip`: a tenth of an E.-coli-sized sequence (random stand-in, the PRODORIC
+// site planted once so that the maximum is unique, which is all the reference's test exercises), scores from the back-end,
+// the expected cell from `unstripe().max_by(..)` on the host.
+static void test_argmax_property_dispatch_hip(size_t columns)
+{
+    const size_t n = 464165;
+    std::string seq(n, 'A');
+    unsigned long long z = 0x5EED0003ull;
+    for (size_t i = 0; i < n; ++i) {
+        z = z * 6364136223846793005ull + 1442695040888963407ull;
+        seq[i] = "ACGT"[(z >> 33) & 3];
+    }
+    seq.replace(391677, 15, "GTTGACCTTATCAAC");
+    auto striped = host::StripedSequence<Dna>::stripe(EncodedSequence<Dna>::encode(seq), columns);
+    const auto pssm = golden_pssm();
+    striped.configure(pssm);
+    const auto scores = HipDispatch::score(pssm, striped);
+    const auto flat = scores.unstripe();
+    CHECK(flat.size() == n - 15 + 1);
+    size_t best = 0;
+    for (size_t i = 1; i < flat.size(); ++i)
+        if (!(flat[i] < flat[best]))   // max_by keeps the last of equal elements
+            best = i;
+    const auto m = HipDispatch::argmax(scores);
+    CHECK(m.has_value() && scores.offset(*m) == best && best == 391677);
+    CHECK(m.has_value() && scores.matrix()(m->row, m->col) == flat[best]);
+    const auto top = HipDispatch::max(scores);
+    CHECK(top.has_value() && *top == flat[best]);
+}
+
 int main()
 {
-    for (size_t columns : {32u, 1u, 16u})
+    for (size_t columns : {32u, 1u, 16u}) {
         test_dispatch_hip_on_host_matrices(columns);
+        test_argmax_property_dispatch_hip(columns);
+    }
     Pipeline<Dna> pli = Pipeline<Dna>::hip();
     for (size_t columns : {32u, 1u, 16u}) {   // mod generic: U32, U1 (+ sse2's U16), tests/dna.rs:201-233
         test_score_rows(pli, columns);
