@@ -98,6 +98,13 @@ void lm_hip_free(void *p);
  * locked memory; a pointer may be NULL (not all three). */
 int lm_hip_result_pool_info(size_t *pinned_idle, size_t *pinned_in_use, size_t *budget);
 
+/* Diagnostic: the shader clock (MHz) the device sustains over the next `window_us` microseconds, measured by one
+ * mostly-sleeping wavefront on a high-priority stream of its own (s_memtime ticks per s_memrealtime tick) -- call it from
+ * a second host thread while the kernels of interest run to learn the clock THEY get (the part clocks to its power
+ * budget; a roofline priced at the 2.4 GHz of the data sheet is not what an LDS- or VALU-bound kernel can reach).
+ * No reference counterpart; bench.py reports it next to every LDS fraction. */
+int lm_hip_device_clock_mhz(int device, unsigned window_us, double *mhz);
+
 /* DenseMatrix::stride (dense.rs:126-128) for x86-64 hosts: elements per row. */
 size_t lm_hip_stride(size_t cols, size_t elem_size);
 
@@ -521,9 +528,13 @@ int lm_hip_merge_threshold(lm_hip_ctx *ctx, lm_hip_comm *comm, const lm_hip_coor
 
 /* Exactly what a Rust shim can obtain from &StripedSequence / &DenseMatrix / &mut StripedScores: pageable host
  * matrices in, pageable host matrices out (csrc/hostptr.hip).  No context argument: every calling host thread is given
- * a lane of its own (context + stream, persistent staging, a cache of device PSSM tables keyed on the weights) on device
- * 0 or $LM_HIP_DEVICE, so threads overlap; large calls (>= 96 MB of scores) run as a tile pipeline over a process-wide
- * ring of pinned buffers and take turns on it.  1 B per position travels up and 4 B down per lm_hip_score_f32 call. */
+ * a lane of its own (context + stream, persistent staging, a cache of device PSSM tables keyed on the weights), so
+ * threads overlap.  Lanes are dealt round-robin over the usable devices -- the reference's parallel axis is the CLI's
+ * worker threads over (motif, sequence) jobs (lightmotif-cli main.rs:240-378), which then spread over the GPUs and PCIe
+ * links of a node with no change to the caller; $LM_HIP_DEVICE (read once per process) puts every lane on one ordinal,
+ * lm_hip_host_bind_thread one thread.  Large calls (>= 96 MB of scores) run as a tile pipeline over a per-device ring of
+ * pinned buffers (allocated on, and served by helper threads bound to, the GPU's NUMA node) and take turns on it.
+ * 1 B per position travels up and 4 B down per lm_hip_score_f32 call. */
 int lm_hip_score_f32(const uint8_t *seq, size_t seq_rows_total, size_t seq_stride, size_t cols,
                      size_t wrap, size_t length,
                      const float *pssm, size_t m, size_t pssm_stride, size_t k,
@@ -544,11 +555,20 @@ int lm_hip_max_f32(const float *scores, size_t rows, size_t stride, size_t cols,
                    int *found, float *value);
 int lm_hip_threshold_f32(const float *scores, size_t rows, size_t stride, size_t cols, float t,
                          lm_hip_coords **coords, size_t *n);
-/* Hands back what the host-pointer functions keep between calls: the pinned ring of the tile pipeline (128 MB of
- * page-locked memory), its device tiles, and the device staging of this thread's lane and of lanes whose threads have
- * exited.  Contexts and cached PSSM tables stay; the next call sets up again what it needs.  Safe at any time (waits for
+/* Hands back what the host-pointer functions keep between calls: the pinned rings of the tile pipelines (128 MB of
+ * page-locked memory per device used), their device tiles, and the device staging AND reduction scratch of this thread's
+ * lane and of lanes whose threads have exited; lanes of other live threads hand theirs back at the end of their next
+ * call.  Contexts and cached PSSM tables stay; the next call sets up again what it needs.  Safe at any time (waits for
  * a large call in flight); for hosts that score a genome and then sit idle. */
 int lm_hip_host_trim(void);
+/* Puts the calling thread's host-pointer lane on `device` (a HIP ordinal from lm_hip_device_ordinal) from its next call
+ * on; -1 = back to the automatic placement ($LM_HIP_DEVICE, else round-robin).  For hosts that place their worker
+ * threads themselves (one thread per GPU, threads pinned next to their GPU). */
+int lm_hip_host_bind_thread(int device);
+/* Where the calling thread's lane is (creates it if need be): its device ordinal, the NUMA node the platform reports for
+ * that GPU (-1: none reported) and how many CPUs of that node the pipeline's helper threads are confined to (0: unbound).
+ * Any pointer may be NULL (not all three). */
+int lm_hip_host_lane_info(int *device, int *numa_node, int *helper_cpus);
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,7 @@ SIGNATURES = {
     "lm_hip_device_ordinal": (C.c_int, [C.c_int, _ip]),
     "lm_hip_free": (None, [_vp]),
     "lm_hip_result_pool_info": (C.c_int, [_szp, _szp, _szp]),
+    "lm_hip_device_clock_mhz": (C.c_int, [C.c_int, C.c_uint, C.POINTER(C.c_double)]),
     "lm_hip_stride": (_sz, [_sz, _sz]),
     "lm_hip_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "lm_hip_ctx_create_on_stream": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
@@ -135,6 +136,8 @@ SIGNATURES = {
     "lm_hip_max_f32": (C.c_int, [_vp, _sz, _sz, _sz, _ip, _fp]),
     "lm_hip_threshold_f32": (C.c_int, [_vp, _sz, _sz, _sz, C.c_float, C.POINTER(_cp), _szp]),
     "lm_hip_host_trim": (C.c_int, []),
+    "lm_hip_host_bind_thread": (C.c_int, [C.c_int]),
+    "lm_hip_host_lane_info": (C.c_int, [_ip, _ip, _ip]),
 }
 
 _lib = None

@@ -258,6 +258,73 @@ size_t lm_hip_stride(size_t cols, size_t elem_size)
     return bytes / elem_size;
 }
 
+// ---- shader clock ------------------------------------------------------------------------
+
+// One wavefront that mostly sleeps: the shader clock counter (s_memtime ticks at the clock the SIMDs run at,
+// MI355X_MICROARCH.md "s_memtime tick = shader cycle") against the constant-rate counter (s_memrealtime) over a window.
+// Launched on a stream of its own beside the kernels under measurement it reports the clock THEY run at: the part
+// clocks to its power budget, so the 2.4 GHz of the data sheet is not what an LDS- or VALU-bound kernel sustains.
+namespace lm {
+__global__ void clock_probe_kernel(unsigned long long window_ticks, unsigned long long *out)
+{
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < window_ticks) {
+        __builtin_amdgcn_s_sleep(127);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = r1 - r0;
+    }
+}
+}  // namespace lm
+
+int lm_hip_device_clock_mhz(int device, unsigned window_us, double *mhz)
+{
+    if (!mhz)
+        return fail(LM_HIP_ERR_BAD_ARGS, "device_clock_mhz: null output");
+    *mhz = 0.0;
+    if (window_us == 0 || window_us > 2000000u)
+        return fail(LM_HIP_ERR_BAD_ARGS, "device_clock_mhz: window of %u us (1 ... 2 000 000)", window_us);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n)
+        return fail(LM_HIP_ERR_NO_DEVICE, "device %d out of range (%d devices)", device, n);
+    DeviceGuard guard(device);
+    int wall_khz = 0;
+    LM_HIP_TRY(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, device));
+    if (wall_khz <= 0)
+        return fail(LM_HIP_ERR_HIP, "device_clock_mhz: the device reports no constant-rate counter");
+    int lo = 0, hi = 0;
+    hipStream_t stream = nullptr;
+    unsigned long long *rec = nullptr;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // `hi` = the numerically lowest = the greatest priority
+    hipError_t e = hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi);
+    if (e == hipSuccess)
+        e = hipHostMalloc(reinterpret_cast<void **>(&rec), 2 * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e == hipSuccess) {
+        rec[0] = rec[1] = 0;
+        hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, stream,
+                           (unsigned long long)window_us * (unsigned long long)wall_khz / 1000ull, rec);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(stream);
+    const unsigned long long ticks = rec ? rec[0] : 0, ref = rec ? rec[1] : 0;
+    if (rec)
+        (void)hipHostFree(rec);
+    if (stream)
+        (void)hipStreamDestroy(stream);
+    if (e != hipSuccess)
+        return fail(LM_HIP_ERR_HIP, "device_clock_mhz: %s", hipGetErrorString(e));
+    if (ref == 0)
+        return fail(LM_HIP_ERR_HIP, "device_clock_mhz: the constant-rate counter did not advance");
+    *mhz = (double)ticks / (double)ref * (double)wall_khz / 1000.0;
+    return LM_HIP_OK;
+}
+
 // ---- context ----------------------------------------------------------------------------
 
 // Options of a context: each selects an alternative path that gives the SAME results (the GPU suite sets several of them

@@ -13,7 +13,11 @@
 //    buffers that persist between calls, and a small cache of device-side PSSM tables keyed on the weights -- so the
 //    CLI's worker threads (main.rs:270) and GIL-released Python threads (lightmotif-py lib.rs:865) overlap instead of
 //    queueing on one context, and a loop over one motif (lightmotif-bench dna.rs:104-107) builds its tables once.
-//    A lane whose thread has exited is handed to the next new thread.
+//    A lane whose thread has exited is handed to the next new thread.  Lanes are dealt ROUND-ROBIN over the usable
+//    devices of the process (the reference's own parallel axis is the CLI's worker threads over (motif, sequence) jobs,
+//    lightmotif-cli main.rs:240-378, 502-524: eight threads on an 8-GPU node then use eight GPUs and eight PCIe links
+//    with no change to the caller); $LM_HIP_DEVICE (read once) pins every lane to one ordinal, lm_hip_host_bind_thread
+//    one thread.
 //  * SMALL calls (the reference's own bench: 464 165 positions; a Scanner block: 256 rows) are latency-bound:
 //    one pageable copy up, one kernel, one pageable copy down, one synchronisation; no allocation, no table build.
 //    The tiniest (<= 128 KB each way) skip the copy commands altogether: the kernel reads the symbols from and writes
@@ -23,15 +27,23 @@
 //    way back is the long one (4 B per position): the runtime's pageable D2H reaches 48 GB/s, a copy into pinned
 //    memory 56.6 GB/s -- so tiles land in a ring of four pinned 32 MB buffers and four copier threads move them into
 //    the caller's matrix while the next tiles are in flight (measured: hostpipe_bench, profiles/r04_hostpipe_bench.txt).
-//    The ring, its streams and the device tile buffers exist once per process: large calls of several threads take
-//    turns on it (the link is the bound; side by side they only get in each other's way).
+//    The ring, its streams and the device tile buffers exist once per DEVICE: large calls of several threads on one
+//    device take turns on it (the link is the bound; side by side they only get in each other's way), calls on
+//    different devices run side by side.  The ring is allocated, and the uploader / copier threads run, on the CPUs of
+//    the GPU's NUMA node (/sys/bus/pci/devices/<bdf>/numa_node), inside the affinity mask the process already has.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cctype>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <thread>
+
+#include <pthread.h>
+#include <sched.h>
 
 #include "lm_internal.hpp"
 
@@ -79,11 +91,16 @@ struct CachedPssm {
 
 struct HostLane {
     lm_hip_ctx *ctx = nullptr;
+    int device = -1;
     Scratch d_in, d_out;
     uint8_t *zc = nullptr;  // 2 x kZeroCopyBytes, pinned and device-visible
     std::vector<CachedPssm> pssms;
     uint64_t stamp = 0;
+    uint64_t trim_epoch = 0;  // g_trim_epoch as of this lane's last trim
 };
+
+// lm_hip_host_trim bumps it: a lane that belongs to a live thread hands its staging back at the end of its next call
+std::atomic<uint64_t> g_trim_epoch{0};
 
 // process lifetime (never destroyed: host threads may still be inside the library when the process exits)
 std::mutex &lanes_mu()
@@ -99,6 +116,7 @@ std::vector<HostLane *> &idle_lanes()
 
 struct LaneRef {
     HostLane *lane = nullptr;
+    int want_device = -1;  // lm_hip_host_bind_thread
     ~LaneRef()
     {
         if (lane) {  // the thread is gone; its lane (stream idle: every call synchronises) serves the next one
@@ -109,20 +127,73 @@ struct LaneRef {
 };
 thread_local LaneRef t_lane;
 
+// $LM_HIP_DEVICE, read ONCE per process: every lane on that ordinal (-1: not set)
+int env_device()
+{
+    static const int dev = [] {
+        const char *e = getenv("LM_HIP_DEVICE");
+        return e && *e ? atoi(e) : -1;
+    }();
+    return dev;
+}
+
+// HIP ordinals of the usable (gfx950) devices, in ordinal order
+const std::vector<int> &usable_devices()
+{
+    static const std::vector<int> *list = [] {
+        auto *v = new std::vector<int>();
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess)
+            n = 0;
+        for (int d = 0; d < n; ++d) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, d) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0)
+                v->push_back(d);
+        }
+        return v;
+    }();
+    return *list;
+}
+
+// Device of a NEW lane: the thread's binding, else $LM_HIP_DEVICE, else the next usable device in turn.
+int pick_device(int *out)
+{
+    static std::atomic<unsigned> next{0};
+    if (t_lane.want_device >= 0)
+        *out = t_lane.want_device;
+    else if (env_device() >= 0)
+        *out = env_device();
+    else {
+        const std::vector<int> &devs = usable_devices();
+        if (devs.empty())
+            return fail(LM_HIP_ERR_NO_DEVICE, "no gfx950 device available");
+        *out = devs[next.fetch_add(1, std::memory_order_relaxed) % devs.size()];
+    }
+    return LM_HIP_OK;
+}
+
 int acquire_lane(HostLane **out)
 {
+    const int demanded = t_lane.want_device >= 0 ? t_lane.want_device : env_device();
+    if (t_lane.lane && demanded >= 0 && t_lane.lane->device != demanded) {  // re-bound: this lane serves someone else
+        std::lock_guard<std::mutex> lock(lanes_mu());
+        idle_lanes().push_back(t_lane.lane);
+        t_lane.lane = nullptr;
+    }
     if (!t_lane.lane) {
         {
             std::lock_guard<std::mutex> lock(lanes_mu());
-            if (!idle_lanes().empty()) {
-                t_lane.lane = idle_lanes().back();
-                idle_lanes().pop_back();
-            }
+            std::vector<HostLane *> &idle = idle_lanes();
+            for (size_t i = idle.size(); i-- > 0;)
+                if (demanded < 0 || idle[i]->device == demanded) {
+                    t_lane.lane = idle[i];
+                    idle.erase(idle.begin() + (long)i);
+                    break;
+                }
         }
         if (!t_lane.lane) {
             int dev = 0;
-            if (const char *e = getenv("LM_HIP_DEVICE"))
-                dev = atoi(e);
+            LM_TRY(pick_device(&dev));
             lm_hip_ctx *ctx = nullptr;
             LM_TRY(lm_hip_ctx_create(dev, &ctx));
             HostLane *lane = new (std::nothrow) HostLane();
@@ -131,6 +202,8 @@ int acquire_lane(HostLane **out)
                 return fail(LM_HIP_ERR_OOM, "out of host memory");
             }
             lane->ctx = ctx;
+            lane->device = dev;
+            lane->trim_epoch = g_trim_epoch.load(std::memory_order_acquire);
             DeviceGuard guard(ctx->device);
             if (hipHostMalloc(reinterpret_cast<void **>(&lane->zc), 2 * kZeroCopyBytes, hipHostMallocDefault) != hipSuccess) {
                 (void)hipGetLastError();
@@ -141,6 +214,101 @@ int acquire_lane(HostLane **out)
     }
     *out = t_lane.lane;
     return LM_HIP_OK;
+}
+
+// ---- NUMA placement of the pipeline's helper threads and its pinned ring ------------------------------------------------
+
+struct NodeCpus {
+    int node = -1;
+    bool valid = false;  // `set` = the node's CPUs inside the process's own affinity mask, non-empty
+    cpu_set_t set;
+};
+
+// "0-63,128-191" -> cpu set
+bool parse_cpulist(const char *text, cpu_set_t *set)
+{
+    CPU_ZERO(set);
+    bool any = false;
+    const char *p = text;
+    while (*p) {
+        char *end = nullptr;
+        const long a = strtol(p, &end, 10);
+        if (end == p)
+            break;
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            b = strtol(p + 1, &end, 10);
+            if (end == p + 1)
+                break;
+            p = end;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+            if (c >= 0) {
+                CPU_SET((int)c, set);
+                any = true;
+            }
+        if (*p == ',')
+            ++p;
+        else
+            break;
+    }
+    return any;
+}
+
+NodeCpus probe_node(int device)
+{
+    NodeCpus out;
+    CPU_ZERO(&out.set);
+    char bdf[64] = "";
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return out;
+    }
+    for (char *c = bdf; *c; ++c)
+        *c = (char)tolower((unsigned char)*c);
+    char path[160], text[4096] = "";
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+    FILE *f = fopen(path, "r");
+    if (!f)
+        return out;
+    if (fscanf(f, "%d", &out.node) != 1)
+        out.node = -1;
+    fclose(f);
+    if (out.node < 0)
+        return out;  // the platform reports no affinity (single node, or a VM): nothing to bind to
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", out.node);
+    f = fopen(path, "r");
+    if (!f)
+        return out;
+    const bool got = fgets(text, sizeof text, f) != nullptr;
+    fclose(f);
+    cpu_set_t node_set, mine;
+    if (!got || !parse_cpulist(text, &node_set) || sched_getaffinity(0, sizeof mine, &mine) != 0)
+        return out;
+    CPU_AND(&out.set, &node_set, &mine);  // never outside what the process was given (taskset, cgroup cpusets)
+    out.valid = CPU_COUNT(&out.set) > 0;
+    return out;
+}
+
+const NodeCpus &device_node(int device)
+{
+    static std::mutex mu;
+    static std::vector<NodeCpus *> *cache = new std::vector<NodeCpus *>();
+    std::lock_guard<std::mutex> lock(mu);
+    if ((size_t)device >= cache->size())
+        cache->resize((size_t)device + 1, nullptr);
+    if (!(*cache)[(size_t)device])
+        (*cache)[(size_t)device] = new NodeCpus(probe_node(device));
+    return *(*cache)[(size_t)device];
+}
+
+// helper threads only (never the caller's own thread)
+void bind_this_thread_to_node(int device)
+{
+    const NodeCpus &n = device_node(device);
+    if (n.valid)
+        (void)pthread_setaffinity_np(pthread_self(), sizeof n.set, &n.set);
 }
 
 uint64_t hash_weights(const float *w, size_t m, size_t stride, size_t k)
@@ -196,6 +364,25 @@ void trim(Scratch &s)
         s.release();
 }
 
+// End of a call on `lane` (its stream is idle): staging above the keep threshold goes back; after an lm_hip_host_trim on
+// another thread, everything does.
+void lane_trim(HostLane *lane)
+{
+    const uint64_t epoch = g_trim_epoch.load(std::memory_order_acquire);
+    if (lane->trim_epoch != epoch) {
+        lane->trim_epoch = epoch;
+        lane->d_in.release();
+        lane->d_out.release();
+        lane->ctx->scratch.release();
+        lane->ctx->scratch2.release();
+        lane->ctx->chunk_scores.release();
+        lane->ctx->scan_buf.release();
+        return;
+    }
+    trim(lane->d_in);
+    trim(lane->d_out);
+}
+
 void copy_rows(char *dst, size_t dst_pitch, const char *src, size_t src_pitch, size_t width, size_t nrows)
 {
     if (dst_pitch == width && src_pitch == width) {
@@ -217,18 +404,34 @@ struct BigPipe {
     char *pinned = nullptr;  // out_slots x tile_bytes
 };
 
-BigPipe &big_pipe()
+// one per device (process lifetime)
+std::mutex &pipes_mu()
 {
-    static BigPipe *bp = new BigPipe();
-    return *bp;
+    static std::mutex *mu = new std::mutex();
+    return *mu;
+}
+std::vector<BigPipe *> &pipes()
+{
+    static std::vector<BigPipe *> *v = new std::vector<BigPipe *>();
+    return *v;
+}
+BigPipe &big_pipe(int device)
+{
+    std::lock_guard<std::mutex> lock(pipes_mu());
+    std::vector<BigPipe *> &v = pipes();
+    if ((size_t)device >= v.size())
+        v.resize((size_t)device + 1, nullptr);
+    if (!v[(size_t)device])
+        v[(size_t)device] = new BigPipe();
+    return *v[(size_t)device];
 }
 
 int pipe_prepare(BigPipe &bp, int device)
 {
     if (bp.device == device)
         return LM_HIP_OK;
-    if (bp.device >= 0)
-        return fail(LM_HIP_ERR_BAD_ARGS, "host-pointer calls use one device per process");
+    if (bp.device >= 0)  // (cannot happen: one pipe per device) -- the caller falls back to pieces on its own lane
+        return LM_HIP_ERR_CAPACITY;
     hipStream_t up = nullptr, dn = nullptr;
     hipEvent_t ev[kInSlots + kMaxOutSlots] = {};
     char *pin = nullptr;
@@ -237,8 +440,28 @@ int pipe_prepare(BigPipe &bp, int device)
         e = hipStreamCreateWithFlags(&dn, hipStreamNonBlocking);
     for (int i = 0; i < kInSlots + kMaxOutSlots && e == hipSuccess; ++i)
         e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
-    if (e == hipSuccess)
-        e = hipHostMalloc(reinterpret_cast<void **>(&pin), (size_t)pipe_shape().out_slots * pipe_shape().tile_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) {
+        // the ring's pages come from the node of the thread that allocates them (first touch under the default policy):
+        // allocate from a thread that sits on the GPU's node, so the DMA writes and the copiers' reads stay on one socket
+        const size_t bytes = (size_t)pipe_shape().out_slots * pipe_shape().tile_bytes;
+        auto alloc = [&] {
+            if (hipSetDevice(device) != hipSuccess) {
+                e = hipGetLastError();
+                return;
+            }
+            bind_this_thread_to_node(device);
+            e = hipHostMalloc(reinterpret_cast<void **>(&pin), bytes, hipHostMallocDefault);
+        };
+        if (device_node(device).valid) {
+            try {
+                std::thread(alloc).join();
+            } catch (const std::exception &) {
+                alloc();  // no thread to be had: from here, wherever this thread runs
+            }
+        } else {
+            e = hipHostMalloc(reinterpret_cast<void **>(&pin), bytes, hipHostMallocDefault);
+        }
+    }
     if (e != hipSuccess) {  // nothing half-made is kept
         for (hipEvent_t x : ev)
             if (x)
@@ -326,6 +549,7 @@ int run_pipeline(lm_hip_ctx *ctx, BigPipe &bp, const TileJob &job)
     auto upload_loop = [&] {
         if (hipSetDevice(device) != hipSuccess)
             return raise(LM_HIP_ERR_HIP, "hipSetDevice", hipGetLastError());
+        bind_this_thread_to_node(device);
         for (size_t t = 0; t < n; ++t) {
             hipError_t e = hipSuccess;
             {   // input slot t % kInSlots was read by tile t - kInSlots: its kernel must have been launched ...
@@ -353,6 +577,7 @@ int run_pipeline(lm_hip_ctx *ctx, BigPipe &bp, const TileJob &job)
     auto copy_loop = [&](int j) {
         if (hipSetDevice(device) != hipSuccess)
             return raise(LM_HIP_ERR_HIP, "hipSetDevice", hipGetLastError());
+        bind_this_thread_to_node(device);
         for (size_t t = 0; t < n; ++t) {
             const int slot = (int)(t % (size_t)out_slots);
             {
@@ -541,7 +766,7 @@ int score_call(HostLane *lane, const ScoreCall &c)
     if (c.nrows * c.cols * c.elem >= kPipeMinOutBytes) {
         // link-bound: large calls of several threads take turns on the ring (run side by side through the runtime's
         // pageable copies they were 2.2 x slower than one after the other -- profiles/r04_host_pointer.json)
-        BigPipe &bp = big_pipe();
+        BigPipe &bp = big_pipe(ctx->device);
         std::lock_guard<std::mutex> pipe(bp.mu);
         st = score_pipelined(lane, bp, c);
     }
@@ -552,8 +777,7 @@ int score_call(HostLane *lane, const ScoreCall &c)
             st = score_piece(lane, c, r0, std::min(c.nrows, r0 + piece));
         if (st != LM_HIP_OK)
             (void)hipStreamSynchronize(ctx->stream);
-        trim(lane->d_in);
-        trim(lane->d_out);
+        lane_trim(lane);
     }
     return st;
 }
@@ -670,8 +894,15 @@ int lm_hip_score_u8_host(const uint8_t *seq, size_t seq_rows_total, size_t seq_s
 int lm_hip_host_trim(void)
 {
     return guarded("host_trim", [&]() -> int {
+        std::vector<BigPipe *> all;
         {
-            BigPipe &bp = big_pipe();
+            std::lock_guard<std::mutex> lock(pipes_mu());
+            all = pipes();
+        }
+        for (BigPipe *pb : all) {
+            if (!pb)
+                continue;
+            BigPipe &bp = *pb;
             std::lock_guard<std::mutex> pipe(bp.mu);
             if (bp.device >= 0) {
                 DeviceGuard guard(bp.device);
@@ -702,8 +933,44 @@ int lm_hip_host_trim(void)
                 (void)hipStreamSynchronize(lane->ctx->stream);
                 lane->d_in.release();
                 lane->d_out.release();
+                // the lane context's own scratch: reduction partials / hit lists, the chunk of a sliced u8 store
+                lane->ctx->scratch.release();
+                lane->ctx->scratch2.release();
+                lane->ctx->chunk_scores.release();
+                lane->ctx->scan_buf.release();
             }
         }
+        // lanes of threads that are still alive cannot be touched from here (their streams may be busy): they trim
+        // themselves at the end of their next call
+        g_trim_epoch.fetch_add(1, std::memory_order_release);
+        return LM_HIP_OK;
+    });
+}
+
+int lm_hip_host_bind_thread(int device)
+{
+    return guarded("host_bind_thread", [&]() -> int {
+        if (device >= 0) {
+            const std::vector<int> &devs = usable_devices();
+            if (std::find(devs.begin(), devs.end(), device) == devs.end())
+                return fail(LM_HIP_ERR_NO_DEVICE, "host_bind_thread: %d is not a usable (gfx950) device ordinal", device);
+        }
+        t_lane.want_device = device < 0 ? -1 : device;  // takes effect at the thread's next host-pointer call
+        return LM_HIP_OK;
+    });
+}
+
+int lm_hip_host_lane_info(int *device, int *numa_node, int *helper_cpus)
+{
+    return guarded("host_lane_info", [&]() -> int {
+        if (!device && !numa_node && !helper_cpus)
+            return fail(LM_HIP_ERR_BAD_ARGS, "host_lane_info: no output asked for");
+        HostLane *lane = nullptr;
+        LM_TRY(acquire_lane(&lane));
+        const NodeCpus &n = device_node(lane->device);
+        if (device) *device = lane->device;
+        if (numa_node) *numa_node = n.node;
+        if (helper_cpus) *helper_cpus = n.valid ? CPU_COUNT(&n.set) : 0;
         return LM_HIP_OK;
     });
 }
@@ -723,6 +990,7 @@ int lm_hip_argmax_f32(const float *scores, size_t rows, size_t stride, size_t co
         LM_TRY(acquire_lane(&lane));
         lm_hip_ctx *ctx = lane->ctx;  // the lane is this thread's alone: nothing to lock
         DeviceGuard guard(ctx->device);
+        ScratchTrim scratch_trim(ctx);
         const float *d = nullptr;
         ArgmaxRecord rec{};
         int st = stage_scores(lane, scores, rows, stride, cols, &d);
@@ -730,7 +998,7 @@ int lm_hip_argmax_f32(const float *scores, size_t rows, size_t stride, size_t co
             st = launch_argmax(ctx, d, rows, cols, cols, 1, &rec);
         if (st != LM_HIP_OK)
             (void)hipStreamSynchronize(ctx->stream);
-        trim(lane->d_in);
+        lane_trim(lane);
         if (st != LM_HIP_OK)
             return st;
         *found = rec.found;
@@ -768,13 +1036,15 @@ int lm_hip_threshold_f32(const float *scores, size_t rows, size_t stride, size_t
         LM_TRY(acquire_lane(&lane));
         lm_hip_ctx *ctx = lane->ctx;  // the lane is this thread's alone: nothing to lock
         DeviceGuard guard(ctx->device);
+        // a dense list grows ctx->scratch / scratch2 to 16 B per hit: handed back when the call ends (score_api.hip does the same)
+        ScratchTrim scratch_trim(ctx);
         const float *d = nullptr;
         int st = stage_scores(lane, scores, rows, stride, cols, &d);
         if (st == LM_HIP_OK)
             st = launch_threshold(ctx, d, rows, cols, cols, t, coords, n);
         if (st != LM_HIP_OK)
             (void)hipStreamSynchronize(ctx->stream);
-        trim(lane->d_in);
+        lane_trim(lane);
         return st;
     });
 }

@@ -92,6 +92,8 @@ def avx2() -> C.CDLL:
         L.lma_score_rows_f32_mt.restype = C.c_int
         L.lma_score_rows_f32_mt.argtypes = [_u8p, _sz, _sz, _sz, _f32p, _sz, _sz,
                                             _sz, _sz, _sz, _f32p, _sz, C.c_int]
+        L.lma_score_rows_u8.restype = C.c_int
+        L.lma_score_rows_u8.argtypes = [_u8p, _sz, _sz, _sz, _u8p, _sz, _sz, _sz, _sz, _u8p, _sz]
         L.lma_argmax_f32.restype = C.c_int
         L.lma_argmax_f32.argtypes = [_f32p, _sz, _sz, _sz, _szp, _szp]
         _avx = L
@@ -305,3 +307,22 @@ def avx2_argmax(scores: np.ndarray, max_index: int):
     if ok < 0:
         raise OverflowError("more than u32::MAX positions")
     return (int(r.value), int(c.value)) if ok else None
+
+
+def avx2_score_rows_u8(s: Striped, weights: np.ndarray, out: np.ndarray | None = None,
+                       row_begin: int | None = None, row_end: int | None = None) -> np.ndarray:
+    """avx2.rs:292-347 (what Dispatch::Avx2 runs for Score<u8, Dna>): saturating sums.  `weights`: (M, stride >= 16) u8,
+    16-byte aligned rows (a DenseMatrix<u8, K> has 32-byte rows)."""
+    assert s.cols == 32 and weights.dtype == np.uint8 and weights.shape[1] >= 16
+    a = 0 if row_begin is None else row_begin
+    b = s.rows if row_end is None else row_end
+    assert weights.ctypes.data % 16 == 0 and weights.strides[0] % 16 == 0 and s.data.ctypes.data % 32 == 0
+    if out is None:
+        out = aligned_empty((max(b - a, 0), 32), np.uint8)
+    rc = avx2().lma_score_rows_u8(_p8(s.data), s.stride, s.wrap, s.length, _p8(weights), weights.shape[0],
+                                  weights.strides[0], a, b, _p8(out), out.strides[0])
+    if rc == 2:
+        raise RuntimeError(f"not enough wrapping rows for motif of length {weights.shape[0]}")
+    if s.length < weights.shape[0] or a >= b:
+        return out[:0]
+    return out

@@ -8,6 +8,8 @@
  *   score : lightmotif/src/pli/platform/avx2.rs:104-199 (score_f32_avx2_permute,
  *           K <= 8) and :204-290 (score_f32_avx2_gather, any K)
  *   argmax: lightmotif/src/pli/platform/avx2.rs:351-426 (argmax_f32_avx2)
+ *   u8    : lightmotif/src/pli/platform/avx2.rs:292-347 (score_u8_avx2_shuffle: what
+ *           `Dispatch::Avx2` runs for Score<u8, Dna> -- dispatch.rs:124 -- i.e. per Scanner block)
  * The reference core crate is single-threaded; the *_mt entry points split
  * the row range across pthreads using the score_rows_into row-range contract
  * (pli/mod.rs:72-78), which is how a caller would parallelise it.
@@ -198,4 +200,37 @@ int lma_argmax_f32(const float *scores, size_t rows, size_t stride,
     *row = best_row;
     *col = best_col;
     return 1;
+}
+
+/* avx2.rs:292-347 (score_u8_avx2_shuffle) behind the pre-checks of avx2.rs:921-931: per output row the M sequence
+ * rows are loaded (32 symbol bytes), each looks its weights up with one in-register byte shuffle of the (broadcast)
+ * 16-byte PSSM row, saturating byte adds, non-temporal store.  weights: M rows of `wstride` bytes (>= 16, 16-byte
+ * aligned), out: rows of `out_stride` bytes (32-byte aligned).  Returns 0 ok, 2 when wrap < m-1. */
+int lma_score_rows_u8(const uint8_t *seq, size_t seq_stride, size_t wrap, size_t length,
+                      const uint8_t *weights, size_t m, size_t wstride, size_t row_begin,
+                      size_t row_end, uint8_t *out, size_t out_stride)
+{
+    if (wrap + 1 < m)
+        return 2;
+    if (length < m || row_begin >= row_end)
+        return 0;
+    uint8_t *rowptr = out;
+    const uint8_t *seqptr = seq + row_begin * seq_stride;
+    for (size_t r = row_begin; r < row_end; r++) {
+        __m256i s = _mm256_setzero_si256();
+        const uint8_t *seqrow = seqptr, *psmrow = weights;
+        for (size_t j = 0; j < m; j++) {
+            const __m256i x = _mm256_load_si256((const __m256i *)seqrow);
+            const __m256i t = _mm256_castps_si256(_mm256_broadcast_ps((const __m128 *)psmrow));
+            const __m256i y = _mm256_shuffle_epi8(t, x);
+            s = _mm256_adds_epu8(s, y);
+            seqrow += seq_stride;
+            psmrow += wstride;
+        }
+        _mm256_stream_si256((__m256i *)rowptr, s);
+        rowptr += out_stride;
+        seqptr += seq_stride;
+    }
+    _mm_sfence();
+    return 0;
 }
