@@ -764,8 +764,6 @@ def main() -> None:
                     help="N > 1: bound on every collective's wait (process group and the C ABI's communicator)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip extras.configs (configs[0], [2], [4] of BASELINE.json after the timed region)")
-    ap.add_argument("--ab", action="store_true",
-                    help="development: interleaved A/B of the store kernel's tuning knobs, then exit")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:    # no launcher: become one (before stdout is set aside)
         if not args.single_device and torch.cuda.device_count() < args.gpus:
@@ -919,23 +917,6 @@ def main() -> None:
     run_steps(args.warmup)
     barrier()
     kernel_name = pli.last_kernel
-
-    if args.ab:  # same process, same buffers, configurations interleaved round by round
-        cfgs = [(x, t) for x in (0, 1) for t in (61, 121, 241)]
-        times = {c: [] for c in cfgs}
-        for _ in range(args.steps):
-            for x, t in cfgs:
-                pli.set_xcd_remap(bool(x))
-                pli.set_rows_per_stream(t)
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(stream)
-                pli.score_into(pssm, seq, scores_h)
-                b.record(stream)
-                torch.cuda.synchronize()
-                times[(x, t)].append(a.elapsed_time(b))
-        for (x, t), v in times.items():
-            print(f"xcd_remap={x} rows_per_stream={t}: median {np.median(v):.4f} ms  min {min(v):.4f} ms")
-        return
 
     # --- timed region: exactly K steps ---------------------------------------------------
     # HIP events on the launch stream bracket the score kernel of every step (the context

@@ -125,10 +125,6 @@ int lm_hip_ctx_stream(lm_hip_ctx *ctx, void **hip_stream);
 /* Tuning knob: output rows each wavefront half sweeps in the C=32 score
  * kernels (0 = library default). */
 int lm_hip_ctx_set_rows_per_stream(lm_hip_ctx *ctx, size_t rows);
-/* Tuning knob of the materialising C=32 kernel: 1 = workgroups are remapped so that
- * each XCD (private L2) sweeps one contiguous eighth of the rows; 0 (default) = plain
- * dispatch order, one compact window.  Speed only, results are identical. */
-int lm_hip_ctx_set_xcd_remap(lm_hip_ctx *ctx, int enabled);
 /* Tuning knob of the fused score+threshold scans (lm_hip_score_threshold_f32_dptr,
  * lm_hip_scan_f32, lm_hip_scan_threshold_batch): 1 (default) = candidates are found
  * with a packed 16-bit over-estimating discretisation of the PSSM (the GPU form of the
@@ -146,7 +142,7 @@ int lm_hip_ctx_set_prefilter(lm_hip_ctx *ctx, int enabled);
 int lm_hip_ctx_set_track_argmax(lm_hip_ctx *ctx, int enabled);
 /* Selects an alternative path inside the library for this context.  Every option leaves the RESULTS unchanged (the
  * test-suite runs both sides of each against the oracle); they exist for A/B measurements and to exercise paths that
- * are otherwise taken only for some shapes.  Names: "track_argmax", "prefilter", "xcd_remap" (= the setters above),
+ * are otherwise taken only for some shapes.  Names: "track_argmax", "prefilter" (= the setters above),
  * "pair_prefilter", "pair_prefilter_protein", "speculate_order", "suffix_argmax", "suffix_occurrences", "multi_motif",
  * "skip_unreachable", "quad_loads", "xlong_store", "host_fold", "chunked_fused", "chunk_rows", "tiled".  Unknown names:
  * LM_HIP_ERR_BAD_ARGS.  The shipped library reads none of them from the environment. */

@@ -61,7 +61,6 @@ SIGNATURES = {
     "lm_hip_ctx_sync": (C.c_int, [_vp]),
     "lm_hip_ctx_stream": (C.c_int, [_vp, C.POINTER(_vp)]),
     "lm_hip_ctx_set_rows_per_stream": (C.c_int, [_vp, _sz]),
-    "lm_hip_ctx_set_xcd_remap": (C.c_int, [_vp, C.c_int]),
     "lm_hip_ctx_set_prefilter": (C.c_int, [_vp, C.c_int]),
     "lm_hip_ctx_set_track_argmax": (C.c_int, [_vp, C.c_int]),
     "lm_hip_ctx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),

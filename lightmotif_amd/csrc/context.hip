@@ -333,7 +333,7 @@ int lm_hip_device_clock_mhz(int device, unsigned window_us, double *mhz)
 static const char *const kOptionNames[] = {"track_argmax", "xlong_store", "host_fold", "speculate_order", "suffix_argmax",
                                            "multi_motif", "quad_loads", "skip_unreachable", "pair_prefilter",
                                            "pair_prefilter_protein", "chunked_fused", "chunk_rows", "tiled",
-                                           "suffix_occurrences", "prefilter", "xcd_remap"};
+                                           "suffix_occurrences", "prefilter"};
 
 static int set_option(lm_hip_ctx *ctx, const char *name, double value)
 {
@@ -352,7 +352,6 @@ static int set_option(lm_hip_ctx *ctx, const char *name, double value)
     else if (n == "chunked_fused") ctx->chunked_fused = on;          // 0 = fused scans of M > 36 go cell by cell
     else if (n == "tiled") ctx->tiled = on;                          // 0 = column counts off 32 / 16 go cell by cell
     else if (n == "prefilter") ctx->use_prefilter = on;
-    else if (n == "xcd_remap") ctx->xcd_remap = on;
     else if (n == "chunk_rows") {
         if (!(value >= 64))
             return fail(LM_HIP_ERR_BAD_ARGS, "ctx_set_option: chunk_rows must be >= 64");
@@ -491,14 +490,6 @@ int lm_hip_ctx_set_rows_per_stream(lm_hip_ctx *ctx, size_t rows)
     if (!ctx)
         return fail(LM_HIP_ERR_BAD_ARGS, "null context");
     ctx->rows_per_stream = rows;
-    return LM_HIP_OK;
-}
-
-int lm_hip_ctx_set_xcd_remap(lm_hip_ctx *ctx, int enabled)
-{
-    if (!ctx)
-        return fail(LM_HIP_ERR_BAD_ARGS, "null context");
-    ctx->xcd_remap = enabled != 0;
     return LM_HIP_OK;
 }
 

@@ -1049,4 +1049,83 @@ int lm_hip_threshold_f32(const float *scores, size_t rows, size_t stride, size_t
     });
 }
 
+// ---- Scanner on host matrices (scan.rs:166-249) ------------------------------------------------------------------------
+
+// The caller's StripedSequence on the lane's staging buffer, as a (borrowed) resident sequence: 1 B per position up.
+static int stage_sequence(HostLane *lane, const uint8_t *seq, size_t seq_rows_total, size_t seq_stride, size_t cols, size_t wrap,
+                          size_t length, size_t k, lm_hip_seq *out)
+{
+    if (!seq || cols == 0 || seq_stride < cols || wrap > seq_rows_total)
+        return fail(LM_HIP_ERR_BAD_ARGS, "scan: bad sequence matrix (%zu rows, stride %zu, %zu columns, wrap %zu)",
+                    seq_rows_total, seq_stride, cols, wrap);
+    lm_hip_ctx *ctx = lane->ctx;
+    const size_t bytes = seq_rows_total * seq_stride;
+    LM_TRY(lane->d_in.reserve(bytes + 64));
+    LM_HIP_TRY(hipMemcpyAsync(lane->d_in.ptr, seq, bytes, hipMemcpyHostToDevice, ctx->stream));
+    out->device = ctx->device;
+    out->d_data = static_cast<uint8_t *>(lane->d_in.ptr);
+    out->capacity_rows = seq_rows_total;
+    out->rows = seq_rows_total - wrap;
+    out->wrap = wrap;
+    out->stride = seq_stride;
+    out->cols = cols;
+    out->length = length;
+    out->k = k;
+    out->owns = false;
+    return LM_HIP_OK;
+}
+
+int lm_hip_scan_f32_host(const uint8_t *seq, size_t seq_rows_total, size_t seq_stride, size_t cols, size_t wrap, size_t length,
+                         const float *pssm, size_t m, size_t pssm_stride, size_t k, float threshold, lm_hip_hit **hits,
+                         size_t *n)
+{
+    return guarded("scan", [&]() -> int {
+        if (!hits || !n)
+            return fail(LM_HIP_ERR_BAD_ARGS, "scan: null argument");
+        *hits = nullptr;
+        *n = 0;
+        HostLane *lane = nullptr;
+        LM_TRY(acquire_lane(&lane));
+        lm_hip_ctx *ctx = lane->ctx;
+        DeviceGuard guard(ctx->device);
+        lm_hip_pssm *p = nullptr;
+        LM_TRY(lane_pssm(lane, pssm, m, pssm_stride, k, &p));
+        lm_hip_seq view;
+        int st = stage_sequence(lane, seq, seq_rows_total, seq_stride, cols, wrap, length, k, &view);
+        if (st == LM_HIP_OK)
+            st = lm_hip_scan_f32(ctx, p, &view, threshold, hits, n);  // synchronises
+        if (st != LM_HIP_OK)
+            (void)hipStreamSynchronize(ctx->stream);
+        lane_trim(lane);
+        return st;
+    });
+}
+
+int lm_hip_scan_max_f32_host(const uint8_t *seq, size_t seq_rows_total, size_t seq_stride, size_t cols, size_t wrap,
+                             size_t length, const float *pssm, size_t m, size_t pssm_stride, size_t k,
+                             const uint8_t *dweights, size_t dweights_stride, int saturate, unsigned level, int have,
+                             size_t position, float score, size_t first_row, int *found, lm_hip_hit *best)
+{
+    return guarded("scan_max", [&]() -> int {
+        if (!found || !best || !dweights)
+            return fail(LM_HIP_ERR_BAD_ARGS, "scan_max: null argument");
+        *found = 0;
+        HostLane *lane = nullptr;
+        LM_TRY(acquire_lane(&lane));
+        lm_hip_ctx *ctx = lane->ctx;
+        DeviceGuard guard(ctx->device);
+        lm_hip_pssm *p = nullptr;
+        LM_TRY(lane_pssm(lane, pssm, m, pssm_stride, k, &p));
+        lm_hip_seq view;
+        int st = stage_sequence(lane, seq, seq_rows_total, seq_stride, cols, wrap, length, k, &view);
+        if (st == LM_HIP_OK)
+            st = lm_hip_scan_max_f32(ctx, p, &view, dweights, dweights_stride, saturate, level, have, position, score, first_row,
+                                     found, best);
+        if (st != LM_HIP_OK)
+            (void)hipStreamSynchronize(ctx->stream);
+        lane_trim(lane);
+        return st;
+    });
+}
+
 }  // extern "C"

@@ -102,7 +102,6 @@ struct lm_hip_ctx {
     unsigned *d_ticket = nullptr; // "last workgroup folds the records" counter of the single-launch argmax forms (zero between launches)
     size_t rows_per_stream = 0; // 0 = default
     bool use_prefilter = true;  // fused threshold: packed 16-bit discrete prefilter (A/B knob)
-    bool xcd_remap = false;      // A/B knob of the store kernel (lm_hip_ctx_set_xcd_remap)
     bool pair_prefilter = true;  // DNA prefilter scans look up two symbols at a time
     bool pair_prefilter_protein = false;  // the 441-row protein pair scan: correct, measured 4 % slower
     bool quad_loads = true;      // store kernel: quad-gathered dword symbol loads (M % 4 == 0; +1 %)

@@ -202,7 +202,7 @@ static int launch_score_argmax_exact(lm_hip_ctx *ctx, const ScoreArgs *jobs, siz
             fo.batch = n > 1 ? d_bparams + bp_pos : nullptr;
             const ExactMotif em = exact_motif(a.pssm, a.d_seq);  // (a group shares length, hence padding)
             fo.lead_rows = em.lead;
-            ScoreC32Launcher fn = score_c32_lookup((int)em.m, MODE_ARGMAX, false, lds_wide((int)a.pssm->k));
+            ScoreC32Launcher fn = score_c32_lookup((int)em.m, MODE_ARGMAX, lds_wide((int)a.pssm->k));
             ctx->last_kernel = score_c32_name((int)em.m, MODE_ARGMAX);
             LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, em.table, (int)a.pssm->k,
                           a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, nullptr, fo));

@@ -29,28 +29,27 @@ struct RegisterRange {
         tab[MODE_STORE] = &score_c32_launch<M, MODE_STORE>;
         tab[MODE_ARGMAX] = &score_c32_launch<M, MODE_ARGMAX>;
         tab[MODE_THRESHOLD] = &score_c32_launch<M, MODE_THRESHOLD>;
-        tab[3] = &score_c32_launch<M, MODE_STORE, 1>;
         if constexpr (M % 4 == 0) {
-            tab[7] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1>;
-            tab[10] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1, 16>;
-            tab[11] = &score_c32_launch<M, MODE_STORE_TRACK, LM_SCORE_XCD_REMAP, 1>;
+            tab[7] = &score_c32_launch<M, MODE_STORE, 1>;
+            tab[10] = &score_c32_launch<M, MODE_STORE, 1, 16>;
+            tab[11] = &score_c32_launch<M, MODE_STORE_TRACK, 1>;
         }
-        tab[8] = &score_c32_launch<M, MODE_STORE_ARGMAX, LM_SCORE_XCD_REMAP, 1>;
-        tab[9] = &score_c32_launch<M, MODE_CONTINUE, LM_SCORE_XCD_REMAP, 1>;
+        tab[8] = &score_c32_launch<M, MODE_STORE_ARGMAX, 1>;
+        tab[9] = &score_c32_launch<M, MODE_CONTINUE, 1>;
         // wide alphabets (protein): the slots the launchers use at C = 32
         r.prew[M] = &score_c32_prefilter_launch<M, 1>;
         r.u8w[M] = &score_c32_u8_launch<M, 1>;
         ScoreC32Launcher *tw = r.c32w[M];
-        tw[MODE_STORE] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 0, 32, 1>;
-        tw[MODE_ARGMAX] = &score_c32_launch<M, MODE_ARGMAX, LM_SCORE_XCD_REMAP, 0, 32, 1>;
-        tw[MODE_THRESHOLD] = &score_c32_launch<M, MODE_THRESHOLD, LM_SCORE_XCD_REMAP, 0, 32, 1>;
+        tw[MODE_STORE] = &score_c32_launch<M, MODE_STORE, 0, 32, 1>;
+        tw[MODE_ARGMAX] = &score_c32_launch<M, MODE_ARGMAX, 0, 32, 1>;
+        tw[MODE_THRESHOLD] = &score_c32_launch<M, MODE_THRESHOLD, 0, 32, 1>;
         if constexpr (M % 4 == 0) {
-            tw[7] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1, 32, 1>;
-            tw[10] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1, 16, 1>;
-            tw[11] = &score_c32_launch<M, MODE_STORE_TRACK, LM_SCORE_XCD_REMAP, 1, 32, 1>;
+            tw[7] = &score_c32_launch<M, MODE_STORE, 1, 32, 1>;
+            tw[10] = &score_c32_launch<M, MODE_STORE, 1, 16, 1>;
+            tw[11] = &score_c32_launch<M, MODE_STORE_TRACK, 1, 32, 1>;
         }
-        tw[8] = &score_c32_launch<M, MODE_STORE_ARGMAX, LM_SCORE_XCD_REMAP, 1, 32, 1>;
-        tw[9] = &score_c32_launch<M, MODE_CONTINUE, LM_SCORE_XCD_REMAP, 1, 32, 1>;
+        tw[8] = &score_c32_launch<M, MODE_STORE_ARGMAX, 1, 32, 1>;
+        tw[9] = &score_c32_launch<M, MODE_CONTINUE, 1, 32, 1>;
         if constexpr (M < LM_M_HI)
             RegisterRange<M + 1>::run(r);
     }

@@ -42,10 +42,7 @@
 
 namespace lm {
 
-#ifndef LM_BLOCK
-#define LM_BLOCK 256
-#endif
-constexpr int kBlock = LM_BLOCK;                 // threads per workgroup (4 wavefronts)
+constexpr int kBlock = 256;                      // threads per workgroup (4 wavefronts)
 constexpr int kStreamsPerBlock = kBlock / 32;    // 2 per wavefront
 constexpr int kMaxFastM = 36;        // largest motif the whole kernel family (every length, prefilters, u8) is built for
 // 36 < M <= 64: the exact f32 kernels only, for the padded lengths M' = 40, 44 ... 64 (leading zero rows, see
@@ -248,45 +245,22 @@ __device__ __forceinline__ void record_hit(const FusedOut &fo, unsigned long lon
     }
 }
 
-// Tuning parameters of score_c32 (fixed per build; tools/kbench sweeps them):
-//   PF  global prefetch distance in steps: the symbol byte of step k+PF is
-//       requested while step k is processed (0 = load at use);
-//   LP  1 = the LDS reads of step k+1 are issued before the adds of step k.
-#ifndef LM_EMIT_FAST_PATH
-#define LM_EMIT_FAST_PATH 1  // A/B: 0 = the candidate epilogue always runs its prefix sum
-#endif
-#ifndef LM_SCORE_STORE_BATCH
-#define LM_SCORE_STORE_BATCH 1
-#endif
-#ifndef LM_SCORE_PF
-#define LM_SCORE_PF 12
-#endif
-#ifndef LM_SCORE_LP
-#define LM_SCORE_LP 0
-#endif
-// Minimum wavefronts per SIMD the register allocator must leave room for (2nd
-// __launch_bounds__ argument).  Without it the fused-threshold variant is allocated
-// 228 VGPRs (2 waves/SIMD) although ~75 suffice.
-#ifndef LM_SCORE_MIN_WAVES
-#define LM_SCORE_MIN_WAVES(M) ((M) <= 20 ? 6 : (M) <= 40 ? 4 : 3)
-#endif
-// 1 = score rows are written with non-temporal (streaming) stores
-// A/B (tools/build_variant.py): 1 = the quad symbol loads of the store / fused kernels are non-temporal too
-#ifndef LM_SCORE_NT_LOAD
-#define LM_SCORE_NT_LOAD 0
-#endif
-#ifndef LM_SCORE_NT_STORE
-#define LM_SCORE_NT_STORE 1
-#endif
+// Tuning constants of score_c32 (every alternative was measured and its losing side removed; HISTORY 4.7-4.8 and the
+// profiles/r0*_*_ab.txt files keep the numbers):
+//   kScorePF  global prefetch distance in steps of the byte-load form: the symbol byte of step k + PF is requested
+//             while step k is processed.  (Issuing the LDS reads of step k + 1 before the adds of step k, batched row
+//             stores, non-temporal symbol loads, plain stores and an XCD-aware workgroup remap all measured equal or
+//             slower, bit-identical: r01_kbench*, r02_store_batch_ab, r02_store_policy, r03_nt_symbol_loads_ab.)
+constexpr int kScorePF = 12;
+// Minimum wavefronts per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument).  Without
+// it the fused-threshold variant is allocated 228 VGPRs (2 waves/SIMD) although ~75 suffice.
+constexpr int score_min_waves_base(int m) { return m <= 20 ? 6 : m <= 40 ? 4 : 3; }
 
 // The long family (M' = 44 ... 64) is compiled against a budget of two wavefronts per SIMD (256 VGPRs).  Most of
 // its kernels need 130-170 registers and still run three wavefronts; where the tighter bound made the
 // scheduler serialise reads and adds it cost more than the wavefront (plain store, 1 Gbp: M' = 44 1.85 -> 1.50 ms,
 // M' = 64 2.24 -> 2.04 ms, the other lengths unchanged; profiles/r03_long_variants_ab.txt), and the fused forms
 // from M' = 56 on would spill at the bound of three (15-38 VGPRs at M' = 64).
-#ifndef LM_LONG_STORE_MINW
-#define LM_LONG_STORE_MINW 2
-#endif
 // The fused forms, measured per length (fused threshold / argmax call, 1 Gbp, bound 3 vs 2: M' = 44 1.66 / 1.88 vs
 // 1.41 / 1.28 ms, 48 1.95 / 1.42 vs 1.55 / 1.40, 52 1.86 / 1.56 vs 2.15 / 1.56; profiles/r03_long_variants_ab.txt):
 // two everywhere but at M' = 52.
@@ -294,23 +268,18 @@ __device__ __forceinline__ void record_hit(const FusedOut &fo, unsigned long lon
 //  1.11 -> 0.99 ms, M = 33 1.48 -> 1.04 per Gbp, the other modes and lengths unchanged; tools/fused_ab.sh, round 3)
 // (the tracked store of M <= 20 takes 74 VGPRs = six wavefronts where the plain store's 68 allow seven; compiled against a
 //  bound of seven it fits 72 + 2 spills and runs 2 % SLOWER at M = 20, equal at 12 / 16: profiles/r03_track_ab.txt)
-#ifndef LM_TRACK_MINW_LE20
-#define LM_TRACK_MINW_LE20 6
-#endif
 constexpr int score_min_waves(int m, int mode)
 {
     return m <= 40 ? ((mode == 2 /* MODE_THRESHOLD */ && m > 28 && m <= 36) ? 3
-                      : (mode == 3 /* MODE_STORE_ARGMAX */ && m <= 20) ? LM_TRACK_MINW_LE20 : LM_SCORE_MIN_WAVES(m))
-                   : mode == 0 /* MODE_STORE */ ? LM_LONG_STORE_MINW : m == 52 ? 3 : 2;
+                      : (mode == 3 /* MODE_STORE_ARGMAX */ && m <= 20) ? 6 : score_min_waves_base(m))
+                   : mode == 0 /* MODE_STORE */ ? 2 : m == 52 ? 3 : 2;
 }
 
 // MODE_CONTINUE: how many steps ahead a row's partial sum is requested (see score_group)
-#ifndef LM_CONTINUE_AHEAD
-#define LM_CONTINUE_AHEAD 4
-#endif
+constexpr int kContinueAhead = 4;
 // (M' = 52, the one continuation kernel on a bound of three wavefronts per SIMD, gets SLOWER with the ring: 2.28 -> ~3.1 ms
 //  per Gbp; it keeps the step-ahead form.  profiles/r03_continue_ahead_ab.txt)
-constexpr int continue_ahead(int m) { return (m % LM_CONTINUE_AHEAD == 0 && m != 52) ? LM_CONTINUE_AHEAD : 1; }
+constexpr int continue_ahead(int m) { return (m % kContinueAhead == 0 && m != 52) ? kContinueAhead : 1; }
 // Upper bound of the wavefronts per SIMD (second argument of amdgpu_waves_per_eu; 0 = none, i.e. plain
 // __launch_bounds__).  hipcc schedules two tracked store kernels of the long family badly when it is free to aim at
 // a higher occupancy than the bound asks for: M' = 56 with 1 424 `s_waitcnt` instead of the plain store's 823 (LDS
@@ -318,10 +287,10 @@ constexpr int continue_ahead(int m) { return (m % LM_CONTINUE_AHEAD == 0 && m !=
 // Capped at their lower bound the register allocator stops trading the schedule for a wavefront it does not get:
 // 484 waits, 2.00 / 1.43 ms.  The same cap on every other store kernel is a disaster (M' = 44 1.52 -> 3.11 ms,
 // M = 24 1.04 -> 1.88; profiles/r03_maxw_ab.txt), hence the two lengths by name.
-#ifndef LM_MAXW
-#define LM_MAXW(M, MODE, MINW) (((MODE) == 3 /* MODE_STORE_ARGMAX */ && ((M) == 40 || (M) == 56)) ? (MINW) : 0)
-#endif
-constexpr int score_max_waves(int m, int mode, int minw) { return LM_MAXW(m, mode, minw); }
+constexpr int score_max_waves(int m, int mode, int minw)
+{
+    return (mode == 3 /* MODE_STORE_ARGMAX */ && (m == 40 || m == 56)) ? minw : 0;
+}
 
 template <int M, int WIDE = 0>
 __device__ __forceinline__ void lds_fetch_column(float (&w)[4 * ((M + 3) / 4)],
@@ -369,9 +338,7 @@ __device__ __forceinline__ void lds_fetch_column(float (&w)[4 * ((M + 3) / 4)],
 // 1.296 vs 1.306 -- but M = 20 0.958 vs 0.940 at every stream length (the volatile reads also
 // pin the schedule of the edge groups; at five chunks per column that costs more than the
 // narrow reads do), hence the hole in the middle.
-#ifndef LM_SCORE_EDGE_B128
-#define LM_SCORE_EDGE_B128(M) ((M) <= 16 || (M) >= 24)
-#endif
+constexpr bool edge_reads_whole(int m) { return m <= 16 || m >= 24; }
 template <int M, int WIDE = 0>
 __device__ __forceinline__ void lds_fetch_chunks(float (&w)[4 * ((M + 3) / 4)], const char *__restrict__ tab,
                                                  const unsigned s, const int c0, const int c1)
@@ -417,26 +384,19 @@ enum : int { PHASE_FIRST = 0, PHASE_MAIN = 1, PHASE_LAST = 2 };
 // group's first step; `tbase` = index of that step within the stream (wave-uniform;
 // the output row completed by step t is o0 + t - (M-1)); `orow` = output row completed by
 // the group's first step (in the FIRST group only step M-1 completes a row).
-// `sym` is a ring of symbol bytes indexed by step mod M (only ~PF are live),
-// `wc` carries the prefetched LDS column across steps when LP = 1.
-template <int M, int MODE, int PF, int LP, int PHASE, int QL = 0, int OC = 32, int WIDE = 0>
+// `sym` is a ring of symbol bytes indexed by step mod M (only ~PF are live).
+template <int M, int MODE, int PF, int PHASE, int QL = 0, int OC = 32, int WIDE = 0>
 __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
-                                            float (&wc)[4 * ((M + 3) / 4)],
                                             const uint8_t *__restrict__ sp,
                                             const char *__restrict__ tab,
                                             float *__restrict__ op, const unsigned tbase,
                                             const int col, float &best_v, unsigned &best_t,
                                             const FusedOut &fo, const unsigned shq, float &init_next,
-                                            float (&initq)[LM_CONTINUE_AHEAD], const bool prelast)
+                                            float (&initq)[kContinueAhead], const bool prelast)
 {
     constexpr int NW = 4 * ((M + 3) / 4);
     constexpr int NB = M / 4;                  // QL: 4-row symbol blocks per group (M % 4 == 0)
     constexpr int PFB = NB > 3 ? 3 : NB;       // QL: blocks requested ahead of use
-    // experiment (LM_SCORE_STORE_BATCH = 2 / 4): completed rows wait in registers and leave as SB
-    // back-to-back row stores, i.e. SB * 128 contiguous bytes per half-wave within a few cycles
-    constexpr int SB = (mode_stores(MODE) && MODE != MODE_CONTINUE && PHASE != PHASE_FIRST &&
-                        M % LM_SCORE_STORE_BATCH == 0) ? LM_SCORE_STORE_BATCH : 1;
-    float pend[SB];
 #pragma unroll
     for (int k = 0; k < M; ++k) {
         // (1) request the symbol byte PF steps ahead (stays inside the stream's
@@ -450,9 +410,7 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
                     : (k % 4 == 2) ? quad_symbol<2>(d, shq)
                                    : quad_symbol<3>(d, shq);
             if (k % 4 == 3 && (PHASE != PHASE_LAST || k / 4 + PFB < NB))
-                sym[(k / 4 + PFB) % NB] = LM_SCORE_NT_LOAD
-                                              ? __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(sp + (k / 4 + PFB) * 128))
-                                              : *reinterpret_cast<const unsigned *>(sp + (k / 4 + PFB) * 128);
+                sym[(k / 4 + PFB) % NB] = *reinterpret_cast<const unsigned *>(sp + (k / 4 + PFB) * 128);
         } else if (PF > 0) {
             if (PHASE != PHASE_LAST || k + PF < M)
                 sym[(k + PF) % M] = sp[(k + PF) * 32];
@@ -461,7 +419,7 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
         }
         // (2) the PSSM column of this step's symbol
         float w[NW];
-        if (LM_SCORE_EDGE_B128(M) && !LP && PHASE != PHASE_MAIN) {
+        if (edge_reads_whole(M) && PHASE != PHASE_MAIN) {
             // FIRST: outputs started at steps 0..k -> weights 0..k.  LAST: the stream's last output
             // starts at the group's step 0, so step k still needs weights k..M-1
             const unsigned sy = QL ? s_now : sym[k];
@@ -474,12 +432,6 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
                 lds_fetch_chunks<M, WIDE>(w, tab, sy, k / 4, (M + 3) / 4);
         } else if (QL) {
             lds_fetch_column<M, WIDE>(w, tab, s_now);
-        } else if (LP) {
-#pragma unroll
-            for (int i = 0; i < NW; ++i)
-                w[i] = wc[i];
-            if (PHASE != PHASE_LAST || k + 1 < M)
-                lds_fetch_column<M, WIDE>(wc, tab, sym[(k + 1) % M]);
         } else {
             lds_fetch_column<M, WIDE>(w, tab, sym[k]);
         }
@@ -518,23 +470,8 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
             const float score = acc[(k + 1) % M];
             if (mode_tracks_cell(MODE) && PHASE == PHASE_FIRST)
                 init_next = score;  // (MODE_CONTINUE's carrier is free in these modes) the stream's first output
-            if (mode_stores(MODE) && SB > 1) {
-                pend[k % SB] = score;
-                if (k % SB == SB - 1) {
-#pragma unroll
-                    for (int i = 0; i < SB; ++i) {
-                        if (LM_SCORE_NT_STORE)
-                            __builtin_nontemporal_store(pend[i], op + (k - SB + 1 + i) * OC);
-                        else
-                            op[(k - SB + 1 + i) * OC] = pend[i];
-                    }
-                }
-            } else if (mode_stores(MODE)) {
-                if (LM_SCORE_NT_STORE)
-                    __builtin_nontemporal_store(score, op + k * OC);
-                else
-                    op[k * OC] = score;
-            }
+            if (mode_stores(MODE))
+                __builtin_nontemporal_store(score, op + k * OC);  // streaming: the matrix is never read back by this kernel
             if (MODE == MODE_STORE_ARGMAX) {
                 // value only (one v_max_f32; NaN operands are ignored, the NaN start value
                 // survives only if every score was NaN): the cell is located afterwards in
@@ -588,7 +525,7 @@ __device__ __forceinline__ void emit_candidates(const unsigned long long hit_gro
     // sum below is six ds_bpermute -- LDS-pipeline instructions, which the scans that end here are bound
     // by (one epilogue per ~64-row stream and motif: ~8 % of the pair scan's LDS instructions).
     unsigned incl = mine;
-    if (!LM_EMIT_FAST_PATH || __ballot(mine != 0)) {  // wavefront-uniform
+    if (__ballot(mine != 0)) {  // wavefront-uniform
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const unsigned y = __shfl_up(incl, off);
@@ -629,17 +566,16 @@ __device__ __forceinline__ void emit_candidates(const unsigned long long hit_gro
 // (q+1)*M steps = one FIRST group, q-1 MAIN groups and one LAST group.  The last
 // stream is shifted back so that it ends at row_end; idle half-waves re-do the
 // last stream (identical values -> benign duplicates).
-#ifndef LM_SCORE_XCD_REMAP
-#define LM_SCORE_XCD_REMAP 0
-#endif
-template <int M, int MODE, int PF = LM_SCORE_PF, int LP = LM_SCORE_LP, int BLK = LM_BLOCK,
-          int XCD = LM_SCORE_XCD_REMAP, int MINW = LM_SCORE_MIN_WAVES(M), int QLREQ = 0, int OC = 32, int WIDE = 0>
-__global__ __attribute__((amdgpu_flat_work_group_size(1, BLK), amdgpu_waves_per_eu(MINW, score_max_waves(M, MODE, MINW)))) void score_c32(
+template <int M, int MODE, int QLREQ = 0, int OC = 32, int WIDE = 0>
+__global__ __attribute__((amdgpu_flat_work_group_size(1, kBlock),
+                          amdgpu_waves_per_eu(score_min_waves(M, MODE),
+                                              score_max_waves(M, MODE, score_min_waves(M, MODE))))) void score_c32(
     const uint8_t *__restrict__ seq, const float *__restrict__ table, const int K,
     const unsigned long long row_begin, const unsigned long long row_end,
     const unsigned long long T, const unsigned long long nstreams, float *__restrict__ out,
     const FusedOut fo_in)
 {
+    constexpr int BLK = kBlock, PF = kScorePF;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     FusedOut fo = fo_in;
     if (!mode_stores(MODE) && fo_in.batch) {  // multi-job launch: this block's job (wave-uniform)
@@ -665,14 +601,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(1, BLK), amdgpu_waves_per_
     static_assert(OC == 32 || (OC == 16 && MODE == MODE_STORE), "C = 16 is built for the plain store kernel");
     const int lane = threadIdx.x & 63;
     const int col = lane & (OC - 1);
-    unsigned long long bid = blockIdx.x;
-    if (XCD) {
-        // Workgroup b runs on XCD b % 8 (observed dispatch order; speed only, never
-        // correctness): give each XCD one contiguous eighth of the rows.  Bijective for
-        // any grid size.
-        const unsigned long long nb = gridDim.x, xcd = bid % 8, q = nb / 8, r = nb % 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-    }
+    // (plain dispatch order = one compact window of rows in flight; an XCD-aware remap -- each XCD one contiguous
+    //  eighth of the rows -- measured slower on this write pattern: HISTORY 4.7)
+    const unsigned long long bid = blockIdx.x;
     unsigned long long stream = (bid * (BLK / 64) + (threadIdx.x >> 6)) * (64 / OC) + lane / OC;
     const bool idle = stream >= nstreams;  // re-does the last stream, reports nothing
     if (MODE == MODE_CONTINUE && idle)
@@ -684,7 +615,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(1, BLK), amdgpu_waves_per_
         o0 = row_end - T;
 
     // quad-gathered symbol loads need whole 4-row blocks per group
-    constexpr int QL = (QLREQ && M % 4 == 0 && LP == 0) ? 1 : 0;
+    constexpr int QL = (QLREQ && M % 4 == 0) ? 1 : 0;
     const unsigned shq = 8u * (col & 3);
     // (padded motifs: the first `lead` rows of a window carry zero weights and may lie before the matrix)
     // (the fused modes of the short family are never launched on padded tables; the long family always is)
@@ -695,11 +626,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(1, BLK), amdgpu_waves_per_
     const long long orow = (long long)(o0 - row_begin) - (M - 1);
     float *op = mode_stores(MODE) ? out + orow * OC + col : nullptr;
 
-    constexpr int NW = 4 * ((M + 3) / 4);
     constexpr int PFE = PF < M ? PF : M - 1;  // look-ahead stays inside one group
     float acc[M];
     unsigned sym[M];
-    float wc[NW];
 #pragma unroll
     for (int j = 0; j < M; ++j) {
         acc[j] = 0.0f;
@@ -717,12 +646,6 @@ __global__ __attribute__((amdgpu_flat_work_group_size(1, BLK), amdgpu_waves_per_
         for (int j = 0; j < PFE; ++j)
             sym[j] = sp[j * 32];
     }
-#pragma unroll
-    for (int i = 0; i < NW; ++i)
-        wc[i] = 0.0f;
-    constexpr int LPE = (PFE >= 1) ? LP : 0;
-    if (LPE)
-        lds_fetch_column<M, WIDE>(wc, lds_raw, sym[0]);
     float best_v = (MODE == MODE_STORE_ARGMAX) ? __builtin_nanf("") : -INFINITY;
     // argmax mode: step index of the lane's best score (0xffffffff = none);
     // threshold mode: "this group saw a hit" flag
@@ -730,9 +653,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(1, BLK), amdgpu_waves_per_
     unsigned tbase = 0;
     // MODE_CONTINUE: partial sum of the row started at step 0 (= the stream's first row)
     float init_next = 0.0f;
-    float initq[LM_CONTINUE_AHEAD];
+    float initq[kContinueAhead];
 #pragma unroll
-    for (int d = 0; d < LM_CONTINUE_AHEAD; ++d)  // rows started at steps 0 .. CD-1 of the stream (T >= M + 1 rows: they exist)
+    for (int d = 0; d < kContinueAhead; ++d)  // rows started at steps 0 .. CD-1 of the stream (T >= M + 1 rows: they exist)
         initq[d] = (MODE == MODE_CONTINUE && d < continue_ahead(M)) ? op[(d + M - 1) * OC] : 0.0f;
 
     const unsigned long long ngroups = (T + M - 1) / M;  // exact: T = q*M + 1, >= 2
@@ -755,7 +678,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(1, BLK), amdgpu_waves_per_
         }
     };
 
-    score_group<M, MODE, PFE, LPE, PHASE_FIRST, QL, OC, WIDE>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
+    score_group<M, MODE, PFE, PHASE_FIRST, QL, OC, WIDE>(acc, sym, sp, lds_raw, op, tbase, col, best_v,
                                                 best_t, fo, shq, init_next, initq, ngroups == 2);
     const float first_out = init_next;  // MODE_STORE_TRACK: the stream's first output (scores[0][0] for stream 0, column 0)
     note_group();
@@ -764,7 +687,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(1, BLK), amdgpu_waves_per_
         tbase += M;
         if (mode_stores(MODE))
             op += M * OC;
-        score_group<M, MODE, PFE, LPE, PHASE_MAIN, QL, OC, WIDE>(acc, sym, wc, sp, lds_raw, op, tbase, col,
+        score_group<M, MODE, PFE, PHASE_MAIN, QL, OC, WIDE>(acc, sym, sp, lds_raw, op, tbase, col,
                                                    best_v, best_t, fo, shq, init_next, initq, g + 2 == ngroups);
         note_group();
     }
@@ -772,7 +695,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(1, BLK), amdgpu_waves_per_
     tbase += M;
     if (mode_stores(MODE))
         op += M * OC;
-    score_group<M, MODE, PFE, LPE, PHASE_LAST, QL, OC, WIDE>(acc, sym, wc, sp, lds_raw, op, tbase, col, best_v,
+    score_group<M, MODE, PFE, PHASE_LAST, QL, OC, WIDE>(acc, sym, sp, lds_raw, op, tbase, col, best_v,
                                                best_t, fo, shq, init_next, initq, false);
     note_group();
 
@@ -1097,28 +1020,25 @@ using ScoreC32Launcher = hipError_t (*)(dim3 grid, size_t lds_bytes, hipStream_t
                                         unsigned long long T, unsigned long long nstreams,
                                         float *out, FusedOut fo);
 
-template <int M, int MODE, int XCD = LM_SCORE_XCD_REMAP, int QL = 0, int OC = 32, int WIDE = 0>
+template <int M, int MODE, int QL = 0, int OC = 32, int WIDE = 0>
 hipError_t score_c32_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, const uint8_t *seq,
                             const float *table, int K, unsigned long long row_begin,
                             unsigned long long row_end, unsigned long long T,
                             unsigned long long nstreams, float *out, FusedOut fo)
 {
-    hipLaunchKernelGGL((score_c32<M, MODE, LM_SCORE_PF, LM_SCORE_LP, LM_BLOCK, XCD,
-                                  score_min_waves(M, MODE), QL, OC, WIDE>), grid,
-                       dim3(kBlock), lds_bytes, stream, seq, table, K, row_begin, row_end, T,
-                       nstreams, out, fo);
+    hipLaunchKernelGGL((score_c32<M, MODE, QL, OC, WIDE>), grid, dim3(kBlock), lds_bytes, stream, seq, table, K,
+                       row_begin, row_end, T, nstreams, out, fo);
     return hipGetLastError();
 }
 
 // Filled by the score_inst_*.hip translation units; [M][MODE], nullptr if absent.
-// Registry row: [0..2] = modes, [3] = store kernel WITH the XCD remap (A/B knob),
-// [4..6] = unused, [7] = store kernel with quad-gathered symbol
+// Registry row: [0..2] = modes, [3..6] = unused, [7] = store kernel with quad-gathered symbol
 // loads (M % 4 == 0), [8] = store + running maximum (score_into on handles).
 constexpr int kRegistrySlots = 12;  // [9] = MODE_CONTINUE (later passes of motifs longer than kMaxFastM),
                                     // [10] = store kernel for C = 16 (M % 4 == 0, quad loads),
                                     // [11] = MODE_STORE_TRACK (M % 4 == 0, quad loads): small score_into + argmax
 // `wide`: the kernels for alphabets of more than 16 symbols (lds_wide(K): 8-byte LDS reads)
-ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap = false, bool wide = false);
+ScoreC32Launcher score_c32_lookup(int M, int mode, bool wide = false);
 ScoreC32Launcher score_c32_lookup_ql(int M, bool wide = false);
 ScoreC32Launcher score_c32_lookup_store_argmax(int M, bool wide = false);
 ScoreC32Launcher score_c32_lookup_continue(int M, bool wide = false);

@@ -32,12 +32,10 @@ struct C32Plan {
 // order, which HBM (and the TLB) reward more than the M-1 fill steps per stream
 // cost -- the kernel is HBM-bound, not LDS-bound (profiles/r01_kbench2_nt.txt:
 // T=61 0.947 ms, T=501 0.995 ms, T=4001 1.12 ms at M=20 on 1 Gbp).
-// The XCD-aware block remap (lm_hip_ctx_set_xcd_remap) is OFF by default: it wins
-// 3 % when the buffers are fresh, separately hipMalloc'ed regions (kbench5_ab.txt:
-// 0.908 vs 0.941 ms) but loses 3 % inside one large arena or under PyTorch's
-// allocator (kbench6_place.txt, `bench.py --ab`: 1.00 vs 0.97 ms on the same box) --
-// eight distant windows instead of one compact one; the compact window is the
-// robust choice.
+// (An XCD-aware block remap -- each XCD one contiguous eighth of the rows -- won 3 % on fresh,
+// separately hipMalloc'ed buffers and lost 3 % inside one large arena or under PyTorch's
+// allocator: eight distant windows instead of one compact one.  Removed in round 5; numbers in
+// profiles/r01_kbench5_ab.txt, r01_kbench6_place.txt.)
 // `prefilter`: 0 = exact kernels, 1 = one-symbol prefilter (streams of q*MP + 1 rows),
 // 2 = pair-symbol prefilter (streams of q*RING + 2 rows)
 // what the planner needs to know about the matrix (a.pssm may be absent: u8 scores)

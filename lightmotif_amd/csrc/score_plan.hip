@@ -78,16 +78,12 @@ static void init_registry()
             snprintf(g_c32_names[m][mode], sizeof g_c32_names[m][mode], "score_c32<%d,%d>", m, mode);
 }
 
-ScoreC32Launcher score_c32_lookup(int M, int mode, bool xcd_remap, bool wide)
+ScoreC32Launcher score_c32_lookup(int M, int mode, bool wide)
 {
     std::call_once(g_c32_once, init_registry);
     if (M < 1 || M > kMaxStoreM || mode < 0 || mode > 2)
         return nullptr;
-    if (wide)
-        return g_c32w[M][mode];  // (no XCD-remap variant: an A/B knob of the DNA store kernel)
-    if (mode == MODE_STORE && xcd_remap)
-        return g_c32[M][3];
-    return g_c32[M][mode];
+    return (wide ? g_c32w : g_c32)[M][mode];
 }
 
 PrefilterLauncher score_c32_prefilter_lookup(int M, bool wide)

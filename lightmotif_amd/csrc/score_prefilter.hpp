@@ -201,7 +201,7 @@ __device__ __forceinline__ void prefilter_group(unsigned (&acc2)[prefilter_mp(M)
 // Same geometry as score_c32<M, MODE_THRESHOLD> with M replaced by MP: every stream
 // sweeps T = q*MP + 1 outputs in (q+1) groups of MP steps.  `image` = the LDS image
 // described above; `td` = discrete threshold.
-template <int M, int PF = LM_SCORE_PF, int WIDE = 0>
+template <int M, int PF = kScorePF, int WIDE = 0>
 __global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter(
     const uint8_t *__restrict__ seq, const unsigned *__restrict__ image, const int K,
     const unsigned long long row_begin, const unsigned long long row_end,
@@ -327,7 +327,7 @@ hipError_t score_c32_prefilter_launch(dim3 grid, size_t lds_bytes, hipStream_t s
                                       unsigned long long T, unsigned long long nstreams,
                                       unsigned td, FusedOut fo)
 {
-    hipLaunchKernelGGL((score_c32_prefilter<M, LM_SCORE_PF, WIDE>), grid, dim3(kBlock), lds_bytes, stream, seq, image,
+    hipLaunchKernelGGL((score_c32_prefilter<M, kScorePF, WIDE>), grid, dim3(kBlock), lds_bytes, stream, seq, image,
                        K, row_begin, row_end, T, nstreams, td, fo);
     return hipGetLastError();
 }

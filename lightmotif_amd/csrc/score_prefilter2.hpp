@@ -29,11 +29,9 @@
 
 #include "score_prefilter.hpp"
 
-#ifndef LM_PREFILTER2_PFB
-#define LM_PREFILTER2_PFB 3  // 4-row symbol blocks requested ahead of use in the pair scans
-#endif
-
 namespace lm {
+
+constexpr int kPairPFB = 3;  // 4-row symbol blocks requested ahead of use in the pair scans
 
 // padded length M' = 3 (mod 4).  A table row of NPAIR = (M' + 1) / 2 dwords is read as whole 16-byte pieces plus,
 // when NPAIR % 4 == 2 (M' = 11, 19, 27, 35), an 8-byte tail.  Left to itself the compiler fuses those tails (of
@@ -44,17 +42,8 @@ namespace lm {
 // (two whole 16-byte reads, +33 % adds: the 2 346-motif batch 37.2 -> 33.8 ms).  Round 3 reads the tail through a
 // volatile LDS pointer instead -- a lone ds_read_b64 costs 2 cycles, as the protein counters showed -- and drops the
 // padding: the JASPAR batch 22.5 -> 20.6 ms (mean of six interleaved runs; with the padding kept: 22.0;
-// profiles/r03_pair_tail_ab.txt).  LM_PREFILTER2_PAD811 = 1 / LM_PREFILTER2_TAIL_VOLATILE = 0 restore round 2.
-#ifndef LM_PREFILTER2_MO8
-#define LM_PREFILTER2_MO8 0
-#endif
-#ifndef LM_PREFILTER2_PAD811
-#define LM_PREFILTER2_PAD811 0
-#endif
-#ifndef LM_PREFILTER2_TAIL_VOLATILE
-#define LM_PREFILTER2_TAIL_VOLATILE 1
-#endif
-constexpr int prefilter2_mo(int m) { return (LM_PREFILTER2_MO8 || (LM_PREFILTER2_PAD811 && m >= 8 && m <= 11)) ? (m | 7) : (m | 3); }
+// profiles/r03_pair_tail_ab.txt).
+constexpr int prefilter2_mo(int m) { return m | 3; }
 constexpr int prefilter2_ring(int m) { return prefilter2_mo(m) + 1; }   // input rows per group
 constexpr int prefilter2_npair(int m) { return prefilter2_ring(m) / 2; }
 // dwords per table row: 4 * odd >= NPAIR (rows 0..15 then sit in distinct 16-byte slots)
@@ -151,11 +140,7 @@ __device__ __forceinline__ void prefilter2_group(unsigned (&acc)[prefilter2_npai
             w[4 * q + 3] = v.w;
         }
         if (NP % 4 >= 2) {
-#if LM_PREFILTER2_TAIL_VOLATILE
             const lm_u32x2_t v = *(lm_lds_u64_ptr)(row + 16 * (NP / 4));
-#else
-            const uint2 v = *reinterpret_cast<const uint2 *>(row + 16 * (NP / 4));
-#endif
             w[4 * (NP / 4) + 0] = v.x;
             w[4 * (NP / 4) + 1] = v.y;
         }
@@ -239,7 +224,7 @@ __global__ __launch_bounds__(kBlock, (KA == 5 && M <= kMaxFastM) ? 6 : M <= 52 ?
     const unsigned shq = 8u * (col & 3);
     const uint8_t *spq = seq + (in0 + (col & 3)) * 32 + (col >> 2) * 4;  // this lane's row of a block
     constexpr int NB = RING / 4;
-    constexpr int PFB = NB > LM_PREFILTER2_PFB ? LM_PREFILTER2_PFB : NB;                       // blocks requested ahead of use (<= NB:
+    constexpr int PFB = NB > kPairPFB ? kPairPFB : NB;                       // blocks requested ahead of use (<= NB:
                                                                // a request reuses a slot only after its last read)
     unsigned acc[NP];
     unsigned blk[NB];
@@ -318,11 +303,7 @@ __global__ __launch_bounds__(kBlock, (KA == 5 && M <= kMaxFastM) ? 6 : M <= 52 ?
 // whose td = 0xffffffff flags nothing).
 constexpr int prefilter2_multi(int m)  // motifs per pass: bounded by the accumulator registers
 {
-#ifdef LM_PREFILTER2_NM3  // experiment: three motifs per pass for M' = 19, 23
-    return prefilter2_npair(m) <= 8 ? 4 : prefilter2_npair(m) <= 12 ? 3 : prefilter2_npair(m) <= 16 ? 2 : 1;
-#else
     return prefilter2_npair(m) <= 8 ? 4 : prefilter2_npair(m) <= 16 ? 2 : 1;
-#endif
 }
 
 template <int M, int NM, int PFB, int PHASE>
@@ -358,11 +339,7 @@ __device__ __forceinline__ void prefilter2_group_multi(unsigned (&acc)[NM][prefi
                 w[4 * q + 3] = v.w;
             }
             if (NP % 4 >= 2) {
-    #if LM_PREFILTER2_TAIL_VOLATILE
-            const lm_u32x2_t v = *(lm_lds_u64_ptr)(row + 16 * (NP / 4));
-#else
-            const uint2 v = *reinterpret_cast<const uint2 *>(row + 16 * (NP / 4));
-#endif
+                const lm_u32x2_t v = *(lm_lds_u64_ptr)(row + 16 * (NP / 4));
                 w[4 * (NP / 4) + 0] = v.x;
                 w[4 * (NP / 4) + 1] = v.y;
             }
@@ -416,7 +393,7 @@ __global__ __launch_bounds__(kBlock, 4) void score_c32_prefilter2_multi(
     const unsigned shq = 8u * (col & 3);
     const uint8_t *spq = seq + (in0 + (col & 3)) * 32 + (col >> 2) * 4;
     constexpr int NB = RING / 4;
-    constexpr int PFB = NB > LM_PREFILTER2_PFB ? LM_PREFILTER2_PFB : NB;
+    constexpr int PFB = NB > kPairPFB ? kPairPFB : NB;
     unsigned acc[NM][NP];
     unsigned blk[NB];
 #pragma unroll

@@ -45,7 +45,7 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
 {
     FusedOut fo{};
     const bool wide = lds_wide((int)a.pssm->k);
-    const bool dwords = ctx->quad_loads && !ctx->xcd_remap && reinterpret_cast<uintptr_t>(a.d_seq) % 4 == 0;
+    const bool dwords = ctx->quad_loads && reinterpret_cast<uintptr_t>(a.d_seq) % 4 == 0;
     if (dwords && a.pssm->d_table_pad) {
         // M % 4 != 0: the table padded with leading zero rows to M' = 4 * ceil(M / 4) -- the same f32
         // sums (0.0 + 0.0 + P[0] ... ), with the dword symbol loads and 4-row blocks of the M' kernel
@@ -67,7 +67,7 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
                                                                   store_rows_hint(a.pssm->m, a.cols), c16)
                                                       : C32Plan{};  // longer: the slices below
     if (p.ok) {
-        ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_STORE, ctx->xcd_remap, wide);
+        ScoreC32Launcher fn = score_c32_lookup((int)a.pssm->m, MODE_STORE, wide);
         if (dwords && score_c32_lookup_ql((int)a.pssm->m, wide))
             fn = score_c32_lookup_ql((int)a.pssm->m, wide);  // dword symbol loads (M % 4 == 0)
         if (c16)
@@ -100,7 +100,7 @@ int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
             if (i == 0) {
                 ScoreC32Launcher fn = score_c32_lookup_ql((int)part.m, wide);
                 if (!fn)
-                    fn = score_c32_lookup((int)part.m, MODE_STORE, false, wide);
+                    fn = score_c32_lookup((int)part.m, MODE_STORE, wide);
                 LM_HIP_TRY(fn(p.grid, p.lds, ctx->stream, sa.d_seq, part.d_table, (int)a.pssm->k, a.row_begin, a.row_end,
                               p.T, p.nstreams, a.d_out, pfo));
                 continue;
@@ -501,7 +501,7 @@ int launch_score_store_track(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *
     const size_t mk = longm ? em.m : a.pssm->m + (pad ? a.pssm->lead : 0);
     const unsigned lead = longm ? em.lead : (unsigned)a.pssm->lead;
     const float *table = pad ? (longm ? em.table : a.pssm->d_table_pad) : a.pssm->d_table;
-    const C32Plan p = (mk >= 1 && mk % 4 == 0 && a.cols == 32 && a.out_stride == 32 && ctx->quad_loads && !ctx->xcd_remap &&
+    const C32Plan p = (mk >= 1 && mk % 4 == 0 && a.cols == 32 && a.out_stride == 32 && ctx->quad_loads &&
                        reinterpret_cast<uintptr_t>(a.d_seq) % 4 == 0)
                           ? plan_c32(ctx, MotifShape{mk, a.pssm->k, false}, a, true, 0, 1, store_rows_hint(mk, a.cols))
                           : C32Plan{};

@@ -361,7 +361,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
                 const ExactMotif em = exact_motif(a.pssm, a.d_seq);
                 FusedOut efo = fo;
                 efo.lead_rows = em.lead;
-                ScoreC32Launcher fn = score_c32_lookup((int)em.m, MODE_THRESHOLD, false, lds_wide((int)a.pssm->k));
+                ScoreC32Launcher fn = score_c32_lookup((int)em.m, MODE_THRESHOLD, lds_wide((int)a.pssm->k));
                 ctx->last_kernel = score_c32_name((int)em.m, MODE_THRESHOLD);
                 LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, em.table, (int)a.pssm->k,
                               a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, nullptr, efo));

@@ -14,15 +14,12 @@
 
 #include "score_prefilter2.hpp"
 
-#ifndef LM_PREFILTER2_PFB
-#define LM_PREFILTER2_PFB 3  // 4-row symbol blocks requested ahead of use in the pair scans
-#endif
 
 namespace lm {
 
 // `image` = prefilter image built from the u8 weights (score_store.hip: launch_score_u8);
 // `out` = row `row_begin` of the u8 score matrix, row stride 32.
-template <int M, int PF = LM_SCORE_PF, int WIDE = 0>
+template <int M, int PF = kScorePF, int WIDE = 0>
 __global__ __launch_bounds__(kBlock, 6) void score_c32_u8(
     const uint8_t *__restrict__ seq, const unsigned *__restrict__ image, const int K,
     const unsigned long long row_begin, const unsigned long long row_end,
@@ -127,7 +124,7 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_u8_pairs(
     const unsigned shq = 8u * (col & 3);
     const uint8_t *spq = seq + (in0 + (col & 3)) * 32 + (col >> 2) * 4;  // this lane's row of a block
     constexpr int NB = RING / 4;
-    constexpr int PFB = NB > LM_PREFILTER2_PFB ? LM_PREFILTER2_PFB : NB;
+    constexpr int PFB = NB > kPairPFB ? kPairPFB : NB;
     unsigned acc[NP];
     unsigned blk[NB];
 #pragma unroll
@@ -172,7 +169,7 @@ hipError_t score_c32_u8_launch(dim3 grid, size_t lds_bytes, hipStream_t stream, 
                                unsigned long long row_end, unsigned long long T, unsigned long long nstreams,
                                uint8_t *out, unsigned wrap_mask)
 {
-    hipLaunchKernelGGL((score_c32_u8<M, LM_SCORE_PF, WIDE>), grid, dim3(kBlock), lds_bytes, stream, seq, image, K, row_begin,
+    hipLaunchKernelGGL((score_c32_u8<M, kScorePF, WIDE>), grid, dim3(kBlock), lds_bytes, stream, seq, image, K, row_begin,
                        row_end, T, nstreams, out, wrap_mask);
     return hipGetLastError();
 }

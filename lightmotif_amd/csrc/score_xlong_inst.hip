@@ -24,10 +24,10 @@ void LM_CAT(register_score_c32_xlong_, LM_XLONG_M)(const KernelRegistry &r)
 {
     constexpr int M = LM_XLONG_M;
     ScoreC32Launcher *tab = r.c32[M];
-    tab[MODE_STORE] = tab[7] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1>;  // dword symbol loads
+    tab[MODE_STORE] = tab[7] = &score_c32_launch<M, MODE_STORE, 1>;  // dword symbol loads
     // alphabets of more than 16 symbols (8-byte LDS reads; 148 VGPRs at M' = 72, 203 at 88)
     ScoreC32Launcher *tw = r.c32w[M];
-    tw[MODE_STORE] = tw[7] = &score_c32_launch<M, MODE_STORE, LM_SCORE_XCD_REMAP, 1, 32, 1>;
+    tw[MODE_STORE] = tw[7] = &score_c32_launch<M, MODE_STORE, 1, 32, 1>;
 }
 
 }  // namespace lm

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import lightmotif_amd as lm
+from host_walk import scanner_max_strict_host
 from oracle import c_oracle as co
 from oracle import np_oracle as no
 
@@ -109,7 +110,7 @@ def test_random_configuration(pli, seed):
             for sat in (True, False):
                 for t in ts[1:3]:
                     got = walk(lambda: lm.Scanner(pssm, seq, threshold=t).max(sat))
-                    host = walk(lambda: lm.Scanner(pssm, seq, threshold=t)._max_strict(sat))
+                    host = walk(lambda: scanner_max_strict_host(lm.Scanner(pssm, seq, threshold=t), sat))
                     assert got == host, (t, sat, got, host)
     finally:
         pli.set_rows_per_stream(0)

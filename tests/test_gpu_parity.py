@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import lightmotif_amd as lm
+from host_walk import scanner_max_strict_host
 from oracle import c_oracle as co
 from oracle import np_oracle as no
 
@@ -678,7 +679,7 @@ def test_entry_points_are_thread_safe(pli):
     seq0 = pli.stripe(lm.EncodedSequence(enc), 32)
     seq0.configure_wrap(26)
     for p_, t_ in zip(motifs, ts):
-        h = lm.Scanner(lm.ScoringMatrix(p_), seq0, threshold=t_)._max_strict()
+        h = scanner_max_strict_host(lm.Scanner(lm.ScoringMatrix(p_), seq0, threshold=t_))
         want_walk.append(None if h is None else (h.position, h.score))
 
     def worker(p, k):
@@ -770,7 +771,7 @@ def test_scanner_max_strict_reference_mode(pli, kind):
         else:
             assert got is not None and got.position == want[0] and np.float32(got.score) == want[1], (kind, bs, got, want)
         if kind != "partially_consumed":                # ... and the same walk on the host from the downloaded matrices
-            host = lm.Scanner(pssm, seq, threshold=t, block_size=bs)._max_strict()
+            host = scanner_max_strict_host(lm.Scanner(pssm, seq, threshold=t, block_size=bs))
             assert (host is None) == (got is None) and (host is None or (host.position, host.score) == (got.position, got.score))
     # the opt-in variant: the best valid hit, whatever the u8 scores say
     best = no.scanner_max(scores, 32, length, m, t)
@@ -1075,7 +1076,7 @@ def test_scanner_max_walk_batched_windows_stall_and_resume(pli, threshold):
     ith = iter(host)
     for _ in range(3):
         next(ith)
-    a, b = sc.max(), host._max_strict()
+    a, b = sc.max(), scanner_max_strict_host(host)
     assert (a is None) == (b is None) and (a is None or (a.position, a.score) == (b.position, b.score))
 
 
@@ -1136,6 +1137,6 @@ def test_scanner_max_walk_on_other_column_counts(pli, cols):
     for q in (0.999, 0.5):
         t = float(np.quantile(mat[np.isfinite(mat)], q))
         got = lm.Scanner(pssm, seq, threshold=t).max()
-        host = lm.Scanner(pssm, seq, threshold=t)._max_strict()
+        host = scanner_max_strict_host(lm.Scanner(pssm, seq, threshold=t))
         assert (got is None) == (host is None)
         assert got is None or (got.position, got.score) == (host.position, host.score), (cols, q, got, host)
