@@ -99,7 +99,7 @@ void lm_hip_free(void *p);
 int lm_hip_result_pool_info(size_t *pinned_idle, size_t *pinned_in_use, size_t *budget);
 
 /* Diagnostic: the shader clock (MHz) the device sustains over the next `window_us` microseconds, measured by one
- * mostly-sleeping wavefront on a high-priority stream of its own (s_memtime ticks per s_memrealtime tick) -- call it from
+ * mostly-sleeping wavefront on a stream of its own (s_memtime ticks per s_memrealtime tick) -- call it from
  * a second host thread while the kernels of interest run to learn the clock THEY get (the part clocks to its power
  * budget; a roofline priced at the 2.4 GHz of the data sheet is not what an LDS- or VALU-bound kernel can reach).
  * No reference counterpart; bench.py reports it next to every LDS fraction. */
@@ -551,6 +551,48 @@ int lm_hip_max_f32(const float *scores, size_t rows, size_t stride, size_t cols,
                    int *found, float *value);
 int lm_hip_threshold_f32(const float *scores, size_t rows, size_t stride, size_t cols, float t,
                          lm_hip_coords **coords, size_t *n);
+/* Scanner (scan.rs:96-250) on a HOST StripedSequence: what `Dispatch::Hip` specialises `Scanner` onto instead of driving
+ * its 256-row block loop through the Score<u8> arm (a block is ~19 us of launch + link latency for 8 192 cells).  The striped
+ * matrix goes up once (1 B per position), then lm_hip_scan_f32 / lm_hip_scan_max_f32 run on it; same results, same
+ * conventions, same errors as those.  A host that scans one sequence with MANY motifs should upload it once
+ * (lm_hip_seq_upload) and use the resident forms. */
+int lm_hip_scan_f32_host(const uint8_t *seq, size_t seq_rows_total, size_t seq_stride, size_t cols,
+                         size_t wrap, size_t length,
+                         const float *pssm, size_t m, size_t pssm_stride, size_t k,
+                         float threshold, lm_hip_hit **hits, size_t *n);
+int lm_hip_scan_max_f32_host(const uint8_t *seq, size_t seq_rows_total, size_t seq_stride, size_t cols,
+                             size_t wrap, size_t length,
+                             const float *pssm, size_t m, size_t pssm_stride, size_t k,
+                             const uint8_t *dweights, size_t dweights_stride, int saturate, unsigned level,
+                             int have, size_t position, float score, size_t first_row,
+                             int *found, lm_hip_hit *best);
+
+/* ---- the `Dispatch::Hip` policy --------------------------------------------------------------------
+ *
+ * lightmotif/src/pli/dispatch.rs has seven `match self.backend` sites, and `Scanner` hard-codes `Pipeline<A, Dispatch>`
+ * (scan.rs:166).  A `Hip` variant must say what it does at EACH of them: a call on host matrices pays a launch, a
+ * synchronisation and the link both ways, so below some size -- and for operations that only move bytes -- the right arm is
+ * the CPU tier the variant carries (`Hip { cpu: Avx2 | Sse2 | Neon | Generic }` = what Pipeline::dispatch() would have
+ * picked without a GPU, pli/mod.rs:269-308), never `_ => Generic`.  lm_hip_host_crossover returns, per site, the number of
+ * cells (rows x columns of the call) from which the host-pointer entry point is expected to beat ONE thread of the AVX2
+ * tier: SIZE_MAX = the site stays on the CPU tier at every size (Encode, Stripe: one pass over bytes that a core streams
+ * faster than the link carries them; Maximum / Threshold on u8: Scanner-internal, specialised away), 0 = always the GPU.
+ * The constants are measured (tools/crossover.py on MI355X + EPYC 9575F, profiles/r05_crossover.json) and a function of
+ * the motif length where the CPU's cost is (Score: CPU time ~ M x cells, GPU time ~ latency + 5 B x cells / link). */
+typedef enum lm_hip_host_op {
+    LM_HIP_OP_ENCODE = 0,        /* Encode::encode_into           dispatch.rs:58-77   -> CPU tier            */
+    LM_HIP_OP_SCORE_F32 = 1,     /* Score<f32>::score_rows_into   dispatch.rs:79-108  -> lm_hip_score_f32     */
+    LM_HIP_OP_SCORE_U8 = 2,      /* Score<u8>::score_rows_into    dispatch.rs:110-137 -> lm_hip_score_u8_host */
+    LM_HIP_OP_STRIPE = 3,        /* Stripe::stripe_into           dispatch.rs:139-153 -> CPU tier            */
+    LM_HIP_OP_MAXIMUM_F32 = 4,   /* Maximum<f32>::argmax / max    dispatch.rs:155-179 -> lm_hip_argmax_f32 / lm_hip_max_f32 */
+    LM_HIP_OP_MAXIMUM_U8 = 5,    /* Maximum<u8>::argmax / max     dispatch.rs:181-205 -> CPU tier            */
+    LM_HIP_OP_THRESHOLD_F32 = 6, /* Threshold<f32>::threshold     dispatch.rs:205     -> lm_hip_threshold_f32 */
+    LM_HIP_OP_THRESHOLD_U8 = 7,  /* Threshold<u8>::threshold      dispatch.rs:207     -> CPU tier            */
+    LM_HIP_OP_SCAN = 8           /* Scanner::next / max           scan.rs:166-249     -> lm_hip_scan_f32_host / lm_hip_scan_max_f32_host */
+} lm_hip_host_op;
+/* m = motif length (0 where it plays no part), k = alphabet size.  LM_HIP_ERR_BAD_ARGS for an unknown op. */
+int lm_hip_host_crossover(int op, size_t m, size_t k, size_t *cells);
+
 /* Hands back what the host-pointer functions keep between calls: the pinned rings of the tile pipelines (128 MB of
  * page-locked memory per device used), their device tiles, and the device staging AND reduction scratch of this thread's
  * lane and of lanes whose threads have exited; lanes of other live threads hand theirs back at the end of their next

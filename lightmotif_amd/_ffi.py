@@ -134,6 +134,10 @@ SIGNATURES = {
     "lm_hip_argmax_f32": (C.c_int, [_vp, _sz, _sz, _sz, _ip, _cp, _fp]),
     "lm_hip_max_f32": (C.c_int, [_vp, _sz, _sz, _sz, _ip, _fp]),
     "lm_hip_threshold_f32": (C.c_int, [_vp, _sz, _sz, _sz, C.c_float, C.POINTER(_cp), _szp]),
+    "lm_hip_scan_f32_host": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _sz, _vp, _sz, _sz, _sz, C.c_float, C.POINTER(C.POINTER(Hit)), _szp]),
+    "lm_hip_scan_max_f32_host": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _sz, _vp, _sz, _sz, _sz, _vp, _sz, C.c_int, C.c_uint, C.c_int,
+                                           _sz, C.c_float, _sz, _ip, C.POINTER(Hit)]),
+    "lm_hip_host_crossover": (C.c_int, [C.c_int, _sz, _sz, _szp]),
     "lm_hip_host_trim": (C.c_int, []),
     "lm_hip_host_bind_thread": (C.c_int, [C.c_int]),
     "lm_hip_host_lane_info": (C.c_int, [_ip, _ip, _ip]),

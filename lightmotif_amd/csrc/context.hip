@@ -297,11 +297,11 @@ int lm_hip_device_clock_mhz(int device, unsigned window_us, double *mhz)
     LM_HIP_TRY(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, device));
     if (wall_khz <= 0)
         return fail(LM_HIP_ERR_HIP, "device_clock_mhz: the device reports no constant-rate counter");
-    int lo = 0, hi = 0;
     hipStream_t stream = nullptr;
     unsigned long long *rec = nullptr;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // `hi` = the numerically lowest = the greatest priority
-    hipError_t e = hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi);
+    // default priority: on a high-priority queue the probe's (long-lived) wavefront held back the dispatch of the
+    // kernels under measurement (round 5: 0.34 ms calls took 5 ms each beside it, and it reported the idle clock)
+    hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
     if (e == hipSuccess)
         e = hipHostMalloc(reinterpret_cast<void **>(&rec), 2 * sizeof(unsigned long long), hipHostMallocDefault);
     if (e == hipSuccess) {

@@ -1128,4 +1128,65 @@ int lm_hip_scan_max_f32_host(const uint8_t *seq, size_t seq_rows_total, size_t s
     });
 }
 
+// ---- the Dispatch::Hip policy: where a call on host matrices should go ------------------------------
+
+// Cost model behind lm_hip_host_crossover, constants measured by tools/crossover.py (profiles/r05_crossover.json: MI355X on
+// PCIe Gen5, 2 x EPYC 9575F; one CPU thread, as the reference gives a call):
+//   GPU call  ~ t0 + g * cells     t0 = launch + synchronisation + copy set-up of the copy path (calls above 128 KB;
+//                                  the zero-copy path below is cheaper but so is the CPU there), g = link bytes per cell
+//   CPU tier  ~ c * cells          Score: c = c_row * M (AVX2 f32 permute / u8 shuffle kernels), reductions: one pass
+// crossover = t0 / (c - g), never when the CPU's per-cell cost does not exceed the link's by a margin.
+namespace {
+struct HostCost {
+    double t0_us, gpu_ns, cpu_ns, cpu_ns_per_row;
+};
+//                                      t0 us  GPU ns/cell  CPU ns/cell  CPU ns/(cell x motif row)
+constexpr HostCost kCostScoreF32{45.0, 0.094, 0.0, 0.0314};      // 1 B up + 4 B down; AVX2 f32 permute kernel
+constexpr HostCost kCostScoreU8{55.0, 0.038, 0.0, 0.0071};       // 1 B up + 1 B down; AVX2 u8 shuffle kernel
+constexpr HostCost kCostMaximumF32{35.0, 0.078, 0.75, 0.0};      // 4 B up; the Generic scan (the rule the variant keeps, pli/mod.rs:135-160)
+constexpr HostCost kCostThresholdF32{55.0, 0.078, 0.42, 0.0};    // 4 B up; the default body (pli/mod.rs:210-221)
+constexpr HostCost kCostScan{70.0, 0.020, 0.03, 0.0071};         // 1 B up + the scan; the reference's block loop on the AVX2 tier
+constexpr double kCrossoverMargin = 1.25;  // the CPU must cost this much more per cell than the link before a call leaves it
+size_t crossover_cells(const HostCost &k, size_t m)
+{
+    const double c = k.cpu_ns + k.cpu_ns_per_row * (double)m;
+    if (c <= k.gpu_ns * kCrossoverMargin)
+        return SIZE_MAX;
+    const double cells = k.t0_us * 1e3 / (c - k.gpu_ns);
+    return cells >= 9e18 ? SIZE_MAX : (size_t)cells + 1;
+}
+}  // namespace
+
+int lm_hip_host_crossover(int op, size_t m, size_t k, size_t *cells)
+{
+    (void)k;
+    if (!cells)
+        return fail(LM_HIP_ERR_BAD_ARGS, "host_crossover: null output");
+    switch (op) {
+    case LM_HIP_OP_ENCODE:         // one LUT pass over bytes: a core streams them faster than the link carries them
+    case LM_HIP_OP_STRIPE:         // (1 B up + 1 B down); resident sequences are made by lm_hip_seq_from_ascii / _encoded
+    case LM_HIP_OP_MAXIMUM_U8:     // Scanner-internal (scan.rs:181-184): specialised away by LM_HIP_OP_SCAN
+    case LM_HIP_OP_THRESHOLD_U8:
+        *cells = SIZE_MAX;
+        return LM_HIP_OK;
+    case LM_HIP_OP_SCORE_F32:      // 1 B up + 4 B down per cell; AVX2: ~0.031 ns per cell and motif row
+        *cells = crossover_cells(kCostScoreF32, m);
+        return LM_HIP_OK;
+    case LM_HIP_OP_SCORE_U8:       // 1 B up + 1 B down; AVX2 shuffle kernel: ~0.007 ns per cell and motif row
+        *cells = crossover_cells(kCostScoreU8, m);
+        return LM_HIP_OK;
+    case LM_HIP_OP_MAXIMUM_F32:    // 4 B up per cell against the Generic scan (the rule the variant must keep: pli/mod.rs:135-160)
+        *cells = crossover_cells(kCostMaximumF32, 0);
+        return LM_HIP_OK;
+    case LM_HIP_OP_THRESHOLD_F32:  // 4 B up per cell against the default body (pli/mod.rs:210-221)
+        *cells = crossover_cells(kCostThresholdF32, 0);
+        return LM_HIP_OK;
+    case LM_HIP_OP_SCAN:           // 1 B up per cell + the scan, against the reference's block loop on the AVX2 tier
+        *cells = crossover_cells(kCostScan, m);
+        return LM_HIP_OK;
+    default:
+        return fail(LM_HIP_ERR_BAD_ARGS, "host_crossover: unknown operation %d", op);
+    }
+}
+
 }  // extern "C"

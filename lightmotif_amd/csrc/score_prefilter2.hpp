@@ -10,7 +10,7 @@
 //
 // so one row of (M'+1) u16 entries advances all in-flight outputs by two input rows: half
 // the LDS bytes and half the adds per position of the one-symbol prefilter, and a quarter
-// of the exact f32 kernel's.  The table has 25 rows for DNA (K = 5), ordered so that the 16
+// of the exact f32 kernel's.  The table has 25 live rows for DNA (K = 5), placed so that the 16
 // pairs without N occupy rows 0..15 -- distinct 16-byte LDS slots, conflict-free reads.
 //
 // Geometry.  The motif is padded to a length M' = 3 (mod 4) by leading all-zero rows, so
@@ -48,24 +48,78 @@ constexpr int prefilter2_ring(int m) { return prefilter2_mo(m) + 1; }   // input
 constexpr int prefilter2_npair(int m) { return prefilter2_ring(m) / 2; }
 // dwords per table row: 4 * odd >= NPAIR (rows 0..15 then sit in distinct 16-byte slots)
 constexpr int prefilter2_stride_dw(int m) { return 4 * (((prefilter2_npair(m) + 3) / 4) | 1); }
-// table rows = symbol pairs: 25 for DNA (K = 5), 441 for protein (K = 21).  Protein rows cannot be
-// conflict-free (441 rows, 16 slots): tools/kbench/lds_rows_bench measures 5.5 ns per wavefront read
-// against 3.5 ns for the 21 rows of the one-symbol prefilter -- but the pair scan needs half the reads.
-constexpr int prefilter2_rows(int ka) { return ka * ka; }
+// table rows = symbol pairs.  Protein (K = 21): 441 rows, a * 21 + b.  Protein rows cannot be conflict-free
+// (441 rows, 16 slots): tools/kbench/lds_rows_bench measures 5.5 ns per wavefront read against 3.5 ns for the 21
+// rows of the one-symbol prefilter -- but the pair scan needs half the reads.
+// DNA (K = 5): row(a, b) = 4 a + b', b' = b for A C T G and 20 for N -- ADDITIVE in the two symbols, so that a lane
+// can look both terms up in registers (dna_pair_offsets below).  The 16 pairs without N sit in rows 0..15 = distinct
+// 16-byte LDS slots (conflict-free reads); (N, b) in 16..19, (a, N) in 20, 24, 28, 32, (N, N) in 36; the other rows
+// of the 37 are never read.
+constexpr int prefilter2_rows(int ka) { return ka == 5 ? 37 : ka * ka; }
 constexpr int prefilter2_image_dw(int m, int ka = 5) { return prefilter2_rows(ka) * prefilter2_stride_dw(m); }
 
-// table row of the pair (a, b): the 16 pairs of A, C, T, G first
 __host__ __device__ __forceinline__ unsigned dna_pair_row(unsigned a, unsigned b)
 {
-    unsigned idx = 4u * a + b;  // a, b < 4: 0..15;  a == 4: 16..20
-    if (b == 4u && a != 4u)
-        idx = 21u + a;          // (a, N), a < 4: 21..24
-    return idx;
+    return 4u * a + (b == 4u ? 20u : b);
 }
 template <int KA>
 __host__ __device__ __forceinline__ unsigned pair_row(unsigned a, unsigned b)
 {
     return KA == 5 ? dna_pair_row(a, b) : a * (unsigned)KA + b;
+}
+
+// DNA decode in registers.  The lanes of a quad hold a 4 x 4 block of symbol bytes (lane q: row r + q, columns
+// 4i .. 4i+3).  Picking one symbol apart costs a DPP move + a bit-field extract, and the pair's row another five
+// operations -- together more than half of the scan's VALU work once the adds were halved (round 5 counters:
+// 18.4 VALU per super-step, 10 of them decode, LDS array busy 66 %).  Instead the quad TRANSPOSES its block (two DPP
+// moves + two v_perm_b32: every lane then holds the four rows of its OWN column in one dword), two more v_perm_b32
+// use that dword as a selector into byte tables -- 4 so a / so b' in units of 16 bytes, `so` = 16-byte slots per
+// table row -- and one shifted add leaves row(a, b) * so of the block's two pairs in bytes 0 and 2.  Eight
+// operations per four symbols, and the byte select rides on the shift that makes the LDS address (SDWA).
+// Needs 20 so + 16 so < 256: table rows of up to 7 slots (M' <= 55); longer motifs keep the one-by-one decode.
+constexpr bool prefilter2_lut_decode(int m, int ka) { return ka == 5 && prefilter2_stride_dw(m) / 4 <= 7; }
+
+struct QuadTranspose {  // per-lane selectors of the two v_perm_b32 steps (set once per kernel)
+    unsigned sel1, sel2;
+    unsigned four;  // the shift count of byte_times_16 (an SDWA operand must be a register)
+};
+__device__ __forceinline__ QuadTranspose quad_transpose_setup()
+{
+    const unsigned lane = threadIdx.x;
+    QuadTranspose qt;
+    qt.sel1 = (lane & 1u) ? 0x03070105u : 0x06020400u;
+    qt.sel2 = (lane & 2u) ? 0x03020706u : 0x05040100u;
+    qt.four = 4u;
+    return qt;
+}
+// lane q of a quad: dword = (row r + q; columns c0 .. c0 + 3)  ->  (rows r .. r + 3; column c0 + q)
+__device__ __forceinline__ unsigned quad_transpose(unsigned d, const QuadTranspose &qt)
+{
+    const unsigned x = (unsigned)__builtin_amdgcn_mov_dpp((int)d, 0xb1, 0xf, 0xf, true);  // quad_perm [1, 0, 3, 2]
+    const unsigned p = __builtin_amdgcn_perm(x, d, qt.sel1);
+    const unsigned y = (unsigned)__builtin_amdgcn_mov_dpp((int)p, 0x4e, 0xf, 0xf, true);  // quad_perm [2, 3, 0, 1]
+    return __builtin_amdgcn_perm(y, p, qt.sel2);
+}
+// bytes 0 / 2 = row(a, b) * SO of the pairs (rows 0, 1) / (rows 2, 3) of a transposed block; SO = 16-byte slots per row
+template <int SO>
+__device__ __forceinline__ unsigned dna_pair_offsets(unsigned t)
+{
+    constexpr unsigned A_LO = 0u | (4u * SO << 8) | (8u * SO << 16) | (12u * SO << 24), A_HI = 16u * SO;
+    constexpr unsigned B_LO = 0u | (1u * SO << 8) | (2u * SO << 16) | (3u * SO << 24), B_HI = 20u * SO;
+    const unsigned qa = __builtin_amdgcn_perm(A_HI, A_LO, t);  // byte k = 4 SO * symbol(row k)
+    const unsigned pb = __builtin_amdgcn_perm(B_HI, B_LO, t);  // byte k = SO * b'(row k)
+    return qa + (pb >> 8);  // no byte carries: every sum is below 256
+}
+// ((s >> 8 * BYTE) & 0xff) << 4 in ONE operation: the byte select rides on the shift (SDWA; hipcc emits and + shift)
+template <int BYTE>
+__device__ __forceinline__ unsigned byte_times_16(unsigned s, unsigned four)
+{
+    unsigned r;
+    if constexpr (BYTE == 0)
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(four), "v"(s));
+    else
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(four), "v"(s));
+    return r;
 }
 
 // Host side: the pair table from the unpadded discrete weights d[j * ka + s], j < m.
@@ -106,9 +160,12 @@ __device__ __forceinline__ void prefilter2_group(unsigned (&acc)[prefilter2_npai
                                                  unsigned (&blk)[prefilter2_ring(M) / 4],
                                                  const uint8_t *__restrict__ spq, const unsigned shq,
                                                  const char *__restrict__ tab, unsigned &mx,
+                                                 const QuadTranspose &qt,
                                                  uint8_t *__restrict__ op = nullptr,
                                                  const unsigned wrap_mask = 0)
 {
+    constexpr bool LUT = prefilter2_lut_decode(M, KA);
+    unsigned pair_off = 0;  // LUT: dna_pair_offsets of the current block
     const unsigned q = STORE ? (threadIdx.x & 3u) : 0u;
     uint8_t *oq = STORE ? op - q + q * 32 : nullptr;  // lane q of a quad writes row +q, the quad's 4 columns
     const unsigned sel_lo = 0x0c0c0000u | q | ((4u + q) << 8);
@@ -123,13 +180,20 @@ __device__ __forceinline__ void prefilter2_group(unsigned (&acc)[prefilter2_npai
     for (int k = 0; k < NP; ++k) {
         // this super-step's two symbols: rows 2k, 2k+1 of the group = block k/2, rows (2k)%4, +1
         const unsigned d = blk[k / 2];
-        const unsigned a = (k & 1) ? quad_symbol<2>(d, shq) : quad_symbol<0>(d, shq);
-        const unsigned b = (k & 1) ? quad_symbol<3>(d, shq) : quad_symbol<1>(d, shq);
+        unsigned row_off;
+        if constexpr (LUT) {
+            if ((k & 1) == 0)
+                pair_off = dna_pair_offsets<(int)(DSB / 16)>(quad_transpose(d, qt));
+            row_off = (k & 1) ? byte_times_16<2>(pair_off, qt.four) : byte_times_16<0>(pair_off, qt.four);
+        } else {
+            const unsigned a = (k & 1) ? quad_symbol<2>(d, shq) : quad_symbol<0>(d, shq);
+            const unsigned b = (k & 1) ? quad_symbol<3>(d, shq) : quad_symbol<1>(d, shq);
+            row_off = __umul24(pair_row<KA>(a, b), DSB);
+        }
         // a block is free once its second pair is taken: request the block PFB ahead
         if ((k & 1) && (PHASE != PHASE_LAST || k / 2 + PFB < NB))
             blk[(k / 2 + PFB) % NB] = *reinterpret_cast<const unsigned *>(spq + (k / 2 + PFB) * 128);
-        const unsigned idx = pair_row<KA>(a, b);
-        const char *row = static_cast<const char *>(__builtin_assume_aligned(tab + __umul24(idx, DSB), 16));
+        const char *row = static_cast<const char *>(__builtin_assume_aligned(tab + row_off, 16));
         unsigned w[NV * 4];
 #pragma unroll
         for (int q = 0; q < NP / 4; ++q) {
@@ -258,16 +322,17 @@ __global__ __launch_bounds__(kBlock, (KA == 5 && M <= kMaxFastM) ? 6 : M <= 52 ?
         }
     };
 
-    prefilter2_group<M, PFB, PHASE_FIRST, 0, KA>(acc, blk, spq, shq, lds_raw, mx);
+    const QuadTranspose qt = quad_transpose_setup();
+    prefilter2_group<M, PFB, PHASE_FIRST, 0, KA>(acc, blk, spq, shq, lds_raw, mx, qt);
     note_group();
     for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
         spq += RING * 32;
-        prefilter2_group<M, PFB, PHASE_MAIN, 0, KA>(acc, blk, spq, shq, lds_raw, mx);
+        prefilter2_group<M, PFB, PHASE_MAIN, 0, KA>(acc, blk, spq, shq, lds_raw, mx, qt);
         note_group();
     }
     if (ngroups > 1) {
         spq += RING * 32;
-        prefilter2_group<M, PFB, PHASE_LAST, 0, KA>(acc, blk, spq, shq, lds_raw, mx);
+        prefilter2_group<M, PFB, PHASE_LAST, 0, KA>(acc, blk, spq, shq, lds_raw, mx, qt);
         note_group();
     }
 
@@ -310,8 +375,11 @@ template <int M, int NM, int PFB, int PHASE>
 __device__ __forceinline__ void prefilter2_group_multi(unsigned (&acc)[NM][prefilter2_npair(M)],
                                                        unsigned (&blk)[prefilter2_ring(M) / 4],
                                                        const uint8_t *__restrict__ spq, const unsigned shq,
-                                                       const char *__restrict__ tab, unsigned (&mx)[NM])
+                                                       const char *__restrict__ tab, unsigned (&mx)[NM],
+                                                       const QuadTranspose &qt)
 {
+    constexpr bool LUT = prefilter2_lut_decode(M, 5);
+    unsigned pair_off = 0;
     constexpr int RING = prefilter2_ring(M);
     constexpr int NB = RING / 4;
     constexpr int NP = prefilter2_npair(M);
@@ -321,11 +389,19 @@ __device__ __forceinline__ void prefilter2_group_multi(unsigned (&acc)[NM][prefi
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const unsigned d = blk[k / 2];
-        const unsigned a = (k & 1) ? quad_symbol<2>(d, shq) : quad_symbol<0>(d, shq);
-        const unsigned b = (k & 1) ? quad_symbol<3>(d, shq) : quad_symbol<1>(d, shq);
+        unsigned row_off;
+        if constexpr (LUT) {
+            if ((k & 1) == 0)
+                pair_off = dna_pair_offsets<(int)(DSB / 16)>(quad_transpose(d, qt));
+            row_off = (k & 1) ? byte_times_16<2>(pair_off, qt.four) : byte_times_16<0>(pair_off, qt.four);
+        } else {
+            const unsigned a = (k & 1) ? quad_symbol<2>(d, shq) : quad_symbol<0>(d, shq);
+            const unsigned b = (k & 1) ? quad_symbol<3>(d, shq) : quad_symbol<1>(d, shq);
+            row_off = __umul24(dna_pair_row(a, b), DSB);
+        }
         if ((k & 1) && (PHASE != PHASE_LAST || k / 2 + PFB < NB))
             blk[(k / 2 + PFB) % NB] = *reinterpret_cast<const unsigned *>(spq + (k / 2 + PFB) * 128);
-        const char *row0 = tab + __umul24(dna_pair_row(a, b), DSB);
+        const char *row0 = tab + row_off;
 #pragma unroll
         for (int mi = 0; mi < NM; ++mi) {
             const char *row = static_cast<const char *>(__builtin_assume_aligned(row0 + mi * IMG, 16));
@@ -434,16 +510,17 @@ __global__ __launch_bounds__(kBlock, 4) void score_c32_prefilter2_multi(
             gbit <<= 1;
         }
     };
-    prefilter2_group_multi<M, NM, PFB, PHASE_FIRST>(acc, blk, spq, shq, lds_raw, mx);
+    const QuadTranspose qt = quad_transpose_setup();
+    prefilter2_group_multi<M, NM, PFB, PHASE_FIRST>(acc, blk, spq, shq, lds_raw, mx, qt);
     note_group();
     for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
         spq += RING * 32;
-        prefilter2_group_multi<M, NM, PFB, PHASE_MAIN>(acc, blk, spq, shq, lds_raw, mx);
+        prefilter2_group_multi<M, NM, PFB, PHASE_MAIN>(acc, blk, spq, shq, lds_raw, mx, qt);
         note_group();
     }
     if (ngroups > 1) {
         spq += RING * 32;
-        prefilter2_group_multi<M, NM, PFB, PHASE_LAST>(acc, blk, spq, shq, lds_raw, mx);
+        prefilter2_group_multi<M, NM, PFB, PHASE_LAST>(acc, blk, spq, shq, lds_raw, mx, qt);
         note_group();
     }
 

@@ -144,16 +144,17 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_u8_pairs(
     const unsigned long long ngroups = (T - 2) / RING + 1;  // exact: T = q*RING + 2
     uint8_t *op = out + (o0 - row_begin) * 32 + col;
     unsigned mx = 0;
-    prefilter2_group<M, PFB, PHASE_FIRST, 1>(acc, blk, spq, shq, lds_raw, mx, op, wrap_mask);
+    const QuadTranspose qt = quad_transpose_setup();
+    prefilter2_group<M, PFB, PHASE_FIRST, 1>(acc, blk, spq, shq, lds_raw, mx, qt, op, wrap_mask);
     op += 2 * 32;
     for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
         spq += RING * 32;
-        prefilter2_group<M, PFB, PHASE_MAIN, 1>(acc, blk, spq, shq, lds_raw, mx, op, wrap_mask);
+        prefilter2_group<M, PFB, PHASE_MAIN, 1>(acc, blk, spq, shq, lds_raw, mx, qt, op, wrap_mask);
         op += RING * 32;
     }
     if (ngroups > 1) {
         spq += RING * 32;
-        prefilter2_group<M, PFB, PHASE_LAST, 1>(acc, blk, spq, shq, lds_raw, mx, op, wrap_mask);
+        prefilter2_group<M, PFB, PHASE_LAST, 1>(acc, blk, spq, shq, lds_raw, mx, qt, op, wrap_mask);
     }
 }
 

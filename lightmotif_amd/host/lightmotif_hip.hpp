@@ -471,8 +471,8 @@ private:
 // The C++ twin of the Rust shim in INTEGRATION.md 2-4b.  `host::StripedSequence` / `host::StripedScores` are the
 // reference's own structs (seq.rs:288-294, scores.rs:102-107) with their data in ordinary host memory, striped and wrapped
 // by the Generic loops (pli/mod.rs:178-200, seq.rs:362-381) -- what a Rust caller holds when `Dispatch::Hip` is asked to
-// score.  `HipDispatch` binds exactly the host-pointer entry points that shim binds, with the same resize-then-call
-// order (avx2.rs:839-844), so the functions behind a `Dispatch::Hip` arm are exercised from compiled host code.
+// score.  `Hip` binds exactly the host-pointer entry points that shim binds, with the same resize-then-call order
+// (avx2.rs:839-844); `HipDispatch<Cpu>` is the `Dispatch::Hip { cpu }` variant: the arm table with its size policy.
 
 namespace host {
 
@@ -555,7 +555,9 @@ private:
 
 }  // namespace host
 
-struct HipDispatch {
+// The back-end marker and its associated functions (`impl Hip { ... }` of INTEGRATION.md 2, cf. `Avx2` in
+// platform/avx2.rs): the raw host-pointer bindings, no policy.
+struct Hip {
     // Hip::available(): `Pipeline::hip()` mirrors `Pipeline::avx2()` (pli/mod.rs:401-407)
     static bool available()
     {
@@ -639,6 +641,238 @@ struct HipDispatch {
             out.push_back(MatrixCoordinates{c[i].row, c[i].col});
         lm_hip_free(c);
         return out;
+    }
+    // Scanner (scan.rs:96-250) on a host sequence: every hit (score >= t, position + M <= L), ascending position
+    struct Hit {
+        size_t position;
+        float score;
+    };
+    template <class A>
+    static std::vector<Hit> scan(const ScoringMatrix<A> &pssm, const host::StripedSequence<A> &seq, float threshold)
+    {
+        const DenseMatrix<float> &w = pssm.matrix();
+        const DenseMatrix<uint8_t> &m = seq.matrix();
+        lm_hip_hit *h = nullptr;
+        size_t n = 0;
+        check(lm_hip_scan_f32_host(m.ptr(), m.rows(), m.stride(), seq.columns(), seq.wrap(), seq.len(), w.ptr(), w.rows(),
+                                   w.stride(), A::K, threshold, &h, &n));
+        std::vector<Hit> out(n);
+        for (size_t i = 0; i < n; ++i)
+            out[i] = Hit{h[i].position, h[i].score};
+        lm_hip_free(h);
+        return out;
+    }
+    // Scanner::max as the reference walks it (scan.rs:200-249) on a fresh scanner
+    template <class A>
+    static std::optional<Hit> scan_max(const ScoringMatrix<A> &pssm, const host::StripedSequence<A> &seq, float threshold,
+                                       bool saturate = true)
+    {
+        const DiscreteMatrix<A> dm = pssm.to_discrete();
+        const DenseMatrix<float> &w = pssm.matrix();
+        const DenseMatrix<uint8_t> &m = seq.matrix();
+        int found = 0;
+        lm_hip_hit best{0, 0.0f};
+        check(lm_hip_scan_max_f32_host(m.ptr(), m.rows(), m.stride(), seq.columns(), seq.wrap(), seq.len(), w.ptr(), w.rows(),
+                                       w.stride(), A::K, dm.data.ptr(), dm.data.stride(), saturate ? 1 : 0, dm.scale(threshold), 0,
+                                       0, 0.0f, 0, &found, &best));
+        return found ? std::optional<Hit>(Hit{best.position, best.score}) : std::nullopt;
+    }
+};
+
+// ---- enum Dispatch { ..., Hip { cpu } } ---------------------------------------------------------------
+//
+// The complete arm table of lightmotif/src/pli/dispatch.rs:58-207 + Scanner (scan.rs:166-249) for a `Hip` variant
+// (INTEGRATION.md 3).  The variant CARRIES the CPU tier `Pipeline::dispatch()` would have picked without a GPU
+// (pli/mod.rs:269-308) and hands a call to it where the GPU cannot win: operations that only move bytes (Encode, Stripe),
+// the Scanner-internal u8 reductions, and any call below the measured crossover (lm_hip_host_crossover).  In the Rust
+// shim the tier is the reference's own Avx2 / Sse2 / Neon / Generic marker; in this C++ twin it is a template parameter
+// with the trait methods' names -- this header ships NO CPU scoring code (there is no CPU fallback in the product: without a
+// device `Hip::available()` is false and the variant is never constructed).  `Cpu` provides:
+//
+//   static constexpr bool saturating_u8;                       // Score<u8> saturates (avx2.rs:336) or wraps (Generic)
+//   encode_into<A>(text, dst) / stripe_into<A>(encoded, striped)
+//   score_rows_into(pssm | dm, seq, rb, re, scores)            // f32: every tier is bit-identical to Generic
+//   argmax / max (f32): MUST be the Generic rule (pli/mod.rs:135-160) -- Avx2::argmax_f32 differs on ties and
+//                      Avx2::max_f32 seeds with 0.0 (avx2.rs:351-441), and a variant has to give ONE answer at every size
+//   threshold (f32), argmax / max / threshold (u8)
+//   scan / scan_max: the reference's Scanner loop over the tier (scan.rs:169-249)
+enum class Route { Cpu, Gpu };
+
+struct HipPolicy {
+    // cells (rows x columns of the call) from which the site goes to the GPU; SIZE_MAX = never, 0 = always
+    size_t cells(lm_hip_host_op op, size_t m, size_t k) const
+    {
+        if (forced[op] != kUnset)
+            return forced[op];
+        size_t c = 0;
+        check(lm_hip_host_crossover((int)op, m, k, &c));
+        return c;
+    }
+    void force(lm_hip_host_op op, size_t cells) { forced[op] = cells; }   // tests / embedders with their own numbers
+    void reset(lm_hip_host_op op) { forced[op] = kUnset; }
+    static constexpr size_t kUnset = (size_t)-2;
+    std::array<size_t, 9> forced{kUnset, kUnset, kUnset, kUnset, kUnset, kUnset, kUnset, kUnset, kUnset};
+};
+
+template <class Cpu>
+class HipDispatch {
+public:
+    using Hit = Hip::Hit;
+    explicit HipDispatch(Cpu tier = Cpu()) : cpu(std::move(tier))
+    {
+        if (!Hip::available())  // Pipeline::hip() -> Err(UnsupportedBackend) (pli/mod.rs:401-407): never a silent CPU-only variant
+            throw UnsupportedBackend("no gfx950 device");
+    }
+    Cpu cpu;
+    HipPolicy policy;
+    mutable Route last_route = Route::Cpu;   // where the last call went
+    mutable size_t calls_cpu = 0, calls_gpu = 0;
+
+    // Encode<A> (dispatch.rs:58-77): the CPU tier, at every size -- a LUT pass over bytes a core streams faster than the
+    // link carries them (1 B up + 1 B down).  (Host text that should END UP on the device: lm_hip_seq_from_ascii.)
+    template <class A>
+    void encode_into(const std::string &text, std::vector<uint8_t> &dst) const
+    {
+        went(Route::Cpu);
+        cpu.template encode_into<A>(text, dst);
+    }
+    // Stripe<A, C> (dispatch.rs:139-153): the CPU tier, same argument (lm_hip_seq_from_encoded for resident sequences)
+    template <class A>
+    void stripe_into(const EncodedSequence<A> &seq, host::StripedSequence<A> &striped) const
+    {
+        went(Route::Cpu);
+        cpu.template stripe_into<A>(seq, striped);
+    }
+    // Score<f32, A, C> (dispatch.rs:79-108)
+    template <class A>
+    void score_rows_into(const ScoringMatrix<A> &pssm, const host::StripedSequence<A> &seq, size_t row_begin, size_t row_end,
+                         host::StripedScores<float> &scores) const
+    {
+        const size_t cells = row_end > row_begin ? (row_end - row_begin) * seq.columns() : 0;
+        if (cells < policy.cells(LM_HIP_OP_SCORE_F32, pssm.len(), A::K)) {
+            went(Route::Cpu);
+            cpu.score_rows_into(pssm, seq, row_begin, row_end, scores);
+        } else {
+            went(Route::Gpu);
+            Hip::score_rows_into(pssm, seq, row_begin, row_end, scores);
+        }
+    }
+    template <class A>
+    host::StripedScores<float> score(const ScoringMatrix<A> &pssm, const host::StripedSequence<A> &seq) const
+    {
+        host::StripedScores<float> scores(seq.columns());
+        score_rows_into(pssm, seq, 0, seq.matrix().rows() - seq.wrap(), scores);  // pli/mod.rs:115-116
+        return scores;
+    }
+    // Score<u8, Dna, C> (dispatch.rs:110-137): the tier's own overflow rule travels with the call
+    template <class A>
+    void score_rows_into(const DiscreteMatrix<A> &dm, const host::StripedSequence<A> &seq, size_t row_begin, size_t row_end,
+                         host::StripedScores<uint8_t> &scores) const
+    {
+        const size_t cells = row_end > row_begin ? (row_end - row_begin) * seq.columns() : 0;
+        if (cells < policy.cells(LM_HIP_OP_SCORE_U8, dm.len(), A::K)) {
+            went(Route::Cpu);
+            cpu.score_rows_into(dm, seq, row_begin, row_end, scores);
+        } else {
+            went(Route::Gpu);
+            Hip::score_rows_into(dm, seq, row_begin, row_end, scores, Cpu::saturating_u8);
+        }
+    }
+    // Maximum<f32, C> (dispatch.rs:155-179)
+    std::optional<MatrixCoordinates> argmax(const host::StripedScores<float> &scores) const
+    {
+        if (cells_of(scores) < policy.cells(LM_HIP_OP_MAXIMUM_F32, 0, 0)) {
+            went(Route::Cpu);
+            return cpu.argmax(scores);
+        }
+        went(Route::Gpu);
+        return Hip::argmax(scores);
+    }
+    std::optional<float> max(const host::StripedScores<float> &scores) const
+    {
+        if (cells_of(scores) < policy.cells(LM_HIP_OP_MAXIMUM_F32, 0, 0)) {
+            went(Route::Cpu);
+            return cpu.max(scores);
+        }
+        went(Route::Gpu);
+        return Hip::max(scores);
+    }
+    // Threshold<f32, C> (dispatch.rs:205: today an empty impl = the default body, pli/mod.rs:210-221)
+    std::vector<MatrixCoordinates> threshold(const host::StripedScores<float> &scores, float t) const
+    {
+        if (cells_of(scores) < policy.cells(LM_HIP_OP_THRESHOLD_F32, 0, 0)) {
+            went(Route::Cpu);
+            return cpu.threshold(scores, t);
+        }
+        went(Route::Gpu);
+        return Hip::threshold(scores, t);
+    }
+    // Maximum<u8, C> / Threshold<u8, C> (dispatch.rs:181-207): the CPU tier.  Their only caller is the Scanner's block loop
+    // (scan.rs:181-184), which this variant replaces as a whole below; a stray call on a host u8 matrix is one pass over
+    // 1 B per cell.
+    std::optional<MatrixCoordinates> argmax(const host::StripedScores<uint8_t> &scores) const
+    {
+        went(Route::Cpu);
+        return cpu.argmax(scores);
+    }
+    std::optional<uint8_t> max(const host::StripedScores<uint8_t> &scores) const
+    {
+        went(Route::Cpu);
+        return cpu.max(scores);
+    }
+    std::vector<MatrixCoordinates> threshold(const host::StripedScores<uint8_t> &scores, uint8_t t) const
+    {
+        went(Route::Cpu);
+        return cpu.threshold(scores, t);
+    }
+    // Scanner (scan.rs:166 hard-codes Pipeline<A, Dispatch>): with `Hip` the iterator is SPECIALISED -- the whole scan is
+    // one lm_hip_scan_f32_host (upload + prefilter scan + exact re-scoring), the hits are yielded in the reference's
+    // own order (blocks ascending, last row-major hit of a block first: scan.rs:184-198) -- instead of driving 256-row
+    // blocks through the Score<u8> arm.  Small sequences stay on the tier's Scanner.
+    template <class A>
+    std::vector<Hit> scan(const ScoringMatrix<A> &pssm, const host::StripedSequence<A> &seq, float threshold,
+                          size_t block_size = 256) const
+    {
+        const size_t rows = seq.matrix().rows() - seq.wrap();
+        if (rows * seq.columns() < policy.cells(LM_HIP_OP_SCAN, pssm.len(), A::K)) {
+            went(Route::Cpu);
+            return cpu.scan(pssm, seq, threshold, block_size);
+        }
+        went(Route::Gpu);
+        std::vector<Hit> hits = Hip::scan(pssm, seq, threshold);
+        if (rows == 0 || block_size == 0)
+            return hits;
+        std::sort(hits.begin(), hits.end(), [=](const Hit &a, const Hit &b) {
+            const size_t ra = a.position % rows, rb = b.position % rows;
+            if (ra / block_size != rb / block_size)
+                return ra / block_size < rb / block_size;
+            if (ra != rb)
+                return ra > rb;
+            return a.position / rows > b.position / rows;
+        });
+        return hits;
+    }
+    // Scanner::max (scan.rs:200-249), quirks included, on a fresh scanner
+    template <class A>
+    std::optional<Hit> scan_max(const ScoringMatrix<A> &pssm, const host::StripedSequence<A> &seq, float threshold,
+                                size_t block_size = 256) const
+    {
+        const size_t rows = seq.matrix().rows() - seq.wrap();
+        if (rows * seq.columns() < policy.cells(LM_HIP_OP_SCAN, pssm.len(), A::K)) {
+            went(Route::Cpu);
+            return cpu.scan_max(pssm, seq, threshold, block_size);
+        }
+        went(Route::Gpu);
+        return Hip::scan_max(pssm, seq, threshold, Cpu::saturating_u8);
+    }
+
+private:
+    template <class T>
+    static size_t cells_of(const host::StripedScores<T> &s) { return s.matrix().rows() * s.matrix().columns(); }
+    void went(Route r) const
+    {
+        last_route = r;
+        ++(r == Route::Cpu ? calls_cpu : calls_gpu);
     }
 };
 

@@ -435,10 +435,10 @@ static void test_resident_flow(const Pipeline<Dna> &pli)
 
 // lightmotif/tests/dna.rs as it would run with `Dispatch::Hip` selected: the sequence, the PSSM and the scores are the
 // reference's own HOST structs (striped and wrapped by the Generic loops), and every call goes through the host-pointer
-// entry points the Rust shim of INTEGRATION.md binds (`HipDispatch` = its C++ twin).
+// entry points the Rust shim of INTEGRATION.md binds (`Hip` = the C++ twin of its `impl Hip`).
 static void test_dispatch_hip_on_host_matrices(size_t columns)
 {
-    CHECK(HipDispatch::available());
+    CHECK(Hip::available());
     const auto encoded = EncodedSequence<Dna>::encode(SEQUENCE);
     auto striped = host::StripedSequence<Dna>::stripe(encoded, columns);
     const auto pssm = golden_pssm();
@@ -448,49 +448,49 @@ static void test_dispatch_hip_on_host_matrices(size_t columns)
     // tests/dna.rs:40-63 test_score_rows
     host::StripedScores<float> part(columns);
     const size_t rows = (64 + columns - 1) / columns;
-    HipDispatch::score_rows_into(pssm, striped, 0, std::min<size_t>(2, rows), part);
+    Hip::score_rows_into(pssm, striped, 0, std::min<size_t>(2, rows), part);
     CHECK(part.matrix().rows() == std::min<size_t>(2, rows));
     CHECK(part.matrix()(0, 0) == EXPECTED[0]);
     if (rows > 1) {
         CHECK(part.matrix()(1, 0) == EXPECTED[1]);
-        HipDispatch::score_rows_into(pssm, striped, 1, 2, part);
+        Hip::score_rows_into(pssm, striped, 1, 2, part);
         CHECK(part.matrix().rows() == 1 && part.matrix()(0, 0) == EXPECTED[1]);
     }
-    HipDispatch::score_rows_into(pssm, striped, 1, 1, part);         // pli/mod.rs:603-623: an empty range resizes to nothing
+    Hip::score_rows_into(pssm, striped, 1, 1, part);         // pli/mod.rs:603-623: an empty range resizes to nothing
     CHECK(part.matrix().rows() == 0 && part.max_index() == 0);
 
     // tests/dna.rs:65-91 test_score
-    const auto result = HipDispatch::score(pssm, striped);
+    const auto result = Hip::score(pssm, striped);
     const auto scores = result.unstripe();
     CHECK(scores.size() == 50);
     for (size_t i = 0; i < scores.size() && i < 50; ++i)
         CHECK(std::fabs(scores[i] - EXPECTED[i]) < 1e-5f);
 
     // tests/dna.rs:123-139 test_argmax, scores.rs:181-192
-    const auto mc = HipDispatch::argmax(result);
+    const auto mc = Hip::argmax(result);
     CHECK(mc.has_value() && result.offset(*mc) == 18);
-    const auto top = HipDispatch::max(result);
+    const auto top = Hip::max(result);
     CHECK(top.has_value() && std::fabs(*top - (-5.50167f)) < 1e-5f);
 
     // tests/dna.rs:141-173 test_threshold
     std::vector<size_t> indices;
-    for (const auto &c : HipDispatch::threshold(result, -10.0f))
+    for (const auto &c : Hip::threshold(result, -10.0f))
         indices.push_back(result.offset(c));
     if (columns == 32)
         CHECK((indices == std::vector<size_t>{18, 32, 27}));         // the reference's row-major push order, unsorted
     std::sort(indices.begin(), indices.end());
     CHECK((indices == std::vector<size_t>{18, 27, 32}));
     indices.clear();
-    for (const auto &c : HipDispatch::threshold(result, -15.0f))
+    for (const auto &c : Hip::threshold(result, -15.0f))
         indices.push_back(result.offset(c));
     std::sort(indices.begin(), indices.end());
     CHECK((indices == std::vector<size_t>{10, 13, 14, 18, 24, 27, 32, 35, 40, 47}));
-    CHECK(HipDispatch::threshold(result, 10.0f).empty());
+    CHECK(Hip::threshold(result, 10.0f).empty());
 
     // tests/dna.rs:93-120 test_score_discrete: unscale(u8 score) >= the f32 score, position by position
     const auto dm = pssm.to_discrete();
     host::StripedScores<uint8_t> dscores(columns);
-    HipDispatch::score_rows_into(dm, striped, 0, striped.matrix().rows() - striped.wrap(), dscores);
+    Hip::score_rows_into(dm, striped, 0, striped.matrix().rows() - striped.wrap(), dscores);
     const auto d = dscores.unstripe();
     CHECK(d.size() == 50);
     for (size_t i = 0; i < d.size() && i < 50; ++i)
@@ -499,12 +499,12 @@ static void test_dispatch_hip_on_host_matrices(size_t columns)
     // a sequence shorter than the motif: Ok, nothing scored (pli/mod.rs:85-88); too few wrap rows: the reference panics
     auto tiny = host::StripedSequence<Dna>::stripe(EncodedSequence<Dna>::encode("ACGT"), columns);
     tiny.configure(pssm);
-    const auto none = HipDispatch::score(pssm, tiny);
-    CHECK(none.matrix().rows() == 0 && !HipDispatch::argmax(none).has_value());
+    const auto none = Hip::score(pssm, tiny);
+    CHECK(none.matrix().rows() == 0 && !Hip::argmax(none).has_value());
     auto bare = host::StripedSequence<Dna>::stripe(encoded, columns);   // no configure(): wrap = 0
     bool threw = false;
     try {
-        (void)HipDispatch::score(pssm, bare);
+        (void)Hip::score(pssm, bare);
     } catch (const std::runtime_error &e) {
         threw = std::string(e.what()).find("wrapping rows") != std::string::npos;   // avx2.rs:832-837
     }
@@ -527,17 +527,17 @@ static void test_argmax_property_dispatch_hip(size_t columns)
     auto striped = host::StripedSequence<Dna>::stripe(EncodedSequence<Dna>::encode(seq), columns);
     const auto pssm = golden_pssm();
     striped.configure(pssm);
-    const auto scores = HipDispatch::score(pssm, striped);
+    const auto scores = Hip::score(pssm, striped);
     const auto flat = scores.unstripe();
     CHECK(flat.size() == n - 15 + 1);
     size_t best = 0;
     for (size_t i = 1; i < flat.size(); ++i)
         if (!(flat[i] < flat[best]))   // max_by keeps the last of equal elements
             best = i;
-    const auto m = HipDispatch::argmax(scores);
+    const auto m = Hip::argmax(scores);
     CHECK(m.has_value() && scores.offset(*m) == best && best == 391677);
     CHECK(m.has_value() && scores.matrix()(m->row, m->col) == flat[best]);
-    const auto top = HipDispatch::max(scores);
+    const auto top = Hip::max(scores);
     CHECK(top.has_value() && *top == flat[best]);
 }
 

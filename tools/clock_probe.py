@@ -35,7 +35,7 @@ def sysfs_clocks():
     return out
 
 
-def clock_under(L, load, seconds=0.6, window_us=20_000):
+def clock_under(L, load, seconds=0.6, window_us=5_000):
     """load(): enqueues ~a few ms of work and returns without waiting; the main thread keeps it queued for `seconds`
     while a second thread takes windows of the shader clock."""
     samples, stop = [], threading.Event()
@@ -51,6 +51,16 @@ def clock_under(L, load, seconds=0.6, window_us=20_000):
     while time.perf_counter() - t0 < 0.3:
         load()
         torch.cuda.synchronize()
+    # the same loop without the probe: the probe must not change what it measures
+    t0 = time.perf_counter()
+    n0 = 0
+    while time.perf_counter() - t0 < 0.3:
+        load()
+        n0 += 1
+        if n0 % 4 == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    alone_ms = (time.perf_counter() - t0) / n0 * 1e3
     th = threading.Thread(target=sampler)
     th.start()
     t0 = time.perf_counter()
@@ -67,7 +77,7 @@ def clock_under(L, load, seconds=0.6, window_us=20_000):
     s = np.asarray(samples[1:-1] if len(samples) > 4 else samples)
     return {"mhz_median": round(float(np.median(s)), 1) if len(s) else None,
             "mhz_min": round(float(s.min()), 1) if len(s) else None, "mhz_max": round(float(s.max()), 1) if len(s) else None,
-            "windows": int(len(s)), "calls": n, "ms_per_call": round(wall / n * 1e3, 4)}
+            "windows": int(len(s)), "calls": n, "ms_per_call": round(wall / n * 1e3, 4), "ms_per_call_without_probe": round(alone_ms, 4)}
 
 
 def main():
