@@ -321,7 +321,19 @@ C3_LDS_MODEL = ("pair-prefilter scans (score_prefilter2.hpp): one LDS table row 
                 "whole call on the wall clock (re-scoring, ordering and read-back of the hits included)")
 
 
-def fused_roofline(ms: float, rows: int, m: int, kernel: str) -> dict:
+def at_sustained_clock(mhz: float, lds_bytes_per_s: float, valu_lane_ops_per_s: float, valu_model: str) -> dict:
+    """The LDS and VALU fractions of a kernel at the shader clock it was MEASURED to sustain (marks in the stream,
+    lm_hip_ctx_clock_begin / _end): 256 B/clk/CU of LDS reads and 64 lanes/clk/CU of 32-bit VALU issue on 256 CUs."""
+    if not mhz or mhz <= 0:
+        return {"sclk_mhz_sustained": None}
+    hz = mhz * 1e6
+    return {"sclk_mhz_sustained": round(mhz, 1),
+            "lds_frac_at_sustained_clock": round(lds_bytes_per_s / (256 * 256 * hz), 4),
+            "valu_frac_at_sustained_clock": round(valu_lane_ops_per_s / (256 * 64 * hz), 4),
+            "valu_model": valu_model + "; 64 lanes/clk/CU x 256 CUs"}
+
+
+def fused_roofline(ms: float, rows: int, m: int, kernel: str, mhz: float = 0.0) -> dict:
     """A fused score+argmax / score+threshold call over `rows` x 32 positions, whole call on the wall clock (scan, re-scoring,
     reductions, read-back).  SURVEY 8(d): no score matrix is written, so the binding ceiling is the LDS gather -- here the
     pair table's (M | 3) + 1 bytes per position (score_prefilter2.hpp) against 256 B/clk/CU x 256 CUs x 2.4 GHz; the one
@@ -332,7 +344,12 @@ def fused_roofline(ms: float, rows: int, m: int, kernel: str) -> dict:
             "roofline": {"bound": "lds", "achieved": round(lds / 1e12, 2), "peak": round(LDS_PEAK_BYTES_PER_S / 1e12, 1),
                          "unit": "TB/s", "frac": round(lds / LDS_PEAK_BYTES_PER_S, 4),
                          "lds_bytes_per_position": (m | 3) + 1, "hbm_read_gbs": round(ach, 1),
-                         "hbm_read_frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_hbm_bytes_per_call": rows * COLS}}
+                         "hbm_read_frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_hbm_bytes_per_call": rows * COLS,
+                         # the pair scan's issue per position and lane: (NP + 1) accumulate operations + 6 of decode per
+                         # pair of super-steps = 4 positions (score_prefilter2.hpp), NP = ((M | 3) + 1) / 2
+                         **at_sustained_clock(mhz, lds, (((m | 3) + 1) // 2 + 7) / 4 * rows * COLS / (ms * 1e-3),
+                                              f"{(((m | 3) + 1) // 2 + 7) / 4:.2f} VALU operations per position "
+                                              "(v_add3_u32 accumulation + register decode of the pair scan)")}}
 
 
 def lds_roofline(lds_bytes: float, seconds: float, note: str) -> dict:
@@ -653,6 +670,7 @@ def secondary_configs(pli, dev) -> dict:
     c1.update(hpb.bench_c1())
     c1.update(hpb.bench_block())
     out["c1"] = c1
+    out["readme_10kb"] = hpb.bench_readme_10kb()
 
     # --- the reference's own published benchmark (README.md:102-108): `score` of MX000001 (M = 15) over
     # the WHOLE E. coli K12 genome, 4 641 652 bp -- AVX2 4.51 ms, Generic 317.7 ms on an i7-10710U, one thread.  The genome
@@ -957,6 +975,20 @@ def main() -> None:
             best = dt if best is None else min(best, dt)
         return best, out
 
+    # The shader clock each kind of call sustains: marks IN the stream around a batch of launches (lm_hip_ctx_clock_begin /
+    # _end), after the timed region.  The part clocks to its power budget, so every LDS / VALU fraction below is also
+    # quoted at this clock, not only at the 2.4 GHz of the data sheet.
+    def sustained_clock(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        pli.clock_begin()
+        for _ in range(reps):
+            fn()
+        mhz, us = pli.clock_end()
+        return mhz, us / reps / 1e3
+
+    store_mhz, store_clock_ms = sustained_clock(lambda: pli.score_into(pssm, seq, scores_h), max(args.steps, 50))
+
     sc_ptr = scores_h.data_ptr
     am_ms, am = timed(lambda: pli.argmax_dptr(sc_ptr, rows, COLS, COLS, first_cell_rule=rank == 0))
     fam_ms, fam = timed(lambda: pli.score_argmax_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS,
@@ -978,6 +1010,10 @@ def main() -> None:
                                                           m - 1, total_length, 0, rows, thr_t), reps=5)
     fth_kernel = pli.last_kernel
     assert np.array_equal(hits, fhits[0]), "fused threshold differs from materialised threshold"
+    fam_mhz, _ = sustained_clock(lambda: pli.score_argmax_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS, m - 1,
+                                                               total_length, 0, rows, first_cell_rule=rank == 0), 20)
+    fth_mhz, _ = sustained_clock(lambda: pli.score_threshold_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS, m - 1,
+                                                                  total_length, 0, rows, thr_t), 20)
     mt_ms, all_hits = timed(lambda: (comm.merge_threshold(hits, row0) if comm is not None else
                                      D.merge_threshold(hits, row0, device=coll_dev)), reps=3)
     # the same list through the other transport (one timed merge per variant of the step)
@@ -1063,6 +1099,9 @@ def main() -> None:
             "frac_of_measured_copy": round(achieved / 6290.0, 4),   # MI355X_MICROARCH.md: best measured copy 6.29 TB/s
             "lds_frac": round(lds_bytes_per_s / LDS_PEAK_BYTES_PER_S, 4),
             "lds_note": f"secondary ceiling: {4 * m} B of LDS gathers per position against 256 B/clk/CU x 256 CUs x 2.4 GHz",
+            **at_sustained_clock(store_mhz, lds_bytes_per_s, m * rows * COLS / (kernel_avg_ms * 1e-3),
+                                 f"{m} v_add_f32 per position (the algorithm's adds alone)"),
+            "clock_pass_kernel_ms": round(store_clock_ms, 4),
         },
         "extras": {
             "argmax_ms": round(am_ms, 4), "fused_score_argmax_ms": round(fam_ms, 4),
@@ -1074,8 +1113,8 @@ def main() -> None:
             "kernel_ms_min": round(min(kernel_ms), 4), "kernel_ms_max": round(max(kernel_ms), 4),
             # the fused forms never write the score matrix -- priced against the LDS-gather ceiling (the pair
             # table's (M | 3) + 1 bytes per position), the 1 B per position of HBM reads beside it
-            "fused_score_argmax": fused_roofline(fam_ms, rows, m, fam_kernel),
-            "fused_score_threshold": fused_roofline(fth_ms, rows, m, fth_kernel),
+            "fused_score_argmax": fused_roofline(fam_ms, rows, m, fam_kernel, fam_mhz),
+            "fused_score_threshold": fused_roofline(fth_ms, rows, m, fth_kernel, fth_mhz),
             "merge_threshold_ms_torch": round(mt_torch_ms, 4),
             "merge_us": (None if not rank_merge else
                          {"p50": round(float(np.median([x[0] for x in rank_merge])), 1),
@@ -1091,6 +1130,7 @@ def main() -> None:
     if world == 1 and not args.no_extras:
         out["extras"]["end_to_end"] = end_to_end(shard, rows, m, total_length, pssm, scores_h, dev)
         out["extras"]["configs"] = secondary_configs(pli, dev)
+        out["extras"]["crossover_positions"] = host_pointer_bench().crossover_positions()
     elif c3_sharded is not None:
         out["extras"]["configs"] = {"c3": c3_sharded}
     if not args.no_cpu_baseline:

@@ -104,6 +104,13 @@ int lm_hip_result_pool_info(size_t *pinned_idle, size_t *pinned_in_use, size_t *
  * budget; a roofline priced at the 2.4 GHz of the data sheet is not what an LDS- or VALU-bound kernel can reach).
  * No reference counterpart; bench.py reports it next to every LDS fraction. */
 int lm_hip_device_clock_mhz(int device, unsigned window_us, double *mhz);
+/* The same two counters read IN the context's stream: `begin` enqueues a one-wavefront kernel that records them, `end`
+ * enqueues a second one, waits for it and returns the mean shader clock (MHz) and the elapsed time (us) of everything
+ * the stream ran in between -- the clock the bracketed kernels got, with no second queue beside them (a probe on a
+ * stream of its own slowed synchronising callers: profiles/r05_clock_probe.json).  One bracket at a time per context;
+ * LM_HIP_ERR_BAD_ARGS for `end` without `begin`.  Either output may be NULL. */
+int lm_hip_ctx_clock_begin(lm_hip_ctx *ctx);
+int lm_hip_ctx_clock_end(lm_hip_ctx *ctx, double *mhz, double *elapsed_us);
 
 /* DenseMatrix::stride (dense.rs:126-128) for x86-64 hosts: elements per row. */
 size_t lm_hip_stride(size_t cols, size_t elem_size);
@@ -153,6 +160,11 @@ int lm_hip_ctx_set_option(lm_hip_ctx *ctx, const char *name, double value);
  * 2 fused threshold); the store kernel's tracking forms (lm_hip_ctx_set_track_argmax:
  * template modes 3 and 5 in a rocprofv3 trace) report as "score_c32<M,0>". */
 const char *lm_hip_ctx_last_kernel(lm_hip_ctx *ctx);
+/* Diagnostic: what the last fused threshold scan on this context (single or batched) produced -- hits, and CANDIDATES: the
+ * pieces of up to 32 rows the discrete prefilter flagged for exact re-scoring.  Candidates per hit is how much a
+ * sequence costs beyond the scan itself (low-complexity tracts and N runs raise it: profiles/r05_realistic_inputs.json).
+ * Either output may be NULL. */
+int lm_hip_ctx_last_scan_counts(lm_hip_ctx *ctx, unsigned long long *hits, unsigned long long *candidates);
 
 /* ---- PSSM ---------------------------------------------------------------- */
 

@@ -54,6 +54,8 @@ SIGNATURES = {
     "lm_hip_free": (None, [_vp]),
     "lm_hip_result_pool_info": (C.c_int, [_szp, _szp, _szp]),
     "lm_hip_device_clock_mhz": (C.c_int, [C.c_int, C.c_uint, C.POINTER(C.c_double)]),
+    "lm_hip_ctx_clock_begin": (C.c_int, [_vp]),
+    "lm_hip_ctx_clock_end": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lm_hip_stride": (_sz, [_sz, _sz]),
     "lm_hip_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "lm_hip_ctx_create_on_stream": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
@@ -65,6 +67,7 @@ SIGNATURES = {
     "lm_hip_ctx_set_track_argmax": (C.c_int, [_vp, C.c_int]),
     "lm_hip_ctx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
     "lm_hip_ctx_last_kernel": (C.c_char_p, [_vp]),
+    "lm_hip_ctx_last_scan_counts": (C.c_int, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "lm_hip_pssm_create": (C.c_int, [_vp, _vp, _sz, _sz, _sz, C.POINTER(_vp)]),
     "lm_hip_pssm_reverse_complement": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
     "lm_hip_pssm_destroy": (C.c_int, [_vp]),

@@ -175,6 +175,7 @@ struct lm_hip_comm {
     ncclComm_t nccl = nullptr;
     int rank = 0, nranks = 1, device = 0;
     bool broken = false;  // a collective timed out or failed: the communicator was aborted, every later call fails
+    bool undrained = false;  // ... and a stream behind it did not drain within the bound: its buffers are leaked, never freed under it
     long long timeout_ms = 120000;  // LM_HIP_COMM_TIMEOUT_MS when the communicator was made; 0 = wait for ever
     lm::Scratch buf;  // device staging of the collectives
     // pipelined argmax merges (lm_hip_argmax_sharded_begin / _end): two slots, each with its own device
@@ -209,17 +210,36 @@ int comm_usable(const lm_hip_comm *comm)
 // Work queued BEHIND the stuck collective (read-backs into pinned areas and into result blocks the caller is about to
 // free) would still land after the call has returned: ncclCommAbort has released the kernel, so the streams drain in
 // bounded time, and they are drained here before anything is handed back or freed.
+// (The drain is itself a bounded poll: if ncclCommAbort fails or does not release the kernel, a blocking synchronise would
+// hang the very call whose job is to return LM_HIP_ERR_COMM.  A stream that has not drained by then marks the communicator
+// `undrained`: its device buffers, pinned areas and streams are leaked at destruction rather than freed under queued work.)
+bool drain_bounded(hipStream_t st, long long bound_ms)
+{
+    using clock = std::chrono::steady_clock;
+    const auto t0 = clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady)
+            return true;  // drained, or in an error state nothing will write through
+        if (std::chrono::duration_cast<std::chrono::milliseconds>(clock::now() - t0).count() > bound_ms)
+            return false;
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+}
+
 void abort_comm(lm_hip_comm *comm, hipStream_t waited_on = nullptr)
 {
     comm->broken = true;
+    bool released = true;
     if (comm->nccl) {
-        (void)rccl().CommAbort(comm->nccl);
+        released = rccl().CommAbort(comm->nccl) == ncclSuccess;
         comm->nccl = nullptr;
     }
-    if (waited_on)
-        (void)hipStreamSynchronize(waited_on);
-    if (comm->side && comm->side != waited_on)
-        (void)hipStreamSynchronize(comm->side);
+    const long long bound_ms = released ? 5000 : 500;
+    if (waited_on && !drain_bounded(waited_on, bound_ms))
+        comm->undrained = true;
+    if (comm->side && comm->side != waited_on && !drain_bounded(comm->side, bound_ms))
+        comm->undrained = true;
     for (auto &sl : comm->slot)
         sl.pending = false;
 }
@@ -369,6 +389,13 @@ int lm_hip_comm_destroy(lm_hip_comm *comm)
     if (comm->nccl && rccl().ok)
         (void)rccl().CommDestroy(comm->nccl);  // (an aborted communicator is gone already: never destroyed twice)
     comm->nccl = nullptr;
+    if (comm->undrained) {
+        // work may still be queued on streams the abort could not release: nothing it reads or writes is freed
+        comm->buf.forget();
+        comm->abuf.forget();
+        delete comm;
+        return LM_HIP_OK;
+    }
     if (comm->side)
         (void)hipStreamDestroy(comm->side);
     for (auto &sl : comm->slot) {

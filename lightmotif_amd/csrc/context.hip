@@ -94,6 +94,7 @@ struct ResultBlock {
     unsigned long long stamp;
 };
 std::mutex g_pool_mu;
+size_t g_pool_reserved = 0;  // bytes of blocks being page-locked right now (counted against the cap)
 std::vector<ResultBlock> g_pool;
 unsigned long long g_pool_stamp = 0;
 constexpr size_t kPoolMin = 1u << 20;  // smaller results: malloc
@@ -152,17 +153,22 @@ void *result_alloc(size_t bytes)
         size_t pinned_total = 0;
         for (const ResultBlock &b : g_pool)
             pinned_total += b.cap;
-        if (pinned_total + cap > 4 * pool_budget())
+        if (pinned_total + g_pool_reserved + cap > 4 * pool_budget())
             return malloc(bytes);  // the cap on page-locked memory is reached: a plain block, freed by free()
+        g_pool_reserved += cap;    // check and reservation under ONE lock: concurrent callers cannot exceed the cap together
     }
     void *p = nullptr;
-    if (posix_memalign(&p, kHuge, cap) != 0)
+    if (posix_memalign(&p, kHuge, cap) != 0) {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        g_pool_reserved -= cap;
         return malloc(bytes);
+    }
     (void)madvise(p, cap, MADV_HUGEPAGE);  // advisory: plain pages if unavailable
     const bool pinned = hipHostRegister(p, cap, hipHostRegisterPortable) == hipSuccess;
     if (!pinned)
         (void)hipGetLastError();
     std::lock_guard<std::mutex> lock(g_pool_mu);
+    g_pool_reserved -= cap;
     g_pool.push_back(ResultBlock{p, cap, pinned, true, 0});
     return p;
 }
@@ -325,6 +331,58 @@ int lm_hip_device_clock_mhz(int device, unsigned window_us, double *mhz)
     return LM_HIP_OK;
 }
 
+namespace lm {
+__global__ void clock_mark_kernel(unsigned long long *out)
+{
+    const unsigned long long c = __builtin_amdgcn_s_memtime();
+    const unsigned long long r = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[0] = c;
+        out[1] = r;
+    }
+}
+}  // namespace lm
+
+int lm_hip_ctx_clock_begin(lm_hip_ctx *ctx)
+{
+    if (!ctx)
+        return fail(LM_HIP_ERR_BAD_ARGS, "ctx_clock_begin: null context");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    DeviceGuard guard(ctx->device);
+    if (!ctx->clock_rec)
+        LM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->clock_rec), 4 * sizeof(unsigned long long), hipHostMallocDefault));
+    hipLaunchKernelGGL(clock_mark_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->clock_rec);
+    LM_HIP_TRY(hipGetLastError());
+    ctx->clock_open = true;
+    return LM_HIP_OK;
+}
+
+int lm_hip_ctx_clock_end(lm_hip_ctx *ctx, double *mhz, double *elapsed_us)
+{
+    if (!ctx)
+        return fail(LM_HIP_ERR_BAD_ARGS, "ctx_clock_end: null context");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->clock_open)
+        return fail(LM_HIP_ERR_BAD_ARGS, "ctx_clock_end without ctx_clock_begin");
+    DeviceGuard guard(ctx->device);
+    ctx->clock_open = false;
+    int wall_khz = 0;
+    LM_HIP_TRY(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, ctx->device));
+    if (wall_khz <= 0)
+        return fail(LM_HIP_ERR_HIP, "ctx_clock_end: the device reports no constant-rate counter");
+    hipLaunchKernelGGL(clock_mark_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->clock_rec + 2);
+    LM_HIP_TRY(hipGetLastError());
+    LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const unsigned long long ticks = ctx->clock_rec[2] - ctx->clock_rec[0], ref = ctx->clock_rec[3] - ctx->clock_rec[1];
+    if (ref == 0)
+        return fail(LM_HIP_ERR_HIP, "ctx_clock_end: the constant-rate counter did not advance");
+    if (mhz)
+        *mhz = (double)ticks / (double)ref * (double)wall_khz / 1000.0;
+    if (elapsed_us)
+        *elapsed_us = (double)ref / (double)wall_khz * 1000.0;
+    return LM_HIP_OK;
+}
+
 // ---- context ----------------------------------------------------------------------------
 
 // Options of a context: each selects an alternative path that gives the SAME results (the GPU suite sets several of them
@@ -353,8 +411,8 @@ static int set_option(lm_hip_ctx *ctx, const char *name, double value)
     else if (n == "tiled") ctx->tiled = on;                          // 0 = column counts off 32 / 16 go cell by cell
     else if (n == "prefilter") ctx->use_prefilter = on;
     else if (n == "chunk_rows") {
-        if (!(value >= 64))
-            return fail(LM_HIP_ERR_BAD_ARGS, "ctx_set_option: chunk_rows must be >= 64");
+        if (!(value >= 64) || !(value <= 2147483648.0))  // (also rejects NaN and +inf: the cast below must be defined)
+            return fail(LM_HIP_ERR_BAD_ARGS, "ctx_set_option: chunk_rows must be 64 ... 2^31");
         ctx->chunk_rows = (size_t)value;
     } else if (n == "suffix_occurrences") {
         ctx->suffix_occurrences = value > 0 ? value : 0;
@@ -446,6 +504,8 @@ int lm_hip_ctx_destroy(lm_hip_ctx *ctx)
     ctx->u8_tables.release();
     if (ctx->pinned)
         (void)hipHostFree(ctx->pinned);
+    if (ctx->clock_rec)
+        (void)hipHostFree(ctx->clock_rec);
     if (ctx->d_ticket)
         (void)hipFree(ctx->d_ticket);
     if (ctx->copy_stream) {
@@ -518,5 +578,17 @@ int lm_hip_ctx_set_option(lm_hip_ctx *ctx, const char *name, double value)
 }
 
 const char *lm_hip_ctx_last_kernel(lm_hip_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
+
+int lm_hip_ctx_last_scan_counts(lm_hip_ctx *ctx, unsigned long long *hits, unsigned long long *candidates)
+{
+    if (!ctx)
+        return fail(LM_HIP_ERR_BAD_ARGS, "ctx_last_scan_counts: null context");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (hits)
+        *hits = ctx->last_hit_count;
+    if (candidates)
+        *candidates = ctx->last_cand_count;
+    return LM_HIP_OK;
+}
 
 }  // extern "C"

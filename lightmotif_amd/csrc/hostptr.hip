@@ -1141,10 +1141,10 @@ struct HostCost {
     double t0_us, gpu_ns, cpu_ns, cpu_ns_per_row;
 };
 //                                      t0 us  GPU ns/cell  CPU ns/cell  CPU ns/(cell x motif row)
-constexpr HostCost kCostScoreF32{45.0, 0.094, 0.0, 0.0314};      // 1 B up + 4 B down; AVX2 f32 permute kernel
-constexpr HostCost kCostScoreU8{55.0, 0.038, 0.0, 0.0071};       // 1 B up + 1 B down; AVX2 u8 shuffle kernel
-constexpr HostCost kCostMaximumF32{35.0, 0.078, 0.75, 0.0};      // 4 B up; the Generic scan (the rule the variant keeps, pli/mod.rs:135-160)
-constexpr HostCost kCostThresholdF32{55.0, 0.078, 0.42, 0.0};    // 4 B up; the default body (pli/mod.rs:210-221)
+constexpr HostCost kCostScoreF32{47.0, 0.093, 0.0, 0.0316};      // 1 B up + 4 B down; AVX2 f32 permute kernel (M = 4 ... 30 measured)
+constexpr HostCost kCostScoreU8{60.0, 0.036, 0.0, 0.0071};       // 1 B up + 1 B down; AVX2 u8 shuffle kernel
+constexpr HostCost kCostMaximumF32{37.0, 0.070, 0.247, 0.0};     // 4 B up; the Generic scan (the rule the variant keeps, pli/mod.rs:135-160)
+constexpr HostCost kCostThresholdF32{63.0, 0.073, 0.252, 0.0};   // 4 B up; the default body (pli/mod.rs:210-221)
 constexpr HostCost kCostScan{70.0, 0.020, 0.03, 0.0071};         // 1 B up + the scan; the reference's block loop on the AVX2 tier
 constexpr double kCrossoverMargin = 1.25;  // the CPU must cost this much more per cell than the link before a call leaves it
 size_t crossover_cells(const HostCost &k, size_t m)

@@ -58,6 +58,7 @@ struct Scratch {
     size_t bytes = 0;
     int reserve(size_t n);  // grows (never shrinks); contents are not preserved
     void release();
+    void forget() { ptr = nullptr; bytes = 0; }  // leaks the block on purpose: work that may still write it is queued (comm.hip)
 };
 
 // Record written by the reductions (device) and read back through pinned memory.
@@ -98,6 +99,8 @@ struct lm_hip_ctx {
     size_t chunk_rows = 1u << 22; // rows of that chunk (512 MB at C = 32; option "chunk_rows")
     bool chunked_fused = true;  // A/B knob: 0 = such motifs go cell by cell (option "chunked_fused")
     void *pinned = nullptr;     // kPinnedBytes of host-pinned memory for read-backs
+    unsigned long long *clock_rec = nullptr;  // lm_hip_ctx_clock_begin / _end: {shader ticks, constant-rate ticks} x 2, pinned
+    bool clock_open = false;
     unsigned fold_generation = 0; // of the last single-job fused argmax whose kernel wrote its result into `pinned`
     unsigned *d_ticket = nullptr; // "last workgroup folds the records" counter of the single-launch argmax forms (zero between launches)
     size_t rows_per_stream = 0; // 0 = default

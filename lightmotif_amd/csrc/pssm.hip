@@ -45,7 +45,7 @@ static bool build_prefilter(lm_hip_pssm &p, std::vector<unsigned> *image, std::v
     }
     if (!(range > 0))
         return false;
-    const double factor = range / 65000.0;
+    const double factor = range / (double)kPrefilterTop;
     // discrete weights d'[0..mp): leading zero row when m is odd
     std::vector<unsigned> d((size_t)mp * k, 0);
     for (int j = 0; j < m; ++j)

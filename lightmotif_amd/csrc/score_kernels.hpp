@@ -75,6 +75,19 @@ typedef float lm_f32x2_t __attribute__((ext_vector_type(2)));
 typedef const volatile __attribute__((address_space(3))) lm_f32x2_t *lm_lds_b64_ptr;  // volatile: never fused into ds_read2_b64
 typedef unsigned lm_u32x2_t __attribute__((ext_vector_type(2)));
 typedef const volatile __attribute__((address_space(3))) lm_u32x2_t *lm_lds_u64_ptr;
+// LDS reads at an address computed as an INTEGER (kernels whose dynamic LDS starts at address 0, see lds_zero_based)
+typedef unsigned lm_u32x4_t __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) lm_u32x4_t *lm_lds_u128_ptr;
+typedef const __attribute__((address_space(3))) unsigned *lm_lds_u32_ptr;
+// A kernel without static LDS has its dynamic LDS at address 0, but the compiler learns that only after instruction
+// selection: `table + offset` stays a v_add_u32 with a zero operand in front of every LDS read (one per super-step of
+// the pair scans, which are bound by VALU issue).  Such kernels form their LDS addresses from the offset alone and
+// check the premise once: a trap (the launch fails loudly) if a static LDS object ever slips in.
+__device__ __forceinline__ void lds_zero_based(const void *dynamic_lds)
+{
+    if ((unsigned)(size_t)(const __attribute__((address_space(3))) char *)dynamic_lds != 0u)
+        __builtin_trap();
+}
 
 // MODE_CONTINUE: like MODE_STORE, but every output starts from the partial sum already stored in
 // its cell instead of +0.0 -- the later passes of a motif longer than kMaxFastM, which is scored
@@ -507,12 +520,27 @@ __device__ __forceinline__ void score_group(float (&acc)[M], unsigned (&sym)[M],
 // single list counter serialise in L2 at ~6 ns each; a counter bump per wavefront and
 // loop trip cost 0.4 ms per launch at 1e6 candidates): count, workgroup prefix sum,
 // reserve, write.  Every thread of the workgroup must call this.
-template <typename Range>
+//
+// OVERLAY: the 72 bytes of workgroup scratch live at `overlay` (16-byte aligned dynamic LDS the caller no longer
+// needs -- the pair scans hand in their table, behind a barrier) instead of in static LDS.  A kernel without
+// static LDS has its dynamic LDS at address 0, and the table-row address of every LDS read of its hot loop is then
+// the row offset itself: one v_add_u32 per super-step less in scans that are bound by VALU issue.
+template <bool OVERLAY = false, typename Range>
 __device__ __forceinline__ void emit_candidates(const unsigned long long hit_groups, const int col,
-                                                const FusedOut &fo, Range range)
+                                                const FusedOut &fo, Range range, char *overlay = nullptr)
 {
-    __shared__ unsigned wave_total[16];
-    __shared__ unsigned long long block_base;
+    unsigned *wave_total;
+    unsigned long long *block_base_p;
+    if constexpr (OVERLAY) {
+        block_base_p = reinterpret_cast<unsigned long long *>(overlay);
+        wave_total = reinterpret_cast<unsigned *>(overlay + 8);
+    } else {
+        __shared__ unsigned wave_total_s[16];
+        __shared__ unsigned long long block_base_s;
+        wave_total = wave_total_s;
+        block_base_p = &block_base_s;
+    }
+    unsigned long long &block_base = *block_base_p;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     unsigned mine = 0;
     for (unsigned long long m = hit_groups; m; m &= m - 1) {

@@ -9,7 +9,7 @@
 // form of that idea:
 //
 //   * weights are u16 (the reference uses u8 for AVX2's byte shuffles; 16 bits keep
-//     the false-positive rate negligible and cannot overflow: sum <= 65000 + M);
+//     the false-positive rate negligible and cannot overflow: sum <= kPrefilterTop + 2 M);
 //   * two accumulators share one VGPR and are advanced by ONE 32-bit add (sums cannot carry
 //     across the halves), and a
 //     symbol's whole column is M*2 bytes of LDS instead of M*4 -> half the LDS
@@ -20,7 +20,7 @@
 //
 // Soundness (no false negatives): with P' = P where finite and the row minimum where
 // P = -inf, off_j = min_s P'[j][s], O = sum off_j, factor = (sum_j max_s P'[j][s] - O)
-// / 65000, d[j][s] = ceil((P'[j][s] - off_j) / factor), an f32 score S >= t implies
+// / kPrefilterTop, d[j][s] = ceil((P'[j][s] - off_j) / factor), an f32 score S >= t implies
 // sum d >= floor((t - O) / factor) - ceil(E / factor) where E bounds the rounding error
 // of the M sequential f32 adds (host side, pssm.hip: build_prefilter).
 //
@@ -36,6 +36,11 @@
 
 namespace lm {
 
+// The discrete weights of a matrix add up to at most kPrefilterTop + 2 M (every weight is rounded up, once for the
+// ceiling and once to guard it): below 0x8000 for every supported length, so bit 15 of a biased sum can serve as its
+// "reached the threshold" flag in the pair scans (score_prefilter2.hpp: kFlagBits).  15 bits of resolution over the
+// matrix's score range: the over-estimate is at most 2 M quanta of range / 32000.
+constexpr unsigned kPrefilterTop = 32000u;
 constexpr int prefilter_mp(int m) { return (m + 1) / 2 * 2; }
 // dwords per symbol row of one discrete layout: 4 * odd >= MP / 2 (conflict-free b128)
 // (wide alphabets, lds_wide(k): 2 * odd, read with single ds_read_b64 -- see table_stride in score_kernels.hpp)
@@ -71,7 +76,7 @@ inline void prefilter_pack_image(const unsigned *d, int m, int k, unsigned *imag
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-// Adds two pairs of u16 accumulators.  No 16-bit sum can exceed 65000 + 2M < 65536 (host
+// Adds two pairs of u16 accumulators.  No 16-bit sum can exceed kPrefilterTop + 2M < 32768 (host
 // side, build_prefilter), so nothing ever carries from the low into the high half and a
 // plain 32-bit add IS the packed add -- v_add_u32 issues at twice the rate of v_pk_add_u16
 // on this part (tools/kbench/valu_bench: 64 vs 38 T lane-instr/s).

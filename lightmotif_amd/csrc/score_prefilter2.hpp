@@ -31,7 +31,11 @@
 
 namespace lm {
 
-constexpr int kPairPFB = 3;  // 4-row symbol blocks requested ahead of use in the pair scans
+// 4-row symbol blocks requested ahead of their decode in the pair scans, at most the ring of a group (RING / 4 registers,
+// held anyway).  Three were enough while the scan was VALU-bound; at 0.24 ms per Gbp the single-motif scan reads 4.2 TB/s
+// with ~6 000 resident wavefronts, and 3 x 256 B in flight per wavefront (4.7 MB) is less than bandwidth x latency
+// (round 5: VALU 59 %, LDS 69 % busy after the hand-pipelining -- neither pipe saturated).
+constexpr int kPairPFB = 8;
 
 // padded length M' = 3 (mod 4).  A table row of NPAIR = (M' + 1) / 2 dwords is read as whole 16-byte pieces plus,
 // when NPAIR % 4 == 2 (M' = 11, 19, 27, 35), an 8-byte tail.  Left to itself the compiler fuses those tails (of
@@ -70,45 +74,45 @@ __host__ __device__ __forceinline__ unsigned pair_row(unsigned a, unsigned b)
 
 // DNA decode in registers.  The lanes of a quad hold a 4 x 4 block of symbol bytes (lane q: row r + q, columns
 // 4i .. 4i+3).  Picking one symbol apart costs a DPP move + a bit-field extract, and the pair's row another five
-// operations -- together more than half of the scan's VALU work once the adds were halved (round 5 counters:
-// 18.4 VALU per super-step, 10 of them decode, LDS array busy 66 %).  Instead the quad TRANSPOSES its block (two DPP
-// moves + two v_perm_b32: every lane then holds the four rows of its OWN column in one dword), two more v_perm_b32
-// use that dword as a selector into byte tables -- 4 so a / so b' in units of 16 bytes, `so` = 16-byte slots per
-// table row -- and one shifted add leaves row(a, b) * so of the block's two pairs in bytes 0 and 2.  Eight
-// operations per four symbols, and the byte select rides on the shift that makes the LDS address (SDWA).
-// Needs 20 so + 16 so < 256: table rows of up to 7 slots (M' <= 55); longer motifs keep the one-by-one decode.
+// operations -- together more than half of the scan's VALU work once the adds were halved (round 5 counters of
+// score_c32_prefilter2<20, 5>: 18.4 VALU per super-step, 10 of them decode; VALU 98 % busy, LDS array 66 %,
+// profiles/r05_stalls_prefilter2.txt).  row(a, b) is additive, so the look-up happens BEFORE the bytes change lanes:
+//   c = v_perm_b32(table_q, d)     lane q even: byte j = 4 so a(row r + q, column 4i + j), lane q odd: so b'(...)
+//   s = c + c[quad lane q ^ 1]     bytes = so row(a, b) of rows (r, r + 1) in lanes 0, 1; of (r + 2, r + 3) in lanes 2, 3
+//   y = s[quad lane q ^ 2]         the other pair of rows
+//   p = v_perm_b32(y, s, sel_q)    byte 0 / byte 2 = own column's offset of the block's first / second pair
+// with `so` = 16-byte slots per table row; four operations per block of four symbols (the transposition that
+// preceded the look-up in the first register form cost two more), and the byte select rides on the shift that
+// makes the LDS address (SDWA).  Needs 20 so + 16 so < 256: table rows of up to 7 slots (M' <= 55); longer motifs
+// keep the one-by-one decode.
 constexpr bool prefilter2_lut_decode(int m, int ka) { return ka == 5 && prefilter2_stride_dw(m) / 4 <= 7; }
 
-struct QuadTranspose {  // per-lane selectors of the two v_perm_b32 steps (set once per kernel)
-    unsigned sel1, sel2;
-    unsigned four;  // the shift count of byte_times_16 (an SDWA operand must be a register)
+struct PairDecode {  // per-lane constants (set once per kernel)
+    unsigned tab_lo, tab_hi;  // byte tables of the lane's row parity: 4 so a (even rows of a pair) or so b' (odd rows)
+    unsigned sel;             // byte selector of the last step
+    unsigned four;            // the shift count of byte_times_16 (an SDWA operand must be a register)
 };
-__device__ __forceinline__ QuadTranspose quad_transpose_setup()
-{
-    const unsigned lane = threadIdx.x;
-    QuadTranspose qt;
-    qt.sel1 = (lane & 1u) ? 0x03070105u : 0x06020400u;
-    qt.sel2 = (lane & 2u) ? 0x03020706u : 0x05040100u;
-    qt.four = 4u;
-    return qt;
-}
-// lane q of a quad: dword = (row r + q; columns c0 .. c0 + 3)  ->  (rows r .. r + 3; column c0 + q)
-__device__ __forceinline__ unsigned quad_transpose(unsigned d, const QuadTranspose &qt)
-{
-    const unsigned x = (unsigned)__builtin_amdgcn_mov_dpp((int)d, 0xb1, 0xf, 0xf, true);  // quad_perm [1, 0, 3, 2]
-    const unsigned p = __builtin_amdgcn_perm(x, d, qt.sel1);
-    const unsigned y = (unsigned)__builtin_amdgcn_mov_dpp((int)p, 0x4e, 0xf, 0xf, true);  // quad_perm [2, 3, 0, 1]
-    return __builtin_amdgcn_perm(y, p, qt.sel2);
-}
-// bytes 0 / 2 = row(a, b) * SO of the pairs (rows 0, 1) / (rows 2, 3) of a transposed block; SO = 16-byte slots per row
 template <int SO>
-__device__ __forceinline__ unsigned dna_pair_offsets(unsigned t)
+__device__ __forceinline__ PairDecode pair_decode_setup()
 {
     constexpr unsigned A_LO = 0u | (4u * SO << 8) | (8u * SO << 16) | (12u * SO << 24), A_HI = 16u * SO;
     constexpr unsigned B_LO = 0u | (1u * SO << 8) | (2u * SO << 16) | (3u * SO << 24), B_HI = 20u * SO;
-    const unsigned qa = __builtin_amdgcn_perm(A_HI, A_LO, t);  // byte k = 4 SO * symbol(row k)
-    const unsigned pb = __builtin_amdgcn_perm(B_HI, B_LO, t);  // byte k = SO * b'(row k)
-    return qa + (pb >> 8);  // no byte carries: every sum is below 256
+    const unsigned q = threadIdx.x & 3u;
+    PairDecode pd;
+    pd.tab_lo = (q & 1u) ? B_LO : A_LO;
+    pd.tab_hi = (q & 1u) ? B_HI : A_HI;
+    // lanes 0, 1 hold the first pair in `s` and receive the second in `y`; lanes 2, 3 the other way round
+    pd.sel = (q & 2u) ? (0x0c000c00u | (4u + q) | (q << 16)) : (0x0c000c00u | q | ((4u + q) << 16));
+    pd.four = 4u;
+    return pd;
+}
+// bytes 0 / 2 = row(a, b) * SO of the lane's column for the pairs (rows 0, 1) / (rows 2, 3) of the quad's block `d`
+__device__ __forceinline__ unsigned dna_pair_offsets(unsigned d, const PairDecode &pd)
+{
+    const unsigned c = __builtin_amdgcn_perm(pd.tab_hi, pd.tab_lo, d);
+    const unsigned s = c + (unsigned)__builtin_amdgcn_mov_dpp((int)c, 0xb1, 0xf, 0xf, true);  // quad_perm [1, 0, 3, 2]; no byte carries
+    const unsigned y = (unsigned)__builtin_amdgcn_mov_dpp((int)s, 0x4e, 0xf, 0xf, true);      // quad_perm [2, 3, 0, 1]
+    return __builtin_amdgcn_perm(y, s, pd.sel);
 }
 // ((s >> 8 * BYTE) & 0xff) << 4 in ONE operation: the byte select rides on the shift (SDWA; hipcc emits and + shift)
 template <int BYTE>
@@ -120,6 +124,54 @@ __device__ __forceinline__ unsigned byte_times_16(unsigned s, unsigned four)
     else
         asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(four), "v"(s));
     return r;
+}
+
+// Flags instead of maxima.  The scans only ask whether a completed sum reached the discrete threshold td.  The
+// table copy in LDS carries  bias = 0x8000 - td  in both halves of dword 0 of every row -- every output receives
+// dword 0 exactly once -- so a sum >= td shows as bit 15 of its half (sums stay below 0x8000 - 2 M': kPrefilterTop,
+// no carry into the neighbour), and the completed dwords are OR-ed together: v_or3_b32 folds two per operation where
+// the packed maximum took one each.  td > 0x8000 is out of reach of every sum: bias 0, nothing flagged.  The
+// other half of a completed dword is a partial sum of an output in flight, as before (score_prefilter.hpp).
+constexpr unsigned kFlagBits = 0x80008000u;
+static_assert(kPrefilterTop + 2u * (unsigned)kMaxPairM < 0x8000u, "biased sums must stay within their 16-bit half");
+__device__ __forceinline__ unsigned prefilter2_bias(unsigned td) { return td <= 0x8000u ? (0x8000u - td) * 0x10001u : 0u; }
+
+// One bit per NOTE (= G groups of a stream), up to 64 per stream, collected without a compare: the field shifts right
+// one bit per note and takes the note's flag in at bit 63, so after n notes they sit in its top n bits, oldest lowest.
+struct GroupNotes {
+    unsigned lo = 0, hi = 0;
+    __device__ __forceinline__ void note(unsigned &mx)
+    {
+        const unsigned either = mx | (mx << 16);  // bit 31: one of the two halves reached the threshold
+        lo = __builtin_amdgcn_alignbit(hi, lo, 1);  // (hi:lo) >> 1
+        hi = (hi >> 1) | (either & 0x80000000u);
+        mx = 0;
+    }
+    __device__ __forceinline__ unsigned long long finish(unsigned n) const  // n = notes taken, 1 ... 64
+    {
+        return (((unsigned long long)hi << 32) | lo) >> (64u - n);
+    }
+};
+
+// Opaque to the optimiser on purpose: LLVM re-associates chains of integer adds and ORs into trees, which keeps table
+// rows and completed sums alive across many super-steps (round 5: hundreds of spilled registers in the unrolled scans).
+__device__ __forceinline__ unsigned add3_u32(unsigned a, unsigned b, unsigned c)
+{
+    unsigned d;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ unsigned or3_b32(unsigned a, unsigned b, unsigned c)
+{
+    unsigned d;
+    asm("v_or3_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ unsigned or_b32(unsigned a, unsigned b)
+{
+    unsigned d;
+    asm("v_or_b32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
 }
 
 // Host side: the pair table from the unpadded discrete weights d[j * ka + s], j < m.
@@ -141,108 +193,233 @@ inline void prefilter2_pack_image(const unsigned *d, int m, unsigned *image2, in
         }
 }
 
-// Symbol loads.  A byte load per lane and row moves 64 bytes per wavefront instruction, and
-// at > 3 Tpos/s the scan is bound by that request rate, not by LDS or VALU.  So the lanes
-// of a quad (columns 4i..4i+3) fetch a 4 x 4 block of symbols with ONE dword load each --
-// lane q reads row r+q, columns 4i..4i+3; a half-wave instruction covers 4 rows = 128
-// contiguous bytes -- and every lane picks its column out of its neighbours' registers:
-// symbol(row r+t, own column) = byte (lane & 3) of the dword held by quad lane t (one DPP
-// quad broadcast + one bit-field extract).  RING is a multiple of 4, so blocks never
-// straddle a group; `blk` is a ring of the RING/4 blocks of a group, prefetched PFB ahead.
+// ---- the scan loop, software-pipelined by hand ------------------------------------------------------------
 //
-// STORE = 1 (score_u8.hpp): the sums are a DiscreteMatrix's u8 scores.  A super-step completes
-// two rows of the lane's column; two super-steps make a 4-row block that is transposed inside
-// the quad of lanes and written with one dword store per lane (128 contiguous bytes per
-// half-wave instruction).  `op` = the lane's cell of the group's first completed row; the
-// FIRST group completes rows 0 and 1 only (byte stores).  `wrap_mask` as in prefilter_group.
-template <int M, int PFB, int PHASE, int STORE = 0, int KA = 5>
-__device__ __forceinline__ void prefilter2_group(unsigned (&acc)[prefilter2_npair(M)],
-                                                 unsigned (&blk)[prefilter2_ring(M) / 4],
-                                                 const uint8_t *__restrict__ spq, const unsigned shq,
-                                                 const char *__restrict__ tab, unsigned &mx,
-                                                 const QuadTranspose &qt,
-                                                 uint8_t *__restrict__ op = nullptr,
-                                                 const unsigned wrap_mask = 0)
+// Symbol loads.  A byte load per lane and row moves 64 bytes per wavefront instruction, and at > 3 Tpos/s the scan
+// is bound by that request rate, not by LDS or VALU.  So the lanes of a quad (columns 4i..4i+3) fetch a 4 x 4 block of
+// symbols with ONE dword load each -- lane q reads row r+q, columns 4i..4i+3; a half-wave instruction covers 4 rows =
+// 128 contiguous bytes.  RING is a multiple of 4, so blocks never straddle a group; `blk` is a ring of the RING/4
+// blocks of a group, requested PFB blocks ahead of their decode.
+//
+// The schedule is spelled out, not left to the compiler.  Integer adds and ORs may be re-associated, and LLVM pairs an
+// accumulator's terms into v_add3_u32 across distant super-steps, which keeps table rows alive for several steps
+// (round 5: 36 scratch operations in the unrolled loop of <20, 5> once its decode was cheap; thousands of spilled
+// registers in the long kernels).  A PAIR of super-steps (one 4-row block of symbols, table rows R0 and R1) advances
+// every accumulator by two entries at once:
+//     slot (2p - m) mod NP  +=  R0[m] + R1[m + 1]        m = 1 .. NP - 2     one v_add3_u32 (opaque to the optimiser)
+//     slot (2p) mod NP       =  R0[0] + R1[1]            (it completed, and was taken, at the end of the pair before)
+//     slot (2p + 1) mod NP  +=  R0[NP - 1]  -> complete (`fin0`); restarts as R1[0]
+//     slot (2p + 2) mod NP  completes with m = NP - 2
+// NP + 1 operations per pair where one add per entry takes 2 NP.  The rows of the NEXT item -- the next motif of a
+// multi-motif pass, else the next pair -- are requested WHILE the current ones are consumed, chunk by chunk (16 bytes
+// of each row per chunk): about one item's rows are in flight per wavefront, at most a chunk's worth of extra
+// registers is live, and scheduling barriers pin that order.  All LDS addresses are integers: the kernels that use
+// this have no static LDS (lds_zero_based).
+
+template <int NP>
+struct PairRows {  // the two table rows of a pair of super-steps
+    unsigned r0[(NP + 3) / 4 * 4], r1[(NP + 3) / 4 * 4];
+};
+
+// chunk C (dwords 4C .. 4C + 3) of the table row at LDS address `off`: a whole 16-byte piece or, when NP % 4 == 2, the
+// 8-byte tail read on its own (see prefilter2_mo)
+template <int NP, int C>
+__device__ __forceinline__ void read_row_chunk(unsigned (&w)[(NP + 3) / 4 * 4], const unsigned off)
 {
-    constexpr bool LUT = prefilter2_lut_decode(M, KA);
-    unsigned pair_off = 0;  // LUT: dna_pair_offsets of the current block
-    const unsigned q = STORE ? (threadIdx.x & 3u) : 0u;
-    uint8_t *oq = STORE ? op - q + q * 32 : nullptr;  // lane q of a quad writes row +q, the quad's 4 columns
-    const unsigned sel_lo = 0x0c0c0000u | q | ((4u + q) << 8);
-    const unsigned sel_hi = 0x00000c0cu | (q << 16) | ((4u + q) << 24);
-    unsigned pack = 0;
-    constexpr int RING = prefilter2_ring(M);
-    constexpr int NB = RING / 4;
-    constexpr int NP = prefilter2_npair(M);
-    constexpr int NV = (NP + 3) / 4;
-    constexpr unsigned DSB = prefilter2_stride_dw(M) * 4;
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        // this super-step's two symbols: rows 2k, 2k+1 of the group = block k/2, rows (2k)%4, +1
-        const unsigned d = blk[k / 2];
-        unsigned row_off;
-        if constexpr (LUT) {
-            if ((k & 1) == 0)
-                pair_off = dna_pair_offsets<(int)(DSB / 16)>(quad_transpose(d, qt));
-            row_off = (k & 1) ? byte_times_16<2>(pair_off, qt.four) : byte_times_16<0>(pair_off, qt.four);
-        } else {
-            const unsigned a = (k & 1) ? quad_symbol<2>(d, shq) : quad_symbol<0>(d, shq);
-            const unsigned b = (k & 1) ? quad_symbol<3>(d, shq) : quad_symbol<1>(d, shq);
-            row_off = __umul24(pair_row<KA>(a, b), DSB);
-        }
-        // a block is free once its second pair is taken: request the block PFB ahead
-        if ((k & 1) && (PHASE != PHASE_LAST || k / 2 + PFB < NB))
-            blk[(k / 2 + PFB) % NB] = *reinterpret_cast<const unsigned *>(spq + (k / 2 + PFB) * 128);
-        const char *row = static_cast<const char *>(__builtin_assume_aligned(tab + row_off, 16));
-        unsigned w[NV * 4];
-#pragma unroll
-        for (int q = 0; q < NP / 4; ++q) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(row + 16 * q);
-            w[4 * q + 0] = v.x;
-            w[4 * q + 1] = v.y;
-            w[4 * q + 2] = v.z;
-            w[4 * q + 3] = v.w;
-        }
-        if (NP % 4 >= 2) {
-            const lm_u32x2_t v = *(lm_lds_u64_ptr)(row + 16 * (NP / 4));
-            w[4 * (NP / 4) + 0] = v.x;
-            w[4 * (NP / 4) + 1] = v.y;
-        }
-        if (NP % 2 == 1)
-            w[NP - 1] = *reinterpret_cast<const unsigned *>(row + 4 * (NP - 1));
-#pragma unroll
-        for (int m = 0; m < NP; ++m)
-            acc[(k - m + NP) % NP] = pk_add_u16(acc[(k - m + NP) % NP], w[m]);
-        // dword (k+1) mod NP received its last entry: both of its outputs are complete
-        const int c = (k + 1) % NP;
-        if (STORE) {
-            if (PHASE != PHASE_FIRST || k == NP - 1) {
-                // (lo, hi) = (even row, odd row): clamp or mask both halves at once
-                const unsigned r = wrap_mask ? (acc[c] & 0x00ff00ffu) : pk_min_u16(acc[c], 0x00ff00ffu);
-                if (PHASE == PHASE_FIRST) {
-                    op[0] = (uint8_t)(r & 0xffu);
-                    op[32] = (uint8_t)(r >> 16);
-                } else if ((k & 1) == 0) {
-                    pack = __builtin_amdgcn_perm(r, r, 0x0c0c0200u);            // bytes 0, 1 = rows 2k, 2k+1
-                } else {
-                    pack |= __builtin_amdgcn_perm(r, r, 0x02000c0cu);           // bytes 2, 3
-                    const unsigned p0 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0x00, 0xf, 0xf, true);
-                    const unsigned p1 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0x55, 0xf, 0xf, true);
-                    const unsigned p2 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0xaa, 0xf, 0xf, true);
-                    const unsigned p3 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0xff, 0xf, 0xf, true);
-                    const unsigned row = __builtin_amdgcn_perm(p1, p0, sel_lo) | __builtin_amdgcn_perm(p3, p2, sel_hi);
-                    *reinterpret_cast<unsigned *>(oq + 2 * (k - 1) * 32) = row;
-                }
-            }
-        } else if (PHASE != PHASE_FIRST || k == NP - 1) {
-            mx = pk_max_u16(mx, acc[c]);
-        }
-        acc[c] = 0;
+    if constexpr (4 * C + 4 <= NP) {
+        const lm_u32x4_t v = *(lm_lds_u128_ptr)(off + 16u * C);
+        w[4 * C + 0] = v.x;
+        w[4 * C + 1] = v.y;
+        w[4 * C + 2] = v.z;
+        w[4 * C + 3] = v.w;
+    } else {
+        const lm_u32x2_t v = *(lm_lds_u64_ptr)(off + 16u * C);
+        w[4 * C + 0] = v.x;
+        w[4 * C + 1] = v.y;
     }
 }
 
+template <int NP, int P, int C>
+__device__ __forceinline__ void consume_chunk(unsigned (&acc)[NP], const PairRows<NP> &cur, unsigned &fin0)
+{
+#pragma unroll
+    for (int m = 4 * C; m < 4 * C + 4 && m < NP; ++m) {
+        const int j = ((2 * P - m) % NP + NP) % NP;
+        if (m == NP - 1) {
+            fin0 = acc[j] + cur.r0[NP - 1];
+            acc[j] = cur.r1[0];
+        } else if (m == 0) {
+            acc[j] = cur.r0[0] + cur.r1[1];
+        } else {
+            acc[j] = add3_u32(acc[j], cur.r0[m], cur.r1[m + 1]);
+        }
+    }
+}
+
+template <int NP, int P, int C>
+__device__ __forceinline__ void pair_chunks(unsigned (&acc)[NP], const PairRows<NP> &cur, PairRows<NP> &nxt, const unsigned off0,
+                                            const unsigned off1, unsigned &fin0, const bool has_next)
+{
+    if constexpr (C < (NP + 3) / 4) {
+        if (has_next) {
+            read_row_chunk<NP, C>(nxt.r0, off0);
+            read_row_chunk<NP, C>(nxt.r1, off1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        consume_chunk<NP, P, C>(acc, cur, fin0);
+        __builtin_amdgcn_sched_barrier(0);
+        pair_chunks<NP, P, C + 1>(acc, cur, nxt, off0, off1, fin0, has_next);
+    }
+}
+
+// LDS byte offsets of the table rows of a block's two pairs of symbols
+template <int M, int KA>
+__device__ __forceinline__ void decode_block(const unsigned d, const unsigned shq, const PairDecode &pd, unsigned &off0, unsigned &off1)
+{
+    if constexpr (prefilter2_lut_decode(M, KA)) {
+        const unsigned pair_off = dna_pair_offsets(d, pd);
+        off0 = byte_times_16<0>(pair_off, pd.four);
+        off1 = byte_times_16<2>(pair_off, pd.four);
+    } else {  // one symbol at a time: own column's byte of a quad neighbour's dword (DPP move + bit-field extract)
+        constexpr unsigned DSB = prefilter2_stride_dw(M) * 4;
+        off0 = __umul24(pair_row<KA>(quad_symbol<0>(d, shq), quad_symbol<1>(d, shq)), DSB);
+        off1 = __umul24(pair_row<KA>(quad_symbol<2>(d, shq), quad_symbol<3>(d, shq)), DSB);
+    }
+}
+
+// What becomes of the two dwords a pair completes (`fin0`: outputs of super-step 2P, `fin1`: of 2P + 1).
+//
+// Scans: flags of motif MI (kFlagBits).  The FIRST group completes the stream's outputs 0 and 1 only (its last dword).
+template <int NM>
+struct FlagSink {
+    unsigned (&mx)[NM];
+    template <int PHASE, int P, int NB, int MI>
+    __device__ __forceinline__ void complete(const unsigned fin0, const unsigned fin1)
+    {
+        if (PHASE != PHASE_FIRST)
+            mx[MI] = or3_b32(mx[MI], fin0, fin1);
+        else if (P == NB - 1)
+            mx[MI] = or_b32(mx[MI], fin1);
+    }
+};
+// Score<u8> (score_u8.hpp): the sums are a DiscreteMatrix's u8 scores.  A pair completes four rows of the lane's
+// column, which are transposed inside the quad of lanes and written with one dword store per lane (128 contiguous bytes
+// per half-wave instruction).  `op` = the lane's cell of the group's first completed row; the FIRST group completes
+// rows 0 and 1 only (byte stores).  `wrap_mask`: 0 = clamp at 255 (avx2.rs:336), 0xff = mod 256 (Generic's +=).
+struct StoreSink {
+    uint8_t *op, *oq;
+    unsigned wrap_mask, sel_lo, sel_hi;
+    __device__ __forceinline__ StoreSink(uint8_t *o, unsigned wm) : op(o), wrap_mask(wm)
+    {
+        const unsigned q = threadIdx.x & 3u;
+        oq = op - q + q * 32;  // lane q of a quad writes row +q, the quad's 4 columns
+        sel_lo = 0x0c0c0000u | q | ((4u + q) << 8);
+        sel_hi = 0x00000c0cu | (q << 16) | ((4u + q) << 24);
+    }
+    __device__ __forceinline__ void advance(const size_t bytes)
+    {
+        op += bytes;
+        oq += bytes;
+    }
+    __device__ __forceinline__ unsigned narrow(const unsigned a) const
+    {   // (lo, hi) = (even row, odd row): clamp or mask both halves at once
+        return wrap_mask ? (a & 0x00ff00ffu) : pk_min_u16(a, 0x00ff00ffu);
+    }
+    template <int PHASE, int P, int NB, int MI>
+    __device__ __forceinline__ void complete(const unsigned fin0, const unsigned fin1)
+    {
+        if (PHASE == PHASE_FIRST) {
+            if (P == NB - 1) {
+                const unsigned r = narrow(fin1);
+                op[0] = (uint8_t)(r & 0xffu);
+                op[32] = (uint8_t)(r >> 16);
+            }
+        } else {
+            const unsigned r0 = narrow(fin0), r1 = narrow(fin1);
+            const unsigned pack = __builtin_amdgcn_perm(r0, r0, 0x0c0c0200u) | __builtin_amdgcn_perm(r1, r1, 0x02000c0cu);  // rows 4P .. 4P + 3
+            const unsigned p0 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0x00, 0xf, 0xf, true);
+            const unsigned p1 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0x55, 0xf, 0xf, true);
+            const unsigned p2 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0xaa, 0xf, 0xf, true);
+            const unsigned p3 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0xff, 0xf, 0xf, true);
+            const unsigned row = __builtin_amdgcn_perm(p1, p0, sel_lo) | __builtin_amdgcn_perm(p3, p2, sel_hi);
+            *reinterpret_cast<unsigned *>(oq + 4 * P * 32) = row;
+        }
+    }
+};
+
+// One group = NB pairs x NM motifs, item IDX = P * NM + MI.  On entry `cur` holds (or is about to receive) the rows of
+// item IDX, (off0, off1) are the LDS offsets of pair P's rows in motif 0's table, and blk[] holds the PFB blocks after
+// block P; on exit `cur` is the next item's (requested), unless this was the stream's last.
+template <int M, int KA, int NM, int PFB, int PHASE, int IDX, class Sink>
+__device__ __forceinline__ void pair_items(unsigned (&acc)[NM][prefilter2_npair(M)], unsigned (&blk)[prefilter2_ring(M) / 4],
+                                           PairRows<prefilter2_npair(M)> &cur, unsigned &off0, unsigned &off1,
+                                           const uint8_t *__restrict__ spq, const unsigned shq, const PairDecode &pd, Sink &sink)
+{
+    constexpr int NP = prefilter2_npair(M);
+    constexpr int NB = prefilter2_ring(M) / 4;  // = NP / 2 pairs per group
+    constexpr unsigned IMG = prefilter2_image_dw(M, KA) * 4;  // bytes per motif's table
+    if constexpr (IDX < NB * NM) {
+        constexpr int P = IDX / NM, MI = IDX % NM;
+        constexpr bool has_next = PHASE != PHASE_LAST || IDX + 1 < NB * NM;
+        constexpr unsigned next_table = MI + 1 < NM ? (MI + 1) * IMG : 0u;  // folded into the reads' offset field
+        if constexpr (has_next && MI + 1 == NM) {
+            // the next item starts pair P + 1 (the next group's pair 0 after the last): decode its block, whose register
+            // then takes block P + 1 + PFB
+            decode_block<M, KA>(blk[(P + 1) % NB], shq, pd, off0, off1);
+            if (PHASE != PHASE_LAST || P + 1 + PFB < NB)
+                blk[(P + 1 + PFB) % NB] = *reinterpret_cast<const unsigned *>(spq + (P + 1 + PFB) * 128);
+        }
+        PairRows<NP> nxt;
+        unsigned fin0 = 0;
+        pair_chunks<NP, P, 0>(acc[MI], cur, nxt, off0 + next_table, off1 + next_table, fin0, has_next);
+        sink.template complete<PHASE, P, NB, MI>(fin0, acc[MI][(2 * P + 2) % NP]);
+        if constexpr (has_next) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                cur.r0[i] = nxt.r0[i];
+                cur.r1[i] = nxt.r1[i];
+            }
+        }
+        pair_items<M, KA, NM, PFB, PHASE, IDX + 1>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
+    }
+}
+
+template <int NP, int C>
+__device__ __forceinline__ void pair_begin_rows(PairRows<NP> &cur, const unsigned off0, const unsigned off1)
+{
+    if constexpr (C < (NP + 3) / 4) {
+        read_row_chunk<NP, C>(cur.r0, off0);
+        read_row_chunk<NP, C>(cur.r1, off1);
+        pair_begin_rows<NP, C + 1>(cur, off0, off1);
+    }
+}
+
+// The FIRST group's lead-in: block 0 is decoded, item 0's rows are requested, block PFB follows the PFB blocks the
+// kernel's prologue requested.
+template <int M, int KA, int PFB>
+__device__ __forceinline__ void pair_begin(unsigned (&blk)[prefilter2_ring(M) / 4], PairRows<prefilter2_npair(M)> &cur,
+                                           unsigned &off0, unsigned &off1, const uint8_t *__restrict__ spq, const unsigned shq,
+                                           const PairDecode &pd)
+{
+    constexpr int NP = prefilter2_npair(M);
+    constexpr int NB = prefilter2_ring(M) / 4;
+    decode_block<M, KA>(blk[0], shq, pd, off0, off1);
+    blk[PFB % NB] = *reinterpret_cast<const unsigned *>(spq + PFB * 128);
+    pair_begin_rows<NP, 0>(cur, off0, off1);
+}
+
+// wavefronts per SIMD the register budget is cut for.  The hand-pipelined DNA scan keeps 3 NP + ~40 registers live
+// (accumulators, one pair of rows, a chunk of the next), the unrolled form about as many with its rows in flight.
+constexpr int prefilter2_waves(int m, int ka)
+{
+    const int np = prefilter2_npair(m);
+    if (ka != 5)
+        return m <= 52 ? 4 : m <= 80 ? 3 : 2;
+    return np <= 12 ? 6 : np <= 16 ? 5 : np <= 22 ? 4 : np <= 32 ? 3 : 2;
+}
+
 template <int M, int KA = 5>
-__global__ __launch_bounds__(kBlock, (KA == 5 && M <= kMaxFastM) ? 6 : M <= 52 ? 4 : M <= 80 ? 3 : 2) void score_c32_prefilter2(
+__global__ __launch_bounds__(kBlock, prefilter2_waves(M, KA)) void score_c32_prefilter2(
     const uint8_t *__restrict__ seq, const unsigned *__restrict__ image, const int K,
     const unsigned long long row_begin, const unsigned long long row_end,
     const unsigned long long T, const unsigned long long nstreams, unsigned td,
@@ -261,12 +438,18 @@ __global__ __launch_bounds__(kBlock, (KA == 5 && M <= kMaxFastM) ? 6 : M <= 52 ?
     constexpr int RING = prefilter2_ring(M);
     constexpr int NP = prefilter2_npair(M);
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    lds_zero_based(lds_raw);
     {
         uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
         const uint4 *src = reinterpret_cast<const uint4 *>(image);
-        constexpr int n4 = prefilter2_image_dw(M, KA) / 4;
-        for (int i = threadIdx.x; i < n4; i += kBlock)
-            dst[i] = src[i];
+        constexpr int n4 = prefilter2_image_dw(M, KA) / 4, row4 = prefilter2_stride_dw(M) / 4;
+        const unsigned bias = prefilter2_bias(td);
+        for (int i = threadIdx.x; i < n4; i += kBlock) {
+            uint4 v = src[i];
+            if (i % row4 == 0)
+                v.x += bias;  // dword 0 of a table row (see kFlagBits)
+            dst[i] = v;
+        }
     }
     __syncthreads();
 
@@ -290,11 +473,11 @@ __global__ __launch_bounds__(kBlock, (KA == 5 && M <= kMaxFastM) ? 6 : M <= 52 ?
     constexpr int NB = RING / 4;
     constexpr int PFB = NB > kPairPFB ? kPairPFB : NB;                       // blocks requested ahead of use (<= NB:
                                                                // a request reuses a slot only after its last read)
-    unsigned acc[NP];
+    unsigned acc[1][NP];
     unsigned blk[NB];
 #pragma unroll
     for (int i = 0; i < NP; ++i)
-        acc[i] = 0;
+        acc[0][i] = 0;
 #pragma unroll
     for (int j = 0; j < NB; ++j)
         blk[j] = 0;
@@ -307,34 +490,43 @@ __global__ __launch_bounds__(kBlock, (KA == 5 && M <= kMaxFastM) ? 6 : M <= 52 ?
         if (4 * j >= SHIFT || in0 + 4 * j + (long long)(col & 3) >= 0)  // SHIFT > 3: block 1 may start before the matrix too
             blk[j] = *reinterpret_cast<const unsigned *>(spq + j * 128);
 
-    const unsigned long long ngroups = (T - 2) / RING + 1;  // exact: T = q*RING + 2
-    unsigned long long hit_groups = 0;
-    const unsigned long long G = (ngroups + 63) / 64;  // groups per bit
-    unsigned long long gbit = 1, gleft = G;
-    unsigned mx = 0;
-    auto note_group = [&]() {
-        const bool flag = (mx & 0xffffu) >= td || (mx >> 16) >= td;
-        hit_groups |= flag ? gbit : 0ull;
-        mx = 0;
+    // wave-uniform 32-bit bookkeeping (T <= 2^30, score_plan.hip): in 64 bits the division lands on the VALU and
+    // drags the group counters into vector registers
+    const unsigned ngroups = (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)T - 2u) / (unsigned)RING + 1u));  // exact: T = q*RING + 2
+    const unsigned G = (ngroups + 63u) / 64u;  // groups per note (= per bit of hit_groups)
+    unsigned gleft = G, nnotes = 0;
+    unsigned mx[1] = {0};
+    GroupNotes notes;
+    auto end_group = [&]() {
         if (--gleft == 0) {
             gleft = G;
-            gbit <<= 1;
+            ++nnotes;
+            notes.note(mx[0]);
         }
     };
 
-    const QuadTranspose qt = quad_transpose_setup();
-    prefilter2_group<M, PFB, PHASE_FIRST, 0, KA>(acc, blk, spq, shq, lds_raw, mx, qt);
-    note_group();
-    for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
+    const PairDecode pd = pair_decode_setup<prefilter2_stride_dw(M) / 4>();
+    PairRows<NP> cur;
+    unsigned off0, off1;
+    FlagSink<1> sink{mx};
+    pair_begin<M, KA, PFB>(blk, cur, off0, off1, spq, shq, pd);
+    pair_items<M, KA, 1, PFB, PHASE_FIRST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
+    end_group();
+    for (unsigned g = 1; g + 1 < ngroups; ++g) {
         spq += RING * 32;
-        prefilter2_group<M, PFB, PHASE_MAIN, 0, KA>(acc, blk, spq, shq, lds_raw, mx, qt);
-        note_group();
+        pair_items<M, KA, 1, PFB, PHASE_MAIN, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
+        end_group();
     }
     if (ngroups > 1) {
         spq += RING * 32;
-        prefilter2_group<M, PFB, PHASE_LAST, 0, KA>(acc, blk, spq, shq, lds_raw, mx, qt);
-        note_group();
+        pair_items<M, KA, 1, PFB, PHASE_LAST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
+        end_group();
     }
+    if (gleft != G) {  // the last, partly filled note
+        ++nnotes;
+        notes.note(mx[0]);
+    }
+    unsigned long long hit_groups = notes.finish(nnotes);
 
     // flagged groups -> candidate row ranges (group 0: outputs 0, 1; group g >= 1: outputs
     // (g-1)*RING + 2 .. g*RING + 1, counted from the stream's first output row)
@@ -342,7 +534,8 @@ __global__ __launch_bounds__(kBlock, (KA == 5 && M <= kMaxFastM) ? 6 : M <= 52 ?
     const long long own_row = (long long)(stream * T);
     if (idle)
         hit_groups = 0;
-    emit_candidates(hit_groups, col, fo, [=](int bit, long long &r0, long long &r1) {
+    __syncthreads();  // the table is done with: its first bytes become emit_candidates' scratch
+    emit_candidates<true>(hit_groups, col, fo, [=](int bit, long long &r0, long long &r1) {
         const unsigned long long g0 = (unsigned long long)bit * G;
         unsigned long long g1 = g0 + G;
         if (g1 > ngroups)
@@ -355,7 +548,7 @@ __global__ __launch_bounds__(kBlock, (KA == 5 && M <= kMaxFastM) ? 6 : M <= 52 ?
         if (r0 < own_row)
             r0 = own_row;
         r1 = first_row + i1;
-    });
+    }, lds_raw);
 }
 
 // ---- several motifs of one length per pass ------------------------------------------------------
@@ -369,67 +562,6 @@ __global__ __launch_bounds__(kBlock, (KA == 5 && M <= kMaxFastM) ? 6 : M <= 52 ?
 constexpr int prefilter2_multi(int m)  // motifs per pass: bounded by the accumulator registers
 {
     return prefilter2_npair(m) <= 8 ? 4 : prefilter2_npair(m) <= 16 ? 2 : 1;
-}
-
-template <int M, int NM, int PFB, int PHASE>
-__device__ __forceinline__ void prefilter2_group_multi(unsigned (&acc)[NM][prefilter2_npair(M)],
-                                                       unsigned (&blk)[prefilter2_ring(M) / 4],
-                                                       const uint8_t *__restrict__ spq, const unsigned shq,
-                                                       const char *__restrict__ tab, unsigned (&mx)[NM],
-                                                       const QuadTranspose &qt)
-{
-    constexpr bool LUT = prefilter2_lut_decode(M, 5);
-    unsigned pair_off = 0;
-    constexpr int RING = prefilter2_ring(M);
-    constexpr int NB = RING / 4;
-    constexpr int NP = prefilter2_npair(M);
-    constexpr int NV = (NP + 3) / 4;
-    constexpr unsigned DSB = prefilter2_stride_dw(M) * 4;
-    constexpr unsigned IMG = prefilter2_image_dw(M) * 4;  // bytes per motif's table
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        const unsigned d = blk[k / 2];
-        unsigned row_off;
-        if constexpr (LUT) {
-            if ((k & 1) == 0)
-                pair_off = dna_pair_offsets<(int)(DSB / 16)>(quad_transpose(d, qt));
-            row_off = (k & 1) ? byte_times_16<2>(pair_off, qt.four) : byte_times_16<0>(pair_off, qt.four);
-        } else {
-            const unsigned a = (k & 1) ? quad_symbol<2>(d, shq) : quad_symbol<0>(d, shq);
-            const unsigned b = (k & 1) ? quad_symbol<3>(d, shq) : quad_symbol<1>(d, shq);
-            row_off = __umul24(dna_pair_row(a, b), DSB);
-        }
-        if ((k & 1) && (PHASE != PHASE_LAST || k / 2 + PFB < NB))
-            blk[(k / 2 + PFB) % NB] = *reinterpret_cast<const unsigned *>(spq + (k / 2 + PFB) * 128);
-        const char *row0 = tab + row_off;
-#pragma unroll
-        for (int mi = 0; mi < NM; ++mi) {
-            const char *row = static_cast<const char *>(__builtin_assume_aligned(row0 + mi * IMG, 16));
-            unsigned w[NV * 4];
-#pragma unroll
-            for (int q = 0; q < NP / 4; ++q) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(row + 16 * q);
-                w[4 * q + 0] = v.x;
-                w[4 * q + 1] = v.y;
-                w[4 * q + 2] = v.z;
-                w[4 * q + 3] = v.w;
-            }
-            if (NP % 4 >= 2) {
-                const lm_u32x2_t v = *(lm_lds_u64_ptr)(row + 16 * (NP / 4));
-                w[4 * (NP / 4) + 0] = v.x;
-                w[4 * (NP / 4) + 1] = v.y;
-            }
-            if (NP % 2 == 1)
-                w[NP - 1] = *reinterpret_cast<const unsigned *>(row + 4 * (NP - 1));
-#pragma unroll
-            for (int m = 0; m < NP; ++m)
-                acc[mi][(k - m + NP) % NP] = pk_add_u16(acc[mi][(k - m + NP) % NP], w[m]);
-            const int c = (k + 1) % NP;
-            if (PHASE != PHASE_FIRST || k == NP - 1)
-                mx[mi] = pk_max_u16(mx[mi], acc[mi][c]);
-            acc[mi][c] = 0;
-        }
-    }
 }
 
 // (register budget: at least 4 workgroups per CU; 3 and 5 measure the same, 6 spills: 32 vs 18 ms on the JASPAR argmax batch)
@@ -446,12 +578,18 @@ __global__ __launch_bounds__(kBlock, 4) void score_c32_prefilter2_multi(
     constexpr int IMG_DW = prefilter2_image_dw(M);
     const BatchParams *bps = fo_in.batch + (size_t)blockIdx.y * NM;  // this workgroup's NM jobs
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    lds_zero_based(lds_raw);
 #pragma unroll
     for (int mi = 0; mi < NM; ++mi) {
         uint4 *dst = reinterpret_cast<uint4 *>(lds_raw) + mi * (IMG_DW / 4);
         const uint4 *src = static_cast<const uint4 *>(bps[mi].table);
-        for (int i = threadIdx.x; i < IMG_DW / 4; i += kBlock)
-            dst[i] = src[i];
+        const unsigned bias = prefilter2_bias(bps[mi].td);
+        for (int i = threadIdx.x; i < IMG_DW / 4; i += kBlock) {
+            uint4 v = src[i];
+            if (i % (prefilter2_stride_dw(M) / 4) == 0)
+                v.x += bias;  // dword 0 of a table row (see kFlagBits)
+            dst[i] = v;
+        }
     }
     __syncthreads();
 
@@ -487,42 +625,50 @@ __global__ __launch_bounds__(kBlock, 4) void score_c32_prefilter2_multi(
         if (4 * j >= SHIFT || in0 + 4 * j + (long long)(col & 3) >= 0)  // SHIFT > 3: block 1 may start before the matrix too
             blk[j] = *reinterpret_cast<const unsigned *>(spq + j * 128);
 
-    const unsigned long long ngroups = (T - 2) / RING + 1;
-    const unsigned long long G = (ngroups + 63) / 64;
-    unsigned long long gbit = 1, gleft = G;
-    unsigned long long hit_groups[NM];
-    unsigned mx[NM], td[NM];
+    const unsigned ngroups = (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)T - 2u) / (unsigned)RING + 1u));
+    const unsigned G = (ngroups + 63u) / 64u;
+    unsigned gleft = G, nnotes = 0;
+    unsigned mx[NM];
+    GroupNotes notes[NM];
 #pragma unroll
-    for (int mi = 0; mi < NM; ++mi) {
-        hit_groups[mi] = 0;
+    for (int mi = 0; mi < NM; ++mi)
         mx[mi] = 0;
-        td[mi] = bps[mi].td;
-    }
-    auto note_group = [&]() {
-#pragma unroll
-        for (int mi = 0; mi < NM; ++mi) {
-            const bool flag = (mx[mi] & 0xffffu) >= td[mi] || (mx[mi] >> 16) >= td[mi];
-            hit_groups[mi] |= flag ? gbit : 0ull;
-            mx[mi] = 0;
-        }
+    auto end_group = [&]() {
         if (--gleft == 0) {
             gleft = G;
-            gbit <<= 1;
+            ++nnotes;
+#pragma unroll
+            for (int mi = 0; mi < NM; ++mi)
+                notes[mi].note(mx[mi]);
         }
     };
-    const QuadTranspose qt = quad_transpose_setup();
-    prefilter2_group_multi<M, NM, PFB, PHASE_FIRST>(acc, blk, spq, shq, lds_raw, mx, qt);
-    note_group();
-    for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
+    const PairDecode pd = pair_decode_setup<prefilter2_stride_dw(M) / 4>();
+    PairRows<NP> cur;
+    unsigned off0, off1;
+    FlagSink<NM> sink{mx};
+    pair_begin<M, 5, PFB>(blk, cur, off0, off1, spq, shq, pd);
+    pair_items<M, 5, NM, PFB, PHASE_FIRST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
+    end_group();
+    for (unsigned g = 1; g + 1 < ngroups; ++g) {
         spq += RING * 32;
-        prefilter2_group_multi<M, NM, PFB, PHASE_MAIN>(acc, blk, spq, shq, lds_raw, mx, qt);
-        note_group();
+        pair_items<M, 5, NM, PFB, PHASE_MAIN, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
+        end_group();
     }
     if (ngroups > 1) {
         spq += RING * 32;
-        prefilter2_group_multi<M, NM, PFB, PHASE_LAST>(acc, blk, spq, shq, lds_raw, mx, qt);
-        note_group();
+        pair_items<M, 5, NM, PFB, PHASE_LAST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
+        end_group();
     }
+    if (gleft != G) {
+        ++nnotes;
+#pragma unroll
+        for (int mi = 0; mi < NM; ++mi)
+            notes[mi].note(mx[mi]);
+    }
+    unsigned long long hit_groups[NM];
+#pragma unroll
+    for (int mi = 0; mi < NM; ++mi)
+        hit_groups[mi] = notes[mi].finish(nnotes);
 
     const long long first_row = (long long)(o0 - row_begin);
     const long long own_row = (long long)(stream * T);
@@ -530,7 +676,8 @@ __global__ __launch_bounds__(kBlock, 4) void score_c32_prefilter2_multi(
     for (int mi = 0; mi < NM; ++mi) {
         FusedOut fo = fo_in;
         fo.job_key = bps[mi].job_key;
-        emit_candidates(idle ? 0ull : hit_groups[mi], col, fo, [=](int bit, long long &r0, long long &r1) {
+        __syncthreads();  // the tables are done with (first motif) / the scratch is reused (the others)
+        emit_candidates<true>(idle ? 0ull : hit_groups[mi], col, fo, [=](int bit, long long &r0, long long &r1) {
             const unsigned long long g0 = (unsigned long long)bit * G;
             unsigned long long g1 = g0 + G;
             if (g1 > ngroups)
@@ -543,8 +690,7 @@ __global__ __launch_bounds__(kBlock, 4) void score_c32_prefilter2_multi(
             if (r0 < own_row)
                 r0 = own_row;
             r1 = first_row + i1;
-        });
-        __syncthreads();  // emit_candidates' shared scratch is reused by the next motif
+        }, lds_raw);
     }
 }
 

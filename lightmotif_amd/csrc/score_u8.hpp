@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_u8(
 // per LDS lookup, dword symbol loads).  `image` = pair table of the u8 weights
 // (prefilter2_pack_image); the sequence matrix must be 4-byte aligned.
 template <int M>
-__global__ __launch_bounds__(kBlock, 6) void score_c32_u8_pairs(
+__global__ __launch_bounds__(kBlock, prefilter2_waves(M, 5)) void score_c32_u8_pairs(
     const uint8_t *__restrict__ seq, const unsigned *__restrict__ image,
     const unsigned long long row_begin, const unsigned long long row_end,
     const unsigned long long T, const unsigned long long nstreams, uint8_t *__restrict__ out,
@@ -101,6 +101,7 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_u8_pairs(
     constexpr int RING = prefilter2_ring(M);
     constexpr int NP = prefilter2_npair(M);
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    lds_zero_based(lds_raw);
     {
         uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
         const uint4 *src = reinterpret_cast<const uint4 *>(image);
@@ -125,11 +126,11 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_u8_pairs(
     const uint8_t *spq = seq + (in0 + (col & 3)) * 32 + (col >> 2) * 4;  // this lane's row of a block
     constexpr int NB = RING / 4;
     constexpr int PFB = NB > kPairPFB ? kPairPFB : NB;
-    unsigned acc[NP];
+    unsigned acc[1][NP];
     unsigned blk[NB];
 #pragma unroll
     for (int i = 0; i < NP; ++i)
-        acc[i] = 0;
+        acc[0][i] = 0;
 #pragma unroll
     for (int j = 0; j < NB; ++j)
         blk[j] = 0;
@@ -143,18 +144,21 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_u8_pairs(
     // group 0 completes rows 0 and 1, group g >= 1 rows (g-1)*RING + 2 .. g*RING + 1
     const unsigned long long ngroups = (T - 2) / RING + 1;  // exact: T = q*RING + 2
     uint8_t *op = out + (o0 - row_begin) * 32 + col;
-    unsigned mx = 0;
-    const QuadTranspose qt = quad_transpose_setup();
-    prefilter2_group<M, PFB, PHASE_FIRST, 1>(acc, blk, spq, shq, lds_raw, mx, qt, op, wrap_mask);
-    op += 2 * 32;
+    const PairDecode pd = pair_decode_setup<prefilter2_stride_dw(M) / 4>();
+    PairRows<NP> cur;
+    unsigned off0, off1;
+    StoreSink sink(op, wrap_mask);
+    pair_begin<M, 5, PFB>(blk, cur, off0, off1, spq, shq, pd);
+    pair_items<M, 5, 1, PFB, PHASE_FIRST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
+    sink.advance(2 * 32);
     for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
         spq += RING * 32;
-        prefilter2_group<M, PFB, PHASE_MAIN, 1>(acc, blk, spq, shq, lds_raw, mx, qt, op, wrap_mask);
-        op += RING * 32;
+        pair_items<M, 5, 1, PFB, PHASE_MAIN, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
+        sink.advance(RING * 32);
     }
     if (ngroups > 1) {
         spq += RING * 32;
-        prefilter2_group<M, PFB, PHASE_LAST, 1>(acc, blk, spq, shq, lds_raw, mx, qt, op, wrap_mask);
+        pair_items<M, 5, 1, PFB, PHASE_LAST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
     }
 }
 

@@ -142,6 +142,23 @@ class Pipeline:
     def last_kernel(self) -> str:
         return self._L.lm_hip_ctx_last_kernel(self._h).decode()
 
+    @property
+    def last_scan_counts(self) -> Tuple[int, int]:
+        """(hits, candidate pieces) of the last fused threshold scan on this pipeline (lm_hip_ctx_last_scan_counts)."""
+        h, c = C.c_ulonglong(0), C.c_ulonglong(0)
+        check(self._L.lm_hip_ctx_last_scan_counts(self._h, C.byref(h), C.byref(c)))
+        return int(h.value), int(c.value)
+
+    def clock_begin(self) -> None:
+        """Marks the start of a bracket on the pipeline's stream (lm_hip_ctx_clock_begin)."""
+        check(self._L.lm_hip_ctx_clock_begin(self._h))
+
+    def clock_end(self) -> Tuple[float, float]:
+        """(mean shader clock in MHz, elapsed us) of what the stream ran since clock_begin(); waits for it."""
+        mhz, us = C.c_double(0.0), C.c_double(0.0)
+        check(self._L.lm_hip_ctx_clock_end(self._h, C.byref(mhz), C.byref(us)))
+        return mhz.value, us.value
+
     # -- Encode / Stripe (pli/mod.rs:34-67, 164-201) ---------------------------
 
     def encode(self, sequence: Union[str, bytes], protein: bool = False) -> "EncodedSequence":

@@ -210,8 +210,54 @@ static void test_other_geometries()
     }
 }
 
-int main()
+// `test_dispatch --bench`: the Scanner site's two routes by sequence length (one CPU thread, as the reference gives a
+// Scanner), as JSON lines -- the numbers behind kCostScan (csrc/hostptr.hip) and INTEGRATION.md 3.
+#include <chrono>
+template <class F>
+static double median_us(F &&f, int reps)
 {
+    std::vector<double> t;
+    for (int i = 0; i < reps + 2; ++i) {
+        const auto t0 = std::chrono::steady_clock::now();
+        f();
+        const auto t1 = std::chrono::steady_clock::now();
+        if (i >= 2)
+            t.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
+    }
+    std::sort(t.begin(), t.end());
+    return t[t.size() / 2];
+}
+
+static int bench_scan()
+{
+    HipDispatch<PortTier> gpu, cpu;
+    gpu.policy.force(LM_HIP_OP_SCAN, 0);
+    cpu.policy.force(LM_HIP_OP_SCAN, SIZE_MAX);
+    const auto pssm = mx000001();
+    std::printf("{\"motif\": \"MX000001 (M = 15)\", \"threshold\": 10.0, \"scan\": [");
+    bool first = true;
+    for (size_t len : {(size_t)10'000, (size_t)50'000, (size_t)100'000, (size_t)464'165, (size_t)1'000'000, (size_t)4'641'652, (size_t)20'000'000}) {
+        host::StripedSequence<Dna> seq = host::StripedSequence<Dna>::stripe(EncodedSequence<Dna>::encode(random_dna(len, (unsigned)len)), 32);
+        seq.configure(pssm);
+        const int reps = len > 2'000'000 ? 5 : 25;
+        size_t na = 0, nb = 0;
+        const double g = median_us([&] { na = gpu.scan(pssm, seq, 10.0f).size(); }, reps);
+        const double c = median_us([&] { nb = cpu.scan(pssm, seq, 10.0f).size(); }, reps);
+        const double gm = median_us([&] { (void)gpu.scan_max(pssm, seq, 10.0f); }, reps);
+        const double cm = median_us([&] { (void)cpu.scan_max(pssm, seq, 10.0f); }, reps);
+        std::printf("%s{\"length\": %zu, \"hits\": %zu, \"same_hit_count\": %s, \"scan_host_pointer_us\": %.2f, \"scan_cpu_tier_us\": %.2f, "
+                    "\"scan_max_host_pointer_us\": %.2f, \"scan_max_cpu_tier_us\": %.2f}",
+                    first ? "" : ", ", len, na, na == nb ? "true" : "false", g, c, gm, cm);
+        first = false;
+    }
+    std::printf("]}\n");
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1 && std::string(argv[1]) == "--bench")
+        return Hip::available() ? bench_scan() : 2;
     bool threw = false;
     if (!Hip::available()) {
         try {

@@ -106,6 +106,61 @@ def bench_c1():
             "x_avx2_port": round(c_med / med, 2)}
 
 
+def bench_readme_10kb():
+    """The reference's second published benchmark (README.md:111-118): the highest-scoring
+    position of a 10 kb sequence, MX000001 (M = 15) -- 12.797 us with AVX2 on an i7-10710U.  Through host pointers
+    (lm_hip_score_f32 + lm_hip_argmax_f32) and with the one-thread AVX2 port on this box (Avx2::score_f32_rows_into +
+    Avx2::argmax_f32, called as the shim would: no thread start, no conversions).  A `Dispatch::Hip { cpu }` variant keeps
+    this size on its CPU tier; `crossover_positions` = the shipped policy at this motif length."""
+    from oracle import c_oracle as co
+    length = 10_000
+    enc = np.random.default_rng(0x10CB).integers(0, 4, length, dtype=np.uint8)
+    pssm = lm.create(["GTTGACCTTATCAAC", "GTTGATCCAGTCAAC"]).counts.normalize(0.1).log_odds().data
+    m = pssm.shape[0]
+    mat, rows, _ = striped(enc, m)
+    out = co.aligned_empty((rows, COLS), np.float32)
+    best = [None]
+
+    def it():
+        score_f32(mat, rows, length, pssm, out)
+        best[0] = argmax_f32(out, rows)
+    med, mn = loop_us(it, 500, 50)
+    data = co.aligned_empty(mat.shape, np.uint8)
+    data[:] = mat
+    p = co.aligned_empty(pssm.shape, np.float32)
+    p[:] = pssm
+    cout = co.aligned_empty((rows, COLS), np.float32)
+    A = co.avx2()
+    u8p, f32p = C.POINTER(C.c_uint8), C.POINTER(C.c_float)
+    seq_p, p_p, cout_p = data.ctypes.data_as(u8p), p.ctypes.data_as(f32p), cout.ctypes.data_as(f32p)
+    r_, c_ = C.c_size_t(0), C.c_size_t(0)
+
+    def cpu_it():
+        A.lma_score_rows_f32(seq_p, COLS, m - 1, length, p_p, m, p.shape[1], 5, 0, rows, cout_p, COLS)
+        A.lma_argmax_f32(cout_p, rows, COLS, length + 1 - m, C.byref(r_), C.byref(c_))
+    c_med, c_min = loop_us(cpu_it, 500, 50)
+    same = bool(np.array_equal(cout.view(np.uint32), out.view(np.uint32)))
+    return {"workload": "README.md:111-118: score + argmax of a 10 kb sequence, MX000001 (M = 15), per iteration",
+            "host_pointer_us": round(med, 2), "host_pointer_us_min": round(mn, 2), "avx2_port_us": round(c_med, 2),
+            "avx2_port_us_min": round(c_min, 2), "published_avx2_us": 12.797, "scores_match_avx2_port_bitwise": same,
+            "dispatch_hip_route": "cpu tier (10 000 cells < every crossover)"}
+
+
+def crossover_positions(m: int = 15, k: int = 5):
+    """lm_hip_host_crossover per `dispatch.rs` site: cells (= positions) from which `Dispatch::Hip { cpu }` sends a call on
+    host matrices to the GPU; None = the site stays on the CPU tier at every size."""
+    names = ["encode", "score_f32", "score_u8", "stripe", "maximum_f32", "maximum_u8", "threshold_f32", "threshold_u8", "scan"]
+    out = {}
+    for op, name in enumerate(names):
+        cells = C.c_size_t(0)
+        st = L.lm_hip_host_crossover(op, m, k, C.byref(cells))
+        assert st == 0, _ffi.last_error()
+        out[name] = None if cells.value == C.c_size_t(-1).value else int(cells.value)
+    return {"motif_len": m, "cells": out,
+            "source": "cost model of csrc/hostptr.hip (kCost*), constants measured by tools/crossover.py + tests/cpp/test_dispatch --bench "
+                      "on MI355X + EPYC 9575F, one CPU thread (profiles/r05_crossover.json)"}
+
+
 def bench_block():
     """Scanner::next's inner step (scan.rs:174-178): pli.score_rows_into(&dm, seq, row..row+256, &mut dscores) -- u8 scores of
     one 256-row block land in the caller's host matrix"""
