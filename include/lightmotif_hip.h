@@ -102,15 +102,10 @@ int lm_hip_result_pool_info(size_t *pinned_idle, size_t *pinned_in_use, size_t *
  * mostly-sleeping wavefront on a stream of its own (s_memtime ticks per s_memrealtime tick) -- call it from
  * a second host thread while the kernels of interest run to learn the clock THEY get (the part clocks to its power
  * budget; a roofline priced at the 2.4 GHz of the data sheet is not what an LDS- or VALU-bound kernel can reach).
+ * The probe's stream and record are made once per device and kept.  (Two marks enqueued IN the measured stream were tried
+ * and dropped: the counter is per XCD and not comparable between the places two one-workgroup kernels land.)
  * No reference counterpart; bench.py reports it next to every LDS fraction. */
 int lm_hip_device_clock_mhz(int device, unsigned window_us, double *mhz);
-/* The same two counters read IN the context's stream: `begin` enqueues a one-wavefront kernel that records them, `end`
- * enqueues a second one, waits for it and returns the mean shader clock (MHz) and the elapsed time (us) of everything
- * the stream ran in between -- the clock the bracketed kernels got, with no second queue beside them (a probe on a
- * stream of its own slowed synchronising callers: profiles/r05_clock_probe.json).  One bracket at a time per context;
- * LM_HIP_ERR_BAD_ARGS for `end` without `begin`.  Either output may be NULL. */
-int lm_hip_ctx_clock_begin(lm_hip_ctx *ctx);
-int lm_hip_ctx_clock_end(lm_hip_ctx *ctx, double *mhz, double *elapsed_us);
 
 /* DenseMatrix::stride (dense.rs:126-128) for x86-64 hosts: elements per row. */
 size_t lm_hip_stride(size_t cols, size_t elem_size);

@@ -54,8 +54,6 @@ SIGNATURES = {
     "lm_hip_free": (None, [_vp]),
     "lm_hip_result_pool_info": (C.c_int, [_szp, _szp, _szp]),
     "lm_hip_device_clock_mhz": (C.c_int, [C.c_int, C.c_uint, C.POINTER(C.c_double)]),
-    "lm_hip_ctx_clock_begin": (C.c_int, [_vp]),
-    "lm_hip_ctx_clock_end": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lm_hip_stride": (_sz, [_sz, _sz]),
     "lm_hip_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "lm_hip_ctx_create_on_stream": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),

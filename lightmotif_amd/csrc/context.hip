@@ -303,83 +303,39 @@ int lm_hip_device_clock_mhz(int device, unsigned window_us, double *mhz)
     LM_HIP_TRY(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, device));
     if (wall_khz <= 0)
         return fail(LM_HIP_ERR_HIP, "device_clock_mhz: the device reports no constant-rate counter");
-    hipStream_t stream = nullptr;
-    unsigned long long *rec = nullptr;
-    // default priority: on a high-priority queue the probe's (long-lived) wavefront held back the dispatch of the
-    // kernels under measurement (round 5: 0.34 ms calls took 5 ms each beside it, and it reported the idle clock)
-    hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
-    if (e == hipSuccess)
-        e = hipHostMalloc(reinterpret_cast<void **>(&rec), 2 * sizeof(unsigned long long), hipHostMallocDefault);
+    // One probe stream and one pinned record per device, made once and kept: creating and freeing them per window
+    // (hipHostFree and hipStreamDestroy synchronise the device) stalled every other thread's synchronising calls --
+    // fused scans took 1.4 ms instead of 0.29 beside the probe (profiles/r05_clock_probe.json).  Default priority: on a
+    // high-priority queue the probe's long-lived wavefront held back the dispatch of the kernels under measurement.
+    struct Probe {
+        hipStream_t stream = nullptr;
+        unsigned long long *rec = nullptr;
+    };
+    static std::mutex probe_mu;
+    static Probe probes[64];
+    std::lock_guard<std::mutex> probe_lock(probe_mu);  // one window at a time per process
+    if (device >= 64)
+        return fail(LM_HIP_ERR_BAD_ARGS, "device_clock_mhz: device ordinal %d", device);
+    Probe &pr = probes[device];
+    hipError_t e = hipSuccess;
+    if (!pr.stream)
+        e = hipStreamCreateWithFlags(&pr.stream, hipStreamNonBlocking);
+    if (e == hipSuccess && !pr.rec)
+        e = hipHostMalloc(reinterpret_cast<void **>(&pr.rec), 2 * sizeof(unsigned long long), hipHostMallocDefault);
     if (e == hipSuccess) {
-        rec[0] = rec[1] = 0;
-        hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, stream,
-                           (unsigned long long)window_us * (unsigned long long)wall_khz / 1000ull, rec);
+        pr.rec[0] = pr.rec[1] = 0;
+        hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, pr.stream,
+                           (unsigned long long)window_us * (unsigned long long)wall_khz / 1000ull, pr.rec);
         e = hipGetLastError();
     }
     if (e == hipSuccess)
-        e = hipStreamSynchronize(stream);
-    const unsigned long long ticks = rec ? rec[0] : 0, ref = rec ? rec[1] : 0;
-    if (rec)
-        (void)hipHostFree(rec);
-    if (stream)
-        (void)hipStreamDestroy(stream);
+        e = hipStreamSynchronize(pr.stream);
+    const unsigned long long ticks = pr.rec ? pr.rec[0] : 0, ref = pr.rec ? pr.rec[1] : 0;
     if (e != hipSuccess)
         return fail(LM_HIP_ERR_HIP, "device_clock_mhz: %s", hipGetErrorString(e));
     if (ref == 0)
         return fail(LM_HIP_ERR_HIP, "device_clock_mhz: the constant-rate counter did not advance");
     *mhz = (double)ticks / (double)ref * (double)wall_khz / 1000.0;
-    return LM_HIP_OK;
-}
-
-namespace lm {
-__global__ void clock_mark_kernel(unsigned long long *out)
-{
-    const unsigned long long c = __builtin_amdgcn_s_memtime();
-    const unsigned long long r = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0) {
-        out[0] = c;
-        out[1] = r;
-    }
-}
-}  // namespace lm
-
-int lm_hip_ctx_clock_begin(lm_hip_ctx *ctx)
-{
-    if (!ctx)
-        return fail(LM_HIP_ERR_BAD_ARGS, "ctx_clock_begin: null context");
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    DeviceGuard guard(ctx->device);
-    if (!ctx->clock_rec)
-        LM_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->clock_rec), 4 * sizeof(unsigned long long), hipHostMallocDefault));
-    hipLaunchKernelGGL(clock_mark_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->clock_rec);
-    LM_HIP_TRY(hipGetLastError());
-    ctx->clock_open = true;
-    return LM_HIP_OK;
-}
-
-int lm_hip_ctx_clock_end(lm_hip_ctx *ctx, double *mhz, double *elapsed_us)
-{
-    if (!ctx)
-        return fail(LM_HIP_ERR_BAD_ARGS, "ctx_clock_end: null context");
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    if (!ctx->clock_open)
-        return fail(LM_HIP_ERR_BAD_ARGS, "ctx_clock_end without ctx_clock_begin");
-    DeviceGuard guard(ctx->device);
-    ctx->clock_open = false;
-    int wall_khz = 0;
-    LM_HIP_TRY(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, ctx->device));
-    if (wall_khz <= 0)
-        return fail(LM_HIP_ERR_HIP, "ctx_clock_end: the device reports no constant-rate counter");
-    hipLaunchKernelGGL(clock_mark_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->clock_rec + 2);
-    LM_HIP_TRY(hipGetLastError());
-    LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    const unsigned long long ticks = ctx->clock_rec[2] - ctx->clock_rec[0], ref = ctx->clock_rec[3] - ctx->clock_rec[1];
-    if (ref == 0)
-        return fail(LM_HIP_ERR_HIP, "ctx_clock_end: the constant-rate counter did not advance");
-    if (mhz)
-        *mhz = (double)ticks / (double)ref * (double)wall_khz / 1000.0;
-    if (elapsed_us)
-        *elapsed_us = (double)ref / (double)wall_khz * 1000.0;
     return LM_HIP_OK;
 }
 
@@ -504,8 +460,6 @@ int lm_hip_ctx_destroy(lm_hip_ctx *ctx)
     ctx->u8_tables.release();
     if (ctx->pinned)
         (void)hipHostFree(ctx->pinned);
-    if (ctx->clock_rec)
-        (void)hipHostFree(ctx->clock_rec);
     if (ctx->d_ticket)
         (void)hipFree(ctx->d_ticket);
     if (ctx->copy_stream) {

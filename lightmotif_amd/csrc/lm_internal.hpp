@@ -99,8 +99,6 @@ struct lm_hip_ctx {
     size_t chunk_rows = 1u << 22; // rows of that chunk (512 MB at C = 32; option "chunk_rows")
     bool chunked_fused = true;  // A/B knob: 0 = such motifs go cell by cell (option "chunked_fused")
     void *pinned = nullptr;     // kPinnedBytes of host-pinned memory for read-backs
-    unsigned long long *clock_rec = nullptr;  // lm_hip_ctx_clock_begin / _end: {shader ticks, constant-rate ticks} x 2, pinned
-    bool clock_open = false;
     unsigned fold_generation = 0; // of the last single-job fused argmax whose kernel wrote its result into `pinned`
     unsigned *d_ticket = nullptr; // "last workgroup folds the records" counter of the single-launch argmax forms (zero between launches)
     size_t rows_per_stream = 0; // 0 = default

@@ -101,6 +101,37 @@ static int launch_score_argmax_exact(lm_hip_ctx *ctx, const ScoreArgs *jobs, siz
 {
     if (n == 0)
         return LM_HIP_OK;
+    // One small job off the C = 32 kernels (C = 1 is the Generic geometry of the reference's own bench, dna.rs:112-116):
+    // ONE launch.  The tiled store kernel scores into the chunk buffer and leaves a (value, cell) record per workgroup
+    // in the pinned block, folded here -- what score_into + argmax on handles do (27 us per iteration of configs[0]);
+    // the chunked route below takes a store, a reduction and a finalize launch (41 us).
+    // (C = 16 has an unrolled store kernel of its own, which leaves no records)
+    if (n == 1 && ctx->host_fold && jobs[0].cols != 32 && jobs[0].cols != 16 && chunked_ok(ctx, jobs[0]) && !plan_c32(ctx, jobs[0], false).ok) {
+        const ScoreArgs &a = jobs[0];
+        const unsigned long long rows = a.row_end - a.row_begin;
+        const unsigned nrec = tiled_records(ctx, a);
+        if (nrec && rows <= chunk_rows_for(ctx, a) && rows * a.cols < (1ull << 32) && 4096 + ((size_t)nrec + 1) * 16 <= kPinnedBytes) {
+            LM_TRY(ctx->chunk_scores.reserve(rows * a.cols * sizeof(float)));
+            uint4 *records = reinterpret_cast<uint4 *>(static_cast<char *>(ctx->pinned) + 4096);
+            for (size_t r = 0; r <= nrec; ++r)  // shared staging: stale bytes must not look like this launch's generation
+                reinterpret_cast<volatile unsigned long long *>(records)[2 * r] = 0ull;
+            const unsigned gen = ++ctx->fold_generation ? ctx->fold_generation : ++ctx->fold_generation;
+            unsigned written = 0;
+            ScoreArgs t = a;
+            t.d_out = static_cast<float *>(ctx->chunk_scores.ptr);
+            t.out_stride = a.cols;
+            t.track_records = records;
+            t.track_generation = gen;
+            t.track_cap = (size_t)nrec + 1;
+            t.track_nrec = &written;
+            LM_TRY(launch_score_store(ctx, t));
+            if (written) {
+                ctx->last_kernel = "score_tiled+host_fold";
+                return fold_host_records(ctx, records, written, gen, first_cell_rule != 0, out);
+            }
+            LM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // (no records after all: the general route, buffer quiescent)
+        }
+    }
     const std::vector<JobGroup> groups = group_jobs(ctx, jobs, n, [&](size_t i) {
         return plan_c32(ctx, jobs[i], false).ok ? KIND_EXACT : chunked_ok(ctx, jobs[i]) ? KIND_CHUNKED : KIND_GENERIC;
     });

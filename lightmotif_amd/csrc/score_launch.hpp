@@ -153,6 +153,7 @@ std::vector<JobGroup> group_jobs(const lm_hip_ctx *ctx, const ScoreArgs *jobs, s
 // position) once the input is large enough for two more launches not to matter: their fused forms
 // otherwise run one thread per cell (30-70 Gpos/s).
 bool chunked_ok(const lm_hip_ctx *ctx, const ScoreArgs &a);
+unsigned tiled_records(const lm_hip_ctx *ctx, const ScoreArgs &a);  // score_store.hip: records of the tiled store kernel, 0 = not its shape
 unsigned long long chunk_rows_for(const lm_hip_ctx *ctx, const ScoreArgs &a);  // ctx->chunk_rows is quoted for C = 32
 unsigned long long chunk_count(const lm_hip_ctx *ctx, const ScoreArgs &a);
 unsigned chunk_argmax_grid(const lm_hip_ctx *ctx);  // workgroups of the per-chunk argmax (a full chunk is 2^25 cells)

@@ -415,7 +415,10 @@ constexpr int prefilter2_waves(int m, int ka)
     const int np = prefilter2_npair(m);
     if (ka != 5)
         return m <= 52 ? 4 : m <= 80 ? 3 : 2;
-    return np <= 12 ? 6 : np <= 16 ? 5 : np <= 22 ? 4 : np <= 32 ? 3 : 2;
+    // (one step below what the registers in use would allow: at the tighter bound the allocator spills a few registers
+    // around the loop, and a kernel with ANY scratch pays for it at every wavefront launch -- M = 20: 80 VGPRs either way,
+    // 0.302 -> 0.283 ms per Gbp without the 12 bytes of scratch; profiles/r05_pair_scan_ab.txt)
+    return np <= 14 ? 5 : np <= 22 ? 4 : np <= 30 ? 3 : 2;
 }
 
 template <int M, int KA = 5>
@@ -566,7 +569,7 @@ constexpr int prefilter2_multi(int m)  // motifs per pass: bounded by the accumu
 
 // (register budget: at least 4 workgroups per CU; 3 and 5 measure the same, 6 spills: 32 vs 18 ms on the JASPAR argmax batch)
 template <int M, int NM>
-__global__ __launch_bounds__(kBlock, 4) void score_c32_prefilter2_multi(
+__global__ __launch_bounds__(kBlock, prefilter2_npair(M) <= 14 ? 4 : 3) void score_c32_prefilter2_multi(
     const uint8_t *__restrict__ seq, const unsigned long long row_begin, const unsigned long long row_end,
     const unsigned long long T, const unsigned long long nstreams, const FusedOut fo_in)
 {

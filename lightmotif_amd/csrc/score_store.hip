@@ -41,6 +41,14 @@ static unsigned tiled_plan(const lm_hip_ctx *ctx, const ScoreArgs &a, unsigned l
     return (unsigned)((n + tr - 1) / tr);
 }
 
+// workgroup records the tiled kernel would leave for `a` (0: the shape does not go through it)
+unsigned tiled_records(const lm_hip_ctx *ctx, const ScoreArgs &a)
+{
+    unsigned long long tr = 0;
+    size_t lds = 0;
+    return tiled_plan(ctx, a, &tr, &lds);
+}
+
 int launch_score_store(lm_hip_ctx *ctx, const ScoreArgs &a)
 {
     FusedOut fo{};

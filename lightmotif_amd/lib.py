@@ -149,15 +149,37 @@ class Pipeline:
         check(self._L.lm_hip_ctx_last_scan_counts(self._h, C.byref(h), C.byref(c)))
         return int(h.value), int(c.value)
 
-    def clock_begin(self) -> None:
-        """Marks the start of a bracket on the pipeline's stream (lm_hip_ctx_clock_begin)."""
-        check(self._L.lm_hip_ctx_clock_begin(self._h))
+    def sustained_clock_mhz(self, load, seconds: float = 0.25, window_us: int = 3000):
+        """Shader clock (MHz, median over windows) the device sustains while `load()` is called back to back for
+        `seconds` from this thread; a second thread runs lm_hip_device_clock_mhz windows beside it.  Returns
+        (mhz or None, ms per call with the probe running, ms per call without)."""
+        import threading
+        import time
+        dev = C.c_int(self.device)
 
-    def clock_end(self) -> Tuple[float, float]:
-        """(mean shader clock in MHz, elapsed us) of what the stream ran since clock_begin(); waits for it."""
-        mhz, us = C.c_double(0.0), C.c_double(0.0)
-        check(self._L.lm_hip_ctx_clock_end(self._h, C.byref(mhz), C.byref(us)))
-        return mhz.value, us.value
+        def run(duration):
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < duration:
+                load()
+                n += 1
+            self.sync()
+            return (time.perf_counter() - t0) / max(n, 1) * 1e3
+        run(0.05)
+        alone = run(seconds / 2)
+        samples, stop = [], threading.Event()
+
+        def sampler():
+            mhz = C.c_double(0.0)
+            while not stop.is_set():
+                if self._L.lm_hip_device_clock_mhz(dev.value, window_us, C.byref(mhz)) == 0:
+                    samples.append(mhz.value)
+        th = threading.Thread(target=sampler)
+        th.start()
+        beside = run(seconds)
+        stop.set()
+        th.join()
+        s = sorted(samples[1:-1] if len(samples) > 4 else samples)
+        return (s[len(s) // 2] if s else None), beside, alone
 
     # -- Encode / Stripe (pli/mod.rs:34-67, 164-201) ---------------------------
 

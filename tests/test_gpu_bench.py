@@ -66,6 +66,30 @@ def test_two_ranks_without_a_launcher():
     assert "invalid" not in out
 
 
+def test_eight_ranks_rehearsed_on_one_device():
+    """The first real 8-GPU run must not also be the first 8-rank run: the launcher-less line at --gpus 8 with all ranks
+    on cuda:0 over gloo -- 8 row shards + halos, 8 merge records per step, the threshold lists of 8 ranks concatenated,
+    and the motif-sharded configs[2] leg (LPT over 2 346 motifs, 8 shares).  NOT a scaling number: one device."""
+    out = run_bench("--gpus", "8", "--single-device", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1",
+                    "--length", "50000000", "--preheat-ms", "20", "--cpu-seconds", "1", "--cpu-sample", "4000000", timeout=1500)
+    assert out["n_gpus"] == 8 and "invalid" not in out
+    cfg = out["config"]
+    assert cfg["parallelism"] == "row-shard x8" and cfg["halo_verified"] is True and cfg["process_group"] == "gloo x8"
+    assert len(cfg["devices"]) == 8 and cfg["distinct_devices"] == 1
+    whole = run_bench("--gpus", "1", "--steps", "2", "--warmup", "1", "--length", "400000000", "--preheat-ms", "20",
+                      "--no-cpu-baseline", "--no-extras")
+    assert out["extras"]["argmax_global"] == whole["extras"]["argmax_global"]     # 8 shards merge to the whole job's cell
+    assert out["extras"]["threshold_hits"] > 0
+    c3 = out["extras"]["configs"]["c3"]
+    assert c3["parallelism"].startswith("motif-shard x8") and len(c3["motifs_per_rank"]) == 8
+    assert sum(c3["motifs_per_rank"]) == 2346 and min(c3["motifs_per_rank"]) > 0 and c3["hits_total"] > 0
+    one = run_bench("--config", "c3", "--gpus", "1", "--steps", "1", "--warmup", "1", "--no-cpu-baseline")
+    assert c3["hits_total"] == one["extras"]["hits_total"]     # 8 shares of the motif list find what one rank finds
+    (ROOT / "gpurun_out").mkdir(exist_ok=True)
+    (ROOT / "gpurun_out" / "bench_8rank_gloo_single_device.json").write_text(json.dumps(
+        {"note": "8 ranks on ONE device over gloo: a rehearsal of the control flow, NOT a scaling number", **out}) + "\n")
+
+
 def test_a_line_that_is_not_n_ranks_on_n_devices_fails_loudly():
     """Two ranks on one device WITHOUT the rehearsal flag's exemption cannot happen by accident (LOCAL_RANK picks the
     device), but a launcher that maps both ranks to one GPU can: the line carries `invalid` and the exit status is 3."""
@@ -111,6 +135,18 @@ def test_single_gpu_line_has_every_contract_field():
         assert fr["bound"] == "lds" and 0 < fr["frac"] < 1.2 and 0 < fr["hbm_read_frac"] < 1
     assert ex["c3"]["roofline"]["bound"] == "lds" and 0 < ex["c3"]["roofline"]["frac"] < 1.2
     assert ex["c5"]["roofline"]["bound"] == "hbm" and ex["c5"]["roofline"]["frac"] == ex["c5"]["hbm_frac"]
+    # round 5: the clock every LDS / VALU fraction is also quoted at, the reference's 10 kb benchmark, the shipped crossovers
+    assert 500 < rf["sclk_mhz_sustained"] < 3000 and 0 < rf["lds_frac_at_sustained_clock"] < 1.2 and 0 < rf["valu_frac_at_sustained_clock"] < 1.2
+    for key in ("fused_score_argmax", "fused_score_threshold"):
+        fr = out["extras"][key]["roofline"]
+        assert fr["sclk_mhz_sustained"] is None or 0 < fr["lds_frac_at_sustained_clock"] < 1.5
+    r10 = ex["readme_10kb"]
+    assert r10["published_avx2_us"] == 12.797 and r10["host_pointer_us"] > 0 and r10["avx2_port_us"] > 0
+    assert r10["scores_match_avx2_port_bitwise"] is True
+    xo = out["extras"]["crossover_positions"]["cells"]
+    assert xo["encode"] is None and xo["stripe"] is None and xo["maximum_u8"] is None and xo["threshold_u8"] is None
+    assert 10_000 < xo["score_f32"] < xo["score_u8"] and xo["scan"] > 10_000 and xo["maximum_f32"] > 10_000
+    assert ex["c1"]["C1_generic_bench_geometry"]["fused_score_argmax_us"] <= 1.25 * ex["c1"]["C1_generic_bench_geometry"]["us_per_iter"]
 
 
 def test_one_rank_through_the_c_abi_communicator():

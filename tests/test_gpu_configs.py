@@ -598,7 +598,8 @@ def test_other_geometries_take_the_tiled_kernel(pli, cols, m, k):
     a, b = ref.rows - 3, ref.rows
     big = pli.score_argmax(pssm, seq)
     # (short motifs may be settled from the last rows -- a small sub-range, scanned cell by cell -- before that)
-    assert pli.last_kernel == "score_store+reduce" or (m <= 9 and pli.last_kernel.startswith("score_generic<")), \
+    # (one launch when a single chunk holds the matrix: the tiled kernel's workgroup records, folded by the host)
+    assert pli.last_kernel in ("score_store+reduce", "score_tiled+host_fold") or (m <= 9 and pli.last_kernel.startswith("score_generic<")), \
         pli.last_kernel
     full, _ = co.score_rows(ref, p)
     assert big[0] == co.argmax(full, cols)

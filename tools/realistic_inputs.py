@@ -188,7 +188,9 @@ def main():
                 p = pssms[i]
                 m = p.data.shape[0]
                 co.configure_wrap(s, m - 1)
-                want = co.avx2_score_rows(s, np.ascontiguousarray(p.data, np.float32), threads=NTHREADS)
+                pa = co.aligned_empty(p.data.shape, np.float32)
+                pa[:] = p.data
+                want = co.avx2_score_rows(s, pa, threads=NTHREADS)
                 rc = co.threshold(want, COLS, ts[i])
                 g_rc, g_val = res[0][i]
                 ok = np.array_equal(np.asarray(g_rc), rc) and np.array_equal(
@@ -198,7 +200,9 @@ def main():
                                 "argmax_matches_oracle": bool(ok_am)})
             r["parity_vs_avx2_port_whole_sequence"] = checked
             co.configure_wrap(s, 19)
-            want = co.avx2_score_rows(s, np.ascontiguousarray(m20.data, np.float32), threads=NTHREADS)
+            pa = co.aligned_empty(m20.data.shape, np.float32)
+            pa[:] = m20.data
+            want = co.avx2_score_rows(s, pa, threads=NTHREADS)
             rc = co.threshold(want, COLS, t20)
             r["fused_threshold_m20_matches_oracle"] = bool(np.array_equal(np.asarray(one[0][0]), [tuple(x) for x in rc.tolist()])
                                                            if len(rc) else len(one[0][0]) == 0)
