@@ -272,6 +272,13 @@ __device__ __forceinline__ void pair_chunks(unsigned (&acc)[NP], const PairRows<
     }
 }
 
+// A 4-row block of symbols: one dword per lane.  (Non-temporal loads measured for the single-motif scans, which read the
+// sequence once: 1-3 %, profiles/r05_pair_scan_ab.txt -- not worth a second instantiation of every kernel.)
+__device__ __forceinline__ unsigned load_block(const uint8_t *__restrict__ p)
+{
+    return *reinterpret_cast<const unsigned *>(p);
+}
+
 // LDS byte offsets of the table rows of a block's two pairs of symbols
 template <int M, int KA>
 __device__ __forceinline__ void decode_block(const unsigned d, const unsigned shq, const PairDecode &pd, unsigned &off0, unsigned &off1)
@@ -367,7 +374,7 @@ __device__ __forceinline__ void pair_items(unsigned (&acc)[NM][prefilter2_npair(
             // then takes block P + 1 + PFB
             decode_block<M, KA>(blk[(P + 1) % NB], shq, pd, off0, off1);
             if (PHASE != PHASE_LAST || P + 1 + PFB < NB)
-                blk[(P + 1 + PFB) % NB] = *reinterpret_cast<const unsigned *>(spq + (P + 1 + PFB) * 128);
+                blk[(P + 1 + PFB) % NB] = load_block(spq + (P + 1 + PFB) * 128);
         }
         PairRows<NP> nxt;
         unsigned fin0 = 0;
@@ -404,7 +411,7 @@ __device__ __forceinline__ void pair_begin(unsigned (&blk)[prefilter2_ring(M) / 
     constexpr int NP = prefilter2_npair(M);
     constexpr int NB = prefilter2_ring(M) / 4;
     decode_block<M, KA>(blk[0], shq, pd, off0, off1);
-    blk[PFB % NB] = *reinterpret_cast<const unsigned *>(spq + PFB * 128);
+    blk[PFB % NB] = load_block(spq + PFB * 128);
     pair_begin_rows<NP, 0>(cur, off0, off1);
 }
 
