@@ -90,9 +90,18 @@ __global__ __launch_bounds__(kBlock) void hits_rank_emit(
     const unsigned long long *__restrict__ offsets, const unsigned long long *__restrict__ tiles,
     const unsigned long long cols, lm_hip_coords *__restrict__ coords, float *__restrict__ values,
     lm_hip_hit *__restrict__ out_hits, const unsigned long long max_bucket, unsigned *__restrict__ abort_flag,
-    void *__restrict__ pre_out, float *__restrict__ pre_values, const unsigned long long pre)
+    void *__restrict__ pre_out, float *__restrict__ pre_values, const unsigned long long pre,
+    const unsigned long long njobs, unsigned long long *__restrict__ starts, unsigned long long *__restrict__ header)
 {
     const unsigned long long count = live_count(count_ptr, cap);
+    if (starts && blockIdx.x == 0) {  // few jobs: the job offsets and the raw counters ride along (no launch of their own)
+        if (threadIdx.x == 0 && header) {
+            header[0] = count_ptr[0];
+            header[1] = count_ptr[1];
+        }
+        for (unsigned long long j = threadIdx.x; j <= njobs; j += kBlock)
+            starts[j] = bucket_start(j * nb, nbuckets, count, offsets, tiles);
+    }
     for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < count;
          i += (unsigned long long)gridDim.x * kBlock) {
         const HitRecord r = grouped[i];
@@ -207,6 +216,11 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
             ++shift;
         while (shift < 40 && (((max_low - 1) >> shift) + 1) * njobs > (1ull << 26))
             ++shift;
+        // short lists (one motif at p = 1e-5 leaves ~10^4 hits per Gbp): four records per bucket keep the histogram within
+        // the single-launch scan (scan_small: three tiles), and ranking 4 x 4 keys costs nothing -- one launch less of the
+        // launch-bound tail of a fused threshold call (profiles/r05_fused_kernel_stats.csv)
+        if (sized_for <= 12288 && njobs == 1 && shift + 2 < 40)
+            shift += 2;
     }
     const unsigned long long nb = ((max_low - 1) >> shift) + 1;
     const unsigned long long nbuckets = nb * njobs;
@@ -273,6 +287,7 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
     const unsigned grid = (unsigned)std::max<unsigned long long>(
         std::min<unsigned long long>((sized_for + kBlock - 1) / kBlock, (unsigned long long)ctx->num_cus * 32), 1);
     LM_HIP_TRY(hipMemsetAsync(counts, 0, (nbuckets * 4 + 255) / 256 * 256, st));  // whole 256-B units: one fill kernel
+    const bool inline_starts = njobs <= 1024;  // (one workgroup of hits_rank_emit writes them)
     hipLaunchKernelGGL(hits_bucket_count, dim3(grid), dim3(kBlock), 0, st, d_hits, d_counters, cap, shift, nb,
                        counts);
     LM_TRY(launch_scan_u32(ctx, counts, nbuckets, offsets, tiles, total));
@@ -282,15 +297,18 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
         hipLaunchKernelGGL(hits_rank_emit<0>, dim3(grid), dim3(kBlock), 0, st, grouped, d_counters, cap, shift,
                            nb, nbuckets, offsets, tiles, (unsigned long long)cols,
                            static_cast<lm_hip_coords *>(d_out), d_values,
-                           static_cast<lm_hip_hit *>(nullptr), max_bucket, abort_flag, pre_out, pre_values, pre);
+                           static_cast<lm_hip_hit *>(nullptr), max_bucket, abort_flag, pre_out, pre_values, pre,
+                           (unsigned long long)njobs, inline_starts ? starts : nullptr, inline_starts && speculative ? header : nullptr);
     else
         hipLaunchKernelGGL(hits_rank_emit<1>, dim3(grid), dim3(kBlock), 0, st, grouped, d_counters, cap, shift,
                            nb, nbuckets, offsets, tiles, (unsigned long long)cols,
                            static_cast<lm_hip_coords *>(nullptr), static_cast<float *>(nullptr),
-                           static_cast<lm_hip_hit *>(d_out), max_bucket, abort_flag, pre_out, pre_values, pre);
-    hipLaunchKernelGGL(hits_job_starts, dim3((unsigned)((njobs + 1 + 255) / 256)), dim3(256), 0, st,
-                       (unsigned long long)njobs, nb, nbuckets, d_counters, cap, offsets, tiles, starts,
-                       speculative ? header : static_cast<unsigned long long *>(nullptr));
+                           static_cast<lm_hip_hit *>(d_out), max_bucket, abort_flag, pre_out, pre_values, pre,
+                           (unsigned long long)njobs, inline_starts ? starts : nullptr, inline_starts && speculative ? header : nullptr);
+    if (!inline_starts)
+        hipLaunchKernelGGL(hits_job_starts, dim3((unsigned)((njobs + 1 + 255) / 256)), dim3(256), 0, st,
+                           (unsigned long long)njobs, nb, nbuckets, d_counters, cap, offsets, tiles, starts,
+                           speculative ? header : static_cast<unsigned long long *>(nullptr));
     LM_HIP_TRY(hipGetLastError());
 
     if (speculative) {
