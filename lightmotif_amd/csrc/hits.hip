@@ -13,6 +13,13 @@
 //                           keys there; the final slot is bucket start + rank, written
 //                           directly in the caller's output format
 //
+// Long lists (the JASPAR batch leaves 2.6 M hits, a non-i.i.d. genome 4.6 M) take a different road: the histogram and the
+// scatter are one DEVICE-SCOPE atomic per record, which this part executes at the memory side (the XCDs' L2s are not coherent):
+// ~4 G atomics/s, 0.67 + 0.74 ms for 2.6 M records -- a tenth of the batch.  From kSortFrom records on the keys are radix-sorted
+// instead (rocPRIM's device radix sort, LDS-privatised digit histograms: 0.32 ms for 2.6 M (key, value) pairs on 52 bits,
+// tools/kbench/radix_sort_bench.hip): hits_split (records -> key / value arrays, unused slots = an all-ones sentinel that sorts
+// last), the sort, hits_sorted_emit (caller's output format), hits_sorted_starts (lower bound of every job's first key).
+//
 // `shift` is chosen from the hit density so that a bucket holds ~1 record on
 // average; a bucket never holds more records than it has cells (2^shift), which bounds
 // step 4 at 8 x (cells of the batch) comparisons whatever the distribution of hits.
@@ -21,6 +28,8 @@
 #include <cstring>
 
 #include "score_kernels.hpp"
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 namespace lm {
 
@@ -158,6 +167,94 @@ __global__ void hits_job_starts(const unsigned long long njobs, const unsigned l
         starts[j] = bucket_start(j * nb, nbuckets, count, offsets, tiles);
 }
 
+constexpr unsigned long long kSortFrom = 1ull << 17;  // expected records from which the list is radix-sorted
+
+__global__ __launch_bounds__(kBlock) void hits_split(const HitRecord *__restrict__ hits,
+                                                     const unsigned long long *__restrict__ count_ptr,
+                                                     const unsigned long long cap, const unsigned long long n_sort,
+                                                     unsigned long long *__restrict__ keys, float *__restrict__ values,
+                                                     unsigned *__restrict__ abort_flag)
+{
+    const unsigned long long count = live_count(count_ptr, cap);
+    if (count > n_sort) {  // more records than the arrays were sized for (speculative form): the host runs the exact form
+        if (blockIdx.x == 0 && threadIdx.x == 0 && abort_flag)
+            *abort_flag = 1u;
+        return;
+    }
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < n_sort;
+         i += (unsigned long long)gridDim.x * kBlock) {
+        if (i < count) {
+            const HitRecord r = hits[i];
+            keys[i] = r.key;
+            values[i] = r.value;
+        } else {
+            keys[i] = ~0ull;
+        }
+    }
+}
+
+template <int EMIT>
+__global__ __launch_bounds__(kBlock) void hits_sorted_emit(
+    const unsigned long long *__restrict__ keys, const float *__restrict__ vals,
+    const unsigned long long *__restrict__ count_ptr, const unsigned long long cap, const unsigned long long n_sort,
+    const unsigned long long cols, lm_hip_coords *__restrict__ coords, float *__restrict__ values,
+    lm_hip_hit *__restrict__ out_hits, void *__restrict__ pre_out, float *__restrict__ pre_values,
+    const unsigned long long pre, unsigned long long *__restrict__ header)
+{
+    unsigned long long count = live_count(count_ptr, cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && header) {  // raw counters {hits, candidates} for the host
+        header[0] = count_ptr[0];
+        header[1] = count_ptr[1];
+    }
+    if (count > n_sort)
+        return;  // (hits_split raised the abort flag)
+    for (unsigned long long pos = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; pos < count;
+         pos += (unsigned long long)gridDim.x * kBlock) {
+        const unsigned long long low = keys[pos] & kLowMask;
+        const float v = vals[pos];
+        if (EMIT == 0) {
+            lm_hip_coords c;
+            c.row = low / cols;
+            c.col = low - c.row * cols;
+            coords[pos] = c;
+            values[pos] = v;
+            if (pos < pre) {
+                static_cast<lm_hip_coords *>(pre_out)[pos] = c;
+                pre_values[pos] = v;
+            }
+        } else {
+            lm_hip_hit h;
+            h.position = low;
+            h.score = v;
+            out_hits[pos] = h;
+            if (pos < pre)
+                static_cast<lm_hip_hit *>(pre_out)[pos] = h;
+        }
+    }
+}
+
+// starts[j] = number of keys below (j << 40): lower bound in the sorted keys (sentinels sort behind every real key)
+__global__ void hits_sorted_starts(const unsigned long long *__restrict__ keys,
+                                   const unsigned long long *__restrict__ count_ptr, const unsigned long long cap,
+                                   const unsigned long long n_sort, const unsigned long long njobs,
+                                   unsigned long long *__restrict__ starts)
+{
+    const unsigned long long count = std::min(live_count(count_ptr, cap), n_sort);
+    const unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > njobs)
+        return;
+    const unsigned long long want = j << 40;
+    unsigned long long lo = 0, hi = count;
+    while (lo < hi) {
+        const unsigned long long mid = (lo + hi) / 2;
+        if (keys[mid] < want)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    starts[j] = lo;
+}
+
 size_t align16(size_t x) { return (x + 15) / 16 * 16; }
 
 }  // namespace
@@ -227,11 +324,27 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
     const unsigned long long ntiles = (nbuckets + kScanTile - 1) / kScanTile;
 
     const size_t rec_bytes = emit == 0 ? sizeof(lm_hip_coords) : sizeof(lm_hip_hit);
+    // long lists: radix sort (see the head of this file).  Speculative form: the arrays hold the expected count with a
+    // quarter of headroom; a longer list raises the abort flag and the exact form sorts the true count.
+    const bool sorted = ctx->sort_hits && sized_for >= kSortFrom && njobs < (1ull << 22);
+    const unsigned long long n_sort = !sorted ? 0 : speculative ? std::min(room, sized_for + sized_for / 4 + 4096) : count;
+    int end_bit = 41;
+    while ((1ull << (end_bit - 41)) < njobs)
+        ++end_bit;  // keys are below njobs << 40; one spare bit keeps the all-ones sentinel strictly behind them
+    size_t sort_temp = 0;
+    if (sorted) {
+        unsigned long long *kp = nullptr;
+        float *vp = nullptr;
+        LM_HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_temp, kp, kp, vp, vp, (size_t)n_sort, 0u, (unsigned)end_bit, ctx->stream));
+    }
+    const size_t off_keys_in = 0, off_keys_out = off_keys_in + align16(n_sort * 8);
+    const size_t off_vals_in = off_keys_out + align16(n_sort * 8), off_vals_out = off_vals_in + align16(n_sort * 4);
+    const size_t off_sort_temp = off_vals_out + align16(n_sort * 4);
     const size_t off_grouped = 0;
     const size_t off_counts = off_grouped + align16(room * sizeof(HitRecord));
     const size_t off_offsets = off_counts + (nbuckets * 4 + 255) / 256 * 256;
     const size_t off_tiles = off_offsets + align16(nbuckets * 8);
-    const size_t off_total = off_tiles + align16(ntiles * 8);
+    const size_t off_total = sorted ? (off_sort_temp + sort_temp + 255) / 256 * 256 : off_tiles + align16(ntiles * 8);
     // head of the list mirrored into the staging block: the previous call's length with headroom,
     // bounded so that the staging copy stays a small pinned transfer
     const unsigned long long pre =
@@ -286,6 +399,30 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
     hipStream_t st = ctx->stream;
     const unsigned grid = (unsigned)std::max<unsigned long long>(
         std::min<unsigned long long>((sized_for + kBlock - 1) / kBlock, (unsigned long long)ctx->num_cus * 32), 1);
+    if (sorted) {
+        unsigned long long *keys_in = reinterpret_cast<unsigned long long *>(base + off_keys_in);
+        unsigned long long *keys_out = reinterpret_cast<unsigned long long *>(base + off_keys_out);
+        float *vals_in = reinterpret_cast<float *>(base + off_vals_in), *vals_out = reinterpret_cast<float *>(base + off_vals_out);
+        hipLaunchKernelGGL(hits_split, dim3(grid), dim3(kBlock), 0, st, d_hits, d_counters, cap, n_sort, keys_in, vals_in,
+                           speculative ? abort_flag : static_cast<unsigned *>(nullptr));
+        LM_HIP_TRY(hipGetLastError());
+        size_t tb = sort_temp;
+        LM_HIP_TRY(rocprim::radix_sort_pairs(base + off_sort_temp, tb, keys_in, keys_out, vals_in, vals_out, (size_t)n_sort, 0u,
+                                             (unsigned)end_bit, st));
+        if (emit == 0)
+            hipLaunchKernelGGL(hits_sorted_emit<0>, dim3(grid), dim3(kBlock), 0, st, keys_out, vals_out, d_counters, cap, n_sort,
+                               (unsigned long long)cols, static_cast<lm_hip_coords *>(d_out), d_values,
+                               static_cast<lm_hip_hit *>(nullptr), pre_out, pre_values, pre,
+                               speculative ? header : static_cast<unsigned long long *>(nullptr));
+        else
+            hipLaunchKernelGGL(hits_sorted_emit<1>, dim3(grid), dim3(kBlock), 0, st, keys_out, vals_out, d_counters, cap, n_sort,
+                               (unsigned long long)cols, static_cast<lm_hip_coords *>(nullptr), static_cast<float *>(nullptr),
+                               static_cast<lm_hip_hit *>(d_out), pre_out, pre_values, pre,
+                               speculative ? header : static_cast<unsigned long long *>(nullptr));
+        hipLaunchKernelGGL(hits_sorted_starts, dim3((unsigned)((njobs + 1 + 255) / 256)), dim3(256), 0, st, keys_out, d_counters, cap,
+                           n_sort, (unsigned long long)njobs, starts);
+        LM_HIP_TRY(hipGetLastError());
+    } else {
     LM_HIP_TRY(hipMemsetAsync(counts, 0, (nbuckets * 4 + 255) / 256 * 256, st));  // whole 256-B units: one fill kernel
     const bool inline_starts = njobs <= 1024;  // (one workgroup of hits_rank_emit writes them)
     hipLaunchKernelGGL(hits_bucket_count, dim3(grid), dim3(kBlock), 0, st, d_hits, d_counters, cap, shift, nb,
@@ -310,6 +447,7 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
                            (unsigned long long)njobs, nb, nbuckets, d_counters, cap, offsets, tiles, starts,
                            speculative ? header : static_cast<unsigned long long *>(nullptr));
     LM_HIP_TRY(hipGetLastError());
+    }
 
     if (speculative) {
         LM_HIP_TRY(hipStreamSynchronize(st));

@@ -110,6 +110,7 @@ struct lm_hip_ctx {
     bool xlong_store = true;     // motifs of 65 ... kMaxStoreM rows are stored in one pass (option "xlong_store" = 0: slices of <= 64)
     bool host_fold = true;       // ... small matrices: per-wavefront records folded by the host (option "host_fold" = 0: on the device)
     bool speculate_order = true; // fused threshold: order the hit list before the host knows its length
+    bool sort_hits = true;       // ... long lists by radix sort instead of the bucket passes (hits.hip; option "sort_hits")
     bool suffix_argmax = true;   // fused argmax of short motifs: try the last rows first (score_argmax.hip)
     bool multi_motif = true;     // many-motif threshold batches: several motifs of one length per pass
     bool skip_unreachable = true; // fused threshold: no scan when the threshold exceeds the best k-mer's score

@@ -44,7 +44,11 @@ struct Aligned {
         if (posix_memalign(reinterpret_cast<void **>(&p), 32, std::max<size_t>(count * sizeof(T), 32)) != 0)
             throw std::bad_alloc();
     }
-    Aligned(const T *src, size_t count) : Aligned(count) { std::memcpy(p, src, count * sizeof(T)); }
+    Aligned(const T *src, size_t count) : Aligned(count)
+    {
+        if (count)
+            std::memcpy(p, src, count * sizeof(T));
+    }
     ~Aligned() { free(p); }
     Aligned(const Aligned &) = delete;
 };
@@ -190,6 +194,27 @@ struct PortTier {
                     out.push_back(MatrixCoordinates{r, c});
         return out;
     }
+    // One Scanner block on copies aligned ONCE per scan (the port wants 32-byte aligned rows; a Rust `StripedSequence` is
+    // aligned already -- copying the sequence per block made the loop quadratic and the crossover measurement meaningless)
+    template <class A>
+    void score_u8_block(const DiscreteMatrix<A> &dm, const host::StripedSequence<A> &seq, const Aligned<uint8_t> *s,
+                        const Aligned<uint8_t> *p, Aligned<uint8_t> *o, size_t rb, size_t re, host::StripedScores<uint8_t> &scores) const
+    {
+        if (!s || seq.columns() != 32) {
+            score_rows_into(dm, seq, rb, re, scores);
+            return;
+        }
+        ++n.score_u8;
+        const DenseMatrix<uint8_t> &w = dm.matrix();
+        const DenseMatrix<uint8_t> &m = seq.matrix();
+        if (seq.len() < w.rows() || rb >= re) {
+            scores.resize(0, 0);
+            return;
+        }
+        scores.resize(re - rb, seq.len() + 1 - w.rows());
+        lma_score_rows_u8(s->p, m.stride(), seq.wrap(), seq.len(), p->p, w.rows(), w.stride(), rb, re, o->p, scores.data.stride());
+        std::memcpy(scores.data.ptr(), o->p, (re - rb) * scores.data.stride());   // (the port streams to 32-byte aligned rows)
+    }
     // Scanner::next until exhaustion, in yield order (scan.rs:169-198)
     template <class A>
     std::vector<Hit> scan(const ScoringMatrix<A> &pssm, const host::StripedSequence<A> &seq, float threshold, size_t block_size) const
@@ -204,9 +229,13 @@ struct PortTier {
         const DenseMatrix<float> &w = pssm.matrix();
         const size_t total = m.rows(), seq_rows = total - seq.wrap();
         host::StripedScores<uint8_t> ds(seq.columns());
+        const bool port = seq.columns() == 32 && seq.len() >= pssm.len();
+        const Aligned<uint8_t> sa(port ? m.ptr() : nullptr, port ? m.rows() * m.stride() : 0);
+        const Aligned<uint8_t> pa(port ? dm.matrix().ptr() : nullptr, port ? dm.matrix().rows() * dm.matrix().stride() : 0);
+        Aligned<uint8_t> oa(port ? block_size * ds.data.stride() + 64 : 0);
         for (size_t row = 0; row < total; row += block_size) {
             const size_t end = std::min(row + block_size, seq_rows);
-            score_rows_into(dm, seq, row, end, ds);
+            score_u8_block(dm, seq, port ? &sa : nullptr, port ? &pa : nullptr, &oa, row, end, ds);
             std::vector<Hit> hits;
             if (max(ds).value_or(0) >= t)
                 for (const auto &c : threshold_u8(ds, t)) {
@@ -236,9 +265,13 @@ struct PortTier {
         const DenseMatrix<float> &w = pssm.matrix();
         const size_t total = m.rows(), seq_rows = total - seq.wrap();
         host::StripedScores<uint8_t> ds(seq.columns());
+        const bool port = seq.columns() == 32 && seq.len() >= pssm.len();
+        const Aligned<uint8_t> sa(port ? m.ptr() : nullptr, port ? m.rows() * m.stride() : 0);
+        const Aligned<uint8_t> pa(port ? dm.matrix().ptr() : nullptr, port ? dm.matrix().rows() * dm.matrix().stride() : 0);
+        Aligned<uint8_t> oa(port ? block_size * ds.data.stride() + 64 : 0);
         for (size_t row = 0; row < total; row += block_size) {
             const size_t end = std::min(row + block_size, seq_rows);
-            score_rows_into(dm, seq, row, end, ds);
+            score_u8_block(dm, seq, port ? &sa : nullptr, port ? &pa : nullptr, &oa, row, end, ds);
             if (max(ds).value_or(0) >= best_discrete)
                 for (const auto &c : threshold_u8(ds, best_discrete)) {
                     const uint8_t dscore = ds.matrix()(c.row, c.col);
