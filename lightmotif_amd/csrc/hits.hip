@@ -13,12 +13,15 @@
 //                           keys there; the final slot is bucket start + rank, written
 //                           directly in the caller's output format
 //
-// Long lists (the JASPAR batch leaves 2.6 M hits, a non-i.i.d. genome 4.6 M) take a different road: the histogram and the
-// scatter are one DEVICE-SCOPE atomic per record, which this part executes at the memory side (the XCDs' L2s are not coherent):
-// ~4 G atomics/s, 0.67 + 0.74 ms for 2.6 M records -- a tenth of the batch.  From kSortFrom records on the keys are radix-sorted
-// instead (rocPRIM's device radix sort, LDS-privatised digit histograms: 0.32 ms for 2.6 M (key, value) pairs on 52 bits,
-// tools/kbench/radix_sort_bench.hip): hits_split (records -> key / value arrays, unused slots = an all-ones sentinel that sorts
-// last), the sort, hits_sorted_emit (caller's output format), hits_sorted_starts (lower bound of every job's first key).
+// Long lists (the JASPAR batch leaves 2.6 M hits, a non-i.i.d. genome 4.6 M) take a different road.  The histogram and the
+// scatter are one device-scope atomic per record on buckets whose geometry assumes an even hit density: fine on uniform input
+// (0.15 + 0.19 + 0.07 ms for 2.6 M records), but where hits cluster -- low-complexity tracts, short motifs -- or the expected
+// count is off (a context's first call: 2.2 + 2.4 + 0.9 ms) the atomics pile up on few addresses.  From kSortFrom records on
+// the keys are radix-sorted instead (rocPRIM's device radix sort, LDS-privatised digit histograms: 0.32 ms for 2.6 M (key, value)
+// pairs on 52 bits, tools/kbench/radix_sort_bench.hip; insensitive to the distribution): hits_split (records -> key / value
+// arrays, unused slots = an all-ones sentinel that sorts last), the sort, hits_sorted_emit (caller's output format),
+// hits_sorted_starts (lower bound of every job's first key).  JASPAR batch: 17.6 vs 17.7 ms uniform, 21.5 vs 23.2 ms on the
+// non-i.i.d. sequence (tools/sort_ab.py).
 //
 // `shift` is chosen from the hit density so that a bucket holds ~1 record on
 // average; a bucket never holds more records than it has cells (2^shift), which bounds

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, seventh GPU call: suite with the realistic-input / 8-rank tests, bench line with the per-XCD clock marks, realistic inputs
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$ROOT/gpurun_out/r05g
+OUT=$ROOT/gpurun_out/r05m
 mkdir -p "$OUT"
 cd "$ROOT"
 make -C tests/cpp > "$OUT/make.log" 2>&1
