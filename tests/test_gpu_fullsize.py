@@ -20,11 +20,17 @@ def make_workload(pli, length, m, k, seed):
     rows = -(-length // COLS)
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
-    seq = torch.empty((rows + m - 1, COLS), dtype=torch.uint8, device=dev)
-    seq[:rows] = torch.randint(0, k - 1, (rows, COLS), dtype=torch.uint8, device=dev, generator=gen)
-    if length < rows * COLS:  # padded tail = default symbol (pli/mod.rs:194-196)
-        idx = torch.arange(length, rows * COLS, device=dev)
-        seq[idx % rows, idx // rows] = k - 1
+    if k == 5:
+        # DNA: the SplitMix64 stream SURVEY 8(d) prescribes (2 bits per base, position i at [i % R][i / R], N past the end) --
+        # the generator of bench.py, seeded per case
+        import bench
+        seq = bench.synth_shard(rows, 0, rows, length, m - 1, dev, seed=0x5EED0001 + seed)
+    else:
+        seq = torch.empty((rows + m - 1, COLS), dtype=torch.uint8, device=dev)
+        seq[:rows] = torch.randint(0, k - 1, (rows, COLS), dtype=torch.uint8, device=dev, generator=gen)
+        if length < rows * COLS:  # padded tail = default symbol (pli/mod.rs:194-196)
+            idx = torch.arange(length, rows * COLS, device=dev)
+            seq[idx % rows, idx // rows] = k - 1
     pli.configure_wrap_dptr(seq.data_ptr(), rows, COLS, COLS, m - 1, k - 1)
     rng = np.random.default_rng(seed)
     sym = lm.lib.PROTEIN_SYMBOLS if k == 21 else lm.lib.DNA_SYMBOLS

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, seventh GPU call: suite with the realistic-input / 8-rank tests, bench line with the per-XCD clock marks, realistic inputs
+# round 5 GPU call: suite with the realistic-input / 8-rank tests, bench line with the per-XCD clock marks, realistic inputs
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/r05m
 mkdir -p "$OUT"
