@@ -158,7 +158,11 @@ def lib() -> C.CDLL:
                 f"{path} is missing: build it with `python -m lightmotif_amd.build` "
                 "(there is no CPU fallback)")
         L = C.CDLL(str(path))
+        # (an OLDER build under LM_HIP_LIBRARY, for bisecting: entry points it lacks are skipped when LM_HIP_LIBRARY_OLDER is set)
+        lenient = "LM_HIP_LIBRARY" in os.environ and os.environ.get("LM_HIP_LIBRARY_OLDER")
         for name, (res, args) in SIGNATURES.items():
+            if lenient and not hasattr(L, name):
+                continue
             fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args

@@ -170,6 +170,8 @@ C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const ScoreArgs &a
         return p;
     if (prefilter == 0 && ms.m > (size_t)kMaxFastM && (ms.m % 4 != 0 || reinterpret_cast<uintptr_t>(a.d_seq) % 4 != 0))
         return p;  // the long family: padded lengths, dword symbol loads
+    if (prefilter == 1 && !store && ms.m <= 2)
+        return p;  // scans: a ring of two symbol registers has no spare slot (prefilter_lookahead): the exact kernel, which costs nothing here
     // (the pair-symbol kernel fetches symbols with dword loads: 4-byte aligned matrix)
     if (prefilter == 2 && ((K != 5 && !(K == 21 && ctx->pair_prefilter_protein)) || !ms.pair_table || ms.m < 2 ||
                            reinterpret_cast<uintptr_t>(a.d_seq) % 4 != 0))

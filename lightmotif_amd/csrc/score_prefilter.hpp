@@ -42,6 +42,14 @@ namespace lm {
 // matrix's score range: the over-estimate is at most 2 M quanta of range / 32000.
 constexpr unsigned kPrefilterTop = 32000u;
 constexpr int prefilter_mp(int m) { return (m + 1) / 2 * 2; }
+// Symbol look-ahead of the one-symbol scans, in steps: the ring of MP symbol registers must keep ONE slot between the
+// step being consumed and the slot being refilled.  With a look-ahead of MP - 1 the refill of step k lands in the register of
+// step k - 1 -- which, compiled, still holds the LDS address of that step's reads -- and the protein kernels of M = 7, 8
+// (MP = 8: the only wide-alphabet length whose look-ahead was MP - 1 AND whose schedule put the load right behind the reads)
+// lost a varying quarter of their candidates on hardware (round 5: 5 573 ... 5 907 of 7 455 hits from run to run, same in the
+// round-4 binary; the ISA's wait counts are right, MP - 2 is exact: tools/protein_pair_ab.py found it, tests/test_gpu_protein_prefilter.py
+// holds it).  The symptom is timing-dependent, so every ring of this shape keeps the spare slot.
+constexpr int prefilter_lookahead(int pf, int mp) { return mp <= 2 ? 1 : (pf < mp - 1 ? pf : mp - 2); }
 // dwords per symbol row of one discrete layout: 4 * odd >= MP / 2 (conflict-free b128)
 // (wide alphabets, lds_wide(k): 2 * odd, read with single ds_read_b64 -- see table_stride in score_kernels.hpp)
 constexpr int prefilter_stride_dw(int m, int wide = 0)
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter(
     // padded output o' = o - SHIFT covers input rows o' .. o'+MP-1; its first row carries
     // the all-zero weight row, so when o0 == 0 that (non-existent) row is never loaded
     const uint8_t *sp = seq + (long long)(o0 - SHIFT) * 32 + col;
-    constexpr int PFE = PF < MP ? PF : MP - 1;
+    constexpr int PFE = prefilter_lookahead(PF, MP);
     unsigned acc2[NP];
     unsigned sym[MP];
 #pragma unroll

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_u8(
         o0 = row_end - T;
 
     const uint8_t *sp = seq + (long long)(o0 - SHIFT) * 32 + col;
-    constexpr int PFE = PF < MP ? PF : MP - 1;
+    constexpr int PFE = prefilter_lookahead(PF, MP);
     unsigned acc2[NP];
     unsigned sym[MP];
 #pragma unroll
