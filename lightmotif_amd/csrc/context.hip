@@ -347,7 +347,7 @@ int lm_hip_device_clock_mhz(int device, unsigned window_us, double *mhz)
 static const char *const kOptionNames[] = {"track_argmax", "xlong_store", "host_fold", "speculate_order", "suffix_argmax",
                                            "multi_motif", "quad_loads", "skip_unreachable", "pair_prefilter",
                                            "pair_prefilter_protein", "chunked_fused", "chunk_rows", "tiled",
-                                           "suffix_occurrences", "prefilter", "sort_hits"};
+                                           "suffix_occurrences", "prefilter", "sort_hits", "short_order"};
 
 static int set_option(lm_hip_ctx *ctx, const char *name, double value)
 {
@@ -358,6 +358,7 @@ static int set_option(lm_hip_ctx *ctx, const char *name, double value)
     else if (n == "host_fold") ctx->host_fold = on;                  // 0 = small score_into folds its records on the device
     else if (n == "speculate_order") ctx->speculate_order = on;      // 0 = fused threshold reads the counts first
     else if (n == "sort_hits") ctx->sort_hits = on;                  // 0 = long hit lists through the bucket passes too
+    else if (n == "short_order") ctx->short_order = on;              // 0 = short hit lists of one job through the five-launch form too
     else if (n == "suffix_argmax") ctx->suffix_argmax = on;          // 0 = fused argmax always scans the whole range
     else if (n == "multi_motif") ctx->multi_motif = on;              // 0 = one motif per workgroup pass in batches
     else if (n == "quad_loads") ctx->quad_loads = on;                // 0 = byte symbol loads in the store kernel
@@ -463,6 +464,8 @@ int lm_hip_ctx_destroy(lm_hip_ctx *ctx)
         (void)hipHostFree(ctx->pinned);
     if (ctx->d_ticket)
         (void)hipFree(ctx->d_ticket);
+    if (ctx->d_short)
+        (void)hipFree(ctx->d_short);
     if (ctx->copy_stream) {
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamDestroy(ctx->copy_stream);

@@ -13,6 +13,9 @@
 //                           keys there; the final slot is bucket start + rank, written
 //                           directly in the caller's output format
 //
+// Short lists of ONE job skip steps 1 and 2 as launches: the re-scoring kernel counts while it stores, every workgroup
+// of the scatter scans the histogram itself (ShortOrder, below).
+//
 // Long lists (the JASPAR batch leaves 2.6 M hits, a non-i.i.d. genome 4.6 M) take a different road.  The histogram and the
 // scatter are one device-scope atomic per record on buckets whose geometry assumes an even hit density: fine on uniform input
 // (0.15 + 0.19 + 0.07 ms for 2.6 M records), but where hits cluster -- low-complexity tracts, short motifs -- or the expected
@@ -103,9 +106,16 @@ __global__ __launch_bounds__(kBlock) void hits_rank_emit(
     const unsigned long long cols, lm_hip_coords *__restrict__ coords, float *__restrict__ values,
     lm_hip_hit *__restrict__ out_hits, const unsigned long long max_bucket, unsigned *__restrict__ abort_flag,
     void *__restrict__ pre_out, float *__restrict__ pre_values, const unsigned long long pre,
-    const unsigned long long njobs, unsigned long long *__restrict__ starts, unsigned long long *__restrict__ header)
+    const unsigned long long njobs, unsigned long long *__restrict__ starts, unsigned long long *__restrict__ header,
+    unsigned *__restrict__ clean_counts, unsigned *__restrict__ clean_cursors)
 {
     const unsigned long long count = live_count(count_ptr, cap);
+    if (clean_counts)  // ShortOrder: nothing reads the histogram or the cursors any more; the next call finds them zero
+        for (unsigned long long b = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; b < nbuckets;
+             b += (unsigned long long)gridDim.x * kBlock) {
+            clean_counts[b] = 0u;
+            clean_cursors[b] = 0u;
+        }
     if (starts && blockIdx.x == 0) {  // few jobs: the job offsets and the raw counters ride along (no launch of their own)
         if (threadIdx.x == 0 && header) {
             header[0] = count_ptr[0];
@@ -168,6 +178,94 @@ __global__ void hits_job_starts(const unsigned long long njobs, const unsigned l
     }
     if (j <= njobs)
         starts[j] = bucket_start(j * nb, nbuckets, count, offsets, tiles);
+}
+
+// ---- short lists of one job (ShortOrder) ---------------------------------------------------------------------
+//
+// Each launch of the tail costs ~5 us whatever it does, and a 1 Gbp scan at p = 1e-5 spent 28 of its 280 us in the five
+// above (fill, count, scan, scatter, rank: profiles/r05_timeline_fused.txt); a 5 Mbp scan spends more there than in
+// its scan.  For ONE job with a short list expected:
+//   * the re-scoring kernel bumps the bucket count of every record it stores (rescore_candidates);
+//   * hits_short_scatter: every workgroup scans the whole histogram in LDS (<= kShortBuckets counts), workgroup 0
+//     publishes the offsets, records go to offset + cursor++;
+//   * hits_rank_emit as above, which also clears counts and cursors: the buffers are zero between calls (ctx->d_short,
+//     ctx->short_dirty covers calls that failed in between).
+constexpr unsigned long long kShortRecords = 40960;  // expected records (the previous call's count + 25 %) up to which a list is "short"
+constexpr int kShortBuckets = 10496;                 // >= kShortRecords / 4 + 1 (bucket_geometry), a multiple of kBlock; 41 KB of LDS
+constexpr size_t kShortTiles = kShortBuckets / kScanTile + 1;
+// ctx->d_short: counts | cursors | tiles (zero for ever: one "tile" per kScanTile buckets, see bucket_start) | offsets
+constexpr size_t kShortOffCursors = kShortBuckets * 4, kShortOffTiles = 2 * kShortOffCursors,
+                 kShortOffOffsets = kShortOffTiles + 128, kShortBytes = kShortOffOffsets + (kShortBuckets + 1) * 8;
+static_assert(kShortTiles * 8 <= 128 && kShortBuckets % kBlock == 0 && kShortRecords / 4 + 1 <= kShortBuckets, "layout of the short form");
+
+__global__ __launch_bounds__(kBlock) void hits_short_scatter(
+    const HitRecord *__restrict__ hits, const unsigned long long *__restrict__ count_ptr, const unsigned long long cap,
+    const int shift, const unsigned nb, const unsigned *__restrict__ counts, unsigned *__restrict__ cursors,
+    unsigned long long *__restrict__ offsets, HitRecord *__restrict__ grouped)
+{
+    constexpr int PER = kShortBuckets / kBlock;  // buckets per thread, contiguous
+    __shared__ unsigned pre[kShortBuckets];
+    __shared__ unsigned wave_sum[kBlock / 64];
+    unsigned v[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const unsigned b = threadIdx.x * PER + k;
+        v[k] = b < nb ? counts[b] : 0u;
+        sum += v[k];
+    }
+    unsigned inc = sum;  // inclusive scan over the wavefront
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(inc, off);
+        if (lane >= off)
+            inc += o;
+    }
+    if (lane == 63)
+        wave_sum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    unsigned run = inc - sum;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w)
+        run += wave_sum[w];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        pre[threadIdx.x * PER + k] = run;
+        run += v[k];
+    }
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (unsigned b = threadIdx.x; b < nb; b += kBlock)
+            offsets[b] = pre[b];
+    const unsigned long long count = live_count(count_ptr, cap);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < count;
+         i += (unsigned long long)gridDim.x * kBlock) {
+        const HitRecord r = hits[i];
+        const unsigned b = (unsigned)((r.key & kLowMask) >> shift);
+        grouped[pre[b] + atomicAdd(&cursors[b], 1u)] = r;
+    }
+}
+
+// bucket geometry of order_hits for `sized_for` expected records (one place: the re-scoring kernel counts with it)
+void bucket_geometry(unsigned long long sized_for, size_t njobs, unsigned long long max_low, int *shift_out,
+                     unsigned long long *nb_out)
+{
+    // ~1 record per bucket on average; at most 2^26 buckets.  (Ranking is quadratic in the bucket
+    // size and the density is far from uniform across jobs: in the JASPAR batch a length-4 motif
+    // has 150 x the average hit density; at 8 records per average bucket its buckets held 2 800
+    // records and hits_rank_emit took 7 ms of the batch's 47.)
+    int shift = 5;
+    const long double universe = (long double)max_low * (long double)njobs;
+    while (shift < 40 && ((long double)(1ull << shift) * (long double)sized_for < 1.0L * universe))
+        ++shift;
+    while (shift < 40 && (((max_low - 1) >> shift) + 1) * njobs > (1ull << 26))
+        ++shift;
+    // short lists (one motif at p = 1e-5 leaves ~10^4 hits per Gbp): four records per bucket keep the histogram small
+    // (<= kShortBuckets: the short form above; three tiles of the single-launch scan otherwise), and ranking 4 x 4 keys
+    // costs nothing
+    if (sized_for <= kShortRecords && njobs == 1 && shift + 2 < 40)
+        shift += 2;
+    *shift_out = shift;
+    *nb_out = ((max_low - 1) >> shift) + 1;
 }
 
 constexpr unsigned long long kSortFrom = 1ull << 17;  // expected records from which the list is radix-sorted
@@ -262,6 +360,28 @@ size_t align16(size_t x) { return (x + 15) / 16 * 16; }
 
 }  // namespace
 
+int short_order_begin(lm_hip_ctx *ctx, unsigned long long expected, size_t njobs, unsigned long long max_low, ShortOrder *so)
+{
+    so->on = false;
+    const unsigned long long sized_for = std::max<unsigned long long>(expected, 4096);
+    if (njobs != 1 || sized_for > kShortRecords || max_low == 0 || max_low > kLowMask + 1)
+        return LM_HIP_OK;
+    bucket_geometry(sized_for, njobs, max_low, &so->shift, &so->nb);
+    if (so->nb > (unsigned long long)kShortBuckets)
+        return LM_HIP_OK;
+    if (!ctx->d_short) {
+        LM_HIP_TRY(hipMalloc(&ctx->d_short, kShortBytes));
+        ctx->short_dirty = false;
+        LM_HIP_TRY(hipMemsetAsync(ctx->d_short, 0, kShortBytes, ctx->stream));
+    } else if (ctx->short_dirty) {
+        LM_HIP_TRY(hipMemsetAsync(ctx->d_short, 0, kShortOffTiles, ctx->stream));
+    }
+    ctx->short_dirty = true;  // until order_hits has seen the clean-up through
+    so->counts = ctx->d_short;
+    so->on = true;
+    return LM_HIP_OK;
+}
+
 void HitOutput::release()
 {
     result_free(coords);
@@ -290,7 +410,7 @@ constexpr unsigned long long kPrefix = 12800;  // x 20 B = 256 KB
 int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long long *d_counters,
                unsigned long long count, unsigned long long cap, unsigned long long cand_cap,
                unsigned long long expected, size_t njobs, unsigned long long max_low, int emit, size_t cols,
-               HitOutput *out, int *status, unsigned long long counts_out[2])
+               HitOutput *out, int *status, unsigned long long counts_out[2], const ShortOrder *so)
 {
     const bool speculative = count == ~0ull;
     *status = 0;
@@ -305,24 +425,12 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
                     max_low);
     const unsigned long long sized_for = speculative ? std::max<unsigned long long>(expected, 4096) : count;
     const unsigned long long room = speculative ? cap : count;  // records the arrays must hold
-    // ~1 record per bucket on average; at most 2^26 buckets.  (Ranking is quadratic in the bucket
-    // size and the density is far from uniform across jobs: in the JASPAR batch a length-4 motif
-    // has 150 x the average hit density; at 8 records per average bucket its buckets held 2 800
-    // records and hits_rank_emit took 7 ms of the batch's 47.)
-    int shift = 5;
-    {
-        const long double universe = (long double)max_low * (long double)njobs;
-        while (shift < 40 && ((long double)(1ull << shift) * (long double)sized_for < 1.0L * universe))
-            ++shift;
-        while (shift < 40 && (((max_low - 1) >> shift) + 1) * njobs > (1ull << 26))
-            ++shift;
-        // short lists (one motif at p = 1e-5 leaves ~10^4 hits per Gbp): four records per bucket keep the histogram within
-        // the single-launch scan (scan_small: three tiles), and ranking 4 x 4 keys costs nothing -- one launch less of the
-        // launch-bound tail of a fused threshold call (profiles/r05_fused_kernel_stats.csv)
-        if (sized_for <= 12288 && njobs == 1 && shift + 2 < 40)
-            shift += 2;
-    }
-    const unsigned long long nb = ((max_low - 1) >> shift) + 1;
+    int shift = 0;
+    unsigned long long nb = 0;
+    bucket_geometry(sized_for, njobs, max_low, &shift, &nb);
+    const bool short_form = so && so->on;
+    if (short_form && (!speculative || so->shift != shift || so->nb != nb || njobs != 1))
+        return fail(LM_HIP_ERR_BAD_ARGS, "fused threshold: the short ordering was begun with another geometry");
     const unsigned long long nbuckets = nb * njobs;
     const unsigned long long ntiles = (nbuckets + kScanTile - 1) / kScanTile;
 
@@ -384,6 +492,12 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
     unsigned long long *offsets = reinterpret_cast<unsigned long long *>(base + off_offsets);
     unsigned long long *tiles = reinterpret_cast<unsigned long long *>(base + off_tiles);
     unsigned long long *total = reinterpret_cast<unsigned long long *>(base + off_total);
+    if (short_form) {  // histogram, cursors, offsets and the (zero) tiles of the short form live in the context
+        char *sb = reinterpret_cast<char *>(ctx->d_short);
+        counts = reinterpret_cast<unsigned *>(sb);
+        tiles = reinterpret_cast<unsigned long long *>(sb + kShortOffTiles);
+        offsets = reinterpret_cast<unsigned long long *>(sb + kShortOffOffsets);
+    }
     unsigned long long *header = reinterpret_cast<unsigned long long *>(pin);
     unsigned *abort_flag = reinterpret_cast<unsigned *>(pin + p_abort);
     void *pre_out = pin + p_out;
@@ -426,25 +540,33 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
                            n_sort, (unsigned long long)njobs, starts);
         LM_HIP_TRY(hipGetLastError());
     } else {
-    LM_HIP_TRY(hipMemsetAsync(counts, 0, (nbuckets * 4 + 255) / 256 * 256, st));  // whole 256-B units: one fill kernel
     const bool inline_starts = njobs <= 1024;  // (one workgroup of hits_rank_emit writes them)
-    hipLaunchKernelGGL(hits_bucket_count, dim3(grid), dim3(kBlock), 0, st, d_hits, d_counters, cap, shift, nb,
-                       counts);
-    LM_TRY(launch_scan_u32(ctx, counts, nbuckets, offsets, tiles, total));
-    hipLaunchKernelGGL(hits_bucket_scatter, dim3(grid), dim3(kBlock), 0, st, d_hits, d_counters, cap, shift, nb,
-                       offsets, tiles, counts, grouped);
+    unsigned *cursors = short_form ? counts + kShortBuckets : nullptr;
+    if (short_form) {  // the re-scoring kernel has counted
+        hipLaunchKernelGGL(hits_short_scatter, dim3(grid), dim3(kBlock), 0, st, d_hits, d_counters, cap, shift, (unsigned)nb,
+                           counts, cursors, offsets, grouped);
+    } else {
+        LM_HIP_TRY(hipMemsetAsync(counts, 0, (nbuckets * 4 + 255) / 256 * 256, st));  // whole 256-B units: one fill kernel
+        hipLaunchKernelGGL(hits_bucket_count, dim3(grid), dim3(kBlock), 0, st, d_hits, d_counters, cap, shift, nb,
+                           counts);
+        LM_TRY(launch_scan_u32(ctx, counts, nbuckets, offsets, tiles, total));
+        hipLaunchKernelGGL(hits_bucket_scatter, dim3(grid), dim3(kBlock), 0, st, d_hits, d_counters, cap, shift, nb,
+                           offsets, tiles, counts, grouped);
+    }
     if (emit == 0)
         hipLaunchKernelGGL(hits_rank_emit<0>, dim3(grid), dim3(kBlock), 0, st, grouped, d_counters, cap, shift,
                            nb, nbuckets, offsets, tiles, (unsigned long long)cols,
                            static_cast<lm_hip_coords *>(d_out), d_values,
                            static_cast<lm_hip_hit *>(nullptr), max_bucket, abort_flag, pre_out, pre_values, pre,
-                           (unsigned long long)njobs, inline_starts ? starts : nullptr, inline_starts && speculative ? header : nullptr);
+                           (unsigned long long)njobs, inline_starts ? starts : nullptr, inline_starts && speculative ? header : nullptr,
+                           short_form ? counts : nullptr, cursors);
     else
         hipLaunchKernelGGL(hits_rank_emit<1>, dim3(grid), dim3(kBlock), 0, st, grouped, d_counters, cap, shift,
                            nb, nbuckets, offsets, tiles, (unsigned long long)cols,
                            static_cast<lm_hip_coords *>(nullptr), static_cast<float *>(nullptr),
                            static_cast<lm_hip_hit *>(d_out), max_bucket, abort_flag, pre_out, pre_values, pre,
-                           (unsigned long long)njobs, inline_starts ? starts : nullptr, inline_starts && speculative ? header : nullptr);
+                           (unsigned long long)njobs, inline_starts ? starts : nullptr, inline_starts && speculative ? header : nullptr,
+                           short_form ? counts : nullptr, cursors);
     if (!inline_starts)
         hipLaunchKernelGGL(hits_job_starts, dim3((unsigned)((njobs + 1 + 255) / 256)), dim3(256), 0, st,
                            (unsigned long long)njobs, nb, nbuckets, d_counters, cap, offsets, tiles, starts,
@@ -454,6 +576,8 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
 
     if (speculative) {
         LM_HIP_TRY(hipStreamSynchronize(st));
+        if (short_form)
+            ctx->short_dirty = false;  // both kernels ran: counts and cursors are zero again
         counts_out[0] = reinterpret_cast<unsigned long long *>(pin)[0];
         counts_out[1] = reinterpret_cast<unsigned long long *>(pin)[1];
         if (counts_out[0] > cap || counts_out[1] > cand_cap) {

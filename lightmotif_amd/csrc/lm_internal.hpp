@@ -101,6 +101,8 @@ struct lm_hip_ctx {
     void *pinned = nullptr;     // kPinnedBytes of host-pinned memory for read-backs
     unsigned fold_generation = 0; // of the last single-job fused argmax whose kernel wrote its result into `pinned`
     unsigned *d_ticket = nullptr; // "last workgroup folds the records" counter of the single-launch argmax forms (zero between launches)
+    unsigned *d_short = nullptr;  // short hit lists (hits.hip, ShortOrder): bucket counts | cursors | zero tiles | offsets; counts and cursors are zero between calls
+    bool short_dirty = false;     // ... unless a call failed between the count and the clean-up: the next one clears them first
     size_t rows_per_stream = 0; // 0 = default
     bool use_prefilter = true;  // fused threshold: packed 16-bit discrete prefilter (A/B knob)
     bool pair_prefilter = true;  // DNA prefilter scans look up two symbols at a time
@@ -111,6 +113,7 @@ struct lm_hip_ctx {
     bool host_fold = true;       // ... small matrices: per-wavefront records folded by the host (option "host_fold" = 0: on the device)
     bool speculate_order = true; // fused threshold: order the hit list before the host knows its length
     bool sort_hits = true;       // ... long lists by radix sort instead of the bucket passes (hits.hip; option "sort_hits")
+    bool short_order = true;     // ... short lists of one job counted by the re-scoring kernel, two launches behind it (hits.hip; option "short_order")
     bool suffix_argmax = true;   // fused argmax of short motifs: try the last rows first (score_argmax.hip)
     bool multi_motif = true;     // many-motif threshold batches: several motifs of one length per pass
     bool skip_unreachable = true; // fused threshold: no scan when the threshold exceeds the best k-mer's score
@@ -319,11 +322,21 @@ int launch_score_argmax_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
 
 // hits.hip: device-side ordering of the fused kernels' hit list
 struct HitRecord;
+// Short lists of ONE job (a scan at p = 1e-5 leaves ~10^4 hits per Gbp): the re-scoring kernel counts the records per
+// bucket as it stores them, so the ordering behind it is two launches instead of five (hits.hip).  `on` = the geometry
+// below was handed to launch_rescore and order_hits must be called with the same object.
+struct ShortOrder {
+    bool on = false;
+    int shift = 0;
+    unsigned long long nb = 0;
+    unsigned *counts = nullptr;
+};
+int short_order_begin(lm_hip_ctx *ctx, unsigned long long expected, size_t njobs, unsigned long long max_low, ShortOrder *so);
 // count == ~0: speculative (the host has not read the counters yet); see hits.hip
 int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long long *d_counters,
                unsigned long long count, unsigned long long cap, unsigned long long cand_cap,
                unsigned long long expected, size_t njobs, unsigned long long max_low, int emit, size_t cols,
-               HitOutput *out, int *status, unsigned long long counts_out[2]);
+               HitOutput *out, int *status, unsigned long long counts_out[2], const ShortOrder *so = nullptr);
 
 // reduce.hip: exclusive scan of n u32 counts (async on ctx->stream); the offset of
 // element i is tiles[i / kScanTile] + offsets[i], *total the grand total.

@@ -388,8 +388,8 @@ __global__ __launch_bounds__(kBlock) void argmax_sample(const SampleJob *__restr
         const unsigned o = __shfl_xor(best, off);
         best = o > best ? o : best;
     }
-    // one record per workgroup, folded by argmax_prepare: 2 048 atomics on one address would
-    // serialise at ~6 ns each (12 us, more than the sampling itself)
+    // one record per workgroup, folded by argmax_prepare: thousands of atomics on one address serialise at ~12 ns each
+    // (round 5 tried a ticket per workgroup so that the last one folds, to save that launch: 19 + 5 -> 62 us)
     __shared__ unsigned wave_best[kBlock / 64];
     if ((threadIdx.x & 63) == 0)
         wave_best[threadIdx.x >> 6] = best;
@@ -528,6 +528,66 @@ __global__ void argmax_collect(const unsigned n, const unsigned *__restrict__ be
     out[j] = r;
 }
 
+// ONE job: the three launches above in one workgroup -- best value, greatest key among its ties, the record and the
+// counters for the host.  The list holds ~10^3 records (at most its capacity, 8 192 + 65 536) and every launch of the
+// tail costs ~5 us whatever it does (profiles/r05_timeline_fused.txt), 15 of the call's 280.
+constexpr int kBestSingleBlock = 1024;
+__global__ __launch_bounds__(kBestSingleBlock) void hits_best_single(const HitRecord *__restrict__ hits,
+                                                                     const unsigned long long *__restrict__ counters,
+                                                                     const unsigned long long capacity,
+                                                                     ArgmaxRecord *__restrict__ out,
+                                                                     unsigned long long *__restrict__ counters_out)
+{
+    __shared__ unsigned wave_value[kBestSingleBlock / 64];
+    __shared__ unsigned long long wave_key[kBestSingleBlock / 64];
+    unsigned long long n = counters[0];
+    if (n > capacity)
+        n = capacity;
+    unsigned bv = kOrderedNegInf;
+    for (unsigned long long i = threadIdx.x; i < n; i += kBestSingleBlock) {
+        const unsigned v = ordered_bits(hits[i].value);
+        bv = v > bv ? v : bv;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = __shfl_xor(bv, off);
+        bv = o > bv ? o : bv;
+    }
+    if ((threadIdx.x & 63) == 0)
+        wave_value[threadIdx.x >> 6] = bv;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < kBestSingleBlock / 64; ++w)
+        bv = wave_value[w] > bv ? wave_value[w] : bv;
+    unsigned long long bk = 0;  // (low + 1) of the greatest tied key; 0 = no record reaches the value
+    for (unsigned long long i = threadIdx.x; i < n; i += kBestSingleBlock) {
+        const HitRecord h = hits[i];
+        const unsigned long long k = ordered_bits(h.value) == bv ? (h.key & ((1ull << 40) - 1)) + 1 : 0ull;
+        bk = k > bk ? k : bk;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(bk, off);
+        bk = o > bk ? o : bk;
+    }
+    if ((threadIdx.x & 63) == 0)
+        wave_key[threadIdx.x >> 6] = bk;
+    __syncthreads();
+    if (threadIdx.x != 0)
+        return;
+    for (int w = 0; w < kBestSingleBlock / 64; ++w)
+        bk = wave_key[w] > bk ? wave_key[w] : bk;
+    if (counters_out) {
+        counters_out[0] = counters[0];
+        counters_out[1] = counters[1];
+    }
+    ArgmaxRecord r;
+    r.found = bk != 0;
+    r.value = from_ordered_bits(bv);
+    r.index = (long long)bk - 1;
+    out[0] = r;
+}
+
 // The route has ~60 us of fixed cost per call (sample, five small launches): it pays from
 // ~100 M cells per call on (measured crossover at M = 20), whether in one job or in a batch.
 constexpr unsigned long long kPrefilterArgmaxMinCells = 8ull << 20;     // per job
@@ -568,7 +628,12 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
         qjobs[q] = a;
         // 1/1024 of the rows, in chunks of kSampleRows rows spread evenly (rows >= 2^20 here)
         const unsigned long long rows = a.row_end - a.row_begin;
-        const unsigned long long nchunks = std::max<unsigned long long>(rows / 1024 / kSampleRows, 32);
+        unsigned long long nchunks = std::max<unsigned long long>(rows / 1024 / kSampleRows, 32);
+        // a lone job: at most one chunk per workgroup of the sample's grid (1 Gbp: 2 048 chunks instead of 3 815 -- one
+        // chain of loads per workgroup instead of two, 19 -> 14 us; the bound of a smaller sample is lower, ~1 900 cells
+        // tie or beat it instead of ~1 000, which the re-scoring does not notice).  More workgroups instead: 24 -> 33 us.
+        if (nq == 1)
+            nchunks = std::min<unsigned long long>(nchunks, (unsigned long long)ctx->num_cus * 8);
         max_chunks = std::max(max_chunks, nchunks);
         sjobs[q] = SampleJob{a.d_seq + a.row_begin * a.seq_stride, a.pssm->d_dense, (unsigned)a.pssm->m,
                              (unsigned)a.pssm->k, nchunks, (rows - kSampleRows) / (nchunks - 1),
@@ -705,16 +770,21 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
         LM_TRY(batch_join(ctx));
     fo.batch = nullptr;
     LM_TRY(launch_rescore(ctx, st, d_rj, fo, rj.data(), npos));
-    const unsigned hgrid = (unsigned)ctx->num_cus * 2;
-    hipLaunchKernelGGL(hits_best_value, dim3(hgrid), dim3(kBlock), 0, st, fo.hits, fo.hit_count, cap, d_bval);
-    hipLaunchKernelGGL(hits_best_key, dim3(hgrid), dim3(kBlock), 0, st, fo.hits, fo.hit_count, cap, d_bval,
-                       d_bkey);
     // results and the two list counters are written straight into the pinned buffer's lower half
     const bool pin = 16 + npos * sizeof(ArgmaxRecord) <= kPinnedBytes / 2;
     ArgmaxRecord *res = pin ? reinterpret_cast<ArgmaxRecord *>(static_cast<char *>(ctx->pinned) + 16) : d_res;
-    hipLaunchKernelGGL(argmax_collect, dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, st, (unsigned)npos,
-                       d_bval, d_bkey, res, fo.hit_count,
-                       pin ? static_cast<unsigned long long *>(ctx->pinned) : static_cast<unsigned long long *>(nullptr));
+    if (npos == 1) {
+        hipLaunchKernelGGL(hits_best_single, dim3(1), dim3(kBestSingleBlock), 0, st, fo.hits, fo.hit_count, cap, res,
+                           pin ? static_cast<unsigned long long *>(ctx->pinned) : static_cast<unsigned long long *>(nullptr));
+    } else {
+        const unsigned hgrid = (unsigned)ctx->num_cus * 2;
+        hipLaunchKernelGGL(hits_best_value, dim3(hgrid), dim3(kBlock), 0, st, fo.hits, fo.hit_count, cap, d_bval);
+        hipLaunchKernelGGL(hits_best_key, dim3(hgrid), dim3(kBlock), 0, st, fo.hits, fo.hit_count, cap, d_bval,
+                           d_bkey);
+        hipLaunchKernelGGL(argmax_collect, dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, st, (unsigned)npos,
+                           d_bval, d_bkey, res, fo.hit_count,
+                           pin ? static_cast<unsigned long long *>(ctx->pinned) : static_cast<unsigned long long *>(nullptr));
+    }
     LM_HIP_TRY(hipGetLastError());
     std::vector<ArgmaxRecord> host_res(pin ? 0 : npos);
     if (!pin) {

@@ -200,7 +200,7 @@ struct RescoreJob {
 };
 
 int launch_rescore(lm_hip_ctx *ctx, hipStream_t st, const RescoreJob *d_jobs, const FusedOut &fo, const RescoreJob *host_jobs,
-                   size_t n);
+                   size_t n, const ShortOrder *so = nullptr);
 
 // ---- reductions of block records (score_argmax.hip, score_store.hip) ------------------------------------------
 

@@ -64,9 +64,12 @@ constexpr int kRescoreCheck = 2;     // rounds between two flush decisions
 constexpr int kRescoreTabFloats = 2048;
 constexpr int kRescoreTabJobs = 8;
 
+// `bucket_counts` (ShortOrder; one job): every record stored also bumps the count of its bucket, key >> bucket_shift --
+// the histogram pass of the ordering, without a launch of its own.
 template <bool LDS_TAB>
 __global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const RescoreJob *__restrict__ jobs,
-                                                             const FusedOut fo, const unsigned njobs)
+                                                             const FusedOut fo, const unsigned njobs,
+                                                             unsigned *__restrict__ bucket_counts, const int bucket_shift)
 {
     __shared__ HitRecord stage[kHitStage];
     __shared__ unsigned nstage;
@@ -99,8 +102,11 @@ __global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const Rescor
             gbase = atomicAdd(fo.hit_count, (unsigned long long)cnt);
         __syncthreads();
         for (unsigned i = threadIdx.x; i < cnt; i += kRescoreBlock)
-            if (gbase + i < fo.hit_capacity)
+            if (gbase + i < fo.hit_capacity) {
                 fo.hits[gbase + i] = stage[i];
+                if (bucket_counts)
+                    atomicAdd(&bucket_counts[(stage[i].key & ((1ull << 40) - 1)) >> bucket_shift], 1u);
+            }
         __syncthreads();
         if (threadIdx.x == 0)
             nstage = 0;
@@ -180,16 +186,18 @@ __global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const Rescor
 }
 
 int launch_rescore(lm_hip_ctx *ctx, hipStream_t st, const RescoreJob *d_jobs, const FusedOut &fo,
-                          const RescoreJob *host_jobs, size_t n)
+                          const RescoreJob *host_jobs, size_t n, const ShortOrder *so)
 {
+    unsigned *counts = so && so->on ? so->counts : nullptr;
+    const int shift = so && so->on ? so->shift : 0;
     size_t floats = 0;
     for (size_t i = 0; i < n && i <= (size_t)kRescoreTabJobs; ++i)
         floats += (size_t)host_jobs[i].m * host_jobs[i].k;
     const dim3 grid((unsigned)ctx->num_cus * kRescoreBlocksPerCu), block(kRescoreBlock);
     if (n <= (size_t)kRescoreTabJobs && floats <= (size_t)kRescoreTabFloats)
-        hipLaunchKernelGGL(rescore_candidates<true>, grid, block, 0, st, d_jobs, fo, (unsigned)n);
+        hipLaunchKernelGGL(rescore_candidates<true>, grid, block, 0, st, d_jobs, fo, (unsigned)n, counts, shift);
     else
-        hipLaunchKernelGGL(rescore_candidates<false>, grid, block, 0, st, d_jobs, fo, (unsigned)n);
+        hipLaunchKernelGGL(rescore_candidates<false>, grid, block, 0, st, d_jobs, fo, (unsigned)n, counts, shift);
     LM_HIP_TRY(hipGetLastError());
     return LM_HIP_OK;
 }
@@ -386,8 +394,15 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
         }
         if (two_streams)
             LM_TRY(batch_join(ctx));
+        // one job whose hits all pass through the re-scoring kernel, list expected short: the kernel counts them per
+        // bucket as well (hits.hip, ShortOrder)
+        ShortOrder so;
+        const unsigned long long expected = ctx->last_hit_count + ctx->last_hit_count / 4;
+        if (attempt == 0 && ctx->speculate_order && ctx->short_order && n == 1 && any_candidates &&
+            (groups[0].kind == KIND_PREFILTER || groups[0].kind == KIND_PREFILTER2 || groups[0].kind == KIND_EXACT))
+            LM_TRY(short_order_begin(ctx, expected, n, max_low, &so));
         if (any_candidates) {
-            LM_TRY(launch_rescore(ctx, ctx->stream, d_jobs, fo, rjobs.data(), n));
+            LM_TRY(launch_rescore(ctx, ctx->stream, d_jobs, fo, rjobs.data(), n, &so));
             LM_HIP_TRY(hipGetLastError());
         }
         const int emit = keys == HitKeys::Position ? 1 : 0;
@@ -399,8 +414,8 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
             // call's count, and learn the counts from the same single synchronisation.
             int status = 0;
             unsigned long long counts[2] = {0, 0};
-            LM_TRY(order_hits(ctx, fo.hits, fo.hit_count, ~0ull, cap, ccap, ctx->last_hit_count + ctx->last_hit_count / 4,
-                              n, max_low, emit, jobs[0].cols, out, &status, counts));
+            LM_TRY(order_hits(ctx, fo.hits, fo.hit_count, ~0ull, cap, ccap, expected, n, max_low, emit, jobs[0].cols, out,
+                              &status, counts, &so));
             count = counts[0];
             ncand = counts[1];
             ordered = status == 0;

@@ -333,11 +333,13 @@ def test_hit_ordering_with_and_without_known_count():
     torch.cuda.set_device(0)
     stream = torch.cuda.current_stream().cuda_stream
     plis = {}
-    for flag in ("0", "1", "0-buckets", "1-buckets"):
+    for flag in ("0", "1", "0-buckets", "1-buckets", "1-five-launches"):
         plis[flag] = lm.Pipeline.hip(0, stream=stream)
         plis[flag].set_option("speculate_order", int(flag[0]))
         if flag.endswith("buckets"):
             plis[flag].set_option("sort_hits", 0)     # long lists: radix sort (default) or the bucket passes
+        if flag.endswith("five-launches"):
+            plis[flag].set_option("short_order", 0)   # short lists: counted by the re-scoring kernel (default) or by the bucket passes
     length, m = 40_000_003, 10
     seq, rows, pssm = make_workload(plis["1"], length, m, 5, seed=77)
     scores = score_all(plis["1"], pssm, seq, rows, m, length)

@@ -22,6 +22,6 @@ def dump(last_name, title, before, after):
     for r in sel:
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         print(f"  {(s - t0) / 1e3:9.1f} us  +{(e - s) / 1e3:8.1f} us  {r['Kernel_Name'][:80]}")
-dump("hits_job_starts", "fused threshold (last call)", 14, 2)
-dump("argmax_collect", "fused argmax (last call)", 10, 1)
+dump("hits_rank_emit", "fused threshold (last call)", 12, 2)
+dump("hits_best_single", "fused argmax (last call)", 9, 1)
 PY
