@@ -333,7 +333,24 @@ def at_sustained_clock(mhz: float, lds_bytes_per_s: float, valu_lane_ops_per_s: 
             "valu_model": valu_model + "; 64 lanes/clk/CU x 256 CUs"}
 
 
-def fused_roofline(ms: float, rows: int, m: int, kernel: str, mhz: float = 0.0) -> dict:
+def scan_kernel_ms(pli, call, reps: int = 25, warm: int = 40):
+    """Median duration of the scan kernel alone inside a fused call: HIP events around it on the library's stream
+    (context option "time_scan", lm_hip_ctx_last_scan_kernel_ms) -- measured in calls of their own, not in the timed ones,
+    after `warm` calls (behind a pause the device runs at a lower clock: 0.25 against 0.22 ms)."""
+    pli.set_option("time_scan", 1)
+    try:
+        ms = []
+        for i in range(warm + reps):
+            call()
+            k = pli.last_scan_kernel_ms
+            if k is not None and i >= warm:
+                ms.append(k)
+    finally:
+        pli.set_option("time_scan", 0)
+    return float(np.median(ms)) if ms else None
+
+
+def fused_roofline(ms: float, rows: int, m: int, kernel: str, mhz: float = 0.0, kernel_ms=None) -> dict:
     """A fused score+argmax / score+threshold call over `rows` x 32 positions, whole call on the wall clock (scan, re-scoring,
     reductions, read-back).  SURVEY 8(d): no score matrix is written, so the binding ceiling is the LDS gather -- here the
     pair table's (M | 3) + 1 bytes per position (score_prefilter2.hpp) against 256 B/clk/CU x 256 CUs x 2.4 GHz; the one
@@ -345,6 +362,11 @@ def fused_roofline(ms: float, rows: int, m: int, kernel: str, mhz: float = 0.0) 
                          "unit": "TB/s", "frac": round(lds / LDS_PEAK_BYTES_PER_S, 4),
                          "lds_bytes_per_position": (m | 3) + 1, "hbm_read_gbs": round(ach, 1),
                          "hbm_read_frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_hbm_bytes_per_call": rows * COLS,
+                         # the scan kernel alone (what the LDS ceiling bounds), without the call's launch-bound tail:
+                         # re-scoring, ordering / reduction of the hit list, read-back (profiles/r05_timeline_fused.txt)
+                         **({"kernel_ms": round(kernel_ms, 4),
+                             "kernel_frac": round(((m | 3) + 1) * rows * COLS / (kernel_ms * 1e-3) / LDS_PEAK_BYTES_PER_S, 4)}
+                            if kernel_ms else {}),
                          # the pair scan's issue per position and lane: (NP + 1) accumulate operations + 6 of decode per
                          # pair of super-steps = 4 positions (score_prefilter2.hpp), NP = ((M | 3) + 1) / 2
                          **at_sustained_clock(mhz, lds, (((m | 3) + 1) // 2 + 7) / 4 * rows * COLS / (ms * 1e-3),
@@ -991,8 +1013,13 @@ def main() -> None:
         by_rank = [mine]
 
     # --- reductions / merge on the last step's matrix (outside the timed region; "extras") --------
-    def timed(fn, reps=5):
+    def timed(fn, reps=5, warm=0):
         best, out = None, None
+        # the fused scans are quoted in steady state: the first ~60 calls of a process (or behind a pause of the device)
+        # take 0.30-0.33 ms where later ones take 0.27 -- host-side pools filling, then the clock governor
+        # (tools/scan_kernel_timer_check.py, profiles/r05_fused_call_warmup.txt)
+        for _ in range(warm):
+            fn()
         for _ in range(reps):
             torch.cuda.synchronize()
             t = time.perf_counter()
@@ -1015,7 +1042,7 @@ def main() -> None:
     sc_ptr = scores_h.data_ptr
     am_ms, am = timed(lambda: pli.argmax_dptr(sc_ptr, rows, COLS, COLS, first_cell_rule=rank == 0))
     fam_ms, fam = timed(lambda: pli.score_argmax_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS,
-                                                      m - 1, total_length, 0, rows, first_cell_rule=rank == 0))
+                                                      m - 1, total_length, 0, rows, first_cell_rule=rank == 0), warm=60)
     fam_kernel = pli.last_kernel
     assert am == fam, (am, fam)
     mg_ms, best = timed(lambda: D.merge_argmax(am, row0, device=coll_dev))
@@ -1030,9 +1057,13 @@ def main() -> None:
         thr_t = float(tt.item())
     th_ms, hits = timed(lambda: pli.threshold_dptr(sc_ptr, rows, COLS, COLS, thr_t), reps=5)
     fth_ms, fhits = timed(lambda: pli.score_threshold_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS,
-                                                          m - 1, total_length, 0, rows, thr_t), reps=5)
+                                                          m - 1, total_length, 0, rows, thr_t), reps=5, warm=60)
     fth_kernel = pli.last_kernel
     assert np.array_equal(hits, fhits[0]), "fused threshold differs from materialised threshold"
+    fam_kms = scan_kernel_ms(pli, lambda: pli.score_argmax_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS, m - 1,
+                                                                 total_length, 0, rows))
+    fth_kms = scan_kernel_ms(pli, lambda: pli.score_threshold_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS, m - 1,
+                                                                    total_length, 0, rows, thr_t))
     fam_mhz, _ = sustained_clock(lambda: pli.score_argmax_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS, m - 1,
                                                                total_length, 0, rows, first_cell_rule=rank == 0))
     fth_mhz, _ = sustained_clock(lambda: pli.score_threshold_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS, m - 1,
@@ -1136,8 +1167,8 @@ def main() -> None:
             "kernel_ms_min": round(min(kernel_ms), 4), "kernel_ms_max": round(max(kernel_ms), 4),
             # the fused forms never write the score matrix -- priced against the LDS-gather ceiling (the pair
             # table's (M | 3) + 1 bytes per position), the 1 B per position of HBM reads beside it
-            "fused_score_argmax": fused_roofline(fam_ms, rows, m, fam_kernel, fam_mhz),
-            "fused_score_threshold": fused_roofline(fth_ms, rows, m, fth_kernel, fth_mhz),
+            "fused_score_argmax": fused_roofline(fam_ms, rows, m, fam_kernel, fam_mhz, fam_kms),
+            "fused_score_threshold": fused_roofline(fth_ms, rows, m, fth_kernel, fth_mhz, fth_kms),
             "merge_threshold_ms_torch": round(mt_torch_ms, 4),
             "merge_us": (None if not rank_merge else
                          {"p50": round(float(np.median([x[0] for x in rank_merge])), 1),

@@ -147,7 +147,7 @@ int lm_hip_ctx_set_track_argmax(lm_hip_ctx *ctx, int enabled);
  * are otherwise taken only for some shapes.  Names: "track_argmax", "prefilter" (= the setters above),
  * "pair_prefilter", "pair_prefilter_protein", "speculate_order", "suffix_argmax", "suffix_occurrences", "multi_motif",
  * "skip_unreachable", "quad_loads", "xlong_store", "host_fold", "chunked_fused", "chunk_rows", "tiled", "sort_hits",
- * "short_order".  Unknown names:
+ * "short_order", "time_scan".  Unknown names:
  * LM_HIP_ERR_BAD_ARGS.  The shipped library reads none of them from the environment. */
 int lm_hip_ctx_set_option(lm_hip_ctx *ctx, const char *name, double value);
 /* Name of the kernel the last score call on this context launched
@@ -161,6 +161,11 @@ const char *lm_hip_ctx_last_kernel(lm_hip_ctx *ctx);
  * sequence costs beyond the scan itself (low-complexity tracts and N runs raise it: profiles/r05_realistic_inputs.json).
  * Either output may be NULL. */
 int lm_hip_ctx_last_scan_counts(lm_hip_ctx *ctx, unsigned long long *hits, unsigned long long *candidates);
+/* Diagnostic: with the context option "time_scan" = 1, the duration (ms, HIP events on the context's stream) of the scan
+ * kernel(s) of the last fused threshold / fused argmax call -- the part of the call that the LDS roofline bounds, without
+ * the re-scoring, the ordering of the hit list and the read-back behind it (bench.py: roofline.kernel_frac of the fused
+ * blocks).  -1 when the option is off or the call took a route without a scan kernel. */
+int lm_hip_ctx_last_scan_kernel_ms(lm_hip_ctx *ctx, float *ms);
 
 /* ---- PSSM ---------------------------------------------------------------- */
 

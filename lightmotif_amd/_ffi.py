@@ -66,6 +66,7 @@ SIGNATURES = {
     "lm_hip_ctx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
     "lm_hip_ctx_last_kernel": (C.c_char_p, [_vp]),
     "lm_hip_ctx_last_scan_counts": (C.c_int, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
+    "lm_hip_ctx_last_scan_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "lm_hip_pssm_create": (C.c_int, [_vp, _vp, _sz, _sz, _sz, C.POINTER(_vp)]),
     "lm_hip_pssm_reverse_complement": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
     "lm_hip_pssm_destroy": (C.c_int, [_vp]),

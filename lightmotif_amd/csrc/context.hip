@@ -347,7 +347,7 @@ int lm_hip_device_clock_mhz(int device, unsigned window_us, double *mhz)
 static const char *const kOptionNames[] = {"track_argmax", "xlong_store", "host_fold", "speculate_order", "suffix_argmax",
                                            "multi_motif", "quad_loads", "skip_unreachable", "pair_prefilter",
                                            "pair_prefilter_protein", "chunked_fused", "chunk_rows", "tiled",
-                                           "suffix_occurrences", "prefilter", "sort_hits", "short_order"};
+                                           "suffix_occurrences", "prefilter", "sort_hits", "short_order", "time_scan"};
 
 static int set_option(lm_hip_ctx *ctx, const char *name, double value)
 {
@@ -358,6 +358,7 @@ static int set_option(lm_hip_ctx *ctx, const char *name, double value)
     else if (n == "host_fold") ctx->host_fold = on;                  // 0 = small score_into folds its records on the device
     else if (n == "speculate_order") ctx->speculate_order = on;      // 0 = fused threshold reads the counts first
     else if (n == "sort_hits") ctx->sort_hits = on;                  // 0 = long hit lists through the bucket passes too
+    else if (n == "time_scan") ctx->time_scan = on;                  // 1 = events around the scan kernels of fused calls (lm_hip_ctx_last_scan_kernel_ms)
     else if (n == "short_order") ctx->short_order = on;              // 0 = short hit lists of one job through the five-launch form too
     else if (n == "suffix_argmax") ctx->suffix_argmax = on;          // 0 = fused argmax always scans the whole range
     else if (n == "multi_motif") ctx->multi_motif = on;              // 0 = one motif per workgroup pass in batches
@@ -480,6 +481,9 @@ int lm_hip_ctx_destroy(lm_hip_ctx *ctx)
         (void)hipEventDestroy(ctx->fork_event);
         (void)hipEventDestroy(ctx->join_event);
     }
+    for (hipEvent_t e : ctx->scan_ev)
+        if (e)
+            (void)hipEventDestroy(e);
     if (ctx->owns_stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -546,6 +550,15 @@ int lm_hip_ctx_last_scan_counts(lm_hip_ctx *ctx, unsigned long long *hits, unsig
         *hits = ctx->last_hit_count;
     if (candidates)
         *candidates = ctx->last_cand_count;
+    return LM_HIP_OK;
+}
+
+int lm_hip_ctx_last_scan_kernel_ms(lm_hip_ctx *ctx, float *ms)
+{
+    if (!ctx || !ms)
+        return fail(LM_HIP_ERR_BAD_ARGS, "ctx_last_scan_kernel_ms: null argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    *ms = ctx->last_scan_kernel_ms;
     return LM_HIP_OK;
 }
 

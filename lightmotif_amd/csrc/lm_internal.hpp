@@ -113,6 +113,10 @@ struct lm_hip_ctx {
     bool host_fold = true;       // ... small matrices: per-wavefront records folded by the host (option "host_fold" = 0: on the device)
     bool speculate_order = true; // fused threshold: order the hit list before the host knows its length
     bool sort_hits = true;       // ... long lists by radix sort instead of the bucket passes (hits.hip; option "sort_hits")
+    bool time_scan = false;      // diagnostic (option "time_scan"): events around the scan kernel(s) of a fused call -> last_scan_kernel_ms
+    hipEvent_t scan_ev[2] = {nullptr, nullptr};
+    bool scan_timed = false;
+    float last_scan_kernel_ms = -1.0f;
     bool short_order = true;     // ... short lists of one job counted by the re-scoring kernel, two launches behind it (hits.hip; option "short_order")
     bool suffix_argmax = true;   // fused argmax of short motifs: try the last rows first (score_argmax.hip)
     bool multi_motif = true;     // many-motif threshold batches: several motifs of one length per pass
@@ -128,6 +132,35 @@ struct lm_hip_ctx {
     lm::Scratch u8_tables;
     std::vector<uint8_t> u8_key;
 };
+
+namespace lm {
+// option "time_scan": the scan kernels of a fused call between two events on their stream, read after the call's
+// synchronisation (lm_hip_ctx_last_scan_kernel_ms).  Off: nothing is recorded.
+inline int scan_timer_begin(lm_hip_ctx *ctx, hipStream_t st)
+{
+    ctx->last_scan_kernel_ms = -1.0f;
+    ctx->scan_timed = false;
+    if (!ctx->time_scan)
+        return 0;
+    for (hipEvent_t &e : ctx->scan_ev)
+        if (!e && hipEventCreate(&e) != hipSuccess)
+            return 0;  // (a diagnostic: the call goes on untimed)
+    ctx->scan_timed = hipEventRecord(ctx->scan_ev[0], st) == hipSuccess;
+    return 0;
+}
+inline void scan_timer_end(lm_hip_ctx *ctx, hipStream_t st)
+{
+    if (ctx->scan_timed)
+        ctx->scan_timed = hipEventRecord(ctx->scan_ev[1], st) == hipSuccess;
+}
+inline void scan_timer_read(lm_hip_ctx *ctx)  // the stream has been synchronised
+{
+    float ms = -1.0f;
+    if (ctx->scan_timed && hipEventElapsedTime(&ms, ctx->scan_ev[0], ctx->scan_ev[1]) == hipSuccess)
+        ctx->last_scan_kernel_ms = ms;
+    ctx->scan_timed = false;
+}
+}  // namespace lm
 
 struct lm_hip_pssm {
     int device = 0;

@@ -743,6 +743,7 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
                        d_rj, d_bp);
     LM_HIP_TRY(hipGetLastError());
     const bool two_streams = groups.size() > 1;
+    scan_timer_begin(ctx, st);
     if (two_streams)
         LM_TRY(batch_fork(ctx));
     size_t launch = 0;
@@ -768,6 +769,7 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
     }
     if (two_streams)
         LM_TRY(batch_join(ctx));
+    scan_timer_end(ctx, st);
     fo.batch = nullptr;
     LM_TRY(launch_rescore(ctx, st, d_rj, fo, rj.data(), npos));
     // results and the two list counters are written straight into the pinned buffer's lower half
@@ -792,6 +794,7 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
         LM_HIP_TRY(hipMemcpyAsync(host_res.data(), d_res, npos * sizeof(ArgmaxRecord), hipMemcpyDeviceToHost, st));
     }
     LM_HIP_TRY(hipStreamSynchronize(st));
+    scan_timer_read(ctx);
     const unsigned long long nhits = static_cast<unsigned long long *>(ctx->pinned)[0];
     const unsigned long long ncand = static_cast<unsigned long long *>(ctx->pinned)[1];
     if (getenv("LM_HIP_TRACE"))

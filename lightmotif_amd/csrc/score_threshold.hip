@@ -337,6 +337,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
                                       ctx->stream));
         }
         const bool two_streams = groups.size() > 1;
+        scan_timer_begin(ctx, ctx->stream);
         if (two_streams)
             LM_TRY(batch_fork(ctx));
         bool any_candidates = false;
@@ -394,6 +395,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
         }
         if (two_streams)
             LM_TRY(batch_join(ctx));
+        scan_timer_end(ctx, ctx->stream);
         // one job whose hits all pass through the re-scoring kernel, list expected short: the kernel counts them per
         // bucket as well (hits.hip, ShortOrder)
         ShortOrder so;
@@ -454,6 +456,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
             LM_TRY(order_hits(ctx, fo.hits, fo.hit_count, count, cap, ccap, count, n, max_low, emit, jobs[0].cols,
                               out, &status, counts));
         }
+        scan_timer_read(ctx);
         if (getenv("LM_HIP_TRACE")) {
             const auto t_end = std::chrono::steady_clock::now();
             fprintf(stderr, "[lm_hip] fused threshold: %zu jobs, %llu candidates, %llu hits; %s; scans enqueued in "

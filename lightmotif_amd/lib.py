@@ -149,6 +149,14 @@ class Pipeline:
         check(self._L.lm_hip_ctx_last_scan_counts(self._h, C.byref(h), C.byref(c)))
         return int(h.value), int(c.value)
 
+    @property
+    def last_scan_kernel_ms(self) -> Optional[float]:
+        """Duration of the scan kernel(s) of the last fused call, with ``set_option("time_scan", 1)``; None otherwise
+        (lm_hip_ctx_last_scan_kernel_ms)."""
+        ms = C.c_float(-1.0)
+        check(self._L.lm_hip_ctx_last_scan_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value) if ms.value >= 0 else None
+
     def sustained_clock_mhz(self, load, seconds: float = 0.25, window_us: int = 3000):
         """Shader clock (MHz, median over windows) the device sustains while `load()` is called back to back for
         `seconds` from this thread; a second thread runs lm_hip_device_clock_mhz windows beside it.  Returns

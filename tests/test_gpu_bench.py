@@ -140,6 +140,10 @@ def test_single_gpu_line_has_every_contract_field():
     for key in ("fused_score_argmax", "fused_score_threshold"):
         fr = out["extras"][key]["roofline"]
         assert fr["sclk_mhz_sustained"] is None or 0 < fr["lds_frac_at_sustained_clock"] < 1.5
+        # the scan kernel alone, by events inside the library: shorter than the call, and what the ceiling bounds
+        # (absent when the call took a route without a scan kernel: small test lengths)
+        if "kernel_ms" in fr:
+            assert 0 < fr["kernel_ms"] < 1.1 * out["extras"][key]["ms"] and 0 < fr["kernel_frac"] < 1.2
     r10 = ex["readme_10kb"]
     assert r10["published_avx2_us"] == 12.797 and r10["host_pointer_us"] > 0 and r10["avx2_port_us"] > 0
     assert r10["scores_match_avx2_port_bitwise"] is True

@@ -127,3 +127,19 @@ def test_clock_probe_and_scan_counts(pli):
     rc, _ = pli.score_threshold(pssm, seq, t)
     hits, cands = pli.last_scan_counts
     assert hits == len(rc) and cands * 32 >= hits
+    # the scan kernel's own duration: only when asked for, and then for both fused calls
+    assert pli.last_scan_kernel_ms is None
+    pli.set_option("time_scan", 1)
+    try:
+        import time
+        t0 = time.perf_counter()
+        rc2, _ = pli.score_threshold(pssm, seq, t)
+        wall_ms = (time.perf_counter() - t0) * 1e3
+        k_thr = pli.last_scan_kernel_ms
+        best = pli.score_argmax(pssm, seq)
+        k_am = pli.last_scan_kernel_ms if pli.last_kernel.startswith("score_c32_prefilter") else 0.001
+    finally:
+        pli.set_option("time_scan", 0)
+    assert rc2 == rc and best is not None and 0 < k_thr < wall_ms and k_am > 0
+    pli.score_threshold(pssm, seq, t)
+    assert pli.last_scan_kernel_ms is None
