@@ -107,15 +107,21 @@ __global__ __launch_bounds__(kBlock) void hits_rank_emit(
     lm_hip_hit *__restrict__ out_hits, const unsigned long long max_bucket, unsigned *__restrict__ abort_flag,
     void *__restrict__ pre_out, float *__restrict__ pre_values, const unsigned long long pre,
     const unsigned long long njobs, unsigned long long *__restrict__ starts, unsigned long long *__restrict__ header,
-    unsigned *__restrict__ clean_counts, unsigned *__restrict__ clean_cursors)
+    unsigned *__restrict__ clean_counts, unsigned *__restrict__ clean_cursors, unsigned long long *__restrict__ clean_counters)
 {
     const unsigned long long count = live_count(count_ptr, cap);
-    if (clean_counts)  // ShortOrder: nothing reads the histogram or the cursors any more; the next call finds them zero
+    if (clean_counts) {  // ShortOrder: nothing reads the histogram, the cursors or the list's own counters any more (`count_ptr`
+                         // is their copy); the next call finds them zero
         for (unsigned long long b = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; b < nbuckets;
              b += (unsigned long long)gridDim.x * kBlock) {
             clean_counts[b] = 0u;
             clean_cursors[b] = 0u;
         }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            clean_counters[0] = 0ull;
+            clean_counters[1] = 0ull;
+        }
+    }
     if (starts && blockIdx.x == 0) {  // few jobs: the job offsets and the raw counters ride along (no launch of their own)
         if (threadIdx.x == 0 && header) {
             header[0] = count_ptr[0];
@@ -182,27 +188,38 @@ __global__ void hits_job_starts(const unsigned long long njobs, const unsigned l
 
 // ---- short lists of one job (ShortOrder) ---------------------------------------------------------------------
 //
-// Each launch of the tail costs ~5 us whatever it does, and a 1 Gbp scan at p = 1e-5 spent 28 of its 280 us in the five
-// above (fill, count, scan, scatter, rank: profiles/r05_timeline_fused.txt); a 5 Mbp scan spends more there than in
-// its scan.  For ONE job with a short list expected:
+// Each launch of the tail costs 2-5 us whatever it does (5 as the profiler shows them), and a 1 Gbp scan at p = 1e-5 spent
+// 28 of its 280 us in the five above (fill, count, scan, scatter, rank: profiles/r05_timeline_fused.txt), a copy-in of
+// zeroed counters + the job table before its scan; a 5 Mbp scan spends more there than in its scan.  For ONE job with a short
+// list expected:
 //   * the re-scoring kernel bumps the bucket count of every record it stores (rescore_candidates);
 //   * hits_short_scatter: every workgroup scans the whole histogram in LDS (<= kShortBuckets counts), workgroup 0
 //     publishes the offsets, records go to offset + cursor++;
 //   * hits_rank_emit as above, which also clears counts and cursors: the buffers are zero between calls (ctx->d_short,
-//     ctx->short_dirty covers calls that failed in between).
+//     ctx->short_dirty covers calls that failed in between);
+//   * the list's counters {hits, candidates} live there as well: the scatter kernel leaves a copy for the ranking kernel,
+//     which clears the originals -- the next scan starts without a head block copied in, its job an argument of the
+//     re-scoring kernel.
 constexpr unsigned long long kShortRecords = 40960;  // expected records (the previous call's count + 25 %) up to which a list is "short"
 constexpr int kShortBuckets = 10496;                 // >= kShortRecords / 4 + 1 (bucket_geometry), a multiple of kBlock; 41 KB of LDS
 constexpr size_t kShortTiles = kShortBuckets / kScanTile + 1;
-// ctx->d_short: counts | cursors | tiles (zero for ever: one "tile" per kScanTile buckets, see bucket_start) | offsets
+// ctx->d_short: counts | cursors | tiles (zero for ever: one "tile" per kScanTile buckets, see bucket_start) | offsets |
+// the list's counters (zero between calls) | their copy for the ranking kernel, which clears the originals
 constexpr size_t kShortOffCursors = kShortBuckets * 4, kShortOffTiles = 2 * kShortOffCursors,
-                 kShortOffOffsets = kShortOffTiles + 128, kShortBytes = kShortOffOffsets + (kShortBuckets + 1) * 8;
+                 kShortOffOffsets = kShortOffTiles + 128,
+                 kShortOffCounters = (kShortOffOffsets + (kShortBuckets + 1) * 8 + 255) / 256 * 256,  // {hits, candidates}: a line of their own
+                 kShortOffCopy = kShortOffCounters + 256, kShortBytes = kShortOffCopy + 256;
 static_assert(kShortTiles * 8 <= 128 && kShortBuckets % kBlock == 0 && kShortRecords / 4 + 1 <= kShortBuckets, "layout of the short form");
 
 __global__ __launch_bounds__(kBlock) void hits_short_scatter(
     const HitRecord *__restrict__ hits, const unsigned long long *__restrict__ count_ptr, const unsigned long long cap,
     const int shift, const unsigned nb, const unsigned *__restrict__ counts, unsigned *__restrict__ cursors,
-    unsigned long long *__restrict__ offsets, HitRecord *__restrict__ grouped)
+    unsigned long long *__restrict__ offsets, HitRecord *__restrict__ grouped, unsigned long long *__restrict__ counters_copy)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // what the ranking kernel reads while it clears the counters themselves
+        counters_copy[0] = count_ptr[0];
+        counters_copy[1] = count_ptr[1];
+    }
     constexpr int PER = kShortBuckets / kBlock;  // buckets per thread, contiguous
     __shared__ unsigned pre[kShortBuckets];
     __shared__ unsigned wave_sum[kBlock / 64];
@@ -374,10 +391,12 @@ int short_order_begin(lm_hip_ctx *ctx, unsigned long long expected, size_t njobs
         ctx->short_dirty = false;
         LM_HIP_TRY(hipMemsetAsync(ctx->d_short, 0, kShortBytes, ctx->stream));
     } else if (ctx->short_dirty) {
-        LM_HIP_TRY(hipMemsetAsync(ctx->d_short, 0, kShortOffTiles, ctx->stream));
+        LM_HIP_TRY(hipMemsetAsync(ctx->d_short, 0, kShortBytes, ctx->stream));
     }
     ctx->short_dirty = true;  // until order_hits has seen the clean-up through
     so->counts = ctx->d_short;
+    so->counters = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(ctx->d_short) + kShortOffCounters);
+    so->counters_copy = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(ctx->d_short) + kShortOffCopy);
     so->on = true;
     return LM_HIP_OK;
 }
@@ -429,7 +448,7 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
     unsigned long long nb = 0;
     bucket_geometry(sized_for, njobs, max_low, &shift, &nb);
     const bool short_form = so && so->on;
-    if (short_form && (!speculative || so->shift != shift || so->nb != nb || njobs != 1))
+    if (short_form && (!speculative || so->shift != shift || so->nb != nb || njobs != 1 || d_counters != so->counters))
         return fail(LM_HIP_ERR_BAD_ARGS, "fused threshold: the short ordering was begun with another geometry");
     const unsigned long long nbuckets = nb * njobs;
     const unsigned long long ntiles = (nbuckets + kScanTile - 1) / kScanTile;
@@ -542,9 +561,10 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
     } else {
     const bool inline_starts = njobs <= 1024;  // (one workgroup of hits_rank_emit writes them)
     unsigned *cursors = short_form ? counts + kShortBuckets : nullptr;
+    const unsigned long long *rank_counters = short_form ? so->counters_copy : d_counters;
     if (short_form) {  // the re-scoring kernel has counted
         hipLaunchKernelGGL(hits_short_scatter, dim3(grid), dim3(kBlock), 0, st, d_hits, d_counters, cap, shift, (unsigned)nb,
-                           counts, cursors, offsets, grouped);
+                           counts, cursors, offsets, grouped, so->counters_copy);
     } else {
         LM_HIP_TRY(hipMemsetAsync(counts, 0, (nbuckets * 4 + 255) / 256 * 256, st));  // whole 256-B units: one fill kernel
         hipLaunchKernelGGL(hits_bucket_count, dim3(grid), dim3(kBlock), 0, st, d_hits, d_counters, cap, shift, nb,
@@ -554,19 +574,19 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
                            offsets, tiles, counts, grouped);
     }
     if (emit == 0)
-        hipLaunchKernelGGL(hits_rank_emit<0>, dim3(grid), dim3(kBlock), 0, st, grouped, d_counters, cap, shift,
+        hipLaunchKernelGGL(hits_rank_emit<0>, dim3(grid), dim3(kBlock), 0, st, grouped, rank_counters, cap, shift,
                            nb, nbuckets, offsets, tiles, (unsigned long long)cols,
                            static_cast<lm_hip_coords *>(d_out), d_values,
                            static_cast<lm_hip_hit *>(nullptr), max_bucket, abort_flag, pre_out, pre_values, pre,
                            (unsigned long long)njobs, inline_starts ? starts : nullptr, inline_starts && speculative ? header : nullptr,
-                           short_form ? counts : nullptr, cursors);
+                           short_form ? counts : nullptr, cursors, short_form ? so->counters : nullptr);
     else
-        hipLaunchKernelGGL(hits_rank_emit<1>, dim3(grid), dim3(kBlock), 0, st, grouped, d_counters, cap, shift,
+        hipLaunchKernelGGL(hits_rank_emit<1>, dim3(grid), dim3(kBlock), 0, st, grouped, rank_counters, cap, shift,
                            nb, nbuckets, offsets, tiles, (unsigned long long)cols,
                            static_cast<lm_hip_coords *>(nullptr), static_cast<float *>(nullptr),
                            static_cast<lm_hip_hit *>(d_out), max_bucket, abort_flag, pre_out, pre_values, pre,
                            (unsigned long long)njobs, inline_starts ? starts : nullptr, inline_starts && speculative ? header : nullptr,
-                           short_form ? counts : nullptr, cursors);
+                           short_form ? counts : nullptr, cursors, short_form ? so->counters : nullptr);
     if (!inline_starts)
         hipLaunchKernelGGL(hits_job_starts, dim3((unsigned)((njobs + 1 + 255) / 256)), dim3(256), 0, st,
                            (unsigned long long)njobs, nb, nbuckets, d_counters, cap, offsets, tiles, starts,

@@ -363,6 +363,9 @@ struct ShortOrder {
     int shift = 0;
     unsigned long long nb = 0;
     unsigned *counts = nullptr;
+    // the list's two counters {hits, candidates} live in the context as well, zero between calls: the scans need no
+    // head block copied in first (the single job reaches the re-scoring kernel as an argument)
+    unsigned long long *counters = nullptr, *counters_copy = nullptr;
 };
 int short_order_begin(lm_hip_ctx *ctx, unsigned long long expected, size_t njobs, unsigned long long max_low, ShortOrder *so);
 // count == ~0: speculative (the host has not read the counters yet); see hits.hip

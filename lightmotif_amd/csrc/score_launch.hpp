@@ -199,6 +199,7 @@ struct RescoreJob {
     unsigned long long key_rows;
 };
 
+// `so` on: one job, handed to the kernel by value (d_jobs is not read), records counted per bucket (hits.hip)
 int launch_rescore(lm_hip_ctx *ctx, hipStream_t st, const RescoreJob *d_jobs, const FusedOut &fo, const RescoreJob *host_jobs,
                    size_t n, const ShortOrder *so = nullptr);
 

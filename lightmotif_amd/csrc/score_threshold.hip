@@ -69,8 +69,10 @@ constexpr int kRescoreTabJobs = 8;
 template <bool LDS_TAB>
 __global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const RescoreJob *__restrict__ jobs,
                                                              const FusedOut fo, const unsigned njobs,
-                                                             unsigned *__restrict__ bucket_counts, const int bucket_shift)
+                                                             unsigned *__restrict__ bucket_counts, const int bucket_shift,
+                                                             const RescoreJob job0)
 {
+    const bool by_value = bucket_counts != nullptr;  // ShortOrder: the one job is `job0`, `jobs` is not read
     __shared__ HitRecord stage[kHitStage];
     __shared__ unsigned nstage;
     __shared__ unsigned long long gbase;
@@ -79,9 +81,10 @@ __global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const Rescor
     if (LDS_TAB) {
         unsigned off = 0;
         for (unsigned j = 0; j < njobs; ++j) {  // block-uniform
-            const unsigned nf = jobs[j].m * jobs[j].k;
+            const unsigned nf = by_value ? job0.m * job0.k : jobs[j].m * jobs[j].k;
+            const float *dense = by_value ? job0.dense : jobs[j].dense;
             for (unsigned i = threadIdx.x; i < nf; i += kRescoreBlock)
-                tab[off + i] = jobs[j].dense[i];
+                tab[off + i] = dense[i];
             if (threadIdx.x == 0)
                 tab_off[j] = off;
             off += nf;
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const Rescor
         const unsigned long long c = c0 + (threadIdx.x >> 5);
         if (c < n) {
             const Candidate cd = fo.cands[c];
-            const RescoreJob jb = jobs[cd.key >> 40];
+            const RescoreJob jb = by_value ? job0 : jobs[cd.key >> 40];
             const unsigned long long r0 = cd.key & ((1ull << 40) - 1);
             // every symbol of the piece's column window is loaded once (<= 3 loads per
             // lane, all in flight together) and shared through LDS
@@ -195,9 +198,9 @@ int launch_rescore(lm_hip_ctx *ctx, hipStream_t st, const RescoreJob *d_jobs, co
         floats += (size_t)host_jobs[i].m * host_jobs[i].k;
     const dim3 grid((unsigned)ctx->num_cus * kRescoreBlocksPerCu), block(kRescoreBlock);
     if (n <= (size_t)kRescoreTabJobs && floats <= (size_t)kRescoreTabFloats)
-        hipLaunchKernelGGL(rescore_candidates<true>, grid, block, 0, st, d_jobs, fo, (unsigned)n, counts, shift);
+        hipLaunchKernelGGL(rescore_candidates<true>, grid, block, 0, st, d_jobs, fo, (unsigned)n, counts, shift, host_jobs[0]);
     else
-        hipLaunchKernelGGL(rescore_candidates<false>, grid, block, 0, st, d_jobs, fo, (unsigned)n, counts, shift);
+        hipLaunchKernelGGL(rescore_candidates<false>, grid, block, 0, st, d_jobs, fo, (unsigned)n, counts, shift, host_jobs[0]);
     LM_HIP_TRY(hipGetLastError());
     return LM_HIP_OK;
 }
@@ -322,7 +325,17 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
         fo.key_rows = key_rows;
         RescoreJob *d_jobs = reinterpret_cast<RescoreJob *>(base + off_jobs);
         BatchParams *d_bparams = reinterpret_cast<BatchParams *>(base + off_batch);
-        if (off_hits <= kPinnedBytes / 2) {
+        // one job whose hits all pass through the re-scoring kernel, list expected short: the kernel counts them per
+        // bucket as well, and the counters live in the context -- nothing to copy in before the scan (hits.hip, ShortOrder)
+        ShortOrder so;
+        const unsigned long long expected = ctx->last_hit_count + ctx->last_hit_count / 4;
+        if (attempt == 0 && ctx->speculate_order && ctx->short_order && n == 1 && groups.size() == 1 &&
+            (groups[0].kind == KIND_PREFILTER || groups[0].kind == KIND_PREFILTER2 || groups[0].kind == KIND_EXACT))
+            LM_TRY(short_order_begin(ctx, expected, n, max_low, &so));
+        if (so.on) {
+            fo.hit_count = so.counters;
+            fo.cand_count = so.counters + 1;
+        } else if (off_hits <= kPinnedBytes / 2) {
             char *head = static_cast<char *>(ctx->pinned) + kPinnedBytes / 2;
             memset(head, 0, off_jobs);
             memcpy(head + off_jobs, rjobs.data(), n * sizeof(RescoreJob));
@@ -396,14 +409,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
         if (two_streams)
             LM_TRY(batch_join(ctx));
         scan_timer_end(ctx, ctx->stream);
-        // one job whose hits all pass through the re-scoring kernel, list expected short: the kernel counts them per
-        // bucket as well (hits.hip, ShortOrder)
-        ShortOrder so;
-        const unsigned long long expected = ctx->last_hit_count + ctx->last_hit_count / 4;
-        if (attempt == 0 && ctx->speculate_order && ctx->short_order && n == 1 && any_candidates &&
-            (groups[0].kind == KIND_PREFILTER || groups[0].kind == KIND_PREFILTER2 || groups[0].kind == KIND_EXACT))
-            LM_TRY(short_order_begin(ctx, expected, n, max_low, &so));
-        if (any_candidates) {
+        if (any_candidates || so.on) {
             LM_TRY(launch_rescore(ctx, ctx->stream, d_jobs, fo, rjobs.data(), n, &so));
             LM_HIP_TRY(hipGetLastError());
         }
@@ -453,7 +459,8 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
         if (!ordered) {  // exact form: the count is known
             int status = 0;
             unsigned long long counts[2];
-            LM_TRY(order_hits(ctx, fo.hits, fo.hit_count, count, cap, ccap, count, n, max_low, emit, jobs[0].cols,
+            // (after a short form that gave up, the list's counters have been cleared: their copy still holds them)
+            LM_TRY(order_hits(ctx, fo.hits, so.on ? so.counters_copy : fo.hit_count, count, cap, ccap, count, n, max_low, emit, jobs[0].cols,
                               out, &status, counts));
         }
         scan_timer_read(ctx);
