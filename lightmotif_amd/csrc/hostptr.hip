@@ -1145,11 +1145,11 @@ constexpr HostCost kCostScoreF32{47.0, 0.093, 0.0, 0.0316};      // 1 B up + 4 B
 constexpr HostCost kCostScoreU8{60.0, 0.036, 0.0, 0.0071};       // 1 B up + 1 B down; AVX2 u8 shuffle kernel
 constexpr HostCost kCostMaximumF32{37.0, 0.070, 0.247, 0.0};     // 4 B up; the Generic scan (the rule the variant keeps, pli/mod.rs:135-160)
 constexpr HostCost kCostThresholdF32{63.0, 0.073, 0.252, 0.0};   // 4 B up; the default body (pli/mod.rs:210-221)
-// Scanner: t0 and g measured (tests/cpp/test_dispatch --bench -> profiles/r05_scan_crossover.json: 46-52 us at 10 kbp, 85-96 us
-// at 1 Mbp); the CPU side is the reference's block loop on its AVX2 tier, PRICED from the u8 shuffle kernel + one pass of the
+// Scanner: t0 and g measured (tests/cpp/test_dispatch --bench -> profiles/r05_scan_crossover.json: 29 us at 10 kbp, 41 at
+// 100 kbp, 78 at 1 Mbp with the short form of the hit-list ordering; 46 / 49 / 85 before it); the CPU side is the reference's block loop on its AVX2 tier, PRICED from the u8 shuffle kernel + one pass of the
 // vectorised u8 reductions -- the C++ port that stands in for it in the tests has scalar reductions (0.54 ns per cell: it
 // crosses over at ~85 k cells); a Rust build should re-measure with its own tier (HipPolicy::force).
-constexpr HostCost kCostScan{52.0, 0.044, 0.03, 0.0071};
+constexpr HostCost kCostScan{38.0, 0.044, 0.03, 0.0071};
 constexpr double kCrossoverMargin = 1.25;  // the CPU must cost this much more per cell than the link before a call leaves it
 size_t crossover_cells(const HostCost &k, size_t m)
 {
