@@ -353,24 +353,27 @@ def scan_kernel_ms(pli, call, reps: int = 25, warm: int = 40):
 def fused_roofline(ms: float, rows: int, m: int, kernel: str, mhz: float = 0.0, kernel_ms=None) -> dict:
     """A fused score+argmax / score+threshold call over `rows` x 32 positions, whole call on the wall clock (scan, re-scoring,
     reductions, read-back).  SURVEY 8(d): no score matrix is written, so the binding ceiling is the LDS gather -- here the
-    pair table's (M | 3) + 1 bytes per position (score_prefilter2.hpp) against 256 B/clk/CU x 256 CUs x 2.4 GHz; the one
+    pair table's (M' | 3) + 1 bytes per position, M' = the rows scanned (score_prefilter2.hpp) against 256 B/clk/CU x 256 CUs x 2.4 GHz; the one
     byte per position the scan must still read from HBM is reported beside it (`hbm_read_frac`), not as the bound."""
-    lds = ((m | 3) + 1) * rows * COLS / (ms * 1e-3)
+    # a single scan of M = 20, 24, ... 36 looks M - 1 rows up (drop-last form, csrc/score_threshold.hip): the bytes it reads
+    scanned = m - 1 if (m % 4 == 0 and 20 <= m <= 36) else m
+    row_bytes = (scanned | 3) + 1
+    lds = row_bytes * rows * COLS / (ms * 1e-3)
     ach = rows * COLS / (ms * 1e-3) / 1e9
     return {"ms": round(ms, 4), "kernel": kernel, "Gpos_s": round(rows * COLS / ms / 1e6, 1),
             "roofline": {"bound": "lds", "achieved": round(lds / 1e12, 2), "peak": round(LDS_PEAK_BYTES_PER_S / 1e12, 1),
                          "unit": "TB/s", "frac": round(lds / LDS_PEAK_BYTES_PER_S, 4),
-                         "lds_bytes_per_position": (m | 3) + 1, "hbm_read_gbs": round(ach, 1),
+                         "lds_bytes_per_position": row_bytes, "motif_rows_scanned": scanned, "hbm_read_gbs": round(ach, 1),
                          "hbm_read_frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_hbm_bytes_per_call": rows * COLS,
                          # the scan kernel alone (what the LDS ceiling bounds), without the call's launch-bound tail:
                          # re-scoring, ordering / reduction of the hit list, read-back (profiles/r05_timeline_fused.txt)
                          **({"kernel_ms": round(kernel_ms, 4),
-                             "kernel_frac": round(((m | 3) + 1) * rows * COLS / (kernel_ms * 1e-3) / LDS_PEAK_BYTES_PER_S, 4)}
+                             "kernel_frac": round(row_bytes * rows * COLS / (kernel_ms * 1e-3) / LDS_PEAK_BYTES_PER_S, 4)}
                             if kernel_ms else {}),
                          # the pair scan's issue per position and lane: (NP + 1) accumulate operations + 6 of decode per
                          # pair of super-steps = 4 positions (score_prefilter2.hpp), NP = ((M | 3) + 1) / 2
-                         **at_sustained_clock(mhz, lds, (((m | 3) + 1) // 2 + 7) / 4 * rows * COLS / (ms * 1e-3),
-                                              f"{(((m | 3) + 1) // 2 + 7) / 4:.2f} VALU operations per position "
+                         **at_sustained_clock(mhz, lds, (row_bytes // 2 + 7) / 4 * rows * COLS / (ms * 1e-3),
+                                              f"{(row_bytes // 2 + 7) / 4:.2f} VALU operations per position "
                                               "(v_add3_u32 accumulation + register decode of the pair scan)")}}
 
 

@@ -117,6 +117,7 @@ struct lm_hip_ctx {
     hipEvent_t scan_ev[2] = {nullptr, nullptr};
     bool scan_timed = false;
     float last_scan_kernel_ms = -1.0f;
+    bool drop_last = true;       // single pair scans of M = 20, 24, ... 36 over M - 1 rows (option "drop_last"; lm_hip_pssm::d_image2_drop)
     bool short_order = true;     // ... short lists of one job counted by the re-scoring kernel, two launches behind it (hits.hip; option "short_order")
     bool suffix_argmax = true;   // fused argmax of short motifs: try the last rows first (score_argmax.hip)
     bool multi_motif = true;     // many-motif threshold batches: several motifs of one length per pass
@@ -190,6 +191,11 @@ struct lm_hip_pssm {
     // discrete = (score - pre_offset) / pre_factor, pre_emax = f32 rounding-error bound.
     unsigned *d_image = nullptr;
     unsigned *d_image2 = nullptr;  // DNA / protein: pair-symbol table of score_prefilter2.hpp (25 / 441 rows)
+    // DNA, M = 20, 24, ... 36: the pair table of the first M - 1 rows.  The padded length of such a motif wastes a 16-byte
+    // read per table row (M' = M + 3); a prefilter only has to over-estimate, so a single scan looks the first M - 1 rows up
+    // and credits the last row with its best weight, `drop_dmax` (score_threshold.hip: drop_last_form)
+    unsigned *d_image2_drop = nullptr;
+    unsigned drop_dmax = 0;
     bool has_prefilter = false;
     double pre_offset = 0, pre_factor = 0, pre_emax = 0;
 };

@@ -15,7 +15,8 @@ namespace lm {
 // and the affine map discrete ~ (score - offset) / factor.  Follows the
 // idea of DiscreteMatrix (pwm/mod.rs:665-696: per-row offsets, one global factor,
 // weights rounded UP) on 16 bits.  Returns false when no sound prefilter exists.
-static bool build_prefilter(lm_hip_pssm &p, std::vector<unsigned> *image, std::vector<unsigned> *image2)
+static bool build_prefilter(lm_hip_pssm &p, std::vector<unsigned> *image, std::vector<unsigned> *image2,
+                            std::vector<unsigned> *image2_drop = nullptr)
 {
     const int m = (int)p.m, k = (int)p.k;
     if (m < 1)
@@ -66,6 +67,18 @@ static bool build_prefilter(lm_hip_pssm &p, std::vector<unsigned> *image, std::v
     if (k == 5 || k == 21) {  // DNA: 25 pair rows; protein: 441
         image2->assign((size_t)prefilter2_image_dw(m, k), 0u);
         prefilter2_pack_image(d.data() + (size_t)shift * k, m, image2->data(), k);
+    }
+    // the same table without the motif's last row, for lengths whose padding wastes a read (lm_hip_pssm::d_image2_drop);
+    // what the last row can add at most goes into the bound
+    if (image2_drop) {
+        image2_drop->clear();
+        p.drop_dmax = 0;
+        if (k == 5 && m >= 20 && m % 4 == 0) {  // (M = 12, 16: the shorter ring of M - 1 rows costs more than the read it saves: 188 -> 219, 183 -> 192 us per Gbp)
+            image2_drop->assign((size_t)prefilter2_image_dw(m - 1, k), 0u);
+            prefilter2_pack_image(d.data() + (size_t)shift * k, m - 1, image2_drop->data(), k);
+            for (int sy = 0; sy < k; ++sy)
+                p.drop_dmax = std::max(p.drop_dmax, d[(size_t)(m - 1 + shift) * k + sy]);
+        }
     }
     p.pre_offset = offset;
     p.pre_factor = factor;
@@ -153,8 +166,8 @@ int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stri
             // discrete prefilter image (score_prefilter.hpp); absent when the matrix has
             // NaN / +inf entries or no spread -- the exact f32 fused kernel is used then
             std::vector<unsigned> image;
-            std::vector<unsigned> image2;
-            if (build_prefilter(*p, &image, &image2)) {
+            std::vector<unsigned> image2, image2_drop;
+            if (build_prefilter(*p, &image, &image2, &image2_drop)) {
                 e = hipMalloc(&p->d_image, image.size() * sizeof(unsigned));
                 if (e != hipSuccess)
                     return cleanup(fail(LM_HIP_ERR_OOM, "hipMalloc(prefilter) failed: %s", hipGetErrorString(e)));
@@ -174,6 +187,16 @@ int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stri
                     if (e != hipSuccess)
                         return cleanup(fail(LM_HIP_ERR_HIP, "pair prefilter upload failed: %s",
                                             hipGetErrorString(e)));
+                }
+                if (!image2_drop.empty()) {
+                    e = hipMalloc(&p->d_image2_drop, image2_drop.size() * sizeof(unsigned));
+                    if (e == hipSuccess)
+                        e = hipMemcpyAsync(p->d_image2_drop, image2_drop.data(), image2_drop.size() * sizeof(unsigned),
+                                           hipMemcpyHostToDevice, ctx->stream);
+                    if (e == hipSuccess)
+                        e = hipStreamSynchronize(ctx->stream);
+                    if (e != hipSuccess)
+                        return cleanup(fail(LM_HIP_ERR_HIP, "pair prefilter upload failed: %s", hipGetErrorString(e)));
                 }
                 p->has_prefilter = true;
             }
@@ -269,6 +292,8 @@ int lm_hip_pssm_destroy(lm_hip_pssm *p)
         (void)hipFree(p->d_image);
     if (p->d_image2)
         (void)hipFree(p->d_image2);
+    if (p->d_image2_drop)
+        (void)hipFree(p->d_image2_drop);
     delete p;
     return LM_HIP_OK;
 }

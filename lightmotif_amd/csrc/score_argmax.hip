@@ -316,6 +316,7 @@ struct SampleJob {
     unsigned m, k;
     unsigned long long nchunks, stride;  // chunk c starts at row c * stride
     double pre_offset, pre_factor, pre_emax;
+    unsigned td_drop;  // drop-last form of the scan (lm_hip_pssm::d_image2_drop): what the unscanned last row may add; else 0
 };
 
 __device__ __forceinline__ unsigned ordered_bits(float v)
@@ -432,6 +433,14 @@ __global__ __launch_bounds__(64) void argmax_prepare(const SampleJob *__restrict
             td = scaled > 65535.0 ? 65535u : (unsigned)scaled;
         else
             t = INFINITY;  // the bound is too low for the 16-bit range: leave the job to the exact kernel
+        if (td != 0xffffffffu && jobs[j].td_drop) {
+            if (td > 4u * jobs[j].td_drop) {
+                td -= jobs[j].td_drop;
+            } else {  // the unscanned row carries too much of the bound: nothing is flagged, the exact kernel takes over
+                td = 0xffffffffu;
+                t = INFINITY;
+            }
+        }
     }
     rjobs[j].threshold = t;
     bparams[j].td = td;
@@ -637,7 +646,7 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
         max_chunks = std::max(max_chunks, nchunks);
         sjobs[q] = SampleJob{a.d_seq + a.row_begin * a.seq_stride, a.pssm->d_dense, (unsigned)a.pssm->m,
                              (unsigned)a.pssm->k, nchunks, (rows - kSampleRows) / (nchunks - 1),
-                             a.pssm->pre_offset, a.pssm->pre_factor, a.pssm->pre_emax};
+                             a.pssm->pre_offset, a.pssm->pre_factor, a.pssm->pre_emax, 0u};
         rjobs[q] = RescoreJob{sjobs[q].seq, a.pssm->d_dense, (unsigned)a.pssm->m, (unsigned)a.pssm->k,
                               INFINITY, 0, 0};
     }
@@ -649,6 +658,14 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
     for (const JobGroup &g : groups)
         for (size_t q : g.idx)
             pairs_of[q] = g.kind == KIND_PREFILTER2;
+    // a lone pair scan of M = 20, 24, ... 36 rows: the drop-last form (score_threshold.hip, lm_hip_pssm::d_image2_drop)
+    C32Plan drop_plan;
+    if (nq == 1 && groups.size() == 1 && groups[0].kind == KIND_PREFILTER2 && ctx->drop_last && qjobs[0].pssm->d_image2_drop &&
+        score_c32_prefilter2_lookup((int)qjobs[0].pssm->m - 1, (int)qjobs[0].pssm->k))
+        drop_plan = plan_c32(ctx, MotifShape{qjobs[0].pssm->m - 1, qjobs[0].pssm->k, true}, qjobs[0], false, 2, 1);
+    const bool drop_last_form = drop_plan.ok;
+    if (drop_last_form)
+        sjobs[0].td_drop = qjobs[0].pssm->drop_dmax;
     std::vector<BatchParams> bparams;  // launch order; rjobs / sjobs are permuted the same way
     // positions in launch order; groups of the pair scan with several jobs run `per_pass[g]`
     // motifs per pass and are padded to a multiple of that (a padding position samples nothing,
@@ -682,8 +699,10 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
         if (is_pad[pos])
             sj[pos].nchunks = 0;
         rj[pos] = rjobs[q];
-        bparams.push_back(BatchParams{pairs_of[q] ? qjobs[q].pssm->d_image2 : qjobs[q].pssm->d_image, nullptr,
-                                      0.0f, 0xffffffffu, (unsigned long long)pos << 40});
+        bparams.push_back(BatchParams{drop_last_form ? qjobs[q].pssm->d_image2_drop
+                                      : pairs_of[q]  ? qjobs[q].pssm->d_image2
+                                                     : qjobs[q].pssm->d_image,
+                                      nullptr, 0.0f, 0xffffffffu, (unsigned long long)pos << 40});
     }
     // ~1024 cells tie with or beat the bound of a 1/1024 sample; leave room for 8x that
     // (bounded at 32 M / 128 M records = 2.5 GB for very large batches: lists that overflow send
@@ -761,9 +780,15 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
             continue;
         }
         const bool pairs = g.kind == KIND_PREFILTER2;
+        ctx->last_kernel = pairs ? "score_c32_prefilter2" : "score_c32_prefilter";
+        if (drop_last_form) {  // (table and threshold come from the job's BatchParams)
+            PrefilterLauncher fn = score_c32_prefilter2_lookup((int)a.pssm->m - 1, (int)a.pssm->k);
+            LM_HIP_TRY(fn(drop_plan.grid, drop_plan.lds, ls, a.d_seq, a.pssm->d_image2_drop, (int)a.pssm->k, a.row_begin, a.row_end,
+                          drop_plan.T, drop_plan.nstreams, 0xffffffffu, fo));
+            continue;
+        }
         PrefilterLauncher fn = pairs ? score_c32_prefilter2_lookup((int)a.pssm->m, (int)a.pssm->k)
                                      : score_c32_prefilter_lookup((int)a.pssm->m, lds_wide((int)a.pssm->k));
-        ctx->last_kernel = pairs ? "score_c32_prefilter2" : "score_c32_prefilter";
         LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, ls, a.d_seq, pairs ? a.pssm->d_image2 : a.pssm->d_image,
                       (int)a.pssm->k, a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, 0xffffffffu, fo));
     }

@@ -92,27 +92,46 @@ struct PairDecode {  // per-lane constants (set once per kernel)
     unsigned sel;             // byte selector of the last step
     unsigned four;            // the shift count of byte_times_16 (an SDWA operand must be a register)
 };
-template <int SO>
+//
+// LIN: which lanes form a "quad".  With four ADJACENT lanes on the four rows of a block, adjacent lanes read addresses 32
+// bytes apart, and the symbol loads alone -- nothing else in the kernel -- take 208 us per Gbp (4.8 TB/s), which is what
+// every single scan of M <= 20 took whatever its table (tools/kbench/symload_bench: the same loads with adjacent lanes on
+// adjacent dwords 173 us, 5.8 TB/s).  LIN = lane l of a half-wave reads dword l of the block's 128 bytes: its row is
+// q = l >> 3, its four columns 4 (l & 7) .., and it accumulates column 4 (l & 7) + q; the "quad" of a 4 x 4 tile is the lanes
+// {b, 8 + b, 16 + b, 24 + b}.  The exchanges become row_ror:8 (lane ^ 8, a DPP modifier as before) and
+// v_permlane16_swap (lane ^ 16: one operation for both directions, where the quad form took a DPP move) -- 7 operations
+// per block instead of 6.
+template <int SO, bool LIN = false>
 __device__ __forceinline__ PairDecode pair_decode_setup()
 {
     constexpr unsigned A_LO = 0u | (4u * SO << 8) | (8u * SO << 16) | (12u * SO << 24), A_HI = 16u * SO;
     constexpr unsigned B_LO = 0u | (1u * SO << 8) | (2u * SO << 16) | (3u * SO << 24), B_HI = 20u * SO;
-    const unsigned q = threadIdx.x & 3u;
+    const unsigned q = LIN ? (threadIdx.x >> 3) & 3u : threadIdx.x & 3u;
     PairDecode pd;
     pd.tab_lo = (q & 1u) ? B_LO : A_LO;
     pd.tab_hi = (q & 1u) ? B_HI : A_HI;
-    // lanes 0, 1 hold the first pair in `s` and receive the second in `y`; lanes 2, 3 the other way round
-    pd.sel = (q & 2u) ? (0x0c000c00u | (4u + q) | (q << 16)) : (0x0c000c00u | q | ((4u + q) << 16));
+    // quad form: lanes 0, 1 hold the first pair in `s` and receive the second in `y`; lanes 2, 3 the other way round.
+    // LIN: after the swap the first pair is in one register and the second in the other for every lane.
+    pd.sel = (!LIN && (q & 2u)) ? (0x0c000c00u | (4u + q) | (q << 16)) : (0x0c000c00u | q | ((4u + q) << 16));
     pd.four = 4u;
     return pd;
 }
 // bytes 0 / 2 = row(a, b) * SO of the lane's column for the pairs (rows 0, 1) / (rows 2, 3) of the quad's block `d`
+template <bool LIN = false>
 __device__ __forceinline__ unsigned dna_pair_offsets(unsigned d, const PairDecode &pd)
 {
     const unsigned c = __builtin_amdgcn_perm(pd.tab_hi, pd.tab_lo, d);
-    const unsigned s = c + (unsigned)__builtin_amdgcn_mov_dpp((int)c, 0xb1, 0xf, 0xf, true);  // quad_perm [1, 0, 3, 2]; no byte carries
-    const unsigned y = (unsigned)__builtin_amdgcn_mov_dpp((int)s, 0x4e, 0xf, 0xf, true);      // quad_perm [2, 3, 0, 1]
-    return __builtin_amdgcn_perm(y, s, pd.sel);
+    if constexpr (LIN) {
+        const unsigned s = c + (unsigned)__builtin_amdgcn_mov_dpp((int)c, 0x128, 0xf, 0xf, true);  // row_ror:8 = lane ^ 8; no byte carries
+        // rows of 16 lanes: r[0] = (s.row0, s.row0, s.row2, s.row2) -- the first pair of every lane's tile,
+        //                   r[1] = (s.row1, s.row1, s.row3, s.row3) -- the second
+        const auto r = __builtin_amdgcn_permlane16_swap(s, s, false, false);
+        return __builtin_amdgcn_perm(r[1], r[0], pd.sel);
+    } else {
+        const unsigned s = c + (unsigned)__builtin_amdgcn_mov_dpp((int)c, 0xb1, 0xf, 0xf, true);  // quad_perm [1, 0, 3, 2]; no byte carries
+        const unsigned y = (unsigned)__builtin_amdgcn_mov_dpp((int)s, 0x4e, 0xf, 0xf, true);      // quad_perm [2, 3, 0, 1]
+        return __builtin_amdgcn_perm(y, s, pd.sel);
+    }
 }
 // ((s >> 8 * BYTE) & 0xff) << 4 in ONE operation: the byte select rides on the shift (SDWA; hipcc emits and + shift)
 template <int BYTE>
@@ -280,11 +299,12 @@ __device__ __forceinline__ unsigned load_block(const uint8_t *__restrict__ p)
 }
 
 // LDS byte offsets of the table rows of a block's two pairs of symbols
-template <int M, int KA>
+template <int M, int KA, bool LIN = false>
 __device__ __forceinline__ void decode_block(const unsigned d, const unsigned shq, const PairDecode &pd, unsigned &off0, unsigned &off1)
 {
+    static_assert(!LIN || prefilter2_lut_decode(M, KA), "the linear lane map exists for the register decode only");
     if constexpr (prefilter2_lut_decode(M, KA)) {
-        const unsigned pair_off = dna_pair_offsets(d, pd);
+        const unsigned pair_off = dna_pair_offsets<LIN>(d, pd);
         off0 = byte_times_16<0>(pair_off, pd.four);
         off1 = byte_times_16<2>(pair_off, pd.four);
     } else {  // one symbol at a time: own column's byte of a quad neighbour's dword (DPP move + bit-field extract)
@@ -297,8 +317,9 @@ __device__ __forceinline__ void decode_block(const unsigned d, const unsigned sh
 // What becomes of the two dwords a pair completes (`fin0`: outputs of super-step 2P, `fin1`: of 2P + 1).
 //
 // Scans: flags of motif MI (kFlagBits).  The FIRST group completes the stream's outputs 0 and 1 only (its last dword).
-template <int NM>
+template <int NM, bool LIN = false>
 struct FlagSink {
+    static constexpr bool kLinear = LIN;  // the lane map of the symbol blocks (pair_decode_setup)
     unsigned (&mx)[NM];
     template <int PHASE, int P, int NB, int MI>
     __device__ __forceinline__ void complete(const unsigned fin0, const unsigned fin1)
@@ -314,6 +335,7 @@ struct FlagSink {
 // per half-wave instruction).  `op` = the lane's cell of the group's first completed row; the FIRST group completes
 // rows 0 and 1 only (byte stores).  `wrap_mask`: 0 = clamp at 255 (avx2.rs:336), 0xff = mod 256 (Generic's +=).
 struct StoreSink {
+    static constexpr bool kLinear = false;  // (its transposed stores are built on adjacent-lane quads)
     uint8_t *op, *oq;
     unsigned wrap_mask, sel_lo, sel_hi;
     __device__ __forceinline__ StoreSink(uint8_t *o, unsigned wm) : op(o), wrap_mask(wm)
@@ -372,7 +394,7 @@ __device__ __forceinline__ void pair_items(unsigned (&acc)[NM][prefilter2_npair(
         if constexpr (has_next && MI + 1 == NM) {
             // the next item starts pair P + 1 (the next group's pair 0 after the last): decode its block, whose register
             // then takes block P + 1 + PFB
-            decode_block<M, KA>(blk[(P + 1) % NB], shq, pd, off0, off1);
+            decode_block<M, KA, Sink::kLinear>(blk[(P + 1) % NB], shq, pd, off0, off1);
             if (PHASE != PHASE_LAST || P + 1 + PFB < NB)
                 blk[(P + 1 + PFB) % NB] = load_block(spq + (P + 1 + PFB) * 128);
         }
@@ -403,14 +425,14 @@ __device__ __forceinline__ void pair_begin_rows(PairRows<NP> &cur, const unsigne
 
 // The FIRST group's lead-in: block 0 is decoded, item 0's rows are requested, block PFB follows the PFB blocks the
 // kernel's prologue requested.
-template <int M, int KA, int PFB>
+template <int M, int KA, int PFB, bool LIN = false>
 __device__ __forceinline__ void pair_begin(unsigned (&blk)[prefilter2_ring(M) / 4], PairRows<prefilter2_npair(M)> &cur,
                                            unsigned &off0, unsigned &off1, const uint8_t *__restrict__ spq, const unsigned shq,
                                            const PairDecode &pd)
 {
     constexpr int NP = prefilter2_npair(M);
     constexpr int NB = prefilter2_ring(M) / 4;
-    decode_block<M, KA>(blk[0], shq, pd, off0, off1);
+    decode_block<M, KA, LIN>(blk[0], shq, pd, off0, off1);
     blk[PFB % NB] = load_block(spq + PFB * 128);
     pair_begin_rows<NP, 0>(cur, off0, off1);
 }
@@ -464,7 +486,10 @@ __global__ __launch_bounds__(kBlock, prefilter2_waves(M, KA)) void score_c32_pre
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    const int col = lane & 31;
+    // the lane's row of a 4-row symbol block is col & 3 and its four columns 4 (col >> 2) ..; LIN (pair_decode_setup):
+    // lane l of a half-wave reads dword l of the block, i.e. row l >> 3
+    constexpr bool LIN = prefilter2_lut_decode(M, KA);
+    const int col = LIN ? 4 * (lane & 7) + ((lane >> 3) & 3) : lane & 31;
     unsigned long long stream =
         ((unsigned long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
     const bool idle = stream >= nstreams;  // re-does the last stream, reports nothing
@@ -515,11 +540,11 @@ __global__ __launch_bounds__(kBlock, prefilter2_waves(M, KA)) void score_c32_pre
         }
     };
 
-    const PairDecode pd = pair_decode_setup<prefilter2_stride_dw(M) / 4>();
+    const PairDecode pd = pair_decode_setup<prefilter2_stride_dw(M) / 4, LIN>();
     PairRows<NP> cur;
     unsigned off0, off1;
-    FlagSink<1> sink{mx};
-    pair_begin<M, KA, PFB>(blk, cur, off0, off1, spq, shq, pd);
+    FlagSink<1, LIN> sink{mx};
+    pair_begin<M, KA, PFB, LIN>(blk, cur, off0, off1, spq, shq, pd);
     pair_items<M, KA, 1, PFB, PHASE_FIRST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
     end_group();
     for (unsigned g = 1; g + 1 < ngroups; ++g) {

@@ -302,6 +302,16 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
         }
     }
     const size_t nbp = bparams.size();
+    // One pair scan of a motif of M = 20, 24, ... 36 rows: its first M - 1 rows are looked up and the last row is credited with
+    // its best weight (lm_hip_pssm::d_image2_drop) -- table rows of one 16-byte read less, up to four times the candidate
+    // pieces, identical hits (every candidate is re-scored over all M rows).  Not when the last row carries a large part of
+    // the threshold: the scan would flag too much.
+    C32Plan drop_plan;
+    if (n == 1 && groups.size() == 1 && groups[0].kind == KIND_PREFILTER2 && ctx->drop_last && jobs[0].pssm->d_image2_drop &&
+        (unsigned long long)jobs[0].pssm->drop_dmax * 4 <= tds[0] &&
+        score_c32_prefilter2_lookup((int)jobs[0].pssm->m - 1, (int)jobs[0].pssm->k))
+        drop_plan = plan_c32(ctx, MotifShape{jobs[0].pssm->m - 1, jobs[0].pssm->k, true}, jobs[0], false, 2, 1);
+    const bool drop_last_form = drop_plan.ok;
     for (int attempt = 0; attempt < 3; ++attempt) {
         // layout: [hit count u64][candidate count u64][jobs][batch][HitRecord x cap][Candidate x ccap];
         // the head -- zeroed counters and the two job tables -- is assembled in the upper half of the
@@ -373,11 +383,17 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
                 any_candidates = true;
             } else if (g.kind == KIND_PREFILTER || g.kind == KIND_PREFILTER2) {
                 const bool pairs = g.kind == KIND_PREFILTER2;
-                PrefilterLauncher fn = pairs ? score_c32_prefilter2_lookup((int)a.pssm->m, (int)a.pssm->k)
-                                             : score_c32_prefilter_lookup((int)a.pssm->m, lds_wide((int)a.pssm->k));
                 ctx->last_kernel = pairs ? "score_c32_prefilter2" : "score_c32_prefilter";
-                LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, pairs ? a.pssm->d_image2 : a.pssm->d_image,
-                              (int)a.pssm->k, a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, tds[i], fo));
+                if (pairs && drop_last_form) {
+                    PrefilterLauncher fn = score_c32_prefilter2_lookup((int)a.pssm->m - 1, (int)a.pssm->k);
+                    LM_HIP_TRY(fn(drop_plan.grid, drop_plan.lds, st, a.d_seq, a.pssm->d_image2_drop, (int)a.pssm->k, a.row_begin,
+                                  a.row_end, drop_plan.T, drop_plan.nstreams, tds[i] - a.pssm->drop_dmax, fo));
+                } else {
+                    PrefilterLauncher fn = pairs ? score_c32_prefilter2_lookup((int)a.pssm->m, (int)a.pssm->k)
+                                                 : score_c32_prefilter_lookup((int)a.pssm->m, lds_wide((int)a.pssm->k));
+                    LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, pairs ? a.pssm->d_image2 : a.pssm->d_image,
+                                  (int)a.pssm->k, a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, tds[i], fo));
+                }
                 any_candidates = true;
             } else if (g.kind == KIND_EXACT) {
                 const ExactMotif em = exact_motif(a.pssm, a.d_seq);
