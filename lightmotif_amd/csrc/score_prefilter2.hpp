@@ -332,18 +332,39 @@ struct FlagSink {
 };
 // Score<u8> (score_u8.hpp): the sums are a DiscreteMatrix's u8 scores.  A pair completes four rows of the lane's
 // column, which are transposed inside the quad of lanes and written with one dword store per lane (128 contiguous bytes
-// per half-wave instruction).  `op` = the lane's cell of the group's first completed row; the FIRST group completes
+// per half-wave instruction; LIN: the quad of a tile is the four lanes 8 apart and lane l writes dword l of the 128 bytes,
+// see pair_decode_setup).  `op` = the lane's cell of the group's first completed row; the FIRST group completes
 // rows 0 and 1 only (byte stores).  `wrap_mask`: 0 = clamp at 255 (avx2.rs:336), 0xff = mod 256 (Generic's +=).
+template <bool LIN = false>
 struct StoreSink {
-    static constexpr bool kLinear = false;  // (its transposed stores are built on adjacent-lane quads)
+    static constexpr bool kLinear = LIN;  // the lane map of the symbol blocks and of the stored tiles (pair_decode_setup)
     uint8_t *op, *oq;
     unsigned wrap_mask, sel_lo, sel_hi;
-    __device__ __forceinline__ StoreSink(uint8_t *o, unsigned wm) : op(o), wrap_mask(wm)
+    // `o`: the lane's cell (its column `col`) of the group's first completed row
+    __device__ __forceinline__ StoreSink(uint8_t *o, unsigned wm, int col) : op(o), wrap_mask(wm)
     {
-        const unsigned q = threadIdx.x & 3u;
-        oq = op - q + q * 32;  // lane q of a quad writes row +q, the quad's 4 columns
-        sel_lo = 0x0c0c0000u | q | ((4u + q) << 8);
-        sel_hi = 0x00000c0cu | (q << 16) | ((4u + q) << 24);
+        const unsigned q = (unsigned)col & 3u;  // lane q of a tile's quad writes row +q, the tile's 4 columns
+        oq = op - col + q * 32 + ((unsigned)col >> 2) * 4;
+        if constexpr (!LIN) {
+            sel_lo = 0x0c0c0000u | q | ((4u + q) << 8);
+            sel_hi = 0x00000c0cu | (q << 16) | ((4u + q) << 24);
+        } else {
+            // the four packs of the quad arrive as (own, lane ^ 16) in one pair of registers and (lane ^ 8, lane ^ 24) in
+            // another, which of a pair is which depending on the lane's row of 16 (v_permlane16_swap): selectors per lane
+            const bool even = q < 2;
+            sel_lo = sel_hi = 0;
+            for (unsigned j = 0; j < 4; ++j) {  // output byte j = byte q of the pack of quad lane j = lane ^ (8 (j ^ q))
+                const unsigned k = j ^ q;
+                const unsigned first = q, second = 4u + q;  // v_perm: 0..3 = bytes of the second source, 4..7 of the first
+                unsigned vp = 0x0cu, vx = 0x0cu;
+                if (k == 0) vp = even ? first : second;
+                if (k == 2) vp = even ? second : first;
+                if (k == 1) vx = even ? first : second;
+                if (k == 3) vx = even ? second : first;
+                sel_lo |= vp << (8 * j);
+                sel_hi |= vx << (8 * j);
+            }
+        }
     }
     __device__ __forceinline__ void advance(const size_t bytes)
     {
@@ -366,11 +387,19 @@ struct StoreSink {
         } else {
             const unsigned r0 = narrow(fin0), r1 = narrow(fin1);
             const unsigned pack = __builtin_amdgcn_perm(r0, r0, 0x0c0c0200u) | __builtin_amdgcn_perm(r1, r1, 0x02000c0cu);  // rows 4P .. 4P + 3
-            const unsigned p0 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0x00, 0xf, 0xf, true);
-            const unsigned p1 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0x55, 0xf, 0xf, true);
-            const unsigned p2 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0xaa, 0xf, 0xf, true);
-            const unsigned p3 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0xff, 0xf, 0xf, true);
-            const unsigned row = __builtin_amdgcn_perm(p1, p0, sel_lo) | __builtin_amdgcn_perm(p3, p2, sel_hi);
+            unsigned row;
+            if constexpr (!LIN) {
+                const unsigned p0 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0x00, 0xf, 0xf, true);
+                const unsigned p1 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0x55, 0xf, 0xf, true);
+                const unsigned p2 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0xaa, 0xf, 0xf, true);
+                const unsigned p3 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0xff, 0xf, 0xf, true);
+                row = __builtin_amdgcn_perm(p1, p0, sel_lo) | __builtin_amdgcn_perm(p3, p2, sel_hi);
+            } else {
+                const unsigned x8 = (unsigned)__builtin_amdgcn_mov_dpp((int)pack, 0x128, 0xf, 0xf, true);  // row_ror:8 = lane ^ 8
+                const auto rp = __builtin_amdgcn_permlane16_swap(pack, pack, false, false);
+                const auto rx = __builtin_amdgcn_permlane16_swap(x8, x8, false, false);
+                row = __builtin_amdgcn_perm(rp[1], rp[0], sel_lo) | __builtin_amdgcn_perm(rx[1], rx[0], sel_hi);
+            }
             *reinterpret_cast<unsigned *>(oq + 4 * P * 32) = row;
         }
     }

@@ -112,7 +112,8 @@ __global__ __launch_bounds__(kBlock, prefilter2_waves(M, 5)) void score_c32_u8_p
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    const int col = lane & 31;
+    constexpr bool LIN = prefilter2_lut_decode(M, 5);  // lane l of a half-wave on dword l of a block (score_prefilter2.hpp)
+    const int col = LIN ? 4 * (lane & 7) + ((lane >> 3) & 3) : lane & 31;
     unsigned long long stream =
         ((unsigned long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
     if (stream >= nstreams)  // idle half-waves redo the last stream (same bytes, same values)
@@ -144,11 +145,11 @@ __global__ __launch_bounds__(kBlock, prefilter2_waves(M, 5)) void score_c32_u8_p
     // group 0 completes rows 0 and 1, group g >= 1 rows (g-1)*RING + 2 .. g*RING + 1
     const unsigned long long ngroups = (T - 2) / RING + 1;  // exact: T = q*RING + 2
     uint8_t *op = out + (o0 - row_begin) * 32 + col;
-    const PairDecode pd = pair_decode_setup<prefilter2_stride_dw(M) / 4>();
+    const PairDecode pd = pair_decode_setup<prefilter2_stride_dw(M) / 4, LIN>();
     PairRows<NP> cur;
     unsigned off0, off1;
-    StoreSink sink(op, wrap_mask);
-    pair_begin<M, 5, PFB>(blk, cur, off0, off1, spq, shq, pd);
+    StoreSink<LIN> sink(op, wrap_mask, col);
+    pair_begin<M, 5, PFB, LIN>(blk, cur, off0, off1, spq, shq, pd);
     pair_items<M, 5, 1, PFB, PHASE_FIRST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
     sink.advance(2 * 32);
     for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
