@@ -34,7 +34,8 @@ namespace lm {
 // 4-row symbol blocks requested ahead of their decode in the pair scans, at most the ring of a group (RING / 4 registers,
 // held anyway).  Three were enough while the scan was VALU-bound; at 0.24 ms per Gbp the single-motif scan reads 4.2 TB/s
 // with ~6 000 resident wavefronts, and 3 x 256 B in flight per wavefront (4.7 MB) is less than bandwidth x latency
-// (round 5: VALU 59 %, LDS 69 % busy after the hand-pipelining -- neither pipe saturated).
+// (round 5: VALU 59 %, LDS 69 % busy after the hand-pipelining -- neither pipe saturated: the loads themselves were the
+// bound, in the lane order they were issued in; see LIN below.  With the linear order: VALU 74 %, LDS 75 %).
 constexpr int kPairPFB = 8;
 
 // padded length M' = 3 (mod 4).  A table row of NPAIR = (M' + 1) / 2 dwords is read as whole 16-byte pieces plus,
@@ -215,9 +216,10 @@ inline void prefilter2_pack_image(const unsigned *d, int m, unsigned *image2, in
 // ---- the scan loop, software-pipelined by hand ------------------------------------------------------------
 //
 // Symbol loads.  A byte load per lane and row moves 64 bytes per wavefront instruction, and at > 3 Tpos/s the scan
-// is bound by that request rate, not by LDS or VALU.  So the lanes of a quad (columns 4i..4i+3) fetch a 4 x 4 block of
-// symbols with ONE dword load each -- lane q reads row r+q, columns 4i..4i+3; a half-wave instruction covers 4 rows =
-// 128 contiguous bytes.  RING is a multiple of 4, so blocks never straddle a group; `blk` is a ring of the RING/4
+// is bound by that request rate, not by LDS or VALU.  So the four lanes of a "quad" fetch a 4 x 4 block of symbols
+// (rows r .. r+3, columns 4i .. 4i+3) with ONE dword load each; a half-wave instruction covers 4 rows = 128 contiguous
+// bytes.  Which lanes form a quad matters (pair_decode_setup, LIN): four adjacent lanes put neighbours 32 bytes apart,
+// and those loads alone cost 208 us per Gbp; lanes 8 apart -- lane l on dword l -- 173 us (profiles/r05_symload_bench.txt).  RING is a multiple of 4, so blocks never straddle a group; `blk` is a ring of the RING/4
 // blocks of a group, requested PFB blocks ahead of their decode.
 //
 // The schedule is spelled out, not left to the compiler.  Integer adds and ORs may be re-associated, and LLVM pairs an
