@@ -7,6 +7,7 @@
 //           adjacent lanes 32 bytes apart)
 //   linear  lane l of a half-wave reads dword l of the same 128 bytes (adjacent lanes adjacent)
 //   x4      lane l reads 16 bytes (four blocks at once): 512 contiguous bytes per half-wave instruction
+//   bytes   one byte per lane and ROW, the one-symbol (protein) scans' loads
 //   ./symload_bench [positions = 1e9] [T = 1024] [rounds = 5]
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -28,7 +29,21 @@ __global__ __launch_bounds__(256) void loads_only(const uint8_t *__restrict__ se
     const uint8_t *p = seq + stream * T * 32;
     unsigned acc = 0;
     const unsigned long long nblk = T / 4;
-    if (MAP == 2) {
+    if (MAP == 3) {  // the one-symbol scans: a byte per lane and row (32 contiguous bytes per half-wave instruction)
+        const uint8_t *q = p + l;
+        unsigned ring[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i)
+            ring[i] = q[(size_t)i * 32];
+        for (unsigned long long r = 0; r + PF < T; r += PF) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const unsigned v = ring[i];
+                ring[i] = q[(size_t)(r + PF + i) * 32];
+                acc += v;
+            }
+        }
+    } else if (MAP == 2) {
         const uint8_t *q = p + l * 16;  // 512 contiguous bytes per half-wave and step of 16 rows
         u32x4 ring[PF];
 #pragma unroll
@@ -78,7 +93,8 @@ int main(int argc, char **argv)
     const unsigned grid = (unsigned)((nstreams + 7) / 8);
     struct V { const char *name; void (*k)(const uint8_t *, unsigned long long, unsigned long long, unsigned *); };
     const V vs[] = {{"quad   PF6", loads_only<0, 6>}, {"linear PF6", loads_only<1, 6>}, {"quad   PF12", loads_only<0, 12>},
-                    {"linear PF12", loads_only<1, 12>}, {"x4     PF2", loads_only<2, 2>}, {"x4     PF4", loads_only<2, 4>}};
+                    {"linear PF12", loads_only<1, 12>}, {"x4     PF2", loads_only<2, 2>}, {"x4     PF4", loads_only<2, 4>},
+                    {"bytes  PF12", loads_only<3, 12>}, {"bytes  PF24", loads_only<3, 24>}};
     for (int r = 0; r < rounds; ++r)
         for (const V &v : vs) {
             CK(hipEventRecord(e0));
