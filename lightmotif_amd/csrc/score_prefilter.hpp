@@ -49,7 +49,11 @@ constexpr int prefilter_mp(int m) { return (m + 1) / 2 * 2; }
 // lost a varying quarter of their candidates on hardware (round 5: 5 573 ... 5 907 of 7 455 hits from run to run, same in the
 // round-4 binary; the ISA's wait counts are right, MP - 2 is exact: tools/protein_pair_ab.py found it, tests/test_gpu_protein_prefilter.py
 // holds it).  The symptom is timing-dependent, so every ring of this shape keeps the spare slot.
+#ifdef LM_RING_LOOKAHEAD_RAW  // tools/ring_isa.py / the round-6 investigation only: the round-4 form (look-ahead MP - 1)
+constexpr int prefilter_lookahead(int pf, int mp) { return pf < mp - 1 ? pf : mp - 1; }
+#else
 constexpr int prefilter_lookahead(int pf, int mp) { return mp <= 2 ? 1 : (pf < mp - 1 ? pf : mp - 2); }
+#endif
 // dwords per symbol row of one discrete layout: 4 * odd >= MP / 2 (conflict-free b128)
 // (wide alphabets, lds_wide(k): 2 * odd, read with single ds_read_b64 -- see table_stride in score_kernels.hpp)
 constexpr int prefilter_stride_dw(int m, int wide = 0)

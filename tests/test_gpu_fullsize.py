@@ -137,6 +137,100 @@ def test_full_size_properties(gpu_pli, length, m, k):
     assert torch.isneginf(scores[tail % rows, tail // rows]).all()
 
 
+def _generic_reductions_by_chunk(want, a, t, state):
+    """Folds one chunk (rows a ... of the WHOLE-matrix oracle scores) into the Generic argmax (last maximal cell in row-major
+    order, NaN never: pli/mod.rs:135-155) and the row-major hit list of `>= t` (pli/mod.rs:210-221)."""
+    flat = want.reshape(-1)
+    vmax = flat.max()                                     # (no NaN in these workloads: -inf and finite sums only)
+    if state["best"] is None or vmax >= state["best"][1]:
+        last = flat.size - 1 - int(np.argmax(flat[::-1] == vmax))
+        state["best"] = ((a + last // COLS, last % COLS), vmax)
+    nz = np.flatnonzero(flat >= np.float32(t))
+    state["hits"].append(np.stack([a + nz // COLS, nz % COLS], axis=1))
+    state["vals"].append(flat[nz])
+
+
+@pytest.mark.parametrize("length,m,k", [(1_000_000_000, 20, 5), (200_000_000, 12, 21), (999_999_937, 15, 5)],
+                         ids=["c2_dna_1Gbp_m20", "c5_protein_200M_m12", "dna_ragged_m15"])
+def test_whole_matrix_against_the_oracle_at_baseline_sizes(gpu_pli, length, m, k):
+    """EVERY cell of the BASELINE configurations against the CPU oracle -- the reference's own large tests are whole-genome
+    relative oracles (lightmotif/tests/argmax.rs:41-52, tests/scan.rs:25-43: every position against Generic).  The oracle
+    side is the AVX2 port on all host threads (oracle/lm_avx2.c, itself pinned bit-equal to the Generic restatement by
+    tests/test_oracle_golden.py::test_avx2_port_matches_generic_scores_bitwise), chunk by chunk; the expectations of argmax,
+    threshold and of every fused route are derived from THAT matrix with the Generic rules, never from the GPU's output."""
+    pli = gpu_pli
+    seq, rows, pssm = make_workload(pli, length, m, k, seed=4321 + m)
+    scores = score_all(pli, pssm, seq, rows, m, length)
+    host = co.aligned_empty((rows + m - 1, COLS), np.uint8)
+    host[:] = seq.cpu().numpy()
+    ref = co.Striped(host, length, m - 1, COLS, k)
+    weights = co.aligned_empty(pssm.data.shape, np.float32)
+    weights[:] = pssm.data
+    threads = os.cpu_count() or 1
+    # the generic restatement itself on the first rows (one thread: a few hundred thousand cells), then the port everywhere
+    gen, _ = co.score_rows(ref, pssm.data, 0, 8192)
+    chunk = 1 << 22
+    buf = co.aligned_empty((chunk, COLS), np.float32)
+    pinned = torch.empty((chunk, COLS), dtype=torch.float32).pin_memory()
+    # a p ~ 1e-5 tail, chosen on the ORACLE's first chunk
+    first = co.avx2_score_rows(ref, weights, out=buf[:min(chunk, rows)], row_begin=0, row_end=min(chunk, rows), threads=threads)
+    assert np.array_equal(first[:8192].view(np.uint32), gen.view(np.uint32))
+    finite = first[np.isfinite(first)]
+    t = float(np.partition(finite, finite.size - finite.size // 100_000)[finite.size - finite.size // 100_000])
+    state = {"best": None, "hits": [], "vals": []}
+    for a in range(0, rows, chunk):
+        b = min(a + chunk, rows)
+        want = co.avx2_score_rows(ref, weights, out=buf[:b - a], row_begin=a, row_end=b, threads=threads)
+        pinned[:b - a].copy_(scores[a:b])
+        torch.cuda.synchronize()
+        got = pinned[:b - a].numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"rows {a} ... {b}"
+        _generic_reductions_by_chunk(want, a, t, state)
+    want_am = (state["best"][0], float(state["best"][1]))
+    want_hits = np.concatenate(state["hits"]).astype(np.int64)
+    want_vals = np.concatenate(state["vals"])
+    assert want_hits.shape[0] > 1000
+
+    # Maximum / Threshold on the stored matrix, and every fused route, against the oracle's answers
+    assert pli.argmax_dptr(scores.data_ptr(), rows, COLS, COLS) == want_am
+    assert np.array_equal(np.asarray(pli.threshold_dptr(scores.data_ptr(), rows, COLS, COLS, t), np.int64), want_hits)
+    del scores
+    args = (pssm, seq.data_ptr(), rows + m - 1, COLS, COLS, m - 1, length, 0, rows)
+    stream = torch.cuda.current_stream().cuda_stream
+    routes = {"default": {}, "exact": {"prefilter": 0}, "one_symbol": {"pair_prefilter": 0, "pair_prefilter_protein": 0},
+              "pairs": {"pair_prefilter_protein": 1}, "pairs_all_rows": {"pair_prefilter_protein": 1, "drop_last": 0},
+              "counted_first": {"speculate_order": 0, "short_order": 0}}
+    for name, options in routes.items():
+        p = lm.Pipeline.hip(0, stream=stream)
+        for key, value in options.items():
+            p.set_option(key, value)
+        for attempt in range(2):                          # twice: a timing-dependent loss must show (DESIGN 4.9)
+            assert p.score_argmax_dptr(*args) == want_am, (name, attempt, p.last_kernel)
+            f_hits, f_vals = p.score_threshold_dptr(*args, t)
+            assert np.array_equal(np.asarray(f_hits, np.int64), want_hits), (name, attempt, p.last_kernel, len(f_hits), len(want_hits))
+            assert np.array_equal(np.asarray(f_vals, np.float32).view(np.uint32), want_vals.view(np.uint32)), (name, attempt)
+
+    # the stores again (two runs of one launch must agree bit for bit with the first, which the oracle checked above)
+    again = score_all(pli, pssm, seq, rows, m, length)
+    for a in (0, rows // 2, rows - min(chunk, rows)):
+        b = min(a + chunk, rows)
+        want = co.avx2_score_rows(ref, weights, out=buf[:b - a], row_begin=a, row_end=b, threads=threads)
+        assert np.array_equal(again[a:b].cpu().numpy().view(np.uint32), want.view(np.uint32)), f"second run, rows {a} ... {b}"
+    del again
+    if k == 5:
+        # Score<u8> with the DiscreteMatrix (avx2.rs:292-347: saturating sums), every cell, twice
+        dm = pssm.to_discrete()
+        w8 = co.aligned_empty((m, 32), np.uint8)
+        w8[:] = dm.data
+        want_u8 = co.avx2_score_rows_u8(ref, w8)
+        out = torch.empty((rows, COLS), dtype=torch.uint8, device=seq.device)
+        for attempt in range(2):
+            out.zero_()
+            assert pli.score_u8_dptr(dm, seq.data_ptr(), rows + m - 1, COLS, COLS, m - 1, length, 0, rows, out.data_ptr(), COLS)[0] == rows
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want_u8[:, :COLS]), (attempt, pli.last_kernel)
+
+
 def test_device_stripe_of_100M_positions_round_trips(gpu_pli):
     """Stripe on the device at scale: position i must land at [i % R][i / R]."""
     pli = gpu_pli
