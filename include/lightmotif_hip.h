@@ -147,9 +147,13 @@ int lm_hip_ctx_set_track_argmax(lm_hip_ctx *ctx, int enabled);
  * are otherwise taken only for some shapes.  Names: "track_argmax", "prefilter" (= the setters above),
  * "pair_prefilter", "pair_prefilter_protein", "speculate_order", "suffix_argmax", "suffix_occurrences", "multi_motif",
  * "skip_unreachable", "quad_loads", "xlong_store", "host_fold", "chunked_fused", "chunk_rows", "tiled", "sort_hits",
- * "short_order", "time_scan", "drop_last".  Unknown names:
+ * "short_order", "time_scan", "drop_last", "block_prefilter" (0 = the protein one-symbol scans load a byte per lane and row
+ * instead of 4-row blocks); "xcd_remap" is accepted and ignored (the remap it selected was removed in round 5).  Unknown names:
  * LM_HIP_ERR_BAD_ARGS.  The shipped library reads none of them from the environment. */
 int lm_hip_ctx_set_option(lm_hip_ctx *ctx, const char *name, double value);
+/* Round-4 ABI: selected an XCD-aware workgroup remap of the store kernel, which measured slower and was removed in round 5.
+ * Kept as a no-op returning LM_HIP_OK so that embedders built against the round-4 header still load and link. */
+int lm_hip_ctx_set_xcd_remap(lm_hip_ctx *ctx, int enabled);
 /* Name of the kernel the last score call on this context launched
  * (for profiling tools); valid until the next call.  "score_c32<M,MODE>" names
  * the kernel family and the length it ran at (MODE 0 store, 1 fused argmax,
@@ -538,10 +542,12 @@ int lm_hip_merge_threshold(lm_hip_ctx *ctx, lm_hip_comm *comm, const lm_hip_coor
 /* Exactly what a Rust shim can obtain from &StripedSequence / &DenseMatrix / &mut StripedScores: pageable host
  * matrices in, pageable host matrices out (csrc/hostptr.hip).  No context argument: every calling host thread is given
  * a lane of its own (context + stream, persistent staging, a cache of device PSSM tables keyed on the weights), so
- * threads overlap.  Lanes are dealt round-robin over the usable devices -- the reference's parallel axis is the CLI's
- * worker threads over (motif, sequence) jobs (lightmotif-cli main.rs:240-378), which then spread over the GPUs and PCIe
- * links of a node with no change to the caller; $LM_HIP_DEVICE (read once per process) puts every lane on one ordinal,
- * lm_hip_host_bind_thread one thread.  Large calls (>= 96 MB of scores) run as a tile pipeline over a per-device ring of
+ * threads overlap.  Lanes sit on ONE device unless told otherwise: $LM_HIP_DEVICE (read once per process; must name a
+ * usable ordinal), else the HIP device current in the thread that made the first host-pointer call -- so a job of one
+ * process per GPU never opens contexts on its neighbours' devices.  lm_hip_host_spread_lanes(1) deals new lanes
+ * round-robin over every usable device instead: the reference's parallel axis is the CLI's worker threads over
+ * (motif, sequence) jobs (lightmotif-cli main.rs:240-378), which then spread over the GPUs and PCIe links of a node with
+ * one call added to the host; lm_hip_host_bind_thread places one thread.  Large calls (>= 96 MB of scores) run as a tile pipeline over a per-device ring of
  * pinned buffers (allocated on, and served by helper threads bound to, the GPU's NUMA node) and take turns on it.
  * 1 B per position travels up and 4 B down per lm_hip_score_f32 call. */
 int lm_hip_score_f32(const uint8_t *seq, size_t seq_rows_total, size_t seq_stride, size_t cols,
@@ -612,8 +618,11 @@ int lm_hip_host_crossover(int op, size_t m, size_t k, size_t *cells);
  * call.  Contexts and cached PSSM tables stay; the next call sets up again what it needs.  Safe at any time (waits for
  * a large call in flight); for hosts that score a genome and then sit idle. */
 int lm_hip_host_trim(void);
+/* != 0: NEW host-pointer lanes are dealt round-robin over every usable device (one process driving a whole node); 0 (the
+ * default): every lane on the process's one host-pointer device (see above).  Lanes that exist stay where they are. */
+int lm_hip_host_spread_lanes(int enabled);
 /* Puts the calling thread's host-pointer lane on `device` (a HIP ordinal from lm_hip_device_ordinal) from its next call
- * on; -1 = back to the automatic placement ($LM_HIP_DEVICE, else round-robin).  For hosts that place their worker
+ * on; -1 = back to the automatic placement ($LM_HIP_DEVICE, else the process's device or the round-robin).  For hosts that place their worker
  * threads themselves (one thread per GPU, threads pinned next to their GPU). */
 int lm_hip_host_bind_thread(int device);
 /* Where the calling thread's lane is (creates it if need be): its device ordinal, the NUMA node the platform reports for

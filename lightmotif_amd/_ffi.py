@@ -64,6 +64,7 @@ SIGNATURES = {
     "lm_hip_ctx_set_prefilter": (C.c_int, [_vp, C.c_int]),
     "lm_hip_ctx_set_track_argmax": (C.c_int, [_vp, C.c_int]),
     "lm_hip_ctx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
+    "lm_hip_ctx_set_xcd_remap": (C.c_int, [_vp, C.c_int]),
     "lm_hip_ctx_last_kernel": (C.c_char_p, [_vp]),
     "lm_hip_ctx_last_scan_counts": (C.c_int, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "lm_hip_ctx_last_scan_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
@@ -142,6 +143,7 @@ SIGNATURES = {
     "lm_hip_host_crossover": (C.c_int, [C.c_int, _sz, _sz, _szp]),
     "lm_hip_host_trim": (C.c_int, []),
     "lm_hip_host_bind_thread": (C.c_int, [C.c_int]),
+    "lm_hip_host_spread_lanes": (C.c_int, [C.c_int]),
     "lm_hip_host_lane_info": (C.c_int, [_ip, _ip, _ip]),
 }
 

@@ -347,7 +347,7 @@ int lm_hip_device_clock_mhz(int device, unsigned window_us, double *mhz)
 static const char *const kOptionNames[] = {"track_argmax", "xlong_store", "host_fold", "speculate_order", "suffix_argmax",
                                            "multi_motif", "quad_loads", "skip_unreachable", "pair_prefilter",
                                            "pair_prefilter_protein", "chunked_fused", "chunk_rows", "tiled",
-                                           "suffix_occurrences", "prefilter", "sort_hits", "short_order", "time_scan", "drop_last"};
+                                           "suffix_occurrences", "prefilter", "sort_hits", "short_order", "time_scan", "drop_last", "block_prefilter"};
 
 static int set_option(lm_hip_ctx *ctx, const char *name, double value)
 {
@@ -366,10 +366,12 @@ static int set_option(lm_hip_ctx *ctx, const char *name, double value)
     else if (n == "quad_loads") ctx->quad_loads = on;                // 0 = byte symbol loads in the store kernel
     else if (n == "skip_unreachable") ctx->skip_unreachable = on;    // 0 = scan even when no cell can reach the threshold
     else if (n == "pair_prefilter") ctx->pair_prefilter = on;        // 0 = one symbol per prefilter lookup
+    else if (n == "block_prefilter") ctx->block_prefilter = on;      // 0 = protein one-symbol scans load a byte per lane and row
     else if (n == "pair_prefilter_protein") ctx->pair_prefilter_protein = on;  // 1 = 441-row pair scan for K = 21
     else if (n == "chunked_fused") ctx->chunked_fused = on;          // 0 = fused scans of M > 36 go cell by cell
     else if (n == "tiled") ctx->tiled = on;                          // 0 = column counts off 32 / 16 go cell by cell
     else if (n == "prefilter") ctx->use_prefilter = on;
+    else if (n == "xcd_remap") (void)on;                             // round-4 option, removed with the remap: accepted, ignored
     else if (n == "chunk_rows") {
         if (!(value >= 64) || !(value <= 2147483648.0))  // (also rejects NaN and +inf: the cast below must be defined)
             return fail(LM_HIP_ERR_BAD_ARGS, "ctx_set_option: chunk_rows must be 64 ... 2^31");
@@ -538,6 +540,12 @@ int lm_hip_ctx_set_option(lm_hip_ctx *ctx, const char *name, double value)
         return fail(LM_HIP_ERR_BAD_ARGS, "ctx_set_option: null argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
     return set_option(ctx, name, value);
+}
+
+int lm_hip_ctx_set_xcd_remap(lm_hip_ctx *ctx, int enabled)  // round-4 ABI, a no-op since round 5 (see the header)
+{
+    (void)enabled;
+    return ctx ? LM_HIP_OK : fail(LM_HIP_ERR_BAD_ARGS, "null context");
 }
 
 const char *lm_hip_ctx_last_kernel(lm_hip_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }

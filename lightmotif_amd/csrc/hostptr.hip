@@ -127,12 +127,16 @@ struct LaneRef {
 };
 thread_local LaneRef t_lane;
 
-// $LM_HIP_DEVICE, read ONCE per process: every lane on that ordinal (-1: not set)
+// $LM_HIP_DEVICE, read ONCE per process: every lane on that ordinal (-1: not set, -2: set to something that is no ordinal)
 int env_device()
 {
     static const int dev = [] {
         const char *e = getenv("LM_HIP_DEVICE");
-        return e && *e ? atoi(e) : -1;
+        if (!e || !*e)
+            return -1;
+        char *end = nullptr;
+        const long v = strtol(e, &end, 10);
+        return (end && *end == 0 && v >= 0 && v < 4096) ? (int)v : -2;
     }();
     return dev;
 }
@@ -155,19 +159,48 @@ const std::vector<int> &usable_devices()
     return *list;
 }
 
-// Device of a NEW lane: the thread's binding, else $LM_HIP_DEVICE, else the next usable device in turn.
+bool is_usable(int dev)
+{
+    const std::vector<int> &devs = usable_devices();
+    return std::find(devs.begin(), devs.end(), dev) != devs.end();
+}
+
+// lm_hip_host_spread_lanes: new lanes are dealt over every usable device in turn (a single process driving a whole node:
+// the reference CLI's worker threads, main.rs:240-378).  Off by default: a job of one process per GPU with every GPU visible
+// must not open contexts, pinned rings and PSSM caches on its neighbours' devices just because it scores from two threads.
+std::atomic<int> g_spread{0};
+
+// Device of a NEW lane: the thread's binding, else $LM_HIP_DEVICE, else -- spread on -- the next usable device in turn, else
+// the process's host-pointer device: the HIP device current in the thread that made the FIRST unbound call (what a rank set
+// with hipSetDevice / torch.cuda.set_device before it started scoring; ordinal 0 if it never did).
 int pick_device(int *out)
 {
     static std::atomic<unsigned> next{0};
-    if (t_lane.want_device >= 0)
+    static std::atomic<int> home{-1};
+    if (t_lane.want_device >= 0) {
         *out = t_lane.want_device;
-    else if (env_device() >= 0)
+    } else if (env_device() != -1) {
+        if (env_device() < 0 || !is_usable(env_device()))
+            return fail(LM_HIP_ERR_NO_DEVICE, "LM_HIP_DEVICE does not name a usable gfx950 device (lm_hip_device_ordinal lists them)");
         *out = env_device();
-    else {
+    } else {
         const std::vector<int> &devs = usable_devices();
         if (devs.empty())
             return fail(LM_HIP_ERR_NO_DEVICE, "no gfx950 device available");
-        *out = devs[next.fetch_add(1, std::memory_order_relaxed) % devs.size()];
+        if (g_spread.load(std::memory_order_relaxed)) {
+            *out = devs[next.fetch_add(1, std::memory_order_relaxed) % devs.size()];
+        } else {
+            int h = home.load(std::memory_order_acquire);
+            if (h < 0) {
+                int cur = 0;
+                if (hipGetDevice(&cur) != hipSuccess || !is_usable(cur))
+                    cur = devs[0];
+                int expected = -1;
+                home.compare_exchange_strong(expected, cur, std::memory_order_acq_rel);
+                h = home.load(std::memory_order_acquire);
+            }
+            *out = h;
+        }
     }
     return LM_HIP_OK;
 }
@@ -769,6 +802,8 @@ int score_call(HostLane *lane, const ScoreCall &c)
         BigPipe &bp = big_pipe(ctx->device);
         std::lock_guard<std::mutex> pipe(bp.mu);
         st = score_pipelined(lane, bp, c);
+        if (st != LM_HIP_ERR_CAPACITY)
+            lane_trim(lane);  // (a trim asked for by another thread while this call ran: honoured at its end, like the small calls')
     }
     if (st == LM_HIP_ERR_CAPACITY) {  // small (or a shape the tiles do not fit): piece by piece on this lane
         const size_t piece = std::max<size_t>((64u << 20) / (c.cols * c.elem), 1);
@@ -956,6 +991,14 @@ int lm_hip_host_bind_thread(int device)
                 return fail(LM_HIP_ERR_NO_DEVICE, "host_bind_thread: %d is not a usable (gfx950) device ordinal", device);
         }
         t_lane.want_device = device < 0 ? -1 : device;  // takes effect at the thread's next host-pointer call
+        return LM_HIP_OK;
+    });
+}
+
+int lm_hip_host_spread_lanes(int enabled)
+{
+    return guarded("host_spread_lanes", [&]() -> int {
+        g_spread.store(enabled != 0, std::memory_order_relaxed);  // lanes that exist stay where they are
         return LM_HIP_OK;
     });
 }

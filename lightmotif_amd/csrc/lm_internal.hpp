@@ -106,6 +106,7 @@ struct lm_hip_ctx {
     size_t rows_per_stream = 0; // 0 = default
     bool use_prefilter = true;  // fused threshold: packed 16-bit discrete prefilter (A/B knob)
     bool pair_prefilter = true;  // DNA prefilter scans look up two symbols at a time
+    bool block_prefilter = true;           // protein one-symbol scans fetch symbols in 4-row blocks (score_prefilter_blk.hpp); 0 = byte loads
     bool pair_prefilter_protein = false;  // the 441-row protein pair scan: correct, measured 4 % slower
     bool quad_loads = true;      // store kernel: quad-gathered dword symbol loads (M % 4 == 0; +1 %)
     bool track_argmax = true;    // score_into on handles also tracks the best cell (cached argmax)

@@ -21,7 +21,7 @@ static bool build_prefilter(lm_hip_pssm &p, std::vector<unsigned> *image, std::v
     const int m = (int)p.m, k = (int)p.k;
     if (m < 1)
         return false;
-    const int mp = prefilter_mp(m), shift = mp - m;
+    const int mp = prefilter_mp(m, lds_wide(k)), shift = mp - m;
     std::vector<double> off(m), top(m);
     double offset = 0, range = 0, abs_sum = 0;
     for (int j = 0; j < m; ++j) {
@@ -47,7 +47,7 @@ static bool build_prefilter(lm_hip_pssm &p, std::vector<unsigned> *image, std::v
     if (!(range > 0))
         return false;
     const double factor = range / (double)kPrefilterTop;
-    // discrete weights d'[0..mp): leading zero row when m is odd
+    // discrete weights d'[0..mp): leading zero rows pad the motif (even length; a multiple of 4 for wide alphabets)
     std::vector<unsigned> d((size_t)mp * k, 0);
     for (int j = 0; j < m; ++j)
         for (int s = 0; s < k; ++s) {

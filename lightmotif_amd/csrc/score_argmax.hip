@@ -780,7 +780,7 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
             continue;
         }
         const bool pairs = g.kind == KIND_PREFILTER2;
-        ctx->last_kernel = pairs ? "score_c32_prefilter2" : "score_c32_prefilter";
+        ctx->last_kernel = pairs ? "score_c32_prefilter2" : block_scan(ctx, a) ? "score_c32_prefilter_blk" : "score_c32_prefilter";
         if (drop_last_form) {  // (table and threshold come from the job's BatchParams)
             PrefilterLauncher fn = score_c32_prefilter2_lookup((int)a.pssm->m - 1, (int)a.pssm->k);
             LM_HIP_TRY(fn(drop_plan.grid, drop_plan.lds, ls, a.d_seq, a.pssm->d_image2_drop, (int)a.pssm->k, a.row_begin, a.row_end,
@@ -788,7 +788,7 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
             continue;
         }
         PrefilterLauncher fn = pairs ? score_c32_prefilter2_lookup((int)a.pssm->m, (int)a.pssm->k)
-                                     : score_c32_prefilter_lookup((int)a.pssm->m, lds_wide((int)a.pssm->k));
+                                     : score_c32_prefilter_lookup((int)a.pssm->m, lds_wide((int)a.pssm->k), block_scan(ctx, a));
         LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, ls, a.d_seq, pairs ? a.pssm->d_image2 : a.pssm->d_image,
                       (int)a.pssm->k, a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, 0xffffffffu, fo));
     }

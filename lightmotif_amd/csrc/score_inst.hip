@@ -38,6 +38,7 @@ struct RegisterRange {
         tab[9] = &score_c32_launch<M, MODE_CONTINUE, 1>;
         // wide alphabets (protein): the slots the launchers use at C = 32
         r.prew[M] = &score_c32_prefilter_launch<M, 1>;
+        r.preblk[M] = &score_c32_prefilter_blk_launch<M>;
         r.u8w[M] = &score_c32_u8_launch<M, 1>;
         ScoreC32Launcher *tw = r.c32w[M];
         tw[MODE_STORE] = &score_c32_launch<M, MODE_STORE, 0, 32, 1>;

@@ -58,6 +58,12 @@ struct ExactMotif {
 ExactMotif exact_motif(const lm_hip_pssm *p, const uint8_t *d_seq);
 C32Plan plan_c32(const lm_hip_ctx *ctx, const ScoreArgs &a, bool store, int prefilter = 0, size_t batch = 1);
 
+// the one-symbol prefilter scan of this job runs on 4-row symbol blocks (score_prefilter_blk.hpp): protein, dword-aligned matrix
+static inline bool block_scan(const lm_hip_ctx *ctx, const ScoreArgs &a)
+{
+    return ctx->block_prefilter && a.pssm->k == (size_t)kBlkKA && reinterpret_cast<uintptr_t>(a.d_seq) % 4 == 0;
+}
+
 dim3 generic_grid(const lm_hip_ctx *ctx, unsigned long long ncells);
 size_t generic_lds(const lm_hip_pssm *p, int *use_lds);
 

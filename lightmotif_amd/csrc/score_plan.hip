@@ -37,6 +37,7 @@ void register_score_pair_113(const KernelRegistry &r);
 static ScoreC32Launcher g_c32[kMaxStoreM + 1][kRegistrySlots];  // rows kMaxFastM + 1 ..: the long family (M % 4 == 0); beyond kMaxLongM: store only (M % 8 == 0)
 static ScoreC32Launcher g_c32w[kMaxStoreM + 1][kRegistrySlots];  // wide alphabets (lds_wide(K))
 static PrefilterLauncher g_prew[kMaxFastM + 1];
+static PrefilterLauncher g_preblk[kMaxFastM + 1];
 static ScoreU8Launcher g_u8w[kMaxFastM + 1];
 static PrefilterLauncher g_pre[kMaxFastM + 1];
 static PrefilterLauncher g_pre2[kMaxPairM + 1];  // DNA pair scan: every length up to kMaxPairM
@@ -49,7 +50,7 @@ static std::once_flag g_c32_once;
 
 static void init_registry()
 {
-    const KernelRegistry r{g_c32, g_pre, g_pre2, g_pre2_protein, g_u8, g_u8_pairs, g_pre2_multi, g_c32w, g_prew, g_u8w};
+    const KernelRegistry r{g_c32, g_pre, g_pre2, g_pre2_protein, g_u8, g_u8_pairs, g_pre2_multi, g_c32w, g_prew, g_u8w, g_preblk};
     register_score_c32_0(r);
     register_score_c32_1(r);
     register_score_c32_2(r);
@@ -86,10 +87,10 @@ ScoreC32Launcher score_c32_lookup(int M, int mode, bool wide)
     return (wide ? g_c32w : g_c32)[M][mode];
 }
 
-PrefilterLauncher score_c32_prefilter_lookup(int M, bool wide)
+PrefilterLauncher score_c32_prefilter_lookup(int M, bool wide, bool blocks)
 {
     std::call_once(g_c32_once, init_registry);
-    return (M >= 1 && M <= kMaxFastM) ? (wide ? g_prew[M] : g_pre[M]) : nullptr;
+    return (M >= 1 && M <= kMaxFastM) ? (wide ? (blocks ? g_preblk[M] : g_prew[M]) : g_pre[M]) : nullptr;
 }
 
 PrefilterLauncher score_c32_prefilter2_lookup(int M, int K)
@@ -159,7 +160,7 @@ C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const ScoreArgs &a
     const size_t K = ms.k;
     // rows per unrolled group: the motif length, padded for the prefilter kernels
     const size_t M = prefilter == 2   ? (size_t)prefilter2_ring((int)ms.m)
-                     : prefilter == 1 ? (size_t)prefilter_mp((int)ms.m)
+                     : prefilter == 1 ? (size_t)prefilter_mp((int)ms.m, lds_wide((int)K))
                                       : ms.m;
     const size_t extra = prefilter == 2 ? 2 : 1;  // rows of a stream beyond q groups
     const unsigned long long n = a.row_end - a.row_begin;
@@ -170,8 +171,6 @@ C32Plan plan_c32(const lm_hip_ctx *ctx, const MotifShape &ms, const ScoreArgs &a
         return p;
     if (prefilter == 0 && ms.m > (size_t)kMaxFastM && (ms.m % 4 != 0 || reinterpret_cast<uintptr_t>(a.d_seq) % 4 != 0))
         return p;  // the long family: padded lengths, dword symbol loads
-    if (prefilter == 1 && !store && ms.m <= 2)
-        return p;  // scans: a ring of two symbol registers has no spare slot (prefilter_lookahead): the exact kernel, which costs nothing here
     // (the pair-symbol kernel fetches symbols with dword loads: 4-byte aligned matrix)
     if (prefilter == 2 && ((K != 5 && !(K == 21 && ctx->pair_prefilter_protein)) || !ms.pair_table || ms.m < 2 ||
                            reinterpret_cast<uintptr_t>(a.d_seq) % 4 != 0))

@@ -41,24 +41,21 @@ namespace lm {
 // "reached the threshold" flag in the pair scans (score_prefilter2.hpp: kFlagBits).  15 bits of resolution over the
 // matrix's score range: the over-estimate is at most 2 M quanta of range / 32000.
 constexpr unsigned kPrefilterTop = 32000u;
-constexpr int prefilter_mp(int m) { return (m + 1) / 2 * 2; }
-// Symbol look-ahead of the one-symbol scans, in steps: the ring of MP symbol registers must keep ONE slot between the
-// step being consumed and the slot being refilled.  With a look-ahead of MP - 1 the refill of step k lands in the register of
-// step k - 1 -- which, compiled, still holds the LDS address of that step's reads -- and the protein kernels of M = 7, 8
-// (MP = 8: the only wide-alphabet length whose look-ahead was MP - 1 AND whose schedule put the load right behind the reads)
-// lost a varying quarter of their candidates on hardware (round 5: 5 573 ... 5 907 of 7 455 hits from run to run, same in the
-// round-4 binary; the ISA's wait counts are right, MP - 2 is exact: tools/protein_pair_ab.py found it, tests/test_gpu_protein_prefilter.py
-// holds it).  The symptom is timing-dependent, so every ring of this shape keeps the spare slot.
-#ifdef LM_RING_LOOKAHEAD_RAW  // tools/ring_isa.py / the round-6 investigation only: the round-4 form (look-ahead MP - 1)
+// padded motif length: even (two accumulators per register); a multiple of 4 for wide alphabets, whose scan fetches symbols
+// in 4-row blocks that must not straddle a group (score_prefilter_blk.hpp) -- every user of a wide image shares that geometry
+constexpr int prefilter_mp(int m, int wide = 0) { return wide ? (m + 3) / 4 * 4 : (m + 1) / 2 * 2; }
+// Symbol look-ahead of the byte-load scans, in steps: at most the ring of MP symbol registers minus the one being consumed.
+// (Round 5 shortened it to MP - 2 because the protein kernels of M = 7, 8 lost a quarter of their candidates at MP - 1.  The ring
+// was innocent: at MP - 1 those kernels used v0..v55 of 56 allocated VGPRs and v55 held the amount of the 64-bit shift that moved
+// the "groups per flag bit" mask -- a shift by the LAST allocated VGPR returns garbage on gfx950 (LLVM's Shift64HighRegBug of
+// gfx11; tools/kbench/shift64_repro.hip, profiles/r06_ring_fault_experiments.txt).  The scans keep their flags in GroupNotes now,
+// which has no such shift, and tools/isa_audit.py checks every kernel of the built library for the pattern: DESIGN 4.9.)
 constexpr int prefilter_lookahead(int pf, int mp) { return pf < mp - 1 ? pf : mp - 1; }
-#else
-constexpr int prefilter_lookahead(int pf, int mp) { return mp <= 2 ? 1 : (pf < mp - 1 ? pf : mp - 2); }
-#endif
 // dwords per symbol row of one discrete layout: 4 * odd >= MP / 2 (conflict-free b128)
 // (wide alphabets, lds_wide(k): 2 * odd, read with single ds_read_b64 -- see table_stride in score_kernels.hpp)
 constexpr int prefilter_stride_dw(int m, int wide = 0)
 {
-    return wide ? 2 * (((prefilter_mp(m) / 2 + 1) / 2) | 1) : 4 * (((prefilter_mp(m) / 2 + 3) / 4) | 1);
+    return wide ? 2 * (((prefilter_mp(m, 1) / 2 + 1) / 2) | 1) : 4 * (((prefilter_mp(m) / 2 + 3) / 4) | 1);
 }
 // total dwords of the LDS image: layout EVEN | layout ODD
 constexpr int prefilter_image_dw(int m, int k)
@@ -66,11 +63,11 @@ constexpr int prefilter_image_dw(int m, int k)
     return 2 * k * prefilter_stride_dw(m, lds_wide(k));
 }
 
-// Host side: packs the padded discrete weights d[j * k + s], j < prefilter_mp(m) (row 0 = the
-// all-zero padding row when m is odd), into the LDS image [layout EVEN | layout ODD].
+// Host side: packs the padded discrete weights d[j * k + s], j < prefilter_mp(m, lds_wide(k)) (leading all-zero
+// padding rows), into the LDS image [layout EVEN | layout ODD].
 inline void prefilter_pack_image(const unsigned *d, int m, int k, unsigned *image)
 {
-    const int mp = prefilter_mp(m), dsd = prefilter_stride_dw(m, lds_wide(k));
+    const int mp = prefilter_mp(m, lds_wide(k)), dsd = prefilter_stride_dw(m, lds_wide(k));
     for (int i = 0; i < prefilter_image_dw(m, k); ++i)
         image[i] = 0u;
     unsigned *even = image;
@@ -109,6 +106,34 @@ __device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b)
     return __builtin_bit_cast(unsigned, __builtin_elementwise_min(x, y));
 }
 
+// One bit per NOTE (= G groups of a stream), up to 64 per stream, collected without a compare AND without a 64-bit shift by
+// a register (prefilter_lookahead above: such a shift is what broke the protein scans): the field shifts right one bit per
+// note and takes the note's flag in at bit 63, so after n notes they sit in its top n bits, oldest lowest.
+struct GroupNotes {
+    unsigned lo = 0, hi = 0;
+    // `mx`: bit 15 of a half = that half reached the threshold (the pair scans' biased sums, score_prefilter2.hpp: kFlagBits)
+    __device__ __forceinline__ void note(unsigned &mx)
+    {
+        const unsigned either = mx | (mx << 16);  // bit 31: one of the two halves reached the threshold
+        push(either);
+        mx = 0;
+    }
+    __device__ __forceinline__ void push(const unsigned flag31)  // bit 31 of `flag31` = the note's flag
+    {
+        lo = __builtin_amdgcn_alignbit(hi, lo, 1);  // (hi:lo) >> 1
+        hi = (hi >> 1) | (flag31 & 0x80000000u);
+    }
+    __device__ __forceinline__ unsigned long long finish(unsigned n) const  // n = notes taken, 1 ... 64 (wave-uniform)
+    {
+        // (hi:lo) >> (64 - n) with 32-bit operations only
+        const unsigned sh = 64u - n;
+        const unsigned a = sh >= 32u ? hi : lo, b = sh >= 32u ? 0u : hi, r = sh & 31u;
+        const unsigned out_lo = r ? (a >> r) | (b << (32u - r)) : a;
+        const unsigned out_hi = r ? (b >> r) : b;
+        return ((unsigned long long)out_hi << 32) | out_lo;
+    }
+};
+
 // `mx` collects (packed max) every register that holds a just-completed sum.  Its other half
 // is the partial sum of an output still in flight; weights are >= 0, so a partial sum that
 // reaches td belongs to an output that will reach it too -- taking it into the maximum can
@@ -120,8 +145,8 @@ __device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b)
 // the FIRST group completes one output only), clamped to 255 (`sat_mask` = 0: the
 // saturating adds of avx2.rs:336) or reduced mod 256 (`sat_mask` = 0xff: Generic's `+=`).
 template <int M, int PF, int PHASE, int STORE = 0, int WIDE = 0>
-__device__ __forceinline__ void prefilter_group(unsigned (&acc2)[prefilter_mp(M) / 2],
-                                                unsigned (&sym)[prefilter_mp(M)],
+__device__ __forceinline__ void prefilter_group(unsigned (&acc2)[prefilter_mp(M, WIDE) / 2],
+                                                unsigned (&sym)[prefilter_mp(M, WIDE)],
                                                 const uint8_t *__restrict__ sp,
                                                 const char *__restrict__ tab_even,
                                                 const char *__restrict__ tab_odd,
@@ -136,7 +161,7 @@ __device__ __forceinline__ void prefilter_group(unsigned (&acc2)[prefilter_mp(M)
     const unsigned sel_lo = 0x0c0c0000u | q | ((4u + q) << 8);
     const unsigned sel_hi = 0x00000c0cu | (q << 16) | ((4u + q) << 24);
     unsigned pack = 0;
-    constexpr int MP = prefilter_mp(M);
+    constexpr int MP = prefilter_mp(M, WIDE);
     constexpr int NP = MP / 2;
     constexpr int NV = (NP + 3) / 4;
     constexpr unsigned DSB = prefilter_stride_dw(M, WIDE) * 4;
@@ -232,7 +257,7 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter(
         td = bp.td;
         fo.job_key = bp.job_key;
     }
-    constexpr int MP = prefilter_mp(M);
+    constexpr int MP = prefilter_mp(M, WIDE);
     constexpr int SHIFT = MP - M;
     constexpr int NP = MP / 2;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -273,32 +298,35 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter(
     static_assert(PFE >= 1, "the prefilter kernel needs a look-ahead of at least one step");
 #pragma unroll
     for (int j = 0; j < PFE; ++j) {
-        if (j == 0 && SHIFT) {
-            if (o0 > 0)  // row -1 does not exist; its weight row is all zero anyway
-                sym[0] = sp[0];
+        if (j < SHIFT) {
+            if (o0 + j >= (unsigned long long)SHIFT)  // rows before the matrix do not exist; their weight rows are all zero anyway
+                sym[j] = sp[j * 32];
         } else {
             sym[j] = sp[j * 32];
         }
     }
 
-    const unsigned long long ngroups = (T + MP - 1) / MP;  // exact: T = q*MP + 1, >= 2
-    unsigned long long hit_groups = 0;
-    const unsigned long long G = (ngroups + 63) / 64;  // groups per bit
-    unsigned long long gbit = 1, gleft = G;
+    // wave-uniform 32-bit bookkeeping (T <= 2^30, score_plan.hip)
+    const unsigned ngroups = (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)T + MP - 1u) / (unsigned)MP));  // exact: T = q*MP + 1, >= 2
+    const unsigned G = (ngroups + 63u) / 64u;  // groups per note (= per bit of hit_groups)
+    unsigned gleft = G, nnotes = 0, pending = 0;
     unsigned mx = 0;
+    GroupNotes notes;
     auto note_group = [&]() {
         const bool flag = (mx & 0xffffu) >= td || (mx >> 16) >= td;
-        hit_groups |= flag ? gbit : 0ull;
+        pending |= flag ? 0x80000000u : 0u;
         mx = 0;
         if (--gleft == 0) {
             gleft = G;
-            gbit <<= 1;
+            ++nnotes;
+            notes.push(pending);
+            pending = 0;
         }
     };
 
     prefilter_group<M, PFE, PHASE_FIRST, 0, WIDE>(acc2, sym, sp, tab_even, tab_odd, mx);
     note_group();
-    for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
+    for (unsigned g = 1; g + 1 < ngroups; ++g) {
         sp += MP * 32;
         prefilter_group<M, PFE, PHASE_MAIN, 0, WIDE>(acc2, sym, sp, tab_even, tab_odd, mx);
         note_group();
@@ -306,6 +334,11 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_prefilter(
     sp += MP * 32;
     prefilter_group<M, PFE, PHASE_LAST, 0, WIDE>(acc2, sym, sp, tab_even, tab_odd, mx);
     note_group();
+    if (gleft != G) {  // the last, partly filled note
+        ++nnotes;
+        notes.push(pending);
+    }
+    unsigned long long hit_groups = notes.finish(nnotes);
 
     // the flagged groups become candidates for exact re-scoring (outputs are counted from the stream's
     // first TRUE output row; group 0 completes output 0, group g >= 1 outputs
@@ -349,6 +382,7 @@ hipError_t score_c32_prefilter_launch(dim3 grid, size_t lds_bytes, hipStream_t s
     return hipGetLastError();
 }
 
-PrefilterLauncher score_c32_prefilter_lookup(int M, bool wide = false);
+// `blocks`: the scan on 4-row symbol blocks (score_prefilter_blk.hpp: K = 21, 4-byte aligned matrix)
+PrefilterLauncher score_c32_prefilter_lookup(int M, bool wide = false, bool blocks = false);
 
 }  // namespace lm

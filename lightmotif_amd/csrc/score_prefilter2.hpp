@@ -156,22 +156,7 @@ constexpr unsigned kFlagBits = 0x80008000u;
 static_assert(kPrefilterTop + 2u * (unsigned)kMaxPairM < 0x8000u, "biased sums must stay within their 16-bit half");
 __device__ __forceinline__ unsigned prefilter2_bias(unsigned td) { return td <= 0x8000u ? (0x8000u - td) * 0x10001u : 0u; }
 
-// One bit per NOTE (= G groups of a stream), up to 64 per stream, collected without a compare: the field shifts right
-// one bit per note and takes the note's flag in at bit 63, so after n notes they sit in its top n bits, oldest lowest.
-struct GroupNotes {
-    unsigned lo = 0, hi = 0;
-    __device__ __forceinline__ void note(unsigned &mx)
-    {
-        const unsigned either = mx | (mx << 16);  // bit 31: one of the two halves reached the threshold
-        lo = __builtin_amdgcn_alignbit(hi, lo, 1);  // (hi:lo) >> 1
-        hi = (hi >> 1) | (either & 0x80000000u);
-        mx = 0;
-    }
-    __device__ __forceinline__ unsigned long long finish(unsigned n) const  // n = notes taken, 1 ... 64
-    {
-        return (((unsigned long long)hi << 32) | lo) >> (64u - n);
-    }
-};
+// (GroupNotes, the per-stream record of flagged groups, lives in score_prefilter.hpp)
 
 // Opaque to the optimiser on purpose: LLVM re-associates chains of integer adds and ORs into trees, which keeps table
 // rows and completed sums alive across many super-steps (round 5: hundreds of spilled registers in the unrolled scans).
@@ -410,10 +395,16 @@ struct StoreSink {
 // One group = NB pairs x NM motifs, item IDX = P * NM + MI.  On entry `cur` holds (or is about to receive) the rows of
 // item IDX, (off0, off1) are the LDS offsets of pair P's rows in motif 0's table, and blk[] holds the PFB blocks after
 // block P; on exit `cur` is the next item's (requested), unless this was the stream's last.
+// `far`: byte offset, from `spq`, of the group TWO groups ahead -- 2 * RING * 32 -- or, where the stream has no such group (the
+// group before the LAST one), of the NEXT group, RING * 32: with PFB == NB the request of the group's last pair reaches block 0
+// of the group after next, which for the final stream of a matrix would lie past its wrap rows (a matrix ending on a page
+// boundary: a memory fault).  The fallback re-reads a block that surely exists (block 0 of the current group may lie BEFORE
+// the matrix: the first stream's padding rows); its value is never used.
 template <int M, int KA, int NM, int PFB, int PHASE, int IDX, class Sink>
 __device__ __forceinline__ void pair_items(unsigned (&acc)[NM][prefilter2_npair(M)], unsigned (&blk)[prefilter2_ring(M) / 4],
                                            PairRows<prefilter2_npair(M)> &cur, unsigned &off0, unsigned &off1,
-                                           const uint8_t *__restrict__ spq, const unsigned shq, const PairDecode &pd, Sink &sink)
+                                           const uint8_t *__restrict__ spq, const unsigned shq, const PairDecode &pd, Sink &sink,
+                                           const unsigned far)
 {
     constexpr int NP = prefilter2_npair(M);
     constexpr int NB = prefilter2_ring(M) / 4;  // = NP / 2 pairs per group
@@ -426,8 +417,12 @@ __device__ __forceinline__ void pair_items(unsigned (&acc)[NM][prefilter2_npair(
             // the next item starts pair P + 1 (the next group's pair 0 after the last): decode its block, whose register
             // then takes block P + 1 + PFB
             decode_block<M, KA, Sink::kLinear>(blk[(P + 1) % NB], shq, pd, off0, off1);
-            if (PHASE != PHASE_LAST || P + 1 + PFB < NB)
-                blk[(P + 1 + PFB) % NB] = load_block(spq + (P + 1 + PFB) * 128);
+            if (PHASE != PHASE_LAST || P + 1 + PFB < NB) {
+                if constexpr (P + 1 + PFB >= 2 * NB)
+                    blk[(P + 1 + PFB) % NB] = load_block(spq + far + (P + 1 + PFB - 2 * NB) * 128);
+                else
+                    blk[(P + 1 + PFB) % NB] = load_block(spq + (P + 1 + PFB) * 128);
+            }
         }
         PairRows<NP> nxt;
         unsigned fin0 = 0;
@@ -440,7 +435,7 @@ __device__ __forceinline__ void pair_items(unsigned (&acc)[NM][prefilter2_npair(
                 cur.r1[i] = nxt.r1[i];
             }
         }
-        pair_items<M, KA, NM, PFB, PHASE, IDX + 1>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
+        pair_items<M, KA, NM, PFB, PHASE, IDX + 1>(acc, blk, cur, off0, off1, spq, shq, pd, sink, far);
     }
 }
 
@@ -576,16 +571,17 @@ __global__ __launch_bounds__(kBlock, prefilter2_waves(M, KA)) void score_c32_pre
     unsigned off0, off1;
     FlagSink<1, LIN> sink{mx};
     pair_begin<M, KA, PFB, LIN>(blk, cur, off0, off1, spq, shq, pd);
-    pair_items<M, KA, 1, PFB, PHASE_FIRST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
+    constexpr unsigned FAR = 2u * RING * 32u, NEAR = RING * 32u;  // (pair_items: the group two groups ahead, where the stream has one)
+    pair_items<M, KA, 1, PFB, PHASE_FIRST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink, ngroups > 2 ? FAR : NEAR);
     end_group();
     for (unsigned g = 1; g + 1 < ngroups; ++g) {
         spq += RING * 32;
-        pair_items<M, KA, 1, PFB, PHASE_MAIN, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
+        pair_items<M, KA, 1, PFB, PHASE_MAIN, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink, g + 2 < ngroups ? FAR : NEAR);
         end_group();
     }
     if (ngroups > 1) {
         spq += RING * 32;
-        pair_items<M, KA, 1, PFB, PHASE_LAST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
+        pair_items<M, KA, 1, PFB, PHASE_LAST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink, 0u);
         end_group();
     }
     if (gleft != G) {  // the last, partly filled note
@@ -713,16 +709,17 @@ __global__ __launch_bounds__(kBlock, prefilter2_npair(M) <= 14 ? 4 : 3) void sco
     unsigned off0, off1;
     FlagSink<NM> sink{mx};
     pair_begin<M, 5, PFB>(blk, cur, off0, off1, spq, shq, pd);
-    pair_items<M, 5, NM, PFB, PHASE_FIRST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
+    constexpr unsigned FAR = 2u * RING * 32u, NEAR = RING * 32u;  // (pair_items: the group two groups ahead, where the stream has one)
+    pair_items<M, 5, NM, PFB, PHASE_FIRST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink, ngroups > 2 ? FAR : NEAR);
     end_group();
     for (unsigned g = 1; g + 1 < ngroups; ++g) {
         spq += RING * 32;
-        pair_items<M, 5, NM, PFB, PHASE_MAIN, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
+        pair_items<M, 5, NM, PFB, PHASE_MAIN, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink, g + 2 < ngroups ? FAR : NEAR);
         end_group();
     }
     if (ngroups > 1) {
         spq += RING * 32;
-        pair_items<M, 5, NM, PFB, PHASE_LAST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
+        pair_items<M, 5, NM, PFB, PHASE_LAST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink, 0u);
         end_group();
     }
     if (gleft != G) {

@@ -270,7 +270,7 @@ int launch_score_u8(lm_hip_ctx *ctx, const DiscreteArgs &a)
         std::vector<char> stage_buf(image_bytes + dense_bytes, 0);
         char *stage = stage_buf.data();
         if (fn) {
-            const int mp = prefilter_mp(m), shift = pairs ? 0 : mp - m;
+            const int mp = prefilter_mp(m, lds_wide(k)), shift = pairs ? 0 : mp - m;
             std::vector<unsigned> d((size_t)(m + shift) * k, 0u);
             for (int j = 0; j < m; ++j)
                 for (int s = 0; s < k; ++s)

@@ -383,14 +383,14 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
                 any_candidates = true;
             } else if (g.kind == KIND_PREFILTER || g.kind == KIND_PREFILTER2) {
                 const bool pairs = g.kind == KIND_PREFILTER2;
-                ctx->last_kernel = pairs ? "score_c32_prefilter2" : "score_c32_prefilter";
+                ctx->last_kernel = pairs ? "score_c32_prefilter2" : block_scan(ctx, a) ? "score_c32_prefilter_blk" : "score_c32_prefilter";
                 if (pairs && drop_last_form) {
                     PrefilterLauncher fn = score_c32_prefilter2_lookup((int)a.pssm->m - 1, (int)a.pssm->k);
                     LM_HIP_TRY(fn(drop_plan.grid, drop_plan.lds, st, a.d_seq, a.pssm->d_image2_drop, (int)a.pssm->k, a.row_begin,
                                   a.row_end, drop_plan.T, drop_plan.nstreams, tds[i] - a.pssm->drop_dmax, fo));
                 } else {
                     PrefilterLauncher fn = pairs ? score_c32_prefilter2_lookup((int)a.pssm->m, (int)a.pssm->k)
-                                                 : score_c32_prefilter_lookup((int)a.pssm->m, lds_wide((int)a.pssm->k));
+                                                 : score_c32_prefilter_lookup((int)a.pssm->m, lds_wide((int)a.pssm->k), block_scan(ctx, a));
                     LM_HIP_TRY(fn(g.plan.grid, g.plan.lds, st, a.d_seq, pairs ? a.pssm->d_image2 : a.pssm->d_image,
                                   (int)a.pssm->k, a.row_begin, a.row_end, g.plan.T, g.plan.nstreams, tds[i], fo));
                 }

@@ -13,6 +13,7 @@
 #pragma once
 
 #include "score_prefilter2.hpp"
+#include "score_prefilter_blk.hpp"
 
 
 namespace lm {
@@ -26,7 +27,7 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_u8(
     const unsigned long long T, const unsigned long long nstreams, uint8_t *__restrict__ out,
     const unsigned wrap_mask)
 {
-    constexpr int MP = prefilter_mp(M);
+    constexpr int MP = prefilter_mp(M, WIDE);
     constexpr int SHIFT = MP - M;
     constexpr int NP = MP / 2;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -63,9 +64,9 @@ __global__ __launch_bounds__(kBlock, 6) void score_c32_u8(
         sym[j] = 0;
 #pragma unroll
     for (int j = 0; j < PFE; ++j) {
-        if (j == 0 && SHIFT) {
-            if (o0 > 0)  // row -1 does not exist; its weight row is all zero anyway
-                sym[0] = sp[0];
+        if (j < SHIFT) {
+            if (o0 + j >= (unsigned long long)SHIFT)  // rows before the matrix do not exist; their weight rows are all zero anyway
+                sym[j] = sp[j * 32];
         } else {
             sym[j] = sp[j * 32];
         }
@@ -150,16 +151,17 @@ __global__ __launch_bounds__(kBlock, prefilter2_waves(M, 5)) void score_c32_u8_p
     unsigned off0, off1;
     StoreSink<LIN> sink(op, wrap_mask, col);
     pair_begin<M, 5, PFB, LIN>(blk, cur, off0, off1, spq, shq, pd);
-    pair_items<M, 5, 1, PFB, PHASE_FIRST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
+    constexpr unsigned FAR = 2u * RING * 32u, NEAR = RING * 32u;  // (pair_items: the group two groups ahead, where the stream has one)
+    pair_items<M, 5, 1, PFB, PHASE_FIRST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink, ngroups > 2 ? FAR : NEAR);
     sink.advance(2 * 32);
     for (unsigned long long g = 1; g + 1 < ngroups; ++g) {
         spq += RING * 32;
-        pair_items<M, 5, 1, PFB, PHASE_MAIN, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
+        pair_items<M, 5, 1, PFB, PHASE_MAIN, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink, g + 2 < ngroups ? FAR : NEAR);
         sink.advance(RING * 32);
     }
     if (ngroups > 1) {
         spq += RING * 32;
-        pair_items<M, 5, 1, PFB, PHASE_LAST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink);
+        pair_items<M, 5, 1, PFB, PHASE_LAST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink, 0u);
     }
 }
 
@@ -204,6 +206,7 @@ struct KernelRegistry {
     ScoreC32Launcher (*c32w)[kRegistrySlots];
     PrefilterLauncher *prew;
     ScoreU8Launcher *u8w;
+    PrefilterLauncher *preblk;  // protein one-symbol scan on 4-row symbol blocks (score_prefilter_blk.hpp)
 };
 
 }  // namespace lm

@@ -119,3 +119,74 @@ def test_stripe_and_wrap_write_only_their_rows(pli, cols, length, wrap):
     assert (host[(PAD_ROWS + rows_total) * stride_:] == CANARY_U8).all()
     assert np.array_equal(host[PAD_ROWS * stride_: (PAD_ROWS + rows_total) * stride_].reshape(rows_total, stride_),
                           ref.data)
+
+
+# ---- reads: nothing past the last wrap row ------------------------------------------------------------------
+
+_READ_BOUNDS_CHILD = r'''
+import ctypes as C, sys
+import numpy as np, torch
+import lightmotif_amd as lm
+from oracle import c_oracle as co
+hip = C.CDLL("libamdhip64.so")
+torch.cuda.set_device(0)
+pli = lm.Pipeline.hip(0, stream=torch.cuda.current_stream().cuda_stream)
+PAGE = 2 << 20
+rng = np.random.default_rng(7)
+checked = 0
+for k, m, length in ((5, 20, 3_000_017), (5, 12, 2_000_003), (5, 31, 2_000_003), (5, 3, 1_000_003), (21, 12, 2_000_003), (21, 7, 1_000_003)):
+    enc = rng.integers(0, k - 1, length, dtype=np.uint8)
+    ref = co.stripe(enc, 32, k)
+    co.configure_wrap(ref, m - 1)                         # exactly M - 1 wrap rows: the least the reference asks for (avx2.rs:832-837)
+    data = np.ascontiguousarray(ref.data[:, :32])
+    nbytes = data.size
+    alloc = (nbytes + PAGE - 1) // PAGE * PAGE
+    base = C.c_void_p()
+    assert hip.hipMalloc(C.byref(base), C.c_size_t(alloc)) == 0
+    ptr = base.value + alloc - nbytes                      # the matrix ENDS where the allocation ends
+    ptr -= ptr % 4                                         # (dword-aligned, as every DenseMatrix row is)
+    assert hip.hipMemcpy(C.c_void_p(ptr), data.ctypes.data_as(C.c_void_p), C.c_size_t(nbytes), 1) == 0
+    p = np.zeros((m, co.stride(k, 4)), np.float32)
+    p[:, :k - 1] = rng.normal(0, 2, (m, k - 1))
+    p[:, k - 1] = -np.inf
+    pssm = lm.ScoringMatrix(p, protein=k == 21)
+    rows = ref.rows
+    want, _ = co.score_rows(ref, p)
+    t = float(np.sort(want[:, :32].ravel())[-200])
+    rc = [tuple(map(int, x)) for x in co.threshold(want, 32, t)]
+    args = (pssm, ptr, rows + m - 1, 32, 32, m - 1, length, 0, rows)
+    hits, _ = pli.score_threshold_dptr(*args, t)           # pair scan / block scan: symbol blocks requested ahead of use
+    assert [tuple(map(int, x)) for x in np.asarray(hits).reshape(-1, 2)] == rc, (k, m, pli.last_kernel)
+    assert pli.score_argmax_dptr(*args)[0] == co.argmax(want, 32), (k, m)
+    if k == 5:
+        batch = pli.scan_threshold_batch([pssm, pssm.reverse_complement(), pssm], [t, t, t],
+                                         pli.adopt_sequence(ptr, rows, m - 1, 32, 32, length))   # several motifs per pass
+        assert [tuple(map(int, x)) for x in np.asarray(batch[0][0]).reshape(-1, 2)] == rc
+        dm = pssm.to_discrete()
+        out = torch.empty((rows, 32), dtype=torch.uint8, device="cuda")
+        pli.score_u8_dptr(dm, ptr, rows + m - 1, 32, 32, m - 1, length, 0, rows, out.data_ptr(), 32)   # the u8 store on the pair pipeline
+        torch.cuda.synchronize()
+        w8 = co.aligned_empty((m, 32), np.uint8)
+        w8[:] = dm.data
+        assert np.array_equal(out.cpu().numpy(), co.avx2_score_rows_u8(ref, w8)[:, :32]), (k, m, pli.last_kernel)
+    torch.cuda.synchronize()
+    checked += 1
+    hip.hipFree(base)
+print("READ_BOUNDS_OK", checked)
+'''
+
+
+def test_scans_read_nothing_past_the_last_wrap_row():
+    """The scans request symbol blocks ahead of their use; a request of the group before a stream's last one used to reach
+    128 bytes past the stream's input (round-5 ADVICE: results unaffected, but a matrix ending on an unmapped page boundary
+    could fault).  A matrix with exactly M - 1 wrap rows (avx2.rs:832-837) is placed so that it ends where a raw hipMalloc
+    allocation of whole 2 MB pages ends, and every scan family runs over it -- in a child process, so that a memory fault
+    shows as a failed test and not as a dead test run."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, PYTHONPATH=str(root) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-c", _READ_BOUNDS_CHILD], capture_output=True, text=True, timeout=600, env=env, cwd=str(root))
+    assert r.returncode == 0 and "READ_BOUNDS_OK 6" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])

@@ -178,6 +178,7 @@ def test_whole_matrix_against_the_oracle_at_baseline_sizes(gpu_pli, length, m, k
     finite = first[np.isfinite(first)]
     t = float(np.partition(finite, finite.size - finite.size // 100_000)[finite.size - finite.size // 100_000])
     state = {"best": None, "hits": [], "vals": []}
+    compared = 0
     for a in range(0, rows, chunk):
         b = min(a + chunk, rows)
         want = co.avx2_score_rows(ref, weights, out=buf[:b - a], row_begin=a, row_end=b, threads=threads)
@@ -185,7 +186,9 @@ def test_whole_matrix_against_the_oracle_at_baseline_sizes(gpu_pli, length, m, k
         torch.cuda.synchronize()
         got = pinned[:b - a].numpy()
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"rows {a} ... {b}"
+        compared += got.size
         _generic_reductions_by_chunk(want, a, t, state)
+    assert compared == rows * COLS >= length                          # every cell of the matrix, padded tail included
     want_am = (state["best"][0], float(state["best"][1]))
     want_hits = np.concatenate(state["hits"]).astype(np.int64)
     want_vals = np.concatenate(state["vals"])

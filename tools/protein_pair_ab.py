@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Protein (K = 21) fused scans: the one-symbol prefilter (default) against the 441-row pair scan (option
-"pair_prefilter_protein" = 1), interleaved in one process; 200 Mres.  python tools/protein_pair_ab.py [M ...]"""
+"""Protein (K = 21) fused scans, interleaved in one process over 200 Mres: the one-symbol prefilter on 4-row symbol blocks
+(default, score_prefilter_blk.hpp), the same with a byte load per lane and row (option "block_prefilter" = 0: the round-5
+kernel) and the 441-row pair scan (option "pair_prefilter_protein" = 1).  Call times (median of 5 x 5) and the scan kernel
+alone (option "time_scan").  python tools/protein_pair_ab.py [M ...]"""
 import json
 import sys
 import time
@@ -34,8 +36,9 @@ for m in ms_list:
     thr = pssm.score_for_pvalue(1e-5)
     res = {}
     for rep in range(-1, 5):
-        for flag in (0, 1):
-            pli.set_option("pair_prefilter_protein", flag)
+        for flag in ("blocks", "bytes", "pairs"):
+            pli.set_option("pair_prefilter_protein", int(flag == "pairs"))
+            pli.set_option("block_prefilter", int(flag != "bytes"))
             for name, fn in (("threshold", lambda: pli.score_threshold_dptr(pssm, pseq.data_ptr(), rows + mmax - 1, COLS, COLS, mmax - 1, length, 0, rows, thr)),
                              ("argmax", lambda: pli.score_argmax_dptr(pssm, pseq.data_ptr(), rows + mmax - 1, COLS, COLS, mmax - 1, length, 0, rows))):
                 out = fn()
@@ -48,6 +51,18 @@ for m in ms_list:
                     res.setdefault((name, flag), []).append((time.perf_counter() - t0) / 5 * 1e3)
                 res[(name, flag, "kernel")] = pli.last_kernel
                 res[(name, flag, "n")] = len(out[0]) if name == "threshold" else out[0]
-    print(json.dumps({"m": m, **{f"{n}_{'pair' if f else 'single'}_ms": round(float(np.median(v)), 4) for (n, f, *r), v in res.items() if not r},
-                      "kernels": {f"{n}_{'pair' if f else 'single'}": res[(n, f, "kernel")] for n in ("threshold", "argmax") for f in (0, 1)},
-                      "same_results": res[("threshold", 0, "n")] == res[("threshold", 1, "n")] and res[("argmax", 0, "n")] == res[("argmax", 1, "n")]}), flush=True)
+                if rep == 4:   # the scan kernel alone, events around it on the library's stream
+                    pli.set_option("time_scan", 1)
+                    ks = []
+                    for _ in range(5):
+                        fn()
+                        ks.append(pli.last_scan_kernel_ms or 0.0)
+                    pli.set_option("time_scan", 0)
+                    res[(name, flag, "kernel_ms")] = round(float(np.median(ks)), 4)
+    forms = ("blocks", "bytes", "pairs")
+    print(json.dumps({"m": m, **{f"{n}_{f}_ms": round(float(np.median(v)), 4) for (n, f, *r), v in res.items() if not r},
+                      **{f"{n}_{f}_scan_kernel_ms": res[(n, f, "kernel_ms")] for n in ("threshold", "argmax") for f in forms},
+                      "kernels": {f"{n}_{f}": res[(n, f, "kernel")] for n in ("threshold", "argmax") for f in forms},
+                      "hits": res[("threshold", "blocks", "n")],
+                      "same_results": all(res[("threshold", f, "n")] == res[("threshold", "blocks", "n")] and
+                                          res[("argmax", f, "n")] == res[("argmax", "blocks", "n")] for f in forms)}), flush=True)
