@@ -333,45 +333,61 @@ def at_sustained_clock(mhz: float, lds_bytes_per_s: float, valu_lane_ops_per_s: 
             "valu_model": valu_model + "; 64 lanes/clk/CU x 256 CUs"}
 
 
-def scan_kernel_ms(pli, call, reps: int = 25, warm: int = 40):
+def scan_kernel_ms(pli, call, reps: int = 25, warm: int = 40, phases=None):
     """Median duration of the scan kernel alone inside a fused call: HIP events around it on the library's stream
     (context option "time_scan", lm_hip_ctx_last_scan_kernel_ms) -- measured in calls of their own, not in the timed ones,
-    after `warm` calls (behind a pause the device runs at a lower clock: 0.25 against 0.22 ms)."""
+    after `warm` calls (behind a pause the device runs at a lower clock: 0.25 against 0.22 ms).  `phases` (a dict): filled
+    with the medians of the threshold call's phases (lm_hip_ctx_last_phases_ms)."""
     pli.set_option("time_scan", 1)
     try:
-        ms = []
+        ms, ph = [], []
         for i in range(warm + reps):
             call()
             k = pli.last_scan_kernel_ms
             if k is not None and i >= warm:
                 ms.append(k)
+                p = pli.last_phases_ms
+                if p and p[1] >= 0 and p[2] >= 0:
+                    ph.append(p)
     finally:
         pli.set_option("time_scan", 0)
+    if phases is not None and ph:
+        med = np.median(np.asarray(ph), axis=0)
+        phases.update({"scan_us": round(float(med[0]) * 1e3, 1), "rescore_us": round(float(med[1]) * 1e3, 1),
+                       "order_us": round(float(med[2]) * 1e3, 1), "host_us": round(float(med[3]) * 1e3, 1),
+                       "what": "medians over calls with events recorded (HIP events on the library's stream: scan kernel | exact "
+                               "re-scoring | ordering kernels; host = the C call minus those: enqueueing, the synchronisation's "
+                               "wake-up, the copy of the hits out of the pinned block)"})
     return float(np.median(ms)) if ms else None
 
 
-def fused_roofline(ms: float, rows: int, m: int, kernel: str, mhz: float = 0.0, kernel_ms=None) -> dict:
+def fused_roofline(ms: float, rows: int, m: int, kernel: str, mhz: float = 0.0, kernel_ms=None, scan_info=(0, 0),
+                   timing: str = "minimum of 5 single calls, each between two device synchronisations, after 60 untimed calls") -> dict:
     """A fused score+argmax / score+threshold call over `rows` x 32 positions, whole call on the wall clock (scan, re-scoring,
-    reductions, read-back).  SURVEY 8(d): no score matrix is written, so the binding ceiling is the LDS gather -- here the
-    pair table's (M' | 3) + 1 bytes per position, M' = the rows scanned (score_prefilter2.hpp) against 256 B/clk/CU x 256 CUs x 2.4 GHz; the one
-    byte per position the scan must still read from HBM is reported beside it (`hbm_read_frac`), not as the bound."""
-    # a single scan of M = 20, 24, ... 36 looks M - 1 rows up (drop-last form, csrc/score_threshold.hip): the bytes it reads
-    scanned = m - 1 if (m % 4 == 0 and 20 <= m <= 36) else m
-    row_bytes = (scanned | 3) + 1
+    reductions, read-back).  SURVEY 8(d): no score matrix is written, so the binding ceiling is the LDS gather -- the table
+    bytes per position the scan kernel that RAN looks up (`scan_info` = lm_hip_ctx_last_scan_info: the motif rows it scanned
+    and what they cost; a pair scan reads one row of ((rows | 3) + 1) u16 entries per two positions, the protein block scan a
+    row of prefilter_mp entries per position) against 256 B/clk/CU x 256 CUs x 2.4 GHz; the one byte per position the scan must
+    still read from HBM is reported beside it (`hbm_read_frac`), not as the bound."""
+    scanned, row_bytes = scan_info
+    if not row_bytes:           # (no prefilter / exact scan kernel ran: price the motif's own pair table)
+        scanned, row_bytes = m, (m | 3) + 1
     lds = row_bytes * rows * COLS / (ms * 1e-3)
     ach = rows * COLS / (ms * 1e-3) / 1e9
-    return {"ms": round(ms, 4), "kernel": kernel, "Gpos_s": round(rows * COLS / ms / 1e6, 1),
+    return {"ms": round(ms, 4), "kernel": kernel, "Gpos_s": round(rows * COLS / ms / 1e6, 1), "timing": timing,
+            # what a call spends outside its scan kernel: re-scoring, ordering / reduction of the hit list, the launches'
+            # gaps, the synchronisation, the copy of the results out of the pinned block, the Python wrapper
+            **({"tail_us": round((ms - kernel_ms) * 1e3, 1)} if kernel_ms else {}),
             "roofline": {"bound": "lds", "achieved": round(lds / 1e12, 2), "peak": round(LDS_PEAK_BYTES_PER_S / 1e12, 1),
                          "unit": "TB/s", "frac": round(lds / LDS_PEAK_BYTES_PER_S, 4),
                          "lds_bytes_per_position": row_bytes, "motif_rows_scanned": scanned, "hbm_read_gbs": round(ach, 1),
                          "hbm_read_frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_hbm_bytes_per_call": rows * COLS,
-                         # the scan kernel alone (what the LDS ceiling bounds), without the call's launch-bound tail:
-                         # re-scoring, ordering / reduction of the hit list, read-back (profiles/r05_timeline_fused.txt)
+                         # the scan kernel alone (what the LDS ceiling bounds), without the call's launch-bound tail
                          **({"kernel_ms": round(kernel_ms, 4),
                              "kernel_frac": round(row_bytes * rows * COLS / (kernel_ms * 1e-3) / LDS_PEAK_BYTES_PER_S, 4)}
                             if kernel_ms else {}),
                          # the pair scan's issue per position and lane: (NP + 1) accumulate operations + 6 of decode per
-                         # pair of super-steps = 4 positions (score_prefilter2.hpp), NP = ((M | 3) + 1) / 2
+                         # pair of super-steps = 4 positions (score_prefilter2.hpp), NP = row bytes / 2
                          **at_sustained_clock(mhz, lds, (row_bytes // 2 + 7) / 4 * rows * COLS / (ms * 1e-3),
                                               f"{(row_bytes // 2 + 7) / 4:.2f} VALU operations per position "
                                               "(v_add3_u32 accumulation + register decode of the pair scan)")}}
@@ -601,8 +617,12 @@ def c3_leg(pli, dev, coll_dev, world: int, rank: int, reps: int = 5) -> dict:
             dt = float(t.item())
         return dt
 
+    # the motif list in the form the C ABI takes it, built once (a job loop scans sequence after sequence with the same
+    # motifs, lightmotif-cli main.rs:502-561)
+    prepared = pli.prepare_batch(pssms, ts) if world == 1 else None
+
     def scan():
-        res[0] = (pli.scan_threshold_batch(pssms, ts, seq) if world == 1 else
+        res[0] = (pli.scan_threshold_batch(prepared, None, seq) if world == 1 else
                   D.scan_threshold_batch_sharded(pli, pssms, ts, seq, device=coll_dev, parts=parts))
     t_th = timed(scan, reps)
     k_th = pli.last_kernel
@@ -610,6 +630,29 @@ def c3_leg(pli, dev, coll_dev, world: int, rank: int, reps: int = 5) -> dict:
                           D.scan_argmax_batch_sharded(pli, pssms, seq, device=coll_dev, parts=parts)), reps)
     lengths = c3["lengths"]
     k_am = pli.last_kernel
+    # the threshold batch by phase, from the library's own events (context option "time_scan"; calls of their own, after the
+    # timed ones): scan kernels | exact re-scoring | ordering kernels on the stream, the rest of the call on the host clock
+    phases = None
+    if world == 1:
+        pli.set_option("time_scan", 1)
+        try:
+            rec = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                scan()
+                ph = pli.last_phases_ms
+                if ph:
+                    rec.append(list(ph) + [(time.perf_counter() - t0) * 1e3])
+            if rec:
+                med = np.median(np.asarray(rec), axis=0)
+                phases = {"scan_ms": round(float(med[0]), 3), "rescore_ms": round(float(med[1]), 3), "order_ms": round(float(med[2]), 3),
+                          "host_ms": round(float(med[3]), 3), "python_call_ms": round(float(med[4]), 3),
+                          "scan_frac_of_lds_ceiling": round(c3["lds_bytes"] / (float(med[0]) * 1e-3) / LDS_PEAK_BYTES_PER_S, 4),
+                          "what": "medians of 3 calls with events recorded; host_ms = the C call minus the three event spans "
+                                  "(enqueueing ~50 launches, the synchronisation, the copy of the hit lists out of the pinned block); "
+                                  "python_call_ms adds the wrapper (per-motif numpy views)"}
+        finally:
+            pli.set_option("time_scan", 0)
     realistic = None
     if world == 1:
         # the same batch on a NON-i.i.d. sequence of the same length (5 % N in runs, microsatellites / homopolymers, 35 % /
@@ -623,7 +666,7 @@ def c3_leg(pli, dev, coll_dev, world: int, rank: int, reps: int = 5) -> dict:
         rres = [None]
 
         def rscan():
-            rres[0] = pli.scan_threshold_batch(pssms, ts, rseq)
+            rres[0] = pli.scan_threshold_batch(prepared, None, rseq)
         rt_th = timed(rscan, max(reps - 1, 2))
         rhits, rcands = pli.last_scan_counts
         rt_am = timed(lambda: pli.scan_argmax_batch(pssms, rseq), max(reps - 1, 2))
@@ -644,6 +687,7 @@ def c3_leg(pli, dev, coll_dev, world: int, rank: int, reps: int = 5) -> dict:
             "motifs_skipped_unreachable": len(c3["unreachable"]),
             "hits_total": int(sum(len(c) for c, _ in res[0])), "kernel": k_th,
             "roofline": lds_roofline(c3["lds_bytes"], t_th, C3_LDS_MODEL),
+            **({"phases": phases} if phases else {}),
             "fused_argmax_ms": round(t_am * 1e3, 3), "fused_argmax_kernel": k_am,
             **({"realistic": realistic} if realistic else {})}
 
@@ -778,11 +822,16 @@ def secondary_configs(pli, dev) -> dict:
     sample = pout[: 1 << 18].flatten()
     thr = float(torch.quantile(sample[torch.isfinite(sample)].float(), 1 - 1e-5))
     fth = lambda: pli.score_threshold_dptr(ppssm, pseq.data_ptr(), rows + m - 1, COLS, COLS, m - 1, length, 0, rows, thr)  # noqa: E731
-    t_th = wall(fth, 20)
-    k_th = pli.last_kernel
+    t_th = wall(fth, 20, warm=40)
+    k_th, i_th = pli.last_kernel, pli.last_scan_info
     n_hits = len(fth()[0])
+    ph_th = {}
+    km_th = scan_kernel_ms(pli, fth, phases=ph_th)
     fam = lambda: pli.score_argmax_dptr(ppssm, pseq.data_ptr(), rows + m - 1, COLS, COLS, m - 1, length, 0, rows)  # noqa: E731
-    t_am = wall(fam, 20)
+    t_am = wall(fam, 20, warm=40)
+    k_am, i_am = pli.last_kernel, pli.last_scan_info
+    km_am = scan_kernel_ms(pli, fam)
+    c5_timing = "median of 20 single calls, each followed by a device synchronisation, after 40 untimed calls"
     out["c5"] = {"workload": "configs[4]: protein (K = 21) len-12 PSSM x 200 Mres, score() materialised",
                  "kernel": k_store, "kernel_ms": round(kms, 4), "Gpos_per_s": round(rows * COLS / kms / 1e6, 1),
                  "hbm_frac": round(BYTES_PER_POS * rows * COLS / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -792,7 +841,12 @@ def secondary_configs(pli, dev) -> dict:
                               "algorithmic_bytes_per_launch": BYTES_PER_POS * rows * COLS,
                               "lds_frac": round(4 * m * rows * COLS / (kms * 1e-3) / LDS_PEAK_BYTES_PER_S, 4)},
                  "fused_threshold_ms": round(t_th * 1e3, 4), "fused_threshold_kernel": k_th, "fused_threshold_hits": n_hits,
-                 "fused_argmax_ms": round(t_am * 1e3, 4), "fused_argmax_kernel": pli.last_kernel}
+                 "fused_argmax_ms": round(t_am * 1e3, 4), "fused_argmax_kernel": k_am,
+                 # the fused scans against the LDS-gather ceiling at the table bytes their kernel reads per residue
+                 # (score_prefilter_blk.hpp: a row of prefilter_mp u16 entries per step), call and kernel alone
+                 "fused_threshold": {**fused_roofline(t_th * 1e3, rows, m, k_th, 0.0, km_th, i_th, c5_timing),
+                                     **({"phases": ph_th} if ph_th else {})},
+                 "fused_argmax": fused_roofline(t_am * 1e3, rows, m, k_am, 0.0, km_am, i_am, c5_timing)}
     del pseq, pout
 
     # --- configs[2]: the 2 346 JASPAR 2024 CORE matrices x 100 Mbp, fused threshold at p = 1e-5 per motif
@@ -1046,7 +1100,7 @@ def main() -> None:
     am_ms, am = timed(lambda: pli.argmax_dptr(sc_ptr, rows, COLS, COLS, first_cell_rule=rank == 0))
     fam_ms, fam = timed(lambda: pli.score_argmax_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS,
                                                       m - 1, total_length, 0, rows, first_cell_rule=rank == 0), warm=60)
-    fam_kernel = pli.last_kernel
+    fam_kernel, fam_info = pli.last_kernel, pli.last_scan_info
     assert am == fam, (am, fam)
     mg_ms, best = timed(lambda: D.merge_argmax(am, row0, device=coll_dev))
     if merged is not None:
@@ -1061,12 +1115,13 @@ def main() -> None:
     th_ms, hits = timed(lambda: pli.threshold_dptr(sc_ptr, rows, COLS, COLS, thr_t), reps=5)
     fth_ms, fhits = timed(lambda: pli.score_threshold_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS,
                                                           m - 1, total_length, 0, rows, thr_t), reps=5, warm=60)
-    fth_kernel = pli.last_kernel
+    fth_kernel, fth_info = pli.last_kernel, pli.last_scan_info
     assert np.array_equal(hits, fhits[0]), "fused threshold differs from materialised threshold"
     fam_kms = scan_kernel_ms(pli, lambda: pli.score_argmax_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS, m - 1,
                                                                  total_length, 0, rows))
+    fth_phases = {}
     fth_kms = scan_kernel_ms(pli, lambda: pli.score_threshold_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS, m - 1,
-                                                                    total_length, 0, rows, thr_t))
+                                                                    total_length, 0, rows, thr_t), phases=fth_phases)
     fam_mhz, _ = sustained_clock(lambda: pli.score_argmax_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS, m - 1,
                                                                total_length, 0, rows, first_cell_rule=rank == 0))
     fth_mhz, _ = sustained_clock(lambda: pli.score_threshold_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS, m - 1,
@@ -1170,8 +1225,9 @@ def main() -> None:
             "kernel_ms_min": round(min(kernel_ms), 4), "kernel_ms_max": round(max(kernel_ms), 4),
             # the fused forms never write the score matrix -- priced against the LDS-gather ceiling (the pair
             # table's (M | 3) + 1 bytes per position), the 1 B per position of HBM reads beside it
-            "fused_score_argmax": fused_roofline(fam_ms, rows, m, fam_kernel, fam_mhz, fam_kms),
-            "fused_score_threshold": fused_roofline(fth_ms, rows, m, fth_kernel, fth_mhz, fth_kms),
+            "fused_score_argmax": fused_roofline(fam_ms, rows, m, fam_kernel, fam_mhz, fam_kms, fam_info),
+            "fused_score_threshold": {**fused_roofline(fth_ms, rows, m, fth_kernel, fth_mhz, fth_kms, fth_info),
+                                      **({"phases": fth_phases} if fth_phases else {})},
             "merge_threshold_ms_torch": round(mt_torch_ms, 4),
             "merge_us": (None if not rank_merge else
                          {"p50": round(float(np.median([x[0] for x in rank_merge])), 1),

@@ -170,6 +170,16 @@ int lm_hip_ctx_last_scan_counts(lm_hip_ctx *ctx, unsigned long long *hits, unsig
  * the re-scoring, the ordering of the hit list and the read-back behind it (bench.py: roofline.kernel_frac of the fused
  * blocks).  -1 when the option is off or the call took a route without a scan kernel. */
 int lm_hip_ctx_last_scan_kernel_ms(lm_hip_ctx *ctx, float *ms);
+/* Diagnostic ("time_scan" = 1): the last fused THRESHOLD call (single or batched) by phase, in ms -- [0] the scan kernels,
+ * [1] the exact re-scoring of their candidates, [2] the kernels that order the hit list (HIP events on the context's
+ * stream), [3] the rest of the call on the host clock: enqueueing, the synchronisation's wake-up, the copy of the results
+ * out of the pinned block.  -1 where nothing was recorded. */
+int lm_hip_ctx_last_phases_ms(lm_hip_ctx *ctx, float phases[4]);
+/* Diagnostic: what the scan kernel of the last SINGLE-job fused call on this context looked up per position -- the motif
+ * rows it scanned (a pair scan of M = 20, 24, ... 36 may look M - 1 rows up and credit the last one with its best weight)
+ * and the bytes of LDS table that costs (what a roofline figure must be priced against).  Zeros: no such scan ran (a batch,
+ * an argmax settled from the last rows, a chunked route).  Either pointer may be NULL. */
+int lm_hip_ctx_last_scan_info(lm_hip_ctx *ctx, size_t *motif_rows_scanned, size_t *lds_bytes_per_position);
 
 /* ---- PSSM ---------------------------------------------------------------- */
 
@@ -611,6 +621,24 @@ typedef enum lm_hip_host_op {
 } lm_hip_host_op;
 /* m = motif length (0 where it plays no part), k = alphabet size.  LM_HIP_ERR_BAD_ARGS for an unknown op. */
 int lm_hip_host_crossover(int op, size_t m, size_t k, size_t *cells);
+/* The reference picks its back-end per HOST, at run time (pli/mod.rs:269-308); so does the policy.  The model behind
+ * lm_hip_host_crossover is  GPU call ~ t0 + g x cells,  CPU tier ~ (c + c_row x M) x cells,  crossover = t0 / (c + c_row M - g)
+ * (never while the tier costs less than 1.25 x the link per cell).  The compiled constants are one box's (EPYC 9575F, PCIe
+ * Gen5); these calls replace them with this process's own:
+ *   lm_hip_host_calibrate   measures the GPU side (t0, g) of every site that can leave the tier by timing the host-pointer
+ *                           entry points themselves on synthetic matrices (8 192 and 4 Mi cells), within ~budget_ms in total
+ *                           (a few tens of milliseconds suffice).  Once per process unless `force`; thread-safe.
+ *   lm_hip_host_set_cpu_cost  the CPU tier's side, which only the caller can time (its tier is Rust code the library never
+ *                           sees): ns per cell, and ns per cell and motif row (0 where M plays no part).
+ *   lm_hip_host_set_crossover pins the answer for a site whatever M (SIZE_MAX = never the GPU, 0 = always); (size_t)-2
+ *                           (LM_HIP_CROSSOVER_MODEL) unpins it.
+ *   lm_hip_host_cost_model  reads the constants in force and whether the GPU side was measured here.  Pointers may be NULL. */
+#define LM_HIP_CROSSOVER_MODEL ((size_t)-2)
+int lm_hip_host_calibrate(double budget_ms, int force);
+int lm_hip_host_set_cpu_cost(int op, double ns_per_cell, double ns_per_cell_and_motif_row);
+int lm_hip_host_set_crossover(int op, size_t cells);
+int lm_hip_host_cost_model(int op, double *t0_us, double *gpu_ns_per_cell, double *cpu_ns_per_cell, double *cpu_ns_per_cell_and_motif_row,
+                           int *gpu_side_measured);
 
 /* Hands back what the host-pointer functions keep between calls: the pinned rings of the tile pipelines (128 MB of
  * page-locked memory per device used), their device tiles, and the device staging AND reduction scratch of this thread's

@@ -40,6 +40,7 @@ class InvalidSymbol(ValueError):
 
 _sz = C.c_size_t
 _vp = C.c_void_p
+_dp = C.POINTER(C.c_double)
 _szp = C.POINTER(C.c_size_t)
 _ip = C.POINTER(C.c_int)
 _fp = C.POINTER(C.c_float)
@@ -68,6 +69,8 @@ SIGNATURES = {
     "lm_hip_ctx_last_kernel": (C.c_char_p, [_vp]),
     "lm_hip_ctx_last_scan_counts": (C.c_int, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "lm_hip_ctx_last_scan_kernel_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "lm_hip_ctx_last_phases_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "lm_hip_ctx_last_scan_info": (C.c_int, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "lm_hip_pssm_create": (C.c_int, [_vp, _vp, _sz, _sz, _sz, C.POINTER(_vp)]),
     "lm_hip_pssm_reverse_complement": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
     "lm_hip_pssm_destroy": (C.c_int, [_vp]),
@@ -141,6 +144,10 @@ SIGNATURES = {
     "lm_hip_scan_max_f32_host": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _sz, _vp, _sz, _sz, _sz, _vp, _sz, C.c_int, C.c_uint, C.c_int,
                                            _sz, C.c_float, _sz, _ip, C.POINTER(Hit)]),
     "lm_hip_host_crossover": (C.c_int, [C.c_int, _sz, _sz, _szp]),
+    "lm_hip_host_calibrate": (C.c_int, [C.c_double, C.c_int]),
+    "lm_hip_host_set_cpu_cost": (C.c_int, [C.c_int, C.c_double, C.c_double]),
+    "lm_hip_host_set_crossover": (C.c_int, [C.c_int, C.c_size_t]),
+    "lm_hip_host_cost_model": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, C.POINTER(C.c_int)]),
     "lm_hip_host_trim": (C.c_int, []),
     "lm_hip_host_bind_thread": (C.c_int, [C.c_int]),
     "lm_hip_host_spread_lanes": (C.c_int, [C.c_int]),

@@ -562,6 +562,28 @@ int lm_hip_ctx_last_scan_counts(lm_hip_ctx *ctx, unsigned long long *hits, unsig
     return LM_HIP_OK;
 }
 
+int lm_hip_ctx_last_phases_ms(lm_hip_ctx *ctx, float phases[4])
+{
+    if (!ctx || !phases)
+        return fail(LM_HIP_ERR_BAD_ARGS, "ctx_last_phases_ms: null argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    for (int i = 0; i < 4; ++i)
+        phases[i] = ctx->last_phase_ms[i];
+    return LM_HIP_OK;
+}
+
+int lm_hip_ctx_last_scan_info(lm_hip_ctx *ctx, size_t *motif_rows_scanned, size_t *lds_bytes_per_position)
+{
+    if (!ctx || (!motif_rows_scanned && !lds_bytes_per_position))
+        return fail(LM_HIP_ERR_BAD_ARGS, "ctx_last_scan_info: null argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (motif_rows_scanned)
+        *motif_rows_scanned = ctx->last_scan_rows;
+    if (lds_bytes_per_position)
+        *lds_bytes_per_position = ctx->last_scan_lds_bytes;
+    return LM_HIP_OK;
+}
+
 int lm_hip_ctx_last_scan_kernel_ms(lm_hip_ctx *ctx, float *ms)
 {
     if (!ctx || !ms)

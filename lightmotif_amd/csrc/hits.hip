@@ -594,6 +594,7 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
     LM_HIP_TRY(hipGetLastError());
     }
 
+    scan_timer_mark(ctx, st, 3);  // (time_scan) behind the ordering kernels
     if (speculative) {
         LM_HIP_TRY(hipStreamSynchronize(st));
         if (short_form)

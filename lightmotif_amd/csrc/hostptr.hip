@@ -34,6 +34,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cctype>
 #include <condition_variable>
 #include <cstdio>
@@ -1191,9 +1192,32 @@ constexpr HostCost kCostThresholdF32{63.0, 0.073, 0.252, 0.0};   // 4 B up; the 
 // Scanner: t0 and g measured (tests/cpp/test_dispatch --bench -> profiles/r05_scan_crossover.json: 29 us at 10 kbp, 41 at
 // 100 kbp, 78 at 1 Mbp with the short form of the hit-list ordering; 46 / 49 / 85 before it); the CPU side is the reference's block loop on its AVX2 tier, PRICED from the u8 shuffle kernel + one pass of the
 // vectorised u8 reductions -- the C++ port that stands in for it in the tests has scalar reductions (0.54 ns per cell: it
-// crosses over at ~85 k cells); a Rust build should re-measure with its own tier (HipPolicy::force).
+// crosses over at ~85 k cells); a Rust build should re-measure with its own tier (lm_hip_host_set_cpu_cost).
 constexpr HostCost kCostScan{38.0, 0.044, 0.03, 0.0071};
 constexpr double kCrossoverMargin = 1.25;  // the CPU must cost this much more per cell than the link before a call leaves it
+constexpr int kOps = 9;
+constexpr size_t kModel = (size_t)-2;      // lm_hip_host_set_crossover: "no pin, ask the model"
+
+// The model in force: the compiled constants (one EPYC 9575F + PCIe Gen5 box) until lm_hip_host_calibrate measures the GPU side
+// on THIS host and link, and lm_hip_host_set_cpu_cost the CPU tier's side; per-op pins on top (lm_hip_host_set_crossover).
+struct CostTable {
+    std::mutex mu;
+    HostCost cost[kOps] = {{}, kCostScoreF32, kCostScoreU8, {}, kCostMaximumF32, {}, kCostThresholdF32, {}, kCostScan};
+    bool gpu_measured[kOps] = {};
+    bool cpu_set[kOps] = {};
+    size_t pin[kOps] = {kModel, kModel, kModel, kModel, kModel, kModel, kModel, kModel, kModel};
+    bool calibrated = false;
+};
+CostTable &cost_table()
+{
+    static CostTable *t = new CostTable();
+    return *t;
+}
+bool leaves_cpu_tier(int op)
+{
+    return op == LM_HIP_OP_SCORE_F32 || op == LM_HIP_OP_SCORE_U8 || op == LM_HIP_OP_MAXIMUM_F32 || op == LM_HIP_OP_THRESHOLD_F32 ||
+           op == LM_HIP_OP_SCAN;
+}
 size_t crossover_cells(const HostCost &k, size_t m)
 {
     const double c = k.cpu_ns + k.cpu_ns_per_row * (double)m;
@@ -1202,6 +1226,19 @@ size_t crossover_cells(const HostCost &k, size_t m)
     const double cells = k.t0_us * 1e3 / (c - k.gpu_ns);
     return cells >= 9e18 ? SIZE_MAX : (size_t)cells + 1;
 }
+
+// median wall time (us) of `reps` calls of f
+double median_us(const std::function<void()> &f, int reps)
+{
+    std::vector<double> t;
+    for (int i = 0; i < reps; ++i) {
+        const auto a = std::chrono::steady_clock::now();
+        f();
+        t.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count());
+    }
+    std::sort(t.begin(), t.end());
+    return t[t.size() / 2];
+}
 }  // namespace
 
 int lm_hip_host_crossover(int op, size_t m, size_t k, size_t *cells)
@@ -1209,31 +1246,160 @@ int lm_hip_host_crossover(int op, size_t m, size_t k, size_t *cells)
     (void)k;
     if (!cells)
         return fail(LM_HIP_ERR_BAD_ARGS, "host_crossover: null output");
-    switch (op) {
-    case LM_HIP_OP_ENCODE:         // one LUT pass over bytes: a core streams them faster than the link carries them
-    case LM_HIP_OP_STRIPE:         // (1 B up + 1 B down); resident sequences are made by lm_hip_seq_from_ascii / _encoded
-    case LM_HIP_OP_MAXIMUM_U8:     // Scanner-internal (scan.rs:181-184): specialised away by LM_HIP_OP_SCAN
-    case LM_HIP_OP_THRESHOLD_U8:
-        *cells = SIZE_MAX;
-        return LM_HIP_OK;
-    case LM_HIP_OP_SCORE_F32:      // 1 B up + 4 B down per cell; AVX2: ~0.031 ns per cell and motif row
-        *cells = crossover_cells(kCostScoreF32, m);
-        return LM_HIP_OK;
-    case LM_HIP_OP_SCORE_U8:       // 1 B up + 1 B down; AVX2 shuffle kernel: ~0.007 ns per cell and motif row
-        *cells = crossover_cells(kCostScoreU8, m);
-        return LM_HIP_OK;
-    case LM_HIP_OP_MAXIMUM_F32:    // 4 B up per cell against the Generic scan (the rule the variant must keep: pli/mod.rs:135-160)
-        *cells = crossover_cells(kCostMaximumF32, 0);
-        return LM_HIP_OK;
-    case LM_HIP_OP_THRESHOLD_F32:  // 4 B up per cell against the default body (pli/mod.rs:210-221)
-        *cells = crossover_cells(kCostThresholdF32, 0);
-        return LM_HIP_OK;
-    case LM_HIP_OP_SCAN:           // 1 B up per cell + the scan, against the reference's block loop on the AVX2 tier
-        *cells = crossover_cells(kCostScan, m);
-        return LM_HIP_OK;
-    default:
+    if (op < 0 || op >= kOps)
         return fail(LM_HIP_ERR_BAD_ARGS, "host_crossover: unknown operation %d", op);
+    CostTable &t = cost_table();
+    std::lock_guard<std::mutex> lock(t.mu);
+    if (t.pin[op] != kModel) {
+        *cells = t.pin[op];
+        return LM_HIP_OK;
     }
+    // Encode / Stripe: one pass over bytes a core streams faster than the link carries them (1 B up + 1 B down); resident
+    // sequences are made by lm_hip_seq_from_ascii / _encoded.  Maximum / Threshold on u8: Scanner-internal (scan.rs:181-184),
+    // specialised away by LM_HIP_OP_SCAN.  The others: the model (Score: 1 B up + 4 / 1 B down per cell against ~0.031 / 0.007
+    // ns per cell and motif row of the AVX2 kernels; reductions: 4 B up against one pass; Scanner: 1 B up + the scan against
+    // the reference's block loop).
+    *cells = leaves_cpu_tier(op) ? crossover_cells(t.cost[op], m) : SIZE_MAX;
+    return LM_HIP_OK;
+}
+
+int lm_hip_host_cost_model(int op, double *t0_us, double *gpu_ns_per_cell, double *cpu_ns_per_cell, double *cpu_ns_per_cell_row,
+                           int *gpu_side_measured)
+{
+    if (op < 0 || op >= kOps)
+        return fail(LM_HIP_ERR_BAD_ARGS, "host_cost_model: unknown operation %d", op);
+    if (!t0_us && !gpu_ns_per_cell && !cpu_ns_per_cell && !cpu_ns_per_cell_row && !gpu_side_measured)
+        return fail(LM_HIP_ERR_BAD_ARGS, "host_cost_model: no output asked for");
+    CostTable &t = cost_table();
+    std::lock_guard<std::mutex> lock(t.mu);
+    if (t0_us) *t0_us = t.cost[op].t0_us;
+    if (gpu_ns_per_cell) *gpu_ns_per_cell = t.cost[op].gpu_ns;
+    if (cpu_ns_per_cell) *cpu_ns_per_cell = t.cost[op].cpu_ns;
+    if (cpu_ns_per_cell_row) *cpu_ns_per_cell_row = t.cost[op].cpu_ns_per_row;
+    if (gpu_side_measured) *gpu_side_measured = t.gpu_measured[op];
+    return LM_HIP_OK;
+}
+
+int lm_hip_host_set_cpu_cost(int op, double ns_per_cell, double ns_per_cell_row)
+{
+    if (op < 0 || op >= kOps || !leaves_cpu_tier(op))
+        return fail(LM_HIP_ERR_BAD_ARGS, "host_set_cpu_cost: operation %d has no cost model (it stays on the CPU tier)", op);
+    if (!(ns_per_cell >= 0) || !(ns_per_cell_row >= 0) || ns_per_cell > 1e6 || ns_per_cell_row > 1e6)
+        return fail(LM_HIP_ERR_BAD_ARGS, "host_set_cpu_cost: costs must be finite and >= 0");
+    CostTable &t = cost_table();
+    std::lock_guard<std::mutex> lock(t.mu);
+    t.cost[op].cpu_ns = ns_per_cell;
+    t.cost[op].cpu_ns_per_row = ns_per_cell_row;
+    t.cpu_set[op] = true;
+    return LM_HIP_OK;
+}
+
+int lm_hip_host_set_crossover(int op, size_t cells)
+{
+    if (op < 0 || op >= kOps)
+        return fail(LM_HIP_ERR_BAD_ARGS, "host_set_crossover: unknown operation %d", op);
+    CostTable &t = cost_table();
+    std::lock_guard<std::mutex> lock(t.mu);
+    t.pin[op] = cells;  // (size_t)-2 = back to the model
+    return LM_HIP_OK;
+}
+
+int lm_hip_host_calibrate(double budget_ms, int force)
+{
+    return guarded("host_calibrate", [&]() -> int {
+        if (!(budget_ms > 0))
+            return fail(LM_HIP_ERR_BAD_ARGS, "host_calibrate: the budget must be positive");
+        CostTable &t = cost_table();
+        {
+            std::lock_guard<std::mutex> lock(t.mu);
+            if (t.calibrated && !force)
+                return LM_HIP_OK;
+        }
+        // Synthetic host matrices in the reference's layouts (dense.rs:43-48): a striped DNA sequence of `big` rows (+ wrap),
+        // a length-16 PSSM, a DiscreteMatrix, a score matrix.  Two sizes per site: a small call is ~t0, the difference to a
+        // large one the per-cell cost.  Every site gets a fifth of the budget.
+        const size_t m = 16, wrap = m - 1, small_rows = 256, big_rows = (size_t)1 << 17;  // 8 192 and 4 Mi cells
+        std::vector<uint8_t> seq((big_rows + wrap) * 32);
+        uint64_t x = 0x5EED0006u;
+        for (uint8_t &b : seq) {
+            x = x * 6364136223846793005ull + 1442695040888963407ull;
+            b = (uint8_t)((x >> 33) & 3u);
+        }
+        std::vector<float> pssm(m * 8, 0.0f), scores(big_rows * 32);
+        std::vector<uint8_t> dw(m * 32, 0), u8out(big_rows * 32);
+        for (size_t j = 0; j < m; ++j)
+            for (size_t sy = 0; sy < 4; ++sy) {
+                pssm[j * 8 + sy] = (float)((int)((j * 7 + sy * 3) % 9) - 4) * 0.37f;
+                dw[j * 32 + sy] = (uint8_t)((j * 5 + sy * 3) % 12);
+            }
+        for (size_t j = 0; j < m; ++j)
+            pssm[j * 8 + 4] = -INFINITY;
+        const auto deadline_per_site = budget_ms * 1e3 / 5.0;  // us
+        struct Probe {
+            int op;
+            std::function<int(size_t rows)> call;
+        };
+        size_t orow = 0, mi = 0;
+        int found = 0;
+        lm_hip_coords best;
+        float val = 0;
+        const float thr = 1e30f;  // nothing passes: the threshold call's list stays empty (its cost is the pass)
+        std::vector<Probe> probes;
+        probes.push_back({LM_HIP_OP_SCORE_F32, [&](size_t rows) {
+                              return lm_hip_score_f32(seq.data(), rows + wrap, 32, 32, wrap, rows * 32, pssm.data(), m, 8, 5, 0, rows, scores.data(), 32,
+                                                      &orow, &mi);
+                          }});
+        probes.push_back({LM_HIP_OP_SCORE_U8, [&](size_t rows) {
+                              return lm_hip_score_u8_host(seq.data(), rows + wrap, 32, 32, wrap, rows * 32, dw.data(), m, 32, 5, 0, rows, 1,
+                                                          u8out.data(), 32, &orow, &mi);
+                          }});
+        probes.push_back({LM_HIP_OP_MAXIMUM_F32, [&](size_t rows) { return lm_hip_argmax_f32(scores.data(), rows, 32, 32, &found, &best, &val); }});
+        probes.push_back({LM_HIP_OP_THRESHOLD_F32, [&](size_t rows) {
+                              lm_hip_coords *c = nullptr;
+                              size_t n = 0;
+                              const int st = lm_hip_threshold_f32(scores.data(), rows, 32, 32, thr, &c, &n);
+                              lm_hip_free(c);
+                              return st;
+                          }});
+        probes.push_back({LM_HIP_OP_SCAN, [&](size_t rows) {
+                              lm_hip_hit *h = nullptr;
+                              size_t n = 0;
+                              const int st = lm_hip_scan_f32_host(seq.data(), rows + wrap, 32, 32, wrap, rows * 32, pssm.data(), m, 8, 5, thr, &h, &n);
+                              lm_hip_free(h);
+                              return st;
+                          }});
+        HostCost measured[kOps] = {};
+        bool ok[kOps] = {};
+        for (const Probe &p : probes) {
+            int st = p.call(small_rows);  // first call: lane, PSSM cache, staging
+            if (st == LM_HIP_OK)
+                st = p.call(big_rows);
+            if (st != LM_HIP_OK)
+                return st;
+            const auto t_begin = std::chrono::steady_clock::now();
+            auto spent = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
+            const double t_small = median_us([&] { (void)p.call(small_rows); }, 15);
+            const double one_big = median_us([&] { (void)p.call(big_rows); }, 1);
+            int reps = (int)std::max(1.0, std::min(9.0, (deadline_per_site - spent()) / std::max(one_big, 1.0)));
+            const double t_big = std::min(one_big, median_us([&] { (void)p.call(big_rows); }, reps));
+            const double cells_small = (double)small_rows * 32, cells_big = (double)big_rows * 32;
+            double g = (t_big - t_small) * 1e3 / (cells_big - cells_small);  // ns per cell
+            if (!(g > 0))
+                g = 0.001;
+            measured[p.op].gpu_ns = g;
+            measured[p.op].t0_us = std::max(t_small - g * cells_small * 1e-3, 1.0);
+            ok[p.op] = true;
+        }
+        std::lock_guard<std::mutex> lock(t.mu);
+        for (int op = 0; op < kOps; ++op)
+            if (ok[op]) {
+                t.cost[op].t0_us = measured[op].t0_us;
+                t.cost[op].gpu_ns = measured[op].gpu_ns;
+                t.gpu_measured[op] = true;
+            }
+        t.calibrated = true;
+        return LM_HIP_OK;
+    });
 }
 
 }  // extern "C"

@@ -115,9 +115,16 @@ struct lm_hip_ctx {
     bool speculate_order = true; // fused threshold: order the hit list before the host knows its length
     bool sort_hits = true;       // ... long lists by radix sort instead of the bucket passes (hits.hip; option "sort_hits")
     bool time_scan = false;      // diagnostic (option "time_scan"): events around the scan kernel(s) of a fused call -> last_scan_kernel_ms
-    hipEvent_t scan_ev[2] = {nullptr, nullptr};
+    hipEvent_t scan_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // before the scans | behind them | behind the re-scoring | behind the ordering
     bool scan_timed = false;
+    int scan_marks = 0;          // events 2 ... recorded in this call
     float last_scan_kernel_ms = -1.0f;
+    // (time_scan) the last fused threshold call by phase: scan kernels, re-scoring, ordering kernels (events on the stream),
+    // and the host's share behind the synchronisation (copy out of the pinned block, allocation) -- lm_hip_ctx_last_phases_ms
+    float last_phase_ms[4] = {-1.0f, -1.0f, -1.0f, -1.0f};
+    // what the scan of the last single-job fused call looked up per position (lm_hip_ctx_last_scan_info): motif rows and
+    // bytes of LDS table; 0 = no scan kernel of the prefilter / exact families ran (a batch, the suffix route, chunks)
+    unsigned last_scan_rows = 0, last_scan_lds_bytes = 0;
     bool drop_last = true;       // single pair scans of M = 20, 24, ... 36 over M - 1 rows (option "drop_last"; lm_hip_pssm::d_image2_drop)
     bool short_order = true;     // ... short lists of one job counted by the re-scoring kernel, two launches behind it (hits.hip; option "short_order")
     bool suffix_argmax = true;   // fused argmax of short motifs: try the last rows first (score_argmax.hip)
@@ -142,6 +149,9 @@ inline int scan_timer_begin(lm_hip_ctx *ctx, hipStream_t st)
 {
     ctx->last_scan_kernel_ms = -1.0f;
     ctx->scan_timed = false;
+    ctx->scan_marks = 0;
+    for (float &x : ctx->last_phase_ms)
+        x = -1.0f;
     if (!ctx->time_scan)
         return 0;
     for (hipEvent_t &e : ctx->scan_ev)
@@ -155,11 +165,22 @@ inline void scan_timer_end(lm_hip_ctx *ctx, hipStream_t st)
     if (ctx->scan_timed)
         ctx->scan_timed = hipEventRecord(ctx->scan_ev[1], st) == hipSuccess;
 }
+// a further mark behind what has been enqueued so far: which = 2 (re-scoring done), 3 (ordering kernels done)
+inline void scan_timer_mark(lm_hip_ctx *ctx, hipStream_t st, int which)
+{
+    if (ctx->scan_timed && which == ctx->scan_marks + 2 && hipEventRecord(ctx->scan_ev[which], st) == hipSuccess)
+        ctx->scan_marks = which - 1;
+}
 inline void scan_timer_read(lm_hip_ctx *ctx)  // the stream has been synchronised
 {
     float ms = -1.0f;
-    if (ctx->scan_timed && hipEventElapsedTime(&ms, ctx->scan_ev[0], ctx->scan_ev[1]) == hipSuccess)
+    if (ctx->scan_timed && hipEventElapsedTime(&ms, ctx->scan_ev[0], ctx->scan_ev[1]) == hipSuccess) {
         ctx->last_scan_kernel_ms = ms;
+        ctx->last_phase_ms[0] = ms;
+        for (int i = 1; i <= ctx->scan_marks; ++i)
+            if (hipEventElapsedTime(&ms, ctx->scan_ev[i], ctx->scan_ev[i + 1]) == hipSuccess)
+                ctx->last_phase_ms[i] = ms;
+    }
     ctx->scan_timed = false;
 }
 }  // namespace lm

@@ -135,6 +135,11 @@ static int launch_score_argmax_exact(lm_hip_ctx *ctx, const ScoreArgs *jobs, siz
     const std::vector<JobGroup> groups = group_jobs(ctx, jobs, n, [&](size_t i) {
         return plan_c32(ctx, jobs[i], false).ok ? KIND_EXACT : chunked_ok(ctx, jobs[i]) ? KIND_CHUNKED : KIND_GENERIC;
     });
+    ctx->last_scan_rows = ctx->last_scan_lds_bytes = 0;
+    if (n == 1 && groups.size() == 1 && groups[0].kind == KIND_EXACT) {
+        ctx->last_scan_rows = (unsigned)jobs[0].pssm->m;
+        ctx->last_scan_lds_bytes = scan_lds_bytes(KIND_EXACT, exact_motif(jobs[0].pssm, jobs[0].d_seq).m, jobs[0].pssm->k);
+    }
     std::vector<unsigned> grids(n);
     size_t total_blocks = 0;
     for (const JobGroup &g : groups)
@@ -666,6 +671,12 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
     const bool drop_last_form = drop_plan.ok;
     if (drop_last_form)
         sjobs[0].td_drop = qjobs[0].pssm->drop_dmax;
+    ctx->last_scan_rows = ctx->last_scan_lds_bytes = 0;
+    if (nq == 1 && groups.size() == 1) {
+        const size_t scanned = qjobs[0].pssm->m - (drop_last_form ? 1 : 0);
+        ctx->last_scan_lds_bytes = scan_lds_bytes(groups[0].kind, scanned, qjobs[0].pssm->k);
+        ctx->last_scan_rows = (unsigned)scanned;
+    }
     std::vector<BatchParams> bparams;  // launch order; rjobs / sjobs are permuted the same way
     // positions in launch order; groups of the pair scan with several jobs run `per_pass[g]`
     // motifs per pass and are padded to a multiple of that (a padding position samples nothing,

@@ -391,6 +391,81 @@ __device__ __forceinline__ unsigned quad_symbol(unsigned block_dword, unsigned s
     return (x >> shift) & 0xffu;
 }
 
+// One bit per NOTE (= G groups of a stream), up to 64 per stream, collected without a compare AND without a 64-bit shift by
+// a register (score_prefilter.hpp, prefilter_lookahead: such a shift by the last allocated VGPR is what broke the protein scans): the field shifts right one bit per
+// note and takes the note's flag in at bit 63, so after n notes they sit in its top n bits, oldest lowest.
+struct GroupNotes {
+    unsigned lo = 0, hi = 0;
+    // `mx`: bit 15 of a half = that half reached the threshold (the pair scans' biased sums, score_prefilter2.hpp: kFlagBits)
+    __device__ __forceinline__ void note(unsigned &mx)
+    {
+        const unsigned either = mx | (mx << 16);  // bit 31: one of the two halves reached the threshold
+        push(either);
+        mx = 0;
+    }
+    __device__ __forceinline__ void push(const unsigned flag31)  // bit 31 of `flag31` = the note's flag
+    {
+        lo = __builtin_amdgcn_alignbit(hi, lo, 1);  // (hi:lo) >> 1
+        hi = (hi >> 1) | (flag31 & 0x80000000u);
+    }
+    __device__ __forceinline__ unsigned long long finish(unsigned n) const  // n = notes taken, 1 ... 64 (wave-uniform)
+    {
+        // (hi:lo) >> (64 - n) with 32-bit operations only
+        const unsigned sh = 64u - n;
+        const unsigned a = sh >= 32u ? hi : lo, b = sh >= 32u ? 0u : hi, r = sh & 31u;
+        const unsigned out_lo = r ? (a >> r) | (b << (32u - r)) : a;
+        const unsigned out_hi = r ? (b >> r) : b;
+        return ((unsigned long long)out_hi << 32) | out_lo;
+    }
+};
+
+// ---- the linear lane map of 4-row symbol blocks (round 6; score_prefilter_blk.hpp) -----------------------------------
+// Lane l of a half-wave reads dword l of a block's 128 bytes (row q = l >> 3, columns 4b .. 4b + 3, b = l & 7) and accumulates
+// column 4b + q.  The four lanes {b, 8 + b, 16 + b, 24 + b} transpose their 4 x 4 bytes with two exchanges -- DPP row_ror:8
+// (lane ^ 8) and v_permlane16_swap (lane ^ 16) -- and two v_perm_b32, after which a lane holds its column's four symbols in ONE
+// register; the LDS address of a step is then byte i of that register times the row size, one SDWA multiply (kernels without
+// static LDS: the product IS the address, lds_zero_based).  The protein block scan is built on it.  The f32 store kernel was
+// tried on it too (2.25 decode operations per step instead of 3, 451 instead of 466 VALU per group at M = 20, bit-identical)
+// and ran SLOWER at M = 20 ... 28 (0.947 against 0.921 ms per Gbp at M = 20; profiles/r06_store_linear_map_ab.json): it keeps
+// the quad map of quad_symbol above.
+struct BlkTranspose {
+    unsigned sel1, sel2;
+    __device__ __forceinline__ BlkTranspose()
+    {
+        const unsigned q = (threadIdx.x >> 3) & 3u;
+        // v_perm_b32(S0, S1, sel): selector bytes 0..3 take from S1, 4..7 from S0
+        // step 1, S0 = partner row (q ^ 1), S1 = own: lanes of an even row keep columns (0, 2) of rows (q, q + 1), of an
+        // odd row columns (1, 3) of rows (q - 1, q)
+        sel1 = (q & 1u) ? 0x03070105u : 0x06020400u;
+        // step 2, S0 = the pair of rows (2, 3), S1 = the pair (0, 1) (v_permlane16_swap hands both to every lane): the
+        // lane's column is the first of its pair for q < 2, the second for q >= 2
+        sel2 = (q & 2u) ? 0x07060302u : 0x05040100u;
+    }
+    __device__ __forceinline__ unsigned operator()(const unsigned d) const
+    {
+        const unsigned x = (unsigned)__builtin_amdgcn_mov_dpp((int)d, 0x128, 0xf, 0xf, true);  // row_ror:8 = lane ^ 8
+        const unsigned u = __builtin_amdgcn_perm(x, d, sel1);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // r[0]: rows (0, 1) of the tile, r[1]: rows (2, 3)
+        return __builtin_amdgcn_perm(r[1], r[0], sel2);
+    }
+};
+
+// byte BYTE of `s` times `mult` (a register: SDWA takes no constants) in one operation
+template <int BYTE>
+__device__ __forceinline__ unsigned byte_times(const unsigned s, const unsigned mult)
+{
+    unsigned r;
+    if constexpr (BYTE == 0)
+        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(s), "v"(mult));
+    else if constexpr (BYTE == 1)
+        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(s), "v"(mult));
+    else if constexpr (BYTE == 2)
+        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(s), "v"(mult));
+    else
+        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(s), "v"(mult));
+    return r;
+}
+
 enum : int { PHASE_FIRST = 0, PHASE_MAIN = 1, PHASE_LAST = 2 };
 
 // One group of M consecutive steps of one lane.  `sp` -> symbol byte of the
@@ -627,6 +702,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(1, kBlock),
     // OC = 16 (the 16-lane back-ends' column count; plain store only): a wavefront carries four streams
     // of 16 columns, score rows are 16 floats; the sequence rows keep their 32-byte stride (dense.rs:43-48)
     static_assert(OC == 32 || (OC == 16 && MODE == MODE_STORE), "C = 16 is built for the plain store kernel");
+    // quad-gathered symbol loads need whole 4-row blocks per group
+    constexpr int QL = (QLREQ && M % 4 == 0) ? 1 : 0;
     const int lane = threadIdx.x & 63;
     const int col = lane & (OC - 1);
     // (plain dispatch order = one compact window of rows in flight; an XCD-aware remap -- each XCD one contiguous
@@ -642,8 +719,6 @@ __global__ __attribute__((amdgpu_flat_work_group_size(1, kBlock),
     if (o0 + T > row_end)
         o0 = row_end - T;
 
-    // quad-gathered symbol loads need whole 4-row blocks per group
-    constexpr int QL = (QLREQ && M % 4 == 0) ? 1 : 0;
     const unsigned shq = 8u * (col & 3);
     // (padded motifs: the first `lead` rows of a window carry zero weights and may lie before the matrix)
     // (the fused modes of the short family are never launched on padded tables; the long family always is)
@@ -690,18 +765,20 @@ __global__ __attribute__((amdgpu_flat_work_group_size(1, kBlock),
 
     // Fused threshold: the hot loop must stay branch-free (any `if` inside the
     // unrolled groups wrecks the schedule: 230 VGPRs / spills), so a lane only
-    // remembers WHICH groups saw a score >= t -- one bit per G groups -- and
+    // remembers WHICH groups saw a score >= t -- one bit per G groups (GroupNotes) -- and
     // re-scores those rows after its stream.  Hits are rare (p ~ 1e-5).
-    unsigned long long hit_groups = 0;
-    const unsigned long long G = (ngroups + 63) / 64;  // groups per bit
-    unsigned long long gbit = 1, gleft = G;
+    const unsigned G = (unsigned)((ngroups + 63) / 64);  // groups per note (T <= 2^30: 32 bits hold every count here)
+    unsigned gleft = G, nnotes = 0, pending = 0;
+    GroupNotes notes;
     auto note_group = [&]() {
         if (MODE == MODE_THRESHOLD) {
-            hit_groups |= best_t ? gbit : 0ull;
+            pending |= best_t ? 0x80000000u : 0u;
             best_t = 0;
             if (--gleft == 0) {
                 gleft = G;
-                gbit <<= 1;
+                ++nnotes;
+                notes.push(pending);
+                pending = 0;
             }
         }
     };
@@ -726,17 +803,20 @@ __global__ __attribute__((amdgpu_flat_work_group_size(1, kBlock),
     score_group<M, MODE, PFE, PHASE_LAST, QL, OC, WIDE>(acc, sym, sp, lds_raw, op, tbase, col, best_v,
                                                best_t, fo, shq, init_next, initq, false);
     note_group();
+    if (MODE == MODE_THRESHOLD && gleft != G) {  // the last, partly filled note
+        ++nnotes;
+        notes.push(pending);
+    }
+    const unsigned long long hit_groups = MODE == MODE_THRESHOLD ? notes.finish(nnotes ? nnotes : 1u) : 0ull;
 
     if (MODE == MODE_THRESHOLD) {
         const long long first_row = (long long)(o0 - row_begin);  // = orow0 + M - 1
         // every cell is reported once: the shifted last stream skips the rows the
         // stream before it owns, idle half-waves report nothing
         const long long own_row = (long long)(stream * T);
-        if (idle)
-            hit_groups = 0;
         // bit b <-> groups [b*G, (b+1)*G): group g completes output rows
         // orow0 + g*M .. orow0 + g*M + M-1, of which group 0 only the stream's first row
-        emit_candidates(hit_groups, col, fo, [=](int bit, long long &r0, long long &r1) {
+        emit_candidates(idle ? 0ull : hit_groups, col, fo, [=](int bit, long long &r0, long long &r1) {
             const unsigned long long g0 = (unsigned long long)bit * G;
             unsigned long long g1 = g0 + G;
             if (g1 > ngroups)

@@ -100,6 +100,17 @@ int batch_join(lm_hip_ctx *ctx);
 // long and the chip full (2 346 JASPAR motifs -> ~50 launches).
 enum : int { KIND_GENERIC = 0, KIND_EXACT = 1, KIND_PREFILTER = 2, KIND_PREFILTER2 = 3, KIND_CHUNKED = 4, KIND_SKIP = 5 };
 static inline bool kind_solo(int kind) { return kind == KIND_GENERIC || kind == KIND_CHUNKED; }
+// LDS table bytes a scan of `kind` reads per position for a motif of `m` rows of which `scanned` are looked up (the pair scans'
+// drop-last form: m - 1): pair scans one row of ((scanned | 3) + 1) u16 entries per TWO positions, one-symbol scans a row of
+// prefilter_mp u16 entries per position, exact kernels m floats
+static inline unsigned scan_lds_bytes(int kind, size_t scanned, size_t k)
+{
+    return kind == KIND_PREFILTER2  ? (unsigned)((scanned | 3) + 1)
+           : kind == KIND_PREFILTER ? 2u * (unsigned)prefilter_mp((int)scanned, lds_wide((int)k))
+           : kind == KIND_EXACT     ? 4u * (unsigned)scanned
+                                    : 0u;
+}
+
 // B = the score of a best k-mer: the row maxima added in motif order.  It bounds every score of the matrix from
 // above -- f32 rounding is monotone, so termwise larger weights added in the same order cannot give a smaller
 // sum -- provided the weights hold no NaN / +inf (lm_hip_pssm::has_prefilter).

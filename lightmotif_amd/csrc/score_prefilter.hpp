@@ -106,33 +106,7 @@ __device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b)
     return __builtin_bit_cast(unsigned, __builtin_elementwise_min(x, y));
 }
 
-// One bit per NOTE (= G groups of a stream), up to 64 per stream, collected without a compare AND without a 64-bit shift by
-// a register (prefilter_lookahead above: such a shift is what broke the protein scans): the field shifts right one bit per
-// note and takes the note's flag in at bit 63, so after n notes they sit in its top n bits, oldest lowest.
-struct GroupNotes {
-    unsigned lo = 0, hi = 0;
-    // `mx`: bit 15 of a half = that half reached the threshold (the pair scans' biased sums, score_prefilter2.hpp: kFlagBits)
-    __device__ __forceinline__ void note(unsigned &mx)
-    {
-        const unsigned either = mx | (mx << 16);  // bit 31: one of the two halves reached the threshold
-        push(either);
-        mx = 0;
-    }
-    __device__ __forceinline__ void push(const unsigned flag31)  // bit 31 of `flag31` = the note's flag
-    {
-        lo = __builtin_amdgcn_alignbit(hi, lo, 1);  // (hi:lo) >> 1
-        hi = (hi >> 1) | (flag31 & 0x80000000u);
-    }
-    __device__ __forceinline__ unsigned long long finish(unsigned n) const  // n = notes taken, 1 ... 64 (wave-uniform)
-    {
-        // (hi:lo) >> (64 - n) with 32-bit operations only
-        const unsigned sh = 64u - n;
-        const unsigned a = sh >= 32u ? hi : lo, b = sh >= 32u ? 0u : hi, r = sh & 31u;
-        const unsigned out_lo = r ? (a >> r) | (b << (32u - r)) : a;
-        const unsigned out_hi = r ? (b >> r) : b;
-        return ((unsigned long long)out_hi << 32) | out_lo;
-    }
-};
+// (GroupNotes, the per-stream record of flagged groups, lives in score_kernels.hpp)
 
 // `mx` collects (packed max) every register that holds a just-completed sum.  Its other half
 // is the partial sum of an output still in flight; weights are >= 0, so a partial sum that

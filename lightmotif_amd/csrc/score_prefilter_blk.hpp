@@ -29,44 +29,7 @@ namespace lm {
 
 constexpr int kBlkKA = 21;  // the alphabet this kernel is built for (the ODD layout's offset is an immediate)
 
-// the lane's column of a block: 4 x 4 bytes of four lanes -> bytes (row 0, row 1, row 2, row 3) of column 4b + q
-struct BlkTranspose {
-    unsigned sel1, sel2;
-    __device__ __forceinline__ BlkTranspose()
-    {
-        const unsigned q = (threadIdx.x >> 3) & 3u;
-        // v_perm_b32(S0, S1, sel): selector bytes 0..3 take from S1, 4..7 from S0
-        // step 1, S0 = partner row (q ^ 1), S1 = own: lanes of an even row keep columns (0, 2) of rows (q, q + 1), of an
-        // odd row columns (1, 3) of rows (q - 1, q)
-        sel1 = (q & 1u) ? 0x03070105u : 0x06020400u;
-        // step 2, S0 = the pair of rows (2, 3), S1 = the pair (0, 1) (v_permlane16_swap hands both to every lane): the
-        // lane's column is the first of its pair for q < 2, the second for q >= 2
-        sel2 = (q & 2u) ? 0x07060302u : 0x05040100u;
-    }
-    __device__ __forceinline__ unsigned operator()(const unsigned d) const
-    {
-        const unsigned x = (unsigned)__builtin_amdgcn_mov_dpp((int)d, 0x128, 0xf, 0xf, true);  // row_ror:8 = lane ^ 8
-        const unsigned u = __builtin_amdgcn_perm(x, d, sel1);
-        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // r[0]: rows (0, 1) of the tile, r[1]: rows (2, 3)
-        return __builtin_amdgcn_perm(r[1], r[0], sel2);
-    }
-};
-
-// byte BYTE of `s` times `mult` (a register: SDWA takes no constants) in one operation
-template <int BYTE>
-__device__ __forceinline__ unsigned byte_times(const unsigned s, const unsigned mult)
-{
-    unsigned r;
-    if constexpr (BYTE == 0)
-        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(s), "v"(mult));
-    else if constexpr (BYTE == 1)
-        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(s), "v"(mult));
-    else if constexpr (BYTE == 2)
-        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(s), "v"(mult));
-    else
-        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(s), "v"(mult));
-    return r;
-}
+// (BlkTranspose, byte_times: score_kernels.hpp -- the store kernels' linear lane map shares them)
 
 // The scan loop, software-pipelined by hand like the pair scans' (score_prefilter2.hpp: pair_items).  An ITEM is a pair of
 // steps (2P, 2P + 1): the EVEN layout's row R0 of the first symbol and the ODD layout's row R1 of the second.  Accumulator

@@ -312,6 +312,13 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
         score_c32_prefilter2_lookup((int)jobs[0].pssm->m - 1, (int)jobs[0].pssm->k))
         drop_plan = plan_c32(ctx, MotifShape{jobs[0].pssm->m - 1, jobs[0].pssm->k, true}, jobs[0], false, 2, 1);
     const bool drop_last_form = drop_plan.ok;
+    ctx->last_scan_rows = ctx->last_scan_lds_bytes = 0;
+    if (n == 1 && groups.size() == 1) {
+        const size_t scanned = jobs[0].pssm->m - (drop_last_form ? 1 : 0);
+        const size_t em = groups[0].kind == KIND_EXACT ? exact_motif(jobs[0].pssm, jobs[0].d_seq).m : scanned;
+        ctx->last_scan_lds_bytes = scan_lds_bytes(groups[0].kind, em, jobs[0].pssm->k);
+        ctx->last_scan_rows = ctx->last_scan_lds_bytes ? (unsigned)scanned : 0u;
+    }
     for (int attempt = 0; attempt < 3; ++attempt) {
         // layout: [hit count u64][candidate count u64][jobs][batch][HitRecord x cap][Candidate x ccap];
         // the head -- zeroed counters and the two job tables -- is assembled in the upper half of the
@@ -429,6 +436,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
             LM_TRY(launch_rescore(ctx, ctx->stream, d_jobs, fo, rjobs.data(), n, &so));
             LM_HIP_TRY(hipGetLastError());
         }
+        scan_timer_mark(ctx, ctx->stream, 2);
         const int emit = keys == HitKeys::Position ? 1 : 0;
         unsigned long long count = 0, ncand = 0;
         const auto t_scan = std::chrono::steady_clock::now();
@@ -480,6 +488,9 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
                               out, &status, counts));
         }
         scan_timer_read(ctx);
+        if (ctx->last_phase_ms[0] >= 0)  // (time_scan) the host's share: everything of the call the events do not cover
+            ctx->last_phase_ms[3] = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count() -
+                                    (ctx->last_phase_ms[0] + std::max(ctx->last_phase_ms[1], 0.0f) + std::max(ctx->last_phase_ms[2], 0.0f));
         if (getenv("LM_HIP_TRACE")) {
             const auto t_end = std::chrono::steady_clock::now();
             fprintf(stderr, "[lm_hip] fused threshold: %zu jobs, %llu candidates, %llu hits; %s; scans enqueued in "

@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -864,6 +865,73 @@ public:
         }
         went(Route::Gpu);
         return Hip::scan_max(pssm, seq, threshold, Cpu::saturating_u8);
+    }
+
+    // The reference picks its back-end per HOST, at run time (pli/mod.rs:269-308); the size policy likewise.  The library
+    // measures the GPU side of its cost model on this host and link (lm_hip_host_calibrate: call latency and per-cell link
+    // cost of every site that can leave the tier); THIS tier is timed here -- the library never sees it -- on a synthetic
+    // 1 Mi-position DNA sequence: Score<f32> and Score<u8> at two motif lengths (a cost per cell and motif row), argmax and
+    // threshold on the f32 scores, the Scanner loop.  ~budget_ms in total, once per process for the GPU side.  Pins made
+    // with policy.force() stay on top.
+    struct Calibration {
+        size_t score_f32_m16 = 0, score_u8_m16 = 0, maximum_f32 = 0, threshold_f32 = 0, scan_m16 = 0;  // crossovers, cells
+    };
+    Calibration calibrate(double budget_ms = 40.0)
+    {
+        check(lm_hip_host_calibrate(budget_ms * 0.5, 0));
+        const size_t n = (size_t)1 << 20;
+        std::string text(n, 'A');
+        uint64_t x = 0x5EED0007u;
+        for (size_t i = 0; i < n; ++i) {
+            x = x * 6364136223846793005ull + 1442695040888963407ull;
+            text[i] = "ACGT"[(x >> 33) & 3u];
+        }
+        auto motif = [&](size_t m) {
+            std::vector<EncodedSequence<Dna>> sites;
+            for (int s = 0; s < 4; ++s)
+                sites.push_back(EncodedSequence<Dna>::encode(text.substr(1000 * (size_t)(s + 1), m)));
+            return CountMatrix<Dna>::from_sequences(sites).to_freq(0.1f).to_scoring();
+        };
+        auto timed_ns = [&](auto &&f, double share_ms) {  // best of a few runs inside its share of the budget, per call
+            double best = 1e300;
+            const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double, std::milli>(share_ms);
+            int runs = 0;
+            do {
+                const auto a = std::chrono::steady_clock::now();
+                f();
+                best = std::min(best, std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - a).count());
+            } while (++runs < 5 && std::chrono::steady_clock::now() < t_end);
+            return best;
+        };
+        const auto p8 = motif(8), p24 = motif(24);
+        host::StripedSequence<Dna> seq = host::StripedSequence<Dna>::stripe(EncodedSequence<Dna>::encode(text), 32);
+        seq.configure(p24);
+        const size_t rows = seq.matrix().rows() - seq.wrap();
+        const double cells = (double)rows * 32, share = budget_ms * 0.5 / 7.0;
+        host::StripedScores<float> sc(32);
+        const double f8 = timed_ns([&] { cpu.score_rows_into(p8, seq, 0, rows, sc); }, share) / cells;
+        const double f24 = timed_ns([&] { cpu.score_rows_into(p24, seq, 0, rows, sc); }, share) / cells;
+        const double f_row = std::max((f24 - f8) / 16.0, 0.0);
+        check(lm_hip_host_set_cpu_cost(LM_HIP_OP_SCORE_F32, std::max(f8 - 8.0 * f_row, 0.0), f_row));
+        const auto d8 = p8.to_discrete(), d24 = p24.to_discrete();
+        host::StripedScores<uint8_t> su(32);
+        const double u8 = timed_ns([&] { cpu.score_rows_into(d8, seq, 0, rows, su); }, share) / cells;
+        const double u24 = timed_ns([&] { cpu.score_rows_into(d24, seq, 0, rows, su); }, share) / cells;
+        const double u_row = std::max((u24 - u8) / 16.0, 0.0);
+        check(lm_hip_host_set_cpu_cost(LM_HIP_OP_SCORE_U8, std::max(u8 - 8.0 * u_row, 0.0), u_row));
+        check(lm_hip_host_set_cpu_cost(LM_HIP_OP_MAXIMUM_F32, timed_ns([&] { (void)cpu.argmax(sc); }, share) / cells, 0.0));
+        check(lm_hip_host_set_cpu_cost(LM_HIP_OP_THRESHOLD_F32, timed_ns([&] { (void)cpu.threshold(sc, 1e30f); }, share) / cells, 0.0));
+        // the Scanner's loop: the u8 score of every block + its reductions (a cost per cell and motif row like Score<u8>,
+        // plus one pass per cell)
+        const double s24 = timed_ns([&] { (void)cpu.scan(p24, seq, 1e30f, 256); }, share) / cells;
+        check(lm_hip_host_set_cpu_cost(LM_HIP_OP_SCAN, std::max(s24 - 24.0 * u_row, 0.0), u_row));
+        Calibration c;
+        check(lm_hip_host_crossover(LM_HIP_OP_SCORE_F32, 16, 5, &c.score_f32_m16));
+        check(lm_hip_host_crossover(LM_HIP_OP_SCORE_U8, 16, 5, &c.score_u8_m16));
+        check(lm_hip_host_crossover(LM_HIP_OP_MAXIMUM_F32, 0, 0, &c.maximum_f32));
+        check(lm_hip_host_crossover(LM_HIP_OP_THRESHOLD_F32, 0, 0, &c.threshold_f32));
+        check(lm_hip_host_crossover(LM_HIP_OP_SCAN, 16, 5, &c.scan_m16));
+        return c;
     }
 
 private:

@@ -150,6 +150,22 @@ class Pipeline:
         return int(h.value), int(c.value)
 
     @property
+    def last_phases_ms(self) -> Optional[Tuple[float, float, float, float]]:
+        """(scan, re-scoring, ordering, host share) of the last fused threshold call in ms, with ``set_option("time_scan", 1)``;
+        None otherwise (lm_hip_ctx_last_phases_ms)."""
+        ph = (C.c_float * 4)()
+        check(self._L.lm_hip_ctx_last_phases_ms(self._h, ph))
+        return tuple(float(x) for x in ph) if ph[0] >= 0 else None
+
+    @property
+    def last_scan_info(self) -> Tuple[int, int]:
+        """(motif rows scanned, LDS table bytes per position) of the last single-job fused scan on this pipeline; zeros
+        when no prefilter / exact scan kernel ran (lm_hip_ctx_last_scan_info)."""
+        r, b = C.c_size_t(0), C.c_size_t(0)
+        check(self._L.lm_hip_ctx_last_scan_info(self._h, C.byref(r), C.byref(b)))
+        return int(r.value), int(b.value)
+
+    @property
     def last_scan_kernel_ms(self) -> Optional[float]:
         """Duration of the scan kernel(s) of the last fused call, with ``set_option("time_scan", 1)``; None otherwise
         (lm_hip_ctx_last_scan_kernel_ms)."""
@@ -363,24 +379,25 @@ class Pipeline:
         check(self._L.lm_hip_scan_argmax_batch(self._h, handles, n, seq._h, found, best, value))
         return [((best[i].row, best[i].col), float(value[i])) if found[i] else None for i in range(n)]
 
-    def scan_threshold_batch(self, pssms: Sequence["ScoringMatrix"], thresholds: Sequence[float],
-                             seq: "StripedSequence"):
-        """Per motif: ``(coords (n_i, 2) int64 in row-major order, values (n_i,) f32)``."""
-        n = len(pssms)
-        handles = (C.c_void_p * n)(*[p._device(self) for p in pssms])
-        ts = (C.c_float * n)(*[float(t) for t in thresholds])
-        counts = (C.c_size_t * n)()
+    def prepare_batch(self, pssms: Sequence["ScoringMatrix"], thresholds: Optional[Sequence[float]] = None) -> "MotifBatch":
+        """The motif list of a batch in the form the C ABI takes it (device handles, thresholds), built once: a job loop that
+        scans sequence after sequence with the same motifs (the CLI, main.rs:502-561) does not rebuild it per call."""
+        return MotifBatch(self, pssms, thresholds)
+
+    def scan_threshold_batch(self, pssms: Union[Sequence["ScoringMatrix"], "MotifBatch"],
+                             thresholds: Optional[Sequence[float]], seq: "StripedSequence") -> "BatchHits":
+        """Per motif: ``(coords (n_i, 2) int64 in row-major order, values (n_i,) f32)`` -- a sequence of such pairs (views
+        into ONE pair of arrays the library returned, cut on access)."""
+        batch = pssms if isinstance(pssms, MotifBatch) else MotifBatch(self, pssms, thresholds)
+        n = len(batch)
+        counts = np.zeros(n, dtype=np.uintp)
         ptr, vals = C.POINTER(Coords)(), C.POINTER(C.c_float)()
-        check(self._L.lm_hip_scan_threshold_batch(self._h, handles, ts, n, seq._h, counts,
-                                                  C.byref(ptr), C.byref(vals)))
-        total = sum(counts)
+        check(self._L.lm_hip_scan_threshold_batch(self._h, batch.handles, batch.thresholds, n, seq._h,
+                                                  counts.ctypes.data_as(C.POINTER(C.c_size_t)), C.byref(ptr), C.byref(vals)))
+        total = int(counts.sum())
         values = self._take_array(vals, total, np.float32)
         coords = self._take_coords_array(ptr, total)
-        out, pos = [], 0
-        for i in range(n):
-            out.append((coords[pos:pos + counts[i]], values[pos:pos + counts[i]]))
-            pos += counts[i]
-        return out
+        return BatchHits(coords, values, counts)
 
     # -- raw device-pointer forms (used with torch tensors by bench.py / tests) -------
 
@@ -941,6 +958,51 @@ class DiscreteMatrix:
     def unscale(self, score: int) -> float:
         """pwm/mod.rs:783-785"""
         return float(np.float32(np.float32(score) * np.float32(self.factor) + np.float32(self.offset)))
+
+
+class MotifBatch:
+    """Device handles (+ thresholds) of a motif list, as arrays the C ABI reads (Pipeline.prepare_batch)."""
+
+    def __init__(self, pli: "Pipeline", pssms: Sequence["ScoringMatrix"], thresholds: Optional[Sequence[float]] = None):
+        self.pssms = list(pssms)          # (keeps the matrices, hence their device tables, alive)
+        n = len(self.pssms)
+        self.handles = (C.c_void_p * n)(*[p._device(pli) for p in self.pssms])
+        self.thresholds = None
+        if thresholds is not None:
+            ts = np.ascontiguousarray(thresholds, dtype=np.float32)
+            if ts.shape != (n,):
+                raise ValueError("one threshold per motif")
+            self._ts = ts
+            self.thresholds = ts.ctypes.data_as(C.POINTER(C.c_float))
+
+    def __len__(self) -> int:
+        return len(self.pssms)
+
+
+class BatchHits(Sequence):
+    """The result of a batched fused threshold scan: per motif ``(coords (n_i, 2) int64, values (n_i,) f32)``, cut out of
+    the two arrays the library returned when an element is asked for (2 346 slices cost a millisecond the scan does not)."""
+
+    def __init__(self, coords: np.ndarray, values: np.ndarray, counts: np.ndarray):
+        self.coords, self.values, self.counts = coords, values, counts
+        self._starts = np.concatenate(([0], np.cumsum(counts, dtype=np.int64)))
+
+    def __len__(self) -> int:
+        return len(self.counts)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        a, b = int(self._starts[i]), int(self._starts[i + 1])
+        return self.coords[a:b], self.values[a:b]
+
+    @property
+    def total(self) -> int:
+        return int(self._starts[-1])
 
 
 # --- scores -----------------------------------------------------------------------------

@@ -254,6 +254,48 @@ static int bench_scan()
     return 0;
 }
 
+// the policy's constants re-measured on THIS host (the reference picks its back-end per host at run time, pli/mod.rs:269-308):
+// the GPU side by the library, the tier's side by the twin; the routes still agree bit for bit either side of the new numbers
+static void test_calibrated_policy()
+{
+    double t0 = 0, g = 0, c = 0, cr = 0;
+    int measured = 1;
+    CHECK(lm_hip_host_cost_model(LM_HIP_OP_SCORE_F32, &t0, &g, &c, &cr, &measured) == LM_HIP_OK && !measured && t0 == 47.0);
+    HipDispatch<PortTier> pli;
+    const auto cal = pli.calibrate(60.0);
+    CHECK(lm_hip_host_cost_model(LM_HIP_OP_SCORE_F32, &t0, &g, &c, &cr, &measured) == LM_HIP_OK && measured);
+    CHECK(t0 > 2.0 && t0 < 2000.0 && g > 0.005 && g < 5.0 && cr > 0.001 && cr < 5.0);   // a launch + link, a SIMD kernel: sane magnitudes
+    std::printf("calibrated on this host: score_f32 t0 %.1f us, link %.4f ns/cell, tier %.4f + %.4f M ns/cell -> crossovers (cells): "
+                "score_f32(M = 16) %zu, score_u8(M = 16) %zu, maximum_f32 %zu, threshold_f32 %zu, scan(M = 16) %zu\n",
+                t0, g, c, cr, cal.score_f32_m16, cal.score_u8_m16, cal.maximum_f32, cal.threshold_f32, cal.scan_m16);
+    CHECK(cal.score_f32_m16 > 500 && cal.score_f32_m16 < ((size_t)1 << 28));
+    // either side of the calibrated crossover: different routes, identical bits
+    const auto pssm = mx000001();
+    size_t x = 0;
+    CHECK(lm_hip_host_crossover(LM_HIP_OP_SCORE_F32, pssm.len(), 5, &x) == LM_HIP_OK && x > 64 && x < ((size_t)1 << 28));
+    const std::string text = random_dna(2 * x + 4096, 99);
+    host::StripedSequence<Dna> below = host::StripedSequence<Dna>::stripe(EncodedSequence<Dna>::encode(text.substr(0, x / 2)), 32);
+    host::StripedSequence<Dna> above = host::StripedSequence<Dna>::stripe(EncodedSequence<Dna>::encode(text), 32);
+    below.configure(pssm);
+    above.configure(pssm);
+    HipDispatch<PortTier> all_cpu, all_gpu;
+    for (int op = 0; op < 9; ++op) {
+        all_cpu.policy.force((lm_hip_host_op)op, SIZE_MAX);
+        all_gpu.policy.force((lm_hip_host_op)op, 0);
+    }
+    const auto s_below = pli.score(pssm, below);
+    CHECK(pli.last_route == Route::Cpu && same_bits(s_below, all_gpu.score(pssm, below)));
+    const auto s_above = pli.score(pssm, above);
+    CHECK(pli.last_route == Route::Gpu && same_bits(s_above, all_cpu.score(pssm, above)));
+    // pins: a site forced through the C ABI answers the pin whatever M, and goes back to the model
+    CHECK(lm_hip_host_set_crossover(LM_HIP_OP_SCORE_F32, 12345) == LM_HIP_OK);
+    CHECK(lm_hip_host_crossover(LM_HIP_OP_SCORE_F32, 30, 5, &x) == LM_HIP_OK && x == 12345);
+    CHECK(lm_hip_host_set_crossover(LM_HIP_OP_SCORE_F32, LM_HIP_CROSSOVER_MODEL) == LM_HIP_OK);
+    CHECK(lm_hip_host_crossover(LM_HIP_OP_SCORE_F32, 30, 5, &x) == LM_HIP_OK && x != 12345);
+    CHECK(lm_hip_host_set_cpu_cost(LM_HIP_OP_ENCODE, 1.0, 0.0) == LM_HIP_ERR_BAD_ARGS);   // a site without a model
+    CHECK(lm_hip_host_calibrate(-1.0, 0) == LM_HIP_ERR_BAD_ARGS);
+}
+
 int main(int argc, char **argv)
 {
     if (argc > 1 && std::string(argv[1]) == "--bench")
@@ -271,6 +313,7 @@ int main(int argc, char **argv)
     test_policy_routes_by_size();
     test_scanner_specialisation();
     test_other_geometries();
+    test_calibrated_policy();   // last: it replaces the process's cost model
     if (failures) {
         std::fprintf(stderr, "%d check(s) failed\n", failures);
         return 1;

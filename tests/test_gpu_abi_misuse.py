@@ -45,7 +45,7 @@ print(json.dumps(out))
 
 # entry points whose all-zero argument list is a valid (empty) request
 EMPTY_IS_VALID = {"lm_hip_ctx_sync", "lm_hip_ctx_set_rows_per_stream", "lm_hip_ctx_set_prefilter",
-                  "lm_hip_ctx_set_track_argmax", "lm_hip_encode_dptr",
+                  "lm_hip_ctx_set_track_argmax", "lm_hip_encode_dptr", "lm_hip_ctx_set_xcd_remap",
                   # diagnostics whose outputs are optional: a bracket with nothing in it, counts nobody asked for
                   "lm_hip_ctx_last_scan_counts"}
 

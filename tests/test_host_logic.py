@@ -172,12 +172,16 @@ def test_bench_roofline_blocks_without_a_gpu():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     rows, m = 31_250_000, 20
-    fr = bench.fused_roofline(0.25, rows, m, "score_c32_prefilter2")
+    # what the scan looked up comes from the library (lm_hip_ctx_last_scan_info): a single scan of M = 20, 24, ... 36 may look
+    # M - 1 rows up (the drop-last form): 19 rows -> 20 B per position; the call's tail = call - scan kernel
+    fr = bench.fused_roofline(0.25, rows, m, "score_c32_prefilter2", kernel_ms=0.19, scan_info=(19, 20))
     rf = fr["roofline"]
-    # a single scan of M = 20, 24, ... 36 looks M - 1 rows up (the drop-last form): 19 rows -> 20 B per position
     assert rf["bound"] == "lds" and rf["motif_rows_scanned"] == 19 and rf["lds_bytes_per_position"] == 20 and rf["peak"] == 157.3
+    assert fr["tail_us"] == 60.0 and "timing" in fr
+    # nothing reported (no scan kernel of the prefilter families ran): the motif's own pair table
+    assert bench.fused_roofline(0.25, rows, m, "x")["roofline"]["lds_bytes_per_position"] == 24
     assert abs(rf["achieved"] - 20 * 1e9 / 0.25e-3 / 1e12) < 0.01 and abs(rf["frac"] - rf["achieved"] / 157.2864) < 1e-3
-    r15 = bench.fused_roofline(0.25, rows, 15, "score_c32_prefilter2", kernel_ms=0.2)["roofline"]
+    r15 = bench.fused_roofline(0.25, rows, 15, "score_c32_prefilter2", kernel_ms=0.2, scan_info=(15, 16))["roofline"]
     assert r15["motif_rows_scanned"] == 15 and r15["lds_bytes_per_position"] == 16 and r15["kernel_ms"] == 0.2
     assert abs(r15["kernel_frac"] - 16 * 1e9 / 0.2e-3 / 157.2864e12) < 1e-3
     assert abs(rf["hbm_read_frac"] - (1e9 / 0.25e-3 / 1e9) / 8000.0) < 1e-4 and fr["Gpos_s"] == 4000.0
