@@ -1126,6 +1126,9 @@ def main() -> None:
                                                                total_length, 0, rows, first_cell_rule=rank == 0))
     fth_mhz, _ = sustained_clock(lambda: pli.score_threshold_dptr(pssm, shard.data_ptr(), rows + m - 1, COLS, COLS, m - 1,
                                                                   total_length, 0, rows, thr_t))
+    # Scanner::max as the reference walks it (scan.rs:200-249; csrc/scanmax.hip), a fresh scanner at the same threshold
+    smax_ms, smax = timed(lambda: lm.Scanner(pssm, seq, threshold=thr_t).max(), reps=5, warm=3)
+    smax_kernel = pli.last_kernel
     mt_ms, all_hits = timed(lambda: (comm.merge_threshold(hits, row0) if comm is not None else
                                      D.merge_threshold(hits, row0, device=coll_dev)), reps=3)
     # the same list through the other transport (one timed merge per variant of the step)
@@ -1221,6 +1224,8 @@ def main() -> None:
             "merge_argmax_ms": round(mg_ms, 4), "threshold_ms": round(th_ms, 4),
             "fused_score_threshold_ms": round(fth_ms, 4), "threshold_t": round(thr_t, 4),
             "merge_threshold_ms": round(mt_ms, 4),
+            "scanner_max_ms": round(smax_ms, 4), "scanner_max_kernel": smax_kernel,
+            "scanner_max": None if smax is None else [int(smax.position), round(float(smax.score), 4)],
             "threshold_hits": int(len(all_hits)), "argmax_global": [int(best[0][0]), int(best[0][1])],
             "kernel_ms_min": round(min(kernel_ms), 4), "kernel_ms_max": round(max(kernel_ms), 4),
             # the fused forms never write the score matrix -- priced against the LDS-gather ceiling (the pair

@@ -147,7 +147,8 @@ int lm_hip_ctx_set_track_argmax(lm_hip_ctx *ctx, int enabled);
  * are otherwise taken only for some shapes.  Names: "track_argmax", "prefilter" (= the setters above),
  * "pair_prefilter", "pair_prefilter_protein", "speculate_order", "suffix_argmax", "suffix_occurrences", "multi_motif",
  * "skip_unreachable", "quad_loads", "xlong_store", "host_fold", "chunked_fused", "chunk_rows", "tiled", "sort_hits",
- * "short_order", "time_scan", "drop_last", "block_prefilter" (0 = the protein one-symbol scans load a byte per lane and row
+ * "short_order", "time_scan", "drop_last", "list_scan_max" (0 = Scanner::max always walks windows of materialised u8 scores),
+ * "block_prefilter" (0 = the protein one-symbol scans load a byte per lane and row
  * instead of 4-row blocks); "xcd_remap" is accepted and ignored (the remap it selected was removed in round 5).  Unknown names:
  * LM_HIP_ERR_BAD_ARGS.  The shipped library reads none of them from the environment. */
 int lm_hip_ctx_set_option(lm_hip_ctx *ctx, const char *name, double value);

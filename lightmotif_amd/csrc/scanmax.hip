@@ -21,8 +21,12 @@
 // find / update rounds, and a window that would have needed more rounds raises a `stall` mark that turns the rest of
 // the batch into no-ops; the host then finishes that window round by round and carries on behind it.
 #include <algorithm>
+#include <utility>
+#include <vector>
+#include <cstdio>
+#include <cstdlib>
 
-#include "score_kernels.hpp"
+#include "score_launch.hpp"
 
 namespace lm {
 
@@ -257,6 +261,193 @@ __global__ void scanmax_resume(ScanMaxState *__restrict__ st)
 
 }  // namespace
 
+// ---- the walk over a candidate LIST (round 6) -------------------------------------------------------------------------
+//
+// The level only rises, so every cell the walk ever acts on has a u8 score >= the level it STARTS with.  At the thresholds a
+// Scanner is used with (the CLI's p = 1e-5: ten thousand such cells per Gbp) materialising 1 B per cell and searching it
+// window by window is the wrong shape: the u8 sums of a DiscreteMatrix are exactly what the pair scan adds up
+// (score_c32_prefilter2 on the pair table of the u8 weights: min(sum, 255) >= level <=> sum >= level for the saturating
+// tiers, avx2.rs:336), so ONE flag scan at td = level finds the row ranges that hold them, `scanmax_gate` turns those into
+// records (row-major cell, u8 score, f32 score = score_position's add sequence), the hit-list ordering of the fused threshold
+// puts them in the walk's order -- the key is cell * 256 + u8, so the u8 rides through the ordering untouched -- and the HOST
+// walks the few thousand records with the reference's rule (scan.rs:229-242).  1.3 -> 0.3 ms per Gbp at p = 1e-5.  Lists
+// that would be long (a low threshold: every cell a candidate), wrapping sums (Generic), other geometries and alphabets take
+// the window walk below, which the tests hold equal to this one.
+
+__global__ __launch_bounds__(kBlock) void scanmax_gate(const FusedOut fo, const uint8_t *__restrict__ seq, const float *__restrict__ dense,
+                                                       const uint8_t *__restrict__ dw, const unsigned m, const unsigned k,
+                                                       const unsigned level, const unsigned long long first_row)
+{
+    unsigned long long n = *fo.cand_count;
+    if (n > fo.cand_capacity)
+        n = fo.cand_capacity;  // overflow: the host sees the count and takes the window walk
+    const unsigned lane = threadIdx.x & 31;
+    const unsigned long long stride = (unsigned long long)gridDim.x * (kBlock / 32);
+    for (unsigned long long c0 = (unsigned long long)blockIdx.x * (kBlock / 32); c0 < n; c0 += stride) {  // block-uniform trip count
+        const unsigned long long c = c0 + (threadIdx.x >> 5);
+        bool hit = false;
+        HitRecord r{};
+        if (c < n) {
+            const Candidate cd = fo.cands[c];
+            const unsigned long long r0 = cd.key & ((1ull << 40) - 1);  // relative to first_row
+            if (lane < cd.nrows) {
+                const unsigned long long row = first_row + r0 + lane;
+                const uint8_t *p = seq + row * 32 + cd.col;
+                unsigned sum = 0;
+                float sc = 0.0f;
+                for (unsigned j = 0; j < m; ++j) {  // the u8 weights and the f32 weights of the same symbols, in motif order
+                    const unsigned sy = p[(unsigned long long)j * 32];
+                    sum += dw[j * k + sy];
+                    sc = sc + dense[j * k + sy];  // score_position (pwm/mod.rs:651-662)
+                }
+                if (sum >= level) {
+                    hit = true;
+                    r.key = ((row * 32ull + cd.col) << 8) | (sum < 255u ? sum : 255u);
+                    r.value = sc;
+                    r.pad = 0;
+                }
+            }
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (mask) {
+            const int wl = threadIdx.x & 63;
+            const int leader = __ffsll((long long)mask) - 1;
+            unsigned long long base = 0;
+            if (wl == leader)
+                base = atomicAdd(fo.hit_count, (unsigned long long)__popcll(mask));
+            base = __shfl(base, leader);
+            const unsigned long long slot = base + __popcll(mask & ((1ull << wl) - 1ull));
+            if (hit && slot < fo.hit_capacity)
+                fo.hits[slot] = r;
+        }
+    }
+}
+
+// The walk's state between two row ranges (and what the window walk takes over when a range's list turns out long)
+struct WalkState {
+    unsigned level;
+    bool have;
+    unsigned long long position;
+    float score;
+};
+
+// Walks rows [first_row, row_end) from `st`.  *route = 0: walked, `st` is the state behind row_end; 1: not this route (no
+// state change): the caller takes the window walk from first_row.
+static int scan_max_by_list(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *seq, const uint8_t *weights, size_t wstride,
+                            size_t first_row, size_t row_end, WalkState *st, int *route)
+{
+    *route = 1;
+    const size_t rows = seq->rows, cols = seq->cols, m = pssm->m, k = pssm->k;
+    const unsigned level = st->level;
+    const unsigned long long cells = (unsigned long long)(row_end - first_row) * cols;
+    // the list's keys are cell * 256 + u8 on 40 bits; a level of 0 makes every cell a candidate
+    if (!ctx->list_scan_max || cols != 32 || seq->stride != 32 || k != 5 || m < 2 || m > (size_t)kMaxFastM || level < 1 || level > 255 ||
+        (unsigned long long)rows * cols >= (1ull << 32) || reinterpret_cast<uintptr_t>(seq->d_data) % 4 != 0)
+        return LM_HIP_OK;
+    PrefilterLauncher scan = score_c32_prefilter2_lookup((int)m, 5);
+    ScoreArgs sa{nullptr, seq->d_data, seq->stride, cols, first_row, row_end, nullptr, cols};
+    const C32Plan plan = plan_c32(ctx, MotifShape{m, k, true}, sa, false, 2, 1);
+    if (!scan || !plan.ok)
+        return LM_HIP_OK;
+    // the pair table and the dense copy of the u8 weights (host-packed, one small copy; the matrix of a Scanner changes per call)
+    const size_t image_bytes = (size_t)prefilter2_image_dw((int)m) * 4, dense_bytes = (m * k + 15) / 16 * 16;
+    std::vector<char> stage(image_bytes + dense_bytes, 0);
+    {
+        std::vector<unsigned> d(m * k, 0u);
+        for (size_t j = 0; j < m; ++j)
+            for (size_t sy = 0; sy < k; ++sy) {
+                d[j * k + sy] = weights[j * wstride + sy];
+                stage[image_bytes + j * k + sy] = (char)weights[j * wstride + sy];
+            }
+        prefilter2_pack_image(d.data(), (int)m, reinterpret_cast<unsigned *>(stage.data()));
+    }
+    // records: room for 2^-12 of the range's cells, at least 16 k, at most 256 k -- a longer list means the level is still
+    // low for this range, and the window walk is the better shape for it
+    const unsigned long long cap = std::min<unsigned long long>(std::max<unsigned long long>(cells >> 12, 1ull << 14), 1ull << 18);
+    const unsigned long long ccap = 2 * cap;
+    const size_t off_tables = 256, off_hits = off_tables + (image_bytes + dense_bytes + 255) / 256 * 256;
+    const size_t off_cands = off_hits + cap * sizeof(HitRecord);
+    LM_TRY(ctx->scratch.reserve(off_cands + ccap * sizeof(Candidate)));
+    char *base = static_cast<char *>(ctx->scratch.ptr);
+    FusedOut fo{};
+    fo.hit_count = reinterpret_cast<unsigned long long *>(base);
+    fo.cand_count = fo.hit_count + 1;
+    fo.hits = reinterpret_cast<HitRecord *>(base + off_hits);
+    fo.hit_capacity = cap;
+    fo.cands = reinterpret_cast<Candidate *>(base + off_cands);
+    fo.cand_capacity = ccap;
+    LM_HIP_TRY(hipMemsetAsync(base, 0, 16, ctx->stream));
+    LM_HIP_TRY(hipMemcpyAsync(base + off_tables, stage.data(), stage.size(), hipMemcpyHostToDevice, ctx->stream));  // (pageable: copied out before the call returns)
+    const unsigned *d_image = reinterpret_cast<const unsigned *>(base + off_tables);
+    const uint8_t *d_dw = reinterpret_cast<const uint8_t *>(base + off_tables + image_bytes);
+    LM_HIP_TRY(scan(plan.grid, plan.lds, ctx->stream, seq->d_data, d_image, 5, first_row, row_end, plan.T, plan.nstreams, level, fo));
+    hipLaunchKernelGGL(scanmax_gate, dim3((unsigned)ctx->num_cus * 8), dim3(kBlock), 0, ctx->stream, fo, seq->d_data, pssm->d_dense, d_dw,
+                       (unsigned)m, (unsigned)k, level, (unsigned long long)first_row);
+    LM_HIP_TRY(hipGetLastError());
+    // the counters and the head of the (unordered) list in one read-back: a list of a few thousand records is put in order by
+    // the host while a longer one goes through the device's ordering passes (hits.hip) -- one synchronisation instead of two
+    // and no ordering launches for the ranges behind the first, which hold hundreds of records
+    constexpr unsigned long long kHostSort = 4096;
+    char *pin = static_cast<char *>(ctx->pinned);
+    unsigned long long *h_counts = reinterpret_cast<unsigned long long *>(pin);
+    HitRecord *h_recs = reinterpret_cast<HitRecord *>(pin + 256);
+    static_assert(256 + kHostSort * sizeof(HitRecord) <= kPinnedBytes / 2, "the head of the list must fit the pinned block");
+    LM_HIP_TRY(hipMemcpyAsync(h_counts, base, 16, hipMemcpyDeviceToHost, ctx->stream));
+    LM_HIP_TRY(hipMemcpyAsync(h_recs, fo.hits, std::min(cap, kHostSort) * sizeof(HitRecord), hipMemcpyDeviceToHost, ctx->stream));
+    LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const unsigned long long count = h_counts[0], ncand = h_counts[1];
+    if (count > cap || ncand > ccap)
+        return LM_HIP_OK;  // a long list after all: the window walk
+    *route = 0;
+    if (count == 0)
+        return LM_HIP_OK;
+    HitOutput out;
+    std::vector<std::pair<unsigned long long, float>> sorted;
+    if (count <= kHostSort) {
+        sorted.reserve(count);
+        for (unsigned long long i = 0; i < count; ++i)
+            sorted.emplace_back(h_recs[i].key, h_recs[i].value);
+        std::sort(sorted.begin(), sorted.end(), [](const auto &a, const auto &b) { return a.first < b.first; });  // (cells are unique)
+    } else {
+        int status = 0;
+        unsigned long long counts[2];
+        LM_TRY(order_hits(ctx, fo.hits, fo.hit_count, count, cap, ccap, count, 1, ((unsigned long long)rows * cols) << 8, 1, cols, &out,
+                          &status, counts));
+    }
+    // the walk (scan.rs:229-242), over records in row-major cell order
+    const unsigned long long total = (unsigned long long)rows * cols;
+    int err = LM_HIP_OK;
+    const size_t nrec = sorted.empty() ? out.total : sorted.size();
+    for (size_t i = 0; i < nrec; ++i) {
+        const unsigned long long key = sorted.empty() ? out.hits[i].position : sorted[i].first, flat = key >> 8;
+        const unsigned u8 = (unsigned)(key & 255u);
+        if (u8 < st->level)
+            continue;
+        const unsigned long long r = flat / cols, c = flat % cols, index = c * rows + r;  // scan.rs:231
+        const float x = sorted.empty() ? out.hits[i].score : sorted[i].second;
+        if (index + m > total) {  // score_position would index column C: the reference panics (seq.rs:433-442)
+            err = fail(LM_HIP_ERR_BAD_ARGS,
+                       "Scanner::max: the window of candidate position %llu (+ %zu rows) leaves the striped matrix; the "
+                       "reference panics here (seq.rs:433-442)", index, m);
+            break;
+        }
+        if (!st->have) {  // the first candidate is taken as it is; the level stays the scaled threshold (scan.rs:241)
+            st->have = true;
+            st->score = x;
+            st->position = index;
+        } else if (x > st->score || (x == st->score && index > st->position)) {
+            st->score = x;
+            st->position = index;
+            st->level = u8;  // scan.rs:238
+        }
+    }
+    out.release();
+    if (getenv("LM_HIP_TRACE"))
+        fprintf(stderr, "[lm_hip] Scanner::max by list: rows %zu ... %zu at level %u: %llu candidate pieces, %llu records -> level %u\n",
+                first_row, row_end, level, ncand, count, st->level);
+    return err;
+}
+
 // `weights`: the DiscreteMatrix's u8 weights on the HOST (M x wstride), `level` / `have` / `position` / `score`: the
 // walk's state on entry (a fresh scanner: level = dm.scale(threshold), no hit), `first_row`: where the walk starts.
 int launch_scan_max(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *seq, const uint8_t *weights, size_t wstride,
@@ -269,6 +460,40 @@ int launch_scan_max(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *
     *best_score = score;
     if (first_row >= rows || seq->length < m)
         return LM_HIP_OK;
+    if (saturate && (unsigned long long)(rows - first_row) * cols >= (1ull << 20)) {
+        // Two row ranges (more on very long sequences: each 128 times the one before), each scanned at the level the walk has
+        // reached: the level rises fast at first -- the first 1/128 of a 1 Gbp sequence lifts it from the scaled threshold
+        // (2e-4 of the cells at p = 1e-5: 211 k records per Gbp) to the top of the u8 range -- so the range behind it
+        // yields hundreds of records instead of hundreds of thousands.
+        WalkState ws{level, have, position, score};
+        size_t r = first_row;
+        size_t step = std::max<size_t>((rows - first_row) / 128, (size_t)1 << 15);
+        bool walked_all = true;
+        while (r < rows) {
+            const size_t r_end = rows - r <= step + step / 2 ? rows : r + step;
+            int route = 1;
+            LM_TRY(scan_max_by_list(ctx, pssm, seq, weights, wstride, r, r_end, &ws, &route));
+            if (route != 0) {
+                walked_all = false;
+                break;
+            }
+            r = r_end;
+            step *= 128;
+        }
+        // the state so far; the window walk below goes on from row r where a list turned out long (or never applied)
+        level = ws.level;
+        have = ws.have;
+        position = ws.position;
+        score = ws.score;
+        first_row = r;
+        *found = have ? 1 : 0;
+        *best_position = position;
+        *best_score = score;
+        if (walked_all) {
+            ctx->last_kernel = "score_c32_prefilter2+scanmax_gate";
+            return LM_HIP_OK;
+        }
+    }
     // window buffer: the u8 scores, dense rows (stride = cols); up to 256 M cells per window (64 M: 8 % slower per Gbp), matrices of very many columns
     // keep at least 64 rows.  (The state block holds 64-bit words the search updates atomically: 256-byte aligned.)
     const size_t max_rows = std::max<size_t>(((size_t)256 << 20) / cols, 64);

@@ -66,14 +66,14 @@ constexpr int kRescoreTabJobs = 8;
 
 // `bucket_counts` (ShortOrder; one job): every record stored also bumps the count of its bucket, key >> bucket_shift --
 // the histogram pass of the ordering, without a launch of its own.
-template <bool LDS_TAB>
-__global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const RescoreJob *__restrict__ jobs,
+template <bool LDS_TAB, int BLOCK = kRescoreBlock, int STAGE = kHitStage>
+__global__ __launch_bounds__(BLOCK) void rescore_candidates(const RescoreJob *__restrict__ jobs,
                                                              const FusedOut fo, const unsigned njobs,
                                                              unsigned *__restrict__ bucket_counts, const int bucket_shift,
                                                              const RescoreJob job0)
 {
     const bool by_value = bucket_counts != nullptr;  // ShortOrder: the one job is `job0`, `jobs` is not read
-    __shared__ HitRecord stage[kHitStage];
+    __shared__ HitRecord stage[STAGE];
     __shared__ unsigned nstage;
     __shared__ unsigned long long gbase;
     __shared__ float tab[LDS_TAB ? kRescoreTabFloats : 1];
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const Rescor
         for (unsigned j = 0; j < njobs; ++j) {  // block-uniform
             const unsigned nf = by_value ? job0.m * job0.k : jobs[j].m * jobs[j].k;
             const float *dense = by_value ? job0.dense : jobs[j].dense;
-            for (unsigned i = threadIdx.x; i < nf; i += kRescoreBlock)
+            for (unsigned i = threadIdx.x; i < nf; i += BLOCK)
                 tab[off + i] = dense[i];
             if (threadIdx.x == 0)
                 tab_off[j] = off;
@@ -97,14 +97,14 @@ __global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const Rescor
     if (n > fo.cand_capacity)
         n = fo.cand_capacity;  // overflow: the launcher re-runs the batch with more room
     const unsigned lane = threadIdx.x & 31;
-    const unsigned long long stride = (unsigned long long)gridDim.x * (kRescoreBlock / 32);
+    const unsigned long long stride = (unsigned long long)gridDim.x * (BLOCK / 32);
     auto flush = [&]() {  // block-uniform
         __syncthreads();
         const unsigned cnt = nstage;
         if (threadIdx.x == 0 && cnt)
             gbase = atomicAdd(fo.hit_count, (unsigned long long)cnt);
         __syncthreads();
-        for (unsigned i = threadIdx.x; i < cnt; i += kRescoreBlock)
+        for (unsigned i = threadIdx.x; i < cnt; i += BLOCK)
             if (gbase + i < fo.hit_capacity) {
                 fo.hits[gbase + i] = stage[i];
                 if (bucket_counts)
@@ -117,9 +117,9 @@ __global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const Rescor
     };
     // block-uniform trip count: one candidate piece per half-wave per round
     constexpr unsigned kWin = (32 + kMaxPairM - 1 + 31) / 32 * 32;  // a piece of <= 32 rows of a motif of <= kMaxPairM rows
-    __shared__ uint8_t window[kRescoreBlock / 32][kWin];  // symbols of rows r0 .. r0 + nrows + M - 2
+    __shared__ uint8_t window[BLOCK / 32][kWin];  // symbols of rows r0 .. r0 + nrows + M - 2
     unsigned round = 0;
-    for (unsigned long long c0 = (unsigned long long)blockIdx.x * (kRescoreBlock / 32); c0 < n; c0 += stride) {
+    for (unsigned long long c0 = (unsigned long long)blockIdx.x * (BLOCK / 32); c0 < n; c0 += stride) {
         const unsigned long long c = c0 + (threadIdx.x >> 5);
         if (c < n) {
             const Candidate cd = fo.cands[c];
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const Rescor
                             (jb.key_rows ? cd.col * jb.key_rows + row : row * 32ull + cd.col);
                     r.value = sc;
                     r.pad = 0;
-                    stage[atomicAdd(&nstage, 1u)] = r;  // <= kRescoreBlock records per round
+                    stage[atomicAdd(&nstage, 1u)] = r;  // <= BLOCK records per round
                 }
             }
         }
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kRescoreBlock) void rescore_candidates(const Rescor
             __syncthreads();
             const unsigned cnt = nstage;
             __syncthreads();
-            if (cnt > kHitStage - kRescoreCheck * kRescoreBlock)
+            if (cnt > STAGE - kRescoreCheck * BLOCK)
                 flush();
         }
     }
@@ -197,6 +197,9 @@ int launch_rescore(lm_hip_ctx *ctx, hipStream_t st, const RescoreJob *d_jobs, co
     for (size_t i = 0; i < n && i <= (size_t)kRescoreTabJobs; ++i)
         floats += (size_t)host_jobs[i].m * host_jobs[i].k;
     const dim3 grid((unsigned)ctx->num_cus * kRescoreBlocksPerCu), block(kRescoreBlock);
+    // (workgroups of 256 threads with a 1 024-record stage for the short lists of single jobs -- more, smaller workgroups on
+    //  the call's critical path -- were measured in round 6: 38 instead of 19 us for 24 k pieces at 1 Gbp, 10.6 instead of 8.0
+    //  at 200 Mres: four times the global atomics on the list's counter, as the constants above already say)
     if (n <= (size_t)kRescoreTabJobs && floats <= (size_t)kRescoreTabFloats)
         hipLaunchKernelGGL(rescore_candidates<true>, grid, block, 0, st, d_jobs, fo, (unsigned)n, counts, shift, host_jobs[0]);
     else

@@ -975,9 +975,17 @@ def test_scanner_max_walk_on_the_device_at_size(pli, kind):
     seq = pli.stripe(lm.EncodedSequence(enc, protein=protein), 32)
     seq.configure(pssm)
     want = no.scanner_max_strict(scores, d, 32, t, scale, 256)
-    got = lm.Scanner(pssm, seq, threshold=t).max()
-    assert pli.last_kernel.startswith("scanmax_find")
-    assert got is not None and (got.position, np.float32(got.score)) == (want[0], want[1]), (got, want)
+    # both routes of csrc/scanmax.hip: the walk over a candidate LIST (one flag scan at the starting level + records in
+    # row-major order walked by the host; DNA, rare candidates) and the walk over windows of materialised u8 scores
+    for by_list in (1, 0):
+        pli.set_option("list_scan_max", by_list)
+        try:
+            got = lm.Scanner(pssm, seq, threshold=t).max()
+        finally:
+            pli.set_option("list_scan_max", 1)
+        listed = by_list and not protein and kind != "low_threshold"
+        assert pli.last_kernel.startswith("score_c32_prefilter2+scanmax_gate" if listed else "scanmax_find"), (kind, by_list, pli.last_kernel)
+        assert got is not None and (got.position, np.float32(got.score)) == (want[0], want[1]), (kind, by_list, got, want)
 
 
 @pytest.mark.parametrize("kind", ["poly_a", "repeat", "random_then_poly_a", "poly_a_2mbp"])
@@ -1064,8 +1072,15 @@ def test_scanner_max_walk_batched_windows_stall_and_resume(pli, threshold):
     seq = pli.stripe(lm.EncodedSequence(enc), 32)
     seq.configure(pssm)
     want = no.scanner_max_strict(scores, d, 32, t, scale, 256)
-    got = lm.Scanner(pssm, seq, threshold=t).max()
+    pli.set_option("list_scan_max", 0)                 # the window walk, whatever the threshold
+    try:
+        got = lm.Scanner(pssm, seq, threshold=t).max()
+    finally:
+        pli.set_option("list_scan_max", 1)
     assert pli.last_kernel == "scanmax_find (a batched window resumed)"     # the stall path was taken
+    assert got is not None and (got.position, np.float32(got.score)) == (want[0], want[1]), (got, want)
+    got = lm.Scanner(pssm, seq, threshold=t).max()     # the default route: the candidate list where candidates are rare
+    assert pli.last_kernel.startswith("score_c32_prefilter2+scanmax_gate" if threshold == "p1e-4" else "scanmax_find")
     assert got is not None and (got.position, np.float32(got.score)) == (want[0], want[1]), (got, want)
     # a scanner that has already yielded part of its hits walks on from where it stands (scan.rs:200-215)
     sc = lm.Scanner(pssm, seq, threshold=float(np.quantile(finite, 0.99999)), block_size=4096)
