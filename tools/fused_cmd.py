@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--length", type=int, default=1_000_000_000)
     ap.add_argument("--motif-len", type=int, default=20)
     ap.add_argument("--c3", action="store_true")
+    ap.add_argument("--protein", action="store_true", help="configs[4]: 200 Mres x M = 12 protein, the block scan (score_prefilter_blk.hpp)")
     ap.add_argument("--motifs", type=int, default=0)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -42,12 +43,20 @@ def main():
         return
     length, m = args.length, args.motif_len
     rng = np.random.default_rng(3)
-    pssm = lm.create(["".join("ACTG"[i] for i in rng.integers(0, 4, m)) for _ in range(10)]).counts.normalize(0.1).log_odds()
+    k = 5
+    if args.protein:
+        k = 21
+        length = args.length if args.length != 1_000_000_000 else 200_000_000
+        m = args.motif_len if args.motif_len != 20 else 12
+        sym = lm.lib.PROTEIN_SYMBOLS[:-1]
+        pssm = lm.create(["".join(sym[i] for i in rng.integers(0, len(sym), m)) for _ in range(6)], protein=True).counts.normalize(0.1).log_odds()
+    else:
+        pssm = lm.create(["".join("ACTG"[i] for i in rng.integers(0, 4, m)) for _ in range(10)]).counts.normalize(0.1).log_odds()
     rows = -(-length // COLS)
     gen = torch.Generator(device=dev)
     gen.manual_seed(5)
-    seq = torch.randint(0, 4, (rows + m - 1, COLS), dtype=torch.uint8, device=dev, generator=gen)
-    pli.configure_wrap_dptr(seq.data_ptr(), rows, COLS, COLS, m - 1, 4)
+    seq = torch.randint(0, k - 1, (rows + m - 1, COLS), dtype=torch.uint8, device=dev, generator=gen)
+    pli.configure_wrap_dptr(seq.data_ptr(), rows, COLS, COLS, m - 1, k - 1)
     h, p = pli._h, pssm._device(pli)
     sp = C.c_void_p(seq.data_ptr())
     t = float(pssm.score_for_pvalue(1e-5))
