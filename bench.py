@@ -419,8 +419,12 @@ def main_c3(args) -> None:
     pssms, lengths, ts, seq, shard, parts, unreachable, rows, max_m = (c3[k] for k in (
         "pssms", "lengths", "ts", "seq", "shard", "parts", "unreachable", "rows", "max_m"))
 
+    # the rank's motif list in the form the C ABI takes it, built once (the CLI converts its motifs once as well,
+    # main.rs:469-498, and then loops over sequences)
+    prepared = D.prepare_sharded_batch(pli, pssms, ts, parts=parts)
+
     def step():
-        return D.scan_threshold_batch_sharded(pli, pssms, ts, seq, device=coll_dev, parts=parts)
+        return D.scan_threshold_batch_sharded(pli, pssms, ts, seq, device=coll_dev, parts=parts, prepared=prepared)
 
     def barrier():
         if world > 1:
@@ -619,11 +623,11 @@ def c3_leg(pli, dev, coll_dev, world: int, rank: int, reps: int = 5) -> dict:
 
     # the motif list in the form the C ABI takes it, built once (a job loop scans sequence after sequence with the same
     # motifs, lightmotif-cli main.rs:502-561)
-    prepared = pli.prepare_batch(pssms, ts) if world == 1 else None
+    prepared = pli.prepare_batch(pssms, ts) if world == 1 else D.prepare_sharded_batch(pli, pssms, ts, parts=parts)
 
     def scan():
         res[0] = (pli.scan_threshold_batch(prepared, None, seq) if world == 1 else
-                  D.scan_threshold_batch_sharded(pli, pssms, ts, seq, device=coll_dev, parts=parts))
+                  D.scan_threshold_batch_sharded(pli, pssms, ts, seq, device=coll_dev, parts=parts, prepared=prepared))
     t_th = timed(scan, reps)
     k_th = pli.last_kernel
     t_am = timed(lambda: (pli.scan_argmax_batch(pssms, seq) if world == 1 else

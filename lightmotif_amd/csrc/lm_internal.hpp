@@ -125,6 +125,7 @@ struct lm_hip_ctx {
     // what the scan of the last single-job fused call looked up per position (lm_hip_ctx_last_scan_info): motif rows and
     // bytes of LDS table; 0 = no scan kernel of the prefilter / exact families ran (a batch, the suffix route, chunks)
     unsigned last_scan_rows = 0, last_scan_lds_bytes = 0;
+    bool order_groups = true;    // fused threshold batches launch their most expensive length class first and balance the two streams (option "order_groups")
     bool list_scan_max = true;   // Scanner::max over a candidate list (scanmax.hip; option "list_scan_max" = 0: always the window walk)
     bool drop_last = true;       // single pair scans of M = 20, 24, ... 36 over M - 1 rows (option "drop_last"; lm_hip_pssm::d_image2_drop)
     bool short_order = true;     // ... short lists of one job counted by the re-scoring kernel, two launches behind it (hits.hip; option "short_order")

@@ -262,21 +262,56 @@ def scan_argmax_batch_sharded(pli, pssms, seq, device: torch.device | str = "cpu
     return out
 
 
-def scan_threshold_batch_sharded(pli, pssms, thresholds, seq, device: torch.device | str = "cpu",
-                                 group=None, parts: Optional[List[List[int]]] = None):
-    """``Pipeline.scan_threshold_batch`` with the motif list split over the ranks: per
-    motif ``(coords (n_i, 2) int64 in row-major order, values (n_i,) f32)``, in motif
-    order, identical on every rank to the single-process call."""
+class _InMotifOrder(Sequence):
+    """One rank's results (in the order of its share) read in motif order; elements are cut on access like
+    ``BatchHits`` cuts them."""
+
+    def __init__(self, local, mine: List[int], n: int):
+        self._local, self._n = local, n
+        self._where = {i: j for j, i in enumerate(mine)}
+
+    def __len__(self) -> int:
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        j = self._where.get(i)
+        return None if j is None else self._local[j]
+
+
+def prepare_sharded_batch(pli, pssms, thresholds, group=None, parts: Optional[List[List[int]]] = None):
+    """This rank's share of the motif list as a ``MotifBatch`` (``Pipeline.prepare_batch``), built once for a loop of
+    ``scan_threshold_batch_sharded(..., prepared=...)`` calls over many sequences; None when the share is empty."""
     rank, world = _world(group)
     if parts is None:
         parts = shard_motifs([len(p) for p in pssms], world)
     mine = parts[rank]
-    local = pli.scan_threshold_batch([pssms[i] for i in mine], [thresholds[i] for i in mine], seq) if mine else []
+    return pli.prepare_batch([pssms[i] for i in mine], [thresholds[i] for i in mine]) if mine else None
+
+
+def scan_threshold_batch_sharded(pli, pssms, thresholds, seq, device: torch.device | str = "cpu",
+                                 group=None, parts: Optional[List[List[int]]] = None, prepared=None):
+    """``Pipeline.scan_threshold_batch`` with the motif list split over the ranks: per
+    motif ``(coords (n_i, 2) int64 in row-major order, values (n_i,) f32)``, in motif
+    order, identical on every rank to the single-process call.  ``prepared``: what
+    ``prepare_sharded_batch`` returned for the same motifs, thresholds and ``parts``."""
+    rank, world = _world(group)
+    if parts is None:
+        parts = shard_motifs([len(p) for p in pssms], world)
+    mine = parts[rank]
+    if prepared is not None and len(prepared) != len(mine):
+        raise ValueError("prepared batch does not match this rank's share of the motif list")
+    if prepared is not None:
+        local = pli.scan_threshold_batch(prepared, None, seq)
+    else:
+        local = pli.scan_threshold_batch([pssms[i] for i in mine], [thresholds[i] for i in mine], seq) if mine else []
     if world == 1:
-        out = [None] * len(pssms)
-        for i, res in zip(mine, local):
-            out[i] = res
-        return out
+        return _InMotifOrder(local, mine, len(pssms))
     head = np.zeros((len(mine), 2), np.int64)           # (motif, hit count)
     for j, (i, (coords, _)) in enumerate(zip(mine, local)):
         head[j] = (i, len(coords))

@@ -172,14 +172,28 @@ class _OraclePipeline:
             out.append(None if cell is None else (cell, float(sc[cell])))
         return out
 
+    def prepare_batch(self, pssms, ts):
+        return _Prepared(pssms, ts)
+
     def scan_threshold_batch(self, pssms, ts, seq):
         from oracle import c_oracle as co
+        if isinstance(pssms, _Prepared):   # the form Pipeline.prepare_batch hands back: thresholds travel inside
+            assert ts is None
+            pssms, ts = pssms.pssms, pssms.ts
         out = []
         for p, t in zip(pssms, ts):
             sc = self._scores(p)
             rc = np.asarray(co.threshold(sc, 32, t), np.int64).reshape(-1, 2)
             out.append((rc, sc[rc[:, 0], rc[:, 1]].astype(np.float32)))
         return out
+
+
+class _Prepared:
+    def __init__(self, pssms, ts):
+        self.pssms, self.ts = list(pssms), list(ts)
+
+    def __len__(self):
+        return len(self.pssms)
 
 
 class _P:
@@ -213,9 +227,12 @@ def _motif_worker(rank, world, port, q):
         want_th = pli.scan_threshold_batch(pssms, ts, None)
         got_am = D.scan_argmax_batch_sharded(pli, pssms, None)
         got_th = D.scan_threshold_batch_sharded(pli, pssms, ts, None)
-        ok = got_am == want_am and len(got_th) == len(want_th)
-        for (gc, gv), (wc, wv) in zip(got_th, want_th):
+        prepared = D.prepare_sharded_batch(pli, pssms, ts)   # the job-loop form: this rank's share built once
+        got_prepared = D.scan_threshold_batch_sharded(pli, pssms, ts, None, prepared=prepared)
+        ok = got_am == want_am and len(got_th) == len(want_th) == len(got_prepared)
+        for (gc, gv), (pc, pv), (wc, wv) in zip(got_th, got_prepared, want_th):
             ok = ok and np.array_equal(gc, wc) and np.array_equal(gv.view(np.uint32), wv.view(np.uint32))
+            ok = ok and np.array_equal(pc, wc) and np.array_equal(pv.view(np.uint32), wv.view(np.uint32))
         parts = D.shard_motifs([len(p) for p in pssms], world)
         q.put((rank, bool(ok), len(parts[rank])))
     finally:

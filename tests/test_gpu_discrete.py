@@ -148,6 +148,40 @@ def test_one_symbol_scan_and_unaligned_buffers(m):
                 assert pli.last_kernel == "score_c32_u8"   # byte symbol loads need no alignment
 
 
+@pytest.mark.parametrize("m,protein", [(1, False), (2, False), (3, False), (1, True), (2, True), (3, True)])
+def test_short_motif_u8_stores_agree_run_after_run(m, protein):
+    """The shortest motifs through the u8 store kernels at a size that fills the chip (4 M cells),
+    pair and one-symbol routes, each run twice: the same bytes every time, and the oracle's.  (The
+    look-ahead of those kernels at M = 1, 2 was once capped for a fault whose cause turned out to be
+    the 64-bit shift erratum of DESIGN 4.9; this is the run-to-run check that stands behind
+    lifting the cap.)"""
+    k = 21 if protein else 5
+    rng = np.random.default_rng(900 + m + 10 * k)
+    length = (1 << 22) + 77
+    rows = -(-length // 32)
+    enc = rng.integers(0, k, length, dtype=np.uint8)
+    weights = rng.integers(0, 256, (m, k), dtype=np.uint8)
+    dm = lm.DiscreteMatrix(weights, 1.0, np.zeros(m, np.float32), 0.0, protein=protein)
+    ref = co.stripe(enc, 32, k)
+    co.configure_wrap(ref, m)
+    want = no.score_rows_u8_saturating(ref.data, 32, length, weights, 0, rows)
+    dev = torch.from_numpy(np.ascontiguousarray(ref.data[: rows + m - 1, :32])).cuda()
+    out = torch.empty((rows, 32), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    routes = []
+    for pairs in (1, 0):
+        pli = lm.Pipeline.hip(0)
+        pli.set_option("pair_prefilter", pairs)
+        for run in range(2):
+            out.fill_(0x5A)
+            torch.cuda.synchronize()
+            pli.score_u8_dptr(dm, dev.data_ptr(), rows + m - 1, 32, 32, m - 1, length, 0, rows, out.data_ptr(), 32)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want), (pairs, run, pli.last_kernel)
+        routes.append(pli.last_kernel)
+    assert "score_generic_u8" not in routes, routes
+
+
 def test_scanner_prefilter_property_on_discrete_scores(pli):
     """scan.rs:169-190: every position with f32 score >= t has a u8 score >= scale(t)."""
     rng = np.random.default_rng(5)

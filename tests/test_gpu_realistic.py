@@ -136,10 +136,17 @@ def test_clock_probe_and_scan_counts(pli):
         rc2, _ = pli.score_threshold(pssm, seq, t)
         wall_ms = (time.perf_counter() - t0) * 1e3
         k_thr = pli.last_scan_kernel_ms
+        # ... the call by phase (scan | re-scoring | ordering on the stream, the rest on the host clock), and what the scan
+        # kernel that ran looked up: a length-20 motif as 19 or 20 rows of a pair table of ((rows | 3) + 1) bytes per position
+        ph = pli.last_phases_ms
+        assert ph is not None and ph[0] == k_thr and ph[1] >= 0 and ph[2] >= 0 and 0 <= ph[3] < wall_ms
+        assert abs(sum(ph) - wall_ms) < 0.5 * wall_ms + 0.05
+        srows, sbytes = pli.last_scan_info
+        assert srows in (19, 20) and sbytes == (srows | 3) + 1
         best = pli.score_argmax(pssm, seq)
         k_am = pli.last_scan_kernel_ms if pli.last_kernel.startswith("score_c32_prefilter") else 0.001
     finally:
         pli.set_option("time_scan", 0)
     assert rc2 == rc and best is not None and 0 < k_thr < wall_ms and k_am > 0
     pli.score_threshold(pssm, seq, t)
-    assert pli.last_scan_kernel_ms is None
+    assert pli.last_scan_kernel_ms is None and pli.last_phases_ms is None

@@ -10,10 +10,6 @@ hipcc $FLAGS -DLM_SCORE_NT_STORE=1 $INC kbench.hip -o kbench_nt &
 if [ "$1" = "all" ]; then
   hipcc $FLAGS -DLM_SCORE_NT_STORE=0 $INC kbench.hip -o kbench_plain &
 fi
-# row-pair kernel experiment + stream-length sweeps of score_c32 for a few motif lengths (rp_bench_<M> [L] [K] [rounds] [c32only])
-for m in 12 20 33; do
-  hipcc $FLAGS -DLM_SCORE_NT_STORE=1 $INC -I. -DKB_M=$m rp_bench.hip -o rp_bench_$m &
-done
 for t in mix_bench stripe_bench valu_bench; do   # stand-alone micro-benchmarks (HBM mix, stripe kernel, VALU rates)
   hipcc --offload-arch=gfx950 -O3 -std=c++17 $INC $t.hip -o $t &
 done
