@@ -673,6 +673,20 @@ def c3_leg(pli, dev, coll_dev, world: int, rank: int, reps: int = 5) -> dict:
             rres[0] = pli.scan_threshold_batch(prepared, None, rseq)
         rt_th = timed(rscan, max(reps - 1, 2))
         rhits, rcands = pli.last_scan_counts
+        rphases = None
+        pli.set_option("time_scan", 1)   # where the non-i.i.d. input's extra time goes: the same phases as above
+        try:
+            rec = []
+            for _ in range(2):
+                rscan()
+                if pli.last_phases_ms:
+                    rec.append(list(pli.last_phases_ms))
+            if rec:
+                med = np.median(np.asarray(rec), axis=0)
+                rphases = {"scan_ms": round(float(med[0]), 3), "rescore_ms": round(float(med[1]), 3),
+                           "order_ms": round(float(med[2]), 3), "host_ms": round(float(med[3]), 3)}
+        finally:
+            pli.set_option("time_scan", 0)
         rt_am = timed(lambda: pli.scan_argmax_batch(pssms, rseq), max(reps - 1, 2))
         scan()
         uhits, ucands = pli.last_scan_counts
@@ -680,6 +694,7 @@ def c3_leg(pli, dev, coll_dev, world: int, rank: int, reps: int = 5) -> dict:
                      "hits_total": int(sum(len(c) for c, _ in rres[0])), "candidate_pieces_per_hit": round(rcands / max(rhits, 1), 2),
                      "uniform_candidate_pieces_per_hit": round(ucands / max(uhits, 1), 2),
                      "threshold_ms_over_uniform": round(rt_th / t_th, 3), "argmax_ms_over_uniform": round(rt_am / t_am, 3),
+                     **({"phases": rphases} if rphases else {}),
                      "parity": "tools/realistic_inputs.py -> profiles/r05_realistic_inputs.json (whole-sequence check against the AVX2 port)"}
         del rseq, enc
     return {"workload": f"configs[2]: {len(pssms)} JASPAR 2024 CORE DNA PSSMs (sum M = {sum(lengths)}) x "

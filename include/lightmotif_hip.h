@@ -149,8 +149,7 @@ int lm_hip_ctx_set_track_argmax(lm_hip_ctx *ctx, int enabled);
  * "skip_unreachable", "quad_loads", "xlong_store", "host_fold", "chunked_fused", "chunk_rows", "tiled", "sort_hits",
  * "short_order", "time_scan", "drop_last", "list_scan_max" (0 = Scanner::max always walks windows of materialised u8 scores),
  * "block_prefilter" (0 = the protein one-symbol scans load a byte per lane and row
- * instead of 4-row blocks), "order_groups" (0 = the length classes of a threshold batch launch in input order on
- * alternating streams instead of most expensive first on the less loaded stream); "xcd_remap" is accepted and ignored (the remap it selected was removed in round 5).  Unknown names:
+ * instead of 4-row blocks); "xcd_remap" is accepted and ignored (the remap it selected was removed in round 5).  Unknown names:
  * LM_HIP_ERR_BAD_ARGS.  The shipped library reads none of them from the environment. */
 int lm_hip_ctx_set_option(lm_hip_ctx *ctx, const char *name, double value);
 /* Round-4 ABI: selected an XCD-aware workgroup remap of the store kernel, which measured slower and was removed in round 5.
@@ -651,6 +650,16 @@ int lm_hip_host_trim(void);
 /* != 0: NEW host-pointer lanes are dealt round-robin over every usable device (one process driving a whole node); 0 (the
  * default): every lane on the process's one host-pointer device (see above).  Lanes that exist stay where they are. */
 int lm_hip_host_spread_lanes(int enabled);
+/* != 0: a lane keeps the device copy of the score matrix its last lm_hip_score_f32 produced, and lm_hip_argmax_f32 /
+ * lm_hip_max_f32 / lm_hip_threshold_f32 called by the same thread on that very matrix (same pointer, shape and stride) reduce
+ * the copy instead of uploading the matrix again -- the reference's own benchmark shape, `score_into` followed by `argmax`
+ * (lightmotif-bench/dna.rs:81-116: 150 -> ~110 us per iteration at 464 kbp).  The caller promises not to write to the matrix
+ * between the two calls; the library checks a 64-bit digest of 67 sampled cells and falls back to the upload when it differs,
+ * which catches a recycled buffer, not a deliberate single-cell edit.  0 (the default): every call uploads what it is given.
+ * Process-wide; always LM_HIP_OK. */
+int lm_hip_host_reuse_scores(int enabled);
+/* How many calls of the calling thread's lane took the kept copy so far (a diagnostic for tests and tools). */
+int lm_hip_host_reuse_count(size_t *count);
 /* Puts the calling thread's host-pointer lane on `device` (a HIP ordinal from lm_hip_device_ordinal) from its next call
  * on; -1 = back to the automatic placement ($LM_HIP_DEVICE, else the process's device or the round-robin).  For hosts that place their worker
  * threads themselves (one thread per GPU, threads pinned next to their GPU). */

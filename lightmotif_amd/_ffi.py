@@ -151,6 +151,8 @@ SIGNATURES = {
     "lm_hip_host_trim": (C.c_int, []),
     "lm_hip_host_bind_thread": (C.c_int, [C.c_int]),
     "lm_hip_host_spread_lanes": (C.c_int, [C.c_int]),
+    "lm_hip_host_reuse_scores": (C.c_int, [C.c_int]),
+    "lm_hip_host_reuse_count": (C.c_int, [C.POINTER(C.c_size_t)]),
     "lm_hip_host_lane_info": (C.c_int, [_ip, _ip, _ip]),
 }
 

@@ -569,13 +569,22 @@ int lm_hip_score_rows_into(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hi
     // a 16-byte read instead of a second pass over 4 B per position
     // (small inputs are launch-latency bound: the extra reduction launch costs more than the
     //  second pass it saves)
+    return score_store_tracked(ctx, a, scores);
+}
+
+}  // extern "C"
+
+int lm::score_store_tracked(lm_hip_ctx *ctx, const ScoreArgs &a, lm_hip_scores *scores)
+{
+    const size_t row_begin = a.row_begin, row_end = a.row_end;
+    scores->best_valid = false;
     scores->best_on_host = false;
     scores->records_on_host = false;
     scores->folded = false;
     if (!scores->d_best || !ctx->track_argmax)
         return launch_score_store(ctx, a);
     bool tracked = false;
-    if ((row_end - row_begin) * seq->cols < (8u << 20)) {
+    if ((row_end - row_begin) * a.cols < (8u << 20)) {
         // small inputs are launch-latency bound: ONE launch stores, tracks the best cell and folds the
         // workgroup records (MODE_STORE_TRACK), and leaves the record in pinned memory as well
         const unsigned gen = ++scores->best_generation ? scores->best_generation : ++scores->best_generation;  // never 0
@@ -589,6 +598,8 @@ int lm_hip_score_rows_into(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hi
     scores->best_valid = tracked;
     return LM_HIP_OK;
 }
+
+extern "C" {
 
 int lm_hip_score_into(lm_hip_ctx *ctx, const lm_hip_pssm *pssm, const lm_hip_seq *seq,
                       lm_hip_scores *scores)

@@ -98,7 +98,23 @@ struct HostLane {
     std::vector<CachedPssm> pssms;
     uint64_t stamp = 0;
     uint64_t trim_epoch = 0;  // g_trim_epoch as of this lane's last trim
+    // the f32 score matrix the last lm_hip_score_f32 of this lane left on the device, dense (lm_hip_host_reuse_scores):
+    // where it is, whose it was on the host, and a digest of a sample of what the caller got
+    const float *kept_dev = nullptr;
+    const float *kept_host = nullptr;
+    size_t kept_rows = 0, kept_cols = 0, kept_stride = 0;
+    uint64_t kept_digest = 0;
+    size_t reuses = 0;
+    const void *piece_dev = nullptr;  // where the last score call left its whole (dense) result on the device, if it did
+    // ... and, for matrices small enough for the tracking store kernel, the best cell that kernel found on the way
+    // (an lm_hip_scores record whose d_data is BORROWED from the staging above, never owned): lm_hip_argmax_f32 on the
+    // kept matrix is then the fold of a few records, like lm_hip_argmax on a handle
+    lm_hip_scores *track = nullptr;
+    bool tracked = false;
 };
+
+// lm_hip_host_reuse_scores: off unless the embedder asks for it
+std::atomic<bool> g_reuse_scores{false};
 
 // lm_hip_host_trim bumps it: a lane that belongs to a live thread hands its staging back at the end of its next call
 std::atomic<uint64_t> g_trim_epoch{0};
@@ -221,6 +237,8 @@ int acquire_lane(HostLane **out)
             for (size_t i = idle.size(); i-- > 0;)
                 if (demanded < 0 || idle[i]->device == demanded) {
                     t_lane.lane = idle[i];
+                    t_lane.lane->kept_dev = nullptr;  // (what another thread's call left behind is not this thread's)
+                    t_lane.lane->reuses = 0;
                     idle.erase(idle.begin() + (long)i);
                     break;
                 }
@@ -732,6 +750,7 @@ int score_piece(HostLane *lane, const ScoreCall &c, size_t r0, size_t r1)
         LM_TRY(c.launch(ctx, zin, w, zout));
         LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
         copy_rows(dst, c.out_stride * c.elem, zout, row_bytes, row_bytes, w);
+        lane->piece_dev = (r0 == 0 && r1 == c.nrows) ? zout : nullptr;
         return LM_HIP_OK;
     }
     LM_TRY(lane->d_in.reserve(in_bytes + 64));
@@ -746,6 +765,7 @@ int score_piece(HostLane *lane, const ScoreCall &c, size_t r0, size_t r1)
                    : hipMemcpy2DAsync(dst, c.out_stride * c.elem, d_out, row_bytes, row_bytes, w, hipMemcpyDeviceToHost,
                                       ctx->stream));
     LM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    lane->piece_dev = (r0 == 0 && r1 == c.nrows) ? d_out : nullptr;
     return LM_HIP_OK;
 }
 
@@ -797,6 +817,10 @@ int score_call(HostLane *lane, const ScoreCall &c)
 {
     lm_hip_ctx *ctx = lane->ctx;
     int st = LM_HIP_ERR_CAPACITY;
+    lane->piece_dev = nullptr;  // the lane's buffers are about to be overwritten: whatever was kept is gone
+    lane->kept_dev = nullptr;
+    if (lane->track)
+        lane->track->d_data = nullptr;
     if (c.nrows * c.cols * c.elem >= kPipeMinOutBytes) {
         // link-bound: large calls of several threads take turns on the ring (run side by side through the runtime's
         // pageable copies they were 2.2 x slower than one after the other -- profiles/r04_host_pointer.json)
@@ -816,6 +840,73 @@ int score_call(HostLane *lane, const ScoreCall &c)
         lane_trim(lane);
     }
     return st;
+}
+
+// 64 bits over the shape and 67 cells spread over the matrix (first, last, 65 in between), by bit pattern.
+uint64_t sample_digest(const float *scores, size_t rows, size_t stride, size_t cols)
+{
+    uint64_t h = 0x9e3779b97f4a7c15ull ^ (rows * 0x100000001b3ull) ^ (cols << 32);
+    const size_t cells = rows * cols;
+    constexpr size_t kSamples = 67;
+    for (size_t i = 0; i < kSamples && cells; ++i) {
+        const size_t cell = cells <= kSamples ? i % cells : (size_t)((unsigned __int128)i * (cells - 1) / (kSamples - 1));
+        uint32_t bits;
+        memcpy(&bits, scores + (cell / cols) * stride + cell % cols, 4);
+        h = (h ^ bits) * 0xff51afd7ed558ccdull;
+        h ^= h >> 29;
+    }
+    return h;
+}
+
+// After a successful lm_hip_score_f32 whose scores went through the lane's buffers in one piece: remember them.
+void keep_scores(HostLane *lane, const float *dev, const float *host, size_t rows, size_t stride, size_t cols)
+{
+    lane->kept_dev = nullptr;
+    if (!g_reuse_scores.load(std::memory_order_relaxed) || !dev)
+        return;
+    const bool zc = lane->zc && dev == reinterpret_cast<const float *>(lane->zc + kZeroCopyBytes);
+    if (!zc && dev != lane->d_out.ptr)  // (the call's own trim handed the buffer back)
+        return;
+    lane->kept_dev = dev;
+    lane->kept_host = host;
+    lane->kept_rows = rows;
+    lane->kept_cols = cols;
+    lane->kept_stride = stride;
+    lane->kept_digest = sample_digest(host, rows, stride, cols);
+}
+
+// The device copy of `scores` if this lane's previous score call produced exactly this matrix (same pointer and shape,
+// same sampled contents) and the buffer is still there; nullptr otherwise.
+const float *kept_scores(HostLane *lane, const float *scores, size_t rows, size_t stride, size_t cols)
+{
+    if (!lane->kept_dev || !g_reuse_scores.load(std::memory_order_relaxed))
+        return nullptr;
+    const bool zc = lane->zc && lane->kept_dev == reinterpret_cast<const float *>(lane->zc + kZeroCopyBytes);
+    if (lane->kept_host != scores || lane->kept_rows != rows || lane->kept_cols != cols || lane->kept_stride != stride)
+        return nullptr;  // another matrix: uploaded to the lane's INPUT staging, what is kept stays
+    if ((!zc && lane->kept_dev != lane->d_out.ptr) ||  // (trimmed or re-allocated since)
+        lane->kept_digest != sample_digest(scores, rows, stride, cols)) {
+        lane->kept_dev = nullptr;
+        return nullptr;
+    }
+    ++lane->reuses;
+    return lane->kept_dev;
+}
+
+// The lane's scores record for `cols` columns (dense rows); false when it cannot be had (the plain store runs then).
+bool lane_track(HostLane *lane, size_t cols)
+{
+    if (!lane->track) {
+        lm_hip_scores *t = nullptr;
+        if (lm_hip_scores_create(lane->ctx, cols, &t) != LM_HIP_OK)
+            return false;
+        lane->track = t;
+    }
+    lane->track->cols = lane->track->stride = cols;
+    lane->track->d_data = nullptr;
+    lane->track->capacity_rows = 0;  // (nothing of its own to free or to grow)
+    lane->track->rows = 0;
+    return lane->track->d_best != nullptr;
 }
 
 // The caller's score matrix on the device, dense (stride == cols): `*d` points into the lane's staging buffer.
@@ -874,11 +965,26 @@ int lm_hip_score_f32(const uint8_t *seq, size_t seq_rows_total, size_t seq_strid
         // only the rows the range needs travel: [row_begin, row_end + m - 1)
         ScoreCall c{seq + row_begin * seq_stride, seq_stride, cols, row_end - row_begin, m ? m - 1 : 0,
                     reinterpret_cast<char *>(out), out_stride, sizeof(float), nullptr};
-        c.launch = [p, seq_stride, cols](lm_hip_ctx *cx, const uint8_t *d_seq, size_t rows, void *d_out) {
+        // (lm_hip_host_reuse_scores: a matrix the tracking store kernel covers -- one piece, below 8 M cells -- is scored
+        //  through the lane's own scores record, so that the argmax that follows reads the kernel's records)
+        const size_t whole = c.nrows;
+        lane->tracked = false;
+        const bool track = g_reuse_scores.load(std::memory_order_relaxed) && whole * cols < (8u << 20) && lane_track(lane, cols);
+        c.launch = [p, seq_stride, cols, lane, track, whole](lm_hip_ctx *cx, const uint8_t *d_seq, size_t rows, void *d_out) {
             ScoreArgs a{p, d_seq, seq_stride, cols, 0, rows, static_cast<float *>(d_out), cols};
-            return launch_score_store(cx, a);
+            if (!track || rows != whole)
+                return launch_score_store(cx, a);
+            lm_hip_scores *t = lane->track;
+            t->d_data = static_cast<float *>(d_out);
+            t->rows = rows;
+            const int st = score_store_tracked(cx, a, t);
+            lane->tracked = st == LM_HIP_OK;
+            return st;
         };
         LM_TRY(score_call(lane, c));
+        keep_scores(lane, static_cast<const float *>(lane->piece_dev), out, c.nrows, out_stride, cols);
+        if (!lane->kept_dev || (lane->track && lane->track->d_data != lane->kept_dev))
+            lane->tracked = false;
         if (out_rows) *out_rows = c.nrows;       // pli/mod.rs:91
         if (max_index) *max_index = length + 1 - m;
         return LM_HIP_OK;
@@ -1004,6 +1110,26 @@ int lm_hip_host_spread_lanes(int enabled)
     });
 }
 
+int lm_hip_host_reuse_scores(int enabled)
+{
+    return guarded("host_reuse_scores", [&]() -> int {
+        g_reuse_scores.store(enabled != 0, std::memory_order_relaxed);
+        return LM_HIP_OK;
+    });
+}
+
+int lm_hip_host_reuse_count(size_t *count)
+{
+    return guarded("host_reuse_count", [&]() -> int {
+        if (!count)
+            return fail(LM_HIP_ERR_BAD_ARGS, "host_reuse_count: null argument");
+        HostLane *lane = nullptr;
+        LM_TRY(acquire_lane(&lane));
+        *count = lane->reuses;
+        return LM_HIP_OK;
+    });
+}
+
 int lm_hip_host_lane_info(int *device, int *numa_node, int *helper_cpus)
 {
     return guarded("host_lane_info", [&]() -> int {
@@ -1035,9 +1161,23 @@ int lm_hip_argmax_f32(const float *scores, size_t rows, size_t stride, size_t co
         lm_hip_ctx *ctx = lane->ctx;  // the lane is this thread's alone: nothing to lock
         DeviceGuard guard(ctx->device);
         ScratchTrim scratch_trim(ctx);
-        const float *d = nullptr;
+        const float *d = kept_scores(lane, scores, rows, stride, cols);
+        if (d && lane->tracked && lane->track && lane->track->d_data == d && lane->track->rows == rows) {
+            // the store kernel that wrote the kept matrix tracked its best cell: fold / read its records (handles.hip)
+            lm_hip_coords cell{0, 0};
+            float v = 0.0f;
+            const int st = lm_hip_argmax(ctx, lane->track, found, &cell, &v);
+            lane_trim(lane);
+            if (st != LM_HIP_OK)
+                return st;
+            if (*found) {
+                if (best) *best = cell;
+                if (value) *value = v;
+            }
+            return LM_HIP_OK;
+        }
         ArgmaxRecord rec{};
-        int st = stage_scores(lane, scores, rows, stride, cols, &d);
+        int st = d ? (int)LM_HIP_OK : stage_scores(lane, scores, rows, stride, cols, &d);
         if (st == LM_HIP_OK)
             st = launch_argmax(ctx, d, rows, cols, cols, 1, &rec);
         if (st != LM_HIP_OK)
@@ -1082,8 +1222,8 @@ int lm_hip_threshold_f32(const float *scores, size_t rows, size_t stride, size_t
         DeviceGuard guard(ctx->device);
         // a dense list grows ctx->scratch / scratch2 to 16 B per hit: handed back when the call ends (score_api.hip does the same)
         ScratchTrim scratch_trim(ctx);
-        const float *d = nullptr;
-        int st = stage_scores(lane, scores, rows, stride, cols, &d);
+        const float *d = kept_scores(lane, scores, rows, stride, cols);
+        int st = d ? (int)LM_HIP_OK : stage_scores(lane, scores, rows, stride, cols, &d);
         if (st == LM_HIP_OK)
             st = launch_threshold(ctx, d, rows, cols, cols, t, coords, n);
         if (st != LM_HIP_OK)

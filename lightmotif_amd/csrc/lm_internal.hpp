@@ -125,7 +125,6 @@ struct lm_hip_ctx {
     // what the scan of the last single-job fused call looked up per position (lm_hip_ctx_last_scan_info): motif rows and
     // bytes of LDS table; 0 = no scan kernel of the prefilter / exact families ran (a batch, the suffix route, chunks)
     unsigned last_scan_rows = 0, last_scan_lds_bytes = 0;
-    bool order_groups = true;    // fused threshold batches launch their most expensive length class first and balance the two streams (option "order_groups")
     bool list_scan_max = true;   // Scanner::max over a candidate list (scanmax.hip; option "list_scan_max" = 0: always the window walk)
     bool drop_last = true;       // single pair scans of M = 20, 24, ... 36 over M - 1 rows (option "drop_last"; lm_hip_pssm::d_image2_drop)
     bool short_order = true;     // ... short lists of one job counted by the re-scoring kernel, two launches behind it (hits.hip; option "short_order")
@@ -352,6 +351,10 @@ int launch_score_store_argmax(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord 
                               int first_cell_rule = 1);
 // small inputs: store + (value, cell) tracking + the fold of the workgroup records in ONE launch
 // (MODE_STORE_TRACK); the record also lands in *h_result (pinned, optional)
+// the store of rows [a.row_begin, a.row_end) into scores->d_data (= a.d_out) that also tracks the best cell, as
+// lm_hip_score_rows_into runs it: lm_hip_argmax on `scores` is then a read of the record(s) (handles.hip; the host-pointer
+// lanes use it for lm_hip_host_reuse_scores)
+int score_store_tracked(lm_hip_ctx *ctx, const ScoreArgs &a, lm_hip_scores *scores);
 int launch_score_store_track(lm_hip_ctx *ctx, const ScoreArgs &a, ArgmaxRecord *d_result, ArgmaxRecord *h_result,
                              unsigned generation, bool *tracked, int first_cell_rule = 1, lm_hip_scores *host_fold = nullptr);
 int finalize_argmax_materialised(lm_hip_ctx *ctx, const ArgmaxRecord *d_blocks, unsigned nblocks,

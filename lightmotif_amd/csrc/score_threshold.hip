@@ -249,7 +249,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
     // sound one exists and the threshold maps into its 16-bit range, the exact f32
     // kernel otherwise, the generic kernel for shapes the C = 32 kernels do not cover
     std::vector<unsigned> tds(n, 0);
-    std::vector<JobGroup> groups = group_jobs(ctx, jobs, n, [&](size_t i) {
+    const std::vector<JobGroup> groups = group_jobs(ctx, jobs, n, [&](size_t i) {
         const ScoreArgs &a = jobs[i];
         // A threshold above the best k-mer's score selects nothing, whatever the sequence: such a job is not
         // scanned at all.  (At the CLI's p = 1e-5 that is every motif too short to reach the p-value -- 1 042 of
@@ -269,15 +269,6 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
         }
         return plan_c32(ctx, a, false).ok ? (int)KIND_EXACT : chunked_ok(ctx, a) ? (int)KIND_CHUNKED : (int)KIND_GENERIC;
     });
-    // Launch order: the most expensive group first.  The groups alternate between two streams, and what the batch waits for
-    // at the end is the last kernel running alone -- so the last launches should be the cheapest.
-    if (groups.size() > 2 && ctx->order_groups) {
-        auto cost = [&](const JobGroup &g) {
-            const ScoreArgs &a = jobs[g.idx[0]];
-            return (double)g.idx.size() * (double)(a.row_end - a.row_begin) * (double)((a.pssm->m | 3) + 1);
-        };
-        std::stable_sort(groups.begin(), groups.end(), [&](const JobGroup &x, const JobGroup &y) { return cost(x) > cost(y); });
-    }
     const unsigned long long key_rows =
         keys == HitKeys::Position ? (unsigned long long)(jobs[0].row_end - jobs[0].row_begin) : 0;
     // job table in launch order: the jobs of a group are contiguous from group_pos[g] on.  Groups
@@ -384,17 +375,14 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
             LM_TRY(batch_fork(ctx));
         bool any_candidates = false;
         size_t launch = 0;
-        double lane_cost[2] = {0.0, 0.0};
         for (size_t gi = 0; gi < groups.size(); ++gi) {
             const JobGroup &g = groups[gi];
             const size_t bp_pos = group_pos[gi];
             const size_t i = g.idx[0];
             const ScoreArgs &a = jobs[i];
-            // (ordered groups go to the stream with less work queued so far; otherwise the two alternate)
-            const double gcost = (double)g.idx.size() * (double)(a.row_end - a.row_begin) * (double)((a.pssm->m | 3) + 1);
-            const int lane_of = !two_streams ? 0 : ctx->order_groups ? (lane_cost[1] < lane_cost[0] ? 1 : 0) : (int)(launch++ & 1);
-            lane_cost[lane_of] += gcost;
-            hipStream_t st = lane_of ? ctx->aux_stream : ctx->stream;
+            // (launch order and stream balance do not matter: most expensive length class first on the less loaded stream
+            //  measured 14.59 against 14.61 ms of scans on the JASPAR batch, round 6 -- the scans are LDS-bound, not gap-bound)
+            hipStream_t st = (two_streams && (launch++ & 1)) ? ctx->aux_stream : ctx->stream;
             fo.threshold = ts[i];
             fo.job_key = (unsigned long long)i << 40;
             fo.batch = (n > 1 && !kind_solo(g.kind)) ? d_bparams + bp_pos : nullptr;

@@ -565,6 +565,10 @@ struct Hip {
         int n = 0;
         return lm_hip_device_count(&n) == LM_HIP_OK && n > 0;
     }
+    // `score_into` followed by `argmax` / `threshold` on the same StripedScores (the reference's bench loop, dna.rs:81-116):
+    // the reduction takes the copy the score call left on the device instead of uploading the matrix again.  A shim can
+    // switch it on for good: between the two calls the scores sit behind a `&StripedScores` nobody writes through.
+    static void reuse_scores(bool on) { check(lm_hip_host_reuse_scores(on ? 1 : 0)); }
     // Score<f32, A, C>::score_rows_into for Dispatch::Hip (dispatch.rs:90-106; contract of avx2.rs:889-904)
     template <class A>
     static void score_rows_into(const ScoringMatrix<A> &pssm, const host::StripedSequence<A> &seq, size_t row_begin,

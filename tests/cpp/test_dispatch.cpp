@@ -254,6 +254,42 @@ static int bench_scan()
     return 0;
 }
 
+// the reference's bench loop (dna.rs:81-116): score_into, then argmax on the matrix just written -- with Hip::reuse_scores
+// the reduction takes the copy the score call left on the device; same cells, same bits, and only for THAT matrix
+static void test_reuse_scores()
+{
+    HipDispatch<PortTier> forced, never;
+    for (int op = 0; op < 9; ++op) {
+        forced.policy.force((lm_hip_host_op)op, 0);
+        never.policy.force((lm_hip_host_op)op, SIZE_MAX);
+    }
+    const auto pssm = mx000001();
+    host::StripedSequence<Dna> seq = host::StripedSequence<Dna>::stripe(EncodedSequence<Dna>::encode(random_dna(464'165, 7)), 32);
+    seq.configure(pssm);
+    auto count = [] {
+        size_t n = 0;
+        CHECK(lm_hip_host_reuse_count(&n) == LM_HIP_OK);
+        return n;
+    };
+    Hip::reuse_scores(true);
+    const size_t c0 = count();
+    const auto s = forced.score(pssm, seq);
+    const auto a = forced.argmax(s);
+    CHECK(count() == c0 + 1);
+    const auto want = never.argmax(never.score(pssm, seq));
+    CHECK(a && want && a->row == want->row && a->col == want->col);
+    const auto mx = forced.max(s);
+    CHECK(count() == c0 + 2 && mx);
+    CHECK(same_cells(forced.threshold(s, *mx - 4.0f), never.threshold(s, *mx - 4.0f)) && count() == c0 + 3);
+    const auto other = never.score(pssm, seq);   // same contents, another matrix: uploaded
+    const auto b = forced.argmax(other);
+    CHECK(count() == c0 + 3 && b && b->row == want->row && b->col == want->col);
+    Hip::reuse_scores(false);
+    const auto s2 = forced.score(pssm, seq);
+    (void)forced.argmax(s2);
+    CHECK(count() == c0 + 3);
+}
+
 // the policy's constants re-measured on THIS host (the reference picks its back-end per host at run time, pli/mod.rs:269-308):
 // the GPU side by the library, the tier's side by the twin; the routes still agree bit for bit either side of the new numbers
 static void test_calibrated_policy()
@@ -313,6 +349,7 @@ int main(int argc, char **argv)
     test_policy_routes_by_size();
     test_scanner_specialisation();
     test_other_geometries();
+    test_reuse_scores();
     test_calibrated_policy();   // last: it replaces the process's cost model
     if (failures) {
         std::fprintf(stderr, "%d check(s) failed\n", failures);

@@ -107,7 +107,7 @@ def test_null_arguments_are_a_status_not_a_crash():
     got = json.loads(r.stdout.strip().splitlines()[-1])
     assert len(got) >= 65
     for name, (st, msg) in got.items():
-        if name.endswith("_destroy") or name in ("lm_hip_host_spread_lanes", "lm_hip_host_set_crossover"):   # (plain switches: nothing to misuse)
+        if name.endswith("_destroy") or name in ("lm_hip_host_spread_lanes", "lm_hip_host_reuse_scores", "lm_hip_host_set_crossover"):   # (plain switches: nothing to misuse)
             assert st == 0, (name, st, msg)
         else:
             assert st != 0 and msg, (name, st, msg)

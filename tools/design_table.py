@@ -63,7 +63,7 @@ def rows_of(d: dict):
     c1 = c.get("c1")
     if c1:
         g32 = c1.get("C32_dispatch_geometry", {})
-        out.append(("the reference's bench (dna.rs:81-116: `score_into` + `argmax`, 464 165 bp)", f"{g32.get('us_per_iter')} us on handles; {c1.get('host_pointer_us_per_iter')} us on host matrices; AVX2 port, one core: {c1.get('avx2_port_1_thread_us_per_iter')} us",
+        out.append(("the reference's bench (dna.rs:81-116: `score_into` + `argmax`, 464 165 bp)", f"{g32.get('us_per_iter')} us on handles; {c1.get('host_pointer_us_per_iter')} us on host matrices" + (f" ({c1['host_pointer_reuse_us_per_iter']} with `lm_hip_host_reuse_scores`)" if 'host_pointer_reuse_us_per_iter' in c1 else "") + f"; AVX2 port, one core: {c1.get('avx2_port_1_thread_us_per_iter')} us",
                     "launch + link latency", "—", "`extras.configs.c1`"))
     ee = e.get("end_to_end")
     if ee:

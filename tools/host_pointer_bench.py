@@ -87,6 +87,18 @@ def bench_c1():
     s_med, _ = loop_us(lambda: score_f32(mat, rows, length, pssm, out), 300, 30)
     a_med, _ = loop_us(lambda: argmax_f32(out, rows), 300, 30)
     pos = best[0][1] * rows + best[0][0]
+    # the same loop with lm_hip_host_reuse_scores(1): argmax reduces the device copy the score call left (opt-in: the
+    # caller promises not to write to `out` in between, as the reference's loop does not)
+    assert L.lm_hip_host_reuse_scores(1) == 0
+    try:
+        before = C.c_size_t(0)
+        L.lm_hip_host_reuse_count(C.byref(before))
+        r_med, r_min = loop_us(it, 300, 30)
+        after = C.c_size_t(0)
+        L.lm_hip_host_reuse_count(C.byref(after))
+        reuse_pos = best[0][1] * rows + best[0][0]
+    finally:
+        L.lm_hip_host_reuse_scores(0)
     # the AVX2 port, one thread, same loop (avx2.rs:104-199 + 351-426)
     data = co.aligned_empty(mat.shape, np.uint8)
     data[:] = mat
@@ -100,7 +112,10 @@ def bench_c1():
         co.avx2_argmax(cout, length + 1 - m)
     c_med, c_min = loop_us(cpu_it, 100, 10)
     same = bool(np.array_equal(cout.view(np.uint32), out.view(np.uint32)))
-    return {"host_pointer_us_per_iter": round(med, 1), "host_pointer_us_min": round(mn, 1), "score_f32_us": round(s_med, 1),
+    return {"host_pointer_us_per_iter": round(med, 1), "host_pointer_us_min": round(mn, 1),
+            "host_pointer_reuse_us_per_iter": round(r_med, 1), "host_pointer_reuse_us_min": round(r_min, 1),
+            "reuse_calls_that_took_the_kept_copy": int(after.value - before.value), "reuse_same_position": bool(reuse_pos == pos),
+            "score_f32_us": round(s_med, 1),
             "argmax_f32_us": round(a_med, 1), "host_pointer_best_position": int(pos), "avx2_port_1_thread_us_per_iter": round(c_med, 1),
             "avx2_port_1_thread_us_min": round(c_min, 1), "scores_match_avx2_port_bitwise": same,
             "x_avx2_port": round(c_med / med, 2)}
