@@ -51,21 +51,40 @@ constexpr int kPairPFB = 8;
 constexpr int prefilter2_mo(int m) { return m | 3; }
 constexpr int prefilter2_ring(int m) { return prefilter2_mo(m) + 1; }   // input rows per group
 constexpr int prefilter2_npair(int m) { return prefilter2_ring(m) / 2; }
-// dwords per table row: 4 * odd >= NPAIR (rows 0..15 then sit in distinct 16-byte slots)
-constexpr int prefilter2_stride_dw(int m) { return 4 * (((prefilter2_npair(m) + 3) / 4) | 1); }
+// DNA tables in 8-byte slots (LM_PAIR_SLOT8, the shipped form; 0 = the 16-byte slots of rounds 3-5, kept for A/B builds):
+// see prefilter2_stride_dw.
+#ifndef LM_PAIR_SLOT8
+#define LM_PAIR_SLOT8 1
+#endif
+constexpr bool prefilter2_slot8(int ka) { return LM_PAIR_SLOT8 != 0 && ka == 5; }
+// dwords per table row.
+//   16-byte slots (protein; DNA until round 5): 4 * odd >= NPAIR, read 16 bytes at a time -- a 16-lane service group of a
+//     ds_read_b128 covers the 64 banks exactly when its lanes sit in 16 DISTINCT slots, which rows 0..15 do.  DNA has 25 pair
+//     rows: the nine with an N alias a row without (mod 16), and a lane on an N row costs its group a second cycle whenever
+//     another lane reads the aliased row -- 0.4 % of the LDS cycles on ACGT-only input, **25-31 %** with 4.6 % N in the
+//     sequence (profiles/r06_stalls_c3_realistic.txt): the whole of the JASPAR batch's 1.3 x on non-i.i.d. input.
+//   8-byte slots (DNA now): 2 * odd >= NPAIR, read 8 bytes at a time -- a ds_read_b64 serves 32 lanes per cycle from 32
+//     slots of 8 bytes, the same 256 B per clock, and all 25 rows (5 a + b) sit in distinct slots whatever the symbols.
+constexpr int prefilter2_stride_dw(int m, int ka = 5)
+{
+    return prefilter2_slot8(ka) ? 2 * ((prefilter2_npair(m) / 2) | 1) : 4 * (((prefilter2_npair(m) + 3) / 4) | 1);
+}
+// ... in slots (what the register decode's byte tables count in), and bytes per slot as a shift
+constexpr int prefilter2_so(int m, int ka = 5) { return prefilter2_stride_dw(m, ka) / (prefilter2_slot8(ka) ? 2 : 4); }
 // table rows = symbol pairs.  Protein (K = 21): 441 rows, a * 21 + b.  Protein rows cannot be conflict-free
 // (441 rows, 16 slots): tools/kbench/lds_rows_bench measures 5.5 ns per wavefront read against 3.5 ns for the 21
 // rows of the one-symbol prefilter -- but the pair scan needs half the reads.
-// DNA (K = 5): row(a, b) = 4 a + b', b' = b for A C T G and 20 for N -- ADDITIVE in the two symbols, so that a lane
-// can look both terms up in registers (dna_pair_offsets below).  The 16 pairs without N sit in rows 0..15 = distinct
-// 16-byte LDS slots (conflict-free reads); (N, b) in 16..19, (a, N) in 20, 24, 28, 32, (N, N) in 36; the other rows
-// of the 37 are never read.
-constexpr int prefilter2_rows(int ka) { return ka == 5 ? 37 : ka * ka; }
-constexpr int prefilter2_image_dw(int m, int ka = 5) { return prefilter2_rows(ka) * prefilter2_stride_dw(m); }
+// DNA (K = 5): row(a, b) is ADDITIVE in the two symbols, so that a lane can look both terms up in registers
+// (dna_pair_offsets below).  8-byte slots: 5 a + b, 25 rows.  (16-byte slots: 4 a + b', b' = b for A C T G and 20 for N --
+// the 16 pairs without N in rows 0..15, (N, b) in 16..19, (a, N) in 20, 24, 28, 32, (N, N) in 36; the other rows of the 37
+// never read.)
+constexpr int prefilter2_rows(int ka) { return ka == 5 ? (prefilter2_slot8(ka) ? 25 : 37) : ka * ka; }
+// (a multiple of 4 dwords: tables are copied 16 bytes at a time, and the tables of a multi-motif pass follow each other)
+constexpr int prefilter2_image_dw(int m, int ka = 5) { return (prefilter2_rows(ka) * prefilter2_stride_dw(m, ka) + 3) / 4 * 4; }
 
 __host__ __device__ __forceinline__ unsigned dna_pair_row(unsigned a, unsigned b)
 {
-    return 4u * a + (b == 4u ? 20u : b);
+    return prefilter2_slot8(5) ? 5u * a + b : 4u * a + (b == 4u ? 20u : b);
 }
 template <int KA>
 __host__ __device__ __forceinline__ unsigned pair_row(unsigned a, unsigned b)
@@ -84,14 +103,17 @@ __host__ __device__ __forceinline__ unsigned pair_row(unsigned a, unsigned b)
 //   p = v_perm_b32(y, s, sel_q)    byte 0 / byte 2 = own column's offset of the block's first / second pair
 // with `so` = 16-byte slots per table row; four operations per block of four symbols (the transposition that
 // preceded the look-up in the first register form cost two more), and the byte select rides on the shift that
-// makes the LDS address (SDWA).  Needs 20 so + 16 so < 256: table rows of up to 7 slots (M' <= 55); longer motifs
-// keep the one-by-one decode.
-constexpr bool prefilter2_lut_decode(int m, int ka) { return ka == 5 && prefilter2_stride_dw(m) / 4 <= 7; }
+// makes the LDS address (SDWA).  Needs the largest row offset below 256 slots: 36 so (16-byte slots: rows of up to 7,
+// M' <= 55) or 24 so (8-byte slots: rows of up to 10, M' <= 35 -- M = 36 keeps the one-by-one decode, like longer motifs).
+constexpr bool prefilter2_lut_decode(int m, int ka)
+{
+    return ka == 5 && (prefilter2_slot8(ka) ? 24 * prefilter2_so(m, ka) <= 255 : prefilter2_so(m, ka) <= 7);
+}
 
 struct PairDecode {  // per-lane constants (set once per kernel)
     unsigned tab_lo, tab_hi;  // byte tables of the lane's row parity: 4 so a (even rows of a pair) or so b' (odd rows)
     unsigned sel;             // byte selector of the last step
-    unsigned four;            // the shift count of byte_times_16 (an SDWA operand must be a register)
+    unsigned four;            // the shift count of byte_times_16: log2 of the slot size (an SDWA operand must be a register)
 };
 //
 // LIN: which lanes form a "quad".  With four ADJACENT lanes on the four rows of a block, adjacent lanes read addresses 32
@@ -105,8 +127,10 @@ struct PairDecode {  // per-lane constants (set once per kernel)
 template <int SO, bool LIN = false>
 __device__ __forceinline__ PairDecode pair_decode_setup()
 {
-    constexpr unsigned A_LO = 0u | (4u * SO << 8) | (8u * SO << 16) | (12u * SO << 24), A_HI = 16u * SO;
-    constexpr unsigned B_LO = 0u | (1u * SO << 8) | (2u * SO << 16) | (3u * SO << 24), B_HI = 20u * SO;
+    constexpr unsigned RA = prefilter2_slot8(5) ? 5u : 4u, RN = prefilter2_slot8(5) ? 4u : 20u;  // dna_pair_row
+    constexpr unsigned A_LO = 0u | (RA * SO << 8) | (2u * RA * SO << 16) | (3u * RA * SO << 24), A_HI = 4u * RA * SO;
+    constexpr unsigned B_LO = 0u | (1u * SO << 8) | (2u * SO << 16) | (3u * SO << 24), B_HI = RN * SO;
+    // ((4 RA + RN) SO > 255: the kernel decodes one symbol at a time and never reads these -- prefilter2_lut_decode)
     const unsigned q = LIN ? (threadIdx.x >> 3) & 3u : threadIdx.x & 3u;
     PairDecode pd;
     pd.tab_lo = (q & 1u) ? B_LO : A_LO;
@@ -114,7 +138,7 @@ __device__ __forceinline__ PairDecode pair_decode_setup()
     // quad form: lanes 0, 1 hold the first pair in `s` and receive the second in `y`; lanes 2, 3 the other way round.
     // LIN: after the swap the first pair is in one register and the second in the other for every lane.
     pd.sel = (!LIN && (q & 2u)) ? (0x0c000c00u | (4u + q) | (q << 16)) : (0x0c000c00u | q | ((4u + q) << 16));
-    pd.four = 4u;
+    pd.four = prefilter2_slot8(5) ? 3u : 4u;
     return pd;
 }
 // bytes 0 / 2 = row(a, b) * SO of the lane's column for the pairs (rows 0, 1) / (rows 2, 3) of the quad's block `d`
@@ -155,6 +179,22 @@ __device__ __forceinline__ unsigned byte_times_16(unsigned s, unsigned four)
 constexpr unsigned kFlagBits = 0x80008000u;
 static_assert(kPrefilterTop + 2u * (unsigned)kMaxPairM < 0x8000u, "biased sums must stay within their 16-bit half");
 __device__ __forceinline__ unsigned prefilter2_bias(unsigned td) { return td <= 0x8000u ? (0x8000u - td) * 0x10001u : 0u; }
+// 16 bytes (dwords 4 i .. 4 i + 3) of a table image on their way into LDS: dword 0 of every row of STRIDE dwords gets the bias
+template <int STRIDE>
+__device__ __forceinline__ uint4 prefilter2_biased(uint4 v, const int i, const unsigned bias)
+{
+    if constexpr (STRIDE % 4 == 0) {
+        if (i % (STRIDE / 4) == 0)
+            v.x += bias;
+    } else {  // rows of 2 * odd dwords start on every second 8-byte boundary
+        const int d = 4 * i;
+        if (d % STRIDE == 0)
+            v.x += bias;
+        if ((d + 2) % STRIDE == 0)
+            v.z += bias;
+    }
+    return v;
+}
 
 // (GroupNotes, the per-stream record of flagged groups, lives in score_prefilter.hpp)
 
@@ -183,7 +223,7 @@ __device__ __forceinline__ unsigned or_b32(unsigned a, unsigned b)
 inline void prefilter2_pack_image(const unsigned *d, int m, unsigned *image2, int ka = 5)
 {
     const int mo = prefilter2_mo(m), shift2 = mo - m, np2 = prefilter2_npair(m);
-    const int dsd2 = prefilter2_stride_dw(m);
+    const int dsd2 = prefilter2_stride_dw(m, ka);
     auto dq = [&](int j, int s) -> unsigned {  // padded weight, 0 outside shift2 .. mo-1
         return (j < shift2 || j >= mo) ? 0u : d[(size_t)(j - shift2) * ka + s];
     };
@@ -229,10 +269,19 @@ struct PairRows {  // the two table rows of a pair of super-steps
 
 // chunk C (dwords 4C .. 4C + 3) of the table row at LDS address `off`: a whole 16-byte piece or, when NP % 4 == 2, the
 // 8-byte tail read on its own (see prefilter2_mo)
-template <int NP, int C>
+template <int NP, int C, bool S8 = false>
 __device__ __forceinline__ void read_row_chunk(unsigned (&w)[(NP + 3) / 4 * 4], const unsigned off)
 {
-    if constexpr (4 * C + 4 <= NP) {
+    if constexpr (S8) {  // 8-byte slots: rows start on 8-byte boundaries, every read is a lone ds_read_b64 (volatile: not fused)
+        const lm_u32x2_t v = *(lm_lds_u64_ptr)(off + 16u * C);
+        w[4 * C + 0] = v.x;
+        w[4 * C + 1] = v.y;
+        if constexpr (4 * C + 2 < NP) {
+            const lm_u32x2_t u = *(lm_lds_u64_ptr)(off + 16u * C + 8u);
+            w[4 * C + 2] = u.x;
+            w[4 * C + 3] = u.y;
+        }
+    } else if constexpr (4 * C + 4 <= NP) {
         const lm_u32x4_t v = *(lm_lds_u128_ptr)(off + 16u * C);
         w[4 * C + 0] = v.x;
         w[4 * C + 1] = v.y;
@@ -262,19 +311,19 @@ __device__ __forceinline__ void consume_chunk(unsigned (&acc)[NP], const PairRow
     }
 }
 
-template <int NP, int P, int C>
+template <int NP, int P, int C, bool S8 = false>
 __device__ __forceinline__ void pair_chunks(unsigned (&acc)[NP], const PairRows<NP> &cur, PairRows<NP> &nxt, const unsigned off0,
                                             const unsigned off1, unsigned &fin0, const bool has_next)
 {
     if constexpr (C < (NP + 3) / 4) {
         if (has_next) {
-            read_row_chunk<NP, C>(nxt.r0, off0);
-            read_row_chunk<NP, C>(nxt.r1, off1);
+            read_row_chunk<NP, C, S8>(nxt.r0, off0);
+            read_row_chunk<NP, C, S8>(nxt.r1, off1);
         }
         __builtin_amdgcn_sched_barrier(0);
         consume_chunk<NP, P, C>(acc, cur, fin0);
         __builtin_amdgcn_sched_barrier(0);
-        pair_chunks<NP, P, C + 1>(acc, cur, nxt, off0, off1, fin0, has_next);
+        pair_chunks<NP, P, C + 1, S8>(acc, cur, nxt, off0, off1, fin0, has_next);
     }
 }
 
@@ -295,7 +344,7 @@ __device__ __forceinline__ void decode_block(const unsigned d, const unsigned sh
         off0 = byte_times_16<0>(pair_off, pd.four);
         off1 = byte_times_16<2>(pair_off, pd.four);
     } else {  // one symbol at a time: own column's byte of a quad neighbour's dword (DPP move + bit-field extract)
-        constexpr unsigned DSB = prefilter2_stride_dw(M) * 4;
+        constexpr unsigned DSB = prefilter2_stride_dw(M, KA) * 4;
         off0 = __umul24(pair_row<KA>(quad_symbol<0>(d, shq), quad_symbol<1>(d, shq)), DSB);
         off1 = __umul24(pair_row<KA>(quad_symbol<2>(d, shq), quad_symbol<3>(d, shq)), DSB);
     }
@@ -426,7 +475,7 @@ __device__ __forceinline__ void pair_items(unsigned (&acc)[NM][prefilter2_npair(
         }
         PairRows<NP> nxt;
         unsigned fin0 = 0;
-        pair_chunks<NP, P, 0>(acc[MI], cur, nxt, off0 + next_table, off1 + next_table, fin0, has_next);
+        pair_chunks<NP, P, 0, prefilter2_slot8(KA)>(acc[MI], cur, nxt, off0 + next_table, off1 + next_table, fin0, has_next);
         sink.template complete<PHASE, P, NB, MI>(fin0, acc[MI][(2 * P + 2) % NP]);
         if constexpr (has_next) {
 #pragma unroll
@@ -439,13 +488,13 @@ __device__ __forceinline__ void pair_items(unsigned (&acc)[NM][prefilter2_npair(
     }
 }
 
-template <int NP, int C>
+template <int NP, int C, bool S8 = false>
 __device__ __forceinline__ void pair_begin_rows(PairRows<NP> &cur, const unsigned off0, const unsigned off1)
 {
     if constexpr (C < (NP + 3) / 4) {
-        read_row_chunk<NP, C>(cur.r0, off0);
-        read_row_chunk<NP, C>(cur.r1, off1);
-        pair_begin_rows<NP, C + 1>(cur, off0, off1);
+        read_row_chunk<NP, C, S8>(cur.r0, off0);
+        read_row_chunk<NP, C, S8>(cur.r1, off1);
+        pair_begin_rows<NP, C + 1, S8>(cur, off0, off1);
     }
 }
 
@@ -460,7 +509,7 @@ __device__ __forceinline__ void pair_begin(unsigned (&blk)[prefilter2_ring(M) / 
     constexpr int NB = prefilter2_ring(M) / 4;
     decode_block<M, KA, LIN>(blk[0], shq, pd, off0, off1);
     blk[PFB % NB] = load_block(spq + PFB * 128);
-    pair_begin_rows<NP, 0>(cur, off0, off1);
+    pair_begin_rows<NP, 0, prefilter2_slot8(KA)>(cur, off0, off1);
 }
 
 // wavefronts per SIMD the register budget is cut for.  The hand-pipelined DNA scan keeps 3 NP + ~40 registers live
@@ -500,14 +549,10 @@ __global__ __launch_bounds__(kBlock, prefilter2_waves(M, KA)) void score_c32_pre
     {
         uint4 *dst = reinterpret_cast<uint4 *>(lds_raw);
         const uint4 *src = reinterpret_cast<const uint4 *>(image);
-        constexpr int n4 = prefilter2_image_dw(M, KA) / 4, row4 = prefilter2_stride_dw(M) / 4;
+        constexpr int n4 = prefilter2_image_dw(M, KA) / 4;
         const unsigned bias = prefilter2_bias(td);
-        for (int i = threadIdx.x; i < n4; i += kBlock) {
-            uint4 v = src[i];
-            if (i % row4 == 0)
-                v.x += bias;  // dword 0 of a table row (see kFlagBits)
-            dst[i] = v;
-        }
+        for (int i = threadIdx.x; i < n4; i += kBlock)
+            dst[i] = prefilter2_biased<prefilter2_stride_dw(M, KA)>(src[i], i, bias);
     }
     __syncthreads();
 
@@ -566,7 +611,7 @@ __global__ __launch_bounds__(kBlock, prefilter2_waves(M, KA)) void score_c32_pre
         }
     };
 
-    const PairDecode pd = pair_decode_setup<prefilter2_stride_dw(M) / 4, LIN>();
+    const PairDecode pd = pair_decode_setup<prefilter2_so(M, KA), LIN>();
     PairRows<NP> cur;
     unsigned off0, off1;
     FlagSink<1, LIN> sink{mx};
@@ -646,12 +691,8 @@ __global__ __launch_bounds__(kBlock, prefilter2_npair(M) <= 14 ? 4 : 3) void sco
         uint4 *dst = reinterpret_cast<uint4 *>(lds_raw) + mi * (IMG_DW / 4);
         const uint4 *src = static_cast<const uint4 *>(bps[mi].table);
         const unsigned bias = prefilter2_bias(bps[mi].td);
-        for (int i = threadIdx.x; i < IMG_DW / 4; i += kBlock) {
-            uint4 v = src[i];
-            if (i % (prefilter2_stride_dw(M) / 4) == 0)
-                v.x += bias;  // dword 0 of a table row (see kFlagBits)
-            dst[i] = v;
-        }
+        for (int i = threadIdx.x; i < IMG_DW / 4; i += kBlock)
+            dst[i] = prefilter2_biased<prefilter2_stride_dw(M)>(src[i], i, bias);
     }
     __syncthreads();
 
@@ -704,7 +745,7 @@ __global__ __launch_bounds__(kBlock, prefilter2_npair(M) <= 14 ? 4 : 3) void sco
                 notes[mi].note(mx[mi]);
         }
     };
-    const PairDecode pd = pair_decode_setup<prefilter2_stride_dw(M) / 4>();
+    const PairDecode pd = pair_decode_setup<prefilter2_so(M)>();
     PairRows<NP> cur;
     unsigned off0, off1;
     FlagSink<NM> sink{mx};

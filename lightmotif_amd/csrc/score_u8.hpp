@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kBlock, prefilter2_waves(M, 5)) void score_c32_u8_p
     // group 0 completes rows 0 and 1, group g >= 1 rows (g-1)*RING + 2 .. g*RING + 1
     const unsigned long long ngroups = (T - 2) / RING + 1;  // exact: T = q*RING + 2
     uint8_t *op = out + (o0 - row_begin) * 32 + col;
-    const PairDecode pd = pair_decode_setup<prefilter2_stride_dw(M) / 4, LIN>();
+    const PairDecode pd = pair_decode_setup<prefilter2_so(M), LIN>();
     PairRows<NP> cur;
     unsigned off0, off1;
     StoreSink<LIN> sink(op, wrap_mask, col);

@@ -15,6 +15,7 @@ import torch
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tools"))
 import lightmotif_amd as lm  # noqa: E402
 from lightmotif_amd._ffi import Coords  # noqa: E402
 
@@ -29,6 +30,7 @@ def main():
     ap.add_argument("--c3", action="store_true")
     ap.add_argument("--protein", action="store_true", help="configs[4]: 200 Mres x M = 12 protein, the block scan (score_prefilter_blk.hpp)")
     ap.add_argument("--motifs", type=int, default=0)
+    ap.add_argument("--realistic", action="store_true", help="with --c3: the non-i.i.d. 100 Mbp of tools/realistic_inputs.py instead of the uniform one")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     pli = lm.Pipeline.hip()
@@ -37,8 +39,14 @@ def main():
         import bench
         from lightmotif_amd import distributed as D
         st = bench.c3_setup(pli, dev, 1, 0, 100_000_000, args.motifs)
+        seq = st["seq"]
+        if args.realistic:
+            import realistic_inputs as ri
+            seq = pli.stripe(lm.EncodedSequence(ri.realistic_dna(100_000_000)))
+            seq.configure_wrap(st["max_m"] - 1)
+        prepared = D.prepare_sharded_batch(pli, st["pssms"], st["ts"], parts=st["parts"])
         for _ in range(args.reps):
-            D.scan_threshold_batch_sharded(pli, st["pssms"], st["ts"], st["seq"], device=dev, parts=st["parts"])
+            D.scan_threshold_batch_sharded(pli, st["pssms"], st["ts"], seq, device=dev, parts=st["parts"], prepared=prepared)
         torch.cuda.synchronize()
         return
     length, m = args.length, args.motif_len
