@@ -218,6 +218,9 @@ struct lm_hip_pssm {
     // read per table row (M' = M + 3); a prefilter only has to over-estimate, so a single scan looks the first M - 1 rows up
     // and credits the last row with its best weight, `drop_dmax` (score_threshold.hip: drop_last_form)
     unsigned *d_image2_drop = nullptr;
+    // DNA: the pair table in the layout the multi-motif passes of a batch read (8-byte LDS slots, score_prefilter2.hpp:
+    // kDnaMulti); nullptr = those passes are not available for this matrix (the jobs run one motif per pass)
+    unsigned *d_image2_multi = nullptr;
     unsigned drop_dmax = 0;
     bool has_prefilter = false;
     double pre_offset = 0, pre_factor = 0, pre_emax = 0;

@@ -16,7 +16,7 @@ namespace lm {
 // idea of DiscreteMatrix (pwm/mod.rs:665-696: per-row offsets, one global factor,
 // weights rounded UP) on 16 bits.  Returns false when no sound prefilter exists.
 static bool build_prefilter(lm_hip_pssm &p, std::vector<unsigned> *image, std::vector<unsigned> *image2,
-                            std::vector<unsigned> *image2_drop = nullptr)
+                            std::vector<unsigned> *image2_drop = nullptr, std::vector<unsigned> *image2_multi = nullptr)
 {
     const int m = (int)p.m, k = (int)p.k;
     if (m < 1)
@@ -67,6 +67,14 @@ static bool build_prefilter(lm_hip_pssm &p, std::vector<unsigned> *image, std::v
     if (k == 5 || k == 21) {  // DNA: 25 pair rows; protein: 441
         image2->assign((size_t)prefilter2_image_dw(m, k), 0u);
         prefilter2_pack_image(d.data() + (size_t)shift * k, m, image2->data(), k);
+    }
+    // the same table in the layout of the batch's multi-motif passes (lm_hip_pssm::d_image2_multi)
+    if (image2_multi) {
+        image2_multi->clear();
+        if (k == 5 && m <= kMaxFastM) {
+            image2_multi->assign((size_t)prefilter2_image_dw(m, kDnaMulti), 0u);
+            prefilter2_pack_image(d.data() + (size_t)shift * k, m, image2_multi->data(), kDnaMulti);
+        }
     }
     // the same table without the motif's last row, for lengths whose padding wastes a read (lm_hip_pssm::d_image2_drop);
     // what the last row can add at most goes into the bound
@@ -166,8 +174,8 @@ int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stri
             // discrete prefilter image (score_prefilter.hpp); absent when the matrix has
             // NaN / +inf entries or no spread -- the exact f32 fused kernel is used then
             std::vector<unsigned> image;
-            std::vector<unsigned> image2, image2_drop;
-            if (build_prefilter(*p, &image, &image2, &image2_drop)) {
+            std::vector<unsigned> image2, image2_drop, image2_multi;
+            if (build_prefilter(*p, &image, &image2, &image2_drop, &image2_multi)) {
                 e = hipMalloc(&p->d_image, image.size() * sizeof(unsigned));
                 if (e != hipSuccess)
                     return cleanup(fail(LM_HIP_ERR_OOM, "hipMalloc(prefilter) failed: %s", hipGetErrorString(e)));
@@ -187,6 +195,16 @@ int lm_hip_pssm_create(lm_hip_ctx *ctx, const float *pssm, size_t m, size_t stri
                     if (e != hipSuccess)
                         return cleanup(fail(LM_HIP_ERR_HIP, "pair prefilter upload failed: %s",
                                             hipGetErrorString(e)));
+                }
+                if (!image2_multi.empty()) {
+                    e = hipMalloc(&p->d_image2_multi, image2_multi.size() * sizeof(unsigned));
+                    if (e == hipSuccess)
+                        e = hipMemcpyAsync(p->d_image2_multi, image2_multi.data(), image2_multi.size() * sizeof(unsigned),
+                                           hipMemcpyHostToDevice, ctx->stream);
+                    if (e == hipSuccess)
+                        e = hipStreamSynchronize(ctx->stream);
+                    if (e != hipSuccess)
+                        return cleanup(fail(LM_HIP_ERR_HIP, "pair prefilter upload failed: %s", hipGetErrorString(e)));
                 }
                 if (!image2_drop.empty()) {
                     e = hipMalloc(&p->d_image2_drop, image2_drop.size() * sizeof(unsigned));
@@ -294,6 +312,8 @@ int lm_hip_pssm_destroy(lm_hip_pssm *p)
         (void)hipFree(p->d_image2);
     if (p->d_image2_drop)
         (void)hipFree(p->d_image2_drop);
+    if (p->d_image2_multi)
+        (void)hipFree(p->d_image2_multi);
     delete p;
     return LM_HIP_OK;
 }

@@ -682,7 +682,7 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
     // motifs per pass and are padded to a multiple of that (a padding position samples nothing,
     // so argmax_prepare leaves its td at "skip" and it flags nothing)
     std::vector<size_t> order, group_pos(groups.size());
-    std::vector<char> is_pad;
+    std::vector<char> is_pad, in_multi;  // in_multi: the position's group runs several motifs per pass (tables in that kernel's layout)
     std::vector<int> per_pass(groups.size(), 1);
     for (size_t gi = 0; gi < groups.size(); ++gi) {
         const JobGroup &g = groups[gi];
@@ -692,14 +692,18 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
             is_pad.push_back(0);
         }
         const int m = (int)qjobs[g.idx[0]].pssm->m;
-        if (g.kind == KIND_PREFILTER2 && ctx->multi_motif && g.idx.size() >= 2 &&
-            qjobs[g.idx[0]].pssm->k == 5 && score_c32_prefilter2_multi_lookup(m)) {
+        bool multi = g.kind == KIND_PREFILTER2 && ctx->multi_motif && g.idx.size() >= 2 && qjobs[g.idx[0]].pssm->k == 5 &&
+                     score_c32_prefilter2_multi_lookup(m);
+        for (size_t q : g.idx)  // (every matrix of the group needs its table in that kernel's layout)
+            multi = multi && qjobs[q].pssm->d_image2_multi != nullptr;
+        if (multi) {
             per_pass[gi] = prefilter2_multi(m);
             while ((order.size() - group_pos[gi]) % per_pass[gi]) {
                 order.push_back(g.idx.back());
                 is_pad.push_back(1);
             }
         }
+        in_multi.resize(order.size(), multi ? 1 : 0);
     }
     const size_t npos = order.size();
     std::vector<SampleJob> sj(npos);
@@ -711,6 +715,7 @@ static int argmax_by_prefilter(lm_hip_ctx *ctx, const ScoreArgs *jobs, size_t n,
             sj[pos].nchunks = 0;
         rj[pos] = rjobs[q];
         bparams.push_back(BatchParams{drop_last_form ? qjobs[q].pssm->d_image2_drop
+                                      : in_multi[pos] ? qjobs[q].pssm->d_image2_multi
                                       : pairs_of[q]  ? qjobs[q].pssm->d_image2
                                                      : qjobs[q].pssm->d_image,
                                       nullptr, 0.0f, 0xffffffffu, (unsigned long long)pos << 40});

@@ -51,20 +51,28 @@ constexpr int kPairPFB = 8;
 constexpr int prefilter2_mo(int m) { return m | 3; }
 constexpr int prefilter2_ring(int m) { return prefilter2_mo(m) + 1; }   // input rows per group
 constexpr int prefilter2_npair(int m) { return prefilter2_ring(m) / 2; }
-// DNA tables in 8-byte slots (LM_PAIR_SLOT8, the shipped form; 0 = the 16-byte slots of rounds 3-5, kept for A/B builds):
-// see prefilter2_stride_dw.
+// Two layouts of a DNA pair table (see prefilter2_stride_dw).  Which one a kernel reads travels in its alphabet argument:
+// KA = 5 -- 16-byte slots; KA = kDnaSlot8 -- 8-byte slots.  The multi-motif passes of a batch (LDS-bound, the layout
+// whose speed does not depend on the input) take the second unless built with -DLM_PAIR_SLOT8=0 (A/B builds); the
+// single-motif scans and the u8 pair store, which are bound by their HBM traffic up to M = 20, keep the first.
 #ifndef LM_PAIR_SLOT8
 #define LM_PAIR_SLOT8 1
 #endif
-constexpr bool prefilter2_slot8(int ka) { return LM_PAIR_SLOT8 != 0 && ka == 5; }
+constexpr int kDnaSlot8 = 5 | 256;
+constexpr int kDnaMulti = LM_PAIR_SLOT8 != 0 ? kDnaSlot8 : 5;   // what score_c32_prefilter2_multi reads (lm_hip_pssm::d_image2_multi)
+constexpr int pair_syms(int ka) { return ka & 255; }
+constexpr bool prefilter2_slot8(int ka) { return (ka & 256) != 0; }
 // dwords per table row.
 //   16-byte slots (protein; DNA until round 5): 4 * odd >= NPAIR, read 16 bytes at a time -- a 16-lane service group of a
 //     ds_read_b128 covers the 64 banks exactly when its lanes sit in 16 DISTINCT slots, which rows 0..15 do.  DNA has 25 pair
 //     rows: the nine with an N alias a row without (mod 16), and a lane on an N row costs its group a second cycle whenever
 //     another lane reads the aliased row -- 0.4 % of the LDS cycles on ACGT-only input, **25-31 %** with 4.6 % N in the
 //     sequence (profiles/r06_stalls_c3_realistic.txt): the whole of the JASPAR batch's 1.3 x on non-i.i.d. input.
-//   8-byte slots (DNA now): 2 * odd >= NPAIR, read 8 bytes at a time -- a ds_read_b64 serves 32 lanes per cycle from 32
-//     slots of 8 bytes, the same 256 B per clock, and all 25 rows (5 a + b) sit in distinct slots whatever the symbols.
+//   8-byte slots (the batch's DNA tables, round 6): 2 * odd >= NPAIR, read 8 bytes at a time -- a ds_read_b64 serves 32
+//     lanes per cycle from 32 slots of 8 bytes, the same 256 B per clock, and all 25 rows (5 a + b) sit in distinct slots
+//     whatever the symbols.  Twice the LDS instructions per byte: on ACGT-only input 1-2 % slower in the batch, 1-6 % in
+//     single scans up to M = 20 and 12-19 % in the long ones, which is why those keep the 16-byte slots
+//     (profiles/r06_pair_slot_ab.txt, r06_single_scan_slot_ab.txt).
 constexpr int prefilter2_stride_dw(int m, int ka = 5)
 {
     return prefilter2_slot8(ka) ? 2 * ((prefilter2_npair(m) / 2) | 1) : 4 * (((prefilter2_npair(m) + 3) / 4) | 1);
@@ -78,18 +86,18 @@ constexpr int prefilter2_so(int m, int ka = 5) { return prefilter2_stride_dw(m, 
 // (dna_pair_offsets below).  8-byte slots: 5 a + b, 25 rows.  (16-byte slots: 4 a + b', b' = b for A C T G and 20 for N --
 // the 16 pairs without N in rows 0..15, (N, b) in 16..19, (a, N) in 20, 24, 28, 32, (N, N) in 36; the other rows of the 37
 // never read.)
-constexpr int prefilter2_rows(int ka) { return ka == 5 ? (prefilter2_slot8(ka) ? 25 : 37) : ka * ka; }
+constexpr int prefilter2_rows(int ka) { return pair_syms(ka) == 5 ? (prefilter2_slot8(ka) ? 25 : 37) : pair_syms(ka) * pair_syms(ka); }
 // (a multiple of 4 dwords: tables are copied 16 bytes at a time, and the tables of a multi-motif pass follow each other)
 constexpr int prefilter2_image_dw(int m, int ka = 5) { return (prefilter2_rows(ka) * prefilter2_stride_dw(m, ka) + 3) / 4 * 4; }
 
-__host__ __device__ __forceinline__ unsigned dna_pair_row(unsigned a, unsigned b)
+__host__ __device__ __forceinline__ unsigned dna_pair_row(unsigned a, unsigned b, bool slot8 = false)
 {
-    return prefilter2_slot8(5) ? 5u * a + b : 4u * a + (b == 4u ? 20u : b);
+    return slot8 ? 5u * a + b : 4u * a + (b == 4u ? 20u : b);
 }
 template <int KA>
 __host__ __device__ __forceinline__ unsigned pair_row(unsigned a, unsigned b)
 {
-    return KA == 5 ? dna_pair_row(a, b) : a * (unsigned)KA + b;
+    return pair_syms(KA) == 5 ? dna_pair_row(a, b, prefilter2_slot8(KA)) : a * (unsigned)pair_syms(KA) + b;
 }
 
 // DNA decode in registers.  The lanes of a quad hold a 4 x 4 block of symbol bytes (lane q: row r + q, columns
@@ -107,7 +115,7 @@ __host__ __device__ __forceinline__ unsigned pair_row(unsigned a, unsigned b)
 // M' <= 55) or 24 so (8-byte slots: rows of up to 10, M' <= 35 -- M = 36 keeps the one-by-one decode, like longer motifs).
 constexpr bool prefilter2_lut_decode(int m, int ka)
 {
-    return ka == 5 && (prefilter2_slot8(ka) ? 24 * prefilter2_so(m, ka) <= 255 : prefilter2_so(m, ka) <= 7);
+    return pair_syms(ka) == 5 && (prefilter2_slot8(ka) ? 24 * prefilter2_so(m, ka) <= 255 : prefilter2_so(m, ka) <= 7);
 }
 
 struct PairDecode {  // per-lane constants (set once per kernel)
@@ -124,10 +132,10 @@ struct PairDecode {  // per-lane constants (set once per kernel)
 // {b, 8 + b, 16 + b, 24 + b}.  The exchanges become row_ror:8 (lane ^ 8, a DPP modifier as before) and
 // v_permlane16_swap (lane ^ 16: one operation for both directions, where the quad form took a DPP move) -- 7 operations
 // per block instead of 6.
-template <int SO, bool LIN = false>
+template <int SO, bool LIN = false, bool S8 = false>
 __device__ __forceinline__ PairDecode pair_decode_setup()
 {
-    constexpr unsigned RA = prefilter2_slot8(5) ? 5u : 4u, RN = prefilter2_slot8(5) ? 4u : 20u;  // dna_pair_row
+    constexpr unsigned RA = S8 ? 5u : 4u, RN = S8 ? 4u : 20u;  // dna_pair_row
     constexpr unsigned A_LO = 0u | (RA * SO << 8) | (2u * RA * SO << 16) | (3u * RA * SO << 24), A_HI = 4u * RA * SO;
     constexpr unsigned B_LO = 0u | (1u * SO << 8) | (2u * SO << 16) | (3u * SO << 24), B_HI = RN * SO;
     // ((4 RA + RN) SO > 255: the kernel decodes one symbol at a time and never reads these -- prefilter2_lut_decode)
@@ -138,7 +146,7 @@ __device__ __forceinline__ PairDecode pair_decode_setup()
     // quad form: lanes 0, 1 hold the first pair in `s` and receive the second in `y`; lanes 2, 3 the other way round.
     // LIN: after the swap the first pair is in one register and the second in the other for every lane.
     pd.sel = (!LIN && (q & 2u)) ? (0x0c000c00u | (4u + q) | (q << 16)) : (0x0c000c00u | q | ((4u + q) << 16));
-    pd.four = prefilter2_slot8(5) ? 3u : 4u;
+    pd.four = S8 ? 3u : 4u;
     return pd;
 }
 // bytes 0 / 2 = row(a, b) * SO of the lane's column for the pairs (rows 0, 1) / (rows 2, 3) of the quad's block `d`
@@ -220,18 +228,20 @@ __device__ __forceinline__ unsigned or_b32(unsigned a, unsigned b)
 }
 
 // Host side: the pair table from the unpadded discrete weights d[j * ka + s], j < m.
-inline void prefilter2_pack_image(const unsigned *d, int m, unsigned *image2, int ka = 5)
+// (`ka_layout`: the alphabet size, or kDnaSlot8 for the 8-byte-slot form of a DNA table)
+inline void prefilter2_pack_image(const unsigned *d, int m, unsigned *image2, int ka_layout = 5)
 {
+    const int ka = pair_syms(ka_layout);
     const int mo = prefilter2_mo(m), shift2 = mo - m, np2 = prefilter2_npair(m);
-    const int dsd2 = prefilter2_stride_dw(m, ka);
+    const int dsd2 = prefilter2_stride_dw(m, ka_layout);
     auto dq = [&](int j, int s) -> unsigned {  // padded weight, 0 outside shift2 .. mo-1
         return (j < shift2 || j >= mo) ? 0u : d[(size_t)(j - shift2) * ka + s];
     };
-    for (int i = 0; i < prefilter2_image_dw(m, ka); ++i)
+    for (int i = 0; i < prefilter2_image_dw(m, ka_layout); ++i)
         image2[i] = 0u;
     for (int a = 0; a < ka; ++a)
         for (int b = 0; b < ka; ++b) {
-            unsigned *row = image2 + (size_t)(ka == 5 ? dna_pair_row((unsigned)a, (unsigned)b) : (unsigned)(a * ka + b)) * dsd2;
+            unsigned *row = image2 + (size_t)(ka == 5 ? dna_pair_row((unsigned)a, (unsigned)b, prefilter2_slot8(ka_layout)) : (unsigned)(a * ka + b)) * dsd2;
             auto entry = [&](int e) -> unsigned { return e > mo ? 0u : dq(e - 1, a) + dq(e, b); };
             for (int w = 0; w < np2; ++w)
                 row[w] = entry(2 * w + 1) | (entry(2 * w) << 16);
@@ -517,7 +527,7 @@ __device__ __forceinline__ void pair_begin(unsigned (&blk)[prefilter2_ring(M) / 
 constexpr int prefilter2_waves(int m, int ka)
 {
     const int np = prefilter2_npair(m);
-    if (ka != 5)
+    if (pair_syms(ka) != 5)
         return m <= 52 ? 4 : m <= 80 ? 3 : 2;
     // (one step below what the registers in use would allow: at the tighter bound the allocator spills a few registers
     // around the loop, and a kernel with ANY scratch pays for it at every wavefront launch -- M = 20: 80 VGPRs either way,
@@ -611,7 +621,7 @@ __global__ __launch_bounds__(kBlock, prefilter2_waves(M, KA)) void score_c32_pre
         }
     };
 
-    const PairDecode pd = pair_decode_setup<prefilter2_so(M, KA), LIN>();
+    const PairDecode pd = pair_decode_setup<prefilter2_so(M, KA), LIN, prefilter2_slot8(KA)>();
     PairRows<NP> cur;
     unsigned off0, off1;
     FlagSink<1, LIN> sink{mx};
@@ -677,12 +687,13 @@ __global__ __launch_bounds__(kBlock, prefilter2_npair(M) <= 14 ? 4 : 3) void sco
     const uint8_t *__restrict__ seq, const unsigned long long row_begin, const unsigned long long row_end,
     const unsigned long long T, const unsigned long long nstreams, const FusedOut fo_in)
 {
-    static_assert(prefilter2_image_dw(M) % 4 == 0, "tables are copied 16 bytes at a time");
+    constexpr int KM = kDnaMulti;  // the tables' layout (lm_hip_pssm::d_image2_multi)
+    static_assert(prefilter2_image_dw(M, KM) % 4 == 0, "tables are copied 16 bytes at a time");
     constexpr int MO = prefilter2_mo(M);
     constexpr int SHIFT = MO - M;
     constexpr int RING = prefilter2_ring(M);
     constexpr int NP = prefilter2_npair(M);
-    constexpr int IMG_DW = prefilter2_image_dw(M);
+    constexpr int IMG_DW = prefilter2_image_dw(M, KM);
     const BatchParams *bps = fo_in.batch + (size_t)blockIdx.y * NM;  // this workgroup's NM jobs
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     lds_zero_based(lds_raw);
@@ -692,7 +703,7 @@ __global__ __launch_bounds__(kBlock, prefilter2_npair(M) <= 14 ? 4 : 3) void sco
         const uint4 *src = static_cast<const uint4 *>(bps[mi].table);
         const unsigned bias = prefilter2_bias(bps[mi].td);
         for (int i = threadIdx.x; i < IMG_DW / 4; i += kBlock)
-            dst[i] = prefilter2_biased<prefilter2_stride_dw(M)>(src[i], i, bias);
+            dst[i] = prefilter2_biased<prefilter2_stride_dw(M, KM)>(src[i], i, bias);
     }
     __syncthreads();
 
@@ -745,22 +756,22 @@ __global__ __launch_bounds__(kBlock, prefilter2_npair(M) <= 14 ? 4 : 3) void sco
                 notes[mi].note(mx[mi]);
         }
     };
-    const PairDecode pd = pair_decode_setup<prefilter2_so(M)>();
+    const PairDecode pd = pair_decode_setup<prefilter2_so(M, KM), false, prefilter2_slot8(KM)>();
     PairRows<NP> cur;
     unsigned off0, off1;
     FlagSink<NM> sink{mx};
-    pair_begin<M, 5, PFB>(blk, cur, off0, off1, spq, shq, pd);
+    pair_begin<M, KM, PFB>(blk, cur, off0, off1, spq, shq, pd);
     constexpr unsigned FAR = 2u * RING * 32u, NEAR = RING * 32u;  // (pair_items: the group two groups ahead, where the stream has one)
-    pair_items<M, 5, NM, PFB, PHASE_FIRST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink, ngroups > 2 ? FAR : NEAR);
+    pair_items<M, KM, NM, PFB, PHASE_FIRST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink, ngroups > 2 ? FAR : NEAR);
     end_group();
     for (unsigned g = 1; g + 1 < ngroups; ++g) {
         spq += RING * 32;
-        pair_items<M, 5, NM, PFB, PHASE_MAIN, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink, g + 2 < ngroups ? FAR : NEAR);
+        pair_items<M, KM, NM, PFB, PHASE_MAIN, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink, g + 2 < ngroups ? FAR : NEAR);
         end_group();
     }
     if (ngroups > 1) {
         spq += RING * 32;
-        pair_items<M, 5, NM, PFB, PHASE_LAST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink, 0u);
+        pair_items<M, KM, NM, PFB, PHASE_LAST, 0>(acc, blk, cur, off0, off1, spq, shq, pd, sink, 0u);
         end_group();
     }
     if (gleft != G) {
@@ -810,7 +821,7 @@ hipError_t score_c32_prefilter2_multi_launch(dim3 grid, hipStream_t stream, cons
 {
     constexpr int NM = prefilter2_multi(M);
     hipLaunchKernelGGL((score_c32_prefilter2_multi<M, NM>), grid, dim3(kBlock),
-                       (size_t)NM * prefilter2_image_dw(M) * 4, stream, seq, row_begin, row_end, T, nstreams, fo);
+                       (size_t)NM * prefilter2_image_dw(M, kDnaMulti) * 4, stream, seq, row_begin, row_end, T, nstreams, fo);
     return hipGetLastError();
 }
 

@@ -281,11 +281,17 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
     for (size_t gi = 0; gi < groups.size(); ++gi) {
         const JobGroup &g = groups[gi];
         group_pos[gi] = bparams.size();
+        // several motifs per pass (score_c32_prefilter2_multi): every matrix of the group needs its table in that kernel's layout
+        bool multi = g.kind == KIND_PREFILTER2 && ctx->multi_motif && n > 1 && g.idx.size() >= 2 && jobs[g.idx[0]].pssm->k == 5 &&
+                     score_c32_prefilter2_multi_lookup((int)jobs[g.idx[0]].pssm->m);
+        for (size_t i : g.idx)
+            multi = multi && jobs[i].pssm->d_image2_multi != nullptr;
         for (size_t i : g.idx) {
             const ScoreArgs &a = jobs[i];
             if (keys == HitKeys::Position && a.row_end - a.row_begin != key_rows)
                 return fail(LM_HIP_ERR_BAD_ARGS, "fused threshold: position keys need equal row ranges");
-            bparams.push_back(BatchParams{g.kind == KIND_PREFILTER2  ? (const void *)a.pssm->d_image2
+            bparams.push_back(BatchParams{multi                      ? (const void *)a.pssm->d_image2_multi
+                                          : g.kind == KIND_PREFILTER2 ? (const void *)a.pssm->d_image2
                                           : g.kind == KIND_PREFILTER ? (const void *)a.pssm->d_image
                                           : g.kind == KIND_EXACT     ? (const void *)exact_motif(a.pssm, a.d_seq).table
                                                                      : (const void *)a.pssm->d_table,
@@ -294,8 +300,7 @@ int launch_score_threshold_batch(lm_hip_ctx *ctx, const ScoreArgs *jobs, const f
                                   (unsigned)a.pssm->m, (unsigned)a.pssm->k, ts[i], 0, key_rows};
         }
         const int m = (int)jobs[g.idx[0]].pssm->m;
-        if (g.kind == KIND_PREFILTER2 && ctx->multi_motif && n > 1 && g.idx.size() >= 2 &&
-            jobs[g.idx[0]].pssm->k == 5 && score_c32_prefilter2_multi_lookup(m)) {
+        if (multi) {
             per_pass[gi] = prefilter2_multi(m);
             while ((bparams.size() - group_pos[gi]) % per_pass[gi]) {
                 BatchParams pad = bparams.back();
