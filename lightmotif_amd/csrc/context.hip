@@ -347,7 +347,7 @@ int lm_hip_device_clock_mhz(int device, unsigned window_us, double *mhz)
 static const char *const kOptionNames[] = {"track_argmax", "xlong_store", "host_fold", "speculate_order", "suffix_argmax",
                                            "multi_motif", "quad_loads", "skip_unreachable", "pair_prefilter",
                                            "pair_prefilter_protein", "chunked_fused", "chunk_rows", "tiled",
-                                           "suffix_occurrences", "prefilter", "sort_hits", "short_order", "time_scan", "drop_last", "block_prefilter", "list_scan_max"};
+                                           "suffix_occurrences", "prefilter", "sort_hits", "short_order", "time_scan", "drop_last", "block_prefilter", "list_scan_max", "poll_done"};
 
 static int set_option(lm_hip_ctx *ctx, const char *name, double value)
 {
@@ -359,6 +359,7 @@ static int set_option(lm_hip_ctx *ctx, const char *name, double value)
     else if (n == "speculate_order") ctx->speculate_order = on;      // 0 = fused threshold reads the counts first
     else if (n == "sort_hits") ctx->sort_hits = on;                  // 0 = long hit lists through the bucket passes too
     else if (n == "time_scan") ctx->time_scan = on;                  // 1 = events around the scan kernels of fused calls (lm_hip_ctx_last_scan_kernel_ms)
+    else if (n == "poll_done") ctx->poll_done = on;                  // 0 = single fused threshold calls wait for their stream instead of polling the ranking kernel's word
     else if (n == "list_scan_max") ctx->list_scan_max = on;          // 0 = Scanner::max always walks windows of materialised u8 scores
     else if (n == "drop_last") ctx->drop_last = on;                  // 0 = single pair scans of M = 4 k look all M rows up
     else if (n == "short_order") ctx->short_order = on;              // 0 = short hit lists of one job through the five-launch form too

@@ -107,7 +107,8 @@ __global__ __launch_bounds__(kBlock) void hits_rank_emit(
     lm_hip_hit *__restrict__ out_hits, const unsigned long long max_bucket, unsigned *__restrict__ abort_flag,
     void *__restrict__ pre_out, float *__restrict__ pre_values, const unsigned long long pre,
     const unsigned long long njobs, unsigned long long *__restrict__ starts, unsigned long long *__restrict__ header,
-    unsigned *__restrict__ clean_counts, unsigned *__restrict__ clean_cursors, unsigned long long *__restrict__ clean_counters)
+    unsigned *__restrict__ clean_counts, unsigned *__restrict__ clean_cursors, unsigned long long *__restrict__ clean_counters,
+    unsigned *__restrict__ done_ticket, unsigned *__restrict__ done_flag, const unsigned generation)
 {
     const unsigned long long count = live_count(count_ptr, cap);
     if (clean_counts) {  // ShortOrder: nothing reads the histogram, the cursors or the list's own counters any more (`count_ptr`
@@ -166,6 +167,20 @@ __global__ __launch_bounds__(kBlock) void hits_rank_emit(
                 static_cast<lm_hip_hit *>(pre_out)[pos] = h;
         }
     }
+    // ShortOrder: the host polls a word in the pinned staging block instead of waiting for the kernel's completion signal
+    // (~10 us of a 90-250 us call).  Every workgroup makes its writes -- to the pinned block as well -- visible system-wide,
+    // then takes a ticket; the last one resets the ticket for the next call and releases `generation` into the word.
+    if (done_flag) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned t = __hip_atomic_fetch_add(done_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == gridDim.x - 1) {
+                __hip_atomic_store(done_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(done_flag, generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 __global__ void hits_job_starts(const unsigned long long njobs, const unsigned long long nb,
@@ -208,7 +223,8 @@ constexpr size_t kShortTiles = kShortBuckets / kScanTile + 1;
 constexpr size_t kShortOffCursors = kShortBuckets * 4, kShortOffTiles = 2 * kShortOffCursors,
                  kShortOffOffsets = kShortOffTiles + 128,
                  kShortOffCounters = (kShortOffOffsets + (kShortBuckets + 1) * 8 + 255) / 256 * 256,  // {hits, candidates}: a line of their own
-                 kShortOffCopy = kShortOffCounters + 256, kShortBytes = kShortOffCopy + 256;
+                 kShortOffCopy = kShortOffCounters + 256, kShortOffTicket = kShortOffCopy + 128,  // (the ticket of hits_rank_emit's last workgroup)
+                 kShortBytes = kShortOffCopy + 256;
 static_assert(kShortTiles * 8 <= 128 && kShortBuckets % kBlock == 0 && kShortRecords / 4 + 1 <= kShortBuckets, "layout of the short form");
 
 __global__ __launch_bounds__(kBlock) void hits_short_scatter(
@@ -533,6 +549,15 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
     const unsigned long long max_bucket = speculative ? 256 : ~0ull;
 
     hipStream_t st = ctx->stream;
+    // short form: the end of the call is polled (hits_rank_emit's last workgroup; the word sits in the zeroed head of the
+    // staging block, the ticket next to the context's counters).  Option "poll_done" = 0: wait for the stream instead.
+    unsigned *done_ticket = nullptr, *done_flag = nullptr;
+    unsigned generation = 0;
+    if (short_form && speculative && ctx->poll_done) {
+        done_ticket = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(ctx->d_short) + kShortOffTicket);
+        done_flag = reinterpret_cast<unsigned *>(pin + 24);
+        generation = ++ctx->short_generation ? ctx->short_generation : ++ctx->short_generation;  // never 0
+    }
     const unsigned grid = (unsigned)std::max<unsigned long long>(
         std::min<unsigned long long>((sized_for + kBlock - 1) / kBlock, (unsigned long long)ctx->num_cus * 32), 1);
     if (sorted) {
@@ -579,14 +604,16 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
                            static_cast<lm_hip_coords *>(d_out), d_values,
                            static_cast<lm_hip_hit *>(nullptr), max_bucket, abort_flag, pre_out, pre_values, pre,
                            (unsigned long long)njobs, inline_starts ? starts : nullptr, inline_starts && speculative ? header : nullptr,
-                           short_form ? counts : nullptr, cursors, short_form ? so->counters : nullptr);
+                           short_form ? counts : nullptr, cursors, short_form ? so->counters : nullptr, done_ticket, done_flag,
+                           generation);
     else
         hipLaunchKernelGGL(hits_rank_emit<1>, dim3(grid), dim3(kBlock), 0, st, grouped, rank_counters, cap, shift,
                            nb, nbuckets, offsets, tiles, (unsigned long long)cols,
                            static_cast<lm_hip_coords *>(nullptr), static_cast<float *>(nullptr),
                            static_cast<lm_hip_hit *>(d_out), max_bucket, abort_flag, pre_out, pre_values, pre,
                            (unsigned long long)njobs, inline_starts ? starts : nullptr, inline_starts && speculative ? header : nullptr,
-                           short_form ? counts : nullptr, cursors, short_form ? so->counters : nullptr);
+                           short_form ? counts : nullptr, cursors, short_form ? so->counters : nullptr, done_ticket, done_flag,
+                           generation);
     if (!inline_starts)
         hipLaunchKernelGGL(hits_job_starts, dim3((unsigned)((njobs + 1 + 255) / 256)), dim3(256), 0, st,
                            (unsigned long long)njobs, nb, nbuckets, d_counters, cap, offsets, tiles, starts,
@@ -596,7 +623,21 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
 
     scan_timer_mark(ctx, st, 3);  // (time_scan) behind the ordering kernels
     if (speculative) {
-        LM_HIP_TRY(hipStreamSynchronize(st));
+        bool seen = false;
+        if (done_flag) {  // the ranking kernel's last workgroup raises the word behind everything it and the others wrote
+            const volatile unsigned *flag = done_flag;
+            for (unsigned spin = 0; spin < (1u << 23); ++spin) {  // bounded: a kernel that never gets there is caught below
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == generation) {
+                    seen = true;
+                    break;
+                }
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+                __builtin_ia32_pause();
+#endif
+            }
+        }
+        if (!seen)
+            LM_HIP_TRY(hipStreamSynchronize(st));
         if (short_form)
             ctx->short_dirty = false;  // both kernels ran: counts and cursors are zero again
         counts_out[0] = reinterpret_cast<unsigned long long *>(pin)[0];

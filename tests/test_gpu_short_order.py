@@ -24,7 +24,10 @@ def motif(m, seed):
     return lm.create(["".join("ACTG"[i] for i in rng.integers(0, 4, m)) for _ in range(8)]).counts.normalize(0.1).log_odds()
 
 
-def test_hit_counts_jumping_across_the_short_form_in_one_context():
+@pytest.mark.parametrize("poll_done", [1, 0])
+def test_hit_counts_jumping_across_the_short_form_in_one_context(poll_done):
+    """(`poll_done`: the end of a short-form call is read from the word the ranking kernel's last workgroup raises in pinned
+    memory -- the shipped form -- or waited for on the stream; both walk the same sequence of list sizes.)"""
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     length, m = 60_000_000, 20
@@ -39,6 +42,7 @@ def test_hit_counts_jumping_across_the_short_form_in_one_context():
     consensus = torch.tensor(np.argmax(pssm.data[:, :4], axis=1).astype(np.uint8), device=dev)
     seq[100_000:100_000 + 2_000 * m, 7] = consensus.repeat(2_000)
     pli = lm.Pipeline.hip(0, stream=torch.cuda.current_stream().cuda_stream)
+    pli.set_option("poll_done", poll_done)
     ref = lm.Pipeline.hip(0, stream=torch.cuda.current_stream().cuda_stream)
     pli.configure_wrap_dptr(seq.data_ptr(), rows, COLS, COLS, m - 1, 4)
     out = torch.empty((rows, COLS), dtype=torch.float32, device=dev)
