@@ -359,7 +359,7 @@ static int set_option(lm_hip_ctx *ctx, const char *name, double value)
     else if (n == "speculate_order") ctx->speculate_order = on;      // 0 = fused threshold reads the counts first
     else if (n == "sort_hits") ctx->sort_hits = on;                  // 0 = long hit lists through the bucket passes too
     else if (n == "time_scan") ctx->time_scan = on;                  // 1 = events around the scan kernels of fused calls (lm_hip_ctx_last_scan_kernel_ms)
-    else if (n == "poll_done") ctx->poll_done = on;                  // 0 = single fused threshold calls wait for their stream instead of polling the ranking kernel's word
+    else if (n == "poll_done") ctx->poll_done = on;                  // 1 = single fused threshold calls poll the ranking kernel's word in pinned memory instead of waiting for their stream
     else if (n == "list_scan_max") ctx->list_scan_max = on;          // 0 = Scanner::max always walks windows of materialised u8 scores
     else if (n == "drop_last") ctx->drop_last = on;                  // 0 = single pair scans of M = 4 k look all M rows up
     else if (n == "short_order") ctx->short_order = on;              // 0 = short hit lists of one job through the five-launch form too

@@ -549,8 +549,11 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
     const unsigned long long max_bucket = speculative ? 256 : ~0ull;
 
     hipStream_t st = ctx->stream;
-    // short form: the end of the call is polled (hits_rank_emit's last workgroup; the word sits in the zeroed head of the
-    // staging block, the ticket next to the context's counters).  Option "poll_done" = 0: wait for the stream instead.
+    // short form, option "poll_done" = 1: the end of the call is polled (hits_rank_emit's last workgroup; the word sits in the
+    // zeroed head of the staging block, the ticket next to the context's counters) instead of waited for on the stream.
+    // 2.6-4.4 us less per call when nothing synchronises behind it -- and ~13 us MORE when the caller follows the call with a
+    // device synchronisation of its own, which then finds the ranking kernel still retiring and pays a full wake-up
+    // (bench.py's protocol does: 0.252 -> 0.265 ms).  Hence off unless asked for (profiles/r06_poll_done_ab.txt).
     unsigned *done_ticket = nullptr, *done_flag = nullptr;
     unsigned generation = 0;
     if (short_form && speculative && ctx->poll_done) {
@@ -636,7 +639,7 @@ int order_hits(lm_hip_ctx *ctx, const HitRecord *d_hits, const unsigned long lon
 #endif
             }
         }
-        if (!seen)
+        if (!seen || ctx->scan_timed)  // (option "time_scan": the events behind the kernels are read next -- they must have completed)
             LM_HIP_TRY(hipStreamSynchronize(st));
         if (short_form)
             ctx->short_dirty = false;  // both kernels ran: counts and cursors are zero again

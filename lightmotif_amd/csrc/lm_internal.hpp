@@ -103,7 +103,7 @@ struct lm_hip_ctx {
     unsigned *d_ticket = nullptr; // "last workgroup folds the records" counter of the single-launch argmax forms (zero between launches)
     unsigned *d_short = nullptr;  // short hit lists (hits.hip, ShortOrder): bucket counts | cursors | zero tiles | offsets; counts and cursors are zero between calls
     unsigned short_generation = 0;  // of the last short ordering whose end the host polled (hits.hip: done_flag)
-    bool poll_done = true;        // the short ordering's end is polled from pinned memory, not waited for (option "poll_done")
+    bool poll_done = false;       // option "poll_done" = 1: the short ordering's end is polled from pinned memory, not waited for (hits.hip)
     bool short_dirty = false;     // ... unless a call failed between the count and the clean-up: the next one clears them first
     size_t rows_per_stream = 0; // 0 = default
     bool use_prefilter = true;  // fused threshold: packed 16-bit discrete prefilter (A/B knob)
