@@ -484,3 +484,49 @@ def test_kept_scores_serve_the_next_reduction_and_nothing_else(length, cols, pad
         assert count() == c0 + 3
     finally:
         L.lm_hip_host_reuse_scores(0)
+
+
+def test_kept_scores_with_host_threads():
+    """`lm_hip_host_reuse_scores(1)` with six host threads in their `score_into` + `argmax` + `threshold` loops at once: what is
+    kept is per lane (per thread), so every thread's reductions answer for ITS matrix, bit for bit, and take the kept copy."""
+    L = _ffi.lib()
+    rng = np.random.default_rng(81)
+    nthreads, m, iters = 6, 15, 25
+    jobs = []
+    for t in range(nthreads):
+        s = striped(rng, 120_000 + 37_000 * t, 32, 5, m)
+        p = aligned(random_pssm(rng, m, 5, "ties" if t % 2 else "normal"))
+        want, _ = co.score_rows(s, p)
+        cut = float(np.sort(want[:, :32][np.isfinite(want[:, :32])])[-10])
+        jobs.append((s, p, want, cut, np.zeros((s.rows, 32), np.float32)))
+    errors, reused = [], []
+
+    def work(job):
+        try:
+            s, p, want, cut, out = job
+            orow, omi, n0, n1 = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+            assert L.lm_hip_host_reuse_count(C.byref(n0)) == 0
+            want_best = co.argmax(want, 32)
+            want_hits = np.asarray(co.threshold(want, 32, cut), np.uintp).reshape(-1, 2)
+            for _ in range(iters):
+                out[:] = 0
+                st = L.lm_hip_score_f32(s.data.ctypes.data, s.data.shape[0], 32, 32, s.wrap, s.length, p.ctypes.data, m, p.shape[1],
+                                        5, 0, s.rows, out.ctypes.data, 32, C.byref(orow), C.byref(omi))
+                assert st == 0 and np.array_equal(bits(out), bits(want[:, :32]))
+                assert host_argmax(out, s.rows, 32, 32)[0] == want_best
+                assert np.array_equal(host_threshold(out, s.rows, 32, 32, cut), want_hits)
+            assert L.lm_hip_host_reuse_count(C.byref(n1)) == 0
+            reused.append(n1.value - n0.value)
+        except Exception as exc:   # noqa: BLE001  (reported from the main thread)
+            errors.append(repr(exc))
+
+    assert L.lm_hip_host_reuse_scores(1) == 0
+    try:
+        th = [threading.Thread(target=work, args=(j,)) for j in jobs]
+        [x.start() for x in th]
+        [x.join() for x in th]
+    finally:
+        L.lm_hip_host_reuse_scores(0)
+    assert not errors, errors
+    # (a lane taken over from an exited thread may owe an lm_hip_host_trim its staging: its first score call then keeps nothing)
+    assert all(2 * (iters - 1) <= r <= 2 * iters for r in reused) and len(reused) == nthreads, reused
